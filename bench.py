@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CLEVR questions/s of one TRAINING step (fwd + bwd + clip + Adam) of the
+Relation Network `original-fp` at B=64 per GPU on the 8x8 conv grid (BASELINE.json configs[1]),
+synthetic 128x128 images + random 20-token questions, random-init weights.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0.  `value` = whole-job questions/s (all ranks, max-over-ranks time).
+`roofline` prices the dominant kernels -- the g_theta GEMMs (forward, dgrad, wgrad launches) --
+in ALGORITHMIC flops (3 x 2*M*sum(K_l*G), padding not counted) against the
+dense bf16 MFMA peak, with durations taken live from HIP events on the launch stream inside the
+timed steps.  `pair_build` reports the K1 HBM roofline the same way.  `cpu_baseline` times the
+oracle's un-fused fp32 CPU restatement of the reference model on this host (rank 0, N=1 only)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def make_batch(B, device, hw=128, T=20):
+    g = torch.Generator().manual_seed(42)            # the reference's default seed (train.py:382)
+    img = torch.rand(B, 3, hw, hw, generator=g)
+    qst = torch.randint(1, 83, (B, T), generator=g)
+    lab = torch.randint(0, 28, (B,), generator=g)
+    return img.to(device), qst.to(device), lab.to(device)
+
+
+def g_flops_fwd(M, hyp, k):
+    gl, inj, Q = hyp["g_layers"], hyp["question_injection_position"], hyp["lstm_hidden"]
+    tot = 0
+    for l, w in enumerate(gl):
+        kin = (2 * k if l == 0 else gl[l - 1]) + (Q if l == inj else 0)
+        tot += 2 * M * kin * w
+    return tot
+
+
+def cpu_baseline(cfg, B, hw, steps=3):
+    """The oracle's torch-CPU restatement of the reference model (same un-fused op sequence), fwd+bwd."""
+    from oracle import formula, rn_oracle as O
+    n_thr = min(len(os.sched_getaffinity(0)), 64)
+    torch.set_num_threads(n_thr)
+    torch.manual_seed(42)
+    m = O.RNOracle(formula.QDICT, formula.ADICT, formula.HYP[cfg])
+    m.train()
+    img, qst, lab = make_batch(B, "cpu", hw)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        m.zero_grad()
+        loss = torch.nn.functional.nll_loss(m(img, qst), lab)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": B / t, "unit": "questions/s", "cores": n_thr, "kind": "port",
+            "sample": "%d timed fwd+bwd steps (median) of the fp32 CPU restatement at B=%d, %s, after 1 warm-up; %s"
+                      % (steps, B, cfg, model)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--config", default="original-fp")
+    ap.add_argument("--precision", default=os.environ.get("RN_PRECISION", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--hw", type=int, default=128, help="image side (224 -> 14x14 grid stress config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import relationnetworks_clevr_amd as pkg
+    from relationnetworks_clevr_amd import dp
+    H = pkg.rn_hip
+    H.load()
+    hyps = json.load(open(os.path.join(ROOT, "relationnetworks-clevr_amd", "config.json")))["hyperparams"]
+    hyp = dict(hyps[args.config], precision=args.precision)
+
+    class A:
+        qdict_size, adict_size = 82, 28
+
+    torch.manual_seed(42)
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = pkg.RN(A, hyp)
+    model.cuda(dev)
+    model.train()
+    try:
+        opt = torch.optim.Adam(model.parameters(), lr=5e-6, weight_decay=1e-4, fused=True)   # train.py:330,376
+    except Exception:
+        opt = torch.optim.Adam(model.parameters(), lr=5e-6, weight_decay=1e-4, foreach=True)
+    trainer = dp.DataParallelTrainer(model, opt, clip_norm=50.0)
+    B = args.batch
+    img, qst, lab = make_batch(B, dev, args.hw)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(img, qst, lab)
+    H.TIMER.enabled = not args.no_kernel_timing
+    H.TIMER.reset()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(img, qst, lab)
+    sync()
+    dt = time.perf_counter() - t0
+    H.TIMER.enabled = False
+    ksum = H.TIMER.summary()
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if not torch.isfinite(loss).item():
+        raise SystemExit("non-finite loss")
+
+    if rank == 0:
+        d = args.hw // 16
+        n, k = d * d, hyp["rl_in_size"] // 2
+        M = B * n * n
+        fwd = g_flops_fwd(M, hyp, k)
+        out = {
+            "metric": "CLEVR questions/sec (train fwd+bwd) at B=64, 8x8 grid",
+            "value": world * B * args.steps / dt, "unit": "questions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "%s train step (conv+LSTM+RN fwd/bwd, clip 50, Adam), B=%d/GPU, %dx%d grid (n=%d, M=%d pair rows/GPU), "
+                                   "synthetic %dx%d images + 20-token questions, random-init weights"
+                                   % (args.config, B, d, d, n, M, args.hw, args.hw),
+                       "global_batch": world * B, "parallelism": "dp%d" % world},
+            "loss": float(loss),
+        }
+        if ksum:
+            g_ms = sum(ksum.get(kk, (0, 0.0))[1] for kk in ("g_fwd", "g_dgrad", "g_wgrad")) / args.steps
+            g_launch = sum(ksum.get(kk, (0, 0.0))[0] for kk in ("g_fwd", "g_dgrad", "g_wgrad")) // args.steps
+            ach = 3 * fwd / (g_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                               "frac": ach / PEAK_TFLOPS[args.precision], "traffic": None,
+                               "kernel": "g_theta GEMMs: gemm_rowtile_kernel (fwd+dgrad) + wgrad_kernel, %d launches/step" % g_launch,
+                               "algorithmic_flops_per_step": 3 * fwd, "ms_per_step": g_ms,
+                               "breakdown_ms_per_step": {kk: v[1] / args.steps for kk, v in sorted(ksum.items())}}
+            pb = ksum.get("pair_build")
+            if pb:
+                esz = 2 if args.precision == "bf16" else 4
+                Q = hyp["lstm_hidden"] if hyp["question_injection_position"] == 0 else 0
+                nbytes = M * (2 * k + Q) * esz + B * n * k * 4 + B * Q * 4
+                gbs = nbytes / (pb[1] / pb[0] * 1e-3) / 1e9
+                out["pair_build"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                     "frac": gbs / PEAK_HBM_GBS, "bytes_per_launch": nbytes, "us_per_launch": 1e3 * pb[1] / pb[0]}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.config, B, args.hw)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+/* rn_hip.h -- C ABI of the MI355X (gfx950) Relation-Network hot-path library.
+ *
+ * The reference (mesnico/RelationNetworks-CLEVR) has no native code and no
+ * FFI: its seam is the Python module model.py.  This
+ * header is the boundary a maintainer binds with ctypes from that module
+ * (see INTEGRATION.md); each entry point names the reference lines whose
+ * stock-PyTorch op sequence it replaces.
+ *
+ * Conventions (all entry points):
+ *   - plain C, POD arguments only: raw DEVICE pointers, sizes, element
+ *     strides / leading dimensions (in ELEMENTS), a dtype enum and a
+ *     hipStream_t passed as void*.
+ *   - the library never allocates, frees, retains or synchronises device
+ *     memory; every buffer (outputs, saved activations, workspace) is owned by
+ *     the caller.  All work is enqueued on the caller's stream.
+ *   - return value: 0 = OK; negative = argument error; positive = hipError_t.
+ *     rn_last_error() returns a thread-local message for the last failure.
+ *   - stateless and re-entrant; kernels are compiled for gfx950 (wave64) only.
+ *
+ * Storage dtypes of the pair / activation / packed-weight buffers:
+ *   RN_BF16 : bf16 storage, bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate.
+ *   RN_F32  : fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32) -- exact-fp32 parity mode.
+ * Row index of every "pair" matrix: r = (b*n + i)*n + j   (model.py:127).
+ */
+#ifndef RN_HIP_H
+#define RN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RN_ABI_VERSION 1
+
+enum { RN_BF16 = 0, RN_F32 = 1 };
+
+/* rn_gemm_f32 flags */
+enum { RN_RELU = 1, RN_ACCUMULATE = 2 };
+
+int rn_abi_version(void);
+const char* rn_last_error(void);
+
+/* K1 -- fused pair-expand + coord-tag carry + question broadcast.
+ * Replaces model.py:112-127 (+ :135-140 when the question is injected at g layer 0).
+ *   P[r, 0:k]      = x[b, j, :]      P[r, k:2k] = x[b, i, :]
+ *   P[r, 2k:2k+Q]  = q[b, :]  (Q == 0: no question columns)     P[r, 2k+Q:ld] = 0
+ * x: fp32 with element strides (sxb, sxn, sxk) -- accepts both a contiguous (B,n,k)
+ * tensor and the permuted (B,k,n) view RN.forward produces (model.py:200-201).
+ * q: fp32 (B,Q), row stride sqb.  P: (B*n*n, ld) of `dtype`, ld % 64 == 0. */
+int rn_pair_build_fwd(const float* x, long sxb, long sxn, long sxk, const float* q, long sqb,
+                      void* P, int dtype, int B, int n, int k, int Q, int ld, void* stream);
+
+/* Question broadcast into columns [col0, col0+Q) of a wide activation buffer
+ * A (B*n*n, ld) -- model.py:135-140 for question_injection_position > 0. */
+int rn_qst_broadcast(const float* q, long sqb, void* A, int dtype, int B, int n, int Q, int col0, int ld,
+                     void* stream);
+
+/* Pack a fp32 matrix into a zero-padded `dtype` matrix: dst[r][c] = src[r*sr + c*sc]
+ * for r < R, c < C; zero for C <= c < ld and R <= r < Rpad.  Used for nn.Linear
+ * weights (out,in) (model.py:96-99) -> MFMA operand layout, plain or transposed. */
+int rn_pack_matrix(const float* src, long sr, long sc, int R, int C, void* dst, int dtype, int ld, int Rpad,
+                   void* stream);
+
+/* K2 -- one g_theta layer:  H = relu(A @ W^T + bias)      (model.py:141-145)
+ * A: (M, lda) dtype, reduction length K (K % 64 == 0, columns >= true K are zero),
+ * Wp: (N, ldw) packed dtype (rn_pack_matrix), bias: fp32 (N), H: (M, ldh) dtype.
+ * N % 256 == 0. */
+int rn_g_linear_fwd(const void* A, int lda, const void* Wp, int ldw, const float* bias, void* H, int ldh,
+                    int dtype, int M, int N, int K, void* stream);
+
+/* K3 -- sum over the n*n pairs of every question: xg[b,:] = sum_p HL[b*npairs+p, :]
+ * (model.py:151-152).  ws: >= rn_pair_sum_ws_bytes(...) bytes of scratch. */
+size_t rn_pair_sum_ws_bytes(int B, int npairs, int G);
+int rn_pair_sum_fwd(const void* HL, int ldh, float* xg, void* ws, int dtype, int B, int npairs, int G,
+                    void* stream);
+
+/* Backward of K3 fused with the last layer's ReLU gate:
+ * dZ[b*npairs+p, c] = dxg[b, c] * (HL[b*npairs+p, c] > 0). */
+int rn_pair_sum_bwd(const float* dxg, const void* HL, int ldh, void* dZ, int lddz, int dtype, int B,
+                    int npairs, int G, void* stream);
+
+/* dgrad of one g layer fused with the previous layer's ReLU gate:
+ *   dZprev = (dZ @ W[:, :Kin]) * (Hprev > 0)
+ * dZ: (M, lddz), reduction length N (layer width, N % 64 == 0); Wt: (Kin, ldwt) packed
+ * transposed weight (Wt[k][n] = W[n][k]); Hprev, dZprev: (M, Kin), Kin % 256 == 0. */
+int rn_g_linear_bwd_dgrad(const void* dZ, int lddz, const void* Wt, int ldwt, const void* Hprev, int ldhp,
+                          void* dZprev, int lddzp, int dtype, int M, int N, int Kin, void* stream);
+
+/* wgrad of one g layer: dW[n, k] = sum_m dZ[m, n] * A[m, k] (k < Ktrue), db[n] = sum_m dZ[m, n].
+ * dZ: (M, lddz) width N (N % 256 == 0); A: (M, lda) with K padded columns (K % 32 == 0);
+ * dW: fp32 (N, Ktrue) contiguous (nn.Linear layout); db: fp32 (N).
+ * Deterministic: split over M into per-block partials in ws, then an ordered reduction. */
+size_t rn_wgrad_ws_bytes(int M, int N, int K);
+int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, int lda, float* dW, float* db, void* ws,
+                          int dtype, int M, int N, int K, int Ktrue, void* stream);
+
+/* Backward of the pair expansion, algebraic form: reduce the gradient
+ * of a g layer's pre-activation over the pair axes instead of materialising dP:
+ *   Rj[b,j,:] = sum_i dZ[(b,i,j),:]   Ri[b,i,:] = sum_j dZ[(b,i,j),:]   Rq[b,:] = sum_ij dZ[(b,i,j),:]
+ * Any of Rj / Ri / Rq may be NULL.  Outputs fp32; Rj, Ri: (B,n,G); Rq: (B,G). */
+size_t rn_pair_reduce_ws_bytes(int B, int n, int G);
+int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri, float* Rq, void* ws, int dtype, int B,
+                       int n, int G, void* stream);
+
+/* K4 -- small fp32 GEMM on the fp32 MFMA, used for f_phi (model.py:155-160), its backward
+ * and the (B*n x G) tail of the pair backward:
+ *   C[m,n] (+)= epi( sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] )
+ *   epi: + bias[n]; * mul[m*ldmul + n] (dropout mask incl. 1/(1-p), model.py:158);
+ *        relu (flags & RN_RELU); * (gate[m*ldgate + n] > 0) (ReLU backward).
+ * Order: bias -> mul -> relu -> gate.  flags & RN_ACCUMULATE adds into C. */
+int rn_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
+                int M, int N, int K, const float* bias, const float* mul, long ldmul, const float* gate,
+                long ldgate, int flags, void* stream);
+
+/* log_softmax over dim 1 (model.py:162) and its backward: dz = g - exp(out) * sum(g). */
+int rn_log_softmax_fwd(const float* z, float* out, int B, int A, void* stream);
+int rn_log_softmax_bwd(const float* out, const float* gout, float* dz, int B, int A, void* stream);
+
+/* column sums: out[c] = sum_r src[r*ld + c]  (bias gradients of f_phi). */
+int rn_colsum_f32(const float* src, long ld, float* out, int R, int C, void* stream);
+
+/* Diagnostics used by the GPU tests: raw lane mapping of ds_read_b64_tr_b16. */
+int rn_probe_tr16(const unsigned short* in4096, unsigned short* out256, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RN_HIP_H */

@@ -1,0 +1,192 @@
+// K2 -- g_theta layer GEMM on the gfx950 matrix cores (model.py:141-145) and its dgrad.
+//
+//   out[m, n] = epi( sum_k A[m, k] * W[n, k] )        A: (M, K) row-major, W: (N, K) row-major
+//
+// Workgroup = 256 threads (4 waves, one per SIMD; two workgroups per CU), tile 128(M) x 256(N),
+// K streamed in 128-byte slabs (64 bf16 / 32 fp32 per row) through one padded LDS buffer with
+// the next slab prefetched into registers while the current one feeds the MFMAs.
+//
+// MFMA operand assignment is "swapped": the weight fragment is the A-operand (rows = output
+// feature n) and the activation fragment is the B-operand (cols = pair row m), so every lane
+// ends up holding 4 CONSECUTIVE output features of one pair row per accumulator group ->
+// row-contiguous 8-byte (bf16) / 16-byte (fp32) epilogue stores instead of 2-byte scatters.
+//
+//   bf16: v_mfma_f32_32x32x16_bf16, lane l supplies row (l&31), k = 8*(l>>5)..+8 of both operands
+//   fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain), 4 MFMAs per 16-byte fragment; the
+//         k order inside a slab is permuted identically for both operands (sum order only).
+//   D layout (both): col j = l&31 (pair row), row i = (reg&3) + 8*(reg>>2) + 4*(l>>5) (feature).
+#include "rn_common.h"
+
+enum { EPI_BIAS_RELU = 0, EPI_GATE = 1 };
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+  typedef bf16x8 Frag;
+  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  typedef f32x4 Frag;
+  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], c, 0, 0, 0);
+  }
+};
+
+constexpr int TM = 128, TN = 256;
+constexpr int SLAB_B = 128;            // bytes of K per row per slab
+constexpr int ROW_B = SLAB_B + 16;     // padded LDS row stride: conflict-free ds_read_b128
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_rowtile_kernel(const T* __restrict__ A, int lda,
+                                                              const T* __restrict__ W, int ldw,
+                                                              const float* __restrict__ bias,
+                                                              const T* __restrict__ gate, int ldg,
+                                                              T* __restrict__ C, int ldc, int M, int K) {
+  constexpr int CH = Elem<T>::kPer16B;
+  constexpr int BKE = SLAB_B / (int)sizeof(T);
+  typedef typename Mma<T>::Frag Frag;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(TM + TN) * ROW_B];
+  unsigned char* ldsA = lds;
+  unsigned char* ldsW = lds + TM * ROW_B;
+
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const long m0 = (long)blockIdx.x * TM;
+  const int n0 = blockIdx.y * TN;
+  const int srow = t >> 3, scc = t & 7;        // staging: 8 consecutive lanes cover one 128-byte row slab
+
+  u32x4 ra[4], rw[8];
+  const T* a_ptr[4];
+  const T* w_ptr[8];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    long r = m0 + srow + 32 * s;
+    if (r > M - 1) r = M - 1;                   // clamp: rows >= M are computed but never stored
+    a_ptr[s] = A + r * lda + scc * CH;
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) w_ptr[s] = W + (long)(n0 + srow + 32 * s) * ldw + scc * CH;
+
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ra[s] = *reinterpret_cast<const u32x4*>(a_ptr[s] + kt * BKE);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) rw[s] = *reinterpret_cast<const u32x4*>(w_ptr[s] + kt * BKE);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4*>(ldsA + (srow + 32 * s) * ROW_B + scc * 16) = ra[s];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) *reinterpret_cast<u32x4*>(ldsW + (srow + 32 * s) * ROW_B + scc * 16) = rw[s];
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = K / BKE;
+  gload(0);
+  lstore();
+  __syncthreads();
+  const unsigned char* fa_base = ldsA + (wm * 64 + (lane & 31)) * ROW_B + (lane >> 5) * 16;
+  const unsigned char* fw_base = ldsW + (wn * 128 + (lane & 31)) * ROW_B + (lane >> 5) * 16;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      Frag fa[2], fw[4];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const Frag*>(fa_base + mt * 32 * ROW_B + ks * 32);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) fw[nt] = *reinterpret_cast<const Frag*>(fw_base + nt * 32 * ROW_B + ks * 32);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) Mma<T>::mma(fw[nt], fa[mt], acc[mt][nt]);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      lstore();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: lane holds, per (mt, nt, g), features nb..nb+3 of pair row `row`
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const long row = m0 + wm * 64 + mt * 32 + (lane & 31);
+    if (row >= M) continue;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nb = n0 + wn * 128 + nt * 32 + 8 * g + 4 * (lane >> 5);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][4 * g + r];
+        if constexpr (EPI == EPI_BIAS_RELU) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + nb);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r] + bv[r], 0.f);
+        } else {
+          T gt[4];
+          if constexpr (sizeof(T) == 2) *reinterpret_cast<u32x2*>(gt) = *reinterpret_cast<const u32x2*>(gate + row * ldg + nb);
+          else *reinterpret_cast<u32x4*>(gt) = *reinterpret_cast<const u32x4*>(gate + row * ldg + nb);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = is_pos<T>(gt[r]) ? v[r] : 0.f;
+        }
+        T o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = Elem<T>::from_f32(v[r]);
+        if constexpr (sizeof(T) == 2) *reinterpret_cast<u32x2*>(C + row * ldc + nb) = *reinterpret_cast<const u32x2*>(o);
+        else *reinterpret_cast<u32x4*>(C + row * ldc + nb) = *reinterpret_cast<const u32x4*>(o);
+      }
+    }
+  }
+}
+
+template <int EPI>
+static int gemm_launch(const void* A, int lda, const void* W, int ldw, const float* bias, const void* gate, int ldg,
+                       void* C, int ldc, int dtype, int M, int N, int K, hipStream_t s, const char* who) {
+  RN_CHECK_ARG(A && W && C && M > 0, "%s: bad pointer/size", who);
+  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "%s: bad dtype %d", who, dtype);
+  const int CH = dtype == RN_BF16 ? 8 : 4;
+  RN_CHECK_ARG(N % TN == 0, "%s: output width %d must be a multiple of %d", who, N, TN);
+  RN_CHECK_ARG(K % 64 == 0 && K > 0, "%s: reduction length %d must be a multiple of 64", who, K);
+  RN_CHECK_ARG(lda % CH == 0 && ldw % CH == 0 && ldc % CH == 0 && lda >= K && ldw >= K && ldc >= N,
+               "%s: leading dimensions (lda=%d ldw=%d ldc=%d) must be 16-byte multiples and cover K=%d / N=%d", who, lda,
+               ldw, ldc, K, N);
+  RN_CHECK_ARG(((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)gate) % 16 == 0, "%s: pointers must be 16-byte aligned", who);
+  dim3 grid(cdiv(M, TM), N / TN);
+  if (dtype == RN_BF16)
+    gemm_rowtile_kernel<bf16, EPI><<<grid, 256, 0, s>>>((const bf16*)A, lda, (const bf16*)W, ldw, bias, (const bf16*)gate,
+                                                        ldg, (bf16*)C, ldc, M, K);
+  else
+    gemm_rowtile_kernel<float, EPI><<<grid, 256, 0, s>>>((const float*)A, lda, (const float*)W, ldw, bias,
+                                                         (const float*)gate, ldg, (float*)C, ldc, M, K);
+  RN_LAUNCH_CHECK(who);
+  return 0;
+}
+
+extern "C" int rn_g_linear_fwd(const void* A, int lda, const void* Wp, int ldw, const float* bias, void* H, int ldh,
+                               int dtype, int M, int N, int K, void* stream) {
+  RN_CHECK_ARG(bias && ((uintptr_t)bias % 16 == 0), "rn_g_linear_fwd: bias must be a 16-byte aligned fp32 vector");
+  return gemm_launch<EPI_BIAS_RELU>(A, lda, Wp, ldw, bias, nullptr, 0, H, ldh, dtype, M, N, K, (hipStream_t)stream,
+                                    "rn_g_linear_fwd");
+}
+
+extern "C" int rn_g_linear_bwd_dgrad(const void* dZ, int lddz, const void* Wt, int ldwt, const void* Hprev, int ldhp,
+                                     void* dZprev, int lddzp, int dtype, int M, int N, int Kin, void* stream) {
+  RN_CHECK_ARG(Hprev, "rn_g_linear_bwd_dgrad: Hprev is NULL");
+  const int CH = dtype == RN_BF16 ? 8 : 4;
+  RN_CHECK_ARG(ldhp % CH == 0 && ldhp >= Kin, "rn_g_linear_bwd_dgrad: bad ldhp=%d", ldhp);
+  // out (M, Kin) = dZ (M, N) @ Wt(Kin, N)^T, gated by Hprev > 0
+  return gemm_launch<EPI_GATE>(dZ, lddz, Wt, ldwt, nullptr, Hprev, ldhp, dZprev, lddzp, dtype, M, Kin, N,
+                               (hipStream_t)stream, "rn_g_linear_bwd_dgrad");
+}

@@ -1,0 +1,346 @@
+// Pair-axis kernels (HBM-bound byte movers and reductions):
+//   K1  pair_build        model.py:112-127      materialise P = [x_j | x_i | q | 0]
+//       qst_broadcast     model.py:135-140      question columns of a wide activation
+//       pack_matrix       model.py:96-99        nn.Linear weights -> padded MFMA operand
+//   K3  segsum / pair_sum model.py:151-152      x_g = sum over the n*n pairs
+//       pair_sum_bwd      (autograd of :151 + last ReLU gate)
+//       pair_reduce_bwd   (autograd of :117-127, algebraic form)
+// All stores are 16-byte, fully coalesced; no MFMA here (K1 is HBM-write bound).
+#include <stdarg.h>
+
+#include "rn_common.h"
+
+// ---------------------------------------------------------------- error state
+static thread_local char g_err[512] = "";
+void rn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* rn_last_error(void) { return g_err; }
+extern "C" int rn_abi_version(void) { return RN_ABI_VERSION; }
+
+// ------------------------------------------------------------------ K1 pair build
+// One workgroup = one question b and IB consecutive "i" objects.  For a fixed (b,i) the
+// n rows (b,i,0..n-1) are one contiguous n*ld*sizeof(T) byte span of P, and only the first
+// k columns change with j.  LDS holds:  pre[n][PW] (first PW = roundup(k,CH) columns of every
+// j-row) and suf[ld] (the j-independent remainder: x_i | q | 0).  The copy loop then streams
+// 16-byte chunks LDS -> HBM, consecutive lanes -> consecutive 16 B.
+template <typename T>
+__global__ __launch_bounds__(256) void pair_build_kernel(const float* __restrict__ x, long sxb, long sxn, long sxk,
+                                                         const float* __restrict__ q, long sqb, T* __restrict__ P,
+                                                         int n, int k, int Q, int ld, int IB) {
+  constexpr int CH = Elem<T>::kPer16B;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int PW = (k + CH - 1) / CH * CH;
+  T* pre = reinterpret_cast<T*>(smem_raw);          // [n][PW]
+  T* suf = pre + (size_t)n * PW;                    // [ld]
+  const int b = blockIdx.y;
+  const int t = threadIdx.x;
+  const float* xb = x + (long)b * sxb;
+  const int cpr = ld / CH;                          // 16-byte chunks per row
+  // j-dependent head: pre[j][e] = x[b,j,e]  (e < k)
+  for (int idx = t; idx < n * k; idx += 256) {
+    const int j = idx % n, e = idx / n;
+    pre[j * PW + e] = Elem<T>::from_f32(xb[(long)j * sxn + (long)e * sxk]);
+  }
+  for (int ii = 0; ii < IB; ++ii) {
+    const int i = blockIdx.x * IB + ii;
+    if (i >= n) break;                               // uniform per block
+    __syncthreads();                                 // previous copy loop done with suf / pre tail
+    for (int c = k + t; c < ld; c += 256) {
+      float v = 0.f;
+      if (c < 2 * k) v = xb[(long)i * sxn + (long)(c - k) * sxk];
+      else if (c < 2 * k + Q) v = q[(long)b * sqb + (c - 2 * k)];
+      suf[c] = Elem<T>::from_f32(v);
+    }
+    __syncthreads();
+    // tail of the head chunk(s): columns k..PW-1 come from suf (they depend on i, not j)
+    if (PW > k) {
+      const int tw = PW - k;
+      for (int idx = t; idx < n * tw; idx += 256) {
+        const int j = idx / tw, e = k + idx % tw;
+        pre[j * PW + e] = suf[e];
+      }
+      __syncthreads();
+    }
+    Chunk16<T>* dst = reinterpret_cast<Chunk16<T>*>(P + ((long)(b * n + i) * n) * ld);
+    const int total = n * cpr;
+    const int hc = PW / CH;                          // head chunks per row
+    for (int g = t; g < total; g += 256) {
+      const int j = g / cpr, c = g - j * cpr;
+      const T* src = (c < hc) ? (pre + j * PW + c * CH) : (suf + c * CH);
+      dst[g] = *reinterpret_cast<const Chunk16<T>*>(src);
+    }
+  }
+}
+
+extern "C" int rn_pair_build_fwd(const float* x, long sxb, long sxn, long sxk, const float* q, long sqb, void* P,
+                                 int dtype, int B, int n, int k, int Q, int ld, void* stream) {
+  RN_CHECK_ARG(x && P && B > 0 && n > 0 && k > 0 && Q >= 0, "rn_pair_build_fwd: bad pointer/size");
+  RN_CHECK_ARG(Q == 0 || q, "rn_pair_build_fwd: Q > 0 but q is NULL");
+  RN_CHECK_ARG(ld % 64 == 0 && ld >= 2 * k + Q, "rn_pair_build_fwd: ld=%d must be a multiple of 64 and >= 2k+Q=%d", ld,
+               2 * k + Q);
+  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "rn_pair_build_fwd: bad dtype %d", dtype);
+  int IB = (int)((long)B * n / 2048);
+  IB = IB < 1 ? 1 : (IB > 8 ? 8 : IB);
+  dim3 grid(cdiv(n, IB), B);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RN_BF16) {
+    size_t lds = ((size_t)n * ((k + 7) / 8 * 8) + ld) * sizeof(bf16);
+    RN_CHECK_ARG(lds <= 64 * 1024, "rn_pair_build_fwd: n*k too large for LDS staging");
+    pair_build_kernel<bf16><<<grid, 256, lds, s>>>(x, sxb, sxn, sxk, q, sqb, (bf16*)P, n, k, Q, ld, IB);
+  } else {
+    size_t lds = ((size_t)n * ((k + 3) / 4 * 4) + ld) * sizeof(float);
+    RN_CHECK_ARG(lds <= 64 * 1024, "rn_pair_build_fwd: n*k too large for LDS staging");
+    pair_build_kernel<float><<<grid, 256, lds, s>>>(x, sxb, sxn, sxk, q, sqb, (float*)P, n, k, Q, ld, IB);
+  }
+  RN_LAUNCH_CHECK("rn_pair_build_fwd");
+  return 0;
+}
+
+// ------------------------------------------------------------ question broadcast
+template <typename T>
+__global__ __launch_bounds__(256) void qst_broadcast_kernel(const float* __restrict__ q, long sqb, T* __restrict__ A,
+                                                            int npairs, int Q, int col0, int ld) {
+  constexpr int CH = Elem<T>::kPer16B;
+  const int b = blockIdx.y;
+  __shared__ __attribute__((aligned(16))) T qs[1024];
+  for (int c = threadIdx.x; c < Q; c += 256) qs[c] = Elem<T>::from_f32(q[(long)b * sqb + c]);
+  __syncthreads();
+  const int cq = Q / CH;
+  const long total = (long)npairs * cq;
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+    const long p = g / cq;
+    const int c = (int)(g - p * cq);
+    *reinterpret_cast<Chunk16<T>*>(A + ((long)b * npairs + p) * ld + col0 + c * CH) =
+        *reinterpret_cast<const Chunk16<T>*>(qs + c * CH);
+  }
+}
+
+extern "C" int rn_qst_broadcast(const float* q, long sqb, void* A, int dtype, int B, int n, int Q, int col0, int ld,
+                                void* stream) {
+  RN_CHECK_ARG(q && A && B > 0 && n > 0, "rn_qst_broadcast: bad pointer/size");
+  RN_CHECK_ARG(Q > 0 && Q <= 1024 && Q % 8 == 0 && col0 % 8 == 0 && ld % 8 == 0 && col0 + Q <= ld,
+               "rn_qst_broadcast: Q=%d col0=%d ld=%d must be multiples of 8, Q <= 1024, col0+Q <= ld", Q, col0, ld);
+  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "rn_qst_broadcast: bad dtype %d", dtype);
+  const int npairs = n * n;
+  dim3 grid(cdiv((long)npairs * Q / 8, 256 * 4) < 1 ? 1 : cdiv((long)npairs * Q / 8, 256 * 4), B);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RN_BF16) qst_broadcast_kernel<bf16><<<grid, 256, 0, s>>>(q, sqb, (bf16*)A, npairs, Q, col0, ld);
+  else qst_broadcast_kernel<float><<<grid, 256, 0, s>>>(q, sqb, (float*)A, npairs, Q, col0, ld);
+  RN_LAUNCH_CHECK("rn_qst_broadcast");
+  return 0;
+}
+
+// ------------------------------------------------------------------ weight pack
+template <typename T>
+__global__ __launch_bounds__(256) void pack_matrix_kernel(const float* __restrict__ src, long sr, long sc, int R, int C,
+                                                          T* __restrict__ dst, int ld, int Rpad) {
+  const long total = (long)Rpad * ld;
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+    const int r = (int)(g / ld), c = (int)(g - (long)r * ld);
+    const float v = (r < R && c < C) ? src[(long)r * sr + (long)c * sc] : 0.f;
+    dst[g] = Elem<T>::from_f32(v);
+  }
+}
+
+extern "C" int rn_pack_matrix(const float* src, long sr, long sc, int R, int C, void* dst, int dtype, int ld, int Rpad,
+                              void* stream) {
+  RN_CHECK_ARG(src && dst && R > 0 && C > 0 && ld >= C && Rpad >= R, "rn_pack_matrix: bad pointer/size");
+  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "rn_pack_matrix: bad dtype %d", dtype);
+  const long total = (long)Rpad * ld;
+  int blocks = cdiv(total, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RN_BF16) pack_matrix_kernel<bf16><<<blocks, 256, 0, s>>>(src, sr, sc, R, C, (bf16*)dst, ld, Rpad);
+  else pack_matrix_kernel<float><<<blocks, 256, 0, s>>>(src, sr, sc, R, C, (float*)dst, ld, Rpad);
+  RN_LAUNCH_CHECK("rn_pack_matrix");
+  return 0;
+}
+
+// ----------------------------------------------------- segmented sum (K3 and Ri)
+// in: (nseg*seglen rows, ld) of T, width G.  Block (slice s, segment) sums up to 256 rows of
+// its segment; thread = (row lane, 16-byte column chunk); fp32 accumulation; the row lanes are
+// combined through LDS in a fixed order -> deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void segsum_kernel(const T* __restrict__ in, int ld, float* __restrict__ out,
+                                                     int seglen, int G, int S) {
+  constexpr int CH = Elem<T>::kPer16B;
+  __shared__ float red[256 * 8];
+  const int seg = blockIdx.y, s = blockIdx.x;
+  const int cpr = G / CH;              // chunks per row (<= 256)
+  const int lanes = 256 / cpr;         // row lanes
+  const int t = threadIdx.x;
+  const int c = t % cpr, rl = t / cpr;
+  float acc[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+  const int r0 = s * 256;
+  const int r1 = (r0 + 256 < seglen) ? r0 + 256 : seglen;
+  if (rl < lanes) {
+    const T* base = in + ((long)seg * seglen) * ld + c * CH;
+    for (int r = r0 + rl; r < r1; r += lanes) {
+      const Chunk16<T> v = *reinterpret_cast<const Chunk16<T>*>(base + (long)r * ld);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) acc[e] += Elem<T>::to_f32(v.v[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < CH; ++e) red[t * CH + e] = acc[e];
+  __syncthreads();
+  // thread t < G sums column t over the row lanes
+  for (int col = t; col < G; col += 256) {
+    const int cc = col / CH, e = col % CH;
+    float sum = 0.f;
+    for (int l = 0; l < lanes; ++l) sum += red[(l * cpr + cc) * CH + e];
+    out[((long)seg * S + s) * G + col] = sum;
+  }
+}
+
+__global__ __launch_bounds__(256) void segsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                            long total, int G, int S) {
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+    const long seg = g / G;
+    const int c = (int)(g - seg * G);
+    float sum = 0.f;
+    for (int s = 0; s < S; ++s) sum += part[(seg * S + s) * G + c];
+    out[g] = sum;
+  }
+}
+
+static int segsum_launch(const void* in, int ld, float* out, void* ws, int dtype, int nseg, int seglen, int G,
+                         hipStream_t s, const char* who) {
+  RN_CHECK_ARG(in && out && nseg > 0 && seglen > 0, "%s: bad pointer/size", who);
+  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "%s: bad dtype %d", who, dtype);
+  const int CH = dtype == RN_BF16 ? 8 : 4;
+  RN_CHECK_ARG(G % CH == 0 && G / CH <= 256 && ld % CH == 0, "%s: G=%d / ld=%d unsupported", who, G, ld);
+  const int S = cdiv(seglen, 256);
+  RN_CHECK_ARG(S == 1 || ws, "%s: workspace required", who);
+  float* part = S == 1 ? out : (float*)ws;
+  dim3 grid(S, nseg);
+  if (dtype == RN_BF16) segsum_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)in, ld, part, seglen, G, S);
+  else segsum_kernel<float><<<grid, 256, 0, s>>>((const float*)in, ld, part, seglen, G, S);
+  RN_LAUNCH_CHECK(who);
+  if (S > 1) {
+    const long total = (long)nseg * G;
+    int blocks = cdiv(total, 256);
+    if (blocks > 1024) blocks = 1024;
+    segsum_finish_kernel<<<blocks, 256, 0, s>>>(part, out, total, G, S);
+    RN_LAUNCH_CHECK(who);
+  }
+  return 0;
+}
+
+extern "C" size_t rn_pair_sum_ws_bytes(int B, int npairs, int G) {
+  return (size_t)B * cdiv(npairs, 256) * G * sizeof(float);
+}
+
+extern "C" int rn_pair_sum_fwd(const void* HL, int ldh, float* xg, void* ws, int dtype, int B, int npairs, int G,
+                               void* stream) {
+  return segsum_launch(HL, ldh, xg, ws, dtype, B, npairs, G, (hipStream_t)stream, "rn_pair_sum_fwd");
+}
+
+// ------------------------------------------ backward of the pair sum + last ReLU gate
+template <typename T>
+__global__ __launch_bounds__(256) void pair_sum_bwd_kernel(const float* __restrict__ dxg, const T* __restrict__ HL,
+                                                           int ldh, T* __restrict__ dZ, int lddz, int npairs, int G,
+                                                           long total) {
+  constexpr int CH = Elem<T>::kPer16B;
+  const int cpr = G / CH;
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+    const long row = g / cpr;
+    const int c = (int)(g - row * cpr);
+    const int b = (int)(row / npairs);
+    const Chunk16<T> h = *reinterpret_cast<const Chunk16<T>*>(HL + row * ldh + c * CH);
+    Chunk16<T> o;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      const float gv = dxg[(long)b * G + c * CH + e];
+      o.v[e] = Elem<T>::from_f32(is_pos<T>(h.v[e]) ? gv : 0.f);
+    }
+    *reinterpret_cast<Chunk16<T>*>(dZ + row * lddz + c * CH) = o;
+  }
+}
+
+extern "C" int rn_pair_sum_bwd(const float* dxg, const void* HL, int ldh, void* dZ, int lddz, int dtype, int B,
+                               int npairs, int G, void* stream) {
+  RN_CHECK_ARG(dxg && HL && dZ && B > 0 && npairs > 0, "rn_pair_sum_bwd: bad pointer/size");
+  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "rn_pair_sum_bwd: bad dtype %d", dtype);
+  const int CH = dtype == RN_BF16 ? 8 : 4;
+  RN_CHECK_ARG(G % CH == 0 && ldh % CH == 0 && lddz % CH == 0, "rn_pair_sum_bwd: G/ld must be multiples of %d", CH);
+  const long total = (long)B * npairs * (G / CH);
+  int blocks = cdiv(total, 256 * 4);
+  if (blocks < 1) blocks = 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RN_BF16)
+    pair_sum_bwd_kernel<bf16><<<blocks, 256, 0, s>>>(dxg, (const bf16*)HL, ldh, (bf16*)dZ, lddz, npairs, G, total);
+  else
+    pair_sum_bwd_kernel<float><<<blocks, 256, 0, s>>>(dxg, (const float*)HL, ldh, (float*)dZ, lddz, npairs, G, total);
+  RN_LAUNCH_CHECK("rn_pair_sum_bwd");
+  return 0;
+}
+
+// ---------------------------------------- backward of the pair expansion (reductions)
+// Rj[b,j,:] = sum_i dZ[(b,i,j),:] : block = (j-group, b); thread = (row-in-group, chunk); every
+// thread walks i with a row stride of n rows; the block reads rpb consecutive rows per i.
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_over_i_kernel(const T* __restrict__ dZ, int ld, float* __restrict__ Rj,
+                                                            int n, int G) {
+  constexpr int CH = Elem<T>::kPer16B;
+  const int cpr = G / CH;
+  const int rpb = 256 / cpr;
+  const int t = threadIdx.x;
+  const int c = t % cpr, jl = t / cpr;
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * rpb + jl;
+  if (jl >= rpb || j >= n) return;
+  float acc[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+  const T* base = dZ + ((long)b * n * n + j) * ld + c * CH;
+#pragma unroll 4
+  for (int i = 0; i < n; ++i) {
+    const Chunk16<T> v = *reinterpret_cast<const Chunk16<T>*>(base + (long)i * n * ld);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) acc[e] += Elem<T>::to_f32(v.v[e]);
+  }
+  float* o = Rj + ((long)b * n + j) * G + c * CH;
+#pragma unroll
+  for (int e = 0; e < CH; ++e) o[e] = acc[e];
+}
+
+extern "C" size_t rn_pair_reduce_ws_bytes(int B, int n, int G) {
+  // Ri scratch (when the caller only wants Rq) + segsum partials for n > 256
+  return (size_t)B * n * G * sizeof(float) + (size_t)B * n * cdiv(n, 256) * G * sizeof(float);
+}
+
+extern "C" int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri, float* Rq, void* ws, int dtype, int B,
+                                  int n, int G, void* stream) {
+  RN_CHECK_ARG(dZ && B > 0 && n > 0 && ws, "rn_pair_reduce_bwd: bad pointer/size");
+  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "rn_pair_reduce_bwd: bad dtype %d", dtype);
+  const int CH = dtype == RN_BF16 ? 8 : 4;
+  RN_CHECK_ARG(G % CH == 0 && G / CH <= 256 && lddz % CH == 0, "rn_pair_reduce_bwd: G=%d unsupported", G);
+  hipStream_t s = (hipStream_t)stream;
+  if (Rj) {
+    const int rpb = 256 / (G / CH);
+    dim3 grid(cdiv(n, rpb), B);
+    if (dtype == RN_BF16) reduce_over_i_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)dZ, lddz, Rj, n, G);
+    else reduce_over_i_kernel<float><<<grid, 256, 0, s>>>((const float*)dZ, lddz, Rj, n, G);
+    RN_LAUNCH_CHECK("rn_pair_reduce_bwd(Rj)");
+  }
+  if (Ri || Rq) {
+    float* ri = Ri ? Ri : (float*)ws;
+    float* part = (float*)ws + (size_t)B * n * G;
+    int rc = segsum_launch(dZ, lddz, ri, part, dtype, B * n, n, G, s, "rn_pair_reduce_bwd(Ri)");
+    if (rc) return rc;
+    if (Rq) {
+      // Rq[b] = sum_i Ri[b,i]: fp32 segmented sum over n rows (n <= 256 -> single slice)
+      RN_CHECK_ARG(G % 4 == 0 && G / 4 <= 256, "rn_pair_reduce_bwd: G=%d unsupported for Rq", G);
+      rc = segsum_launch(ri, G, Rq, part, RN_F32, B, n, G, s, "rn_pair_reduce_bwd(Rq)");
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}

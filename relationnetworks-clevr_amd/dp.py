@@ -1,0 +1,94 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, ONE flat fp32 gradient
+bucket, ONE RCCL all-reduce per step over xGMI.
+
+Replaces the reference's single-process `torch.nn.DataParallel` (train.py:256-258), which
+re-broadcasts the parameters and reduce-adds the gradients onto GPU 0 every step.  Here the
+replicas stay resident; per step each rank computes the mean-loss gradient of its own 1/world
+shard of the global minibatch, the buckets are summed with all-reduce and scaled by 1/world,
+which equals the gradient of the mean loss over the global batch (train.py:41 + DataParallel's
+gather).  BatchNorm statistics stay per replica, exactly like DataParallel (no SyncBN).
+
+The whole model has ~485k parameters (1.94 MB of fp32 gradients for *-fp): a single
+latency-bound collective, so everything goes into one bucket and nothing is overlapped with
+backward (the bucket is complete only when backward ends: the g_theta weight gradients, the
+bulk of the bytes, are produced last-layer-first but conv/LSTM grads arrive at the very end)."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class FlatGradBucket:
+    """Every parameter's .grad is a view into one contiguous fp32 buffer (16-byte aligned slots)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        offs, total = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError("FlatGradBucket expects fp32 master parameters")
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.numel = sum(p.numel() for p in self.params)
+        for p, o in zip(self.params, offs):
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+
+    def zero_(self):
+        """Replaces optimizer.zero_grad(): one memset, and the .grad views stay attached."""
+        self.flat.zero_()
+
+    def check_attached(self):
+        for p in self.params:
+            g = p.grad
+            if g is None or g.untyped_storage().data_ptr() != self.flat.untyped_storage().data_ptr():
+                raise RuntimeError("a .grad left the flat bucket (zero_grad(set_to_none=True) was called?)")
+
+    def all_reduce_mean(self, group=None):
+        """sum over ranks, then scale by 1/world -> gradient of the global-batch mean loss."""
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(group)
+            if world > 1:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                self.flat.mul_(1.0 / world)
+
+    def clip_grad_norm_(self, max_norm: float, eps: float = 1e-6):
+        """Global L2 clip (train.py:45-46, torch clip_grad_norm semantics) on the flat buffer:
+        two kernels and no host synchronisation.  Returns the (device) total norm."""
+        total = torch.linalg.vector_norm(self.flat, 2)
+        coef = torch.clamp(max_norm / (total + eps), max=1.0)
+        self.flat.mul_(coef)
+        return total
+
+
+def broadcast_module_state(module, src: int = 0, group=None):
+    """Make every replica start from rank `src`'s parameters and buffers (BN running stats)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src, group=group)
+
+
+class DataParallelTrainer:
+    """model + optimizer + flat bucket: step(batch) = zero -> fwd -> nll -> bwd -> all-reduce -> clip -> Adam
+    (the loop body of the reference's train(), train.py:36-48)."""
+
+    def __init__(self, model, optimizer, clip_norm: float | None = 50.0, group=None):
+        self.model, self.opt, self.clip_norm, self.group = model, optimizer, clip_norm, group
+        broadcast_module_state(model, 0, group)
+        self.bucket = FlatGradBucket(model.parameters())
+
+    def step(self, img, qst, label):
+        self.bucket.zero_()
+        out = self.model(img, qst)
+        loss = torch.nn.functional.nll_loss(out, label)
+        loss.backward()
+        self.bucket.all_reduce_mean(self.group)
+        if self.clip_norm:
+            self.bucket.clip_grad_norm_(self.clip_norm)
+        self.opt.step()
+        return loss

@@ -1,0 +1,249 @@
+"""Relational-layer hot path (model.py:104-162 of the reference) as ONE
+torch.autograd.Function over the C-ABI HIP kernels.
+
+forward : K1 pair build -> g_theta GEMM chain (bias+ReLU fused) -> pair sum -> f_phi -> log_softmax
+backward: log_softmax/f_phi grads -> pair-sum broadcast + ReLU gate -> per layer {wgrad, dgrad+gate}
+          -> pair-axis reductions (algebraic dP) -> dx, dq
+
+PyTorch only allocates buffers and supplies the stream; all arithmetic runs in
+librn_hip.so.  There is no CPU / eager fallback."""
+from __future__ import annotations
+
+import torch
+
+from . import rn_hip as H
+
+PRECISIONS = ("bf16", "fp32")
+
+
+def _ru(v, m):
+    return (v + m - 1) // m * m
+
+
+class LayerPlan:
+    """Static shape bookkeeping of the g_theta chain for one (n, k, Q, widths, inject)."""
+
+    def __init__(self, k, Q, widths, inject):
+        self.k, self.Q, self.widths, self.inject = k, Q, list(widths), inject
+        self.L = len(widths)
+        self.ktrue, self.kpad, self.qcol = [], [], []
+        for l, w in enumerate(widths):
+            base = 2 * k if l == 0 else widths[l - 1]
+            kt = base + (Q if l == inject else 0)
+            self.ktrue.append(kt)
+            self.kpad.append(_ru(kt, 64))
+            self.qcol.append(base if l == inject else -1)
+        for w in widths:
+            if w % 256:
+                raise RuntimeError("g_layers widths must be multiples of 256 for the MI355X kernels (got %r)" % (widths,))
+        if Q % 8:
+            raise RuntimeError("lstm_hidden must be a multiple of 8 (got %d)" % Q)
+
+    def in_ld(self, l):
+        """leading dimension of the input buffer of layer l (== kpad[l])."""
+        return self.kpad[l]
+
+
+class PackedWeights:
+    """bf16/fp32 MFMA-operand copies of the g weights: forward (N, Kpad) and, for l >= 1,
+    transposed (G_{l-1}, N) for dgrad.  Re-packed only when a weight's version counter moves."""
+
+    def __init__(self):
+        self.key = None
+        self.fwd, self.bwd = [], []
+
+    def get(self, plan: LayerPlan, g_w, code):
+        key = (code, tuple((w.data_ptr(), w._version) for w in g_w))
+        if key == self.key:
+            return self.fwd, self.bwd
+        dt = H.torch_dtype(code)
+        dev = g_w[0].device
+        self.fwd, self.bwd = [], []
+        for l, w in enumerate(g_w):
+            N, kt = w.shape
+            assert kt == plan.ktrue[l] and N == plan.widths[l], (w.shape, plan.ktrue[l], plan.widths[l])
+            wc = w.detach()
+            if not wc.is_contiguous():
+                wc = wc.contiguous()
+            wp = torch.empty(N, plan.kpad[l], dtype=dt, device=dev)
+            H.pack_matrix(wc, kt, 1, N, kt, wp, code, plan.kpad[l], N)
+            self.fwd.append(wp)
+            if l >= 1:
+                gp = plan.widths[l - 1]           # only the H_{l-1} columns take part in dgrad
+                wt = torch.empty(gp, N, dtype=dt, device=dev)
+                H.pack_matrix(wc, 1, kt, gp, N, wt, code, N, gp)      # wt[k][n] = w[n][k]
+                self.bwd.append(wt)
+            else:
+                self.bwd.append(None)
+        self.key = key
+        return self.fwd, self.bwd
+
+
+def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None):
+    """K1 + K2 chain.  Returns the list of layer INPUT buffers [A_0 .. A_{L-1}] and the last
+    activation H_L.  layer_hook(l, A_l, H_out) is called after every layer (hook-compat path)."""
+    B, n, k = x.shape
+    Q = q.shape[1]
+    M = B * n * n
+    dt = H.torch_dtype(code)
+    dev = x.device
+    inj = plan.inject
+    ld0 = plan.kpad[0]
+    P = torch.empty(M, ld0, dtype=dt, device=dev)
+    H.pair_build_fwd(x, q if inj == 0 else None, P, code, B, n, k, Q if inj == 0 else 0, ld0)
+    inputs = [P]
+    cur = P
+    for l in range(plan.L):
+        N = plan.widths[l]
+        nxt_wide = (l + 1 < plan.L) and (l + 1 == inj)
+        ldh = plan.kpad[l + 1] if nxt_wide else N
+        if nxt_wide and ldh > N + Q:
+            out = torch.zeros(M, ldh, dtype=dt, device=dev)
+        else:
+            out = torch.empty(M, ldh, dtype=dt, device=dev)
+        H.g_linear_fwd(cur, plan.kpad[l], wfwd[l], plan.kpad[l], g_b[l], out, ldh, code, M, N, plan.kpad[l])
+        if nxt_wide:
+            H.qst_broadcast(q, out, code, B, n, Q, N, ldh)
+        if layer_hook is not None:
+            layer_hook(l, cur, out)
+        if l + 1 < plan.L:
+            inputs.append(out)
+        if not keep_inputs and l >= 1:
+            inputs[l] = None
+        cur = out
+    return inputs, cur
+
+
+def f_phi_forward(xg, fw, fb, mask):
+    """f_phi + log_softmax (model.py:155-162): fc1 -> relu -> fc2 -> dropout mask -> relu -> fc3, all fp32
+    on the fp32 MFMA.  Returns (f1, f2, log_probs)."""
+    B, G = xg.shape
+    dev = xg.device
+    F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
+    f1 = torch.empty(B, F1, dtype=torch.float32, device=dev)
+    H.gemm_f32(xg, G, 1, fw[0], 1, G, f1, F1, B, F1, G, bias=fb[0], flags=H.RN_RELU)
+    f2 = torch.empty(B, F2, dtype=torch.float32, device=dev)
+    H.gemm_f32(f1, F1, 1, fw[1], 1, F1, f2, F2, B, F2, F1, bias=fb[1], mul=mask, ldmul=F2, flags=H.RN_RELU)
+    z3 = torch.empty(B, A, dtype=torch.float32, device=dev)
+    H.gemm_f32(f2, F2, 1, fw[2], 1, F2, z3, A, B, A, F2, bias=fb[2])
+    out = torch.empty(B, A, dtype=torch.float32, device=dev)
+    H.log_softmax_fwd(z3, out, B, A)
+    return f1, f2, out
+
+
+class RelationalFunction(torch.autograd.Function):
+    """(x, q, dropout_mask | None, plan, packed, precision, g_w.., g_b.., f_w.., f_b..) -> log-probs (B, A)."""
+
+    @staticmethod
+    def forward(ctx, x, q, mask, plan, packed, precision, *params):
+        L = plan.L
+        g_w, g_b = params[0:L], params[L:2 * L]
+        f_w, f_b = params[2 * L:2 * L + 3], params[2 * L + 3:2 * L + 6]
+        H._dev(x, "x")
+        H._dev(q, "qst")
+        code = H.dtype_code(precision)
+        x = x.float() if x.dtype != torch.float32 else x
+        q = q.float().contiguous() if (q.dtype != torch.float32 or not q.is_contiguous()) else q
+        B, n, k = x.shape
+        Q = q.shape[1]
+        M = B * n * n
+        dev = x.device
+        wfwd, wbwd = packed.get(plan, g_w, code)
+        gb = [b.detach().contiguous() for b in g_b]
+        need_grad = any(ctx.needs_input_grad)
+        inputs, HL = g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad)
+        G = plan.widths[-1]
+        xg = torch.empty(B, G, dtype=torch.float32, device=dev)
+        H.pair_sum_fwd(HL, G, xg, code, B, n * n, G)
+        fw = [w.detach().contiguous() for w in f_w]
+        fb = [b.detach().contiguous() for b in f_b]
+        F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
+        if mask is not None:
+            mask = mask.float().contiguous()
+        f1, f2, out = f_phi_forward(xg, fw, fb, mask)
+        if need_grad:
+            ctx.plan, ctx.code, ctx.dims = plan, code, (B, n, k, Q, M, G, F1, F2, A)
+            ctx.inputs, ctx.HL, ctx.wbwd = inputs, HL, wbwd
+            ctx.g_w = [w.detach() for w in g_w]
+            ctx.fw = fw
+            ctx.mask = mask
+            ctx.save_for_backward(x, q, xg, f1, f2, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        plan, code = ctx.plan, ctx.code
+        B, n, k, Q, M, G, F1, F2, A = ctx.dims
+        x, q, xg, f1, f2, out = ctx.saved_tensors
+        dev = x.device
+        L = plan.L
+        f32 = dict(dtype=torch.float32, device=dev)
+        gout = gout.float().contiguous()
+        fw = ctx.fw
+        # ---- f_phi backward (fp32)
+        dz3 = torch.empty(B, A, **f32)
+        H.log_softmax_bwd(out, gout, dz3, B, A)
+        dW3 = torch.empty(A, F2, **f32); db3 = torch.empty(A, **f32)
+        H.gemm_f32(dz3, 1, A, f2, F2, 1, dW3, F2, A, F2, B)                 # dz3^T @ f2
+        H.colsum_f32(dz3, A, db3, B, A)
+        dz2 = torch.empty(B, F2, **f32)
+        H.gemm_f32(dz3, A, 1, fw[2], F2, 1, dz2, F2, B, F2, A, mul=ctx.mask, ldmul=F2, gate=f2, ldgate=F2)
+        dW2 = torch.empty(F2, F1, **f32); db2 = torch.empty(F2, **f32)
+        H.gemm_f32(dz2, 1, F2, f1, F1, 1, dW2, F1, F2, F1, B)
+        H.colsum_f32(dz2, F2, db2, B, F2)
+        dz1 = torch.empty(B, F1, **f32)
+        H.gemm_f32(dz2, F2, 1, fw[1], F1, 1, dz1, F1, B, F1, F2, gate=f1, ldgate=F1)
+        dW1 = torch.empty(F1, G, **f32); db1 = torch.empty(F1, **f32)
+        H.gemm_f32(dz1, 1, F1, xg, G, 1, dW1, G, F1, G, B)
+        H.colsum_f32(dz1, F1, db1, B, F1)
+        dxg = torch.empty(B, G, **f32)
+        H.gemm_f32(dz1, F1, 1, fw[0], G, 1, dxg, G, B, G, F1)
+        # ---- g_theta backward
+        dt = H.torch_dtype(code)
+        inputs, wbwd, g_w = ctx.inputs, ctx.wbwd, ctx.g_w
+        dZ = torch.empty(M, G, dtype=dt, device=dev)
+        H.pair_sum_bwd(dxg, ctx.HL, G, dZ, G, code, B, n * n, G)
+        ctx.HL = None
+        gW, gB = [None] * L, [None] * L
+        dq = None
+        dx = None
+        for l in reversed(range(L)):
+            N = plan.widths[l]
+            A_l = inputs[l]
+            kt, kp = plan.ktrue[l], plan.kpad[l]
+            gW[l] = torch.empty(N, kt, **f32)
+            gB[l] = torch.empty(N, **f32)
+            H.g_linear_bwd_wgrad(dZ, N, A_l, kp, gW[l], gB[l], code, M, N, kp, kt)
+            wl = g_w[l] if g_w[l].is_contiguous() else g_w[l].contiguous()
+            if l == plan.inject:
+                Rq = torch.empty(B, N, **f32)
+                if l == 0:
+                    Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32)
+                    H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N)
+                else:
+                    H.pair_reduce_bwd(dZ, N, None, None, Rq, code, B, n, N)
+                dq = torch.empty(B, Q, **f32)
+                H.gemm_f32(Rq, N, 1, wl, kt, 1, dq, Q, B, Q, N, b_off=kt - Q)   # Rq @ W[:, -Q:]
+            elif l == 0:
+                Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32)
+                H.pair_reduce_bwd(dZ, N, Rj, Ri, None, code, B, n, N)
+            if l == 0:
+                dx = torch.empty(B, n, k, **f32)
+                H.gemm_f32(Rj, N, 1, wl, kt, 1, dx, k, B * n, k, N)                        # Rj @ W0[:, 0:k]
+                H.gemm_f32(Ri, N, 1, wl, kt, 1, dx, k, B * n, k, N, b_off=k, flags=H.RN_ACCUMULATE)   # + Ri @ W0[:, k:2k]
+            else:
+                gp = plan.widths[l - 1]
+                dZp = torch.empty(M, gp, dtype=dt, device=dev)
+                H.g_linear_bwd_dgrad(dZ, N, wbwd[l], N, A_l, kp, dZp, gp, code, M, N, gp)
+                dZ = dZp
+            inputs[l] = None
+        ctx.inputs = None
+        grads = [dx if ctx.needs_input_grad[0] else None, dq if ctx.needs_input_grad[1] else None, None, None, None, None]
+        grads += gW + gB + [dW1, dW2, dW3, db1, db2, db3]
+        return tuple(grads)
+
+
+def relational_forward(x, q, mask, plan, packed, precision, g_w, g_b, f_w, f_b):
+    if precision not in PRECISIONS:
+        raise ValueError("precision must be one of %r" % (PRECISIONS,))
+    return RelationalFunction.apply(x, q, mask, plan, packed, precision, *g_w, *g_b, *f_w, *f_b)

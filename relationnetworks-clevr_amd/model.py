@@ -1,0 +1,239 @@
+"""Drop-in `model.py` for mesnico/RelationNetworks-CLEVR on AMD MI355X (gfx950).
+
+Same public surface as the reference module (`/root/reference/model.py`):
+class names, constructor / forward signatures, attribute names and state_dict
+keys, so `from model import RN` in a train.py-style
+driver keeps working and both released checkpoints load strictly.  What is
+different is everything under `RelationalLayer.forward`: the repeat / cat /
+Linear / relu / sum op sequence of model.py:104-162 is replaced by hand-written
+HIP kernels reached through the C-ABI library librn_hip.so (functional.py).
+
+The conv stack and the LSTM are ordinary torch.nn modules (MIOpen on ROCm); they
+are ~1 % of the step's flops and outside the hot path.
+
+Deliberate deviations from reference quirks:
+  C1  the coordinate tensor is cached per (batch, grid, device) instead of "first batch
+      size forever" -- a different later batch size works instead of raising.
+  C2  .cuda() returns self (the reference returns None; callers ignore the value).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+try:                                    # imported as part of the package ...
+    from . import functional as RF
+    from . import rn_hip as H
+except ImportError:                     # ... or flat, exactly like the reference: `from model import RN`
+    import importlib.util
+    import sys
+
+    _here = os.path.dirname(os.path.abspath(__file__))
+    _spec = importlib.util.spec_from_file_location("relationnetworks_clevr_amd", os.path.join(_here, "__init__.py"),
+                                                   submodule_search_locations=[_here])
+    _pkg = importlib.util.module_from_spec(_spec)
+    sys.modules.setdefault("relationnetworks_clevr_amd", _pkg)
+    from relationnetworks_clevr_amd import functional as RF          # type: ignore
+    from relationnetworks_clevr_amd import rn_hip as H               # type: ignore
+
+
+class ConvInputModel(nn.Module):
+    """4 x [3x3 stride-2 conv (24 ch) -> BatchNorm -> ReLU]: 128x128 image -> 8x8x24 grid
+    (reference model.py:9-36; parameter names conv1..4 / batchNorm1..4 are part of the
+    checkpoint contract)."""
+
+    def __init__(self):
+        super().__init__()
+        cin = 3
+        for i in range(1, 5):
+            self.add_module("conv%d" % i, nn.Conv2d(cin, 24, 3, stride=2, padding=1))
+            self.add_module("batchNorm%d" % i, nn.BatchNorm2d(24))
+            cin = 24
+
+    def forward(self, img):
+        x = img
+        for i in range(1, 5):
+            x = F.relu(self._modules["batchNorm%d" % i](self._modules["conv%d" % i](x)))
+        return x
+
+
+class QuestionEmbedModel(nn.Module):
+    """Embedding(in_size+1, embed) -> 1-layer LSTM(batch_first) -> final hidden state (B, hidden)
+    (reference model.py:39-58)."""
+
+    def __init__(self, in_size, embed=32, hidden=128):
+        super().__init__()
+        self.wembedding = nn.Embedding(in_size + 1, embed)
+        self.lstm = nn.LSTM(embed, hidden, batch_first=True)
+        self.hidden = hidden
+
+    def forward(self, question):
+        _, (h_n, _c_n) = self.lstm(self.wembedding(question))
+        return h_n[0]
+
+
+class RelationalLayerBase(nn.Module):
+    """Owns f_phi (f_fc1/2/3 + dropout) -- reference model.py:60-78."""
+
+    def __init__(self, in_size, out_size, qst_size, hyp):
+        super().__init__()
+        self.f_fc1 = nn.Linear(hyp["g_layers"][-1], hyp["f_fc1"])
+        self.f_fc2 = nn.Linear(hyp["f_fc1"], hyp["f_fc2"])
+        self.f_fc3 = nn.Linear(hyp["f_fc2"], out_size)
+        self.dropout = nn.Dropout(p=hyp["dropout"])
+        self.on_gpu = False
+        self.hyp = hyp
+        self.qst_size = qst_size
+        self.in_size = in_size
+        self.out_size = out_size
+
+    def cuda(self, device=None):
+        self.on_gpu = True
+        return super().cuda(device)
+
+
+class RelationalLayer(RelationalLayerBase):
+    """g_theta over all n^2 object pairs -> sum -> f_phi (reference model.py:81-162), on HIP kernels.
+
+    `g_layers` stays an indexable nn.ModuleList of nn.Linear (the checkpoint keys
+    rl.g_layers.{i}.{weight,bias} and extract.py's forward hooks depend on it); the Linear
+    modules only hold the parameters -- their own forward is never used on the hot path."""
+
+    def __init__(self, in_size, out_size, qst_size, hyp, extraction=False):
+        super().__init__(in_size, out_size, qst_size, hyp)
+        self.quest_inject_position = hyp["question_injection_position"]
+        self.in_size = in_size
+        self.g_layers_size = hyp["g_layers"]
+        layers = []
+        for idx, width in enumerate(self.g_layers_size):
+            fan_in = in_size if idx == 0 else self.g_layers_size[idx - 1]
+            if idx == self.quest_inject_position:
+                fan_in += qst_size                       # the "h" layer that also sees the question
+            layers.append(nn.Linear(fan_in, width))
+        self.g_layers = nn.ModuleList(layers)
+        self.extraction = extraction
+        # MI355X execution options
+        self.precision = hyp.get("precision", os.environ.get("RN_PRECISION", "bf16"))
+        self.forced_dropout_mask = None                  # tests: explicit (B, f_fc2) mask incl. 1/(1-p)
+        self._packed = RF.PackedWeights()
+        self._plan_cache = {}
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _plan(self, k):
+        key = (k, self.qst_size)
+        if key not in self._plan_cache:
+            if 2 * k != self.in_size:
+                raise RuntimeError("object size %d does not match rl_in_size %d" % (k, self.in_size))
+            self._plan_cache[key] = RF.LayerPlan(k, self.qst_size, self.g_layers_size, self.quest_inject_position)
+        return self._plan_cache[key]
+
+    def _dropout_mask(self, b, device):
+        if self.forced_dropout_mask is not None:
+            return self.forced_dropout_mask.to(device=device, dtype=torch.float32)
+        if self.training and self.dropout.p > 0:
+            # same RNG consumption as the reference's self.dropout(x_f) on a (B, f_fc2) tensor
+            return self.dropout(torch.ones(b, self.f_fc2.out_features, device=device))
+        return None
+
+    def _hooked(self):
+        return self.extraction or any(len(l._forward_hooks) for l in self.g_layers)
+
+    def forward(self, x, qst):
+        b, d, k = x.size()
+        plan = self._plan(k)
+        if self._hooked():
+            return self._forward_hook_compat(x, qst, plan)
+        g_w = [l.weight for l in self.g_layers]
+        g_b = [l.bias for l in self.g_layers]
+        f_w = [self.f_fc1.weight, self.f_fc2.weight, self.f_fc3.weight]
+        f_b = [self.f_fc1.bias, self.f_fc2.bias, self.f_fc3.bias]
+        mask = self._dropout_mask(b, x.device)
+        return RF.relational_forward(x, qst, mask, plan, self._packed, self.precision, g_w, g_b, f_w, f_b)
+
+    @torch.no_grad()
+    def _forward_hook_compat(self, x, qst, plan):
+        """extract.py registers forward hooks on g_layers[k] and reads the layer *input*
+        (B*n*n, in) (extract.py:43,64-68).  When hooks (or extraction=True) are present the
+        chain runs layer by layer on the same HIP kernels and each hooked layer's materialised
+        input / output is handed to its hooks as fp32 tensors; inference only."""
+        code = H.dtype_code(self.precision)
+        H._dev(x, "x")
+        x = x.float()
+        q = qst.float().contiguous()
+        wfwd, _ = self._packed.get(plan, [l.weight for l in self.g_layers], code)
+        gb = [l.bias.detach().contiguous() for l in self.g_layers]
+
+        def layer_hook(l, a_in, h_out):
+            layer = self.g_layers[l]
+            if len(layer._forward_hooks):
+                inp = a_in[:, : plan.ktrue[l]].float()
+                outp = h_out[:, : plan.widths[l]].float()      # note: post-ReLU (bias+ReLU are fused)
+                for hook in list(layer._forward_hooks.values()):
+                    hook(layer, (inp,), outp)
+
+        _inputs, HL = RF.g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=False, layer_hook=layer_hook)
+        if self.extraction:
+            return None                                        # reference model.py:147-148
+        B = x.shape[0]
+        G = plan.widths[-1]
+        xg = torch.empty(B, G, dtype=torch.float32, device=x.device)
+        H.pair_sum_fwd(HL, G, xg, code, B, x.shape[1] ** 2, G)
+        fw = [m.weight.detach().contiguous() for m in (self.f_fc1, self.f_fc2, self.f_fc3)]
+        fb = [m.bias.detach().contiguous() for m in (self.f_fc1, self.f_fc2, self.f_fc3)]
+        mask = self._dropout_mask(B, x.device)
+        return RF.f_phi_forward(xg, fw, fb, mask)[2]
+
+
+class RN(nn.Module):
+    """conv grid / state description -> objects with coordinate tags -> LSTM question ->
+    relational layer (reference model.py:164-223)."""
+
+    def __init__(self, args, hyp, extraction=False):
+        super().__init__()
+        self.coord_tensor = None
+        self._coord_key = None
+        self.on_gpu = False
+        self.conv = ConvInputModel()
+        self.state_desc = hyp["state_description"]
+        hidden_size = hyp["lstm_hidden"]
+        self.text = QuestionEmbedModel(args.qdict_size, embed=hyp["lstm_word_emb"], hidden=hidden_size)
+        self.rl_in_size = hyp["rl_in_size"]
+        self.rl_out_size = args.adict_size
+        self.rl = RelationalLayer(self.rl_in_size, self.rl_out_size, hidden_size, hyp, extraction)
+        print("Supposing IR model" if hyp["question_injection_position"] != 0 else "Supposing original DeepMind model")
+
+    def build_coord_tensor(self, b, d, device=None):
+        """(B, 2, d, d): channel 0 = x = lin[col], channel 1 = y = lin[row], lin = linspace(-d/2, d/2, d)
+        computed on the CPU exactly as the reference does (model.py:208-218) and then moved."""
+        lin = torch.linspace(-d / 2.0, d / 2.0, d)
+        ct = torch.stack((lin.unsqueeze(0).expand(d, d), lin.unsqueeze(1).expand(d, d)))
+        ct = ct.unsqueeze(0).expand(b, 2, d, d).contiguous()
+        if device is not None:
+            ct = ct.to(device)
+        elif self.on_gpu:
+            ct = ct.cuda()
+        self.coord_tensor = ct
+        return ct
+
+    def forward(self, img, qst_idxs):
+        if self.state_desc:
+            x = img                                             # (B, 12, 7) state descriptions
+        else:
+            x = self.conv(img)                                  # (B, 24, d, d)
+            b, k, d, _ = x.size()
+            key = (b, d, x.device)
+            if self.coord_tensor is None or self._coord_key != key:
+                self.build_coord_tensor(b, d, x.device)
+                self.coord_tensor = self.coord_tensor.view(b, 2, d * d)
+                self._coord_key = key
+            x = torch.cat([x.view(b, k, d * d), self.coord_tensor], 1).permute(0, 2, 1)   # (B, d*d, 26) strided view
+        qst = self.text(qst_idxs)
+        return self.rl(x, qst)
+
+    def cuda(self, device=None):
+        self.on_gpu = True
+        self.rl.on_gpu = True
+        return super().cuda(device)

@@ -1,0 +1,221 @@
+"""ctypes binding of the C-ABI HIP library (include/rn_hip.h).
+
+Thin by design: torch tensors only supply device pointers, strides and the
+current HIP stream; every call is a plain `extern "C"` entry point.  Nothing
+here falls back to PyTorch or the CPU: if librn_hip.so is missing or a call
+fails, a RuntimeError is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librn_hip.so")
+RN_BF16, RN_F32 = 0, 1
+RN_RELU, RN_ACCUMULATE = 1, 2
+ABI_VERSION = 1
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/rn_hip.h one to one
+_P, _I, _L, _Z = C.c_void_p, C.c_int, C.c_long, C.c_size_t
+SIGNATURES = {
+    "rn_abi_version": (_I, []),
+    "rn_last_error": (C.c_char_p, []),
+    "rn_pair_build_fwd": (_I, [_P, _L, _L, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "rn_qst_broadcast": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "rn_pack_matrix": (_I, [_P, _L, _L, _I, _I, _P, _I, _I, _I, _P]),
+    "rn_g_linear_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_pair_sum_ws_bytes": (_Z, [_I, _I, _I]),
+    "rn_pair_sum_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_pair_sum_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_g_linear_bwd_dgrad": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_wgrad_ws_bytes": (_Z, [_I, _I, _I]),
+    "rn_g_linear_bwd_wgrad": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_pair_reduce_ws_bytes": (_Z, [_I, _I, _I]),
+    "rn_pair_reduce_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_gemm_f32": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _P, _L, _P, _L, _I, _P]),
+    "rn_log_softmax_fwd": (_I, [_P, _P, _I, _I, _P]),
+    "rn_log_softmax_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
+    "rn_colsum_f32": (_I, [_P, _L, _P, _I, _I, _P]),
+    "rn_probe_tr16": (_I, [_P, _P, _P]),
+}
+
+
+def load(path: str | None = None):
+    """dlopen librn_hip.so and attach the prototypes.  Raises loudly if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            "HIP extension %s not found: build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % p)
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype, fn.argtypes = res, args
+    v = lib.rn_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError("librn_hip.so ABI version %d != expected %d" % (v, ABI_VERSION))
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int, name: str):
+    if rc != 0:
+        msg = load().rn_last_error()
+        raise RuntimeError("%s failed (rc=%d): %s" % (name, rc, msg.decode() if msg else "?"))
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def dtype_code(precision: str) -> int:
+    return {"bf16": RN_BF16, "fp32": RN_F32}[precision]
+
+
+def torch_dtype(code: int):
+    return torch.bfloat16 if code == RN_BF16 else torch.float32
+
+
+def _dev(t, name):
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (cuda:N = HIP device); got %s. The MI355X path has no CPU fallback."
+                           % (name, t.device))
+
+
+# ------------------------------------------------------------------ live kernel timing (bench.py)
+class KernelTimer:
+    """HIP-event brackets around selected entry points, recorded on the stream the kernels are
+    launched on (torch's current stream).  Enabled only by bench.py; `summary()` synchronises."""
+
+    def __init__(self):
+        self.enabled = False
+        self.pairs = {}
+
+    def reset(self):
+        self.pairs = {}
+
+    def start(self, name):
+        if not self.enabled:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.pairs.setdefault(name, []).append((e0, e1))
+        return e1
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.pairs.items()}   # (launches, total ms)
+
+
+TIMER = KernelTimer()
+
+
+def _timed(name):
+    def deco(fn):
+        def wrapper(*a, **kw):
+            e1 = TIMER.start(name)
+            r = fn(*a, **kw)
+            if e1 is not None:
+                e1.record()
+            return r
+        wrapper.__name__ = fn.__name__
+        return wrapper
+    return deco
+
+
+# ------------------------------------------------------------------ wrappers
+@_timed("pair_build")
+def pair_build_fwd(x, q, P, code, B, n, k, Q, ld):
+    _dev(x, "x")
+    sx = x.stride()
+    _check(load().rn_pair_build_fwd(x.data_ptr(), sx[0], sx[1], sx[2], _ptr(q), q.stride(0) if q is not None else 0,
+                                    P.data_ptr(), code, B, n, k, Q, ld, _stream()), "rn_pair_build_fwd")
+
+
+def qst_broadcast(q, A, code, B, n, Q, col0, ld):
+    _check(load().rn_qst_broadcast(q.data_ptr(), q.stride(0), A.data_ptr(), code, B, n, Q, col0, ld, _stream()),
+           "rn_qst_broadcast")
+
+
+def pack_matrix(src, sr, sc, R, Cc, dst, code, ld, Rpad, src_offset=0):
+    _check(load().rn_pack_matrix(src.data_ptr() + 4 * src_offset, sr, sc, R, Cc, dst.data_ptr(), code, ld, Rpad, _stream()),
+           "rn_pack_matrix")
+
+
+@_timed("g_fwd")
+def g_linear_fwd(A, lda, Wp, ldw, bias, H, ldh, code, M, N, K, h_offset_elems=0):
+    esz = 2 if code == RN_BF16 else 4
+    _check(load().rn_g_linear_fwd(A.data_ptr(), lda, Wp.data_ptr(), ldw, bias.data_ptr(), H.data_ptr() + esz * h_offset_elems,
+                                  ldh, code, M, N, K, _stream()), "rn_g_linear_fwd")
+
+
+@_timed("pair_sum")
+def pair_sum_fwd(HL, ldh, xg, code, B, npairs, G):
+    lib = load()
+    nb = lib.rn_pair_sum_ws_bytes(B, npairs, G)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=xg.device)
+    _check(lib.rn_pair_sum_fwd(HL.data_ptr(), ldh, xg.data_ptr(), ws.data_ptr(), code, B, npairs, G, _stream()), "rn_pair_sum_fwd")
+
+
+@_timed("pair_sum_bwd")
+def pair_sum_bwd(dxg, HL, ldh, dZ, lddz, code, B, npairs, G):
+    _check(load().rn_pair_sum_bwd(dxg.data_ptr(), HL.data_ptr(), ldh, dZ.data_ptr(), lddz, code, B, npairs, G, _stream()),
+           "rn_pair_sum_bwd")
+
+
+@_timed("g_dgrad")
+def g_linear_bwd_dgrad(dZ, lddz, Wt, ldwt, Hprev, ldhp, dZprev, lddzp, code, M, N, Kin):
+    _check(load().rn_g_linear_bwd_dgrad(dZ.data_ptr(), lddz, Wt.data_ptr(), ldwt, Hprev.data_ptr(), ldhp, dZprev.data_ptr(),
+                                        lddzp, code, M, N, Kin, _stream()), "rn_g_linear_bwd_dgrad")
+
+
+@_timed("g_wgrad")
+def g_linear_bwd_wgrad(dZ, lddz, A, lda, dW, db, code, M, N, K, Ktrue):
+    lib = load()
+    nb = lib.rn_wgrad_ws_bytes(M, N, K)
+    if nb == 0:
+        raise RuntimeError("rn_wgrad_ws_bytes: unsupported shape M=%d N=%d K=%d" % (M, N, K))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dW.device)
+    _check(lib.rn_g_linear_bwd_wgrad(dZ.data_ptr(), lddz, A.data_ptr(), lda, dW.data_ptr(), _ptr(db), ws.data_ptr(), code,
+                                     M, N, K, Ktrue, _stream()), "rn_g_linear_bwd_wgrad")
+
+
+@_timed("pair_reduce")
+def pair_reduce_bwd(dZ, lddz, Rj, Ri, Rq, code, B, n, G):
+    lib = load()
+    ws = torch.empty(max(lib.rn_pair_reduce_ws_bytes(B, n, G), 16), dtype=torch.uint8, device=dZ.device)
+    _check(lib.rn_pair_reduce_bwd(dZ.data_ptr(), lddz, _ptr(Rj), _ptr(Ri), _ptr(Rq), ws.data_ptr(), code, B, n, G, _stream()),
+           "rn_pair_reduce_bwd")
+
+
+def gemm_f32(A, sam, sak, Bm, sbk, sbn, Cm, ldc, M, N, K, bias=None, mul=None, ldmul=0, gate=None, ldgate=0, flags=0,
+             a_off=0, b_off=0, c_off=0):
+    """C[m,n] (+)= epi(sum_k A[a_off + m*sam + k*sak] * B[b_off + k*sbk + n*sbn]); offsets in elements."""
+    _check(load().rn_gemm_f32(A.data_ptr() + 4 * a_off, sam, sak, Bm.data_ptr() + 4 * b_off, sbk, sbn,
+                              Cm.data_ptr() + 4 * c_off, ldc, M, N, K, _ptr(bias), _ptr(mul), ldmul, _ptr(gate), ldgate,
+                              flags, _stream()), "rn_gemm_f32")
+
+
+def log_softmax_fwd(z, out, B, A):
+    _check(load().rn_log_softmax_fwd(z.data_ptr(), out.data_ptr(), B, A, _stream()), "rn_log_softmax_fwd")
+
+
+def log_softmax_bwd(out, gout, dz, B, A):
+    _check(load().rn_log_softmax_bwd(out.data_ptr(), gout.data_ptr(), dz.data_ptr(), B, A, _stream()), "rn_log_softmax_bwd")
+
+
+def colsum_f32(src, ld, out, R, Cc):
+    _check(load().rn_colsum_f32(src.data_ptr(), ld, out.data_ptr(), R, Cc, _stream()), "rn_colsum_f32")

@@ -1,0 +1,290 @@
+"""GPU: every HIP kernel against the CPU oracle, called through the C-ABI (ctypes) wrappers.
+
+Tolerances (written here, per ③ of the build contract):
+  * pure data movement (pair build, question broadcast, pack, pair-sum backward): bit-exact
+    against the oracle rounded to the storage dtype (RNE);
+  * fp32 storage / fp32 MFMA: <= 2e-5 max-norm relative (summation-order noise only);
+  * bf16 storage / bf16 MFMA: compared with an oracle evaluated on the SAME bf16-rounded
+    operands, so only accumulation order and the final RNE differ: <= 1 bf16 ulp (2^-7 rel).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import formula, rn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BF16_ULP = 2.0 ** -7
+F32_TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def H():
+    import relationnetworks_clevr_amd as pkg
+    pkg.rn_hip.load()
+    torch.cuda.set_device(0)
+    return pkg.rn_hip
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).bfloat16().float().numpy()
+
+
+def tdt(code):
+    return torch.bfloat16 if code == 0 else torch.float32
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# ----------------------------------------------------------------------------- probe
+def test_probe_tr16_mapping(H):
+    """ds_read_b64_tr_b16 on a linear image (lane l supplies &lds[4l]): within each 16-lane block,
+    lane i receives column i of the 4x16 block formed by the 16 lanes' 8-byte pieces."""
+    src = np.arange(4096, dtype=np.uint16)
+    out = torch.zeros(256, dtype=torch.int16, device="cuda")
+    rc = H.load().rn_probe_tr16(dev(src.view(np.int16)).data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint16).reshape(64, 4)
+    exp = np.zeros((64, 4), dtype=np.uint16)
+    for lane in range(64):
+        blk, i = lane // 16, lane % 16
+        for j in range(4):       # row j of the block, column i; linear image: block blk = elements 64*blk..+64, row stride 16
+            exp[lane, j] = 64 * blk + 16 * j + i
+    print("tr16 lanes 0..3:", got[:4].tolist(), "lane 17:", got[17].tolist())
+    assert np.array_equal(got, exp), got[:20]
+
+
+# ----------------------------------------------------------------------------- K1
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("B,n,k,Q,strided", [(3, 64, 26, 128, True), (3, 64, 26, 0, False), (4, 12, 7, 256, False),
+                                            (2, 196, 26, 128, True), (1, 5, 3, 8, False)])
+def test_pair_build_exact(H, code, B, n, k, Q, strided):
+    x = formula.hash_uniform((B, n, k), 7, -2, 2)
+    q = formula.hash_uniform((B, max(Q, 1)), 8, -1, 1)
+    ld = (2 * k + Q + 63) // 64 * 64
+    if strided:      # physical (B,k,n) viewed as (B,n,k), like RN.forward's permute (model.py:200-201)
+        xt = dev(x.transpose(0, 2, 1)).permute(0, 2, 1)
+        assert not xt.is_contiguous()
+    else:
+        xt = dev(x)
+    P = torch.full((B * n * n, ld), 7.0, dtype=tdt(code), device="cuda")
+    H.pair_build_fwd(xt, dev(q) if Q else None, P, code, B, n, k, Q, ld)
+    torch.cuda.synchronize()
+    ref = np.zeros((B * n * n, ld), np.float32)
+    ref[:, : 2 * k + Q] = O.pair_matrix(x, q[:, :Q] if Q else None)
+    if code == 0:
+        ref = bf16_round(ref)
+    assert np.array_equal(P.float().cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("code", [0, 1])
+def test_qst_broadcast_exact(H, code):
+    B, n, Q, col0, ld = 3, 12, 128, 256, 384
+    q = formula.hash_uniform((B, Q), 9)
+    A = torch.zeros(B * n * n, ld, dtype=tdt(code), device="cuda")
+    H.qst_broadcast(dev(q), A, code, B, n, Q, col0, ld)
+    ref = np.zeros((B * n * n, ld), np.float32)
+    ref[:, col0:col0 + Q] = np.repeat(q, n * n, axis=0)
+    if code == 0:
+        ref = bf16_round(ref)
+    assert np.array_equal(A.float().cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("code", [0, 1])
+def test_pack_matrix(H, code):
+    N, K, ld = 256, 180, 192
+    w = formula.hash_uniform((N, K), 10)
+    wp = torch.empty(N, ld, dtype=tdt(code), device="cuda")
+    H.pack_matrix(dev(w), K, 1, N, K, wp, code, ld, N)
+    ref = np.zeros((N, ld), np.float32); ref[:, :K] = w
+    wt = torch.empty(128, N, dtype=tdt(code), device="cuda")        # transposed, first 128 input columns
+    H.pack_matrix(dev(w), 1, K, 128, N, wt, code, N, 128)
+    reft = w[:, :128].T.copy()
+    if code == 0:
+        ref, reft = bf16_round(ref), bf16_round(reft)
+    assert np.array_equal(wp.float().cpu().numpy(), ref)
+    assert np.array_equal(wt.float().cpu().numpy(), reft)
+
+
+# ----------------------------------------------------------------------------- K2 + dgrad
+def _gemm_case(M, N, K, Ktrue, seed):
+    A = np.zeros((M, K), np.float32); A[:, :Ktrue] = formula.hash_uniform((M, Ktrue), seed, -1, 1)
+    W = np.zeros((N, K), np.float32); W[:, :Ktrue] = formula.hash_uniform((N, Ktrue), seed + 1, -0.2, 0.2)
+    b = formula.hash_uniform((N,), seed + 2, -0.5, 0.5)
+    return A, W, b
+
+
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("M,N,K,Ktrue", [(128, 256, 192, 180), (576, 512, 320, 270), (1000, 256, 256, 256), (4096, 256, 64, 52)])
+def test_g_linear_fwd(H, code, M, N, K, Ktrue):
+    A, W, b = _gemm_case(M, N, K, Ktrue, 20)
+    if code == 0:
+        A, W = bf16_round(A), bf16_round(W)
+    ref = np.maximum(A.astype(np.float64) @ W.astype(np.float64).T + b, 0)
+    out = torch.full((M, N), -3.0, dtype=tdt(code), device="cuda")
+    H.g_linear_fwd(dev(A).to(tdt(code)), K, dev(W).to(tdt(code)), K, dev(b), out, N, code, M, N, K)
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    tol = BF16_ULP if code == 0 else F32_TOL
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
+    assert err.max() <= tol, (err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
+@pytest.mark.parametrize("code", [0, 1])
+def test_g_linear_fwd_wide_output(H, code):
+    """layer output written into a wider buffer (ld 384) ahead of an injected question (ir-fp)."""
+    M, N, K = 256, 256, 256
+    A, W, b = _gemm_case(M, N, K, K, 30)
+    if code == 0:
+        A, W = bf16_round(A), bf16_round(W)
+    buf = torch.full((M, 384), 5.0, dtype=tdt(code), device="cuda")
+    H.g_linear_fwd(dev(A).to(tdt(code)), K, dev(W).to(tdt(code)), K, dev(b), buf, 384, code, M, N, K)
+    got = buf.float().cpu().numpy()
+    ref = np.maximum(A.astype(np.float64) @ W.astype(np.float64).T + b, 0)
+    assert rel(got[:, :N], ref) <= (BF16_ULP if code == 0 else F32_TOL)
+    assert np.all(got[:, N:] == 5.0)
+
+
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("M,N,Kin", [(384, 256, 256), (700, 512, 512)])
+def test_g_linear_bwd_dgrad(H, code, M, N, Kin):
+    dZ = formula.hash_uniform((M, N), 40, -1, 1)
+    W = formula.hash_uniform((N, Kin), 41, -0.2, 0.2)               # nn.Linear (out=N, in=Kin)
+    Hp = np.maximum(formula.hash_uniform((M, Kin), 42, -1, 1), 0)
+    if code == 0:
+        dZ, W, Hp = bf16_round(dZ), bf16_round(W), bf16_round(Hp)
+    ref = (dZ.astype(np.float64) @ W.astype(np.float64)) * (Hp > 0)
+    Wt = np.ascontiguousarray(W.T)                                  # (Kin, N)
+    out = torch.empty(M, Kin, dtype=tdt(code), device="cuda")
+    H.g_linear_bwd_dgrad(dev(dZ).to(tdt(code)), N, dev(Wt).to(tdt(code)), N, dev(Hp).to(tdt(code)), Kin, out, Kin, code, M, N, Kin)
+    got = out.float().cpu().numpy()
+    tol = BF16_ULP if code == 0 else F32_TOL
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
+    assert err.max() <= tol, err.max()
+    assert np.all(got[Hp <= 0] == 0)
+
+
+# ----------------------------------------------------------------------------- K3
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("B,npairs,G", [(4, 4096, 256), (3, 144, 512), (2, 38416, 256)])
+def test_pair_sum_fwd_bwd(H, code, B, npairs, G):
+    Hl = np.maximum(formula.hash_uniform((B * npairs, G), 50, -1, 1), 0)
+    if code == 0:
+        Hl = bf16_round(Hl)
+    xg = torch.empty(B, G, dtype=torch.float32, device="cuda")
+    Hd = dev(Hl).to(tdt(code))
+    H.pair_sum_fwd(Hd, G, xg, code, B, npairs, G)
+    ref = Hl.reshape(B, npairs, G).sum(1, dtype=np.float64)
+    assert rel(xg.cpu().numpy(), ref) <= F32_TOL
+    dxg = formula.hash_uniform((B, G), 51)
+    dZ = torch.empty(B * npairs, G, dtype=tdt(code), device="cuda")
+    H.pair_sum_bwd(dev(dxg), Hd, G, dZ, G, code, B, npairs, G)
+    refz = np.repeat(dxg, npairs, axis=0) * (Hl > 0)
+    if code == 0:
+        refz = bf16_round(refz)
+    assert np.array_equal(dZ.float().cpu().numpy(), refz)
+
+
+# ----------------------------------------------------------------------------- wgrad
+@pytest.mark.parametrize("no_tr", ["0", "1"])
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("M,N,K,Ktrue", [(4096, 256, 192, 180), (576, 512, 320, 270), (5000, 256, 384, 384), (2048, 256, 64, 52)])
+def test_g_linear_bwd_wgrad(H, code, M, N, K, Ktrue, no_tr):
+    if code == 1 and no_tr == "1":
+        pytest.skip("fp32 path has no transpose read")
+    os.environ["RN_WGRAD_NO_TR"] = no_tr
+    try:
+        dZ = formula.hash_uniform((M, N), 60, -1, 1)
+        A = np.zeros((M, K), np.float32); A[:, :Ktrue] = formula.hash_uniform((M, Ktrue), 61, -1, 1)
+        if code == 0:
+            dZ, A = bf16_round(dZ), bf16_round(A)
+        dW = torch.full((N, Ktrue), 9.0, dtype=torch.float32, device="cuda")
+        db = torch.full((N,), 9.0, dtype=torch.float32, device="cuda")
+        H.g_linear_bwd_wgrad(dev(dZ).to(tdt(code)), N, dev(A).to(tdt(code)), K, dW, db, code, M, N, K, Ktrue)
+        torch.cuda.synchronize()
+        refW = dZ.astype(np.float64).T @ A[:, :Ktrue].astype(np.float64)
+        refb = dZ.sum(0, dtype=np.float64)
+        eW, eb = rel(dW.cpu().numpy(), refW), rel(db.cpu().numpy(), refb)
+        assert eW <= F32_TOL * 5 and eb <= F32_TOL * 5, (eW, eb)
+        # determinism: a second call gives bit-identical results
+        dW2 = torch.empty_like(dW); db2 = torch.empty_like(db)
+        H.g_linear_bwd_wgrad(dev(dZ).to(tdt(code)), N, dev(A).to(tdt(code)), K, dW2, db2, code, M, N, K, Ktrue)
+        assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    finally:
+        os.environ.pop("RN_WGRAD_NO_TR", None)
+
+
+# ----------------------------------------------------------------------------- pair reduce
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("B,n,G", [(3, 64, 256), (2, 12, 512), (1, 196, 256)])
+def test_pair_reduce_bwd(H, code, B, n, G):
+    dZ = formula.hash_uniform((B * n * n, G), 70, -1, 1)
+    if code == 0:
+        dZ = bf16_round(dZ)
+    Rj = torch.empty(B * n, G, dtype=torch.float32, device="cuda")
+    Ri = torch.empty_like(Rj); Rq = torch.empty(B, G, dtype=torch.float32, device="cuda")
+    H.pair_reduce_bwd(dev(dZ).to(tdt(code)), G, Rj, Ri, Rq, code, B, n, G)
+    d4 = dZ.reshape(B, n, n, G).astype(np.float64)
+    assert rel(Rj.cpu().numpy().reshape(B, n, G), d4.sum(1)) <= F32_TOL
+    assert rel(Ri.cpu().numpy().reshape(B, n, G), d4.sum(2)) <= F32_TOL
+    assert rel(Rq.cpu().numpy(), d4.sum((1, 2))) <= F32_TOL
+    Rq2 = torch.empty_like(Rq)
+    H.pair_reduce_bwd(dev(dZ).to(tdt(code)), G, None, None, Rq2, code, B, n, G)
+    assert torch.equal(Rq, Rq2)
+
+
+# ----------------------------------------------------------------------------- K4 small fp32
+def test_gemm_f32_variants(H):
+    B, K, N = 37, 250, 70
+    a = formula.hash_uniform((B, K), 80); w = formula.hash_uniform((N, K), 81); bias = formula.hash_uniform((N,), 82)
+    mul = formula.hash_uniform((B, N), 83, 0, 2); gate = formula.hash_uniform((B, N), 84)
+    c = torch.empty(B, N, dtype=torch.float32, device="cuda")
+    H.gemm_f32(dev(a), K, 1, dev(w), 1, K, c, N, B, N, K, bias=dev(bias), mul=dev(mul), ldmul=N, gate=dev(gate), ldgate=N, flags=H.RN_RELU)
+    ref = np.maximum((a.astype(np.float64) @ w.T + bias) * mul, 0) * (gate > 0)
+    assert rel(c.cpu().numpy(), ref) <= F32_TOL
+    # transposed-A form (weight gradients) + accumulate
+    g = formula.hash_uniform((B, N), 85)
+    dw = torch.ones(N, K, dtype=torch.float32, device="cuda")
+    H.gemm_f32(dev(g), 1, N, dev(a), K, 1, dw, K, N, K, B, flags=H.RN_ACCUMULATE)
+    assert rel(dw.cpu().numpy(), g.astype(np.float64).T @ a + 1.0) <= F32_TOL
+    # column-offset B operand (W[:, off:off+n])
+    out = torch.empty(B, 20, dtype=torch.float32, device="cuda")
+    H.gemm_f32(dev(g), N, 1, dev(w), K, 1, out, 20, B, 20, N, b_off=30)
+    assert rel(out.cpu().numpy(), g.astype(np.float64) @ w[:, 30:50]) <= F32_TOL
+
+
+def test_log_softmax_and_colsum(H):
+    B, A = 67, 28
+    z = formula.hash_uniform((B, A), 90, -30, 30)
+    out = torch.empty(B, A, dtype=torch.float32, device="cuda")
+    H.log_softmax_fwd(dev(z), out, B, A)
+    ref = O.log_softmax_np(z)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-5
+    g = formula.hash_uniform((B, A), 91)
+    dz = torch.empty_like(out)
+    H.log_softmax_bwd(out, dev(g), dz, B, A)
+    refd = g - np.exp(ref.astype(np.float64)) * g.sum(1, keepdims=True)
+    assert rel(dz.cpu().numpy(), refd) <= F32_TOL
+    cs = torch.empty(A, dtype=torch.float32, device="cuda")
+    H.colsum_f32(dev(g), A, cs, B, A)
+    assert rel(cs.cpu().numpy(), g.sum(0, dtype=np.float64)) <= F32_TOL
+
+
+def test_argument_errors_are_loud(H):
+    P = torch.empty(16, 100, dtype=torch.bfloat16, device="cuda")
+    x = torch.zeros(1, 4, 3, device="cuda")
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        H.pair_build_fwd(x, None, P, 0, 1, 4, 3, 0, 100)
+    with pytest.raises(RuntimeError, match="GPU"):
+        H.pair_build_fwd(x.cpu(), None, P, 0, 1, 4, 3, 0, 128)
