@@ -161,7 +161,7 @@ def main():
                                    "synthetic %dx%d images + 20-token questions, random-init weights"
                                    % (args.config, B, d, d, n, M, args.hw, args.hw),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
-            "loss": float(loss),
+            "loss": float(loss.detach()),
         }
         if ksum:
             g_ms = sum(ksum.get(kk, (0, 0.0))[1] for kk in ("g_fwd", "g_dgrad", "g_wgrad")) / args.steps

@@ -1,0 +1,99 @@
+"""CPU, world_size 2 over gloo: the data-parallel host logic (flat gradient bucket, all-reduce
+mean, clip, optimizer) gives the same parameters as one process on the concatenated batch
+(SURVEY.md section 4 (iv) / 8e).  The model here is the oracle's CPU module -- the DP layer is
+model-agnostic; the HIP path itself is exercised by the -m gpu tests."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import formula, rn_oracle as O
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _make(seed=3):
+    torch.manual_seed(seed)
+    hyp = dict(formula.HYP["original-sd"], dropout=0.0)
+    return O.RNOracle(formula.QDICT, formula.ADICT, hyp)
+
+
+def _data(B=4):
+    x = torch.from_numpy(formula.formula_objects(B, 12, 7, 5, from_pixels=False))
+    q = torch.from_numpy(formula.hash_ints((B, 9), 6, 1, formula.QDICT + 1))
+    y = torch.from_numpy(formula.hash_ints((B,), 7, 0, formula.ADICT))
+    return x, q, y
+
+
+def _worker(rank, world, port, steps, out_path):
+    import relationnetworks_clevr_amd as pkg
+    from relationnetworks_clevr_amd import dp
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = _make(seed=3 + rank)          # different init per rank: broadcast must fix it
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)   # (Adam turns 1e-9 round-off on zero-gradient weights into +-lr steps)
+    tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0)
+    x, q, y = _data()
+    sh = x.shape[0] // world
+    sl = slice(rank * sh, (rank + 1) * sh)
+    losses = []
+    for _ in range(steps):
+        losses.append(float(tr.step(x[sl], q[sl], y[sl]).detach()))
+        tr.bucket.check_attached()
+    lt = torch.tensor(losses, dtype=torch.float64)
+    dist.all_reduce(lt)                    # mean of the shard losses == global-batch mean loss
+    if rank == 0:
+        torch.save({"sd": model.state_dict(), "loss": (lt / world).tolist()}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_dp_equals_single_process(tmp_path):
+    from relationnetworks_clevr_amd import dp
+    steps = 3
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_worker, args=(2, _free_port(), steps, out), nprocs=2, join=True)
+    got = torch.load(out)
+    # single process, full batch, same trainer (no process group -> all-reduce is the identity)
+    model = _make(seed=3)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)   # (Adam turns 1e-9 round-off on zero-gradient weights into +-lr steps)
+    tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0)
+    x, q, y = _data()
+    ref_loss = [float(tr.step(x, q, y).detach()) for _ in range(steps)]
+    assert np.allclose(got["loss"], ref_loss, rtol=1e-5, atol=1e-6)
+    for k, v in model.state_dict().items():
+        assert torch.allclose(got["sd"][k], v, rtol=1e-4, atol=1e-6), k
+
+
+def test_flat_bucket_semantics():
+    from relationnetworks_clevr_amd import dp
+    m = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    b = dp.FlatGradBucket(m.parameters())
+    assert b.numel == 5 * 3 + 3 + 3 * 2 + 2 and b.flat.numel() % 4 == 0
+    x = torch.randn(7, 5)
+    m(x).sum().backward()
+    g1 = [p.grad.clone() for p in m.parameters()]
+    b.check_attached()
+    # clip == torch.nn.utils.clip_grad_norm_
+    ref = [g.clone() for g in g1]
+    tot = torch.sqrt(sum((g ** 2).sum() for g in ref))
+    n = b.clip_grad_norm_(0.5)
+    assert torch.allclose(n, tot)
+    for p, g in zip(m.parameters(), ref):
+        assert torch.allclose(p.grad, g * min(1.0, 0.5 / (float(tot) + 1e-6)), atol=1e-7)
+    b.zero_()
+    assert all(float(p.grad.abs().sum()) == 0 for p in m.parameters())
+    m(x).sum().backward()                       # accumulates into the same views
+    for p, g in zip(m.parameters(), g1):
+        assert torch.allclose(p.grad, g)
+    torch.optim.SGD(m.parameters(), lr=0.1).zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError, match="left the flat bucket"):
+        b.check_attached()
