@@ -75,18 +75,53 @@ def broadcast_module_state(module, src: int = 0, group=None):
 
 class DataParallelTrainer:
     """model + optimizer + flat bucket: step(batch) = zero -> fwd -> nll -> bwd -> all-reduce -> clip -> Adam
-    (the loop body of the reference's train(), train.py:36-48)."""
+    (the loop body of the reference's train(), train.py:36-48).
 
-    def __init__(self, model, optimizer, clip_norm: float | None = 50.0, group=None):
+    use_graph=True captures {zero, forward, loss, backward} -- ~150 short kernel launches (conv/BN,
+    LSTM cells, the HIP hot path) -- into ONE hipGraph on first use and replays it every step; the
+    collective, the clip and the optimizer stay eager (a handful of launches, and identical for any
+    world size).  Inputs are copied into static buffers, so shapes must not change between steps."""
+
+    def __init__(self, model, optimizer, clip_norm: float | None = 50.0, group=None, use_graph: bool = False):
         self.model, self.opt, self.clip_norm, self.group = model, optimizer, clip_norm, group
         broadcast_module_state(model, 0, group)
         self.bucket = FlatGradBucket(model.parameters())
+        self.use_graph = use_graph
+        self._graph = None
+        self._static = None
 
-    def step(self, img, qst, label):
+    def _fwd_bwd(self, img, qst, label):
         self.bucket.zero_()
         out = self.model(img, qst)
         loss = torch.nn.functional.nll_loss(out, label)
         loss.backward()
+        return loss
+
+    def _capture(self, img, qst, label):
+        self._static = (img.clone(), qst.clone(), label.clone())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                   # warm-up outside capture (MIOpen find, allocator, packs)
+            for _ in range(2):
+                self._fwd_bwd(*self._static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._loss = self._fwd_bwd(*self._static)
+        self._graph = graph
+
+    def step(self, img, qst, label):
+        if self.use_graph:
+            if self._graph is None:
+                self._capture(img, qst, label)
+            for dst, src in zip(self._static, (img, qst, label)):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+            self._graph.replay()
+            loss = self._loss
+        else:
+            loss = self._fwd_bwd(img, qst, label)
         self.bucket.all_reduce_mean(self.group)
         if self.clip_norm:
             self.bucket.clip_grad_norm_(self.clip_norm)

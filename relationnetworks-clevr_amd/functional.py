@@ -54,7 +54,9 @@ class PackedWeights:
 
     def get(self, plan: LayerPlan, g_w, code):
         key = (code, tuple((w.data_ptr(), w._version) for w in g_w))
-        if key == self.key:
+        # while a hipGraph is being captured the pack kernels must be part of it (a replay sees
+        # new weights every step), so the cache is bypassed
+        if key == self.key and not torch.cuda.is_current_stream_capturing():
             return self.fwd, self.bwd
         dt = H.torch_dtype(code)
         dev = g_w[0].device
