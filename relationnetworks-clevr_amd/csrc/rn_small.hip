@@ -5,50 +5,60 @@
 // fp32 reference, one wave per 32x32 output tile, operands straight from global (L2-resident).
 #include "rn_common.h"
 
+// One workgroup (4 waves) per 32x32 output tile; the 4 waves split K (each runs a k-ordered fp32
+// fmaf chain over its quarter), partial tiles are combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long sam, long sak,
                                                        const float* __restrict__ B, long sbk, long sbn,
                                                        float* __restrict__ C, long ldc, int M, int N, int K,
                                                        const float* __restrict__ bias, const float* __restrict__ mul,
                                                        long ldmul, const float* __restrict__ gate, long ldgate,
-                                                       int flags, int tiles_n, int tiles) {
-  const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tile >= tiles) return;                            // wave-uniform
+                                                       int flags, int tiles_n) {
+  __shared__ float red[4][16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m = tm * 32 + (lane & 31), n = tn * 32 + (lane & 31);
   const int kh = lane >> 5;
   const bool mok = m < M, nok = n < N;
   const float* ap = A + (long)(mok ? m : 0) * sam;
   const float* bp = B + (long)(nok ? n : 0) * sbn;
+  const int kq = ((K + 3) / 4 + 7) / 8 * 8;              // per-wave K range, multiple of 8
+  const int kbeg = w * kq;
+  const int kend = (kbeg + kq < K) ? kbeg + kq : K;
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  int k = 0;
-  for (; k + 8 <= K; k += 8) {
-    float av[4], bv[4];
+  int k = kbeg;
+  for (; k + 16 <= kend; k += 16) {
+    float av[8], bv[8];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 8; ++s) {
       av[s] = ap[(long)(k + 2 * s + kh) * sak];
       bv[s] = bp[(long)(k + 2 * s + kh) * sbk];
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 8; ++s)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mok ? av[s] : 0.f, nok ? bv[s] : 0.f, acc, 0, 0, 0);
   }
-  for (; k < K; k += 2) {
-    const bool kok = (k + kh) < K;
+  for (; k < kend; k += 2) {
+    const bool kok = (k + kh) < kend;
     const float av = (mok && kok) ? ap[(long)(k + kh) * sak] : 0.f;
     const float bv = (nok && kok) ? bp[(long)(k + kh) * sbk] : 0.f;
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
   }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[w][e][lane] = acc[e];
+  __syncthreads();
+  // wave w finishes accumulator registers 4w..4w+3.
   // D[i][j]: j = lane&31 -> column n ; i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> row within the tile
   if (!nok) return;
   const float bn = bias ? bias[n] : 0.f;
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
+  for (int r = 0; r < 4; ++r) {
+    const int reg = 4 * w + r;
     const int row = tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
     if (row < M) {
-      float v = acc[reg] + bn;
+      float v = ((red[0][reg][lane] + red[1][reg][lane]) + red[2][reg][lane]) + red[3][reg][lane] + bn;
       if (mul) v *= mul[(long)row * ldmul + n];
       if (flags & RN_RELU) v = fmaxf(v, 0.f);
       if (gate) v = gate[(long)row * ldgate + n] > 0.f ? v : 0.f;
@@ -64,9 +74,8 @@ extern "C" int rn_gemm_f32(const float* A, long sam, long sak, const float* B, l
                            long ldgate, int flags, void* stream) {
   RN_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "rn_gemm_f32: bad pointer/size");
   const int tiles_m = cdiv(M, 32), tiles_n = cdiv(N, 32);
-  const int tiles = tiles_m * tiles_n;
-  gemm_f32_kernel<<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, mul,
-                                                                   ldmul, gate, ldgate, flags, tiles_n, tiles);
+  gemm_f32_kernel<<<tiles_m * tiles_n, 256, 0, (hipStream_t)stream>>>(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, mul,
+                                                                     ldmul, gate, ldgate, flags, tiles_n);
   RN_LAUNCH_CHECK("rn_gemm_f32");
   return 0;
 }

@@ -165,20 +165,39 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const T* __restrict__ dZ, in
   if (do_db) part_db[(long)blockIdx.z * N + n0 + t] = dbsum;
 }
 
+// Ordered reduction of the per-split partial tiles.  Z slabs of E4 float4's each; a workgroup owns
+// 16 consecutive float4 outputs and splits the Z slabs 16 ways (16 independent 16-byte loads in
+// flight per thread), then combines the 16 slices through LDS in a fixed order -> deterministic.
+// Blocks [0, nbw) reduce dW (trimming the K padding), blocks [nbw, ..) reduce db.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part,
                                                            const float* __restrict__ part_db, float* __restrict__ dW,
-                                                           float* __restrict__ db, int N, int Kpad, int Ktrue, int Z) {
-  const long total = (long)N * Ktrue;
-  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total + N; g += (long)gridDim.x * 256) {
-    float sum = 0.f;
-    if (g < total) {
-      const int n = (int)(g / Ktrue), k = (int)(g - (long)n * Ktrue);
-      for (int z = 0; z < Z; ++z) sum += part[((long)z * N + n) * Kpad + k];
-      dW[g] = sum;
+                                                           float* __restrict__ db, int N, int Kpad, int Ktrue, int Z,
+                                                           int nbw) {
+  __shared__ f32x4 red[16][16];
+  const int o = threadIdx.x & 15, zs = threadIdx.x >> 4;
+  const bool is_w = (int)blockIdx.x < nbw;
+  const long E4 = is_w ? (long)N * Kpad / 4 : N / 4;
+  const long g4 = (long)(is_w ? blockIdx.x : blockIdx.x - nbw) * 16 + o;
+  const f32x4* src = reinterpret_cast<const f32x4*>(is_w ? part : part_db);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (g4 < E4) {
+#pragma unroll 4
+    for (int z = zs; z < Z; z += 16) acc += src[(long)z * E4 + g4];
+  }
+  red[zs][o] = acc;
+  __syncthreads();
+  if (zs == 0 && g4 < E4) {
+    f32x4 sum = red[0][o];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) sum += red[i][o];
+    if (is_w) {
+      const long e = g4 * 4;
+      const int n = (int)(e / Kpad), k = (int)(e - (long)n * Kpad);     // Kpad % 4 == 0: the 4 lanes share n
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (k + i < Ktrue) dW[(long)n * Ktrue + k + i] = sum[i];
     } else if (db) {
-      const int n = (int)(g - total);
-      for (int z = 0; z < Z; ++z) sum += part_db[(long)z * N + n];
-      db[n] = sum;
+      *reinterpret_cast<f32x4*>(db + g4 * 4) = sum;
     }
   }
 }
@@ -258,10 +277,8 @@ extern "C" int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, in
     rc = wgrad_launch_t<float>((const float*)dZ, lddz, (const float*)A, lda, part, part_db, M, N, K, nkt, gy, Z, rps, s);
   if (rc) return rc;
   RN_LAUNCH_CHECK("rn_g_linear_bwd_wgrad");
-  const long total = (long)N * Ktrue + N;
-  int blocks = cdiv(total, 256);
-  if (blocks > 2048) blocks = 2048;
-  wgrad_reduce_kernel<<<blocks, 256, 0, s>>>(part, part_db, dW, db, N, K, Ktrue, Z);
+  const int nbw = cdiv((long)N * K / 4, 16), nbb = cdiv(N / 4, 16);
+  wgrad_reduce_kernel<<<nbw + nbb, 256, 0, s>>>(part, part_db, dW, db, N, K, Ktrue, Z, nbw);
   RN_LAUNCH_CHECK("rn_g_linear_bwd_wgrad(reduce)");
   return 0;
 }

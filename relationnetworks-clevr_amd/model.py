@@ -218,7 +218,23 @@ class RN(nn.Module):
         self.coord_tensor = ct
         return ct
 
+    def _text_on_side_stream(self, qst_idxs):
+        """The LSTM is a serial chain of ~20 tiny kernels that leaves the chip empty; fork it onto a
+        second HIP stream so it (and, through autograd's stream bookkeeping, its backward) overlaps
+        the conv stack.  Joined before the relational layer; capturable in a hipGraph."""
+        cur = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=qst_idxs.device)
+        side = self._side_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            qst = self.text(qst_idxs)
+        return qst, side
+
     def forward(self, img, qst_idxs):
+        side = None
+        if self.overlap_streams and qst_idxs.is_cuda and not self.state_desc:
+            qst, side = self._text_on_side_stream(qst_idxs)
         if self.state_desc:
             x = img                                             # (B, 12, 7) state descriptions
         else:
