@@ -195,6 +195,8 @@ class RN(nn.Module):
         super().__init__()
         self.coord_tensor = None
         self._coord_key = None
+        self._side_stream = None
+        self.overlap_streams = os.environ.get("RN_OVERLAP_STREAMS", "1") != "0"
         self.on_gpu = False
         self.conv = ConvInputModel()
         self.state_desc = hyp["state_description"]
@@ -246,7 +248,12 @@ class RN(nn.Module):
                 self.coord_tensor = self.coord_tensor.view(b, 2, d * d)
                 self._coord_key = key
             x = torch.cat([x.view(b, k, d * d), self.coord_tensor], 1).permute(0, 2, 1)   # (B, d*d, 26) strided view
-        qst = self.text(qst_idxs)
+        if side is None:
+            qst = self.text(qst_idxs)
+        else:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(side)
+            qst.record_stream(cur)
         return self.rl(x, qst)
 
     def cuda(self, device=None):
