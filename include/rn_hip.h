@@ -69,6 +69,17 @@ int rn_pack_matrix(const float* src, long sr, long sc, int R, int C, void* dst, 
 int rn_g_linear_fwd(const void* A, int lda, const void* Wp, int ldw, const float* bias, void* H, int ldh,
                     int dtype, int M, int N, int K, void* stream);
 
+/* Fused K2 chain + K3 partials (bf16 storage; the un-fused entry points above stay the general
+ * path).  Runs all L g layers (model.py:130-145) for every 128-row tile of P with the 256-wide
+ * activation tile resident in LDS; each activation is written once to H[l] (M, 256) -- or not at
+ * all when H or H[l] is NULL (inference) -- and never read back.  xg_part (M/128, 256) fp32 receives
+ * the per-tile column sums of the last activation (model.py:151-152); reduce them per question
+ * with rn_pair_sum_fwd(xg_part, ..., RN_F32, B, n*n/128, 256).
+ * Wp[l]: packed (256, K[l]) weights with ld == K[l]; K[0] % 64 == 0, K[0] <= 256, K[l>0] == 256;
+ * Wp / bias / H / K are HOST arrays of L entries.  Requires M % 128 == 0, G == 256. */
+int rn_g_chain_fwd(const void* P, int ldp, const void* const* Wp, const float* const* bias, void* const* H,
+                   const int* K, float* xg_part, int dtype, int M, int L, int G, void* stream);
+
 /* K3 -- sum over the n*n pairs of every question: xg[b,:] = sum_p HL[b*npairs+p, :]
  * (model.py:151-152).  ws: >= rn_pair_sum_ws_bytes(...) bytes of scratch. */
 size_t rn_pair_sum_ws_bytes(int B, int npairs, int G);

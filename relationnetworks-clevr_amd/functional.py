@@ -81,9 +81,22 @@ class PackedWeights:
         return self.fwd, self.bwd
 
 
+def fused_chain_ok(plan: LayerPlan, code, B, n):
+    """The fused LDS-resident chain (rn_chain.hip) covers the headline shape family: bf16 storage,
+    all g widths 256, question injected at layer 0 (so every later layer has K == 256), and whole
+    128-row tiles per question.  Everything else runs the per-layer kernels."""
+    import os
+    if os.environ.get("RN_NO_FUSED_CHAIN", "0") == "1":
+        return False
+    return (code == H.RN_BF16 and all(w == 256 for w in plan.widths) and plan.kpad[0] <= 256
+            and all(kp == 256 for kp in plan.kpad[1:]) and (n * n) % 128 == 0 and plan.L <= 8)
+
+
 def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None):
-    """K1 + K2 chain.  Returns the list of layer INPUT buffers [A_0 .. A_{L-1}] and the last
-    activation H_L.  layer_hook(l, A_l, H_out) is called after every layer (hook-compat path)."""
+    """K1 + K2 chain (+ K3).  Returns (inputs, H_L, xg): the list of layer INPUT buffers
+    [A_0 .. A_{L-1}], the last activation H_L and -- when the fused chain ran -- the pair sum xg
+    (else None).  layer_hook(l, A_l, H_out) is called after every layer (hook-compat path; forces
+    the per-layer kernels)."""
     B, n, k = x.shape
     Q = q.shape[1]
     M = B * n * n
@@ -93,6 +106,16 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
     ld0 = plan.kpad[0]
     P = torch.empty(M, ld0, dtype=dt, device=dev)
     H.pair_build_fwd(x, q if inj == 0 else None, P, code, B, n, k, Q if inj == 0 else 0, ld0)
+    if layer_hook is None and fused_chain_ok(plan, code, B, n):
+        G = plan.widths[-1]
+        L = plan.L
+        # activations are stored only when the backward pass will need them
+        Hs = [torch.empty(M, G, dtype=dt, device=dev) if keep_inputs else None for _ in range(L)]
+        part = torch.empty(M // 128, G, dtype=torch.float32, device=dev)
+        H.g_chain_fwd(P, ld0, wfwd, g_b, Hs, plan.kpad, part, code, M, G)
+        xg = torch.empty(B, G, dtype=torch.float32, device=dev)
+        H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // 128, G)
+        return [P] + Hs[:-1], Hs[-1], xg
     inputs = [P]
     cur = P
     for l in range(plan.L):
@@ -113,7 +136,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
         if not keep_inputs and l >= 1:
             inputs[l] = None
         cur = out
-    return inputs, cur
+    return inputs, cur, None
 
 
 def f_phi_forward(xg, fw, fb, mask):
@@ -153,10 +176,11 @@ class RelationalFunction(torch.autograd.Function):
         wfwd, wbwd = packed.get(plan, g_w, code)
         gb = [b.detach().contiguous() for b in g_b]
         need_grad = any(ctx.needs_input_grad)
-        inputs, HL = g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad)
+        inputs, HL, xg = g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad)
         G = plan.widths[-1]
-        xg = torch.empty(B, G, dtype=torch.float32, device=dev)
-        H.pair_sum_fwd(HL, G, xg, code, B, n * n, G)
+        if xg is None:
+            xg = torch.empty(B, G, dtype=torch.float32, device=dev)
+            H.pair_sum_fwd(HL, G, xg, code, B, n * n, G)
         fw = [w.detach().contiguous() for w in f_w]
         fb = [b.detach().contiguous() for b in f_b]
         F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]

@@ -174,7 +174,7 @@ class RelationalLayer(RelationalLayerBase):
                 for hook in list(layer._forward_hooks.values()):
                     hook(layer, (inp,), outp)
 
-        _inputs, HL = RF.g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=False, layer_hook=layer_hook)
+        _inputs, HL, _xg = RF.g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=False, layer_hook=layer_hook)
         if self.extraction:
             return None                                        # reference model.py:147-148
         B = x.shape[0]

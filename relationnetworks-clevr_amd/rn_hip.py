@@ -28,6 +28,7 @@ SIGNATURES = {
     "rn_qst_broadcast": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_pack_matrix": (_I, [_P, _L, _L, _I, _I, _P, _I, _I, _I, _P]),
     "rn_g_linear_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_g_chain_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_sum_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_sum_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_sum_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
@@ -160,6 +161,17 @@ def g_linear_fwd(A, lda, Wp, ldw, bias, H, ldh, code, M, N, K, h_offset_elems=0)
     esz = 2 if code == RN_BF16 else 4
     _check(load().rn_g_linear_fwd(A.data_ptr(), lda, Wp.data_ptr(), ldw, bias.data_ptr(), H.data_ptr() + esz * h_offset_elems,
                                   ldh, code, M, N, K, _stream()), "rn_g_linear_fwd")
+
+
+@_timed("g_fwd")
+def g_chain_fwd(P, ldp, Wps, biases, Hs, Ks, xg_part, code, M, G):
+    """Fused forward chain; Hs entries may be None (activation not stored)."""
+    L = len(Wps)
+    wp = (C.c_void_p * L)(*[w.data_ptr() for w in Wps])
+    bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
+    hp = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs])
+    kk = (C.c_int * L)(*Ks)
+    _check(load().rn_g_chain_fwd(P.data_ptr(), ldp, wp, bp, hp, kk, _ptr(xg_part), code, M, L, G, _stream()), "rn_g_chain_fwd")
 
 
 @_timed("pair_sum")

@@ -175,6 +175,39 @@ def test_g_linear_bwd_dgrad(H, code, M, N, Kin):
     assert np.all(got[Hp <= 0] == 0)
 
 
+@pytest.mark.parametrize("K0,K0true,L,store", [(192, 180, 4, True), (64, 52, 2, True), (256, 256, 4, False)])
+def test_g_chain_fwd_fused(H, K0, K0true, L, store):
+    """Fused LDS-resident chain: every stored activation must equal one un-fused layer applied to the
+    kernel's OWN previous activation (<= 1 bf16 ulp), and the per-tile pair-sum partials must be
+    the column sums of the last activation."""
+    M, G = 1024, 256
+    P = np.zeros((M, K0), np.float32); P[:, :K0true] = formula.hash_uniform((M, K0true), 300, -1, 1)
+    P = bf16_round(P)
+    Ws, bs, Ks = [], [], []
+    for l in range(L):
+        kt, kp = (K0true, K0) if l == 0 else (G, G)
+        W = np.zeros((G, kp), np.float32); W[:, :kt] = formula.hash_uniform((G, kt), 310 + l, -0.15, 0.15)
+        Ws.append(bf16_round(W)); bs.append(formula.hash_uniform((G,), 320 + l, -0.3, 0.3)); Ks.append(kp)
+    Hs = [torch.empty(M, G, dtype=torch.bfloat16, device="cuda") if store else None for _ in range(L)]
+    part = torch.empty(M // 128, G, dtype=torch.float32, device="cuda")
+    H.g_chain_fwd(dev(P).bfloat16(), K0, [dev(w).bfloat16() for w in Ws], [dev(b) for b in bs], Hs, Ks, part, 0, M, G)
+    torch.cuda.synchronize()
+    if store:
+        prev = P
+        for l in range(L):
+            got = Hs[l].float().cpu().numpy()
+            ref = np.maximum(prev.astype(np.float64) @ Ws[l].astype(np.float64).T + bs[l], 0)
+            err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
+            assert err.max() <= BF16_ULP, (l, err.max())
+            prev = got
+        assert rel(part.cpu().numpy(), prev.reshape(M // 128, 128, G).sum(1, dtype=np.float64)) <= F32_TOL
+    else:   # nothing stored: the partials must match the un-fused chain's pair sum within bf16 chain noise
+        prev = P
+        for l in range(L):
+            prev = bf16_round(np.maximum(prev.astype(np.float64) @ Ws[l].astype(np.float64).T + bs[l], 0))
+        assert rel(part.cpu().numpy(), prev.reshape(M // 128, 128, G).sum(1, dtype=np.float64)) <= 2e-3
+
+
 # ----------------------------------------------------------------------------- K3
 @pytest.mark.parametrize("code", [0, 1])
 @pytest.mark.parametrize("B,npairs,G", [(4, 4096, 256), (3, 144, 512), (2, 38416, 256)])
