@@ -70,13 +70,15 @@ int rn_g_linear_fwd(const void* A, int lda, const void* Wp, int ldw, const float
                     int dtype, int M, int N, int K, void* stream);
 
 /* Fused K2 chain + K3 partials (bf16 storage; the un-fused entry points above stay the general
- * path).  Runs all L g layers (model.py:130-145) for every 128-row tile of P with the 256-wide
+ * path).  Runs all L g layers (model.py:130-145) for every T-row tile of P with the 256-wide
  * activation tile resident in LDS; each activation is written once to H[l] (M, 256) -- or not at
- * all when H or H[l] is NULL (inference) -- and never read back.  xg_part (M/128, 256) fp32 receives
+ * all when H or H[l] is NULL (inference) -- and never read back.  xg_part (M/T, 256) fp32 receives
  * the per-tile column sums of the last activation (model.py:151-152); reduce them per question
- * with rn_pair_sum_fwd(xg_part, ..., RN_F32, B, n*n/128, 256).
+ * with rn_pair_sum_fwd(xg_part, ..., RN_F32, B, n*n/T, 256).
  * Wp[l]: packed (256, K[l]) weights with ld == K[l]; K[0] % 64 == 0, K[0] <= 256, K[l>0] == 256;
- * Wp / bias / H / K are HOST arrays of L entries.  Requires M % 128 == 0, G == 256. */
+ * Wp / bias / H / K are HOST arrays of L entries.  G == 256; M must be a multiple of the tile
+ * height T = rn_g_chain_tile() (128, or 64 with RN_CHAIN_TILE=64) and xg_part has M/T rows. */
+int rn_g_chain_tile(void);
 int rn_g_chain_fwd(const void* P, int ldp, const void* const* Wp, const float* const* bias, void* const* H,
                    const int* K, float* xg_part, int dtype, int M, int L, int G, void* stream);
 

@@ -12,14 +12,13 @@
 // registers.  Operand assignment is swapped (weights = A-operand) exactly as in rn_gemm.hip, so a
 // lane ends up with 4 consecutive features of one pair row -> one ds_write_b64 into the LDS tile.
 // The tile is then copied LDS -> HBM with 16-byte, fully row-contiguous stores.
+#include <stdlib.h>
+
 #include "rn_common.h"
 
 namespace {
-constexpr int CT_M = 128, CT_G = 256, CT_MAXL = 8;
+constexpr int CT_G = 256, CT_MAXL = 8;
 constexpr int ACT_RS = CT_G * 2 + 16;        // 528 B: act tile row stride (conflict-free b128 reads)
-constexpr int W_RS = 64 * 2 + 16;            // 144 B: weight slab row stride
-constexpr int ACT_BYTES = CT_M * ACT_RS;     // 67584
-constexpr int WBUF_BYTES = CT_G * W_RS;      // 36864
 
 struct ChainArgs {
   const bf16* W[CT_MAXL];
@@ -29,34 +28,44 @@ struct ChainArgs {
 };
 }  // namespace
 
-__global__ __launch_bounds__(512) void g_chain_fwd_kernel(const bf16* __restrict__ P, int ldp, ChainArgs a, int L,
-                                                          float* __restrict__ xg_part) {
+// TM = tile rows (128 with 512 threads: one workgroup per CU; 64 with 256 threads: two co-resident
+// workgroups per CU that overlap each other's load / epilogue / store phases), BK = K-slab width.
+template <int TM, int NT, int BK>
+__global__ __launch_bounds__(NT) void g_chain_fwd_kernel(const bf16* __restrict__ P, int ldp, ChainArgs a, int L,
+                                                         float* __restrict__ xg_part, int abl) {
+  constexpr int W_RS = BK * 2 + 16;             // weight slab row stride (144 / 80 B: conflict-free b128 reads)
+  constexpr int ACT_BYTES = TM * ACT_RS;
+  constexpr int WBUF_BYTES = CT_G * W_RS;
+  constexpr int CPRW = BK / 8;                  // 16-byte chunks per weight-slab row
+  constexpr int KSTEPS = BK / 16;
+  constexpr int GM = TM / 64;                   // wave grid GM x GN, every wave owns 64 x 64
+  static_assert(CT_G * CPRW / NT == 4 && NT / CPRW == 64 && (NT / 64) / GM == 4, "tile geometry");
   __shared__ __attribute__((aligned(16))) unsigned char lds[ACT_BYTES + 2 * WBUF_BYTES];
   unsigned char* act = lds;
   unsigned char* wbuf = lds + ACT_BYTES;
 
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int wm = w & 1, wn = w >> 1;
-  const long m0 = (long)blockIdx.x * CT_M;
+  const int wm = w % GM, wn = w / GM;
+  const long m0 = (long)blockIdx.x * TM;
 
   // ---- stage the P tile: 128 rows x K0 columns -> act[:, 0:K0]
   {
     const int K0 = a.K[0];
     const int cpr = K0 >> 3;                              // 16-byte chunks per row
-    const int total = CT_M * cpr;
-    for (int c = t; c < total; c += 512) {
+    const int total = TM * cpr;
+    for (int c = t; c < total; c += NT) {
       const int r = c / cpr, cc = c - r * cpr;
       *reinterpret_cast<u32x4*>(act + r * ACT_RS + cc * 16) =
           *reinterpret_cast<const u32x4*>(P + (m0 + r) * ldp + cc * 8);
     }
   }
-  // weight slab staging: 256 rows x 128 B = 2048 chunks, 4 per thread; 8 lanes cover one row slab
-  const int srow = t >> 3, scc = t & 7;
+  // weight slab staging: 256 rows x 2*BK bytes, 4 chunks per thread; CPRW lanes cover one row slab
+  const int srow = t / CPRW, scc = t % CPRW;
   u32x4 rw[4];
   auto gload = [&](const bf16* Wl, int ldw, int slab) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      rw[s] = *reinterpret_cast<const u32x4*>(Wl + (long)(srow + 64 * s) * ldw + slab * 64 + scc * 8);
+      rw[s] = *reinterpret_cast<const u32x4*>(Wl + (long)(srow + 64 * s) * ldw + slab * BK + scc * 8);
   };
   auto lstore = [&](int buf) {
 #pragma unroll
@@ -78,28 +87,32 @@ __global__ __launch_bounds__(512) void g_chain_fwd_kernel(const bf16* __restrict
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    const int ns = a.K[l] >> 6;
+    const int ns = a.K[l] / BK;
     for (int s = 0; s < ns; ++s) {
       const bool last_slab = (s == ns - 1);
-      const bool has_next = !(last_slab && l == L - 1);
+      const bool has_next = !(last_slab && l == L - 1) && !(abl & 1);   // abl: timing ablations only (RN_CHAIN_ABLATE)
       if (has_next) {
         if (last_slab) gload(a.W[l + 1], a.K[l + 1], 0);
         else gload(a.W[l], a.K[l], s + 1);
       }
       const unsigned char* fw_base = wbuf + cur * WBUF_BYTES + fw_off;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < KSTEPS; ++ks) {
         bf16x8 fa[2], fw[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
-          fa[mt] = *reinterpret_cast<const bf16x8*>(fa_base + mt * 32 * ACT_RS + s * 128 + ks * 32);
+          fa[mt] = *reinterpret_cast<const bf16x8*>(fa_base + mt * 32 * ACT_RS + s * (2 * BK) + ks * 32);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) fw[nt] = *reinterpret_cast<const bf16x8*>(fw_base + nt * 32 * W_RS + ks * 32);
+        if (!(abl & 4)) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+          for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < 2; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+        } else {
+          asm volatile("" ::"v"(fw[0]), "v"(fw[1]), "v"(fa[0]), "v"(fa[1]));
+        }
       }
       if (has_next) lstore(cur ^ 1);
       __syncthreads();                  // (A) all reads of wbuf[cur] / this act slab done; next slab visible
@@ -107,6 +120,7 @@ __global__ __launch_bounds__(512) void g_chain_fwd_kernel(const bf16* __restrict
     }
     // ---- epilogue: bias + ReLU -> bf16 -> act tile in place (all waves are past barrier A)
     const float* bl = a.bias[l];
+    if (!(abl & 2))
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const int row = wm * 64 + mt * 32 + (lane & 31);
@@ -124,12 +138,12 @@ __global__ __launch_bounds__(512) void g_chain_fwd_kernel(const bf16* __restrict
       }
     }
     __syncthreads();                    // (B) the new activation tile is visible
-    // ---- copy the tile LDS -> HBM: 128 rows x 512 B, 8 x 16-byte chunks per thread, row-contiguous
+    // ---- copy the tile LDS -> HBM: TM rows x 512 B, 8 x 16-byte chunks per thread, row-contiguous
     bf16* Hl = a.H[l];
     if (Hl) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = t + 512 * i;
+      for (int i = 0; i < TM * 32 / NT; ++i) {
+        const int c = t + NT * i;
         const int r = c >> 5, cc = c & 31;
         *reinterpret_cast<u32x4*>(Hl + (m0 + r) * CT_G + cc * 8) = *reinterpret_cast<const u32x4*>(act + r * ACT_RS + cc * 16);
       }
@@ -137,16 +151,27 @@ __global__ __launch_bounds__(512) void g_chain_fwd_kernel(const bf16* __restrict
   }
   // ---- pair-sum partial of this tile: column sums of the bf16 tile (fp32 accumulate, fixed order)
   if (xg_part) {
+    constexpr int NH = NT / 256, RPH = TM / NH;           // NH row groups of RPH rows, one thread per column
     const int c = t & 255, h = t >> 8;
     float s = 0.f;
 #pragma unroll 8
-    for (int r = 0; r < 64; ++r) s += (float)*reinterpret_cast<const bf16*>(act + (h * 64 + r) * ACT_RS + c * 2);
-    float* red = reinterpret_cast<float*>(wbuf);        // weight buffers are idle now (past barrier A/B)
-    if (h == 1) red[c] = s;
-    __syncthreads();
-    if (h == 0) xg_part[(long)blockIdx.x * CT_G + c] = s + red[c];
+    for (int r = 0; r < RPH; ++r) s += (float)*reinterpret_cast<const bf16*>(act + (h * RPH + r) * ACT_RS + c * 2);
+    if constexpr (NH == 2) {
+      float* red = reinterpret_cast<float*>(wbuf);      // weight buffers are idle now (past barrier A/B)
+      if (h == 1) red[c] = s;
+      __syncthreads();
+      if (h == 0) xg_part[(long)blockIdx.x * CT_G + c] = s + red[c];
+    } else {
+      xg_part[(long)blockIdx.x * CT_G + c] = s;
+    }
   }
 }
+
+static int chain_tile_rows() {
+  const char* te = getenv("RN_CHAIN_TILE");       // 128 (default; measured 279 us vs 326 us for 64) or 64
+  return (te && atoi(te) == 64) ? 64 : 128;
+}
+extern "C" int rn_g_chain_tile(void) { return chain_tile_rows(); }
 
 extern "C" int rn_g_chain_fwd(const void* P, int ldp, const void* const* Wp, const float* const* bias,
                               void* const* H, const int* K, float* xg_part, int dtype, int M, int L, int G,
@@ -154,7 +179,8 @@ extern "C" int rn_g_chain_fwd(const void* P, int ldp, const void* const* Wp, con
   RN_CHECK_ARG(P && Wp && bias && K && M > 0, "rn_g_chain_fwd: bad pointer/size");
   RN_CHECK_ARG(dtype == RN_BF16, "rn_g_chain_fwd: only the bf16 storage mode has a fused chain (dtype=%d)", dtype);
   RN_CHECK_ARG(G == CT_G && L >= 1 && L <= CT_MAXL, "rn_g_chain_fwd: needs G == 256 and 1 <= L <= %d (G=%d L=%d)", CT_MAXL, G, L);
-  RN_CHECK_ARG(M % CT_M == 0, "rn_g_chain_fwd: M=%d must be a multiple of %d", M, CT_M);
+  const int TM = chain_tile_rows();
+  RN_CHECK_ARG(M % TM == 0, "rn_g_chain_fwd: M=%d must be a multiple of %d", M, TM);
   RN_CHECK_ARG(ldp % 8 == 0 && ldp >= K[0] && ((uintptr_t)P % 16 == 0), "rn_g_chain_fwd: bad P layout");
   ChainArgs a;
   memset(&a, 0, sizeof(a));
@@ -169,7 +195,10 @@ extern "C" int rn_g_chain_fwd(const void* P, int ldp, const void* const* Wp, con
     a.H[l] = H ? (bf16*)H[l] : nullptr;
     a.K[l] = K[l];
   }
-  g_chain_fwd_kernel<<<M / CT_M, 512, 0, (hipStream_t)stream>>>((const bf16*)P, ldp, a, L, xg_part);
+  const char* ab = getenv("RN_CHAIN_ABLATE");
+  const int abl = ab ? atoi(ab) : 0;
+  if (TM == 128) g_chain_fwd_kernel<128, 512, 64><<<M / 128, 512, 0, (hipStream_t)stream>>>((const bf16*)P, ldp, a, L, xg_part, abl);
+  else g_chain_fwd_kernel<64, 256, 32><<<M / 64, 256, 0, (hipStream_t)stream>>>((const bf16*)P, ldp, a, L, xg_part, abl);
   RN_LAUNCH_CHECK("rn_g_chain_fwd");
   return 0;
 }

@@ -89,7 +89,7 @@ def fused_chain_ok(plan: LayerPlan, code, B, n):
     if os.environ.get("RN_NO_FUSED_CHAIN", "0") == "1":
         return False
     return (code == H.RN_BF16 and all(w == 256 for w in plan.widths) and plan.kpad[0] <= 256
-            and all(kp == 256 for kp in plan.kpad[1:]) and (n * n) % 128 == 0 and plan.L <= 8)
+            and all(kp == 256 for kp in plan.kpad[1:]) and (n * n) % H.g_chain_tile() == 0 and plan.L <= 8)
 
 
 def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None):
@@ -111,10 +111,11 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
         L = plan.L
         # activations are stored only when the backward pass will need them
         Hs = [torch.empty(M, G, dtype=dt, device=dev) if keep_inputs else None for _ in range(L)]
-        part = torch.empty(M // 128, G, dtype=torch.float32, device=dev)
+        T = H.g_chain_tile()
+        part = torch.empty(M // T, G, dtype=torch.float32, device=dev)
         H.g_chain_fwd(P, ld0, wfwd, g_b, Hs, plan.kpad, part, code, M, G)
         xg = torch.empty(B, G, dtype=torch.float32, device=dev)
-        H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // 128, G)
+        H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // T, G)
         return [P] + Hs[:-1], Hs[-1], xg
     inputs = [P]
     cur = P

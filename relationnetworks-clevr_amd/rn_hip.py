@@ -28,6 +28,7 @@ SIGNATURES = {
     "rn_qst_broadcast": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_pack_matrix": (_I, [_P, _L, _L, _I, _I, _P, _I, _I, _I, _P]),
     "rn_g_linear_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_g_chain_tile": (_I, []),
     "rn_g_chain_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_sum_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_sum_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
@@ -161,6 +162,10 @@ def g_linear_fwd(A, lda, Wp, ldw, bias, H, ldh, code, M, N, K, h_offset_elems=0)
     esz = 2 if code == RN_BF16 else 4
     _check(load().rn_g_linear_fwd(A.data_ptr(), lda, Wp.data_ptr(), ldw, bias.data_ptr(), H.data_ptr() + esz * h_offset_elems,
                                   ldh, code, M, N, K, _stream()), "rn_g_linear_fwd")
+
+
+def g_chain_tile() -> int:
+    return load().rn_g_chain_tile()
 
 
 @_timed("g_fwd")

@@ -189,7 +189,8 @@ def test_g_chain_fwd_fused(H, K0, K0true, L, store):
         W = np.zeros((G, kp), np.float32); W[:, :kt] = formula.hash_uniform((G, kt), 310 + l, -0.15, 0.15)
         Ws.append(bf16_round(W)); bs.append(formula.hash_uniform((G,), 320 + l, -0.3, 0.3)); Ks.append(kp)
     Hs = [torch.empty(M, G, dtype=torch.bfloat16, device="cuda") if store else None for _ in range(L)]
-    part = torch.empty(M // 128, G, dtype=torch.float32, device="cuda")
+    T = H.g_chain_tile()
+    part = torch.empty(M // T, G, dtype=torch.float32, device="cuda")
     H.g_chain_fwd(dev(P).bfloat16(), K0, [dev(w).bfloat16() for w in Ws], [dev(b) for b in bs], Hs, Ks, part, 0, M, G)
     torch.cuda.synchronize()
     if store:
@@ -200,12 +201,12 @@ def test_g_chain_fwd_fused(H, K0, K0true, L, store):
             err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
             assert err.max() <= BF16_ULP, (l, err.max())
             prev = got
-        assert rel(part.cpu().numpy(), prev.reshape(M // 128, 128, G).sum(1, dtype=np.float64)) <= F32_TOL
+        assert rel(part.cpu().numpy(), prev.reshape(M // T, T, G).sum(1, dtype=np.float64)) <= F32_TOL
     else:   # nothing stored: the partials must match the un-fused chain's pair sum within bf16 chain noise
         prev = P
         for l in range(L):
             prev = bf16_round(np.maximum(prev.astype(np.float64) @ Ws[l].astype(np.float64).T + bs[l], 0))
-        assert rel(part.cpu().numpy(), prev.reshape(M // 128, 128, G).sum(1, dtype=np.float64)) <= 2e-3
+        assert rel(part.cpu().numpy(), prev.reshape(M // T, T, G).sum(1, dtype=np.float64)) <= 2e-3
 
 
 # ----------------------------------------------------------------------------- K3
