@@ -82,6 +82,17 @@ int rn_g_chain_tile(void);
 int rn_g_chain_fwd(const void* P, int ldp, const void* const* Wp, const float* const* bias, void* const* H,
                    const int* K, float* xg_part, int dtype, int M, int L, int G, void* stream);
 
+/* Fused backward chain (bf16 storage): pair-sum broadcast + last ReLU gate + all L-1 dgrad steps
+ *  for every 128-row tile, tile resident in LDS:
+ *   dZ[0]   = dxg[b] * (HL > 0)                                   (gradient of layer L-1's pre-activation)
+ *   dZ[s+1] = (dZ[s] @ W_{L-1-s}[:, :256]) * (Hgate[s] > 0)        s = 0 .. L-2
+ * Wt[s]: transposed packed weight of layer L-1-s, (256 in, 256 out) row-major (rn_pack_matrix);
+ * Hgate[s]: the INPUT activation of layer L-1-s (= output of layer L-2-s), (M, 256).
+ * All dZ (M, 256) are written (wgrad consumes them).  Wt / Hgate / dZ are HOST arrays.
+ * Requires G == 256, L >= 2, M and rows_per_question (= n*n) multiples of 128. */
+int rn_g_chain_bwd(const void* HL, const float* dxg, const void* const* Wt, const void* const* Hgate,
+                   void* const* dZ, int dtype, int M, int rows_per_question, int L, int G, void* stream);
+
 /* K3 -- sum over the n*n pairs of every question: xg[b,:] = sum_p HL[b*npairs+p, :]
  * (model.py:151-152).  ws: >= rn_pair_sum_ws_bytes(...) bytes of scratch. */
 size_t rn_pair_sum_ws_bytes(int B, int npairs, int G);

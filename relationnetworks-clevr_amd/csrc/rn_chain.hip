@@ -1,11 +1,15 @@
-// Fused g_theta forward chain (model.py:130-152): one launch runs ALL g layers for a 128-row tile
-// of the pair matrix and keeps the 256-wide activation tile in LDS between layers, so each
-// activation is written to HBM exactly once (for the backward pass) and never read back, and
-// the pair sum (model.py:151-152) is taken from the last tile while it is still on chip.
+// Fused g_theta chains (model.py:130-152 and their autograd): one launch runs ALL g layers for a
+// 128-row tile of the pair matrix and keeps the 256-wide tile in LDS between layers.
 //
-//   HBM traffic / step:  read P (M x K0) + write H_1..H_L (M x 256 each), vs. read+write of every
-//   activation in the per-layer kernels (rn_gemm.hip).  Weights (<= 128 KB per layer, bf16) stream
-//   from L2 in 64-wide K slabs through a double-buffered, padded LDS stage.
+//   forward  (MODE_FWD): tile <- P rows;            per layer: tile = relu(tile @ W_l^T + b_l)
+//            each activation is written to HBM exactly once (for the backward pass) and never read
+//            back; the pair sum (model.py:151-152) is taken from the last tile while it is on chip.
+//   backward (MODE_BWD): tile <- dxg[b] * (H_L > 0);  per layer: tile = (tile @ W_l[:, :256]) * (H_{l-1} > 0)
+//            i.e. pair-sum broadcast + last ReLU gate + the whole dgrad chain; every dZ_l is written
+//            once (wgrad reads it), every H_l is read once (as the gate).
+//
+//   Weights (<= 128 KB per layer, bf16) stream from L2 in 64-wide K slabs through a double-buffered,
+//   padded LDS stage (register-staged prefetch one slab ahead).
 //
 // Workgroup = 512 threads (8 waves = 2 per SIMD), tile 128(M) x 256(N); wave (wm, wn) in a 2 x 4
 // grid owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles (v_mfma_f32_32x32x16_bf16), 64 accumulator
@@ -18,21 +22,28 @@
 
 namespace {
 constexpr int CT_G = 256, CT_MAXL = 8;
-constexpr int ACT_RS = CT_G * 2 + 16;        // 528 B: act tile row stride (conflict-free b128 reads)
+constexpr int ACT_RS = CT_G * 2 + 16;        // 528 B: tile row stride (conflict-free b128 reads)
+enum { MODE_FWD = 0, MODE_BWD = 1 };
 
 struct ChainArgs {
-  const bf16* W[CT_MAXL];
-  const float* bias[CT_MAXL];
-  bf16* H[CT_MAXL];                          // may be null: activation not stored (inference)
-  int K[CT_MAXL];                            // padded reduction length of layer l (multiple of 64, <= 256)
+  const bf16* W[CT_MAXL];                    // fwd: packed (256, K[l]);  bwd: transposed (256 kin, 256 n) of step s
+  const float* bias[CT_MAXL];                // fwd only
+  const bf16* gate[CT_MAXL];                 // bwd only: activation gating the output of step s, (M, 256)
+  bf16* out[CT_MAXL];                        // fwd: H_l (may be null);  bwd: dZ after step s
+  int K[CT_MAXL];                            // reduction length of step l (multiple of BK, <= 256)
+  // backward prologue
+  const bf16* HL;                            // last activation (M, 256)
+  const float* dxg;                          // (B, 256) fp32
+  bf16* out0;                                // dZ of the last layer (M, 256)
+  int rows_per_b;                            // n*n
 };
 }  // namespace
 
 // TM = tile rows (128 with 512 threads: one workgroup per CU; 64 with 256 threads: two co-resident
-// workgroups per CU that overlap each other's load / epilogue / store phases), BK = K-slab width.
-template <int TM, int NT, int BK>
-__global__ __launch_bounds__(NT) void g_chain_fwd_kernel(const bf16* __restrict__ P, int ldp, ChainArgs a, int L,
-                                                         float* __restrict__ xg_part, int abl) {
+// workgroups per CU), BK = K-slab width.
+template <int TM, int NT, int BK, int MODE>
+__global__ __launch_bounds__(NT) void g_chain_kernel(const bf16* __restrict__ P, int ldp, ChainArgs a, int L,
+                                                     float* __restrict__ xg_part, int abl) {
   constexpr int W_RS = BK * 2 + 16;             // weight slab row stride (144 / 80 B: conflict-free b128 reads)
   constexpr int ACT_BYTES = TM * ACT_RS;
   constexpr int WBUF_BYTES = CT_G * W_RS;
@@ -48,8 +59,8 @@ __global__ __launch_bounds__(NT) void g_chain_fwd_kernel(const bf16* __restrict_
   const int wm = w % GM, wn = w / GM;
   const long m0 = (long)blockIdx.x * TM;
 
-  // ---- stage the P tile: 128 rows x K0 columns -> act[:, 0:K0]
-  {
+  if constexpr (MODE == MODE_FWD) {
+    // ---- stage the P tile: TM rows x K0 columns -> tile[:, 0:K0]
     const int K0 = a.K[0];
     const int cpr = K0 >> 3;                              // 16-byte chunks per row
     const int total = TM * cpr;
@@ -57,6 +68,26 @@ __global__ __launch_bounds__(NT) void g_chain_fwd_kernel(const bf16* __restrict_
       const int r = c / cpr, cc = c - r * cpr;
       *reinterpret_cast<u32x4*>(act + r * ACT_RS + cc * 16) =
           *reinterpret_cast<const u32x4*>(P + (m0 + r) * ldp + cc * 8);
+    }
+  } else {
+    // ---- dZ_L tile = dxg[b] * (H_L > 0)   (backward of the pair sum + last ReLU), also stored to HBM
+    const int b = (int)(m0 / a.rows_per_b);               // a tile never straddles two questions
+    const float* gb = a.dxg + (long)b * CT_G;
+#pragma unroll
+    for (int i = 0; i < TM * 32 / NT; ++i) {
+      const int c = t + NT * i;
+      const int r = c >> 5, cc = c & 31;
+      const bf16x8 h = *reinterpret_cast<const bf16x8*>(a.HL + (m0 + r) * CT_G + cc * 8);
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gb + cc * 8);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(gb + cc * 8 + 4);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (float)h[e] > 0.f ? (bf16)g0[e] : (bf16)0.f;
+        o[e + 4] = (float)h[e + 4] > 0.f ? (bf16)g1[e] : (bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(act + r * ACT_RS + cc * 16) = o;
+      *reinterpret_cast<bf16x8*>(a.out0 + (m0 + r) * CT_G + cc * 8) = o;
     }
   }
   // weight slab staging: 256 rows x 2*BK bytes, 4 chunks per thread; CPRW lanes cover one row slab
@@ -87,6 +118,19 @@ __global__ __launch_bounds__(NT) void g_chain_fwd_kernel(const bf16* __restrict_
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // backward: fetch this step's ReLU gate (the lane's 2x2x4 groups of 4 features) early, use it in the epilogue
+    u32x2 gt[2][2][4];
+    if constexpr (MODE == MODE_BWD) {
+      const bf16* gl = a.gate[l];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            gt[mt][nt][g] = *reinterpret_cast<const u32x2*>(
+                gl + (m0 + wm * 64 + mt * 32 + (lane & 31)) * CT_G + wn * 64 + nt * 32 + 8 * g + 4 * (lane >> 5));
+    }
     const int ns = a.K[l] / BK;
     for (int s = 0; s < ns; ++s) {
       const bool last_slab = (s == ns - 1);
@@ -115,42 +159,49 @@ __global__ __launch_bounds__(NT) void g_chain_fwd_kernel(const bf16* __restrict_
         }
       }
       if (has_next) lstore(cur ^ 1);
-      __syncthreads();                  // (A) all reads of wbuf[cur] / this act slab done; next slab visible
+      __syncthreads();                  // (A) all reads of wbuf[cur] / this tile slab done; next slab visible
       cur ^= 1;
     }
-    // ---- epilogue: bias + ReLU -> bf16 -> act tile in place (all waves are past barrier A)
-    const float* bl = a.bias[l];
-    if (!(abl & 2))
+    // ---- epilogue -> bf16 -> tile in place (all waves are past barrier A)
+    if (!(abl & 2)) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int row = wm * 64 + mt * 32 + (lane & 31);
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = wm * 64 + mt * 32 + (lane & 31);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nb = wn * 64 + nt * 32 + 8 * g + 4 * (lane >> 5);
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(bl + nb);
-          bf16x4 o;
+          for (int g = 0; g < 4; ++g) {
+            const int nb = wn * 64 + nt * 32 + 8 * g + 4 * (lane >> 5);
+            bf16x4 o;
+            if constexpr (MODE == MODE_FWD) {
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias[l] + nb);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16)fmaxf(acc[mt][nt][4 * g + r] + bv[r], 0.f);
-          *reinterpret_cast<bf16x4*>(act + row * ACT_RS + nb * 2) = o;
+              for (int r = 0; r < 4; ++r) o[r] = (bf16)fmaxf(acc[mt][nt][4 * g + r] + bv[r], 0.f);
+            } else {
+              union { u32x2 u; bf16x4 h; } gv;
+              gv.u = gt[mt][nt][g];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = (float)gv.h[r] > 0.f ? (bf16)acc[mt][nt][4 * g + r] : (bf16)0.f;
+            }
+            *reinterpret_cast<bf16x4*>(act + row * ACT_RS + nb * 2) = o;
+          }
         }
       }
     }
-    __syncthreads();                    // (B) the new activation tile is visible
-    // ---- copy the tile LDS -> HBM: TM rows x 512 B, 8 x 16-byte chunks per thread, row-contiguous
-    bf16* Hl = a.H[l];
-    if (Hl) {
+    __syncthreads();                    // (B) the new tile is visible
+    // ---- copy the tile LDS -> HBM: TM rows x 512 B, 16-byte chunks, row-contiguous
+    bf16* Ol = a.out[l];
+    if (Ol) {
 #pragma unroll
       for (int i = 0; i < TM * 32 / NT; ++i) {
         const int c = t + NT * i;
         const int r = c >> 5, cc = c & 31;
-        *reinterpret_cast<u32x4*>(Hl + (m0 + r) * CT_G + cc * 8) = *reinterpret_cast<const u32x4*>(act + r * ACT_RS + cc * 16);
+        *reinterpret_cast<u32x4*>(Ol + (m0 + r) * CT_G + cc * 8) = *reinterpret_cast<const u32x4*>(act + r * ACT_RS + cc * 16);
       }
     }
   }
-  // ---- pair-sum partial of this tile: column sums of the bf16 tile (fp32 accumulate, fixed order)
-  if (xg_part) {
+  // ---- forward: pair-sum partial of this tile = column sums of the bf16 tile (fp32, fixed order)
+  if (MODE == MODE_FWD && xg_part) {
     constexpr int NH = NT / 256, RPH = TM / NH;           // NH row groups of RPH rows, one thread per column
     const int c = t & 255, h = t >> 8;
     float s = 0.f;
@@ -192,13 +243,42 @@ extern "C" int rn_g_chain_fwd(const void* P, int ldp, const void* const* Wp, con
                  "rn_g_chain_fwd: layer %d pointers must be 16-byte aligned", l);
     a.W[l] = (const bf16*)Wp[l];
     a.bias[l] = bias[l];
-    a.H[l] = H ? (bf16*)H[l] : nullptr;
+    a.out[l] = H ? (bf16*)H[l] : nullptr;
     a.K[l] = K[l];
   }
   const char* ab = getenv("RN_CHAIN_ABLATE");
   const int abl = ab ? atoi(ab) : 0;
-  if (TM == 128) g_chain_fwd_kernel<128, 512, 64><<<M / 128, 512, 0, (hipStream_t)stream>>>((const bf16*)P, ldp, a, L, xg_part, abl);
-  else g_chain_fwd_kernel<64, 256, 32><<<M / 64, 256, 0, (hipStream_t)stream>>>((const bf16*)P, ldp, a, L, xg_part, abl);
+  hipStream_t s = (hipStream_t)stream;
+  if (TM == 128) g_chain_kernel<128, 512, 64, MODE_FWD><<<M / 128, 512, 0, s>>>((const bf16*)P, ldp, a, L, xg_part, abl);
+  else g_chain_kernel<64, 256, 32, MODE_FWD><<<M / 64, 256, 0, s>>>((const bf16*)P, ldp, a, L, xg_part, abl);
   RN_LAUNCH_CHECK("rn_g_chain_fwd");
+  return 0;
+}
+
+extern "C" int rn_g_chain_bwd(const void* HL, const float* dxg, const void* const* Wt, const void* const* Hgate,
+                              void* const* dZ, int dtype, int M, int rows_per_question, int L, int G, void* stream) {
+  RN_CHECK_ARG(HL && dxg && Wt && Hgate && dZ && M > 0, "rn_g_chain_bwd: bad pointer/size");
+  RN_CHECK_ARG(dtype == RN_BF16, "rn_g_chain_bwd: only the bf16 storage mode has a fused chain (dtype=%d)", dtype);
+  RN_CHECK_ARG(G == CT_G && L >= 2 && L <= CT_MAXL, "rn_g_chain_bwd: needs G == 256 and 2 <= L <= %d (G=%d L=%d)", CT_MAXL, G, L);
+  RN_CHECK_ARG(M % 128 == 0 && rows_per_question % 128 == 0 && M % rows_per_question == 0,
+               "rn_g_chain_bwd: M=%d and rows per question=%d must be multiples of 128", M, rows_per_question);
+  ChainArgs a;
+  memset(&a, 0, sizeof(a));
+  RN_CHECK_ARG(dZ[0] && (((uintptr_t)HL | (uintptr_t)dxg | (uintptr_t)dZ[0]) % 16 == 0), "rn_g_chain_bwd: bad HL/dxg/dZ[0]");
+  a.HL = (const bf16*)HL;
+  a.dxg = dxg;
+  a.out0 = (bf16*)dZ[0];
+  a.rows_per_b = rows_per_question;
+  for (int s = 0; s + 1 < L; ++s) {                      // L-1 dgrad steps: step s goes through layer L-1-s
+    RN_CHECK_ARG(Wt[s] && Hgate[s] && dZ[s + 1], "rn_g_chain_bwd: step %d has a NULL pointer", s);
+    RN_CHECK_ARG(((uintptr_t)Wt[s] | (uintptr_t)Hgate[s] | (uintptr_t)dZ[s + 1]) % 16 == 0,
+                 "rn_g_chain_bwd: step %d pointers must be 16-byte aligned", s);
+    a.W[s] = (const bf16*)Wt[s];
+    a.gate[s] = (const bf16*)Hgate[s];
+    a.out[s] = (bf16*)dZ[s + 1];
+    a.K[s] = CT_G;
+  }
+  g_chain_kernel<128, 512, 64, MODE_BWD><<<M / 128, 512, 0, (hipStream_t)stream>>>(nullptr, 0, a, L - 1, nullptr, 0);
+  RN_LAUNCH_CHECK("rn_g_chain_bwd");
   return 0;
 }

@@ -19,7 +19,14 @@ import torch.distributed as dist
 
 
 class FlatGradBucket:
-    """Every parameter's .grad is a view into one contiguous fp32 buffer (16-byte aligned slots)."""
+    """One contiguous fp32 buffer holding every parameter's gradient (the all-reduce message).
+
+    Two ways to fill it:
+      * accumulate mode (`zero_()` then backward): every p.grad is a view into the buffer, autograd
+        adds into it in place -- one add kernel per parameter;
+      * gather mode (`detach_()`, backward, `gather_()`): backward produces fresh gradient tensors
+        (no accumulation kernels, no memset) and ONE concatenation kernel packs them into the buffer,
+        after which the views are re-attached for the optimizer.  Used by the trainer."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
@@ -31,14 +38,37 @@ class FlatGradBucket:
             if p.dtype != torch.float32:
                 raise TypeError("FlatGradBucket expects fp32 master parameters")
             offs.append(total)
-            total += (p.numel() + 3) // 4 * 4
+            total += p.numel()
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.numel = sum(p.numel() for p in self.params)
-        for p, o in zip(self.params, offs):
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
+        self.numel = total
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, offs)]
+        self._zeros = {}
+        self.attach_()
+
+    def attach_(self):
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def detach_(self):
+        """Before backward in gather mode: autograd then assigns instead of accumulating."""
+        for p in self.params:
+            p.grad = None
+
+    def gather_(self):
+        """Pack the freshly produced gradients into the flat buffer (one cat kernel) and re-attach."""
+        parts = []
+        for p in self.params:
+            g = p.grad
+            if g is None:                                   # parameter unused in this graph (e.g. conv for *-sd)
+                g = self._zeros.get(p.numel())
+                if g is None:
+                    g = self._zeros[p.numel()] = torch.zeros(p.numel(), dtype=torch.float32, device=self.flat.device)
+            parts.append(g.reshape(-1))
+        torch.cat(parts, out=self.flat)
+        self.attach_()
 
     def zero_(self):
-        """Replaces optimizer.zero_grad(): one memset, and the .grad views stay attached."""
+        """Accumulate mode: replaces optimizer.zero_grad(): one memset, the .grad views stay attached."""
         self.flat.zero_()
 
     def check_attached(self):
@@ -91,10 +121,11 @@ class DataParallelTrainer:
         self._static = None
 
     def _fwd_bwd(self, img, qst, label):
-        self.bucket.zero_()
+        self.bucket.detach_()
         out = self.model(img, qst)
         loss = torch.nn.functional.nll_loss(out, label)
         loss.backward()
+        self.bucket.gather_()
         return loss
 
     def _capture(self, img, qst, label):
@@ -119,6 +150,7 @@ class DataParallelTrainer:
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
             self._graph.replay()
+            self.bucket.attach_()
             loss = self._loss
         else:
             loss = self._fwd_bwd(img, qst, label)

@@ -9,6 +9,8 @@ PyTorch only allocates buffers and supplies the stream; all arithmetic runs in
 librn_hip.so.  There is no CPU / eager fallback."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import rn_hip as H
@@ -85,7 +87,6 @@ def fused_chain_ok(plan: LayerPlan, code, B, n):
     """The fused LDS-resident chain (rn_chain.hip) covers the headline shape family: bf16 storage,
     all g widths 256, question injected at layer 0 (so every later layer has K == 256), and whole
     128-row tiles per question.  Everything else runs the per-layer kernels."""
-    import os
     if os.environ.get("RN_NO_FUSED_CHAIN", "0") == "1":
         return False
     return (code == H.RN_BF16 and all(w == 256 for w in plan.widths) and plan.kpad[0] <= 256
@@ -228,8 +229,17 @@ class RelationalFunction(torch.autograd.Function):
         # ---- g_theta backward
         dt = H.torch_dtype(code)
         inputs, wbwd, g_w = ctx.inputs, ctx.wbwd, ctx.g_w
-        dZ = torch.empty(M, G, dtype=dt, device=dev)
-        H.pair_sum_bwd(dxg, ctx.HL, G, dZ, G, code, B, n * n, G)
+        fused_bwd = (fused_chain_ok(plan, code, B, n) and L >= 2 and (n * n) % 128 == 0
+                     and os.environ.get("RN_NO_FUSED_BWD", "0") != "1")
+        if fused_bwd:
+            # one launch: dZ_L = dxg * (H_L > 0), then dZ_{l-1} = (dZ_l @ W_l) * (H_{l-1} > 0) for every layer
+            dZs = [torch.empty(M, G, dtype=dt, device=dev) for _ in range(L)]      # dZs[s] belongs to layer L-1-s
+            H.g_chain_bwd(ctx.HL, dxg, [wbwd[L - 1 - s] for s in range(L - 1)], [inputs[L - 1 - s] for s in range(L - 1)],
+                          dZs, code, M, n * n, G)
+            dZ_of = {L - 1 - s: dZs[s] for s in range(L)}
+        else:
+            dZ = torch.empty(M, G, dtype=dt, device=dev)
+            H.pair_sum_bwd(dxg, ctx.HL, G, dZ, G, code, B, n * n, G)
         ctx.HL = None
         gW, gB = [None] * L, [None] * L
         dq = None
@@ -238,6 +248,8 @@ class RelationalFunction(torch.autograd.Function):
             N = plan.widths[l]
             A_l = inputs[l]
             kt, kp = plan.ktrue[l], plan.kpad[l]
+            if fused_bwd:
+                dZ = dZ_of.pop(l)
             gW[l] = torch.empty(N, kt, **f32)
             gB[l] = torch.empty(N, **f32)
             H.g_linear_bwd_wgrad(dZ, N, A_l, kp, gW[l], gB[l], code, M, N, kp, kt)
@@ -258,7 +270,7 @@ class RelationalFunction(torch.autograd.Function):
                 dx = torch.empty(B, n, k, **f32)
                 H.gemm_f32(Rj, N, 1, wl, kt, 1, dx, k, B * n, k, N)                        # Rj @ W0[:, 0:k]
                 H.gemm_f32(Ri, N, 1, wl, kt, 1, dx, k, B * n, k, N, b_off=k, flags=H.RN_ACCUMULATE)   # + Ri @ W0[:, k:2k]
-            else:
+            elif not fused_bwd:
                 gp = plan.widths[l - 1]
                 dZp = torch.empty(M, gp, dtype=dt, device=dev)
                 H.g_linear_bwd_dgrad(dZ, N, wbwd[l], N, A_l, kp, dZp, gp, code, M, N, gp)

@@ -30,6 +30,7 @@ SIGNATURES = {
     "rn_g_linear_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_tile": (_I, []),
     "rn_g_chain_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_g_chain_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_pair_sum_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_sum_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_sum_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
@@ -177,6 +178,17 @@ def g_chain_fwd(P, ldp, Wps, biases, Hs, Ks, xg_part, code, M, G):
     hp = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs])
     kk = (C.c_int * L)(*Ks)
     _check(load().rn_g_chain_fwd(P.data_ptr(), ldp, wp, bp, hp, kk, _ptr(xg_part), code, M, L, G, _stream()), "rn_g_chain_fwd")
+
+
+@_timed("g_dgrad")
+def g_chain_bwd(HL, dxg, Wts, Hgates, dZs, code, M, rows_per_question, G):
+    """Fused backward chain: dZs[0] from (HL, dxg); dZs[s+1] through layer L-1-s gated by Hgates[s]."""
+    L = len(dZs)
+    wp = (C.c_void_p * (L - 1))(*[w.data_ptr() for w in Wts])
+    gp = (C.c_void_p * (L - 1))(*[h.data_ptr() for h in Hgates])
+    zp = (C.c_void_p * L)(*[z.data_ptr() for z in dZs])
+    _check(load().rn_g_chain_bwd(HL.data_ptr(), dxg.data_ptr(), wp, gp, zp, code, M, rows_per_question, L, G, _stream()),
+           "rn_g_chain_bwd")
 
 
 @_timed("pair_sum")

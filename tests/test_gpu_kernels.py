@@ -209,6 +209,30 @@ def test_g_chain_fwd_fused(H, K0, K0true, L, store):
         assert rel(part.cpu().numpy(), prev.reshape(M // T, T, G).sum(1, dtype=np.float64)) <= 2e-3
 
 
+def test_g_chain_bwd_fused(H):
+    """Fused backward chain: dZ[0] = dxg * (HL > 0) exactly; every further dZ must equal one un-fused
+    dgrad step applied to the kernel's OWN previous dZ (<= 1 bf16 ulp)."""
+    B, npairs, G, L = 2, 512, 256, 4
+    M = B * npairs
+    Hs = [bf16_round(np.maximum(formula.hash_uniform((M, G), 400 + l, -1, 1), 0)) for l in range(L)]   # H_1..H_L
+    dxg = formula.hash_uniform((B, G), 410, -1, 1)
+    Ws = [bf16_round(formula.hash_uniform((G, G), 420 + l, -0.15, 0.15)) for l in range(L)]           # W_l (out, in)
+    dZs = [torch.empty(M, G, dtype=torch.bfloat16, device="cuda") for _ in range(L)]
+    Wts = [dev(np.ascontiguousarray(Ws[L - 1 - s].T)).bfloat16() for s in range(L - 1)]              # (in, out)
+    gates = [dev(Hs[L - 2 - s]).bfloat16() for s in range(L - 1)]                                    # input act of layer L-1-s
+    H.g_chain_bwd(dev(Hs[L - 1]).bfloat16(), dev(dxg), Wts, gates, dZs, 0, M, npairs, G)
+    torch.cuda.synchronize()
+    ref0 = bf16_round(np.repeat(dxg, npairs, axis=0) * (Hs[L - 1] > 0))
+    got = dZs[0].float().cpu().numpy()
+    assert np.array_equal(got, ref0)
+    for s in range(L - 1):
+        ref = (got.astype(np.float64) @ Ws[L - 1 - s].astype(np.float64)) * (Hs[L - 2 - s] > 0)
+        got = dZs[s + 1].float().cpu().numpy()
+        err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
+        assert err.max() <= BF16_ULP, (s, err.max())
+        assert np.all(got[Hs[L - 2 - s] <= 0] == 0)
+
+
 # ----------------------------------------------------------------------------- K3
 @pytest.mark.parametrize("code", [0, 1])
 @pytest.mark.parametrize("B,npairs,G", [(4, 4096, 256), (3, 144, 512), (2, 38416, 256)])
