@@ -51,15 +51,20 @@ __global__ __launch_bounds__(NT) void g_chain_kernel(const bf16* __restrict__ P,
   constexpr int KSTEPS = BK / 16;
   constexpr int GM = TM / 64;                   // wave grid GM x GN, every wave owns 64 x 64
   static_assert(CT_G * CPRW / NT == 4 && NT / CPRW == 64 && (NT / 64) / GM == 4, "tile geometry");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[ACT_BYTES + 2 * WBUF_BYTES];
+  constexpr int BIAS_BYTES = (MODE == MODE_FWD) ? CT_MAXL / 2 * CT_G * 4 : 0;      // fwd: up to 4 layers of bias in LDS
+  __shared__ __attribute__((aligned(16))) unsigned char lds[ACT_BYTES + 2 * WBUF_BYTES + BIAS_BYTES];
   unsigned char* act = lds;
   unsigned char* wbuf = lds + ACT_BYTES;
+  float* bias_s = reinterpret_cast<float*>(lds + ACT_BYTES + 2 * WBUF_BYTES);
 
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w % GM, wn = w / GM;
   const long m0 = (long)blockIdx.x * TM;
 
   if constexpr (MODE == MODE_FWD) {
+    const bool bias_in_lds = L <= CT_MAXL / 2;
+    if (bias_in_lds)
+      for (int c = t; c < L * CT_G; c += NT) bias_s[c] = a.bias[c >> 8][c & 255];
     // ---- stage the P tile: TM rows x K0 columns -> tile[:, 0:K0]
     const int K0 = a.K[0];
     const int cpr = K0 >> 3;                              // 16-byte chunks per row
@@ -109,6 +114,19 @@ __global__ __launch_bounds__(NT) void g_chain_kernel(const bf16* __restrict__ P,
 
   const unsigned char* fa_base = act + (wm * 64 + (lane & 31)) * ACT_RS + (lane >> 5) * 16;
   const int fw_off = (wn * 64 + (lane & 31)) * W_RS + (lane >> 5) * 16;
+  // LDS -> HBM copy of the finished tile: TM rows x 512 B, 16-byte chunks, row-contiguous.  It is issued
+  // AFTER the next weight-slab loads of the following layer: vmcnt retires in order, so a load that is
+  // younger than these stores could only be waited for together with them (HBM write latency).
+  auto copy_out = [&](bf16* Ol) {
+    if (Ol) {
+#pragma unroll
+      for (int i = 0; i < TM * 32 / NT; ++i) {
+        const int c = t + NT * i;
+        const int r = c >> 5, cc = c & 31;
+        *reinterpret_cast<u32x4*>(Ol + (m0 + r) * CT_G + cc * 8) = *reinterpret_cast<const u32x4*>(act + r * ACT_RS + cc * 16);
+      }
+    }
+  };
   int cur = 0;
   for (int l = 0; l < L; ++l) {
     f32x16 acc[2][2];
@@ -139,6 +157,7 @@ __global__ __launch_bounds__(NT) void g_chain_kernel(const bf16* __restrict__ P,
         if (last_slab) gload(a.W[l + 1], a.K[l + 1], 0);
         else gload(a.W[l], a.K[l], s + 1);
       }
+      if (s == 0 && l > 0) copy_out(a.out[l - 1]);      // previous layer's tile (still intact in LDS until this layer's epilogue)
       const unsigned char* fw_base = wbuf + cur * WBUF_BYTES + fw_off;
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -174,7 +193,8 @@ __global__ __launch_bounds__(NT) void g_chain_kernel(const bf16* __restrict__ P,
             const int nb = wn * 64 + nt * 32 + 8 * g + 4 * (lane >> 5);
             bf16x4 o;
             if constexpr (MODE == MODE_FWD) {
-              const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias[l] + nb);
+              const f32x4 bv = (L <= CT_MAXL / 2) ? *reinterpret_cast<const f32x4*>(bias_s + l * CT_G + nb)
+                                                  : *reinterpret_cast<const f32x4*>(a.bias[l] + nb);
 #pragma unroll
               for (int r = 0; r < 4; ++r) o[r] = (bf16)fmaxf(acc[mt][nt][4 * g + r] + bv[r], 0.f);
             } else {
@@ -189,16 +209,7 @@ __global__ __launch_bounds__(NT) void g_chain_kernel(const bf16* __restrict__ P,
       }
     }
     __syncthreads();                    // (B) the new tile is visible
-    // ---- copy the tile LDS -> HBM: TM rows x 512 B, 16-byte chunks, row-contiguous
-    bf16* Ol = a.out[l];
-    if (Ol) {
-#pragma unroll
-      for (int i = 0; i < TM * 32 / NT; ++i) {
-        const int c = t + NT * i;
-        const int r = c >> 5, cc = c & 31;
-        *reinterpret_cast<u32x4*>(Ol + (m0 + r) * CT_G + cc * 8) = *reinterpret_cast<const u32x4*>(act + r * ACT_RS + cc * 16);
-      }
-    }
+    if (l == L - 1) copy_out(a.out[l]);
   }
   // ---- forward: pair-sum partial of this tile = column sums of the bf16 tile (fp32, fixed order)
   if (MODE == MODE_FWD && xg_part) {
