@@ -43,7 +43,7 @@ struct ChainArgs {
 // workgroups per CU), BK = K-slab width.
 template <int TM, int NT, int BK, int MODE>
 __global__ __launch_bounds__(NT) void g_chain_kernel(const bf16* __restrict__ P, int ldp, ChainArgs a, int L,
-                                                     float* __restrict__ xg_part, int abl) {
+                                                     float* __restrict__ xg_part) {
   constexpr int W_RS = BK * 2 + 16;             // weight slab row stride (144 / 80 B: conflict-free b128 reads)
   constexpr int ACT_BYTES = TM * ACT_RS;
   constexpr int WBUF_BYTES = CT_G * W_RS;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(NT) void g_chain_kernel(const bf16* __restrict__ P,
     const int ns = a.K[l] / BK;
     for (int s = 0; s < ns; ++s) {
       const bool last_slab = (s == ns - 1);
-      const bool has_next = !(last_slab && l == L - 1) && !(abl & 1);   // abl: timing ablations only (RN_CHAIN_ABLATE)
+      const bool has_next = !(last_slab && l == L - 1);
       if (has_next) {
         if (last_slab) gload(a.W[l + 1], a.K[l + 1], 0);
         else gload(a.W[l], a.K[l], s + 1);
@@ -167,22 +167,18 @@ __global__ __launch_bounds__(NT) void g_chain_kernel(const bf16* __restrict__ P,
           fa[mt] = *reinterpret_cast<const bf16x8*>(fa_base + mt * 32 * ACT_RS + s * (2 * BK) + ks * 32);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) fw[nt] = *reinterpret_cast<const bf16x8*>(fw_base + nt * 32 * W_RS + ks * 32);
-        if (!(abl & 4)) {
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nt], fa[mt], acc[mt][nt], 0, 0, 0);
-        } else {
-          asm volatile("" ::"v"(fw[0]), "v"(fw[1]), "v"(fa[0]), "v"(fa[1]));
-        }
+          for (int nt = 0; nt < 2; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nt], fa[mt], acc[mt][nt], 0, 0, 0);
       }
       if (has_next) lstore(cur ^ 1);
       __syncthreads();                  // (A) all reads of wbuf[cur] / this tile slab done; next slab visible
       cur ^= 1;
     }
     // ---- epilogue -> bf16 -> tile in place (all waves are past barrier A)
-    if (!(abl & 2)) {
+    {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int row = wm * 64 + mt * 32 + (lane & 31);
@@ -257,11 +253,9 @@ extern "C" int rn_g_chain_fwd(const void* P, int ldp, const void* const* Wp, con
     a.out[l] = H ? (bf16*)H[l] : nullptr;
     a.K[l] = K[l];
   }
-  const char* ab = getenv("RN_CHAIN_ABLATE");
-  const int abl = ab ? atoi(ab) : 0;
   hipStream_t s = (hipStream_t)stream;
-  if (TM == 128) g_chain_kernel<128, 512, 64, MODE_FWD><<<M / 128, 512, 0, s>>>((const bf16*)P, ldp, a, L, xg_part, abl);
-  else g_chain_kernel<64, 256, 32, MODE_FWD><<<M / 64, 256, 0, s>>>((const bf16*)P, ldp, a, L, xg_part, abl);
+  if (TM == 128) g_chain_kernel<128, 512, 64, MODE_FWD><<<M / 128, 512, 0, s>>>((const bf16*)P, ldp, a, L, xg_part);
+  else g_chain_kernel<64, 256, 32, MODE_FWD><<<M / 64, 256, 0, s>>>((const bf16*)P, ldp, a, L, xg_part);
   RN_LAUNCH_CHECK("rn_g_chain_fwd");
   return 0;
 }
@@ -289,7 +283,7 @@ extern "C" int rn_g_chain_bwd(const void* HL, const float* dxg, const void* cons
     a.out[s] = (bf16*)dZ[s + 1];
     a.K[s] = CT_G;
   }
-  g_chain_kernel<128, 512, 64, MODE_BWD><<<M / 128, 512, 0, (hipStream_t)stream>>>(nullptr, 0, a, L - 1, nullptr, 0);
+  g_chain_kernel<128, 512, 64, MODE_BWD><<<M / 128, 512, 0, (hipStream_t)stream>>>(nullptr, 0, a, L - 1, nullptr);
   RN_LAUNCH_CHECK("rn_g_chain_bwd");
   return 0;
 }
