@@ -43,7 +43,7 @@ struct ChainArgs {
 // workgroups per CU), BK = K-slab width.
 template <int TM, int NT, int BK, int MODE>
 __global__ __launch_bounds__(NT) void g_chain_kernel(const bf16* __restrict__ P, int ldp, ChainArgs a, int L,
-                                                     float* __restrict__ xg_part) {
+                                                     float* __restrict__ xg_part, unsigned long long* __restrict__ trace) {
   constexpr int W_RS = BK * 2 + 16;             // weight slab row stride (144 / 80 B: conflict-free b128 reads)
   constexpr int ACT_BYTES = TM * ACT_RS;
   constexpr int WBUF_BYTES = CT_G * W_RS;
@@ -60,6 +60,13 @@ __global__ __launch_bounds__(NT) void g_chain_kernel(const bf16* __restrict__ P,
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w % GM, wn = w / GM;
   const long m0 = (long)blockIdx.x * TM;
+  // optional phase timestamps (s_memtime) of wave 0 of a few workgroups: tools/trace_chain.py
+  int tp = 0;
+  const bool tracing = trace != nullptr && t == 0 && (blockIdx.x % 397) == 0;
+  auto stamp = [&]() {
+    if (tracing) trace[(blockIdx.x / 397) * 32 + (tp++)] = __builtin_amdgcn_s_memtime();
+  };
+  stamp();
 
   if constexpr (MODE == MODE_FWD) {
     const bool bias_in_lds = L <= CT_MAXL / 2;
@@ -111,6 +118,7 @@ __global__ __launch_bounds__(NT) void g_chain_kernel(const bf16* __restrict__ P,
   gload(a.W[0], a.K[0], 0);
   lstore(0);
   __syncthreads();
+  stamp();
 
   const unsigned char* fa_base = act + (wm * 64 + (lane & 31)) * ACT_RS + (lane >> 5) * 16;
   const int fw_off = (wn * 64 + (lane & 31)) * W_RS + (lane >> 5) * 16;
@@ -173,10 +181,20 @@ __global__ __launch_bounds__(NT) void g_chain_kernel(const bf16* __restrict__ P,
           for (int nt = 0; nt < 2; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nt], fa[mt], acc[mt][nt], 0, 0, 0);
       }
+#ifdef RN_CHAIN_TRACE_SLABS
+      if (l == 1) stamp();
+#endif
       if (has_next) lstore(cur ^ 1);
+#ifdef RN_CHAIN_TRACE_SLABS
+      if (l == 1) stamp();
+#endif
       __syncthreads();                  // (A) all reads of wbuf[cur] / this tile slab done; next slab visible
       cur ^= 1;
+#ifdef RN_CHAIN_TRACE_SLABS
+      if (l == 1) stamp();
+#endif
     }
+    stamp();
     // ---- epilogue -> bf16 -> tile in place (all waves are past barrier A)
     {
 #pragma unroll
@@ -205,8 +223,10 @@ __global__ __launch_bounds__(NT) void g_chain_kernel(const bf16* __restrict__ P,
       }
     }
     __syncthreads();                    // (B) the new tile is visible
+    stamp();
     if (l == L - 1) copy_out(a.out[l]);
   }
+  stamp();
   // ---- forward: pair-sum partial of this tile = column sums of the bf16 tile (fp32, fixed order)
   if (MODE == MODE_FWD && xg_part) {
     constexpr int NH = NT / 256, RPH = TM / NH;           // NH row groups of RPH rows, one thread per column
@@ -224,6 +244,9 @@ __global__ __launch_bounds__(NT) void g_chain_kernel(const bf16* __restrict__ P,
     }
   }
 }
+
+static unsigned long long* g_trace = nullptr;      // diagnostics only
+extern "C" void rn_debug_set_chain_trace(void* buf) { g_trace = (unsigned long long*)buf; }
 
 static int chain_tile_rows() {
   const char* te = getenv("RN_CHAIN_TILE");       // 128 (default; measured 279 us vs 326 us for 64) or 64
@@ -254,8 +277,8 @@ extern "C" int rn_g_chain_fwd(const void* P, int ldp, const void* const* Wp, con
     a.K[l] = K[l];
   }
   hipStream_t s = (hipStream_t)stream;
-  if (TM == 128) g_chain_kernel<128, 512, 64, MODE_FWD><<<M / 128, 512, 0, s>>>((const bf16*)P, ldp, a, L, xg_part);
-  else g_chain_kernel<64, 256, 32, MODE_FWD><<<M / 64, 256, 0, s>>>((const bf16*)P, ldp, a, L, xg_part);
+  if (TM == 128) g_chain_kernel<128, 512, 64, MODE_FWD><<<M / 128, 512, 0, s>>>((const bf16*)P, ldp, a, L, xg_part, g_trace);
+  else g_chain_kernel<64, 256, 32, MODE_FWD><<<M / 64, 256, 0, s>>>((const bf16*)P, ldp, a, L, xg_part, g_trace);
   RN_LAUNCH_CHECK("rn_g_chain_fwd");
   return 0;
 }
@@ -283,7 +306,7 @@ extern "C" int rn_g_chain_bwd(const void* HL, const float* dxg, const void* cons
     a.out[s] = (bf16*)dZ[s + 1];
     a.K[s] = CT_G;
   }
-  g_chain_kernel<128, 512, 64, MODE_BWD><<<M / 128, 512, 0, (hipStream_t)stream>>>(nullptr, 0, a, L - 1, nullptr);
+  g_chain_kernel<128, 512, 64, MODE_BWD><<<M / 128, 512, 0, (hipStream_t)stream>>>(nullptr, 0, a, L - 1, nullptr, g_trace);
   RN_LAUNCH_CHECK("rn_g_chain_bwd");
   return 0;
 }
