@@ -16,8 +16,8 @@ lib.rn_debug_set_chain_trace.argtypes=[ctypes.c_void_p]; lib.rn_debug_set_chain_
 H.g_chain_fwd(P,K0,Ws,bs,Hs,[K0,G,G,G],part,0,M,G); torch.cuda.synchronize()
 lib.rn_debug_set_chain_trace(None)
 t=tr.cpu().view(8,32)
-names=["start","P+W0","L0slabs","L0epi"]+["s%d_%s"%(s,x) for s in range(4) for x in ("compute","lstore","barrier")]+["L1tail","L1epi","L2slabs","L2epi","L3slabs","L3epi","end"]
-for blk in range(0,6):
+names=["start","staged"]+sum([["L%dslabs"%l,"L%depi"%l] for l in range(4)],[])+["end"]
+for blk in range(0,5):
     row=t[blk]; n=int((row!=0).sum())
     d=[int(row[i+1]-row[i]) for i in range(n-1)]
-    print("wg %4d:"%(blk*397), " ".join("%s=%d"%(names[i+1].replace(' ','_'),d[i]) for i in range(len(d))), "total",int(row[n-1]-row[0]))
+    print("wg %4d:"%(blk*50), " ".join("%s=%d"%(names[i+1].replace(' ','_'),d[i]) for i in range(len(d))), "total",int(row[n-1]-row[0]))
