@@ -9,12 +9,13 @@
 //            i.e. pair-sum broadcast + last ReLU gate + the whole dgrad chain; every dZ_l is written
 //            once (wgrad reads it), every H_l is read once (as the gate).
 //
-// Workgroup = 512 threads (8 waves = 2 per SIMD), one per CU (LDS-limited), tile 128(M) x 256(N);
-// wave (wm, wn) in a 2 x 4 grid owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles
-// (v_mfma_f32_32x32x16_bf16), 64 accumulator registers.  Operand assignment is swapped (weights =
-// MFMA A-operand) exactly as in rn_gemm.hip, so a lane ends up with 4 consecutive features of one
-// pair row -> one ds_write_b64 into the LDS tile; the tile is copied LDS -> HBM with 16-byte,
-// row-contiguous stores.
+// One workgroup per CU (LDS-limited), tile 128(M) x 256(N).  Two wave layouts (template NTILE):
+//   NTILE = 2: 512 threads, 8 waves (2 per SIMD) in a 2 x 4 grid, 64 x 64 per wave (64 accumulators);
+//   NTILE = 4: 256 threads, 4 waves (1 per SIMD, the whole 512-register file each) in a 2 x 2 grid,
+//              64 x 128 per wave (128 accumulators), 25 % fewer LDS fragment reads per MFMA.
+// MFMA = v_mfma_f32_32x32x16_bf16 with swapped operands (weights = A-operand) exactly as in
+// rn_gemm.hip, so a lane ends up with 4 consecutive features of one pair row -> one ds_write_b64
+// into the LDS tile; the tile is copied LDS -> HBM with 16-byte, row-contiguous stores.
 //
 // Weights (<= 128 KB per layer, bf16) stream from L2 in 64-wide K slabs into a 2-deep LDS ring:
 //   GLDS = true : LDS-DMA (global_load_lds_dwordx4): no VGPR staging, no ds_write; the slab image
@@ -27,7 +28,7 @@
 #include "rn_common.h"
 
 namespace {
-constexpr int CT_G = 256, CT_MAXL = 8, CT_TM = 128, CT_NT = 512, CT_BK = 64;
+constexpr int CT_G = 256, CT_MAXL = 8, CT_TM = 128, CT_BK = 64;
 constexpr int ACT_RS = CT_G * 2 + 16;        // 528 B: tile row stride (conflict-free b128 reads)
 constexpr int ACT_BYTES = CT_TM * ACT_RS;    // 67584
 enum { MODE_FWD = 0, MODE_BWD = 1 };
@@ -46,11 +47,17 @@ struct ChainArgs {
 };
 }  // namespace
 
-template <int MODE, bool GLDS>
-__global__ __launch_bounds__(CT_NT) void g_chain_kernel(const bf16* __restrict__ P, int ldp, ChainArgs a, int L,
-                                                        float* __restrict__ xg_part, int ntiles,
-                                                        unsigned long long* __restrict__ trace) {
-  constexpr int TM = CT_TM, NT = CT_NT, BK = CT_BK;
+template <int MODE, bool GLDS, int NTILE, bool PREFETCH, bool SKEW>
+__global__ __launch_bounds__(1024 / NTILE) void g_chain_kernel(const bf16* __restrict__ P, int ldp, ChainArgs a, int L,
+                                                               float* __restrict__ xg_part, int ntiles,
+                                                               unsigned long long* __restrict__ trace) {
+  constexpr int TM = CT_TM, BK = CT_BK;
+  constexpr int NT = 1024 / NTILE;                          // threads: 512 (8 waves) or 256 (4 waves)
+  constexpr int NW = NT / 64;
+  constexpr int WCOLS = 32 * NTILE;                         // output columns per wave (64 / 128)
+  constexpr int NST = TM * 32 / NT;                         // 16-byte chunks per thread of a full tile (8 / 16)
+  constexpr int IPW = 32 / NW;                              // LDS-DMA instructions per wave per slab (4 / 8)
+  constexpr int RWN = 2048 / NT;                            // register path: chunks per thread per slab (4 / 8)
   constexpr int W_RS = GLDS ? BK * 2 : BK * 2 + 16;        // weight slab row stride: 128 B linear / 144 B padded
   constexpr int WBUF_BYTES = CT_G * W_RS;
   constexpr int BIAS_BYTES = CT_MAXL / 2 * CT_G * 4;        // up to 4 layers of bias (fwd)
@@ -63,37 +70,59 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const bf16* __restrict__
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wu = __builtin_amdgcn_readfirstlane(w);         // provably wave-uniform copy for the LDS-DMA base
   const int wm = w & 1, wn = w >> 1;
-  // optional phase timestamps (s_memtime) of wave 0 for the first tile of a few workgroups: tools/trace_chain.py
+  // waves w and w + NW/2 share a SIMD (round-robin placement): the upper half runs the skewed schedule
+  const bool skew = SKEW && (wu >= NW / 2);
+  // optional phase timestamps (s_memtime) of wave 0 for the SECOND tile of a few workgroups: tools/trace_chain.py
   int tp = 0;
-  bool tracing = trace != nullptr && t == 0 && (blockIdx.x % 50) == 0;
+  bool tracing = false;
   auto stamp = [&]() {
     if (tracing) trace[(blockIdx.x / 50) * 32 + (tp++)] = __builtin_amdgcn_s_memtime();
   };
-  stamp();
 
   const bool bias_in_lds = (MODE == MODE_FWD) && L <= CT_MAXL / 2;
   if (bias_in_lds)
     for (int c = t; c < L * CT_G; c += NT) bias_s[c] = a.bias[c >> 8][c & 255];
 
   // ---- tile source prefetch (registers): fwd = P rows (K0 columns), bwd = H_L rows (256 columns)
-  u32x4 rp[8];
+  u32x4 rp[NST];
   const int cpr0 = (MODE == MODE_FWD) ? (a.K[0] >> 3) : 32;          // 16-byte chunks per source row
   auto prefetch_tile = [&](long m0n) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = t + NT * i;
-      if (c < TM * cpr0) {
-        const int r = c / cpr0, cc = c - r * cpr0;
-        if constexpr (MODE == MODE_FWD) rp[i] = *reinterpret_cast<const u32x4*>(P + (m0n + r) * ldp + cc * 8);
-        else rp[i] = *reinterpret_cast<const u32x4*>(a.HL + (m0n + r) * CT_G + cc * 8);
+    for (int i = 0; i < NST; ++i) {                           // always NST loads per thread (the slab barrier counts them)
+      int c = t + NT * i;
+      c = c < TM * cpr0 ? c : TM * cpr0 - 1;
+      const int r = c / cpr0, cc = c - r * cpr0;
+      if constexpr (MODE == MODE_FWD) rp[i] = *reinterpret_cast<const u32x4*>(P + (m0n + r) * ldp + cc * 8);
+      else rp[i] = *reinterpret_cast<const u32x4*>(a.HL + (m0n + r) * CT_G + cc * 8);
+    }
+  };
+  // Barrier at the end of a K slab.  LDS-DMA path: wait only for this slab's weight loads -- vmcnt retires
+  // in order, `younger` = VM operations issued after them (tile stores, next-tile prefetch) that may stay
+  // in flight -- plus all LDS traffic, then a raw s_barrier (a __syncthreads() would drain vmcnt to 0).
+  auto slab_barrier = [&](int younger) {
+    if constexpr (GLDS) {
+      if (younger < 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // no weight load pending
+      else if (younger >= 2 * NST) {
+        if constexpr (NST == 8) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
+      } else if (younger >= NST) {
+        if constexpr (NST == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      __syncthreads();
     }
   };
   auto stage_tile = [&](long m0) {
+    if constexpr (!PREFETCH) prefetch_tile(m0);               // no register prefetch: load the rows right here
     const float* gb = nullptr;
     if constexpr (MODE == MODE_BWD) gb = a.dxg + (long)(m0 / a.rows_per_b) * CT_G;   // a tile never straddles two questions
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NST; ++i) {
       const int c = t + NT * i;
       if (c < TM * cpr0) {
         const int r = c / cpr0, cc = c - r * cpr0;
@@ -120,47 +149,47 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const bf16* __restrict__
 
   // ---- weight slab loaders
   const int srow = t >> 3, scc = t & 7;                     // register path: 8 lanes cover one 128-byte row slab
-  u32x4 rw[4];
+  u32x4 rw[GLDS ? 1 : RWN];
   auto w_issue = [&](const bf16* Wl, int ldw, int slab, int buf) {
     if constexpr (GLDS) {
-      // wave `wu`, instruction s fills LDS bytes [(4*wu+s)*1024, +1024) = slab rows 8*(4*wu+s) .. +7;
+      // wave `wu`, instruction s fills LDS bytes [(IPW*wu+s)*1024, +1024) = slab rows 8*(IPW*wu+s) .. +7;
       // lane i lands at row + (i >> 3), chunk position i & 7 and must therefore FETCH chunk (i & 7) ^ swz(row)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int row = (4 * w + s) * 8 + (lane >> 3);
+      for (int s = 0; s < IPW; ++s) {
+        const int row = (IPW * w + s) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         const bf16* g = Wl + (long)row * ldw + slab * BK + chunk * 8;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(wbuf + buf * WBUF_BYTES + (4 * wu + s) * 1024),
+                                         (__attribute__((address_space(3))) void*)(wbuf + buf * WBUF_BYTES + (IPW * wu + s) * 1024),
                                          16, 0, 0);
       }
     } else {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-        rw[s] = *reinterpret_cast<const u32x4*>(Wl + (long)(srow + 64 * s) * ldw + slab * BK + scc * 8);
+      for (int s = 0; s < RWN; ++s)
+        rw[s] = *reinterpret_cast<const u32x4*>(Wl + (long)(srow + (NT / 8) * s) * ldw + slab * BK + scc * 8);
     }
   };
   auto w_commit = [&](int buf) {                             // register path only: regs -> padded LDS image
     if constexpr (!GLDS) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-        *reinterpret_cast<u32x4*>(wbuf + buf * WBUF_BYTES + (srow + 64 * s) * W_RS + scc * 16) = rw[s];
+      for (int s = 0; s < RWN; ++s)
+        *reinterpret_cast<u32x4*>(wbuf + buf * WBUF_BYTES + (srow + (NT / 8) * s) * W_RS + scc * 16) = rw[s];
     }
   };
 
   // fragment addressing
   const unsigned char* fa_base = act + (wm * 64 + (lane & 31)) * ACT_RS + (lane >> 5) * 16;
-  int fw_row_off[2], fw_swz[2];
+  int fw_row_off[NTILE], fw_swz[NTILE];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int r = wn * 64 + nt * 32 + (lane & 31);
+  for (int nt = 0; nt < NTILE; ++nt) {
+    const int r = wn * WCOLS + nt * 32 + (lane & 31);
     fw_row_off[nt] = r * W_RS;
     fw_swz[nt] = GLDS ? ((r >> 1) & 7) : 0;
   }
   auto copy_out = [&](bf16* Ol, long m0) {                   // LDS tile -> HBM, 16-byte chunks, row-contiguous
     if (Ol) {
 #pragma unroll
-      for (int i = 0; i < TM * 32 / NT; ++i) {
+      for (int i = 0; i < NST; ++i) {
         const int c = t + NT * i;
         const int r = c >> 5, cc = c & 31;
         *reinterpret_cast<u32x4*>(Ol + (m0 + r) * CT_G + cc * 8) = *reinterpret_cast<const u32x4*>(act + r * ACT_RS + cc * 16);
@@ -170,37 +199,49 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const bf16* __restrict__
 
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
-  prefetch_tile((long)tile * TM);
+  if constexpr (PREFETCH) prefetch_tile((long)tile * TM);
   w_issue(a.W[0], a.K[0], 0, 0);
   w_commit(0);
   int cur = 0;
   for (; tile < ntiles; tile += gridDim.x) {
     const long m0 = (long)tile * TM;
     const bool has_next_tile = tile + (int)gridDim.x < ntiles;
+    tracing = trace != nullptr && t == 0 && (blockIdx.x % 50) == 0 && tile == (int)(blockIdx.x + gridDim.x);
+    stamp();
     stage_tile(m0);
     __syncthreads();                    // tile, bias and weight slab `cur` visible (drains the LDS-DMA too)
     stamp();
     for (int l = 0; l < L; ++l) {
-      f32x16 acc[2][2];
+      f32x16 acc[2][NTILE];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NTILE; ++j)
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-      // backward: fetch this step's ReLU gate (the lane's 2x2x4 groups of 4 features) early, use it in the epilogue
-      u32x2 gt[2][2][4];
+      // backward: fetch this step's ReLU gate (the lane's groups of 4 features) early, use it in the epilogue
+      u32x2 gt[2][NTILE][4];
       if constexpr (MODE == MODE_BWD) {
         const bf16* gl = a.gate[l];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+          for (int nt = 0; nt < NTILE; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
               gt[mt][nt][g] = *reinterpret_cast<const u32x2*>(
-                  gl + (m0 + wm * 64 + mt * 32 + (lane & 31)) * CT_G + wn * 64 + nt * 32 + 8 * g + 4 * (lane >> 5));
+                  gl + (m0 + wm * 64 + mt * 32 + (lane & 31)) * CT_G + wn * WCOLS + nt * 32 + 8 * g + 4 * (lane >> 5));
       }
+      bf16x8 fa[2][2], fw[2][NTILE];                 // one half slab of fragments
+      auto mma_half = [&]() {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTILE; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[k2][nt], fa[k2][mt], acc[mt][nt], 0, 0, 0);
+      };
       const int ns = a.K[l] / BK;
       for (int s = 0; s < ns; ++s) {
         const bool last_slab = (s == ns - 1);
@@ -211,45 +252,68 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const bf16* __restrict__
           else if (last_slab) w_issue(a.W[l + 1], a.K[l + 1], 0, cur ^ 1);
           else w_issue(a.W[l], a.K[l], s + 1, cur ^ 1);
         }
+        int younger = 0;
         if (s == 0) {
           // stores / source prefetch go AFTER the weight loads: vmcnt retires in order
-          if (l > 0) copy_out(a.out[l - 1], m0);      // previous layer's tile (intact in LDS until this layer's epilogue)
-          if (l == L - 1 && has_next_tile) prefetch_tile((long)(tile + gridDim.x) * TM);
-        }
-        const unsigned char* wb = wbuf + cur * WBUF_BYTES + (lane >> 5) * 16 * (GLDS ? 0 : 1);
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-          bf16x8 fa[2], fw[2];
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-            fa[mt] = *reinterpret_cast<const bf16x8*>(fa_base + mt * 32 * ACT_RS + s * (2 * BK) + ks * 32);
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            if constexpr (GLDS)
-              fw[nt] = *reinterpret_cast<const bf16x8*>(wb + fw_row_off[nt] + (((2 * ks + (lane >> 5)) ^ fw_swz[nt]) << 4));
-            else
-              fw[nt] = *reinterpret_cast<const bf16x8*>(wb + fw_row_off[nt] + ks * 32);
+          if (l > 0) {
+            copy_out(a.out[l - 1], m0);               // previous layer's tile (intact in LDS until this layer's epilogue)
+            if (a.out[l - 1]) younger += NST;
           }
+        }
+        if (PREFETCH && last_of_tile && has_next_tile) {
+          // next tile's source rows: issued in the LAST slab, after the last weight load of this tile, so no
+          // later wait has to drain them (in-order vmcnt); they land under the epilogue / copy-out / pair sum
+          prefetch_tile((long)(tile + gridDim.x) * TM);
+          younger += NST;
+        }
+        const unsigned char* wb = wbuf + cur * WBUF_BYTES + (GLDS ? 0 : (lane >> 5) * 16);
+        // One half slab = 2 K16 steps: 4 + 2*NTILE fragment reads, then 4*NTILE MFMAs.
+        auto read_half = [&](int h) {
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
+          for (int k2 = 0; k2 < 2; ++k2) {
+            const int ks = 2 * h + k2;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+            for (int mt = 0; mt < 2; ++mt)
+              fa[k2][mt] = *reinterpret_cast<const bf16x8*>(fa_base + mt * 32 * ACT_RS + s * (2 * BK) + ks * 32);
+#pragma unroll
+            for (int nt = 0; nt < NTILE; ++nt) {
+              if constexpr (GLDS)
+                fw[k2][nt] = *reinterpret_cast<const bf16x8*>(wb + fw_row_off[nt] + (((2 * ks + (lane >> 5)) ^ fw_swz[nt]) << 4));
+              else
+                fw[k2][nt] = *reinterpret_cast<const bf16x8*>(wb + fw_row_off[nt] + ks * 32);
+            }
+          }
+        };
+        if (!skew) {
+          read_half(0);
+          mma_half();
+          read_half(1);
+          mma_half();
+        } else {
+          // the second wave of every SIMD runs half a slab behind: it still owes the MFMAs of the previous
+          // slab's second half (fragments already in registers) while its partner is reading, and it reads
+          // its own second half BEFORE the barrier to multiply it after -- LDS and MFMA phases of the two
+          // waves of a SIMD interleave instead of colliding.
+          if (s > 0) mma_half();
+          read_half(0);
+          mma_half();
+          read_half(1);
         }
         if (has_next) w_commit(cur ^ 1);
-        __syncthreads();                  // (A) all reads of wbuf[cur] / this tile slab done; next slab visible
+        slab_barrier(has_next ? younger : -1);       // (A) all reads of wbuf[cur] / this tile slab done; next slab visible
         cur ^= 1;
       }
+      if (skew) mma_half();                          // the trailing half slab of the skewed waves
       stamp();
       // ---- epilogue -> bf16 -> tile in place (all waves are past barrier A)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int row = wm * 64 + mt * 32 + (lane & 31);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NTILE; ++nt) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const int nb = wn * 64 + nt * 32 + 8 * g + 4 * (lane >> 5);
+            const int nb = wn * WCOLS + nt * 32 + 8 * g + 4 * (lane >> 5);
             bf16x4 o;
             if constexpr (MODE == MODE_FWD) {
               const f32x4 bv = bias_in_lds ? *reinterpret_cast<const f32x4*>(bias_s + l * CT_G + nb)
@@ -272,16 +336,20 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const bf16* __restrict__
     copy_out(a.out[L - 1], m0);
     // ---- forward: pair-sum partial of this tile = column sums of the bf16 tile (fp32, fixed order)
     if (MODE == MODE_FWD && xg_part) {
+      constexpr int NH = NT / 256, RPH = TM / NH;
       const int c = t & 255, h = t >> 8;
       float s = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < 64; ++r) s += (float)*reinterpret_cast<const bf16*>(act + (h * 64 + r) * ACT_RS + c * 2);
-      if (h == 1) red[c] = s;
-      __syncthreads();
-      if (h == 0) xg_part[(long)tile * CT_G + c] = s + red[c];
+      for (int r = 0; r < RPH; ++r) s += (float)*reinterpret_cast<const bf16*>(act + (h * RPH + r) * ACT_RS + c * 2);
+      if constexpr (NH == 2) {
+        if (h == 1) red[c] = s;
+        __syncthreads();
+        if (h == 0) xg_part[(long)tile * CT_G + c] = s + red[c];
+      } else {
+        xg_part[(long)tile * CT_G + c] = s;
+      }
     }
     stamp();
-    tracing = false;
     __syncthreads();                      // (C) every reader of the tile is done before the next tile is staged
   }
 }
@@ -302,6 +370,23 @@ static int num_cus() {
 static bool use_glds() {
   const char* e = getenv("RN_CHAIN_GLDS");          // default on; RN_CHAIN_GLDS=0 selects the register-staged slabs
   return !(e && e[0] == '0');
+}
+
+template <int MODE>
+static void chain_launch(int grid, hipStream_t s, const bf16* P, int ldp, const ChainArgs& a, int L, float* xg_part,
+                         int ntiles) {
+  const bool gl = use_glds();
+  const char* pe = getenv("RN_CHAIN_PREFETCH");
+  const bool pf = !(pe && pe[0] == '0');
+  const char* se = getenv("RN_CHAIN_SKEW");
+  const bool sk = (se && se[0] == '1');              // experimental (register spills make it slower): off by default
+#define RN_CHAIN_GO(G, PFV, SKV) g_chain_kernel<MODE, G, 2, PFV, SKV><<<grid, 512, 0, s>>>(P, ldp, a, L, xg_part, ntiles, g_trace)
+  if (!gl) RN_CHAIN_GO(false, true, false);
+  else if (pf && sk) RN_CHAIN_GO(true, true, true);
+  else if (pf) RN_CHAIN_GO(true, true, false);
+  else if (sk) RN_CHAIN_GO(true, false, true);
+  else RN_CHAIN_GO(true, false, false);
+#undef RN_CHAIN_GO
 }
 
 extern "C" int rn_g_chain_tile(void) { return CT_TM; }
@@ -329,9 +414,7 @@ extern "C" int rn_g_chain_fwd(const void* P, int ldp, const void* const* Wp, con
   }
   const int ntiles = M / CT_TM;
   const int grid = ntiles < num_cus() ? ntiles : num_cus();
-  hipStream_t s = (hipStream_t)stream;
-  if (use_glds()) g_chain_kernel<MODE_FWD, true><<<grid, CT_NT, 0, s>>>((const bf16*)P, ldp, a, L, xg_part, ntiles, g_trace);
-  else g_chain_kernel<MODE_FWD, false><<<grid, CT_NT, 0, s>>>((const bf16*)P, ldp, a, L, xg_part, ntiles, g_trace);
+  chain_launch<MODE_FWD>(grid, (hipStream_t)stream, (const bf16*)P, ldp, a, L, xg_part, ntiles);
   RN_LAUNCH_CHECK("rn_g_chain_fwd");
   return 0;
 }
@@ -361,9 +444,7 @@ extern "C" int rn_g_chain_bwd(const void* HL, const float* dxg, const void* cons
   }
   const int ntiles = M / CT_TM;
   const int grid = ntiles < num_cus() ? ntiles : num_cus();
-  hipStream_t st = (hipStream_t)stream;
-  if (use_glds()) g_chain_kernel<MODE_BWD, true><<<grid, CT_NT, 0, st>>>(nullptr, 0, a, L - 1, nullptr, ntiles, g_trace);
-  else g_chain_kernel<MODE_BWD, false><<<grid, CT_NT, 0, st>>>(nullptr, 0, a, L - 1, nullptr, ntiles, g_trace);
+  chain_launch<MODE_BWD>(grid, (hipStream_t)stream, nullptr, 0, a, L - 1, nullptr, ntiles);
   RN_LAUNCH_CHECK("rn_g_chain_bwd");
   return 0;
 }
