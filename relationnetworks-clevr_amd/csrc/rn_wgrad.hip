@@ -20,7 +20,9 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const T* __restrict__ dZ, in
                                                     int M, int N, int Kpad, int rows_per_split) {
   constexpr int CH = Elem<T>::kPer16B;
   constexpr int ROWS = WG<T>::ROWS;
-  constexpr int RSZ = 256 * (int)sizeof(T) + 16;          // LDS row stride (bytes), both tiles
+  // LDS row stride (bytes), both tiles.  bf16: +64 B so that the 4 rows x 64 B a 32-lane group of
+  // ds_read_b64_tr_b16 touches land on 4 distinct 16-bank quarters (stride = 16 dwords mod 64); fp32: +16 B.
+  constexpr int RSZ = 256 * (int)sizeof(T) + (sizeof(T) == 2 ? 64 : 16);
   constexpr int CPZ = 256 / CH;                            // 16-byte chunks per dZ tile row
   constexpr int CPA = NKT * 32 / CH;                       // chunks per A tile row
   constexpr int NZ = ROWS * CPZ / 512;                     // dZ chunks per thread per step (4)
