@@ -73,11 +73,12 @@ int rn_g_linear_fwd(const void* A, int lda, const void* Wp, int ldw, const float
  * path).  Runs all L g layers (model.py:130-145) for every T-row tile of P with the 256-wide
  * activation tile resident in LDS; each activation is written once to H[l] (M, 256) -- or not at
  * all when H or H[l] is NULL (inference) -- and never read back.  xg_part (M/T, 256) fp32 receives
- * the per-tile column sums of the last activation (model.py:151-152); reduce them per question
+ * the per-tile column sums of the last activation (model.py:151-152) -- pass NULL when n*n is not a
+ * multiple of T (tiles straddle questions; use rn_pair_sum_fwd on H[L-1] instead); reduce them per question
  * with rn_pair_sum_fwd(xg_part, ..., RN_F32, B, n*n/T, 256).
  * Wp[l]: packed (256, K[l]) weights with ld == K[l]; K[0] % 64 == 0, K[0] <= 256, K[l>0] == 256;
  * Wp / bias / H / K are HOST arrays of L entries.  G == 256; M must be a multiple of the tile
- * height T = rn_g_chain_tile() (128, or 64 with RN_CHAIN_TILE=64) and xg_part has M/T rows. */
+ * height T = rn_g_chain_tile() (128) and xg_part, when given, has M/T rows. */
 int rn_g_chain_tile(void);
 int rn_g_chain_fwd(const void* P, int ldp, const void* const* Wp, const float* const* bias, void* const* H,
                    const int* K, float* xg_part, int dtype, int M, int L, int G, void* stream);
@@ -89,7 +90,7 @@ int rn_g_chain_fwd(const void* P, int ldp, const void* const* Wp, const float* c
  * Wt[s]: transposed packed weight of layer L-1-s, (256 in, 256 out) row-major (rn_pack_matrix);
  * Hgate[s]: the INPUT activation of layer L-1-s (= output of layer L-2-s), (M, 256).
  * All dZ (M, 256) are written (wgrad consumes them).  Wt / Hgate / dZ are HOST arrays.
- * Requires G == 256, L >= 2, M and rows_per_question (= n*n) multiples of 128. */
+ * Requires G == 256, L >= 2, M % 128 == 0 (a 128-row tile may straddle two questions). */
 int rn_g_chain_bwd(const void* HL, const float* dxg, const void* const* Wt, const void* const* Hgate,
                    void* const* dZ, int dtype, int M, int rows_per_question, int L, int G, void* stream);
 

@@ -119,8 +119,6 @@ __global__ __launch_bounds__(1024 / NTILE) void g_chain_kernel(const bf16* __res
   };
   auto stage_tile = [&](long m0) {
     if constexpr (!PREFETCH) prefetch_tile(m0);               // no register prefetch: load the rows right here
-    const float* gb = nullptr;
-    if constexpr (MODE == MODE_BWD) gb = a.dxg + (long)(m0 / a.rows_per_b) * CT_G;   // a tile never straddles two questions
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
       const int c = t + NT * i;
@@ -132,6 +130,7 @@ __global__ __launch_bounds__(1024 / NTILE) void g_chain_kernel(const bf16* __res
           // dZ_L = dxg[b] * (H_L > 0): backward of the pair sum + last ReLU; also stored to HBM for wgrad
           union { u32x4 u; bf16x8 h; } hv;
           hv.u = rp[i];
+          const float* gb = a.dxg + ((m0 + r) / a.rows_per_b) * CT_G;     // question of THIS row (tiles may straddle)
           const f32x4 g0 = *reinterpret_cast<const f32x4*>(gb + cc * 8);
           const f32x4 g1 = *reinterpret_cast<const f32x4*>(gb + cc * 8 + 4);
           bf16x8 o;
@@ -424,8 +423,8 @@ extern "C" int rn_g_chain_bwd(const void* HL, const float* dxg, const void* cons
   RN_CHECK_ARG(HL && dxg && Wt && Hgate && dZ && M > 0, "rn_g_chain_bwd: bad pointer/size");
   RN_CHECK_ARG(dtype == RN_BF16, "rn_g_chain_bwd: only the bf16 storage mode has a fused chain (dtype=%d)", dtype);
   RN_CHECK_ARG(G == CT_G && L >= 2 && L <= CT_MAXL, "rn_g_chain_bwd: needs G == 256 and 2 <= L <= %d (G=%d L=%d)", CT_MAXL, G, L);
-  RN_CHECK_ARG(M % CT_TM == 0 && rows_per_question % CT_TM == 0 && M % rows_per_question == 0,
-               "rn_g_chain_bwd: M=%d and rows per question=%d must be multiples of %d", M, rows_per_question, CT_TM);
+  RN_CHECK_ARG(M % CT_TM == 0 && rows_per_question > 0 && M % rows_per_question == 0,
+               "rn_g_chain_bwd: M=%d must be a multiple of %d and of rows per question=%d", M, CT_TM, rows_per_question);
   ChainArgs a;
   memset(&a, 0, sizeof(a));
   RN_CHECK_ARG(dZ[0] && (((uintptr_t)HL | (uintptr_t)dxg | (uintptr_t)dZ[0]) % 16 == 0), "rn_g_chain_bwd: bad HL/dxg/dZ[0]");

@@ -90,7 +90,7 @@ def fused_chain_ok(plan: LayerPlan, code, B, n):
     if os.environ.get("RN_NO_FUSED_CHAIN", "0") == "1":
         return False
     return (code == H.RN_BF16 and all(w == 256 for w in plan.widths) and plan.kpad[0] <= 256
-            and all(kp == 256 for kp in plan.kpad[1:]) and (n * n) % H.g_chain_tile() == 0 and plan.L <= 8)
+            and all(kp == 256 for kp in plan.kpad[1:]) and (B * n * n) % H.g_chain_tile() == 0 and plan.L <= 8)
 
 
 def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None):
@@ -110,13 +110,19 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
     if layer_hook is None and fused_chain_ok(plan, code, B, n):
         G = plan.widths[-1]
         L = plan.L
-        # activations are stored only when the backward pass will need them
-        Hs = [torch.empty(M, G, dtype=dt, device=dev) if keep_inputs else None for _ in range(L)]
         T = H.g_chain_tile()
-        part = torch.empty(M // T, G, dtype=torch.float32, device=dev)
+        whole = (n * n) % T == 0                    # whole tiles per question -> pair sum from the on-chip tiles
+        # activations are stored only when the backward pass will need them (the last one also feeds the
+        # stand-alone pair sum when tiles straddle questions)
+        Hs = [torch.empty(M, G, dtype=dt, device=dev) if (keep_inputs or (l == L - 1 and not whole)) else None
+              for l in range(L)]
+        part = torch.empty(M // T, G, dtype=torch.float32, device=dev) if whole else None
         H.g_chain_fwd(P, ld0, wfwd, g_b, Hs, plan.kpad, part, code, M, G)
         xg = torch.empty(B, G, dtype=torch.float32, device=dev)
-        H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // T, G)
+        if whole:
+            H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // T, G)
+        else:
+            H.pair_sum_fwd(Hs[-1], G, xg, code, B, n * n, G)
         return [P] + Hs[:-1], Hs[-1], xg
     inputs = [P]
     cur = P
@@ -229,8 +235,7 @@ class RelationalFunction(torch.autograd.Function):
         # ---- g_theta backward
         dt = H.torch_dtype(code)
         inputs, wbwd, g_w = ctx.inputs, ctx.wbwd, ctx.g_w
-        fused_bwd = (fused_chain_ok(plan, code, B, n) and L >= 2 and (n * n) % 128 == 0
-                     and os.environ.get("RN_NO_FUSED_BWD", "0") != "1")
+        fused_bwd = fused_chain_ok(plan, code, B, n) and L >= 2 and os.environ.get("RN_NO_FUSED_BWD", "0") != "1"
         if fused_bwd:
             # one launch: dZ_L = dxg * (H_L > 0), then dZ_{l-1} = (dZ_l @ W_l) * (H_{l-1} > 0) for every layer
             dZs = [torch.empty(M, G, dtype=dt, device=dev) for _ in range(L)]      # dZs[s] belongs to layer L-1-s

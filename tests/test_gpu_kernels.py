@@ -180,7 +180,7 @@ def test_g_chain_fwd_fused(H, K0, K0true, L, store):
     """Fused LDS-resident chain: every stored activation must equal one un-fused layer applied to the
     kernel's OWN previous activation (<= 1 bf16 ulp), and the per-tile pair-sum partials must be
     the column sums of the last activation."""
-    M, G = 1024, 256
+    M, G = 1024 if L == 2 else 40960, 256          # 40960 rows = 320 tiles > 256 CUs: persistent loop exercised
     P = np.zeros((M, K0), np.float32); P[:, :K0true] = formula.hash_uniform((M, K0true), 300, -1, 1)
     P = bf16_round(P)
     Ws, bs, Ks = [], [], []
@@ -209,10 +209,12 @@ def test_g_chain_fwd_fused(H, K0, K0true, L, store):
         assert rel(part.cpu().numpy(), prev.reshape(M // T, T, G).sum(1, dtype=np.float64)) <= 2e-3
 
 
-def test_g_chain_bwd_fused(H):
+@pytest.mark.parametrize("B,npairs", [(2, 512), (8, 144), (300, 256)])
+def test_g_chain_bwd_fused(H, B, npairs):
     """Fused backward chain: dZ[0] = dxg * (HL > 0) exactly; every further dZ must equal one un-fused
-    dgrad step applied to the kernel's OWN previous dZ (<= 1 bf16 ulp)."""
-    B, npairs, G, L = 2, 512, 256, 4
+    dgrad step applied to the kernel's OWN previous dZ (<= 1 bf16 ulp).  (8, 144): 128-row tiles
+    straddle questions; (300, 256): more tiles than CUs (persistent loop + next-tile prefetch)."""
+    G, L = 256, 4
     M = B * npairs
     Hs = [bf16_round(np.maximum(formula.hash_uniform((M, G), 400 + l, -1, 1), 0)) for l in range(L)]   # H_1..H_L
     dxg = formula.hash_uniform((B, G), 410, -1, 1)
