@@ -194,7 +194,44 @@ def record_pretrained():
         print(tag, len(arrs), lp.shape)
 
 
+def record_train_traj(tag, cfg, b, steps, seed, lr=1e-4):
+    """N1: the reference's training step (train.py:36-48) -- zero_grad, forward, nll_loss, backward,
+    clip_grad_norm(50), Adam(weight_decay=1e-4) -- run for a few steps on fixed closed-form batches with
+    the reference's own model (dropout overridden to 0 as train.py:207-208 allows, train-mode BatchNorm).
+    Questions are reversed and labels shifted to 0-based exactly as utils.load_tensor_data does
+    (utils.py:138-149; restated here because utils.py's Variable(volatile=...) idiom is torch-0.3 only)."""
+    hyp = dict(REF_HYP[cfg], dropout=0.0)
+    m = refmodel.RN(Args, hyp)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = formula.formula_fill_state(shapes, seed)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=lr, weight_decay=1e-4)
+    losses, norms = [], []
+    for s in range(steps):
+        img = torch.from_numpy(formula.hash_uniform((b, 3, 128, 128), seed + 10 * s + 1, 0.0, 1.0))
+        qst = torch.from_numpy(formula.hash_ints((b, 20), seed + 10 * s + 2, 1, formula.QDICT + 1))
+        ans = torch.from_numpy(formula.hash_ints((b, 1), seed + 10 * s + 3, 1, formula.ADICT + 1))      # 1-based like the dataset
+        qst = qst.index_select(1, torch.arange(qst.size(1) - 1, -1, -1).long())
+        label = (ans - 1).squeeze(1)
+        opt.zero_grad()
+        loss = F.nll_loss(m(img, qst), label)
+        loss.backward()
+        norms.append(float(torch.nn.utils.clip_grad_norm_(m.parameters(), 50.0)))
+        opt.step()
+        losses.append(loss.item())
+    final = {k: v.detach().numpy() for k, v in m.state_dict().items() if k in ("rl.g_layers.0.bias", "rl.f_fc3.bias", "conv.batchNorm4.running_mean")}
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), losses=np.array(losses), grad_norms=np.array(norms),
+                        state_names=np.array(json.dumps({k: list(v) for k, v in shapes.items()})),
+                        **{"final/" + k: v for k, v in final.items()},
+                        meta=np.array(json.dumps(dict(cfg=cfg, b=b, steps=steps, seed=seed, lr=lr))))
+    print(tag, "losses", losses, "norms", norms)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "traj":
+        record_train_traj("G-traj", "original-fp", 8, 4, seed=91)
+        sys.exit(0)
     record_rl("G-sd4", "original-sd", 4, 12, seed=11, full=True)
     record_rl("G-irsd4", "ir-sd", 4, 12, seed=12, full=True)
     record_rl("G-fp-small", "original-fp", 2, 64, seed=21, strided=True, full=True, full_grads=True)
@@ -207,3 +244,4 @@ if __name__ == "__main__":
     record_e2e("G-e2e-ir", "ir-fp", 4, seed=72)
     record_extract("G-extract", "ir-fp", 4, seed=81)
     record_pretrained()
+    record_train_traj("G-traj", "original-fp", 8, 4, seed=91)

@@ -1,0 +1,160 @@
+"""Train driver: host logic on CPU; trajectory parity on the GPU."""
+import io
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import gold
+from oracle import formula
+
+
+@pytest.fixture(scope="module")
+def T():
+    import relationnetworks_clevr_amd.train as t
+    return t
+
+
+def test_lr_slow_start_matches_reference_steplr(T):
+    """train.py:330-333,349-350 -- emulate torch-0.3 StepLR(step=20, gamma=2) with last_epoch = start_epoch = 1,
+    stepped once per epoch while lr < lr_max."""
+    def ref(epoch):
+        last, lr = 1, 5e-6
+        for _ in range(epoch):
+            if lr < 5e-4:
+                last += 1
+                lr = 5e-6 * 2 ** (last // 20)
+        return lr
+    for e in (1, 2, 18, 19, 20, 38, 39, 59, 100, 138, 139, 140, 300):
+        assert T.lr_for_epoch(e) == pytest.approx(ref(e), rel=1e-12)
+    assert T.lr_for_epoch(1) == 5e-6 and T.lr_for_epoch(18) == 5e-6 and T.lr_for_epoch(19) == 1e-5
+    assert T.lr_for_epoch(350) == pytest.approx(6.4e-4)                  # freezes at the first value >= lr_max
+    assert T.lr_for_epoch(100, lr_gamma=1.0) == 5e-6
+    assert T.batch_size_for_epoch(50, 640) == 640
+    assert T.batch_size_for_epoch(45, 32, bs_max=100, bs_gamma=2.0, bs_step=20) == 100
+    assert T.batch_size_for_epoch(25, 32, bs_max=-1, bs_gamma=2.0, bs_step=20) == 64
+
+
+def test_load_tensor_data_semantics(T):
+    """utils.py:133-150: question reversed (pad zeros first), labels 1-based (B,1) -> 0-based (B,)."""
+    batch = {"image": torch.zeros(2, 3, 4, 4), "question": torch.tensor([[5, 6, 7, 0, 0], [1, 2, 3, 4, 9]]),
+             "answer": torch.tensor([[3], [28]])}
+    img, q, y = T.load_tensor_data(batch, "cpu", invert_questions=True)
+    assert q.tolist() == [[0, 0, 7, 6, 5], [9, 4, 3, 2, 1]] and y.tolist() == [2, 27]
+    _, q2, _ = T.load_tensor_data(batch, "cpu", invert_questions=False)
+    assert q2.tolist() == batch["question"].tolist()
+
+
+def test_synthetic_batches_have_reference_shapes(T):
+    ds = T.SyntheticClevr(10, 5)
+    b = next(iter(ds))
+    assert len(ds) == 2 and b["image"].shape == (5, 3, 128, 128) and b["question"].shape == (5, 20) and b["answer"].shape == (5, 1)
+    assert b["question"].dtype == torch.int64 and 1 <= int(b["answer"].min()) and int(b["answer"].max()) <= 28
+    assert float(b["image"].min()) >= 0 and float(b["image"].max()) < 1
+    sd = next(iter(T.SyntheticClevr(8, 4, state_description=True)))
+    assert sd["image"].shape == (4, 12, 7) and bool((sd["image"][:, -1] == 0).all())
+
+
+def test_checkpoint_roundtrip_and_module_prefix(T, tmp_path):
+    import relationnetworks_clevr_amd as pkg
+
+    class A:
+        qdict_size, adict_size = 82, 28
+
+    m = pkg.RN(A, formula.HYP["original-fp"])
+    p = T.save_checkpoint(m, str(tmp_path), 7)
+    assert os.path.basename(p) == "RN_epoch_07.pth"
+    m2 = pkg.RN(A, formula.HYP["original-fp"])
+    assert T.load_checkpoint(m2, p) == 7
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    pref = str(tmp_path / "RN_epoch_12.pth")
+    torch.save({"module." + k: v for k, v in m.state_dict().items()}, pref)          # saved from DataParallel
+    assert T.load_checkpoint(m2, pref) == 12
+    m3 = pkg.RN(A, formula.HYP["original-fp"])
+    T.load_checkpoint(m3, p, conv_only=True)
+    assert torch.equal(m3.conv.conv1.weight, m.conv.conv1.weight) and not torch.equal(m3.rl.f_fc1.weight, m.rl.f_fc1.weight)
+    bad = {k: v for k, v in m.state_dict().items() if "f_fc1" not in k}
+    torch.save(bad, str(tmp_path / "RN_epoch_01.pth"))
+    with pytest.raises(RuntimeError, match="does not match"):
+        T.load_checkpoint(m2, str(tmp_path / "RN_epoch_01.pth"))
+
+
+def test_log_lines_parse_with_plot_regexes(T):
+    """plot.py:27 parses r'Train loss: (.*)' and skips lines containing '(0%)'."""
+    class FakeTrainer:
+        class M:
+            def train(self): pass
+        model = M()
+        def step(self, img, q, y):
+            return torch.tensor(1.5)
+    lines = []
+    T.train_epoch(T.SyntheticClevr(40, 4), FakeTrainer(), 3, "cpu", log_interval=5, log=lines.append)
+    assert len(lines) == 2 and lines[0].startswith("Train Epoch: 3 [0/40 (0%)] Train loss: 1.5")
+    m = re.search(r"Train loss: (.*)", lines[1])
+    assert m and float(m.group(1)) == 1.5 and "(0%)" not in lines[1] and "[20/40 (50%)]" in lines[1]
+
+
+@pytest.mark.gpu
+def test_training_trajectory_matches_reference(T):
+    """G-traj: 4 reference training steps (Adam 1e-4 / wd 1e-4 / clip 50, train-mode BN, dropout 0) recorded on
+    the CPU reference; the MI355X trainer in fp32 precision must reproduce the losses to 1e-3 and the
+    pre-clip gradient norms to 1e-2 (the first step exactly tests forward + all gradients)."""
+    import relationnetworks_clevr_amd as pkg
+    from relationnetworks_clevr_amd import dp
+    g = gold.load("G-traj")
+    meta = g["meta"]
+    hyp = dict(formula.HYP[meta["cfg"]], dropout=0.0, precision="fp32")
+
+    class A:
+        qdict_size, adict_size = formula.QDICT, formula.ADICT
+
+    m = pkg.RN(A, hyp)
+    shapes = {k: tuple(v) for k, v in json.loads(str(g["state_names"])).items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in formula.formula_fill_state(shapes, meta["seed"]).items()}, strict=False)
+    m.cuda().train()
+    opt = torch.optim.Adam(m.parameters(), lr=meta["lr"], weight_decay=1e-4)
+    tr = dp.DataParallelTrainer(m, opt, clip_norm=None, use_graph=False)
+    losses, norms = [], []
+    for s in range(meta["steps"]):
+        seed = meta["seed"] + 10 * s
+        batch = {"image": torch.from_numpy(formula.hash_uniform((meta["b"], 3, 128, 128), seed + 1, 0.0, 1.0)),
+                 "question": torch.from_numpy(formula.hash_ints((meta["b"], 20), seed + 2, 1, formula.QDICT + 1)),
+                 "answer": torch.from_numpy(formula.hash_ints((meta["b"], 1), seed + 3, 1, formula.ADICT + 1))}
+        img, q, y = T.load_tensor_data(batch, "cuda", invert_questions=True)
+        loss = tr._fwd_bwd(img, q, y)
+        norms.append(float(tr.bucket.clip_grad_norm_(50.0)))
+        opt.step()
+        losses.append(float(loss.detach()))
+    print("losses", losses, "ref", g["losses"].tolist(), "norms", norms, g["grad_norms"].tolist())
+    assert np.allclose(losses, g["losses"], rtol=1e-3)
+    assert np.allclose(norms, g["grad_norms"], rtol=1e-2)
+    for k in g:
+        if k.startswith("final/"):
+            assert gold.rel_err(m.state_dict()[k[6:]].cpu().numpy(), g[k]) <= 2e-2, k
+
+
+@pytest.mark.gpu
+def test_graph_trainer_overfits_one_batch(T):
+    """hipGraph replay + gather bucket + fused Adam: the loss on a repeated batch must fall (bf16 mode)."""
+    import relationnetworks_clevr_amd as pkg
+    from relationnetworks_clevr_amd import dp
+
+    class A:
+        qdict_size, adict_size = 82, 28
+
+    torch.manual_seed(0)
+    m = pkg.RN(A, dict(formula.HYP["original-fp"], dropout=0.0)).cuda()
+    opt = torch.optim.Adam(m.parameters(), lr=3e-4, weight_decay=1e-4, fused=True)
+    tr = dp.DataParallelTrainer(m, opt, clip_norm=50.0, use_graph=True)
+    batch = next(iter(T.SyntheticClevr(16, 16, seed=3)))
+    img, q, y = T.load_tensor_data(batch, "cuda")
+    first = float(tr.step(img, q, y).detach())
+    for _ in range(40):
+        last = float(tr.step(img, q, y).detach())
+    assert np.isfinite(last) and last < 0.5 * first, (first, last)
+    acc, conf = T.test_epoch([batch], m, 1, torch.device("cuda"), 28, log=lambda *a: None)
+    assert conf.sum() == 16 and 0 <= acc <= 100
