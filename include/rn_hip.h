@@ -20,6 +20,8 @@
  * Storage dtypes of the pair / activation / packed-weight buffers:
  *   RN_BF16 : bf16 storage, bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate.
  *   RN_F32  : fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32) -- exact-fp32 parity mode.
+ *   RN_F16  : accepted by rn_pair_build_fwd / rn_pack_matrix(_split) only: operands of the "f16s"
+ *             forward chain (fp16 activations x fp16 hi+lo split weights, rn_g_chain_fwd_f16s).
  * Row index of every "pair" matrix: r = (b*n + i)*n + j   (model.py:127).
  */
 #ifndef RN_HIP_H
@@ -33,7 +35,7 @@ extern "C" {
 
 #define RN_ABI_VERSION 1
 
-enum { RN_BF16 = 0, RN_F32 = 1 };
+enum { RN_BF16 = 0, RN_F32 = 1, RN_F16 = 2 };   /* RN_F16: pair matrix / split weights of the f16s forward only */
 
 /* rn_gemm_f32 flags */
 enum { RN_RELU = 1, RN_ACCUMULATE = 2 };
@@ -62,6 +64,11 @@ int rn_qst_broadcast(const float* q, long sqb, void* A, int dtype, int B, int n,
 int rn_pack_matrix(const float* src, long sr, long sc, int R, int C, void* dst, int dtype, int ld, int Rpad,
                    void* stream);
 
+/* fp16 hi/lo split of a fp32 matrix: hi = fp16(src), lo = fp16(src - hi) (both zero padded like
+ * rn_pack_matrix) -- weight operands of rn_g_chain_fwd_f16s. */
+int rn_pack_matrix_split(const float* src, long sr, long sc, int R, int C, void* hi, void* lo, int ld, int Rpad,
+                         void* stream);
+
 /* K2 -- one g_theta layer:  H = relu(A @ W^T + bias)      (model.py:141-145)
  * A: (M, lda) dtype, reduction length K (K % 64 == 0, columns >= true K are zero),
  * Wp: (N, ldw) packed dtype (rn_pack_matrix), bias: fp32 (N), H: (M, ldh) dtype.
@@ -82,6 +89,16 @@ int rn_g_linear_fwd(const void* A, int lda, const void* Wp, int ldw, const float
 int rn_g_chain_tile(void);
 int rn_g_chain_fwd(const void* P, int ldp, const void* const* Wp, const float* const* bias, void* const* H,
                    const int* K, float* xg_part, int dtype, int M, int L, int G, void* stream);
+
+/* "f16s" forward chain: same tiling as rn_g_chain_fwd, but the LDS-resident activation tile and P are
+ * fp16 and every product runs twice on v_mfma_f32_32x32x16_f16 against the hi and lo halves of the
+ * split weights (fp32 accumulate).  Weight rounding -- the systematic error that keeps single-pass
+ * bf16 at 1e-2 -- drops out: log-probs land within ~2e-4 of the fp32 reference (bar: 1e-3).
+ * P: (M, ldp) fp16; Whi/Wlo[l]: (256, K[l]) fp16 (rn_pack_matrix_split); H[l]: (M, 256) **bf16** copies of
+ * the activations for the (bf16) backward, may be NULL.  Other arguments as rn_g_chain_fwd. */
+int rn_g_chain_fwd_f16s(const void* P, int ldp, const void* const* Whi, const void* const* Wlo,
+                        const float* const* bias, void* const* H, const int* K, float* xg_part, int M, int L,
+                        int G, void* stream);
 
 /* Fused backward chain (bf16 storage): pair-sum broadcast + last ReLU gate + all L-1 dgrad steps
  *  for every 128-row tile, tile resident in LDS:

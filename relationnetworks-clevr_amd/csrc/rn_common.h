@@ -8,6 +8,9 @@
 #include "../../include/rn_hip.h"
 
 typedef __bf16 bf16;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -44,6 +47,11 @@ template <> struct Elem<bf16> {
   static __device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
   static __device__ __forceinline__ bf16 from_f32(float v) { return (bf16)v; }   // RNE, v_cvt_pk_bf16_f32
 };
+template <> struct Elem<f16> {
+  static constexpr int kPer16B = 8;
+  static __device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
+  static __device__ __forceinline__ f16 from_f32(float v) { return (f16)v; }       // RNE, v_cvt_f16_f32
+};
 template <> struct Elem<float> {
   static constexpr int kPer16B = 4;
   static __device__ __forceinline__ float to_f32(float v) { return v; }
@@ -56,3 +64,4 @@ template <typename T> struct Chunk16 { T v[Elem<T>::kPer16B]; } __attribute__((a
 template <typename T> __device__ __forceinline__ bool is_pos(T v);
 template <> __device__ __forceinline__ bool is_pos<bf16>(bf16 v) { return (float)v > 0.f; }
 template <> __device__ __forceinline__ bool is_pos<float>(float v) { return v > 0.f; }
+template <> __device__ __forceinline__ bool is_pos<f16>(f16 v) { return (float)v > 0.f; }

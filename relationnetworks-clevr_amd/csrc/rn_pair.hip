@@ -82,15 +82,16 @@ extern "C" int rn_pair_build_fwd(const float* x, long sxb, long sxn, long sxk, c
   RN_CHECK_ARG(Q == 0 || q, "rn_pair_build_fwd: Q > 0 but q is NULL");
   RN_CHECK_ARG(ld % 64 == 0 && ld >= 2 * k + Q, "rn_pair_build_fwd: ld=%d must be a multiple of 64 and >= 2k+Q=%d", ld,
                2 * k + Q);
-  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "rn_pair_build_fwd: bad dtype %d", dtype);
+  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32 || dtype == RN_F16, "rn_pair_build_fwd: bad dtype %d", dtype);
   int IB = (int)((long)B * n / 2048);
   IB = IB < 1 ? 1 : (IB > 8 ? 8 : IB);
   dim3 grid(cdiv(n, IB), B);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == RN_BF16) {
+  if (dtype == RN_BF16 || dtype == RN_F16) {
     size_t lds = ((size_t)n * ((k + 7) / 8 * 8) + ld) * sizeof(bf16);
     RN_CHECK_ARG(lds <= 64 * 1024, "rn_pair_build_fwd: n*k too large for LDS staging");
-    pair_build_kernel<bf16><<<grid, 256, lds, s>>>(x, sxb, sxn, sxk, q, sqb, (bf16*)P, n, k, Q, ld, IB);
+    if (dtype == RN_BF16) pair_build_kernel<bf16><<<grid, 256, lds, s>>>(x, sxb, sxn, sxk, q, sqb, (bf16*)P, n, k, Q, ld, IB);
+    else pair_build_kernel<f16><<<grid, 256, lds, s>>>(x, sxb, sxn, sxk, q, sqb, (f16*)P, n, k, Q, ld, IB);
   } else {
     size_t lds = ((size_t)n * ((k + 3) / 4 * 4) + ld) * sizeof(float);
     RN_CHECK_ARG(lds <= 64 * 1024, "rn_pair_build_fwd: n*k too large for LDS staging");
@@ -146,15 +147,40 @@ __global__ __launch_bounds__(256) void pack_matrix_kernel(const float* __restric
   }
 }
 
+__global__ __launch_bounds__(256) void pack_matrix_split_kernel(const float* __restrict__ src, long sr, long sc, int R,
+                                                                int C, f16* __restrict__ hi, f16* __restrict__ lo, int ld,
+                                                                int Rpad) {
+  const long total = (long)Rpad * ld;
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+    const int r = (int)(g / ld), c = (int)(g - (long)r * ld);
+    const float v = (r < R && c < C) ? src[(long)r * sr + (long)c * sc] : 0.f;
+    const f16 h = (f16)v;
+    hi[g] = h;
+    lo[g] = (f16)(v - (float)h);
+  }
+}
+
+extern "C" int rn_pack_matrix_split(const float* src, long sr, long sc, int R, int C, void* hi, void* lo, int ld, int Rpad,
+                                    void* stream) {
+  RN_CHECK_ARG(src && hi && lo && R > 0 && C > 0 && ld >= C && Rpad >= R, "rn_pack_matrix_split: bad pointer/size");
+  const long total = (long)Rpad * ld;
+  int blocks = cdiv(total, 256);
+  if (blocks > 2048) blocks = 2048;
+  pack_matrix_split_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(src, sr, sc, R, C, (f16*)hi, (f16*)lo, ld, Rpad);
+  RN_LAUNCH_CHECK("rn_pack_matrix_split");
+  return 0;
+}
+
 extern "C" int rn_pack_matrix(const float* src, long sr, long sc, int R, int C, void* dst, int dtype, int ld, int Rpad,
                               void* stream) {
   RN_CHECK_ARG(src && dst && R > 0 && C > 0 && ld >= C && Rpad >= R, "rn_pack_matrix: bad pointer/size");
-  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "rn_pack_matrix: bad dtype %d", dtype);
+  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32 || dtype == RN_F16, "rn_pack_matrix: bad dtype %d", dtype);
   const long total = (long)Rpad * ld;
   int blocks = cdiv(total, 256);
   if (blocks > 2048) blocks = 2048;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == RN_BF16) pack_matrix_kernel<bf16><<<blocks, 256, 0, s>>>(src, sr, sc, R, C, (bf16*)dst, ld, Rpad);
+  else if (dtype == RN_F16) pack_matrix_kernel<f16><<<blocks, 256, 0, s>>>(src, sr, sc, R, C, (f16*)dst, ld, Rpad);
   else pack_matrix_kernel<float><<<blocks, 256, 0, s>>>(src, sr, sc, R, C, (float*)dst, ld, Rpad);
   RN_LAUNCH_CHECK("rn_pack_matrix");
   return 0;

@@ -15,7 +15,7 @@ import torch
 
 from . import rn_hip as H
 
-PRECISIONS = ("bf16", "fp32")
+PRECISIONS = ("bf16", "f16s", "fp32")
 
 
 def _ru(v, m):
@@ -53,16 +53,17 @@ class PackedWeights:
     def __init__(self):
         self.key = None
         self.fwd, self.bwd = [], []
+        self.hi, self.lo = [], []                  # fp16 split copies for the f16s forward
 
-    def get(self, plan: LayerPlan, g_w, code):
-        key = (code, tuple((w.data_ptr(), w._version) for w in g_w))
+    def get(self, plan: LayerPlan, g_w, code, split=False):
+        key = (code, split, tuple((w.data_ptr(), w._version) for w in g_w))
         # while a hipGraph is being captured the pack kernels must be part of it (a replay sees
         # new weights every step), so the cache is bypassed
         if key == self.key and not torch.cuda.is_current_stream_capturing():
             return self.fwd, self.bwd
         dt = H.torch_dtype(code)
         dev = g_w[0].device
-        self.fwd, self.bwd = [], []
+        self.fwd, self.bwd, self.hi, self.lo = [], [], [], []
         for l, w in enumerate(g_w):
             N, kt = w.shape
             assert kt == plan.ktrue[l] and N == plan.widths[l], (w.shape, plan.ktrue[l], plan.widths[l])
@@ -72,6 +73,12 @@ class PackedWeights:
             wp = torch.empty(N, plan.kpad[l], dtype=dt, device=dev)
             H.pack_matrix(wc, kt, 1, N, kt, wp, code, plan.kpad[l], N)
             self.fwd.append(wp)
+            if split:
+                hi = torch.empty(N, plan.kpad[l], dtype=torch.float16, device=dev)
+                lo = torch.empty(N, plan.kpad[l], dtype=torch.float16, device=dev)
+                H.pack_matrix_split(wc, kt, 1, N, kt, hi, lo, plan.kpad[l], N)
+                self.hi.append(hi)
+                self.lo.append(lo)
             if l >= 1:
                 gp = plan.widths[l - 1]           # only the H_{l-1} columns take part in dgrad
                 wt = torch.empty(gp, N, dtype=dt, device=dev)
@@ -93,7 +100,7 @@ def fused_chain_ok(plan: LayerPlan, code, B, n):
             and all(kp == 256 for kp in plan.kpad[1:]) and (B * n * n) % H.g_chain_tile() == 0 and plan.L <= 8)
 
 
-def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None):
+def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None, split=None):
     """K1 + K2 chain (+ K3).  Returns (inputs, H_L, xg): the list of layer INPUT buffers
     [A_0 .. A_{L-1}], the last activation H_L and -- when the fused chain ran -- the pair sum xg
     (else None).  layer_hook(l, A_l, H_out) is called after every layer (hook-compat path; forces
@@ -105,6 +112,30 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
     dev = x.device
     inj = plan.inject
     ld0 = plan.kpad[0]
+    if split is not None:
+        # "f16s": fp16 pair matrix + split fp16 weights through the fused chain; the bf16 pair matrix is only
+        # needed by the backward pass (layer-0 wgrad)
+        if layer_hook is not None or not fused_chain_ok(plan, code, B, n):
+            raise RuntimeError('precision "f16s" needs the fused chain (bf16-class storage, all g widths 256, question '
+                               'injected at layer 0, B*n*n a multiple of 128, no forward hooks); use "bf16" or "fp32" here')
+        G, L, T = plan.widths[-1], plan.L, H.g_chain_tile()
+        P16 = torch.empty(M, ld0, dtype=torch.float16, device=dev)
+        H.pair_build_fwd(x, q, P16, H.RN_F16, B, n, k, Q, ld0)
+        P = None
+        if keep_inputs:
+            P = torch.empty(M, ld0, dtype=dt, device=dev)
+            H.pair_build_fwd(x, q, P, code, B, n, k, Q, ld0)
+        whole = (n * n) % T == 0
+        Hs = [torch.empty(M, G, dtype=dt, device=dev) if (keep_inputs or (l == L - 1 and not whole)) else None
+              for l in range(L)]
+        part = torch.empty(M // T, G, dtype=torch.float32, device=dev) if whole else None
+        H.g_chain_fwd_f16s(P16, ld0, split[0], split[1], g_b, Hs, plan.kpad, part, M, G)
+        xg = torch.empty(B, G, dtype=torch.float32, device=dev)
+        if whole:
+            H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // T, G)
+        else:
+            H.pair_sum_fwd(Hs[-1], G, xg, code, B, n * n, G)
+        return [P] + Hs[:-1], Hs[-1], xg
     P = torch.empty(M, ld0, dtype=dt, device=dev)
     H.pair_build_fwd(x, q if inj == 0 else None, P, code, B, n, k, Q if inj == 0 else 0, ld0)
     if layer_hook is None and fused_chain_ok(plan, code, B, n):
@@ -181,10 +212,12 @@ class RelationalFunction(torch.autograd.Function):
         Q = q.shape[1]
         M = B * n * n
         dev = x.device
-        wfwd, wbwd = packed.get(plan, g_w, code)
+        f16s = precision == "f16s"
+        wfwd, wbwd = packed.get(plan, g_w, code, split=f16s)
         gb = [b.detach().contiguous() for b in g_b]
         need_grad = any(ctx.needs_input_grad)
-        inputs, HL, xg = g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad)
+        inputs, HL, xg = g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad,
+                                         split=(packed.hi, packed.lo) if f16s else None)
         G = plan.widths[-1]
         if xg is None:
             xg = torch.empty(B, G, dtype=torch.float32, device=dev)

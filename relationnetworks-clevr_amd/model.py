@@ -163,6 +163,8 @@ class RelationalLayer(RelationalLayerBase):
         H._dev(x, "x")
         x = x.float()
         q = qst.float().contiguous()
+        if self.precision == "f16s":
+            raise RuntimeError('forward hooks / extraction need the per-layer kernels: use precision "bf16" or "fp32"')
         wfwd, _ = self._packed.get(plan, [l.weight for l in self.g_layers], code)
         gb = [l.bias.detach().contiguous() for l in self.g_layers]
 

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librn_hip.so")
-RN_BF16, RN_F32 = 0, 1
+RN_BF16, RN_F32, RN_F16 = 0, 1, 2
 RN_RELU, RN_ACCUMULATE = 1, 2
 ABI_VERSION = 1
 
@@ -27,6 +27,8 @@ SIGNATURES = {
     "rn_pair_build_fwd": (_I, [_P, _L, _L, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_qst_broadcast": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_pack_matrix": (_I, [_P, _L, _L, _I, _I, _P, _I, _I, _I, _P]),
+    "rn_pack_matrix_split": (_I, [_P, _L, _L, _I, _I, _P, _P, _I, _I, _P]),
+    "rn_g_chain_fwd_f16s": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rn_g_linear_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_tile": (_I, []),
     "rn_g_chain_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -84,11 +86,13 @@ def _ptr(t):
 
 
 def dtype_code(precision: str) -> int:
-    return {"bf16": RN_BF16, "fp32": RN_F32}[precision]
+    """Storage dtype of activations / gradients.  "f16s" (fp16 tile x split fp16 weights forward) keeps
+    bf16 storage for everything the backward pass touches."""
+    return {"bf16": RN_BF16, "f16s": RN_BF16, "fp32": RN_F32}[precision]
 
 
 def torch_dtype(code: int):
-    return torch.bfloat16 if code == RN_BF16 else torch.float32
+    return {RN_BF16: torch.bfloat16, RN_F32: torch.float32, RN_F16: torch.float16}[code]
 
 
 def _dev(t, name):
@@ -178,6 +182,24 @@ def g_chain_fwd(P, ldp, Wps, biases, Hs, Ks, xg_part, code, M, G):
     hp = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs])
     kk = (C.c_int * L)(*Ks)
     _check(load().rn_g_chain_fwd(P.data_ptr(), ldp, wp, bp, hp, kk, _ptr(xg_part), code, M, L, G, _stream()), "rn_g_chain_fwd")
+
+
+def pack_matrix_split(src, sr, sc, R, Cc, hi, lo, ld, Rpad):
+    _check(load().rn_pack_matrix_split(src.data_ptr(), sr, sc, R, Cc, hi.data_ptr(), lo.data_ptr(), ld, Rpad, _stream()),
+           "rn_pack_matrix_split")
+
+
+@_timed("g_fwd")
+def g_chain_fwd_f16s(P, ldp, Whis, Wlos, biases, Hs, Ks, xg_part, M, G):
+    """f16s forward chain: P fp16, split fp16 weights, Hs = bf16 activation copies (entries may be None)."""
+    L = len(Whis)
+    hp = (C.c_void_p * L)(*[w.data_ptr() for w in Whis])
+    lp = (C.c_void_p * L)(*[w.data_ptr() for w in Wlos])
+    bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
+    op = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs])
+    kk = (C.c_int * L)(*Ks)
+    _check(load().rn_g_chain_fwd_f16s(P.data_ptr(), ldp, hp, lp, bp, op, kk, _ptr(xg_part), M, L, G, _stream()),
+           "rn_g_chain_fwd_f16s")
 
 
 @_timed("g_dgrad")

@@ -209,6 +209,45 @@ def test_g_chain_fwd_fused(H, K0, K0true, L, store):
         assert rel(part.cpu().numpy(), prev.reshape(M // T, T, G).sum(1, dtype=np.float64)) <= 2e-3
 
 
+def test_g_chain_fwd_f16s(H):
+    """f16s chain (fp16 tile x fp16 hi+lo weights): against a float64 emulation that rounds the tile to fp16
+    after every layer and uses the same split weights.  Stored activations are bf16 copies of the fp16 tile."""
+    M, G, K0, K0true, L = 2048, 256, 192, 180, 4
+    def f16r(a):
+        return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+    P = np.zeros((M, K0), np.float32); P[:, :K0true] = formula.hash_uniform((M, K0true), 500, -1, 1)
+    P = f16r(P)
+    Ws, bs, Ks, his, los = [], [], [], [], []
+    for l in range(L):
+        kt, kp = (K0true, K0) if l == 0 else (G, G)
+        W = np.zeros((G, kp), np.float32); W[:, :kt] = formula.hash_uniform((G, kt), 510 + l, -0.15, 0.15)
+        Ws.append(W); bs.append(formula.hash_uniform((G,), 520 + l, -0.3, 0.3)); Ks.append(kp)
+        hi = torch.empty(G, kp, dtype=torch.float16, device="cuda"); lo = torch.empty_like(hi)
+        H.pack_matrix_split(dev(W), kp, 1, G, kp, hi, lo, kp, G)
+        his.append(hi); los.append(lo)
+        wh = f16r(W)
+        assert np.array_equal(hi.float().cpu().numpy(), wh) and np.array_equal(lo.float().cpu().numpy(), f16r(W - wh))
+    Hs = [torch.empty(M, G, dtype=torch.bfloat16, device="cuda") for _ in range(L)]
+    part = torch.empty(M // 128, G, dtype=torch.float32, device="cuda")
+    H.g_chain_fwd_f16s(dev(P).half(), K0, his, los, [dev(b) for b in bs], Hs, Ks, part, M, G)
+    torch.cuda.synchronize()
+    prev = P.astype(np.float64)
+    for l in range(L):
+        wh = f16r(Ws[l]); wl = f16r(Ws[l] - wh)
+        z = prev @ (wh.astype(np.float64) + wl.astype(np.float64)).T + bs[l]
+        prev = f16r(np.maximum(z, 0)).astype(np.float64)
+        got = Hs[l].float().cpu().numpy()
+        ref = bf16_round(prev)
+        err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
+        assert err.max() <= 2 * BF16_ULP, (l, err.max())
+    assert rel(part.cpu().numpy(), prev.reshape(M // 128, 128, G).sum(1)) <= 1e-3
+    # and it is much closer to the exact fp32 chain than the bf16 chain can be
+    exact = P.astype(np.float64)
+    for l in range(L):
+        exact = np.maximum(exact @ Ws[l].astype(np.float64).T + bs[l], 0)
+    assert rel(part.cpu().numpy(), exact.reshape(M // 128, 128, G).sum(1)) <= 3e-4
+
+
 @pytest.mark.parametrize("B,npairs", [(2, 512), (8, 144), (300, 256)])
 def test_g_chain_bwd_fused(H, B, npairs):
     """Fused backward chain: dZ[0] = dxg * (HL > 0) exactly; every further dZ must equal one un-fused

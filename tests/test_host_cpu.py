@@ -130,4 +130,7 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("the oracle", ""), f
-                assert "/root/reference" not in src or f == "model.py", f
+                # the reference may be CITED in docstrings / comments, never touched by code
+                code = re.sub(r'"""[\s\S]*?"""', "", src)
+                code = "\n".join(l for l in code.splitlines() if not l.strip().startswith(("#", "//", "*", "/*")))
+                assert "/root/reference" not in code, f
