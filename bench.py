@@ -24,7 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"bf16": 2500.0, "f16s": 2500.0, "fp32": 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -74,26 +74,34 @@ def cpu_baseline(cfg, B, hw, steps=3):
 
 
 def parity_mode_rate(pkg, dp, hyp, A, dev, img, qst, lab, B, steps=8):
-    """Same train step with precision="fp32" (fp32 storage + fp32 MFMA): the mode whose log-probs match the
-    reference to <= 5e-7 (tests/test_gpu_parity.py); the headline bf16 mode is at 4e-4..1e-2."""
+    """The same train step in the two precisions whose log-probs meet the 1e-3 bar against the reference
+    (tests/test_gpu_parity.py): "f16s" (fp16 tile x split fp16 weights forward, bf16 backward; measured
+    1e-5..2.3e-4) and "fp32" (fp32 MFMA everywhere; <= 5e-7).  The headline bf16 mode is at 4e-4..1e-2."""
     import io, contextlib
-    torch.manual_seed(42)
-    with contextlib.redirect_stdout(io.StringIO()):
-        model = pkg.RN(A, dict(hyp, precision="fp32"))
-    model.cuda(dev)
-    model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=5e-6, weight_decay=1e-4, fused=True)
-    tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0, use_graph=True)
-    for _ in range(3):
-        tr.step(img, qst, lab)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        tr.step(img, qst, lab)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"precision": "fp32", "value": B * steps / dt, "unit": "questions/s", "ms_per_step": 1e3 * dt / steps,
-            "log_prob_rel_err_vs_reference": "<=5e-7 (bf16 headline mode: 4e-4..1e-2)"}
+    res = {}
+    for prec, err in (("f16s", "1e-5..2.3e-4"), ("fp32", "<=5e-7")):
+        torch.manual_seed(42)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = pkg.RN(A, dict(hyp, precision=prec))
+        model.cuda(dev)
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=5e-6, weight_decay=1e-4, fused=True)
+        tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0, use_graph=True)
+        try:
+            for _ in range(3):
+                tr.step(img, qst, lab)
+        except RuntimeError as e:                      # f16s does not cover every config (ir-*, *-sd)
+            res[prec] = {"unsupported": str(e)[:80]}
+            continue
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step(img, qst, lab)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[prec] = {"value": B * steps / dt, "unit": "questions/s", "ms_per_step": 1e3 * dt / steps,
+                     "log_prob_rel_err_vs_reference": err}
+    return res
 
 
 def main():
@@ -103,7 +111,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--config", default="original-fp")
-    ap.add_argument("--precision", default=os.environ.get("RN_PRECISION", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default=os.environ.get("RN_PRECISION", "bf16"), choices=["bf16", "f16s", "fp32"])
     ap.add_argument("--hw", type=int, default=128, help="image side (224 -> 14x14 grid stress config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -213,7 +221,7 @@ def main():
                                "breakdown_ms_per_step": {kk: v[1] / args.steps for kk, v in sorted(ksum.items())}}
             pb = ksum.get("pair_build")
             if pb:
-                esz = 2 if args.precision == "bf16" else 4
+                esz = 4 if args.precision == "fp32" else 2
                 Q = hyp["lstm_hidden"] if hyp["question_injection_position"] == 0 else 0
                 nbytes = M * (2 * k + Q) * esz + B * n * k * 4 + B * Q * 4
                 gbs = nbytes / (pb[1] / pb[0] * 1e-3) / 1e9

@@ -337,7 +337,11 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const void* __restrict__
               const f32x4 bv = bias_in_lds ? *reinterpret_cast<const f32x4*>(bias_s + l * CT_G + nb)
                                            : *reinterpret_cast<const f32x4*>(a.bias[l] + nb);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] = (T)fmaxf(acc[mt][nt][4 * g + r] + bv[r], 0.f);
+              for (int r = 0; r < 4; ++r) {
+                float v = fmaxf(acc[mt][nt][4 * g + r] + bv[r], 0.f);
+                if constexpr (PREC == PREC_F16S) v = fminf(v, 65504.f);       // saturate instead of overflowing fp16 to inf
+                o[r] = (T)v;
+              }
             } else {
               union { u32x2 u; bf16x4 h; } gv;
               gv.u = gt[mt][nt][g];

@@ -116,7 +116,9 @@ class RelationalLayer(RelationalLayerBase):
         self.g_layers = nn.ModuleList(layers)
         self.extraction = extraction
         # MI355X execution options
-        self.precision = hyp.get("precision", os.environ.get("RN_PRECISION", "bf16"))
+        # "auto" -> "f16s" where the fused chain applies (log-probs within ~2e-4 of the fp32 reference), else
+        # "bf16" (~1e-2); "fp32" = exact-fp32 MFMA everywhere (~5e-7).  See DESIGN.md section 2.
+        self.precision = hyp.get("precision", os.environ.get("RN_PRECISION", "auto"))
         self.forced_dropout_mask = None                  # tests: explicit (B, f_fc2) mask incl. 1/(1-p)
         self._packed = RF.PackedWeights()
         self._plan_cache = {}
@@ -151,7 +153,11 @@ class RelationalLayer(RelationalLayerBase):
         f_w = [self.f_fc1.weight, self.f_fc2.weight, self.f_fc3.weight]
         f_b = [self.f_fc1.bias, self.f_fc2.bias, self.f_fc3.bias]
         mask = self._dropout_mask(b, x.device)
-        return RF.relational_forward(x, qst, mask, plan, self._packed, self.precision, g_w, g_b, f_w, f_b)
+        prec = self.precision
+        if prec == "auto":
+            fused = RF.fused_chain_ok(plan, H.RN_BF16, b, d)
+            prec = "f16s" if fused else "bf16"
+        return RF.relational_forward(x, qst, mask, plan, self._packed, prec, g_w, g_b, f_w, f_b)
 
     @torch.no_grad()
     def _forward_hook_compat(self, x, qst, plan):
@@ -159,12 +165,12 @@ class RelationalLayer(RelationalLayerBase):
         (B*n*n, in) (extract.py:43,64-68).  When hooks (or extraction=True) are present the
         chain runs layer by layer on the same HIP kernels and each hooked layer's materialised
         input / output is handed to its hooks as fp32 tensors; inference only."""
-        code = H.dtype_code(self.precision)
+        if self.precision == "f16s":
+            raise RuntimeError('forward hooks / extraction need the per-layer kernels: use precision "bf16" or "fp32"')
+        code = H.dtype_code("bf16" if self.precision == "auto" else self.precision)
         H._dev(x, "x")
         x = x.float()
         q = qst.float().contiguous()
-        if self.precision == "f16s":
-            raise RuntimeError('forward hooks / extraction need the per-layer kernels: use precision "bf16" or "fp32"')
         wfwd, _ = self._packed.get(plan, [l.weight for l in self.g_layers], code)
         gb = [l.bias.detach().contiguous() for l in self.g_layers]
 
