@@ -122,9 +122,23 @@ class KernelTimer:
         self.pairs.setdefault(name, []).append((e0, e1))
         return e1
 
-    def summary(self):
+    def bracket_overhead_ms(self, n=50):
+        """Duration an EMPTY event bracket reports (event processing on the stream): subtracted per bracket."""
         torch.cuda.synchronize()
-        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.pairs.items()}   # (launches, total ms)
+        pairs = []
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in pairs)
+        return ts[len(ts) // 2]
+
+    def summary(self):
+        """{name: (brackets, total ms)} with the empty-bracket overhead removed from every bracket."""
+        torch.cuda.synchronize()
+        ov = self.bracket_overhead_ms()
+        return {k: (len(v), sum(max(a.elapsed_time(b) - ov, 0.0) for a, b in v)) for k, v in self.pairs.items()}
 
 
 TIMER = KernelTimer()
