@@ -92,11 +92,32 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const void* __restrict__
   constexpr int CPR = BK / 8;                               // 16-byte chunks per slab row (8 / 4)
   constexpr int RPI = 64 / CPR;                             // slab rows covered by one 1-KB LDS-DMA instruction (8 / 16)
   constexpr int BIAS_BYTES = CT_MAXL / 2 * CT_G * 4;        // up to 4 layers of bias (fwd)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[ACT_BYTES + 2 * WBUF_BYTES + BIAS_BYTES + CT_G * 4];
+  constexpr int TAB_BYTES = 6 * CT_MAXL * 8;               // per-layer pointer / size table (see below)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[ACT_BYTES + 2 * WBUF_BYTES + BIAS_BYTES + CT_G * 4 + TAB_BYTES];
   unsigned char* act = lds;
   unsigned char* wbuf = lds + ACT_BYTES;
   float* bias_s = reinterpret_cast<float*>(lds + ACT_BYTES + 2 * WBUF_BYTES);
   float* red = bias_s + CT_MAXL / 2 * CT_G;
+  // The per-layer arguments are indexed with a run-time layer number.  Straight from the kernel-argument
+  // struct that becomes a VMEM load + s_waitcnt vmcnt(0) in front of every weight slab (which drains the
+  // whole in-order VM queue); a copy in LDS is read with ds_read (lgkmcnt) and made scalar again.
+  unsigned long long* tab = reinterpret_cast<unsigned long long*>(red + CT_G);
+  enum { T_W = 0, T_WLO = 1, T_BIAS = 2, T_GATE = 3, T_OUT = 4, T_K = 5 };
+  if (threadIdx.x < CT_MAXL) {
+    const int i = threadIdx.x;
+    tab[T_W * CT_MAXL + i] = (unsigned long long)a.W[i];
+    tab[T_WLO * CT_MAXL + i] = (unsigned long long)a.Wlo[i];
+    tab[T_BIAS * CT_MAXL + i] = (unsigned long long)a.bias[i];
+    tab[T_GATE * CT_MAXL + i] = (unsigned long long)a.gate[i];
+    tab[T_OUT * CT_MAXL + i] = (unsigned long long)a.out[i];
+    tab[T_K * CT_MAXL + i] = (unsigned long long)a.K[i];
+  }
+  __syncthreads();
+  auto tget = [&](int what, int l) -> unsigned long long {       // wave-uniform table read -> SGPR pair
+    const unsigned long long v = tab[what * CT_MAXL + l];
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+  };
   const T* P = static_cast<const T*>(Pv);
 
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -113,11 +134,11 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const void* __restrict__
 
   const bool bias_in_lds = (MODE == MODE_FWD) && L <= CT_MAXL / 2;
   if (bias_in_lds)
-    for (int c = t; c < L * CT_G; c += NT) bias_s[c] = a.bias[c >> 8][c & 255];
+    for (int c = t; c < L * CT_G; c += NT) bias_s[c] = reinterpret_cast<const float*>(tget(T_BIAS, c >> 8))[c & 255];
 
   // ---- tile source prefetch (registers): fwd = P rows (K0 columns), bwd = H_L rows (256 columns)
   u32x4 rp[NST];
-  const int cpr0 = (MODE == MODE_FWD) ? (a.K[0] >> 3) : 32;          // 16-byte chunks per source row
+  const int cpr0 = (MODE == MODE_FWD) ? ((int)tget(T_K, 0) >> 3) : 32;          // 16-byte chunks per source row
   auto prefetch_tile = [&](long m0n) {
 #pragma unroll
     for (int i = 0; i < NST; ++i) {                           // always NST loads per thread (the slab barrier counts them)
@@ -177,7 +198,9 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const void* __restrict__
   const int srow = t >> 3, scc = t & 7;                     // register path: 8 lanes cover one 128-byte row slab
   u32x4 rw[GLDS ? 1 : 4];
   auto w_issue = [&](int l, int slab, int buf) {
-    const int ldw = a.K[l];
+    const int ldw = (int)tget(T_K, l);
+    const T* Whi_l = reinterpret_cast<const T*>(tget(T_W, l));
+    const T* Wlo_l = NPASS == 2 ? reinterpret_cast<const T*>(tget(T_WLO, l)) : Whi_l;
     if constexpr (GLDS) {
       // LDS-DMA instruction q = IPW*wave + s of a stage fills bytes [q*1024, +1024): image q / (32/NPASS), slab
       // rows RPI*(q % ..) .. ; lane i lands at row + i / CPR, chunk position i % CPR and must therefore
@@ -188,14 +211,14 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const void* __restrict__
         const int img = q / (32 / NPASS), qi = q % (32 / NPASS);
         const int row = qi * RPI + lane / CPR;
         const int chunk = (lane % CPR) ^ swz(row);
-        const T* Wl = static_cast<const T*>(img == 0 ? a.W[l] : a.Wlo[l]);
+        const T* Wl = img == 0 ? Whi_l : Wlo_l;
         const T* g = Wl + (long)row * ldw + slab * BK + chunk * 8;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(wbuf + buf * WBUF_BYTES + (IPW * wu + s) * 1024),
                                          16, 0, 0);
       }
     } else {
-      const T* Wl = static_cast<const T*>(a.W[l]);
+      const T* Wl = Whi_l;
 #pragma unroll
       for (int s = 0; s < 4; ++s)
         rw[s] = *reinterpret_cast<const u32x4*>(Wl + (long)(srow + 64 * s) * ldw + slab * BK + scc * 8);
@@ -262,7 +285,7 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const void* __restrict__
       // backward: fetch this step's ReLU gate (the lane's groups of 4 features) early, use it in the epilogue
       u32x2 gt[2][2][4];
       if constexpr (MODE == MODE_BWD) {
-        const bf16* gl = a.gate[l];
+        const bf16* gl = reinterpret_cast<const bf16*>(tget(T_GATE, l));
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -272,7 +295,7 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const void* __restrict__
               gt[mt][nt][g] = *reinterpret_cast<const u32x2*>(
                   gl + (m0 + wm * 64 + mt * 32 + (lane & 31)) * CT_G + wn * 64 + nt * 32 + 8 * g + 4 * (lane >> 5));
       }
-      const int ns = a.K[l] / BK;
+      const int ns = (int)tget(T_K, l) / BK;
       for (int s = 0; s < ns; ++s) {
         const bool last_slab = (s == ns - 1);
         const bool last_of_tile = last_slab && l == L - 1;
@@ -285,8 +308,9 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const void* __restrict__
         int younger = 0;
         if (s == 0 && l > 0) {
           // stores go AFTER the weight loads: vmcnt retires in order
-          copy_out(a.out[l - 1], m0);                 // previous layer's tile (intact in LDS until this layer's epilogue)
-          if (a.out[l - 1]) younger += NST;
+          bf16* prev_out = reinterpret_cast<bf16*>(tget(T_OUT, l - 1));
+          copy_out(prev_out, m0);                     // previous layer's tile (intact in LDS until this layer's epilogue)
+          if (prev_out) younger += NST;
         }
         if (PREFETCH && last_of_tile && has_next_tile) {
           // next tile's source rows: issued in the LAST slab, after the last weight load of this tile, so no
@@ -335,7 +359,7 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const void* __restrict__
             Quad o;
             if constexpr (MODE == MODE_FWD) {
               const f32x4 bv = bias_in_lds ? *reinterpret_cast<const f32x4*>(bias_s + l * CT_G + nb)
-                                           : *reinterpret_cast<const f32x4*>(a.bias[l] + nb);
+                                           : *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(tget(T_BIAS, l)) + nb);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 float v = fmaxf(acc[mt][nt][4 * g + r] + bv[r], 0.f);
@@ -355,7 +379,7 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const void* __restrict__
       __syncthreads();                    // (B) the new tile is visible
       stamp();
     }
-    copy_out(a.out[L - 1], m0);
+    copy_out(reinterpret_cast<bf16*>(tget(T_OUT, L - 1)), m0);
     // ---- forward: pair-sum partial of this tile = column sums of the stored tile (fp32, fixed order)
     if (MODE == MODE_FWD && xg_part) {
       const int c = t & 255, h = t >> 8;
