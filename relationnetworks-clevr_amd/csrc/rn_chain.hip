@@ -72,7 +72,7 @@ template <> struct Prec<PREC_F16S> {
 };
 }  // namespace
 
-template <int MODE, int PREC, bool GLDS, bool PREFETCH>
+template <int MODE, int PREC, bool GLDS, bool PREFETCH, int RDEPTH>
 __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const void* __restrict__ Pv, int ldp, ChainArgs a, int L,
                                                         float* __restrict__ xg_part, int ntiles,
                                                         unsigned long long* __restrict__ trace) {
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const void* __restrict__
   constexpr int NPASS = (PREC == PREC_F16S) ? 2 : 1;        // weight images per slab (hi, lo)
   constexpr int BK = 64 / NPASS;                            // K-slab width: 64 (bf16) / 32 (f16s); 32 KB per stage either way
   constexpr int KS = BK / 16;                               // K16 steps per slab (4 / 2)
+  constexpr int RD = RDEPTH < KS ? RDEPTH : KS;             // K16 steps of fragments read ahead per batch
   constexpr int NST = TM * 32 / NT;                         // 16-byte chunks per thread of a full tile (8)
   constexpr int IPW = 32 / NW;                              // LDS-DMA instructions per wave per slab (4)
   constexpr int W_RS = GLDS ? BK * 2 : BK * 2 + 16;        // weight slab row stride: linear / padded
@@ -319,28 +320,38 @@ __global__ __launch_bounds__(CT_NT) void g_chain_kernel(const void* __restrict__
           younger += NST;
         }
         const unsigned char* wb = wbuf + cur * WBUF_BYTES + (GLDS ? 0 : (lane >> 5) * 16);
+        // Fragment reads are issued in batches of RD K16 steps AHEAD of the MFMAs that consume them (the
+        // compiler otherwise reads 2-4 fragments, waits lgkmcnt(0), issues 2 MFMAs, ... and every wait exposes
+        // a full LDS round trip while the partner wave of the SIMD sits in the same phase).
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          Frag fa[2], fw[NPASS][2];
+        for (int kb = 0; kb < KS; kb += RD) {
+          Frag fa[RD][2], fw[RD][NPASS][2];
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-            fa[mt] = *reinterpret_cast<const Frag*>(fa_base + mt * 32 * ACT_RS + s * (2 * BK) + ks * 32);
-#pragma unroll
-          for (int p = 0; p < NPASS; ++p)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-              if constexpr (GLDS)
-                fw[p][nt] = *reinterpret_cast<const Frag*>(wb + p * IMG_BYTES + fw_row_off[nt] +
-                                                           (((2 * ks + (lane >> 5)) ^ fw_swz[nt]) << 4));
-              else
-                fw[p][nt] = *reinterpret_cast<const Frag*>(wb + fw_row_off[nt] + ks * 32);
-            }
-#pragma unroll
-          for (int p = 0; p < NPASS; ++p)
+          for (int k2 = 0; k2 < RD; ++k2) {
+            const int ks = kb + k2;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
+              fa[k2][mt] = *reinterpret_cast<const Frag*>(fa_base + mt * 32 * ACT_RS + s * (2 * BK) + ks * 32);
 #pragma unroll
-              for (int nt = 0; nt < 2; ++nt) Prec<PREC>::mma(fw[p][nt], fa[mt], acc[mt][nt]);
+            for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt) {
+                if constexpr (GLDS)
+                  fw[k2][p][nt] = *reinterpret_cast<const Frag*>(wb + p * IMG_BYTES + fw_row_off[nt] +
+                                                                 (((2 * ks + (lane >> 5)) ^ fw_swz[nt]) << 4));
+                else
+                  fw[k2][p][nt] = *reinterpret_cast<const Frag*>(wb + fw_row_off[nt] + ks * 32);
+              }
+          }
+          __builtin_amdgcn_sched_barrier(0);        // keep the whole batch of ds_reads above the MFMAs
+#pragma unroll
+          for (int k2 = 0; k2 < RD; ++k2)
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) Prec<PREC>::mma(fw[k2][p][nt], fa[k2][mt], acc[mt][nt]);
         }
         if (has_next) w_commit(cur ^ 1);
         slab_barrier(has_next ? younger : -1);       // (A) all reads of wbuf[cur] / this tile slab done; next slab visible
@@ -419,9 +430,17 @@ static void chain_launch(int grid, hipStream_t s, const void* P, int ldp, const 
                          int ntiles) {
   const bool gl = env_on("RN_CHAIN_GLDS", true);            // RN_CHAIN_GLDS=0: register-staged weight slabs
   const bool pf = env_on("RN_CHAIN_PREFETCH", true);        // RN_CHAIN_PREFETCH=0: no next-tile source prefetch
-  if (!gl) g_chain_kernel<MODE, PREC_BF16, false, true><<<grid, CT_NT, 0, s>>>(P, ldp, a, L, xg_part, ntiles, g_trace);
-  else if (pf) g_chain_kernel<MODE, PREC_BF16, true, true><<<grid, CT_NT, 0, s>>>(P, ldp, a, L, xg_part, ntiles, g_trace);
-  else g_chain_kernel<MODE, PREC_BF16, true, false><<<grid, CT_NT, 0, s>>>(P, ldp, a, L, xg_part, ntiles, g_trace);
+  const char* re = getenv("RN_CHAIN_RDEPTH");               // fragment read-ahead in K16 steps: 1 (default), 2 or 4
+  const int rd = re ? atoi(re) : 1;                          // measured: 1 -> 272 us, 2 -> 287 us, 4 -> 340 us (lock-step phases)
+#define RN_GO(G, PFV, R) g_chain_kernel<MODE, PREC_BF16, G, PFV, R><<<grid, CT_NT, 0, s>>>(P, ldp, a, L, xg_part, ntiles, g_trace)
+  if (!gl) RN_GO(false, true, 1);
+  else if (pf && rd >= 4) RN_GO(true, true, 4);
+  else if (pf && rd == 2) RN_GO(true, true, 2);
+  else if (pf) RN_GO(true, true, 1);
+  else if (rd >= 4) RN_GO(true, false, 4);
+  else if (rd == 2) RN_GO(true, false, 2);
+  else RN_GO(true, false, 1);
+#undef RN_GO
 }
 
 extern "C" int rn_g_chain_tile(void) { return CT_TM; }
@@ -471,7 +490,7 @@ extern "C" int rn_g_chain_fwd_f16s(const void* P, int ldp, const void* const* Wh
   if (int rc = chain_fwd_args("rn_g_chain_fwd_f16s", a, P, ldp, Whi, Wlo, bias, H, K, M, L, G)) return rc;
   const int ntiles = M / CT_TM;
   const int grid = ntiles < num_cus() ? ntiles : num_cus();
-  g_chain_kernel<MODE_FWD, PREC_F16S, true, true><<<grid, CT_NT, 0, (hipStream_t)stream>>>(P, ldp, a, L, xg_part, ntiles,
+  g_chain_kernel<MODE_FWD, PREC_F16S, true, true, 1><<<grid, CT_NT, 0, (hipStream_t)stream>>>(P, ldp, a, L, xg_part, ntiles,
                                                                                            g_trace);
   RN_LAUNCH_CHECK("rn_g_chain_fwd_f16s");
   return 0;
