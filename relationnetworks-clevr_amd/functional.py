@@ -90,6 +90,16 @@ class PackedWeights:
         return self.fwd, self.bwd
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    s = _SIDE_STREAMS.get(dev)
+    if s is None:
+        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
 def fused_chain_ok(plan: LayerPlan, code, B, n):
     """The fused LDS-resident chain (rn_chain.hip) covers the headline shape family: bf16 storage,
     all g widths 256, question injected at layer 0 (so every later layer has K == 256), and whole
@@ -232,6 +242,7 @@ class RelationalFunction(torch.autograd.Function):
             ctx.plan, ctx.code, ctx.dims = plan, code, (B, n, k, Q, M, G, F1, F2, A)
             ctx.inputs, ctx.HL, ctx.wbwd = inputs, HL, wbwd
             ctx.g_w = [w.detach() for w in g_w]
+            ctx.param_refs = list(g_w) + list(g_b)
             ctx.fw = fw
             ctx.mask = mask
             ctx.save_for_backward(x, q, xg, f1, f2, out)
@@ -282,15 +293,38 @@ class RelationalFunction(torch.autograd.Function):
         gW, gB = [None] * L, [None] * L
         dq = None
         dx = None
+        # The weight gradients are not needed by anything upstream: with the fused chain all dZ_l exist now, so
+        # the L wgrad launches go to a side stream and overlap the rest of this backward AND the conv / LSTM
+        # backward that autograd runs next (small kernels that leave the chip mostly empty).  The main stream
+        # re-joins at the end of the backward pass (engine callback).  Only when every parameter's .grad is
+        # None (assign, not accumulate: autograd then launches no kernel on these tensors before the join).
+        overlap = (fused_bwd and os.environ.get("RN_NO_WGRAD_OVERLAP", "0") != "1"
+                   and all(p.grad is None for p in ctx.param_refs))
+        if overlap:
+            main, side = torch.cuda.current_stream(), _side_stream(dev)
+            side.wait_stream(main)
+            keep = [list(dZs), list(inputs)]                       # keep operands alive until the join
+            with torch.cuda.stream(side):
+                for l in range(L):
+                    N, kt, kp = plan.widths[l], plan.ktrue[l], plan.kpad[l]
+                    gW[l] = torch.empty(N, kt, **f32)
+                    gB[l] = torch.empty(N, **f32)
+                    H.g_linear_bwd_wgrad(dZ_of[l], N, inputs[l], kp, gW[l], gB[l], code, M, N, kp, kt)
+
+            def _join():
+                torch.cuda.current_stream().wait_stream(side)
+                keep.clear()
+            torch.autograd.Variable._execution_engine.queue_callback(_join)
         for l in reversed(range(L)):
             N = plan.widths[l]
             A_l = inputs[l]
             kt, kp = plan.ktrue[l], plan.kpad[l]
             if fused_bwd:
                 dZ = dZ_of.pop(l)
-            gW[l] = torch.empty(N, kt, **f32)
-            gB[l] = torch.empty(N, **f32)
-            H.g_linear_bwd_wgrad(dZ, N, A_l, kp, gW[l], gB[l], code, M, N, kp, kt)
+            if not overlap:
+                gW[l] = torch.empty(N, kt, **f32)
+                gB[l] = torch.empty(N, **f32)
+                H.g_linear_bwd_wgrad(dZ, N, A_l, kp, gW[l], gB[l], code, M, N, kp, kt)
             wl = g_w[l] if g_w[l].is_contiguous() else g_w[l].contiguous()
             if l == plan.inject:
                 Rq = torch.empty(B, N, **f32)
