@@ -100,6 +100,26 @@ int rn_g_chain_fwd_f16s(const void* P, int ldp, const void* const* Whi, const vo
                         const float* const* bias, void* const* H, const int* K, float* xg_part, int M, int L,
                         int G, void* stream);
 
+/* Register-resident forward chain (rn_chain_rr.hip): same contract as rn_g_chain_fwd for the headline
+ * shape family (L == 4, G == 256, layer-0 reduction length K0 == 192 or 256, M % 256 == 0), different
+ * mapping: 8 waves x 32 pair rows per workgroup, the activation stays in MFMA operand registers from
+ * layer to layer, LDS carries only the weight stream.  Wf[l]: fragment-major bf16 images (128 KB each)
+ * written by rn_pack_matrix_frag -- layer 0 packed `natural` (its operand is read from the P rows),
+ * layers 1..3 packed permuted (their operand is the previous layer's MFMA output).
+ * H: all four (M, 256) bf16 activations, or NULL (inference; then xg_part is required).
+ * xg_part: (M/32, 256) fp32 per-wave column sums of the last activation, or NULL; requires n*n % 32 == 0
+ * when used -- reduce with rn_pair_sum_fwd(xg_part, 256, xg, ws, RN_F32, B, n*n/32, 256). */
+int rn_g_chain_rr_tile(void);
+int rn_g_chain_fwd_rr(const void* P, int ldp, const void* const* Wf, const float* const* bias, void* const* H,
+                      int K0, float* xg_part, int M, int L, int G, void* stream);
+
+/* MFMA-fragment-major weight image for rn_g_chain_fwd_rr: dst (65536 bf16) gets, for output block ob,
+ * K16 step ks, lane, element e:  src[32 ob + lane % 32][kidx] (0 beyond R rows / C columns) with
+ *   natural != 0:  kidx = 16 ks + 8 (lane / 32) + e
+ *   natural == 0:  kidx = 32 (ks / 2) + 4 (lane / 32) + 8 (2 (ks % 2) + e / 4) + e % 4
+ * src: fp32, element (r, c) at src[r * sr + c * sc] (model.py:96-99 nn.Linear weight: sr = in, sc = 1). */
+int rn_pack_matrix_frag(const float* src, long sr, long sc, int R, int C, void* dst, int natural, void* stream);
+
 /* Fused backward chain (bf16 storage): pair-sum broadcast + last ReLU gate + all L-1 dgrad steps
  *  for every 128-row tile, tile resident in LDS:
  *   dZ[0]   = dxg[b] * (HL > 0)                                   (gradient of layer L-1's pre-activation)

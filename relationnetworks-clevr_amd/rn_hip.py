@@ -32,6 +32,9 @@ SIGNATURES = {
     "rn_g_linear_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_tile": (_I, []),
     "rn_g_chain_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_g_chain_rr_tile": (_I, []),
+    "rn_g_chain_fwd_rr": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "rn_pack_matrix_frag": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
     "rn_g_chain_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_pair_sum_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_sum_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
@@ -196,6 +199,25 @@ def g_chain_fwd(P, ldp, Wps, biases, Hs, Ks, xg_part, code, M, G):
     hp = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs])
     kk = (C.c_int * L)(*Ks)
     _check(load().rn_g_chain_fwd(P.data_ptr(), ldp, wp, bp, hp, kk, _ptr(xg_part), code, M, L, G, _stream()), "rn_g_chain_fwd")
+
+
+def g_chain_rr_tile() -> int:
+    return load().rn_g_chain_rr_tile()
+
+
+def pack_matrix_frag(src, sr, sc, R, Cc, dst, natural, src_offset=0):
+    _check(load().rn_pack_matrix_frag(src.data_ptr() + 4 * src_offset, sr, sc, R, Cc, dst.data_ptr(), int(natural), _stream()),
+           "rn_pack_matrix_frag")
+
+
+@_timed("g_fwd")
+def g_chain_fwd_rr(P, ldp, Wfs, biases, Hs, K0, xg_part, M, G):
+    """Register-resident forward chain; Hs is None (inference) or the 4 activation buffers."""
+    L = len(Wfs)
+    wp = (C.c_void_p * L)(*[w.data_ptr() for w in Wfs])
+    bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
+    hp = (C.c_void_p * L)(*[h.data_ptr() for h in Hs]) if Hs is not None else None
+    _check(load().rn_g_chain_fwd_rr(P.data_ptr(), ldp, wp, bp, hp, K0, _ptr(xg_part), M, L, G, _stream()), "rn_g_chain_fwd_rr")
 
 
 def pack_matrix_split(src, sr, sc, R, Cc, hi, lo, ld, Rpad):

@@ -209,6 +209,65 @@ def test_g_chain_fwd_fused(H, K0, K0true, L, store):
         assert rel(part.cpu().numpy(), prev.reshape(M // T, T, G).sum(1, dtype=np.float64)) <= 2e-3
 
 
+def frag_pack_ref(W, natural):
+    """numpy statement of rn_pack_matrix_frag (include/rn_hip.h)."""
+    R, Cc = W.shape
+    out = np.zeros((8, 16, 64, 8), np.float32)
+    for ks in range(16):
+        for lane in range(64):
+            h, m = lane >> 5, lane & 31
+            for e in range(8):
+                kidx = 16 * ks + 8 * h + e if natural else 32 * (ks >> 1) + 4 * h + 8 * (2 * (ks & 1) + (e >> 2)) + (e & 3)
+                if kidx < Cc:
+                    out[:, ks, lane, e] = W[m:256:32, kidx] if R == 256 else [W[32 * ob + m, kidx] if 32 * ob + m < R else 0 for ob in range(8)]
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("natural", [1, 0])
+def test_pack_matrix_frag(H, natural):
+    W = bf16_round(formula.hash_uniform((256, 180 if natural else 256), 330, -1, 1))
+    dst = torch.empty(65536, dtype=torch.bfloat16, device="cuda")
+    H.pack_matrix_frag(dev(W), W.shape[1], 1, 256, W.shape[1], dst, natural)
+    assert np.array_equal(dst.float().cpu().numpy(), frag_pack_ref(W, natural))
+
+
+@pytest.mark.parametrize("K0,K0true,store,M", [(192, 180, True, 256 * 300), (256, 256, True, 256 * 3), (192, 180, False, 256 * 520)])
+def test_g_chain_fwd_rr(H, K0, K0true, store, M):
+    """Register-resident chain: every stored activation must equal one un-fused layer applied to the kernel's
+    OWN previous activation (<= 1 bf16 ulp); the per-wave pair-sum partials must be the column sums of the
+    last activation.  300 / 520 tiles > 256 CUs: the persistent loop, its seams and the dummy tail are exercised."""
+    L, G = 4, 256
+    P = np.zeros((M, K0), np.float32); P[:, :K0true] = formula.hash_uniform((M, K0true), 300, -1, 1)
+    P = bf16_round(P)
+    Ws, bs, Wf = [], [], []
+    for l in range(L):
+        kt = K0true if l == 0 else G
+        W = bf16_round(formula.hash_uniform((G, kt), 310 + l, -0.15, 0.15))
+        Ws.append(W); bs.append(formula.hash_uniform((G,), 320 + l, -0.3, 0.3))
+        f = torch.empty(65536, dtype=torch.bfloat16, device="cuda")
+        H.pack_matrix_frag(dev(W), kt, 1, G, kt, f, l == 0)
+        Wf.append(f)
+    Hs = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(L)] if store else None
+    part = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
+    H.g_chain_fwd_rr(dev(P).bfloat16(), K0, Wf, [dev(b) for b in bs], Hs, K0, part, M, G)
+    torch.cuda.synchronize()
+    prev = P[:, :K0true]
+    if store:
+        for l in range(L):
+            got = Hs[l].float().cpu().numpy()
+            ref = np.maximum(prev.astype(np.float64) @ Ws[l].astype(np.float64).T + bs[l], 0)
+            err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
+            assert err.max() <= BF16_ULP, (l, err.max())
+            prev = got
+        # the pair sum adds the UN-rounded fp32 activations (not the stored bf16 copies)
+        assert rel(part.cpu().numpy(), ref.reshape(M // 32, 32, G).sum(1)) <= F32_TOL
+    else:
+        for l in range(L):
+            ref = np.maximum(prev.astype(np.float64) @ Ws[l].astype(np.float64).T + bs[l], 0)
+            prev = bf16_round(ref)
+        assert rel(part.cpu().numpy(), ref.reshape(M // 32, 32, G).sum(1)) <= 2e-3
+
+
 def test_g_chain_fwd_f16s(H):
     """f16s chain (fp16 tile x fp16 hi+lo weights): against a float64 emulation that rounds the tile to fp16
     after every layer and uses the same split weights.  Stored activations are bf16 copies of the fp16 tile."""

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Time the forward chains on the headline shape (M = 64 * 4096 pair rows): old LDS-resident kernel vs the
+register-resident one, with and without activation stores."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import torch
+import relationnetworks_clevr_amd as pkg
+H = pkg.rn_hip
+H.load()
+M, G, K0 = 64 * 4096, 256, 192
+torch.manual_seed(0)
+P = (torch.rand(M, K0, device="cuda") * 2 - 1).bfloat16()
+Ws = [(torch.rand(G, K0 if l == 0 else G, device="cuda") - 0.5) * 0.3 for l in range(4)]
+bs = [(torch.rand(G, device="cuda") - 0.5) * 0.6 for _ in range(4)]
+Wp = [w.bfloat16().contiguous() for w in Ws]
+Wf = []
+for l, w in enumerate(Ws):
+    f = torch.empty(65536, dtype=torch.bfloat16, device="cuda")
+    H.pack_matrix_frag(w, w.shape[1], 1, G, w.shape[1], f, l == 0)
+    Wf.append(f)
+Hs = [torch.empty(M, G, dtype=torch.bfloat16, device="cuda") for _ in range(4)]
+part_old = torch.empty(M // H.g_chain_tile(), G, dtype=torch.float32, device="cuda")
+part_rr = torch.empty(M // 32, G, dtype=torch.float32, device="cuda")
+
+
+def timeit(fn, n=20):
+    """median single-launch duration (event bracket per launch: host launch cost does not count)"""
+    for _ in range(3):
+        fn()
+    ts = []
+    for _ in range(n):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+flops = 2.0 * M * G * (K0 + 3 * G)
+for name, fn in [
+    ("old  store", lambda: H.g_chain_fwd(P, K0, Wp, bs, Hs, [K0, G, G, G], part_old, 0, M, G)),
+    ("old  nostore", lambda: H.g_chain_fwd(P, K0, Wp, bs, [None] * 4, [K0, G, G, G], part_old, 0, M, G)),
+    ("rr   store", lambda: H.g_chain_fwd_rr(P, K0, Wf, bs, Hs, K0, part_rr, M, G)),
+    ("rr   store noxg", lambda: H.g_chain_fwd_rr(P, K0, Wf, bs, Hs, K0, None, M, G)),
+    ("rr   nostore", lambda: H.g_chain_fwd_rr(P, K0, Wf, bs, None, K0, part_rr, M, G)),
+]:
+    us = timeit(fn)
+    print("%-14s %8.1f us   %7.1f TFLOP/s" % (name, us, flops / us * 1e-6))
+for abl in ():
+    os.environ["RN_RR_ABL"] = str(abl)
+    us = timeit(lambda: H.g_chain_fwd_rr(P, K0, Wf, bs, None, K0, part_rr, M, G))
+    print("rr nostore ablation %2d (1=no sync 2=no dma 4=no ring reads 8=no epilogue): %8.1f us" % (abl, us))
