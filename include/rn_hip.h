@@ -100,18 +100,36 @@ int rn_g_chain_fwd_f16s(const void* P, int ldp, const void* const* Whi, const vo
                         const float* const* bias, void* const* H, const int* K, float* xg_part, int M, int L,
                         int G, void* stream);
 
-/* Register-resident forward chain (rn_chain_rr.hip): same contract as rn_g_chain_fwd for the headline
- * shape family (L == 4, G == 256, layer-0 reduction length K0 == 192 or 256, M % 256 == 0), different
- * mapping: 8 waves x 32 pair rows per workgroup, the activation stays in MFMA operand registers from
- * layer to layer, LDS carries only the weight stream.  Wf[l]: fragment-major bf16 images (128 KB each)
- * written by rn_pack_matrix_frag -- layer 0 packed `natural` (its operand is read from the P rows),
- * layers 1..3 packed permuted (their operand is the previous layer's MFMA output).
- * H: all four (M, 256) bf16 activations, or NULL (inference; then xg_part is required).
- * xg_part: (M/32, 256) fp32 per-wave column sums of the last activation, or NULL; requires n*n % 32 == 0
- * when used -- reduce with rn_pair_sum_fwd(xg_part, 256, xg, ws, RN_F32, B, n*n/32, 256). */
+/* Register-resident chains (rn_chain_rr.hip): the headline shape family -- L == 4, G == 256, question
+ * injected at layer 0 with a padded layer-0 reduction length K0 of 192 or 256, M % 256 == 0.  Same
+ * arithmetic as rn_g_chain_fwd / rn_g_chain_bwd (bf16 operands, fp32 accumulate), different mapping:
+ * 8 waves x 32 pair rows per workgroup, the activation stays in MFMA operand registers from layer to
+ * layer, LDS carries only the weight stream.
+ *
+ * Forward.  Wf[l]: fragment-major bf16 images (128 KB each) written by rn_pack_matrix_frag -- layer 0
+ * packed `natural` (its operand is read from the P rows), layers 1..3 permuted (their operand is the
+ * previous layer's MFMA output).
+ * H: NULL / four NULLs (inference; xg_part required), all four (M, 256) bf16 activations, or -- with
+ *    mask -- H[0..2] only (H[3] NULL): nobody needs the last activation once its pair sum and its ReLU
+ *    mask are produced on chip.
+ * mask: NULL, or four buffers of rn_g_chain_rr_mask_bytes(M) = 32 M bytes: the ReLU gate (pre-activation
+ *    > 0) of every element of layer l as 64-bit LANE masks in the kernel's own accumulator layout
+ *    (opaque; the consumer is rn_g_chain_bwd_rr).  Requires H[0..2].
+ * xg_part: (M/32, 256) fp32 sums of the UN-rounded last activation over each wave's 32 pair rows, or NULL;
+ *    requires n*n % 32 == 0 -- reduce with rn_pair_sum_fwd(xg_part, 256, xg, ws, RN_F32, B, n*n/32, 256). */
 int rn_g_chain_rr_tile(void);
+size_t rn_g_chain_rr_mask_bytes(int M);
 int rn_g_chain_fwd_rr(const void* P, int ldp, const void* const* Wf, const float* const* bias, void* const* H,
-                      int K0, float* xg_part, int M, int L, int G, void* stream);
+                      void* const* mask, int K0, float* xg_part, int M, int L, int G, void* stream);
+
+/* Backward (pair-sum broadcast + ReLU gates + the three dgrad steps):
+ *   dZ[0]   = dxg[b] * gate_3                         b = question of the pair row
+ *   dZ[s+1] = (dZ[s] @ W_{3-s}) * gate_{2-s}          s = 0, 1, 2
+ * gate_l = mask[l] of the forward call.  Wtf[s]: fragment-major image of W_{3-s}^T, i.e.
+ * rn_pack_matrix_frag(W, 1, in_features, 256, 256, dst, natural = (s == 0)).  All four dZ (M, 256) bf16 are
+ * written (wgrad and the pair reduction consume them).  rows_per_question (= n*n) % 32 == 0. */
+int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M,
+                      int rows_per_question, int L, int G, void* stream);
 
 /* MFMA-fragment-major weight image for rn_g_chain_fwd_rr: dst (65536 bf16) gets, for output block ob,
  * K16 step ks, lane, element e:  src[32 ob + lane % 32][kidx] (0 beyond R rows / C columns) with

@@ -47,11 +47,70 @@ typedef __attribute__((address_space(1))) unsigned char gbl_u8;
 typedef __attribute__((address_space(1))) const unsigned char gbl_cu8;
 typedef __attribute__((ext_vector_type(2))) short s16x2;
 
+typedef unsigned long long u64;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(3))) const Frag lds_frag;
+
 struct RRArgs {
   const bf16* W[RR_L];                                  // fragment-major (rn_pack_matrix_frag), 128 KB each
   const float* bias[RR_L];
   bf16* out[RR_L];                                      // H_l (M, 256) or null
+  u64* mask[RR_L];                                      // ReLU lane masks of layer l (M * 32 bytes) or null
 };
+struct RRBwdArgs {
+  const bf16* W[RR_L - 1];                              // step s: fragment-major W_{3-s}^T
+  const u64* mask[RR_L];                                // lane masks written by the forward kernel
+  bf16* dZ[RR_L];                                       // dZ[s] = gradient of the pre-activation of layer 3-s, (M, 256)
+  const float* dxg;                                     // (B, 256) fp32
+  int rows_per_b;
+};
+
+// What both kernels share: the weight stream (LDS-DMA ring) and its fragment reads.
+struct RRCore {
+  unsigned char* lds;
+  int lane, w, n, h;
+  unsigned lane16;
+  lds_u8* rbase[3];
+  __device__ __forceinline__ void init(unsigned char* l) {
+    lds = l;
+    lane = threadIdx.x & 63;
+    w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    n = lane & 31;
+    h = lane >> 5;
+    lane16 = (unsigned)lane * 16u;
+    // the ring spans 128 KB but a ds_read immediate reaches 64 KB: three lane-constant bases, made opaque so
+    // that the compiler does not materialise (and keep, and spill) one address register per far fragment
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      rbase[r] = (lds_u8*)lds + r * 65536 + lane16;
+      asm volatile("" : "+v"(rbase[r]));
+    }
+  }
+  // one 1-KB piece of a 16-KB weight block: uniform base (SGPR pair) + one lane-constant 32-bit offset
+  __device__ __forceinline__ void dma_piece(const bf16* Wl, int ob2, int slot, int i) const {
+    unsigned z = 0;
+    asm volatile("" : "+s"(z));                        // opaque 0: the base is computed AT the use (SALU), not hoisted and spilled
+    gbl_cu8* ub = (gbl_cu8*)(reinterpret_cast<const unsigned char*>(Wl) + (z + ob2 * RR_STAGE + (RR_DPW * w + i) * 1024));
+    asm volatile("" : "+s"(ub));                       // ... and stays an SGPR base (no per-piece VGPR address)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + lane16),
+                                     (__attribute__((address_space(3))) void*)(lds + RR_OFF_RING + slot * RR_STAGE + (RR_DPW * w + i) * 1024), 16, 0, 0);
+  }
+  __device__ __forceinline__ Frag rd_frag(int slot, int ks) const {
+    const int abs = RR_OFF_RING + slot * RR_STAGE + ks * 1024, r = abs >> 16;
+    return *reinterpret_cast<lds_frag*>(rbase[r] + (abs & 0xffff));
+  }
+};
+
+// four lane masks (SGPR pairs, fresh from v_cmp) -> 32 contiguous bytes.  Scalar stores go through the scalar
+// data cache: the kernel ends with s_dcache_wb.  hipcc neither counts nor pads them (s_nop: VALU-written SGPR
+// read by SMEM).
+__device__ __forceinline__ void mask_store4(u64* p, u64 m0, u64 m1, u64 m2, u64 m3) {
+  asm volatile("s_nop 4\n\ts_store_dwordx2 %0, %4, 0x0\n\ts_store_dwordx2 %1, %4, 0x8\n\ts_store_dwordx2 %2, %4, 0x10\n\t"
+               "s_store_dwordx2 %3, %4, 0x18"
+               :
+               : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(p)
+               : "memory");
+}
 
 template <int N> struct IC { static constexpr int value = N; };
 
@@ -89,46 +148,53 @@ extern "C" int rn_pack_matrix_frag(const float* src, long sr, long sc, int R, in
   return 0;
 }
 
-template <int NK0, bool STORE, bool XG, int ABL = 0>
+// ---- counted waits ------------------------------------------------------------------------------------------
+// At the top of stage s the weights of stage s+1 must have landed.  vmcnt retires in order and counts every
+// VMEM operation of the wave, so the wait names how many operations YOUNGER than those weight requests may
+// stay in flight: the requests of the five stages in between plus whatever else those stages issue (stores,
+// next-tile row loads).  The models below give a LOWER bound of that number per site -- waiting for more than
+// necessary is always safe, waiting for less is a race.
+template <int NK0, bool STORE, bool ST3, bool XG>
+struct FwdVm {
+  static constexpr int PF_PER = (NK0 + 7) / 8;                       // next-tile row loads per stage of the last layer
+  static constexpr int ops(int sidx) {                                // VMEM operations a stage issues (per wave)
+    int k = RR_DPW;
+    if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += 2;
+    if ((sidx >> 3) == RR_L - 1)
+      for (int c = 0; c < PF_PER; ++c) k += ((sidx & 7) * PF_PER + c < NK0) ? 1 : 0;
+    return k;
+  }
+  static constexpr int tail() { return (STORE && ST3 ? 4 : 0) + (XG ? 8 : 0); }
+  static constexpr int younger(int sidx, bool first) {
+    int k = 0;
+    for (int t = sidx - 5; t < sidx; ++t) k += t >= 0 ? ops(t) : (first ? 0 : ops(t + 8 * RR_L));
+    if (sidx < 5 && !first) k += tail();
+    if (first && sidx <= 5) k += RR_DPW * (5 - sidx) + NK0;          // the prologue's later requests and the first pair rows
+    return k < 63 ? k : 63;
+  }
+};
+struct BwdVm {
+  static constexpr int ops(int sidx) { return RR_DPW + (sidx >= 2 ? 2 : 0); }
+  static constexpr int younger(int sidx) {                            // the tile prologue (56 operations) is younger too
+    int k = sidx < 5 ? 40 : 0;
+    for (int t = sidx - 5 > 0 ? sidx - 5 : 0; t < sidx; ++t) k += ops(t);
+    return k < 63 ? k : 63;
+  }
+};
+
+// =================================================================================================== forward
+template <int NK0, bool STORE, bool ST3, bool MASK, bool XG>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restrict__ P, int ldp, RRArgs a,
                                                            float* __restrict__ xg_part, int ntiles) {
   static_assert(NK0 % 4 == 0 && NK0 >= 4 && NK0 <= 16, "layer-0 reduction length");
+  typedef FwdVm<NK0, STORE, ST3, XG> Vm;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
-  const int t = threadIdx.x, lane = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int n = lane & 31, h = lane >> 5;
+  RRCore k;
+  k.init(lds);
+  const int t = threadIdx.x, lane = k.lane, w = k.w, n = k.n, h = k.h;
   unsigned char* const stg = lds + RR_OFF_STG + w * RR_STG;
   float* const bias_s = reinterpret_cast<float*>(lds + RR_OFF_BIAS);
-  // counted waits: at the top of stage s the weights of stage s+1 must have landed.  Younger than them are
-  // 5 stages of weight requests (2 per wave and stage) and, when activations are stored, 2 stores per stage;
-  // the first stages of a tile have no copy-out yet (the tail of the previous tile did it), hence the
-  // smaller layer-0 count.  Waiting for MORE than necessary is always safe.
-  constexpr int VM_L0 = STORE ? 16 : 10, VM_LX = STORE ? 20 : 10;
 
-  const unsigned lane16 = (unsigned)lane * 16u;
-  auto dma_piece = [&](const bf16* Wl, int ob2, int slot, int i) {
-    // uniform base (SGPR pair) + one lane-constant 32-bit offset: no per-piece address registers
-    unsigned z = 0;
-    asm volatile("" : "+s"(z));                        // opaque 0: the base is computed AT the use (SALU), not hoisted and spilled
-    gbl_cu8* ub = (gbl_cu8*)(reinterpret_cast<const unsigned char*>(Wl) + (z + ob2 * RR_STAGE + (RR_DPW * w + i) * 1024));
-    asm volatile("" : "+s"(ub));                       // ... and stays an SGPR base (no per-piece VGPR address)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + lane16),
-                                     (__attribute__((address_space(3))) void*)(lds + RR_OFF_RING + slot * RR_STAGE + (RR_DPW * w + i) * 1024), 16, 0, 0);
-  };
-  // the ring spans 128 KB but a ds_read immediate reaches 64 KB: three lane-constant bases, made opaque so
-  // that the compiler does not materialise (and keep, and spill) one address register per far fragment
-  typedef __attribute__((address_space(3))) unsigned char lds_u8;
-  typedef __attribute__((address_space(3))) const Frag lds_frag;
-  lds_u8* rbase[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    rbase[r] = (lds_u8*)lds + r * 65536 + lane16;
-    asm volatile("" : "+v"(rbase[r]));
-  }
-  auto rd_frag = [&](int slot, int ks) -> Frag {
-    const int abs = RR_OFF_RING + slot * RR_STAGE + ks * 1024, r = abs >> 16;
-    return *reinterpret_cast<lds_frag*>(rbase[r] + (abs & 0xffff));
-  };
   const unsigned prow_off = (unsigned)(n * ldp + 8 * h) * 2u;         // this lane's byte offset inside a wave's 32 pair rows
   auto load_row_frag = [&](long m0w, int ks) -> Frag {                // layer-0 operand straight from the pair rows
     gbl_cu8* base = (gbl_cu8*)reinterpret_cast<const unsigned char*>(P + m0w * ldp);
@@ -146,7 +212,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
 #pragma unroll
   for (int s = 0; s < RR_LA; ++s)
 #pragma unroll
-    for (int i = 0; i < RR_DPW; ++i) dma_piece(a.W[0], s, s, i);
+    for (int i = 0; i < RR_DPW; ++i) k.dma_piece(a.W[0], s, s, i);
 #pragma unroll
   for (int ks = 0; ks < NK0; ++ks) actA[ks] = load_row_frag((long)tile * RR_TM + RR_WR * w, ks);
   if (t < RR_G) {
@@ -156,10 +222,12 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < RR_RD; ++r) ring[r] = rd_frag(0, r);
+  for (int r = 0; r < RR_RD; ++r) ring[r] = k.rd_frag(0, r);
+  bool first = true;
 
   for (; tile < ntiles; tile += gridDim.x) {
     const long m0w = (long)tile * RR_TM + RR_WR * w;                 // this wave's first pair row
+    const long wt = (long)tile * RR_NW + w;                           // ... = its 32-row block number
     const int tnext = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
     const long m0n = (long)tnext * RR_TM + RR_WR * w;
     float xs[8];                                                      // pair-sum partials: feature 32 ob + lane % 32, this lane's 16 rows
@@ -167,7 +235,6 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
     for (int i = 0; i < 8; ++i) xs[i] = 0.f;
 
     // ---- epilogue pieces ---------------------------------------------------------------------------------
-    // group j of output block (pl, pob): features 32 pob + 8 j + 4 h + {0..3} of row n
     auto bias_read = [&](int l, int ob) {                             // -> C operand of the block's first MFMA
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -176,14 +243,21 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
         for (int r = 0; r < 4; ++r) cinit[4 * j + r] = b[r];
       }
     };
-    auto epi_group = [&](int pl, int pob, int j, int phase_lo, int phase_hi, Frag* dst, f32x4 (&v)[4], u32x2 (&pk)[4]) {
-      (void)v;
-      if (phase_lo <= 1 && 1 <= phase_hi) {                           // (the bias came in through the accumulator)
-        pk[j][0] = relu_pack_bf16(acc[pob & 1][4 * j + 0], acc[pob & 1][4 * j + 1]);
-        pk[j][1] = relu_pack_bf16(acc[pob & 1][4 * j + 2], acc[pob & 1][4 * j + 3]);
+    auto mask_out = [&](int pl, int pob, int j, float x0, float x1, float x2, float x3) {
+      if constexpr (MASK) mask_store4(a.mask[pl] + (wt * 8 + pob) * 16 + 4 * j, __ballot(x0 > 0.f), __ballot(x1 > 0.f),
+                                      __ballot(x2 > 0.f), __ballot(x3 > 0.f));
+    };
+    // layers 0..2, group j of output block (pl, pob): features 32 pob + 8 j + 4 h + {0..3} of row n (the bias came
+    // in through the accumulator)
+    auto epi_group = [&](int pl, int pob, int j, int phase_lo, int phase_hi, Frag* dst, u32x2 (&pk)[4]) {
+      const f32x16& c = acc[pob & 1];
+      if (phase_lo <= 0 && 0 <= phase_hi) mask_out(pl, pob, j, c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]);
+      if (phase_lo <= 1 && 1 <= phase_hi) {
+        pk[j][0] = relu_pack_bf16(c[4 * j + 0], c[4 * j + 1]);
+        pk[j][1] = relu_pack_bf16(c[4 * j + 2], c[4 * j + 3]);
       }
       if (phase_lo <= 2 && 2 <= phase_hi) {
-        *reinterpret_cast<u32x2*>(stg + n * RR_SRS + 16 * j + 8 * h) = pk[j];
+        if constexpr (STORE) *reinterpret_cast<u32x2*>(stg + n * RR_SRS + 16 * j + 8 * h) = pk[j];
         if (dst) {
           dst[2 * pob + (j >> 1)][(j & 1) * 2 + 0] = pk[j][0];
           dst[2 * pob + (j >> 1)][(j & 1) * 2 + 1] = pk[j][1];
@@ -196,11 +270,9 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
     };
     const unsigned orow_off = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
     auto co_store = [&](int cl, int cob, int q) {
-      if constexpr (STORE) {
-        gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.out[cl] + m0w * RR_G);
-        asm volatile("" : "+s"(base));
-        *reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2) = co[q];
-      }
+      gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.out[cl] + m0w * RR_G);
+      asm volatile("" : "+s"(base));
+      *reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2) = co[q];
     };
     // LAST layer: operands un-swapped (activations = A, weights = B), so D[row][feature] leaves a lane with ONE
     // feature (32 pob + lane % 32) of 16 rows (8 (i / 4) + 4 h + i % 4): the pair sum (model.py:151-152) is an
@@ -213,100 +285,100 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
       }
       if (phase_lo <= 1 && 1 <= phase_hi) {
         if constexpr (XG) xs[pob] += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        mask_out(RR_L - 1, pob, j, v[j][0], v[j][1], v[j][2], v[j][3]);
       }
       if (phase_lo <= 2 && 2 <= phase_hi) {
-        if constexpr (STORE) {
+        if constexpr (STORE && ST3) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(stg + (8 * j + 4 * h + r) * RR_SRS + n * 2) = (bf16)v[j][r];
         }
       }
     };
-    // ---- one layer = 8 stages ------------------------------------------------------------------------------
-    auto layer = [&](auto lc, Frag (&in)[16], Frag (&out)[16]) {
-      constexpr int l = decltype(lc)::value;
+    // ---- one stage = one 32-feature output block of one layer ------------------------------------------------
+    auto stage = [&](auto lc, auto obc, Frag (&in)[16], Frag (&out)[16]) {
+      constexpr int l = decltype(lc)::value, ob = decltype(obc)::value;
       constexpr int NK = (l == 0) ? NK0 : 16;
       constexpr int CPG = NK / 4;                                     // MFMA gaps per epilogue group
-      constexpr int PF_PER = (NK0 + 7) / 8;                           // next-tile row loads per stage (last layer)
+      constexpr int sidx = l * 8 + ob;
+      constexpr bool has_prev = sidx > 0;                             // (l, ob) == (0, 0): the tail of the last tile did it
+      constexpr int pl = ob ? l : l - 1, pob = ob ? ob - 1 : 7;
+      constexpr int cl = (sidx - 2) >> 3, cob = (sidx - 2) & 7;
+      constexpr bool has_co = STORE && sidx >= 2 && (cl < RR_L - 1 || ST3);
+      constexpr int didx = sidx + RR_LA;                              // stage whose weights are requested now
+      constexpr int dl = (didx >> 3) & 3, dob = didx & 7;
+      constexpr int nob = (sidx + 1) & 7;                             // next stage (the read-ahead crosses into it)
+      if (l < RR_L - 1) bias_read(l, ob);
+      if (has_prev && pl == RR_L - 1) b3 = bias_s[pl * RR_G + 32 * pob + n];
+      if (l == 0 && Vm::younger(sidx, true) != Vm::younger(sidx, false)) {
+        if (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Vm::younger(sidx, true)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Vm::younger(sidx, false)) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Vm::younger(sidx, false)) : "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (has_co) co_read();
+      __builtin_amdgcn_sched_barrier(0);
+      Frag* dst = nullptr;
+      if (has_prev && pl < RR_L - 1) dst = ob ? out : in;
+      f32x4 v[4];
+      u32x2 pk[4];
 #pragma unroll
-      for (int ob = 0; ob < 8; ++ob) {
-        const int sidx = l * 8 + ob;
-        const bool has_prev = sidx > 0;                               // (l, ob) == (0, 0): the tail of the last tile did it
-        const int pl = ob ? l : l - 1, pob = ob ? ob - 1 : 7;
-        const bool has_co = sidx >= 2 && STORE;
-        const int cl = (sidx - 2) >> 3, cob = (sidx - 2) & 7;
-        const int didx = sidx + RR_LA;                                // stage whose weights are requested now
-        const int dl = (didx >> 3) & 3, dob = didx & 7;
-        const int nob = (sidx + 1) & 7;                               // next stage (the read-ahead crosses into it)
-        if (l < RR_L - 1) bias_read(l, ob);
-        if (has_prev && pl == RR_L - 1) b3 = bias_s[pl * RR_G + 32 * pob + n];
-        if (!(ABL & 1)) {
-          if (l == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_L0) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_LX) : "memory");
-          __builtin_amdgcn_s_barrier();
+      for (int ks = 0; ks < NK; ++ks) {
+        const int c = ks;
+        const bf16x8 fw = __builtin_bit_cast(bf16x8, ring[ks % RR_RD]), fx = __builtin_bit_cast(bf16x8, in[ks]);
+        const bf16x8 fa = (l == RR_L - 1) ? fx : fw, fb = (l == RR_L - 1) ? fw : fx;
+        if (ks == 0 && l < RR_L - 1) {
+          acc[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, cinit, 0, 0, 0);
+        } else if (ks == 0) {
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, z, 0, 0, 0);
+        } else {
+          acc[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[ob & 1], 0, 0, 0);
         }
-        asm volatile("" ::: "memory");
-        if (has_co) co_read();
-        __builtin_amdgcn_sched_barrier(0);
-        Frag* dst = nullptr;
-        if (has_prev && pl < RR_L - 1) dst = ob ? out : in;
-        f32x4 v[4];
-        u32x2 pk[4];
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-          const int c = ks;
-          const bf16x8 fw = __builtin_bit_cast(bf16x8, ring[ks % RR_RD]), fx = __builtin_bit_cast(bf16x8, in[ks]);
-          const bf16x8 fa = (l == RR_L - 1) ? fx : fw, fb = (l == RR_L - 1) ? fw : fx;
-          if (ks == 0 && l < RR_L - 1) {
-            acc[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, cinit, 0, 0, 0);
-          } else if (ks == 0) {
-            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            acc[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, z, 0, 0, 0);
+        // ---- fillers of this MFMA gap
+        {                                                             // refill the ring slot just consumed, RR_RD fragments ahead
+          const int f = ks + RR_RD;
+          if (f < NK) ring[ks % RR_RD] = k.rd_frag(ob, f);
+          else ring[ks % RR_RD] = k.rd_frag(nob, f - NK);
+        }
+        if ((c & 1) && (c >> 1) < RR_DPW) k.dma_piece(a.W[dl], dob, dob, c >> 1);
+        if (has_prev && pl == RR_L - 1) {
+          const int j = c / CPG, ph = c % CPG;
+          if (ph < 3) epi3_group(pob, j, ph, ph, v);
+        } else if (has_prev) {
+          const int j = c / CPG, ph = c % CPG;
+          if (CPG >= 3) {
+            if (ph < 3) epi_group(pl, pob, j, ph, ph, dst, pk);
+          } else if (CPG == 2) {
+            if (ph == 0) epi_group(pl, pob, j, 0, 1, dst, pk);
+            else epi_group(pl, pob, j, 2, 2, dst, pk);
           } else {
-            acc[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[ob & 1], 0, 0, 0);
+            epi_group(pl, pob, j, 0, 2, dst, pk);
           }
-          // ---- fillers of this MFMA gap
-          {                                                           // refill the ring slot just consumed, RR_RD fragments ahead
-            const int f = ks + RR_RD;
-            if (ABL & 4) {
-            } else if (f < NK) ring[ks % RR_RD] = rd_frag(ob, f);
-            else ring[ks % RR_RD] = rd_frag(nob, f - NK);
-          }
-          if (!(ABL & 2) && (c & 1) && (c >> 1) < RR_DPW) dma_piece(a.W[dl], dob, dob, c >> 1);
-          if (has_prev && !(ABL & 8) && pl == RR_L - 1) {
-            const int j = c / CPG, ph = c % CPG;
-            if (ph < 3) epi3_group(pob, j, ph, ph, v);
-          } else if (has_prev && !(ABL & 8)) {
-            const int j = c / CPG, ph = c % CPG;
-            if (CPG >= 3) {
-              if (ph < 3) epi_group(pl, pob, j, ph, ph, dst, v, pk);
-            } else if (CPG == 2) {
-              if (ph == 0) epi_group(pl, pob, j, 0, 1, dst, v, pk);
-              else epi_group(pl, pob, j, 2, 2, dst, v, pk);
-            } else {
-              epi_group(pl, pob, j, 0, 2, dst, v, pk);
-            }
-          }
-          if (has_co && (c == 4 || c == 8)) {
-            const int q = (c >> 2) - 1;
-            co_store(cl, cob, q);
-          }
-          if (l == RR_L - 1 && (c & 1) == 0 && (c >> 1) < PF_PER) {   // next tile's pair rows -> the idle half of the ping-pong
-            const int i = ob * PF_PER + (c >> 1);
-            if (i < NK0) out[i] = load_row_frag(m0n, i);
-          }
-          __builtin_amdgcn_sched_barrier(0);
         }
+        if (has_co && (c == 4 || c == 8)) co_store(cl, cob, (c >> 2) - 1);
+        if (l == RR_L - 1 && (c & 1) == 0 && (c >> 1) < Vm::PF_PER) {   // next tile's pair rows -> the idle half of the ping-pong
+          const int i = ob * Vm::PF_PER + (c >> 1);
+          if (i < NK0) out[i] = load_row_frag(m0n, i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
-    layer(IC<0>{}, actA, actB);
-    layer(IC<1>{}, actB, actA);
-    layer(IC<2>{}, actA, actB);
-    layer(IC<3>{}, actB, actA);
+#define RN_LAYER(L_, IN_, OUT_)                                                                                      \
+  stage(IC<L_>{}, IC<0>{}, IN_, OUT_); stage(IC<L_>{}, IC<1>{}, IN_, OUT_); stage(IC<L_>{}, IC<2>{}, IN_, OUT_);      \
+  stage(IC<L_>{}, IC<3>{}, IN_, OUT_); stage(IC<L_>{}, IC<4>{}, IN_, OUT_); stage(IC<L_>{}, IC<5>{}, IN_, OUT_);      \
+  stage(IC<L_>{}, IC<6>{}, IN_, OUT_); stage(IC<L_>{}, IC<7>{}, IN_, OUT_)
+    RN_LAYER(0, actA, actB);
+    RN_LAYER(1, actB, actA);
+    RN_LAYER(2, actA, actB);
+    RN_LAYER(3, actB, actA);
+    first = false;
 
     // ---- tail: blocks (3, 6) and (3, 7) leave the chip
     {
       f32x4 v[4];
-      if constexpr (STORE) {
+      if constexpr (STORE && ST3) {
         co_read();
 #pragma unroll
         for (int q = 0; q < 2; ++q) co_store(RR_L - 1, 6, q);
@@ -314,7 +386,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
       b3 = bias_s[(RR_L - 1) * RR_G + 32 * 7 + n];
 #pragma unroll
       for (int j = 0; j < 4; ++j) epi3_group(7, j, 0, 2, v);
-      if constexpr (STORE) {
+      if constexpr (STORE && ST3) {
         co_read();
 #pragma unroll
         for (int q = 0; q < 2; ++q) co_store(RR_L - 1, 7, q);
@@ -328,8 +400,170 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // trailing (unused) weight requests
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // trailing (unused) weight requests, scalar stores
+  if constexpr (MASK) asm volatile("s_dcache_wb" ::: "memory");
 }
+
+// ================================================================================================== backward
+// dZ[0] = dxg[b] * (H_3 > 0);  dZ[s+1] = (dZ[s] @ W_{3-s}) * (H_{2-s} > 0), s = 0..2 -- the ReLU gates come from the
+// forward kernel's lane masks (32 bytes per pair row and layer instead of a 512-byte activation row).
+__global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int ntiles) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
+  RRCore k;
+  k.init(lds);
+  const int lane = k.lane, w = k.w, n = k.n, h = k.h;
+  unsigned char* const stg = lds + RR_OFF_STG + w * RR_STG;
+  constexpr int NS = RR_L - 1;                                        // dgrad steps
+
+  Frag actA[16], actB[16], ring[RR_RD];
+  f32x16 acc[2];
+  u32x4 co[2];
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+#pragma unroll
+  for (int s = 0; s < RR_LA; ++s)
+#pragma unroll
+    for (int i = 0; i < RR_DPW; ++i) k.dma_piece(a.W[0], s, s, i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RR_RD; ++r) ring[r] = k.rd_frag(0, r);
+  // dword of a block's (un-swapped, last-layer) mask image that holds row n: mask i = 4 (n / 8) + n % 4, half (n / 4) % 2
+  const int rowsel = 2 * (4 * (n >> 3) + (n & 3)) + ((n >> 2) & 1);
+
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long m0w = (long)tile * RR_TM + RR_WR * w;
+    const long wt = (long)tile * RR_NW + w;
+    const long b = m0w / a.rows_per_b;                                // a wave's 32 rows lie in one question
+    auto co_read = [&]() {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) co[q] = *reinterpret_cast<const u32x4*>(stg + (16 * q + (lane >> 2)) * RR_SRS + (lane & 3) * 16);
+    };
+    const unsigned orow_off = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
+    auto co_store = [&](int zi, int cob, int q) {
+      gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.dZ[zi] + m0w * RR_G);
+      asm volatile("" : "+s"(base));
+      *reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2) = co[q];
+    };
+    // ---- prologue: dZ[0] in operand layout (natural feature order) + its copy to HBM
+    {
+      const float* dxb = a.dxg + b * RR_G + 8 * h;
+      const unsigned* m3 = reinterpret_cast<const unsigned*>(a.mask[RR_L - 1]) + wt * 8 * 32 + rowsel;
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob) {
+        const unsigned bits = m3[ob * 32] >> (8 * h);                 // features 32 ob + 8 h + {0..7} and + 16 of row n
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int ks = 2 * ob + s;
+          const f32x4 d0 = *reinterpret_cast<const f32x4*>(dxb + 16 * ks), d1 = *reinterpret_cast<const f32x4*>(dxb + 16 * ks + 4);
+          const float d[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const f32x2 f = {d[2 * p], d[2 * p + 1]};
+            const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+            const unsigned t0 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 16 * s + 2 * p, 1);
+            const unsigned t1 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 16 * s + 2 * p + 1, 1);
+            actA[ks][p] = u & ((t0 & 0xffffu) | (t1 & 0xffff0000u));
+          }
+          *reinterpret_cast<u32x4*>(stg + n * RR_SRS + 32 * s + 16 * h) = actA[ks];
+        }
+        co_read();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) co_store(0, ob, q);
+      }
+    }
+    // ---- one stage = one 32-feature block of one dgrad step ---------------------------------------------------
+    auto stage = [&](auto sc, auto obc, Frag (&in)[16], Frag (&out)[16]) {
+      constexpr int s = decltype(sc)::value, ob = decltype(obc)::value;
+      constexpr int sidx = s * 8 + ob;
+      constexpr bool has_prev = sidx > 0;
+      constexpr int ps = ob ? s : s - 1, pob = ob ? ob - 1 : 7;       // block whose epilogue runs here
+      constexpr int cs = (sidx - 2) >> 3, cob = (sidx - 2) & 7;       // block copied out here
+      constexpr bool has_co = sidx >= 2;
+      constexpr int didx = sidx + RR_LA;
+      constexpr int dl = (didx >> 3) % NS, dob = didx & 7;
+      constexpr int nob = (sidx + 1) & 7;
+      u64 mk[16];
+      if (has_prev) {                                                 // gate of the previous block: layer 2 - ps
+        const u64* mp = a.mask[has_prev ? NS - 1 - ps : 0] + (wt * 8 + pob) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mk[i] = __builtin_nontemporal_load(mp + i);
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BwdVm::younger(sidx)) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (has_co) co_read();
+      __builtin_amdgcn_sched_barrier(0);
+      Frag* dst = nullptr;
+      if (has_prev && ps < NS - 1) dst = ob ? out : in;
+      float x[4][4];
+      u32x2 pk[4];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int c = ks;
+        const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[ks % RR_RD]), fb = __builtin_bit_cast(bf16x8, in[ks]);
+        if (ks == 0) {
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, z, 0, 0, 0);
+        } else {
+          acc[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[ob & 1], 0, 0, 0);
+        }
+        {
+          const int f = ks + RR_RD;
+          if (f < 16) ring[ks % RR_RD] = k.rd_frag(ob, f);
+          else ring[ks % RR_RD] = k.rd_frag(nob, f - 16);
+        }
+        if ((c & 1) && (c >> 1) < RR_DPW) k.dma_piece(a.W[dl], dob, dob, c >> 1);
+        if (has_prev && c >= 2 && c < 14) {                           // epilogue of the previous block, 3 gaps per group
+          const int j = (c - 2) / 3, ph = (c - 2) % 3;
+          if (ph == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[j][r] = __builtin_amdgcn_inverse_ballot_w64(mk[4 * j + r]) ? acc[pob & 1][4 * j + r] : 0.f;
+          } else if (ph == 1) {
+            const f32x2 f0 = {x[j][0], x[j][1]}, f1 = {x[j][2], x[j][3]};
+            pk[j][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f0, bf16x2));
+            pk[j][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f1, bf16x2));
+          } else {
+            *reinterpret_cast<u32x2*>(stg + n * RR_SRS + 16 * j + 8 * h) = pk[j];
+            if (dst) {
+              dst[2 * pob + (j >> 1)][(j & 1) * 2 + 0] = pk[j][0];
+              dst[2 * pob + (j >> 1)][(j & 1) * 2 + 1] = pk[j][1];
+            }
+          }
+        }
+        if (has_co && (c == 4 || c == 8)) co_store(cs + 1, cob, (c >> 2) - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    RN_LAYER(0, actA, actB);
+    RN_LAYER(1, actB, actA);
+    RN_LAYER(2, actA, actB);
+    // ---- tail: blocks (2, 6) and (2, 7)
+    {
+      co_read();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) co_store(NS, 6, q);
+      const u64* mp = a.mask[0] + (wt * 8 + 7) * 16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_inverse_ballot_w64(__builtin_nontemporal_load(mp + 4 * j + r)) ? acc[1][4 * j + r] : 0.f;
+        const f32x2 f0 = {x[0], x[1]}, f1 = {x[2], x[3]};
+        u32x2 pk;
+        pk[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f0, bf16x2));
+        pk[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f1, bf16x2));
+        *reinterpret_cast<u32x2*>(stg + n * RR_SRS + 16 * j + 8 * h) = pk;
+      }
+      co_read();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) co_store(NS, 7, q);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#undef RN_LAYER
 
 static int rr_num_cus() {
   static int n = 0;
@@ -343,51 +577,78 @@ static int rr_num_cus() {
 }
 
 extern "C" int rn_g_chain_rr_tile(void) { return RR_TM; }
+extern "C" size_t rn_g_chain_rr_mask_bytes(int M) { return M > 0 ? (size_t)M * 32 : 0; }
+
+template <int NK0>
+static void rr_fwd_launch(int grid, hipStream_t s, const bf16* P, int ldp, const RRArgs& a, float* xg, int ntiles, bool store,
+                          bool st3, bool mask) {
+#define RN_GO(ST, S3, MK, XG_) g_chain_rr_kernel<NK0, ST, S3, MK, XG_><<<grid, RR_NT, 0, s>>>(P, ldp, a, xg, ntiles)
+  if (!store) RN_GO(false, false, false, true);                        // inference: pair sums only
+  else if (mask && !st3 && xg) RN_GO(true, false, true, true);         // training: H_0..2 + masks + pair sums
+  else if (mask && xg) RN_GO(true, true, true, true);
+  else if (mask) RN_GO(true, true, true, false);
+  else if (xg) RN_GO(true, true, false, true);
+  else RN_GO(true, true, false, false);
+#undef RN_GO
+}
 
 extern "C" int rn_g_chain_fwd_rr(const void* P, int ldp, const void* const* Wf, const float* const* bias, void* const* H,
-                                 int K0, float* xg_part, int M, int L, int G, void* stream) {
+                                 void* const* mask, int K0, float* xg_part, int M, int L, int G, void* stream) {
   RN_CHECK_ARG(P && Wf && bias && M > 0, "rn_g_chain_fwd_rr: bad pointer/size");
   RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_fwd_rr: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
   RN_CHECK_ARG(M % RR_TM == 0, "rn_g_chain_fwd_rr: M=%d must be a multiple of %d", M, RR_TM);
   RN_CHECK_ARG(K0 == 192 || K0 == 256, "rn_g_chain_fwd_rr: layer-0 reduction length %d unsupported (192 or 256)", K0);
   RN_CHECK_ARG(ldp % 8 == 0 && ldp >= K0 && ((uintptr_t)P % 16 == 0), "rn_g_chain_fwd_rr: bad P layout");
   RRArgs a;
-  bool store = false;
+  memset(&a, 0, sizeof(a));
+  int nh = 0, nm = 0;
   for (int l = 0; l < RR_L; ++l) {
     RN_CHECK_ARG(Wf[l] && bias[l], "rn_g_chain_fwd_rr: layer %d weight/bias is NULL", l);
-    RN_CHECK_ARG(((uintptr_t)Wf[l] | (uintptr_t)bias[l] | (uintptr_t)(H ? H[l] : nullptr)) % 16 == 0,
+    RN_CHECK_ARG(((uintptr_t)Wf[l] | (uintptr_t)bias[l] | (uintptr_t)(H ? H[l] : nullptr) | (uintptr_t)(mask ? mask[l] : nullptr)) % 16 == 0,
                  "rn_g_chain_fwd_rr: layer %d pointers must be 16-byte aligned", l);
     a.W[l] = (const bf16*)Wf[l];
     a.bias[l] = bias[l];
     a.out[l] = H ? (bf16*)H[l] : nullptr;
-    store = store || a.out[l];
+    a.mask[l] = mask ? (u64*)mask[l] : nullptr;
+    nh += a.out[l] != nullptr;
+    nm += a.mask[l] != nullptr;
   }
-  RN_CHECK_ARG(store || xg_part, "rn_g_chain_fwd_rr: nothing to compute (no H, no xg_part)");
+  // H: none (inference), all four, or -- together with the masks -- layers 0..2 only (the last activation is
+  // then needed by nobody: its pair sum and its ReLU mask are produced on chip)
+  const bool h012 = nh == 3 && !a.out[RR_L - 1] && nm == RR_L;
+  RN_CHECK_ARG(nh == 0 || nh == RR_L || h012, "rn_g_chain_fwd_rr: H must hold none, all, or (with masks) all but the last activation");
+  RN_CHECK_ARG(nm == 0 || (nm == RR_L && nh >= 3), "rn_g_chain_fwd_rr: masks come as a full set together with the stored activations");
+  RN_CHECK_ARG(nh || xg_part, "rn_g_chain_fwd_rr: nothing to compute (no H, no xg_part)");
   const int ntiles = M / RR_TM;
   const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
-  hipStream_t s = (hipStream_t)stream;
-  const bf16* Pb = (const bf16*)P;
-#define RN_RR(NK0) \
-  do { \
-    if (store && xg_part) g_chain_rr_kernel<NK0, true, true><<<grid, RR_NT, 0, s>>>(Pb, ldp, a, xg_part, ntiles); \
-    else if (store) g_chain_rr_kernel<NK0, true, false><<<grid, RR_NT, 0, s>>>(Pb, ldp, a, xg_part, ntiles); \
-    else g_chain_rr_kernel<NK0, false, true><<<grid, RR_NT, 0, s>>>(Pb, ldp, a, xg_part, ntiles); \
-  } while (0)
-  const char* ae = getenv("RN_RR_ABL");                    // diagnostics: timing-only ablations (results are wrong)
-  const int abl = ae ? atoi(ae) : 0;
-  if (abl && K0 == 192) {
-    switch (abl) {
-      case 1: g_chain_rr_kernel<12, false, true, 1><<<grid, RR_NT, 0, s>>>(Pb, ldp, a, xg_part, ntiles); break;
-      case 2: g_chain_rr_kernel<12, false, true, 2><<<grid, RR_NT, 0, s>>>(Pb, ldp, a, xg_part, ntiles); break;
-      case 3: g_chain_rr_kernel<12, false, true, 3><<<grid, RR_NT, 0, s>>>(Pb, ldp, a, xg_part, ntiles); break;
-      case 4: g_chain_rr_kernel<12, false, true, 4><<<grid, RR_NT, 0, s>>>(Pb, ldp, a, xg_part, ntiles); break;
-      case 7: g_chain_rr_kernel<12, false, true, 7><<<grid, RR_NT, 0, s>>>(Pb, ldp, a, xg_part, ntiles); break;
-      case 8: g_chain_rr_kernel<12, false, true, 8><<<grid, RR_NT, 0, s>>>(Pb, ldp, a, xg_part, ntiles); break;
-      default: g_chain_rr_kernel<12, false, true, 15><<<grid, RR_NT, 0, s>>>(Pb, ldp, a, xg_part, ntiles); break;
-    }
-  } else if (K0 == 192) RN_RR(12);
-  else RN_RR(16);
-#undef RN_RR
+  if (K0 == 192) rr_fwd_launch<12>(grid, (hipStream_t)stream, (const bf16*)P, ldp, a, xg_part, ntiles, nh > 0, nh == RR_L, nm > 0);
+  else rr_fwd_launch<16>(grid, (hipStream_t)stream, (const bf16*)P, ldp, a, xg_part, ntiles, nh > 0, nh == RR_L, nm > 0);
   RN_LAUNCH_CHECK("rn_g_chain_fwd_rr");
+  return 0;
+}
+
+extern "C" int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M,
+                                 int rows_per_question, int L, int G, void* stream) {
+  RN_CHECK_ARG(dxg && mask && Wtf && dZ && M > 0, "rn_g_chain_bwd_rr: bad pointer/size");
+  RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_bwd_rr: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
+  RN_CHECK_ARG(M % RR_TM == 0 && rows_per_question > 0 && rows_per_question % RR_WR == 0 && M % rows_per_question == 0,
+               "rn_g_chain_bwd_rr: M=%d must be a multiple of %d, rows per question=%d of %d", M, RR_TM, rows_per_question, RR_WR);
+  RRBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int l = 0; l < RR_L; ++l) {
+    RN_CHECK_ARG(mask[l] && dZ[l] && (l == RR_L - 1 || Wtf[l]), "rn_g_chain_bwd_rr: entry %d has a NULL pointer", l);
+    RN_CHECK_ARG(((uintptr_t)mask[l] | (uintptr_t)dZ[l] | (uintptr_t)(l < RR_L - 1 ? Wtf[l] : nullptr)) % 16 == 0,
+                 "rn_g_chain_bwd_rr: entry %d pointers must be 16-byte aligned", l);
+    a.mask[l] = (const u64*)mask[l];
+    a.dZ[l] = (bf16*)dZ[l];
+    if (l < RR_L - 1) a.W[l] = (const bf16*)Wtf[l];
+  }
+  RN_CHECK_ARG((uintptr_t)dxg % 16 == 0, "rn_g_chain_bwd_rr: dxg must be 16-byte aligned");
+  a.dxg = dxg;
+  a.rows_per_b = rows_per_question;
+  const int ntiles = M / RR_TM;
+  const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
+  g_chain_rr_bwd_kernel<<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles);
+  RN_LAUNCH_CHECK("rn_g_chain_bwd_rr");
   return 0;
 }

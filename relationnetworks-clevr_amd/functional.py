@@ -54,6 +54,7 @@ class PackedWeights:
         self.key = None
         self.fwd, self.bwd = [], []
         self.hi, self.lo = [], []                  # fp16 split copies for the f16s forward
+        self.frag = []                             # fragment-major copies for the register-resident chain
 
     def get(self, plan: LayerPlan, g_w, code, split=False):
         key = (code, split, tuple((w.data_ptr(), w._version) for w in g_w))
@@ -63,7 +64,8 @@ class PackedWeights:
             return self.fwd, self.bwd
         dt = H.torch_dtype(code)
         dev = g_w[0].device
-        self.fwd, self.bwd, self.hi, self.lo = [], [], [], []
+        self.fwd, self.bwd, self.hi, self.lo, self.frag = [], [], [], [], []
+        rr = rr_chain_ok(plan, code)
         for l, w in enumerate(g_w):
             N, kt = w.shape
             assert kt == plan.ktrue[l] and N == plan.widths[l], (w.shape, plan.ktrue[l], plan.widths[l])
@@ -73,6 +75,10 @@ class PackedWeights:
             wp = torch.empty(N, plan.kpad[l], dtype=dt, device=dev)
             H.pack_matrix(wc, kt, 1, N, kt, wp, code, plan.kpad[l], N)
             self.fwd.append(wp)
+            if rr:
+                wf = torch.empty(256 * 256, dtype=dt, device=dev)
+                H.pack_matrix_frag(wc, kt, 1, N, kt, wf, l == 0)
+                self.frag.append(wf)
             if split:
                 hi = torch.empty(N, plan.kpad[l], dtype=torch.float16, device=dev)
                 lo = torch.empty(N, plan.kpad[l], dtype=torch.float16, device=dev)
@@ -100,6 +106,15 @@ def _side_stream(dev):
     return s
 
 
+def rr_chain_ok(plan: LayerPlan, code):
+    """The register-resident forward chain (rn_chain_rr.hip): bf16, exactly four 256-wide g layers, question
+    injected at layer 0 with a padded layer-0 reduction length of 192 or 256 (the headline shape family)."""
+    if os.environ.get("RN_NO_RR_CHAIN", "0") == "1":
+        return False
+    return (code == H.RN_BF16 and plan.L == 4 and all(w == 256 for w in plan.widths) and plan.kpad[0] in (192, 256)
+            and all(kp == 256 for kp in plan.kpad[1:]))
+
+
 def fused_chain_ok(plan: LayerPlan, code, B, n):
     """The fused LDS-resident chain (rn_chain.hip) covers the headline shape family: bf16 storage,
     all g widths 256, question injected at layer 0 (so every later layer has K == 256), and whole
@@ -110,7 +125,7 @@ def fused_chain_ok(plan: LayerPlan, code, B, n):
             and all(kp == 256 for kp in plan.kpad[1:]) and (B * n * n) % H.g_chain_tile() == 0 and plan.L <= 8)
 
 
-def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None, split=None):
+def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None, split=None, wfrag=None):
     """K1 + K2 chain (+ K3).  Returns (inputs, H_L, xg): the list of layer INPUT buffers
     [A_0 .. A_{L-1}], the last activation H_L and -- when the fused chain ran -- the pair sum xg
     (else None).  layer_hook(l, A_l, H_out) is called after every layer (hook-compat path; forces
@@ -151,6 +166,21 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
     if layer_hook is None and fused_chain_ok(plan, code, B, n):
         G = plan.widths[-1]
         L = plan.L
+        R = 32                                      # pair rows per wave of the register-resident chain
+        if (wfrag is not None and len(wfrag) == L and rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0
+                and (keep_inputs or (n * n) % R == 0)):
+            whole = (n * n) % R == 0
+            Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L)] if keep_inputs else None
+            part = torch.empty(M // R, G, dtype=torch.float32, device=dev) if whole else None
+            H.g_chain_fwd_rr(P, ld0, wfrag, g_b, Hs, ld0, part, M, G)
+            xg = torch.empty(B, G, dtype=torch.float32, device=dev)
+            if whole:
+                H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // R, G)
+            else:
+                H.pair_sum_fwd(Hs[-1], G, xg, code, B, n * n, G)
+            if Hs is None:
+                return [P, None, None, None], None, xg
+            return [P] + Hs[:-1], Hs[-1], xg
         T = H.g_chain_tile()
         whole = (n * n) % T == 0                    # whole tiles per question -> pair sum from the on-chip tiles
         # activations are stored only when the backward pass will need them (the last one also feeds the
@@ -227,7 +257,8 @@ class RelationalFunction(torch.autograd.Function):
         gb = [b.detach().contiguous() for b in g_b]
         need_grad = any(ctx.needs_input_grad)
         inputs, HL, xg = g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad,
-                                         split=(packed.hi, packed.lo) if f16s else None)
+                                         split=(packed.hi, packed.lo) if f16s else None,
+                                         wfrag=None if f16s else packed.frag)
         G = plan.widths[-1]
         if xg is None:
             xg = torch.empty(B, G, dtype=torch.float32, device=dev)

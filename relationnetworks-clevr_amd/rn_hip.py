@@ -33,7 +33,9 @@ SIGNATURES = {
     "rn_g_chain_tile": (_I, []),
     "rn_g_chain_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_g_chain_rr_tile": (_I, []),
-    "rn_g_chain_fwd_rr": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "rn_g_chain_rr_mask_bytes": (_Z, [_I]),
+    "rn_g_chain_fwd_rr": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pack_matrix_frag": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
     "rn_g_chain_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_pair_sum_ws_bytes": (_Z, [_I, _I, _I]),
@@ -211,13 +213,29 @@ def pack_matrix_frag(src, sr, sc, R, Cc, dst, natural, src_offset=0):
 
 
 @_timed("g_fwd")
-def g_chain_fwd_rr(P, ldp, Wfs, biases, Hs, K0, xg_part, M, G):
-    """Register-resident forward chain; Hs is None (inference) or the 4 activation buffers."""
+def g_chain_fwd_rr(P, ldp, Wfs, biases, Hs, masks, K0, xg_part, M, G):
+    """Register-resident forward chain.  Hs: None or 4 entries (the last may be None when masks are given);
+    masks: None or 4 uint8 buffers of g_chain_rr_mask_bytes(M)."""
     L = len(Wfs)
     wp = (C.c_void_p * L)(*[w.data_ptr() for w in Wfs])
     bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
-    hp = (C.c_void_p * L)(*[h.data_ptr() for h in Hs]) if Hs is not None else None
-    _check(load().rn_g_chain_fwd_rr(P.data_ptr(), ldp, wp, bp, hp, K0, _ptr(xg_part), M, L, G, _stream()), "rn_g_chain_fwd_rr")
+    hp = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
+    mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
+    _check(load().rn_g_chain_fwd_rr(P.data_ptr(), ldp, wp, bp, hp, mp, K0, _ptr(xg_part), M, L, G, _stream()), "rn_g_chain_fwd_rr")
+
+
+def g_chain_rr_mask_bytes(M) -> int:
+    return load().rn_g_chain_rr_mask_bytes(M)
+
+
+@_timed("g_dgrad")
+def g_chain_bwd_rr(dxg, masks, Wtfs, dZs, M, rows_per_question, G):
+    """Register-resident backward chain: dZs[0..3] from dxg, the forward masks and the transposed fragment images."""
+    L = len(dZs)
+    mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks])
+    wp = (C.c_void_p * (L - 1))(*[w.data_ptr() for w in Wtfs])
+    zp = (C.c_void_p * L)(*[z.data_ptr() for z in dZs])
+    _check(load().rn_g_chain_bwd_rr(dxg.data_ptr(), mp, wp, zp, M, rows_per_question, L, G, _stream()), "rn_g_chain_bwd_rr")
 
 
 def pack_matrix_split(src, sr, sc, R, Cc, hi, lo, ld, Rpad):

@@ -231,12 +231,25 @@ def test_pack_matrix_frag(H, natural):
     assert np.array_equal(dst.float().cpu().numpy(), frag_pack_ref(W, natural))
 
 
-@pytest.mark.parametrize("K0,K0true,store,M", [(192, 180, True, 256 * 300), (256, 256, True, 256 * 3), (192, 180, False, 256 * 520)])
-def test_g_chain_fwd_rr(H, K0, K0true, store, M):
-    """Register-resident chain: every stored activation must equal one un-fused layer applied to the kernel's
-    OWN previous activation (<= 1 bf16 ulp); the per-wave pair-sum partials must be the column sums of the
-    last activation.  300 / 520 tiles > 256 CUs: the persistent loop, its seams and the dummy tail are exercised."""
-    L, G = 4, 256
+def rr_mask_decode(buf, M, l):
+    """lane masks of rn_g_chain_fwd_rr (include/rn_hip.h) -> boolean (M, 256) gate matrix.
+    layers 0..2: mask i, lane -> row 32 wt + lane % 32, feature 32 ob + 8 (i / 4) + 4 (lane / 32) + i % 4;
+    layer 3 (operands un-swapped): mask i, lane -> row 32 wt + 8 (i / 4) + 4 (lane / 32) + i % 4, feature 32 ob + lane % 32."""
+    m = buf.cpu().numpy().view(np.uint64).reshape(M // 32, 8, 16)
+    bits = ((m[..., None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(bool)    # (wt, ob, i, lane)
+    i = np.arange(16)[:, None]; lane = np.arange(64)[None, :]
+    a_idx = lane % 32 + 0 * i                       # index that is "lane % 32"
+    b_idx = 8 * (i // 4) + 4 * (lane // 32) + i % 4   # index that comes from (i, lane / 32)
+    g = np.zeros((M // 32, 32, 8, 32), bool)        # (wt, row, ob, feature)
+    if l < 3:
+        g[:, a_idx, :, b_idx] = np.moveaxis(bits, 1, -1)[:, i, lane].transpose(1, 2, 0, 3)
+    else:
+        g[:, b_idx, :, a_idx] = np.moveaxis(bits, 1, -1)[:, i, lane].transpose(1, 2, 0, 3)
+    return g.reshape(M, 256)
+
+
+def rr_setup(H, M, K0, K0true):
+    G, L = 256, 4
     P = np.zeros((M, K0), np.float32); P[:, :K0true] = formula.hash_uniform((M, K0true), 300, -1, 1)
     P = bf16_round(P)
     Ws, bs, Wf = [], [], []
@@ -247,25 +260,73 @@ def test_g_chain_fwd_rr(H, K0, K0true, store, M):
         f = torch.empty(65536, dtype=torch.bfloat16, device="cuda")
         H.pack_matrix_frag(dev(W), kt, 1, G, kt, f, l == 0)
         Wf.append(f)
-    Hs = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(L)] if store else None
+    return P, Ws, bs, Wf
+
+
+@pytest.mark.parametrize("K0,K0true,mode,M", [(192, 180, "all", 256 * 300), (256, 256, "all+mask", 256 * 3),
+                                                (192, 180, "train", 256 * 290), (192, 180, "infer", 256 * 520)])
+def test_g_chain_fwd_rr(H, K0, K0true, mode, M):
+    """Register-resident chain: every stored activation must equal one un-fused layer applied to the kernel's
+    OWN previous activation (<= 1 bf16 ulp); the per-wave pair-sum partials are the column sums of the UN-rounded
+    last activation; the lane masks are the ReLU gates.  290 .. 520 tiles > 256 CUs: the persistent loop, its
+    seams and the dummy tail are exercised.  mode: which of (H_0..3, masks) the call asks for."""
+    L, G = 4, 256
+    P, Ws, bs, Wf = rr_setup(H, M, K0, K0true)
+    nan16 = lambda: torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda")
+    Hs = None if mode == "infer" else [nan16() for _ in range(3)] + [None if mode == "train" else nan16()]
+    masks = [torch.zeros(H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda") for _ in range(L)] if "mask" in mode or mode == "train" else None
     part = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
-    H.g_chain_fwd_rr(dev(P).bfloat16(), K0, Wf, [dev(b) for b in bs], Hs, K0, part, M, G)
+    H.g_chain_fwd_rr(dev(P).bfloat16(), K0, Wf, [dev(b) for b in bs], Hs, masks, K0, part, M, G)
     torch.cuda.synchronize()
     prev = P[:, :K0true]
-    if store:
-        for l in range(L):
+    for l in range(L):
+        ref = np.maximum(prev.astype(np.float64) @ Ws[l].astype(np.float64).T + bs[l], 0)
+        if Hs is not None and Hs[l] is not None:
             got = Hs[l].float().cpu().numpy()
-            ref = np.maximum(prev.astype(np.float64) @ Ws[l].astype(np.float64).T + bs[l], 0)
             err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
             assert err.max() <= BF16_ULP, (l, err.max())
             prev = got
-        # the pair sum adds the UN-rounded fp32 activations (not the stored bf16 copies)
-        assert rel(part.cpu().numpy(), ref.reshape(M // 32, 32, G).sum(1)) <= F32_TOL
-    else:
-        for l in range(L):
-            ref = np.maximum(prev.astype(np.float64) @ Ws[l].astype(np.float64).T + bs[l], 0)
+        else:
             prev = bf16_round(ref)
-        assert rel(part.cpu().numpy(), ref.reshape(M // 32, 32, G).sum(1)) <= 2e-3
+        if masks is not None:
+            gate = rr_mask_decode(masks[l], M, l)
+            # the kernel gates on its fp32 pre-activation: only elements whose reference value is rounding noise may differ
+            bad = gate != (ref > 0)
+            assert np.abs(ref[bad]).max(initial=0.0) <= 1e-4 * np.abs(ref).max(), (l, bad.sum())
+            assert bad.mean() <= 1e-4
+    # the pair sum adds the UN-rounded fp32 activations (not the stored bf16 copies)
+    tol = F32_TOL if (Hs is not None and Hs[2] is not None) else 2e-3
+    assert rel(part.cpu().numpy(), ref.reshape(M // 32, 32, G).sum(1)) <= tol
+
+
+@pytest.mark.parametrize("B,npairs", [(2, 512), (24, 32 * 100)])
+def test_g_chain_bwd_rr(H, B, npairs):
+    """Register-resident backward chain on the masks of a real forward call: dZ[0] = bf16(dxg) where gate_3; every
+    further dZ equals one un-fused dgrad step on the kernel's OWN previous dZ (<= 1 bf16 ulp), zero where gated."""
+    G, L, K0 = 256, 4, 192
+    M = B * npairs
+    P, Ws, bs, Wf = rr_setup(H, M, K0, 180)
+    Hs = [torch.empty(M, G, dtype=torch.bfloat16, device="cuda") for _ in range(L)]
+    masks = [torch.zeros(H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda") for _ in range(L)]
+    H.g_chain_fwd_rr(dev(P).bfloat16(), K0, Wf, [dev(b) for b in bs], Hs, masks, K0, None, M, G)
+    dxg = formula.hash_uniform((B, G), 410, -1, 1)
+    Wtf = []
+    for s in range(L - 1):
+        f = torch.empty(65536, dtype=torch.bfloat16, device="cuda")
+        H.pack_matrix_frag(dev(Ws[L - 1 - s]), 1, G, G, G, f, s == 0)       # element (in, out) = W[out][in]
+        Wtf.append(f)
+    dZs = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(L)]
+    H.g_chain_bwd_rr(dev(dxg), masks, Wtf, dZs, M, npairs, G)
+    torch.cuda.synchronize()
+    gates = [rr_mask_decode(masks[l], M, l) for l in range(L)]
+    got = dZs[0].float().cpu().numpy()
+    assert np.array_equal(got, bf16_round(np.repeat(dxg, npairs, axis=0)) * gates[L - 1])
+    for s in range(L - 1):
+        ref = (got.astype(np.float64) @ Ws[L - 1 - s].astype(np.float64)) * gates[L - 2 - s]
+        got = dZs[s + 1].float().cpu().numpy()
+        err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
+        assert err.max() <= BF16_ULP, (s, err.max())
+        assert np.all(got[~gates[L - 2 - s]] == 0)
 
 
 def test_g_chain_fwd_f16s(H):

@@ -19,6 +19,15 @@ for l, w in enumerate(Ws):
     H.pack_matrix_frag(w, w.shape[1], 1, G, w.shape[1], f, l == 0)
     Wf.append(f)
 Hs = [torch.empty(M, G, dtype=torch.bfloat16, device="cuda") for _ in range(4)]
+masks = [torch.zeros(H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda") for _ in range(4)]
+dxg = torch.rand(64, G, device="cuda") - 0.5
+dZs = [torch.empty(M, G, dtype=torch.bfloat16, device="cuda") for _ in range(4)]
+Wts = [Ws[3 - s].t().contiguous().bfloat16() for s in range(3)]
+Wtf = []
+for s in range(3):
+    f = torch.empty(65536, dtype=torch.bfloat16, device="cuda")
+    H.pack_matrix_frag(Ws[3 - s], 1, G, G, G, f, s == 0)
+    Wtf.append(f)
 part_old = torch.empty(M // H.g_chain_tile(), G, dtype=torch.float32, device="cuda")
 part_rr = torch.empty(M // 32, G, dtype=torch.float32, device="cuda")
 
@@ -44,12 +53,14 @@ flops = 2.0 * M * G * (K0 + 3 * G)
 for name, fn in [
     ("old  store", lambda: H.g_chain_fwd(P, K0, Wp, bs, Hs, [K0, G, G, G], part_old, 0, M, G)),
     ("old  nostore", lambda: H.g_chain_fwd(P, K0, Wp, bs, [None] * 4, [K0, G, G, G], part_old, 0, M, G)),
-    ("rr   store", lambda: H.g_chain_fwd_rr(P, K0, Wf, bs, Hs, K0, part_rr, M, G)),
-    ("rr   store noxg", lambda: H.g_chain_fwd_rr(P, K0, Wf, bs, Hs, K0, None, M, G)),
-    ("rr   nostore", lambda: H.g_chain_fwd_rr(P, K0, Wf, bs, None, K0, part_rr, M, G)),
+    ("rr   all H", lambda: H.g_chain_fwd_rr(P, K0, Wf, bs, Hs, None, K0, part_rr, M, G)),
+    ("rr   train (H0-2 + masks)", lambda: H.g_chain_fwd_rr(P, K0, Wf, bs, Hs[:3] + [None], masks, K0, part_rr, M, G)),
+    ("rr   infer", lambda: H.g_chain_fwd_rr(P, K0, Wf, bs, None, None, K0, part_rr, M, G)),
+    ("old  bwd", lambda: H.g_chain_bwd(Hs[3], dxg, Wts, [Hs[2], Hs[1], Hs[0]], dZs, 0, M, 4096, G)),
+    ("rr   bwd", lambda: H.g_chain_bwd_rr(dxg, masks, Wtf, dZs, M, 4096, G)),
 ]:
     us = timeit(fn)
-    print("%-14s %8.1f us   %7.1f TFLOP/s" % (name, us, flops / us * 1e-6))
+    print("%-28s %8.1f us   %7.1f TFLOP/s" % (name, us, (flops * (0.79 if "bwd" in name else 1.0)) / us * 1e-6))
 for abl in ():
     os.environ["RN_RR_ABL"] = str(abl)
     us = timeit(lambda: H.g_chain_fwd_rr(P, K0, Wf, bs, None, K0, part_rr, M, G))
