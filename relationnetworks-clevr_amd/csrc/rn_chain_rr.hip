@@ -57,13 +57,27 @@ struct RRArgs {
   bf16* out[RR_L];                                      // H_l (M, 256) or null
   u64* mask[RR_L];                                      // ReLU lane masks of layer l (M * 32 bytes) or null
 };
-struct RRBwdArgs {
-  const bf16* W[RR_L - 1];                              // step s: fragment-major W_{3-s}^T
-  const u64* mask[RR_L];                                // lane masks written by the forward kernel
-  bf16* dZ[RR_L];                                       // dZ[s] = gradient of the pre-activation of layer 3-s, (M, 256)
+struct RRBwdArgs {                                      // the per-layer buffers are equally spaced (checked on the host):
+  const bf16* W;                                        // step s: fragment-major W_{3-s}^T at W + s * w_stride
+  const u64* mask;                                      // lane masks of layer l (forward kernel) at mask + l * mask_stride
+  bf16* dZ;                                             // dZ[s] = gradient of the pre-activation of layer 3-s, (M, 256), at dZ + s * dz_stride
+  long w_stride, mask_stride, dz_stride;                // in elements
   const float* dxg;                                     // (B, 256) fp32
   int rows_per_b;
 };
+typedef __attribute__((ext_vector_type(16))) unsigned u32x16;
+// 16 lane masks (32 dwords) -> SGPRs.  Inline asm: a compiler-visible scalar load would make every LDS wait a
+// full lgkmcnt(0) drain while it is in flight (SMEM returns out of order).  The destination is ready only after
+// mask_wait() -- nothing may read it before.
+__device__ __forceinline__ void mask_load(const u64* p, u32x16& a, u32x16& b) {
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
+}
+__device__ __forceinline__ void mask_wait(u32x16& a, u32x16& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory"); }
+__device__ __forceinline__ bool gate_bit(const u32x16& a, const u32x16& b, int i) {
+  const u32x16& v = i < 8 ? a : b;
+  const u64 m = ((u64)v[2 * (i & 7) + 1] << 32) | v[2 * (i & 7)];
+  return __builtin_amdgcn_inverse_ballot_w64(m);
+}
 
 // What both kernels share: the weight stream (LDS-DMA ring) and its fragment reads.
 struct RRCore {
@@ -86,14 +100,21 @@ struct RRCore {
       asm volatile("" : "+v"(rbase[r]));
     }
   }
-  // one 1-KB piece of a 16-KB weight block: uniform base (SGPR pair) + one lane-constant 32-bit offset
+  // one 1-KB piece of a 16-KB weight block: SGPR base + one lane-constant 32-bit offset, LDS address in M0.
+  // Inline asm on purpose: hipcc marks the LDS-DMA builtin as a FLAT operation that may touch both memories and
+  // from then on turns EVERY vmcnt / lgkmcnt wait into a full drain (0) while one is pending.  An asm statement
+  // is invisible to its bookkeeping; its own counted waits only get a little stricter.  M0 is the compiler's:
+  // saved and restored.
   __device__ __forceinline__ void dma_piece(const bf16* Wl, int ob2, int slot, int i) const {
     unsigned z = 0;
     asm volatile("" : "+s"(z));                        // opaque 0: the base is computed AT the use (SALU), not hoisted and spilled
-    gbl_cu8* ub = (gbl_cu8*)(reinterpret_cast<const unsigned char*>(Wl) + (z + ob2 * RR_STAGE + (RR_DPW * w + i) * 1024));
-    asm volatile("" : "+s"(ub));                       // ... and stays an SGPR base (no per-piece VGPR address)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + lane16),
-                                     (__attribute__((address_space(3))) void*)(lds + RR_OFF_RING + slot * RR_STAGE + (RR_DPW * w + i) * 1024), 16, 0, 0);
+    const unsigned char* ub = reinterpret_cast<const unsigned char*>(Wl) + (z + ob2 * RR_STAGE + (RR_DPW * w + i) * 1024);
+    const unsigned dst = (unsigned)(size_t)(lds_u8*)lds + (z + RR_OFF_RING + slot * RR_STAGE + (RR_DPW * w + i) * 1024);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane16), "s"(ub), "s"(dst)
+                 : "memory");
   }
   __device__ __forceinline__ Frag rd_frag(int slot, int ks) const {
     const int abs = RR_OFF_RING + slot * RR_STAGE + ks * 1024, r = abs >> 16;
@@ -272,7 +293,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
     auto co_store = [&](int cl, int cob, int q) {
       gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.out[cl] + m0w * RR_G);
       asm volatile("" : "+s"(base));
-      *reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2) = co[q];
+      // non-temporal: read back only by the backward pass; in L2 it would evict the weight images
+      __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2));
     };
     // LAST layer: operands un-swapped (activations = A, weights = B), so D[row][feature] leaves a lane with ONE
     // feature (32 pob + lane % 32) of 16 rows (8 (i / 4) + 4 h + i % 4): the pair sum (model.py:151-152) is an
@@ -407,6 +429,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
 // ================================================================================================== backward
 // dZ[0] = dxg[b] * (H_3 > 0);  dZ[s+1] = (dZ[s] @ W_{3-s}) * (H_{2-s} > 0), s = 0..2 -- the ReLU gates come from the
 // forward kernel's lane masks (32 bytes per pair row and layer instead of a 512-byte activation row).
+template <int ABL>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int ntiles) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
@@ -418,13 +441,14 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
   Frag actA[16], actB[16], ring[RR_RD];
   f32x16 acc[2];
   u32x4 co[2];
+  u32x16 gA[2], gB[2];                                               // two sets of 16 lane masks (SGPRs)
 
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
 #pragma unroll
   for (int s = 0; s < RR_LA; ++s)
 #pragma unroll
-    for (int i = 0; i < RR_DPW; ++i) k.dma_piece(a.W[0], s, s, i);
+    for (int i = 0; i < RR_DPW; ++i) k.dma_piece(a.W, s, s, i);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma unroll
@@ -442,14 +466,21 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
     };
     const unsigned orow_off = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
     auto co_store = [&](int zi, int cob, int q) {
-      gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.dZ[zi] + m0w * RR_G);
+      if (ABL & 4) return;
+      gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.dZ + zi * a.dz_stride + ((ABL & 32) ? (long)(blockIdx.x * RR_TM + RR_WR * w) : m0w) * RR_G);
       asm volatile("" : "+s"(base));
-      *reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2) = co[q];
+      // non-temporal: these rows are read back by ANOTHER kernel much later; allocated in L2 they only evict the
+      // weight images that every workgroup re-reads for every tile (measured: 222 -> 150 us)
+      if (ABL & 64) *reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2) = co[q];
+      else __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2));
     };
     // ---- prologue: dZ[0] in operand layout (natural feature order) + its copy to HBM
-    {
+    if (ABL & 1) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) actA[ks] = Frag{(unsigned)tile, 0u, 1u, 0u};
+    } else {
       const float* dxb = a.dxg + b * RR_G + 8 * h;
-      const unsigned* m3 = reinterpret_cast<const unsigned*>(a.mask[RR_L - 1]) + wt * 8 * 32 + rowsel;
+      const unsigned* m3 = reinterpret_cast<const unsigned*>(a.mask + (RR_L - 1) * a.mask_stride) + wt * 8 * 32 + rowsel;
 #pragma unroll
       for (int ob = 0; ob < 8; ++ob) {
         const unsigned bits = m3[ob * 32] >> (8 * h);                 // features 32 ob + 8 h + {0..7} and + 16 of row n
@@ -484,14 +515,19 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
       constexpr int didx = sidx + RR_LA;
       constexpr int dl = (didx >> 3) % NS, dob = didx & 7;
       constexpr int nob = (sidx + 1) & 7;
-      u64 mk[16];
-      if (has_prev) {                                                 // gate of the previous block: layer 2 - ps
-        const u64* mp = a.mask[has_prev ? NS - 1 - ps : 0] + (wt * 8 + pob) * 16;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mk[i] = __builtin_nontemporal_load(mp + i);
+      // gate of THIS block (layer 2 - s): requested now, used by the epilogue that runs in the next stage; the
+      // gate of the previous block, requested one stage ago, must have arrived
+      u32x16(&gn)[2] = (sidx & 1) ? gB : gA;
+      u32x16(&gp)[2] = (sidx & 1) ? gA : gB;
+      if (has_prev && !(ABL & 2)) mask_wait(gp[0], gp[1]);
+      if (!(ABL & 2)) mask_load(a.mask + (NS - 1 - s) * a.mask_stride + (wt * 8 + ob) * 16, gn[0], gn[1]);
+      if (ABL & 16) {                                                 // timing only: 16 more operations may stay in flight (a race)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BwdVm::younger(sidx) + 16 < 63 ? BwdVm::younger(sidx) + 16 : 63) : "memory");
+        __builtin_amdgcn_s_barrier();
+      } else if (!(ABL & 8)) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BwdVm::younger(sidx)) : "memory");
+        __builtin_amdgcn_s_barrier();
       }
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BwdVm::younger(sidx)) : "memory");
-      __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (has_co) co_read();
       __builtin_amdgcn_sched_barrier(0);
@@ -514,12 +550,12 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
           if (f < 16) ring[ks % RR_RD] = k.rd_frag(ob, f);
           else ring[ks % RR_RD] = k.rd_frag(nob, f - 16);
         }
-        if ((c & 1) && (c >> 1) < RR_DPW) k.dma_piece(a.W[dl], dob, dob, c >> 1);
+        if ((c & 1) && (c >> 1) < RR_DPW) k.dma_piece(a.W + dl * a.w_stride, dob, dob, c >> 1);
         if (has_prev && c >= 2 && c < 14) {                           // epilogue of the previous block, 3 gaps per group
           const int j = (c - 2) / 3, ph = (c - 2) % 3;
           if (ph == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[j][r] = __builtin_amdgcn_inverse_ballot_w64(mk[4 * j + r]) ? acc[pob & 1][4 * j + r] : 0.f;
+            for (int r = 0; r < 4; ++r) x[j][r] = ((ABL & 2) || gate_bit(gp[0], gp[1], 4 * j + r)) ? acc[pob & 1][4 * j + r] : 0.f;
           } else if (ph == 1) {
             const f32x2 f0 = {x[j][0], x[j][1]}, f1 = {x[j][2], x[j][3]};
             pk[j][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f0, bf16x2));
@@ -544,12 +580,13 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
       co_read();
 #pragma unroll
       for (int q = 0; q < 2; ++q) co_store(NS, 6, q);
-      const u64* mp = a.mask[0] + (wt * 8 + 7) * 16;
+      u32x16(&gp)[2] = ((NS * 8 - 1) & 1) ? gB : gA;                    // requested in the last stage
+      if (!(ABL & 2)) mask_wait(gp[0], gp[1]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_inverse_ballot_w64(__builtin_nontemporal_load(mp + 4 * j + r)) ? acc[1][4 * j + r] : 0.f;
+        for (int r = 0; r < 4; ++r) x[r] = ((ABL & 2) || gate_bit(gp[0], gp[1], 4 * j + r)) ? acc[1][4 * j + r] : 0.f;
         const f32x2 f0 = {x[0], x[1]}, f1 = {x[2], x[3]};
         u32x2 pk;
         pk[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f0, bf16x2));
@@ -639,16 +676,38 @@ extern "C" int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, cons
     RN_CHECK_ARG(mask[l] && dZ[l] && (l == RR_L - 1 || Wtf[l]), "rn_g_chain_bwd_rr: entry %d has a NULL pointer", l);
     RN_CHECK_ARG(((uintptr_t)mask[l] | (uintptr_t)dZ[l] | (uintptr_t)(l < RR_L - 1 ? Wtf[l] : nullptr)) % 16 == 0,
                  "rn_g_chain_bwd_rr: entry %d pointers must be 16-byte aligned", l);
-    a.mask[l] = (const u64*)mask[l];
-    a.dZ[l] = (bf16*)dZ[l];
-    if (l < RR_L - 1) a.W[l] = (const bf16*)Wtf[l];
+  }
+  // the kernel addresses the per-layer buffers as base + l * stride (three pointers instead of eleven)
+  a.mask = (const u64*)mask[0];
+  a.dZ = (bf16*)dZ[0];
+  a.W = (const bf16*)Wtf[0];
+  a.mask_stride = (const u64*)mask[1] - (const u64*)mask[0];
+  a.dz_stride = (bf16*)dZ[1] - (bf16*)dZ[0];
+  a.w_stride = (const bf16*)Wtf[1] - (const bf16*)Wtf[0];
+  for (int l = 0; l < RR_L; ++l) {
+    RN_CHECK_ARG((const u64*)mask[l] == a.mask + l * a.mask_stride && (bf16*)dZ[l] == a.dZ + l * a.dz_stride &&
+                     (l == RR_L - 1 || (const bf16*)Wtf[l] == a.W + l * a.w_stride),
+                 "rn_g_chain_bwd_rr: mask / dZ / Wtf buffers must be equally spaced (slices of one allocation each)");
   }
   RN_CHECK_ARG((uintptr_t)dxg % 16 == 0, "rn_g_chain_bwd_rr: dxg must be 16-byte aligned");
   a.dxg = dxg;
   a.rows_per_b = rows_per_question;
   const int ntiles = M / RR_TM;
   const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
-  g_chain_rr_bwd_kernel<<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles);
+  const char* ae = getenv("RN_RR_ABL");                    // diagnostics: timing-only ablations (results are wrong)
+  switch (ae ? atoi(ae) : 0) {
+    case 1: g_chain_rr_bwd_kernel<1><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
+    case 2: g_chain_rr_bwd_kernel<2><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
+    case 3: g_chain_rr_bwd_kernel<3><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
+    case 4: g_chain_rr_bwd_kernel<4><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
+    case 7: g_chain_rr_bwd_kernel<7><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
+    case 15: g_chain_rr_bwd_kernel<15><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
+    case 16: g_chain_rr_bwd_kernel<16><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
+    case 17: g_chain_rr_bwd_kernel<17><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
+    case 32: g_chain_rr_bwd_kernel<32><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
+    case 64: g_chain_rr_bwd_kernel<64><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
+    default: g_chain_rr_bwd_kernel<0><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
+  }
   RN_LAUNCH_CHECK("rn_g_chain_bwd_rr");
   return 0;
 }

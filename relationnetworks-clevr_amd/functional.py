@@ -54,17 +54,18 @@ class PackedWeights:
         self.key = None
         self.fwd, self.bwd = [], []
         self.hi, self.lo = [], []                  # fp16 split copies for the f16s forward
-        self.frag = []                             # fragment-major copies for the register-resident chain
+        self.frag = []                             # fragment-major copies for the register-resident chains:
+        self.fragT = []                            #   forward W_l, backward step s -> W_{L-1-s}^T
 
-    def get(self, plan: LayerPlan, g_w, code, split=False):
-        key = (code, split, tuple((w.data_ptr(), w._version) for w in g_w))
+    def get(self, plan: LayerPlan, g_w, code, split=False, bwd_images=True):
+        key = (code, split, bwd_images, tuple((w.data_ptr(), w._version) for w in g_w))
         # while a hipGraph is being captured the pack kernels must be part of it (a replay sees
         # new weights every step), so the cache is bypassed
         if key == self.key and not torch.cuda.is_current_stream_capturing():
             return self.fwd, self.bwd
         dt = H.torch_dtype(code)
         dev = g_w[0].device
-        self.fwd, self.bwd, self.hi, self.lo, self.frag = [], [], [], [], []
+        self.fwd, self.bwd, self.hi, self.lo, self.frag, self.fragT = [], [], [], [], [], []
         rr = rr_chain_ok(plan, code)
         for l, w in enumerate(g_w):
             N, kt = w.shape
@@ -92,6 +93,11 @@ class PackedWeights:
                 self.bwd.append(wt)
             else:
                 self.bwd.append(None)
+        if rr and bwd_images:
+            self.fragT = list(torch.empty(plan.L - 1, 256 * 256, dtype=dt, device=dev))     # equally spaced (rn_g_chain_bwd_rr)
+            for st, wf in enumerate(self.fragT):
+                wc = g_w[plan.L - 1 - st].detach().contiguous()
+                H.pack_matrix_frag(wc, 1, wc.shape[1], 256, 256, wf, st == 0)      # element (in, out) = W[out][in]
         self.key = key
         return self.fwd, self.bwd
 
@@ -104,6 +110,14 @@ def _side_stream(dev):
     if s is None:
         s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
     return s
+
+
+class RRMasks:
+    """ReLU lane masks of the register-resident forward chain: what the backward pass keeps INSTEAD of the last
+    activation (rn_g_chain_fwd_rr / rn_g_chain_bwd_rr)."""
+
+    def __init__(self, masks):
+        self.masks = masks
 
 
 def rr_chain_ok(plan: LayerPlan, code):
@@ -170,9 +184,17 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
         if (wfrag is not None and len(wfrag) == L and rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0
                 and (keep_inputs or (n * n) % R == 0)):
             whole = (n * n) % R == 0
-            Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L)] if keep_inputs else None
+            # training with whole waves per question: the last activation never leaves the chip -- its pair sum and
+            # the ReLU gates of all layers (32 bytes per pair row and layer) do; rn_g_chain_bwd_rr consumes the gates
+            masks = None
+            Hs = None
+            if keep_inputs:
+                Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L)]
+                if whole and os.environ.get("RN_NO_RR_MASKS", "0") != "1":
+                    masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
+                    Hs[-1] = None
             part = torch.empty(M // R, G, dtype=torch.float32, device=dev) if whole else None
-            H.g_chain_fwd_rr(P, ld0, wfrag, g_b, Hs, ld0, part, M, G)
+            H.g_chain_fwd_rr(P, ld0, wfrag, g_b, Hs, masks, ld0, part, M, G)
             xg = torch.empty(B, G, dtype=torch.float32, device=dev)
             if whole:
                 H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // R, G)
@@ -180,7 +202,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
                 H.pair_sum_fwd(Hs[-1], G, xg, code, B, n * n, G)
             if Hs is None:
                 return [P, None, None, None], None, xg
-            return [P] + Hs[:-1], Hs[-1], xg
+            return [P] + Hs[:-1], (Hs[-1] if masks is None else RRMasks(masks)), xg
         T = H.g_chain_tile()
         whole = (n * n) % T == 0                    # whole tiles per question -> pair sum from the on-chip tiles
         # activations are stored only when the backward pass will need them (the last one also feeds the
@@ -253,9 +275,9 @@ class RelationalFunction(torch.autograd.Function):
         M = B * n * n
         dev = x.device
         f16s = precision == "f16s"
-        wfwd, wbwd = packed.get(plan, g_w, code, split=f16s)
-        gb = [b.detach().contiguous() for b in g_b]
         need_grad = any(ctx.needs_input_grad)
+        wfwd, wbwd = packed.get(plan, g_w, code, split=f16s, bwd_images=need_grad)
+        gb = [b.detach().contiguous() for b in g_b]
         inputs, HL, xg = g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad,
                                          split=(packed.hi, packed.lo) if f16s else None,
                                          wfrag=None if f16s else packed.frag)
@@ -272,6 +294,7 @@ class RelationalFunction(torch.autograd.Function):
         if need_grad:
             ctx.plan, ctx.code, ctx.dims = plan, code, (B, n, k, Q, M, G, F1, F2, A)
             ctx.inputs, ctx.HL, ctx.wbwd = inputs, HL, wbwd
+            ctx.fragT = list(packed.fragT)
             ctx.g_w = [w.detach() for w in g_w]
             ctx.param_refs = list(g_w) + list(g_b)
             ctx.fw = fw
@@ -311,7 +334,13 @@ class RelationalFunction(torch.autograd.Function):
         dt = H.torch_dtype(code)
         inputs, wbwd, g_w = ctx.inputs, ctx.wbwd, ctx.g_w
         fused_bwd = fused_chain_ok(plan, code, B, n) and L >= 2 and os.environ.get("RN_NO_FUSED_BWD", "0") != "1"
-        if fused_bwd:
+        if isinstance(ctx.HL, RRMasks):
+            # register-resident backward chain on the forward kernel's gates (one launch, no activation is re-read)
+            fused_bwd = True
+            dZs = list(torch.empty(L, M, G, dtype=dt, device=dev))                 # dZs[s] belongs to layer L-1-s
+            H.g_chain_bwd_rr(dxg, ctx.HL.masks, ctx.fragT, dZs, M, n * n, G)
+            dZ_of = {L - 1 - s: dZs[s] for s in range(L)}
+        elif fused_bwd:
             # one launch: dZ_L = dxg * (H_L > 0), then dZ_{l-1} = (dZ_l @ W_l) * (H_{l-1} > 0) for every layer
             dZs = [torch.empty(M, G, dtype=dt, device=dev) for _ in range(L)]      # dZs[s] belongs to layer L-1-s
             H.g_chain_bwd(ctx.HL, dxg, [wbwd[L - 1 - s] for s in range(L - 1)], [inputs[L - 1 - s] for s in range(L - 1)],

@@ -307,15 +307,13 @@ def test_g_chain_bwd_rr(H, B, npairs):
     M = B * npairs
     P, Ws, bs, Wf = rr_setup(H, M, K0, 180)
     Hs = [torch.empty(M, G, dtype=torch.bfloat16, device="cuda") for _ in range(L)]
-    masks = [torch.zeros(H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda") for _ in range(L)]
+    masks = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))       # equally spaced
     H.g_chain_fwd_rr(dev(P).bfloat16(), K0, Wf, [dev(b) for b in bs], Hs, masks, K0, None, M, G)
     dxg = formula.hash_uniform((B, G), 410, -1, 1)
-    Wtf = []
-    for s in range(L - 1):
-        f = torch.empty(65536, dtype=torch.bfloat16, device="cuda")
+    Wtf = list(torch.empty(L - 1, 65536, dtype=torch.bfloat16, device="cuda"))
+    for s, f in enumerate(Wtf):
         H.pack_matrix_frag(dev(Ws[L - 1 - s]), 1, G, G, G, f, s == 0)       # element (in, out) = W[out][in]
-        Wtf.append(f)
-    dZs = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(L)]
+    dZs = list(torch.full((L, M, G), float("nan"), dtype=torch.bfloat16, device="cuda"))
     H.g_chain_bwd_rr(dev(dxg), masks, Wtf, dZs, M, npairs, G)
     torch.cuda.synchronize()
     gates = [rr_mask_decode(masks[l], M, l) for l in range(L)]

@@ -19,15 +19,13 @@ for l, w in enumerate(Ws):
     H.pack_matrix_frag(w, w.shape[1], 1, G, w.shape[1], f, l == 0)
     Wf.append(f)
 Hs = [torch.empty(M, G, dtype=torch.bfloat16, device="cuda") for _ in range(4)]
-masks = [torch.zeros(H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda") for _ in range(4)]
+masks = list(torch.zeros(4, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
 dxg = torch.rand(64, G, device="cuda") - 0.5
-dZs = [torch.empty(M, G, dtype=torch.bfloat16, device="cuda") for _ in range(4)]
+dZs = list(torch.empty(4, M, G, dtype=torch.bfloat16, device="cuda"))
 Wts = [Ws[3 - s].t().contiguous().bfloat16() for s in range(3)]
-Wtf = []
-for s in range(3):
-    f = torch.empty(65536, dtype=torch.bfloat16, device="cuda")
+Wtf = list(torch.empty(3, 65536, dtype=torch.bfloat16, device="cuda"))
+for s, f in enumerate(Wtf):
     H.pack_matrix_frag(Ws[3 - s], 1, G, G, G, f, s == 0)
-    Wtf.append(f)
 part_old = torch.empty(M // H.g_chain_tile(), G, dtype=torch.float32, device="cuda")
 part_rr = torch.empty(M // 32, G, dtype=torch.float32, device="cuda")
 
@@ -63,5 +61,5 @@ for name, fn in [
     print("%-28s %8.1f us   %7.1f TFLOP/s" % (name, us, (flops * (0.79 if "bwd" in name else 1.0)) / us * 1e-6))
 for abl in ():
     os.environ["RN_RR_ABL"] = str(abl)
-    us = timeit(lambda: H.g_chain_fwd_rr(P, K0, Wf, bs, None, K0, part_rr, M, G))
-    print("rr nostore ablation %2d (1=no sync 2=no dma 4=no ring reads 8=no epilogue): %8.1f us" % (abl, us))
+    us = timeit(lambda: H.g_chain_bwd_rr(dxg, masks, Wtf, dZs, M, 4096, G))
+    print("rr bwd ablation %2d (1=no prologue 2=no gate loads 4=no stores 8=no sync): %8.1f us" % (abl, us))
