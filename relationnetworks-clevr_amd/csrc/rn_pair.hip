@@ -309,63 +309,148 @@ extern "C" int rn_pair_sum_bwd(const float* dxg, const void* HL, int ldh, void* 
 }
 
 // ---------------------------------------- backward of the pair expansion (reductions)
-// Rj[b,j,:] = sum_i dZ[(b,i,j),:] : block = (j-group, b); thread = (row-in-group, chunk); every
-// thread walks i with a row stride of n rows; the block reads rpb consecutive rows per i.
-template <typename T>
-__global__ __launch_bounds__(256) void reduce_over_i_kernel(const T* __restrict__ dZ, int ld, float* __restrict__ Rj,
-                                                            int n, int G) {
-  constexpr int CH = Elem<T>::kPer16B;
-  const int cpr = G / CH;
-  const int rpb = 256 / cpr;
-  const int t = threadIdx.x;
-  const int c = t % cpr, jl = t / cpr;
-  const int b = blockIdx.y;
-  const int j = blockIdx.x * rpb + jl;
-  if (jl >= rpb || j >= n) return;
-  float acc[CH];
+// Rj[b,j,:] = sum_i dZ[(b,i,j),:]   Ri[b,i,:] = sum_j dZ[(b,i,j),:]   Rq[b,:] = sum_i Ri[b,i,:]
+// ONE pass over dZ (HBM-bound: it is read exactly once).  Workgroup = (block of 16 j, question b); thread =
+// (i-lane il, 16-byte column chunk c) and walks i = il, il + NIL, ...: for every i it loads its 16 rows
+// (j0 .. j0+15; 16 independent 16-byte loads in flight), adds them into Rj accumulators kept in registers for
+// the whole walk and into the Ri partial of that i, which is complete (for this j block) after the 16 rows and
+// is written straight out.  Cross-thread traffic only at the end: the NIL i-lanes combine their Rj sums through
+// LDS in a fixed order -> deterministic.  A tiny finish kernel adds the j-block partials of Ri and forms Rq.
+template <typename T> struct Piece4;                                   // 4 consecutive elements of a row
+template <> struct Piece4<bf16> { typedef u32x2 Raw; static __device__ __forceinline__ void unpack(const Raw& r, float (&x)[4]) {
+  x[0] = __builtin_bit_cast(float, r[0] << 16); x[1] = __builtin_bit_cast(float, r[0] & 0xffff0000u);
+  x[2] = __builtin_bit_cast(float, r[1] << 16); x[3] = __builtin_bit_cast(float, r[1] & 0xffff0000u); } };
+template <> struct Piece4<float> { typedef f32x4 Raw; static __device__ __forceinline__ void unpack(const Raw& r, float (&x)[4]) {
+  x[0] = r[0]; x[1] = r[1]; x[2] = r[2]; x[3] = r[3]; } };
+
+template <typename T, bool WANT_RJ>
+__global__ __launch_bounds__(256) void pair_reduce_kernel(const T* __restrict__ dZ, int ld, float* __restrict__ Rj,
+                                                          float* __restrict__ ri_part, int n, int G, long part_stride) {
+  constexpr int CH = 4;                                               // columns per thread: 64 Rj accumulators, 16 small loads in flight
+  constexpr int JB = 16;
+  typedef typename Piece4<T>::Raw Raw;
+  extern __shared__ __attribute__((aligned(16))) float red[];        // [NIL-1][JB][G] fp32 (Rj hand-over)
+  const int cpr = G / CH;                                             // threads per row (<= 256)
+  const int NIL = 256 / cpr;                                          // i-lanes
+  const int t = threadIdx.x, c = t % cpr, il = t / cpr;
+  const int b = blockIdx.y, jb = blockIdx.x, j0 = jb * JB;
+  const int nj = (n - j0) < JB ? (n - j0) : JB;
+  float rj[WANT_RJ ? JB : 1][CH];
+  if constexpr (WANT_RJ) {
 #pragma unroll
-  for (int e = 0; e < CH; ++e) acc[e] = 0.f;
-  const T* base = dZ + ((long)b * n * n + j) * ld + c * CH;
-#pragma unroll 4
-  for (int i = 0; i < n; ++i) {
-    const Chunk16<T> v = *reinterpret_cast<const Chunk16<T>*>(base + (long)i * n * ld);
+    for (int j = 0; j < JB; ++j)
 #pragma unroll
-    for (int e = 0; e < CH; ++e) acc[e] += Elem<T>::to_f32(v.v[e]);
+      for (int e = 0; e < CH; ++e) rj[j][e] = 0.f;
   }
-  float* o = Rj + ((long)b * n + j) * G + c * CH;
+  if (il < NIL) {
+    // Software pipeline over i: the 16 loads of the NEXT i are in flight while this i is added up (one workgroup per
+    // CU: nobody else hides the HBM latency).  All 16 loads are issued back to back -- a short last block re-reads
+    // its last row and adds zeros: no branch may sit between the loads.
+    Raw v[2][JB];
+    auto issue = [&](Raw (&dst)[JB], int i) {
+      const T* base = dZ + (((long)b * n + i) * n + j0) * ld + c * CH;
 #pragma unroll
-  for (int e = 0; e < CH; ++e) o[e] = acc[e];
+      for (int j = 0; j < JB; ++j) dst[j] = *reinterpret_cast<const Raw*>(base + (long)(j < nj ? j : nj - 1) * ld);
+    };
+    auto consume = [&](const Raw (&src)[JB], int i) {
+      float ri[CH] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+        const float keep = j < nj ? 1.f : 0.f;
+        float x[4];
+        Piece4<T>::unpack(src[j], x);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          ri[e] += x[e] * keep;
+          if constexpr (WANT_RJ) rj[j][e] += x[e] * keep;
+        }
+      }
+      *reinterpret_cast<f32x4*>(ri_part + jb * part_stride + ((long)b * n + i) * G + c * CH) = f32x4{ri[0], ri[1], ri[2], ri[3]};
+    };
+    int i = il;
+    if (i < n) issue(v[0], i);
+    while (i < n) {
+      const int i1 = i + NIL, i2 = i + 2 * NIL;
+      if (i1 < n) issue(v[1], i1);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(v[0], i);
+      if (i1 >= n) break;
+      if (i2 < n) issue(v[0], i2);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(v[1], i1);
+      i = i2;
+    }
+  }
+  if constexpr (WANT_RJ) {
+    // i-lanes 1 .. NIL-1 hand their sums to lane 0 through LDS
+    if (il >= 1 && il < NIL) {
+#pragma unroll
+      for (int j = 0; j < JB; ++j)
+        *reinterpret_cast<f32x4*>(red + ((long)(il - 1) * JB + j) * G + c * CH) = f32x4{rj[j][0], rj[j][1], rj[j][2], rj[j][3]};
+    }
+    __syncthreads();
+    if (il == 0) {
+      for (int l = 0; l + 1 < NIL; ++l)
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+          const f32x4 r = *reinterpret_cast<const f32x4*>(red + ((long)l * JB + j) * G + c * CH);
+          rj[j][0] += r[0]; rj[j][1] += r[1]; rj[j][2] += r[2]; rj[j][3] += r[3];
+        }
+#pragma unroll
+      for (int j = 0; j < JB; ++j)
+        if (j < nj) *reinterpret_cast<f32x4*>(Rj + ((long)b * n + j0 + j) * G + c * CH) = f32x4{rj[j][0], rj[j][1], rj[j][2], rj[j][3]};
+    }
+  }
+}
+
+// Ri = sum over the j-block partial slabs (element-wise, fully parallel)
+__global__ __launch_bounds__(256) void pair_reduce_finish_kernel(const f32x4* __restrict__ ri_part, long part_stride4, int njb,
+                                                                 f32x4* __restrict__ Ri, long total4) {
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total4; g += (long)gridDim.x * 256) {
+    f32x4 r = ri_part[g];
+    for (int p = 1; p < njb; ++p) r += ri_part[p * part_stride4 + g];
+    Ri[g] = r;
+  }
 }
 
 extern "C" size_t rn_pair_reduce_ws_bytes(int B, int n, int G) {
-  // Ri scratch (when the caller only wants Rq) + segsum partials for n > 256
-  return (size_t)B * n * G * sizeof(float) + (size_t)B * n * cdiv(n, 256) * G * sizeof(float);
+  return ((size_t)cdiv(n, 16) + 1) * B * n * G * sizeof(float);      // Ri partials, one slab per block of 16 j, + Ri itself
 }
 
 extern "C" int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri, float* Rq, void* ws, int dtype, int B,
                                   int n, int G, void* stream) {
   RN_CHECK_ARG(dZ && B > 0 && n > 0 && ws, "rn_pair_reduce_bwd: bad pointer/size");
   RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "rn_pair_reduce_bwd: bad dtype %d", dtype);
-  const int CH = dtype == RN_BF16 ? 8 : 4;
-  RN_CHECK_ARG(G % CH == 0 && G / CH <= 256 && lddz % CH == 0, "rn_pair_reduce_bwd: G=%d unsupported", G);
+  const int CH = 4;
+  RN_CHECK_ARG(G % CH == 0 && G / CH <= 256 && 256 % (G / CH) == 0 && lddz % (dtype == RN_BF16 ? 8 : 4) == 0, "rn_pair_reduce_bwd: G=%d unsupported", G);
+  RN_CHECK_ARG(((uintptr_t)dZ | (uintptr_t)Rj | (uintptr_t)Ri | (uintptr_t)Rq | (uintptr_t)ws) % 16 == 0, "rn_pair_reduce_bwd: pointers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  if (Rj) {
-    const int rpb = 256 / (G / CH);
-    dim3 grid(cdiv(n, rpb), B);
-    if (dtype == RN_BF16) reduce_over_i_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)dZ, lddz, Rj, n, G);
-    else reduce_over_i_kernel<float><<<grid, 256, 0, s>>>((const float*)dZ, lddz, Rj, n, G);
-    RN_LAUNCH_CHECK("rn_pair_reduce_bwd(Rj)");
-  }
+  const int njb = cdiv(n, 16), NIL = 256 / (G / CH);
+  const long part_stride = (long)B * n * G;
+  float* part = (float*)ws;
+  dim3 grid(njb, B);
+  const size_t shm = Rj ? (size_t)(NIL > 1 ? NIL - 1 : 1) * 16 * G * sizeof(float) : 0;
+  RN_CHECK_ARG(shm <= 160 * 1024, "rn_pair_reduce_bwd: G=%d needs %zu bytes of LDS", G, shm);
+#define RN_PR(T, RJ)                                                                                                   \
+  do {                                                                                                                 \
+    if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void*)pair_reduce_kernel<T, RJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+    pair_reduce_kernel<T, RJ><<<grid, 256, shm, s>>>((const T*)dZ, lddz, Rj, part, n, G, part_stride);                 \
+  } while (0)
+  if (dtype == RN_BF16) { if (Rj) RN_PR(bf16, true); else RN_PR(bf16, false); }
+  else { if (Rj) RN_PR(float, true); else RN_PR(float, false); }
+#undef RN_PR
+  RN_LAUNCH_CHECK("rn_pair_reduce_bwd");
   if (Ri || Rq) {
-    float* ri = Ri ? Ri : (float*)ws;
-    float* part = (float*)ws + (size_t)B * n * G;
-    int rc = segsum_launch(dZ, lddz, ri, part, dtype, B * n, n, G, s, "rn_pair_reduce_bwd(Ri)");
-    if (rc) return rc;
+    float* ri = Ri ? Ri : part + (size_t)njb * part_stride;
+    const long total4 = part_stride / 4;
+    int blocks = cdiv(total4, 256);
+    if (blocks > 4096) blocks = 4096;
+    pair_reduce_finish_kernel<<<blocks, 256, 0, s>>>((const f32x4*)part, total4, njb, (f32x4*)ri, total4);
+    RN_LAUNCH_CHECK("rn_pair_reduce_bwd(finish)");
     if (Rq) {
-      // Rq[b] = sum_i Ri[b,i]: fp32 segmented sum over n rows (n <= 256 -> single slice)
-      RN_CHECK_ARG(G % 4 == 0 && G / 4 <= 256, "rn_pair_reduce_bwd: G=%d unsupported for Rq", G);
-      rc = segsum_launch(ri, G, Rq, part, RN_F32, B, n, G, s, "rn_pair_reduce_bwd(Rq)");
-      if (rc) return rc;
+      // Rq[b] = sum_i Ri[b,i]: fp32 segmented sum over n rows
+      RN_CHECK_ARG(G % 4 == 0 && G / 4 <= 256 && n <= 256, "rn_pair_reduce_bwd: G=%d / n=%d unsupported for Rq", G, n);
+      return segsum_launch(ri, G, Rq, nullptr, RN_F32, B, n, G, s, "rn_pair_reduce_bwd(Rq)");
     }
   }
   return 0;

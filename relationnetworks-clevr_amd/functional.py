@@ -57,8 +57,10 @@ class PackedWeights:
         self.frag = []                             # fragment-major copies for the register-resident chains:
         self.fragT = []                            #   forward W_l, backward step s -> W_{L-1-s}^T
 
-    def get(self, plan: LayerPlan, g_w, code, split=False, bwd_images=True):
-        key = (code, split, bwd_images, tuple((w.data_ptr(), w._version) for w in g_w))
+    def get(self, plan: LayerPlan, g_w, code, split=False, bwd_images=True, rr_only=False):
+        """rr_only: the call is known to run the register-resident chains in both directions -- only their
+        fragment-major images are packed (the row-major copies feed the other kernels)."""
+        key = (code, split, bwd_images, rr_only, tuple((w.data_ptr(), w._version) for w in g_w))
         # while a hipGraph is being captured the pack kernels must be part of it (a replay sees
         # new weights every step), so the cache is bypassed
         if key == self.key and not torch.cuda.is_current_stream_capturing():
@@ -73,9 +75,12 @@ class PackedWeights:
             wc = w.detach()
             if not wc.is_contiguous():
                 wc = wc.contiguous()
-            wp = torch.empty(N, plan.kpad[l], dtype=dt, device=dev)
-            H.pack_matrix(wc, kt, 1, N, kt, wp, code, plan.kpad[l], N)
-            self.fwd.append(wp)
+            if rr and rr_only:
+                self.fwd.append(None)
+            else:
+                wp = torch.empty(N, plan.kpad[l], dtype=dt, device=dev)
+                H.pack_matrix(wc, kt, 1, N, kt, wp, code, plan.kpad[l], N)
+                self.fwd.append(wp)
             if rr:
                 wf = torch.empty(256 * 256, dtype=dt, device=dev)
                 H.pack_matrix_frag(wc, kt, 1, N, kt, wf, l == 0)
@@ -86,7 +91,7 @@ class PackedWeights:
                 H.pack_matrix_split(wc, kt, 1, N, kt, hi, lo, plan.kpad[l], N)
                 self.hi.append(hi)
                 self.lo.append(lo)
-            if l >= 1:
+            if l >= 1 and not (rr and rr_only):
                 gp = plan.widths[l - 1]           # only the H_{l-1} columns take part in dgrad
                 wt = torch.empty(gp, N, dtype=dt, device=dev)
                 H.pack_matrix(wc, 1, kt, gp, N, wt, code, N, gp)      # wt[k][n] = w[n][k]
@@ -276,7 +281,9 @@ class RelationalFunction(torch.autograd.Function):
         dev = x.device
         f16s = precision == "f16s"
         need_grad = any(ctx.needs_input_grad)
-        wfwd, wbwd = packed.get(plan, g_w, code, split=f16s, bwd_images=need_grad)
+        rr_only = (not f16s and rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0 and (n * n) % 32 == 0
+                   and os.environ.get("RN_NO_RR_MASKS", "0") != "1")
+        wfwd, wbwd = packed.get(plan, g_w, code, split=f16s, bwd_images=need_grad, rr_only=rr_only)
         gb = [b.detach().contiguous() for b in g_b]
         inputs, HL, xg = g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad,
                                          split=(packed.hi, packed.lo) if f16s else None,
