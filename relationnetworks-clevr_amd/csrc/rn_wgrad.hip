@@ -8,6 +8,8 @@
 // 32w..32w+31 and all NKT k-tiles.  Both MFMA operands are read "down a column" of a row-major
 // [m][.] LDS tile; for bf16 that is the gfx950 LDS transpose read (ds_read_b64_tr_b16), for fp32
 // (v_mfma_f32_32x32x2_f32, one value per lane) a plain ds_read_b32.
+#include <stdlib.h>
+
 #include "rn_common.h"
 
 template <typename T> struct WG;
@@ -204,6 +206,158 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Streaming wgrad for the headline shapes (bf16, N == 256, K == 256 or 192, M % 64 == 0).  The product is
+// HBM-bound by 2x (each operand row is read exactly once: 268 MB per layer against 34 GFLOP), so the kernel is
+// built around bytes in flight, not around the MFMA:
+//   * no register staging: 64-row operand tiles stream HBM -> LDS by LDS-DMA into a 4-stage ring, three stages
+//     (96 KB per CU) in flight, one counted s_waitcnt vmcnt + s_barrier per 64 rows;
+//   * output split 2 x KBLK: a workgroup owns a 128 (n) x KB (k) block, KB = 128 (K = 256) or 64 (K = 192), and
+//     1/Z of the rows -- the fp32 partial set is 4x smaller than with full-width blocks (16 MB per layer instead
+//     of 64 MB written and read back);
+//   * the 2 * KBLK workgroups that read the same rows (other column halves) sit on ONE XCD (blockIdx % 8), a few
+//     dispatch slots apart: the second reader hits that XCD's L2;
+//   * the linear LDS image LDS-DMA writes is made conflict-free for ds_read_b64_tr_b16 by an XOR swizzle of the
+//     16-byte chunks, applied to the per-lane SOURCE address (the rows of a 4-row group land 64 B apart mod 256 B).
+// Same partial-tile format and the same fixed-order reduction as wgrad_kernel -> bitwise deterministic.
+template <int KTW>   // 32-wide k tiles per wave: 2 -> KB = 128, 1 -> KB = 64
+__global__ __launch_bounds__(512) void wgrad_stream_kernel(const bf16* __restrict__ dZ, int lddz, const bf16* __restrict__ A,
+                                                           int lda, float* __restrict__ part, float* __restrict__ part_db,
+                                                           int S, int Z, int NB, int Kpad, int abl) {
+  constexpr int KB = KTW * 64;                             // k block width
+  constexpr int ZB = 64 * 256, AB = 64 * KB * 2;           // bytes per stage: dZ tile (64 x 128 cols), A tile (64 x KB cols)
+  constexpr int STG = ZB + AB, NSTG = 4, LA = 3;           // three stages (96 KB) in flight; a 5-stage ring measured slower
+  constexpr int PPW = (ZB + AB) / 1024 / 8;                // 1-KB LDS-DMA pieces per wave and stage (4 / 3)
+  constexpr int RBA = KB * 2;                              // A tile row bytes (256 / 128)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NSTG * STG];
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  // XCD-aware decode: consecutive ids round-robin over the 8 XCDs; the NB blocks of one row range share an XCD
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int blk = slot % NB, z = (slot / NB) * 8 + xcd;
+  if (z >= Z) return;
+  const int nh = blk & 1, kb = blk >> 1;
+  const long s0 = (long)z * S / Z, s1 = (long)(z + 1) * S / Z;  // 64-row steps of this workgroup
+
+  // ---- LDS-DMA: per-lane source offsets (swizzled), uniform bases per piece
+  const int zr = lane >> 4, zc = (lane & 15) ^ (4 * (zr & 3));
+  const unsigned zoff = (unsigned)(zr * lddz * 2 + zc * 16);
+  unsigned aoff;
+  if (KB == 128) {
+    aoff = (unsigned)(zr * lda * 2 + zc * 16);
+  } else {
+    const int ar = lane >> 3, ac = (lane & 7) ^ (4 * ((ar >> 1) & 1));
+    aoff = (unsigned)(ar * lda * 2 + ac * 16);
+  }
+  const unsigned ldsb = (unsigned)(size_t)(lds_u8*)lds;
+  auto issue = [&](long s) {                               // stage of step s -> ring slot s % NSTG
+    const unsigned sb = ldsb + (unsigned)(s % NSTG) * STG;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int q = w * PPW + i;                           // wave-uniform
+      const unsigned char* ub;
+      unsigned off;
+      if (q < 16) {                                        // dZ piece: rows 4q .. 4q+3, 256 B each
+        ub = reinterpret_cast<const unsigned char*>(dZ + (s * 64 + 4 * q) * lddz + nh * 128);
+        off = zoff;
+      } else {                                             // A piece: 1 KB = 4 rows x 256 B or 8 rows x 128 B
+        const int qa = q - 16;
+        ub = reinterpret_cast<const unsigned char*>(A + (s * 64 + qa * (1024 / RBA)) * lda + kb * KB);
+        off = aoff;
+      }
+      const unsigned dst = sb + q * 1024;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(off), "s"(ub), "s"(dst)
+                   : "memory");
+    }
+  };
+
+  // ---- fragment addresses (ds_read_b64_tr_b16: the lane supplies row kk + rb*8 + i16/4 (+4), 4 columns)
+  const int i16 = lane & 15, cb = (lane >> 4) & 1, rb = lane >> 5;
+  const int fr = rb * 8 + (i16 >> 2);                      // row inside a 16-row k step (second read: + 4)
+  const int nb = w & 3, kg = w >> 2;                       // wave: n block (32 features), k group
+  const int zcol = nb * 32 + cb * 16 + 4 * (i16 & 3);      // column inside the 128-wide dZ tile
+  const unsigned zaddr = (unsigned)(fr * 256 + (((zcol >> 3) ^ (4 * (fr & 3))) * 16) + (zcol & 4) * 2);
+  unsigned aaddr[KTW];
+#pragma unroll
+  for (int kt = 0; kt < KTW; ++kt) {
+    const int acol = kg * (KTW * 32) + kt * 32 + cb * 16 + 4 * (i16 & 3);
+    const int sw = KB == 128 ? 4 * (fr & 3) : 4 * ((fr >> 1) & 1);
+    aaddr[kt] = (unsigned)(ZB + fr * RBA + (((acol >> 3) ^ sw) * 16) + (acol & 4) * 2);
+  }
+
+  f32x16 acc[KTW];
+#pragma unroll
+  for (int i = 0; i < KTW; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  f32x16 acc_db;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc_db[e] = 0.f;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+  const bool do_db = (kb == 0) && (kg == 0);
+
+  if (!(abl & 2))
+    for (long s = s0; s < s0 + LA && s < s1; ++s) issue(s);
+  for (long s = s0; s < s1; ++s) {
+    // stage s has landed when at most the requests of the younger stages in flight are outstanding
+    const long younger = (s1 - 1 - s) < (LA - 1) ? (s1 - 1 - s) : (LA - 1);
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // ... for every wave's pieces; and slot (s-1) % NSTG is free
+    asm volatile("" ::: "memory");
+    if (s + LA < s1 && !(abl & 2)) issue(s + LA);
+    const unsigned char* st = lds + (s % NSTG) * STG;
+    typedef __attribute__((address_space(3))) s16x4* lptr;
+    if (abl & 1) continue;                                 // diagnostics: stream only
+    // all 24 (16) transpose reads of the step first, then the MFMAs back to back: read -> wait -> MFMA per k step
+    // exposes the LDS latency four times per step with every wave of the workgroup in the same phase
+    union Fr { struct { s16x4 a, b; } s; bf16x8 v; };
+    Fr uz[4], ua[4][KTW];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      uz[kk].s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(st + kk * 16 * 256 + zaddr));
+      uz[kk].s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(st + kk * 16 * 256 + 4 * 256 + zaddr));
+#pragma unroll
+      for (int kt = 0; kt < KTW; ++kt) {
+        ua[kk][kt].s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(st + kk * 16 * RBA + aaddr[kt]));
+        ua[kk][kt].s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(st + kk * 16 * RBA + 4 * RBA + aaddr[kt]));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int kt = 0; kt < KTW; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uz[kk].v, ua[kk][kt].v, acc[kt], 0, 0, 0);
+      // db = dZ^T 1: one more MFMA against a tile of ones (every output column carries the column sums)
+      if (do_db) acc_db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uz[kk].v, ones, acc_db, 0, 0, 0);
+    }
+  }
+
+  // ---- fp32 partial tile: part[z][n][k]; a lane holds 32 consecutive k... one k column of 16 feature rows
+  float* pz = part + (long)z * 256 * Kpad;
+#pragma unroll
+  for (int kt = 0; kt < KTW; ++kt) {
+    const int kcol = kb * KB + kg * (KTW * 32) + kt * 32 + (lane & 31);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int nrow = nh * 128 + nb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      pz[(long)nrow * Kpad + kcol] = acc[kt][reg];
+    }
+  }
+  if (do_db && (lane & 31) == 0) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg)
+      part_db[(long)z * 256 + nh * 128 + nb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)] = acc_db[reg];
+  }
+}
+
 static void wgrad_plan(int M, int N, int K, int* nkt, int* gy, int* Z, int* rps) {
   const int ktiles = K / 32;
   const int chunks = (ktiles + 7) / 8;
@@ -225,6 +379,15 @@ extern "C" size_t rn_wgrad_ws_bytes(int M, int N, int K) {
   int nkt, gy, Z, rps;
   wgrad_plan(M, N, K, &nkt, &gy, &Z, &rps);
   return ((size_t)Z * N * K + (size_t)Z * N) * sizeof(float);
+}
+
+// The streaming kernel covers bf16, N == 256, K in {256, 192}, whole 64-row steps (RN_WGRAD_V1=1 forces the general kernel).
+static bool wgrad_stream_ok(int dtype, int M, int N, int K, int lddz, int lda) {
+  const char* e = getenv("RN_WGRAD_V1");
+  if (e && e[0] == '1') return false;
+  const char* k192 = getenv("RN_WGRAD_STREAM_192");          // K == 192 (three 64-wide k blocks) measured slower than the general kernel
+  if (K == 192 && !(k192 && k192[0] == '1')) return false;
+  return dtype == RN_BF16 && N == 256 && (K == 256 || K == 192) && M % 64 == 0 && M / 64 >= 64 && lddz % 8 == 0 && lda % 8 == 0;
 }
 
 // USE_TR can be turned off (RN_WGRAD_NO_TR=1) to fall back to scalar LDS column reads.
@@ -270,8 +433,22 @@ extern "C" int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, in
   int nkt, gy, Z, rps;
   wgrad_plan(M, N, K, &nkt, &gy, &Z, &rps);
   float* part = (float*)ws;
-  float* part_db = part + (size_t)Z * N * K;
   hipStream_t s = (hipStream_t)stream;
+  if (wgrad_stream_ok(dtype, M, N, K, lddz, lda)) {
+    const int NB = K == 256 ? 4 : 6, Zs = 256 / NB, S = M / 64;     // (2 n halves) x (2 | 3 k blocks); M-split so that ~256 workgroups run
+    float* part_db = part + (size_t)Zs * N * K;
+    const int grid = 8 * NB * cdiv(Zs, 8);
+    const char* ae = getenv("RN_WGRAD_ABL");
+    const int abl = ae ? atoi(ae) : 0;
+    if (K == 256) wgrad_stream_kernel<2><<<grid, 512, 0, s>>>((const bf16*)dZ, lddz, (const bf16*)A, lda, part, part_db, S, Zs, NB, K, abl);
+    else wgrad_stream_kernel<1><<<grid, 512, 0, s>>>((const bf16*)dZ, lddz, (const bf16*)A, lda, part, part_db, S, Zs, NB, K, abl);
+    RN_LAUNCH_CHECK("rn_g_linear_bwd_wgrad(stream)");
+    const int nbw = cdiv((long)N * K / 4, 16), nbb = cdiv(N / 4, 16);
+    wgrad_reduce_kernel<<<nbw + nbb, 256, 0, s>>>(part, part_db, dW, db, N, K, Ktrue, Zs, nbw);
+    RN_LAUNCH_CHECK("rn_g_linear_bwd_wgrad(reduce)");
+    return 0;
+  }
+  float* part_db = part + (size_t)Z * N * K;
   int rc;
   if (dtype == RN_BF16)
     rc = wgrad_launch_t<bf16>((const bf16*)dZ, lddz, (const bf16*)A, lda, part, part_db, M, N, K, nkt, gy, Z, rps, s);

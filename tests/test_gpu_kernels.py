@@ -419,11 +419,16 @@ def test_pair_sum_fwd_bwd(H, code, B, npairs, G):
 # ----------------------------------------------------------------------------- wgrad
 @pytest.mark.parametrize("no_tr", ["0", "1"])
 @pytest.mark.parametrize("code", [0, 1])
-@pytest.mark.parametrize("M,N,K,Ktrue", [(4096, 256, 192, 180), (576, 512, 320, 270), (5000, 256, 384, 384), (2048, 256, 64, 52)])
+@pytest.mark.parametrize("M,N,K,Ktrue", [(4096, 256, 192, 180), (576, 512, 320, 270), (5000, 256, 384, 384), (2048, 256, 64, 52),
+                                         (64 * 700, 256, 256, 256), (64 * 333, 256, 192, 180)])
 def test_g_linear_bwd_wgrad(H, code, M, N, K, Ktrue, no_tr):
+    """(4096 | 64*700 | 64*333, 256, 256 | 192) in bf16 run the streaming kernel (rn_wgrad.hip), everything else -- and
+    those shapes again under RN_WGRAD_V1=1, the no_tr == "1" leg -- the general one."""
     if code == 1 and no_tr == "1":
         pytest.skip("fp32 path has no transpose read")
     os.environ["RN_WGRAD_NO_TR"] = no_tr
+    os.environ["RN_WGRAD_V1"] = no_tr
+    os.environ["RN_WGRAD_STREAM_192"] = "1"
     try:
         dZ = formula.hash_uniform((M, N), 60, -1, 1)
         A = np.zeros((M, K), np.float32); A[:, :Ktrue] = formula.hash_uniform((M, Ktrue), 61, -1, 1)
@@ -443,6 +448,8 @@ def test_g_linear_bwd_wgrad(H, code, M, N, K, Ktrue, no_tr):
         assert torch.equal(dW, dW2) and torch.equal(db, db2)
     finally:
         os.environ.pop("RN_WGRAD_NO_TR", None)
+        os.environ.pop("RN_WGRAD_V1", None)
+        os.environ.pop("RN_WGRAD_STREAM_192", None)
 
 
 # ----------------------------------------------------------------------------- pair reduce
