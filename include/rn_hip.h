@@ -138,6 +138,10 @@ int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* con
  * src: fp32, element (r, c) at src[r * sr + c * sc] (model.py:96-99 nn.Linear weight: sr = in, sc = 1). */
 int rn_pack_matrix_frag(const float* src, long sr, long sc, int R, int C, void* dst, int natural, void* stream);
 
+/* `count` (<= 8) rn_pack_matrix_frag calls in one launch; all arguments are HOST arrays of `count` entries. */
+int rn_pack_matrix_frag_many(const float* const* src, const long* sr, const long* sc, const int* R, const int* C,
+                             void* const* dst, const int* natural, int count, void* stream);
+
 /* Fused backward chain (bf16 storage): pair-sum broadcast + last ReLU gate + all L-1 dgrad steps
  *  for every 128-row tile, tile resident in LDS:
  *   dZ[0]   = dxg[b] * (HL > 0)                                   (gradient of layer L-1's pre-activation)
@@ -199,6 +203,49 @@ int rn_log_softmax_bwd(const float* out, const float* gout, float* dz, int B, in
 
 /* column sums: out[c] = sum_r src[r*ld + c]  (bias gradients of f_phi). */
 int rn_colsum_f32(const float* src, long ld, float* out, int R, int C, void* stream);
+
+/* f_phi + log_softmax (model.py:155-162) in one launch, its backward in two (rn_small.hip; fp32 FMA):
+ *   f1 = relu(xg W1^T + b1) (B, F1);  f2 = relu((f1 W2^T + b2) * mask) (B, F2);  out = log_softmax(f2 W3^T + b3) (B, A)
+ * W_l: nn.Linear layout (out, in) row-major; mask: (B, F2) dropout mask already scaled by 1/(1-p), or NULL.
+ * Backward: gout = d loss / d out; writes dW_l, db_l and dxg (B, G); ws: rn_f_phi_bwd_ws_bytes(B, F1, F2, A) bytes.
+ * Widths are multiples of 4 (A excepted) and <= 1024, B <= 1024. */
+int rn_f_phi_fwd(const float* xg, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                 const float* b3, const float* mask, float* f1, float* f2, float* out, int B, int G, int F1, int F2, int A,
+                 void* stream);
+size_t rn_f_phi_bwd_ws_bytes(int B, int F1, int F2, int A);
+int rn_f_phi_bwd(const float* gout, const float* out, const float* f2, const float* f1, const float* xg, const float* W1,
+                 const float* W2, const float* W3, const float* mask, float* dW1, float* db1, float* dW2, float* db2,
+                 float* dW3, float* db3, float* dxg, void* ws, int B, int G, int F1, int F2, int A, void* stream);
+
+/* Tail of the training step (reference train.py:45-48) on the flat gradient buffer of the data-parallel bucket:
+ * torch.nn.utils.clip_grad_norm_(params, max_norm) (max_norm <= 0: no clip) followed by torch.optim.Adam
+ * (amsgrad=False, coupled weight_decay) in two launches.  g / m / v: flat fp32 buffers of n elements; `chunks`:
+ * DEVICE array of nchunks records {float* param; long flat_off; int count; int pad} (count <= rn_clip_adam_chunk(),
+ * a chunk never crosses a parameter) mapping flat ranges to the parameter tensors; step: 1-based update count;
+ * ws: rn_clip_adam_ws_bytes() bytes; norm_out: optional device float receiving the gradient norm. */
+int rn_clip_adam_chunk(void);
+size_t rn_clip_adam_ws_bytes(void);
+int rn_clip_adam_step(const void* chunks, int nchunks, float* g, float* m, float* v, long n, void* ws, float max_norm, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int step, float* norm_out, void* stream);
+
+/* BatchNorm2d + ReLU of the conv stack in front of the relation layer (reference model.py:22-35), fused into two
+ * HBM passes per direction (rn_convnorm.hip).  x: (N, C, H, W) fp32 contiguous conv output computed WITHOUT the
+ * conv bias (a bias in front of a batch norm shifts the batch mean by itself and drops out; conv_bias is only added
+ * to the running mean, its gradient is identically zero); HW = H * W, a multiple of 4.
+ *   fwd   (training): batch statistics -> mean / invstd (C) out; y = relu((x - mean) * invstd * gamma + beta);
+ *         running_mean / running_var (may be NULL) updated with `momentum` (unbiased variance), *num_batches += 1.
+ *   apply (evaluation): the same map with caller-prepared mean (= running_mean - conv_bias) and invstd.
+ *   bwd:  dz = dy * (y > 0) (mask recomputed from x), dgamma / dbeta (C) out,
+ *         dx = gamma * invstd * (dz - mean_n(dz) - xhat * mean_n(dz * xhat)).
+ * ws: rn_bn_relu_ws_bytes(N, C, HW) bytes. */
+size_t rn_bn_relu_ws_bytes(int N, int C, int HW);
+int rn_bn_relu_fwd(const float* x, float* y, const float* gamma, const float* beta, const float* conv_bias,
+                   float* running_mean, float* running_var, long long* num_batches, float* mean, float* invstd, void* ws,
+                   float eps, float momentum, int N, int C, int HW, void* stream);
+int rn_bn_relu_apply(const float* x, float* y, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                     int N, int C, int HW, void* stream);
+int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const float* gamma, const float* beta, const float* mean,
+                   const float* invstd, float* dgamma, float* dbeta, void* ws, int N, int C, int HW, void* stream);
 
 /* Diagnostics used by the GPU tests: raw lane mapping of ds_read_b64_tr_b16. */
 int rn_probe_tr16(const unsigned short* in4096, unsigned short* out256, void* stream);

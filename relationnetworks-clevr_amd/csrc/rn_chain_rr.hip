@@ -169,6 +169,35 @@ extern "C" int rn_pack_matrix_frag(const float* src, long sr, long sc, int R, in
   return 0;
 }
 
+// all fragment-major images of a step in ONE launch (7 per training step: 4 forward + 3 transposed)
+namespace {
+constexpr int RR_MAXPACK = 8;
+struct PackMany { const float* src[RR_MAXPACK]; long sr[RR_MAXPACK], sc[RR_MAXPACK]; int R[RR_MAXPACK], C[RR_MAXPACK], natural[RR_MAXPACK]; bf16* dst[RR_MAXPACK]; };
+}  // namespace
+__global__ __launch_bounds__(256) void pack_frag_many_kernel(PackMany a) {
+  const int i = blockIdx.y;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int e = g & 7, lane = (g >> 3) & 63, ks = (g >> 9) & 15, ob = g >> 13;
+  const int h = lane >> 5, m = 32 * ob + (lane & 31);
+  const int kidx = a.natural[i] ? 16 * ks + 8 * h + e : 32 * (ks >> 1) + 4 * h + 8 * (2 * (ks & 1) + (e >> 2)) + (e & 3);
+  const float v = (m < a.R[i] && kidx < a.C[i]) ? a.src[i][(long)m * a.sr[i] + (long)kidx * a.sc[i]] : 0.f;
+  a.dst[i][g] = (bf16)v;
+}
+
+extern "C" int rn_pack_matrix_frag_many(const float* const* src, const long* sr, const long* sc, const int* R, const int* C,
+                                        void* const* dst, const int* natural, int count, void* stream) {
+  RN_CHECK_ARG(src && sr && sc && R && C && dst && natural && count > 0 && count <= RR_MAXPACK, "rn_pack_matrix_frag_many: bad arguments (count=%d, max %d)", count, RR_MAXPACK);
+  PackMany a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < count; ++i) {
+    RN_CHECK_ARG(src[i] && dst[i] && R[i] > 0 && R[i] <= RR_G && C[i] > 0 && C[i] <= RR_G, "rn_pack_matrix_frag_many: entry %d: needs 0 < R, C <= 256", i);
+    a.src[i] = src[i]; a.sr[i] = sr[i]; a.sc[i] = sc[i]; a.R[i] = R[i]; a.C[i] = C[i]; a.natural[i] = natural[i]; a.dst[i] = (bf16*)dst[i];
+  }
+  pack_frag_many_kernel<<<dim3(RR_G * RR_G / 256, count), 256, 0, (hipStream_t)stream>>>(a);
+  RN_LAUNCH_CHECK("rn_pack_matrix_frag_many");
+  return 0;
+}
+
 // ---- counted waits ------------------------------------------------------------------------------------------
 // At the top of stage s the weights of stage s+1 must have landed.  vmcnt retires in order and counts every
 // VMEM operation of the wave, so the wait names how many operations YOUNGER than those weight requests may

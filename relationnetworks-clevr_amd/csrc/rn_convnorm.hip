@@ -1,0 +1,233 @@
+// BatchNorm2d + ReLU of the conv stack that feeds the relation layer (reference model.py:22-35:
+// x = conv(img); x = batchNorm(x); x = relu(x), four times), fused into two HBM passes per direction.
+//
+// The stock path spends ~0.5 ms per training step here in a dozen separate launches (bias add, batch-norm
+// statistics + apply, ReLU, their three backward kernels and a separate bias-gradient reduction), each a full
+// trip over the 25 MB layer-1 activation.  The arithmetic is a per-channel reduction plus a point-wise map:
+//
+//   forward   pass 1: per-channel sum / sum of squares of the conv output x            (read x)
+//             pass 2: y = relu((x - mean) * invstd * gamma + beta)                     (read x, write y)
+//   backward  pass 1: S1 = sum dz, S2 = sum dz * x with dz = dy * (y > 0)              (read dy, x)
+//             pass 2: dx = gamma * invstd * (dz - S1/n - xhat * dgamma/n)              (read dy, x, write dx)
+//
+// The ReLU mask is recomputed from x with the forward's own expression (bit-identical), so neither y nor a mask
+// is read back.  The convolution bias drops out of a batch-normalised output (it shifts the batch mean by the
+// same amount) -- the conv runs without it, the running mean gets it added, and its gradient is identically zero.
+// NCHW fp32; a channel's data are N planes of HW contiguous floats (HW % 4 == 0).
+#include "rn_common.h"
+
+namespace {
+constexpr int CN_T = 256;
+
+// block (x, c): the float4 indices q = x*CN_T*U .. of channel c, q -> plane n = q / hw4, offset q % hw4
+__device__ __forceinline__ long cn_addr4(long q, int c, int C, int hw4) {
+  const long n = q / hw4;
+  return (n * C + c) * hw4 + (q - n * hw4);
+}
+
+template <int NV>
+__device__ __forceinline__ void cn_block_reduce(double (&v)[NV], double* red) {   // fixed order -> deterministic
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double x = v[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+    if (lane == 0) red[w * NV + i] = x;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = red[i] + red[NV + i] + red[2 * NV + i] + red[3 * NV + i];
+  __syncthreads();
+}
+}  // namespace
+
+// part[(c * S + s) * 2 + {0, 1}] = sum, sum of squares over slice s of channel c
+__global__ __launch_bounds__(CN_T) void cn_stats_kernel(const f32x4* __restrict__ x, double* __restrict__ part, int C, int hw4,
+                                                        long n4, int S) {
+  __shared__ double red[8];
+  const int c = blockIdx.y, s = blockIdx.x;
+  float a0 = 0.f, a1 = 0.f;
+  for (long q = (long)s * CN_T + threadIdx.x; q < n4; q += (long)S * CN_T) {
+    const f32x4 v = x[cn_addr4(q, c, C, hw4)];
+    a0 += (v[0] + v[1]) + (v[2] + v[3]);
+    a1 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  double v[2] = {(double)a0, (double)a1};
+  cn_block_reduce<2>(v, red);
+  if (threadIdx.x == 0) {
+    part[((long)c * S + s) * 2] = v[0];
+    part[((long)c * S + s) * 2 + 1] = v[1];
+  }
+}
+
+// per channel: mean / invstd from the slice sums; scale / shift of the affine map; running statistics
+// (torch.nn.BatchNorm2d semantics: biased variance normalises, unbiased variance goes to running_var)
+__global__ void cn_finalize_kernel(const double* __restrict__ part, int S, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, const float* __restrict__ conv_bias, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, long long* __restrict__ num_batches, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches) num_batches[0] += 1;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int s = 0; s < S; ++s) {
+    s0 += part[((long)c * S + s) * 2];
+    s1 += part[((long)c * S + s) * 2 + 1];
+  }
+  const double m = s0 / count;
+  double var = s1 / count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double mb = m + (conv_bias ? (double)conv_bias[c] : 0.0);      // the conv ran without its bias
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mb);
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+  }
+}
+
+// y = relu(x * scale[c] + shift[c]) with scale = gamma * invstd, shift = beta - mean * scale (training) or the
+// running-statistics equivalent prepared by the caller (evaluation)
+__global__ __launch_bounds__(CN_T) void cn_apply_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int C,
+                                                        int hw4, long n4) {
+  const int c = blockIdx.y;
+  const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+  for (long q = (long)blockIdx.x * CN_T + threadIdx.x; q < n4; q += (long)gridDim.x * CN_T) {
+    const long a = cn_addr4(q, c, C, hw4);
+    const f32x4 v = x[a];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaxf(v[e] * sc + sh, 0.f);
+    y[a] = o;
+  }
+}
+
+// part[(c * S + s) * 2 + {0, 1}] = sum dz, sum dz * x   (dz = dy where the forward output was > 0)
+__global__ __launch_bounds__(CN_T) void cn_bwd_sums_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           double* __restrict__ part, int C, int hw4, long n4, int S) {
+  __shared__ double red[8];
+  const int c = blockIdx.y, s = blockIdx.x;
+  const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+  float a0 = 0.f, a1 = 0.f;
+  for (long q = (long)s * CN_T + threadIdx.x; q < n4; q += (long)S * CN_T) {
+    const long a = cn_addr4(q, c, C, hw4);
+    const f32x4 v = x[a], g = dy[a];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float dz = (v[e] * sc + sh > 0.f) ? g[e] : 0.f;
+      a0 += dz;
+      a1 += dz * v[e];
+    }
+  }
+  double v[2] = {(double)a0, (double)a1};
+  cn_block_reduce<2>(v, red);
+  if (threadIdx.x == 0) {
+    part[((long)c * S + s) * 2] = v[0];
+    part[((long)c * S + s) * 2 + 1] = v[1];
+  }
+}
+
+// dgamma = invstd * (S2 - mean * S1), dbeta = S1;
+// dx = gamma * invstd * (dz - S1 / n - (x - mean) * invstd * dgamma / n)
+__global__ __launch_bounds__(CN_T) void cn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x,
+                                                            f32x4* __restrict__ dx, const double* __restrict__ part, int S,
+                                                            double count, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int C, int hw4, long n4) {
+  const int c = blockIdx.y;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < S; ++s) {
+    s1 += part[((long)c * S + s) * 2];
+    s2 += part[((long)c * S + s) * 2 + 1];
+  }
+  const float m = mean[c], is = invstd[c], ga = gamma[c];
+  const float dga = (float)((double)is * (s2 - (double)m * s1));
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    dgamma[c] = dga;
+    dbeta[c] = (float)s1;
+  }
+  const float sc = ga * is, sh = beta[c] - m * sc;
+  const float k0 = (float)(s1 / count), k1 = (float)((double)dga * is / count);
+  for (long q = (long)blockIdx.x * CN_T + threadIdx.x; q < n4; q += (long)gridDim.x * CN_T) {
+    const long a = cn_addr4(q, c, C, hw4);
+    const f32x4 v = x[a], g = dy[a];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float dz = (v[e] * sc + sh > 0.f) ? g[e] : 0.f;
+      o[e] = sc * (dz - k0 - (v[e] - m) * k1);
+    }
+    dx[a] = o;
+  }
+}
+
+static int cn_slices(long n4) {          // workgroups per channel of the reduction passes
+  long s = n4 / (CN_T * 8);
+  if (s < 1) s = 1;
+  if (s > 32) s = 32;
+  return (int)s;
+}
+static int cn_check(const char* who, const void* a, const void* b, int N, int C, int HW) {
+  RN_CHECK_ARG(a && b && N > 0 && C > 0 && HW > 0 && HW % 4 == 0, "%s: bad pointer/size (N=%d C=%d HW=%d; HW must be a multiple of 4)", who, N, C, HW);
+  RN_CHECK_ARG(((uintptr_t)a | (uintptr_t)b) % 16 == 0, "%s: tensors must be 16-byte aligned", who);
+  return 0;
+}
+
+extern "C" size_t rn_bn_relu_ws_bytes(int N, int C, int HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  return (size_t)C * cn_slices((long)N * HW / 4) * 2 * sizeof(double);
+}
+
+extern "C" int rn_bn_relu_fwd(const float* x, float* y, const float* gamma, const float* beta, const float* conv_bias,
+                              float* running_mean, float* running_var, long long* num_batches, float* mean, float* invstd,
+                              void* ws, float eps, float momentum, int N, int C, int HW, void* stream) {
+  if (int rc = cn_check("rn_bn_relu_fwd", x, y, N, C, HW)) return rc;
+  RN_CHECK_ARG(gamma && beta && mean && invstd && ws, "rn_bn_relu_fwd: NULL parameter / workspace");
+  const long n4 = (long)N * HW / 4;
+  const int S = cn_slices(n4), hw4 = HW / 4;
+  hipStream_t s = (hipStream_t)stream;
+  cn_stats_kernel<<<dim3(S, C), CN_T, 0, s>>>((const f32x4*)x, (double*)ws, C, hw4, n4, S);
+  cn_finalize_kernel<<<cdiv(C, 64), 64, 0, s>>>((const double*)ws, S, (double)N * HW, gamma, beta, conv_bias, eps, momentum, mean,
+                                                invstd, running_mean, running_var, num_batches, C);
+  int gx = (int)((n4 + CN_T * 4 - 1) / (CN_T * 4));
+  if (gx < 1) gx = 1;
+  cn_apply_kernel<<<dim3(gx, C), CN_T, 0, s>>>((const f32x4*)x, (f32x4*)y, mean, invstd, gamma, beta, C, hw4, n4);
+  RN_LAUNCH_CHECK("rn_bn_relu_fwd");
+  return 0;
+}
+
+// evaluation mode: `mean` / `invstd` hold (running_mean - conv_bias) and 1 / sqrt(running_var + eps)
+extern "C" int rn_bn_relu_apply(const float* x, float* y, const float* gamma, const float* beta, const float* mean,
+                                const float* invstd, int N, int C, int HW, void* stream) {
+  if (int rc = cn_check("rn_bn_relu_apply", x, y, N, C, HW)) return rc;
+  RN_CHECK_ARG(gamma && beta && mean && invstd, "rn_bn_relu_apply: NULL parameter");
+  const long n4 = (long)N * HW / 4;
+  int gx = (int)((n4 + CN_T * 4 - 1) / (CN_T * 4));
+  if (gx < 1) gx = 1;
+  cn_apply_kernel<<<dim3(gx, C), CN_T, 0, (hipStream_t)stream>>>((const f32x4*)x, (f32x4*)y, mean, invstd, gamma, beta, C, HW / 4, n4);
+  RN_LAUNCH_CHECK("rn_bn_relu_apply");
+  return 0;
+}
+
+extern "C" int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const float* gamma, const float* beta, const float* mean,
+                              const float* invstd, float* dgamma, float* dbeta, void* ws, int N, int C, int HW, void* stream) {
+  if (int rc = cn_check("rn_bn_relu_bwd", dy, x, N, C, HW)) return rc;
+  RN_CHECK_ARG(dx && gamma && beta && mean && invstd && dgamma && dbeta && ws && (uintptr_t)dx % 16 == 0, "rn_bn_relu_bwd: NULL / misaligned argument");
+  const long n4 = (long)N * HW / 4;
+  const int S = cn_slices(n4), hw4 = HW / 4;
+  hipStream_t s = (hipStream_t)stream;
+  cn_bwd_sums_kernel<<<dim3(S, C), CN_T, 0, s>>>((const f32x4*)dy, (const f32x4*)x, mean, invstd, gamma, beta, (double*)ws, C, hw4, n4, S);
+  int gx = (int)((n4 + CN_T * 4 - 1) / (CN_T * 4));
+  if (gx < 1) gx = 1;
+  cn_bwd_apply_kernel<<<dim3(gx, C), CN_T, 0, s>>>((const f32x4*)dy, (const f32x4*)x, (f32x4*)dx, (const double*)ws, S, (double)N * HW,
+                                                   mean, invstd, gamma, beta, dgamma, dbeta, C, hw4, n4);
+  RN_LAUNCH_CHECK("rn_bn_relu_bwd");
+  return 0;
+}

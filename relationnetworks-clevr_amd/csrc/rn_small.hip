@@ -142,3 +142,295 @@ extern "C" int rn_colsum_f32(const float* src, long ld, float* out, int R, int C
   RN_LAUNCH_CHECK("rn_colsum_f32");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ fused f_phi
+// f_phi (model.py:155-162) is three tiny matrix products on B rows (17 MFLOP at B = 64): its cost is the number
+// of dependent launches on the critical path between the forward and the backward chain, not arithmetic.  One
+// launch forward, two backward, plain fp32 FMA (k-ordered sums):
+//   forward : f1 = relu(xg W1^T + b1); f2 = relu((f1 W2^T + b2) * mask); out = log_softmax(f2 W3^T + b3)
+//   backward: dz3 = gout - exp(out) * sum(gout);  dz2 = (dz3 W3) * mask * (f2 > 0);  dz1 = (dz2 W2) * (f1 > 0);
+//             dxg = dz1 W1;   dW_l = dz_l^T act_{l-1}, db_l = colsum(dz_l)
+namespace {
+constexpr int FP_RB = 4;          // rows per workgroup
+constexpr int FP_MAXW = 1024;     // widest activation the LDS staging holds
+
+// out[r][f] = bias[f] + sum_k W[f][k] * in[r][k]; thread = output feature; the rows' inputs sit in LDS
+__device__ __forceinline__ void fp_layer_rows(const float* __restrict__ W, const float* __restrict__ bias, const float* in_s, int K,
+                                              int f, float (&acc)[FP_RB]) {
+  const float b = bias[f];
+#pragma unroll
+  for (int r = 0; r < FP_RB; ++r) acc[r] = b;
+  const float* wr = W + (long)f * K;
+  for (int k = 0; k < K; k += 4) {
+    const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
+#pragma unroll
+    for (int r = 0; r < FP_RB; ++r) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(in_s + r * FP_MAXW + k);
+      acc[r] = fmaf(w[3], x[3], fmaf(w[2], x[2], fmaf(w[1], x[1], fmaf(w[0], x[0], acc[r]))));
+    }
+  }
+}
+// out[r][j] = sum_i in[r][i] * W[i][j]; thread = column j (coalesced over the workgroup)
+__device__ __forceinline__ void fp_layer_cols(const float* __restrict__ W, const float* in_s, int I, int J, int j, float (&acc)[FP_RB]) {
+#pragma unroll
+  for (int r = 0; r < FP_RB; ++r) acc[r] = 0.f;
+  for (int i = 0; i < I; ++i) {
+    const float w = W[(long)i * J + j];
+#pragma unroll
+    for (int r = 0; r < FP_RB; ++r) acc[r] = fmaf(in_s[r * FP_MAXW + i], w, acc[r]);
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void f_phi_fwd_kernel(const float* __restrict__ xg, const float* __restrict__ W1,
+                                                        const float* __restrict__ b1, const float* __restrict__ W2,
+                                                        const float* __restrict__ b2, const float* __restrict__ W3,
+                                                        const float* __restrict__ b3, const float* __restrict__ mask,
+                                                        float* __restrict__ f1, float* __restrict__ f2, float* __restrict__ out,
+                                                        int B, int G, int F1, int F2, int A) {
+  __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW];
+  const int t = threadIdx.x, r0 = blockIdx.x * FP_RB;
+  for (int c = t; c < FP_RB * G; c += 256) {
+    const int r = c / G, k = c - r * G;
+    sa[r * FP_MAXW + k] = (r0 + r < B) ? xg[(long)(r0 + r) * G + k] : 0.f;
+  }
+  __syncthreads();
+  float acc[FP_RB];
+  for (int f = t; f < F1; f += 256) {
+    fp_layer_rows(W1, b1, sa, G, f, acc);
+#pragma unroll
+    for (int r = 0; r < FP_RB; ++r) {
+      const float v = fmaxf(acc[r], 0.f);
+      sb[r * FP_MAXW + f] = v;
+      if (r0 + r < B) f1[(long)(r0 + r) * F1 + f] = v;
+    }
+  }
+  __syncthreads();
+  for (int f = t; f < F2; f += 256) {
+    fp_layer_rows(W2, b2, sb, F1, f, acc);
+#pragma unroll
+    for (int r = 0; r < FP_RB; ++r) {
+      const bool ok = r0 + r < B;
+      const float m = (mask && ok) ? mask[(long)(r0 + r) * F2 + f] : 1.f;
+      const float v = fmaxf(acc[r] * m, 0.f);
+      sa[r * FP_MAXW + f] = v;
+      if (ok) f2[(long)(r0 + r) * F2 + f] = v;
+    }
+  }
+  __syncthreads();
+  for (int f = t; f < A; f += 256) {
+    fp_layer_rows(W3, b3, sa, F2, f, acc);
+#pragma unroll
+    for (int r = 0; r < FP_RB; ++r) sb[r * FP_MAXW + f] = acc[r];
+  }
+  __syncthreads();
+  if (t < FP_RB && r0 + t < B) {                       // log_softmax of one row (A <= 1024 logits in LDS)
+    const float* z = sb + t * FP_MAXW;
+    float mx = z[0];
+    for (int a = 1; a < A; ++a) mx = fmaxf(mx, z[a]);
+    float s = 0.f;
+    for (int a = 0; a < A; ++a) s += expf(z[a] - mx);
+    const float ls = mx + logf(s);
+    for (int a = 0; a < A; ++a) out[(long)(r0 + t) * A + a] = z[a] - ls;
+  }
+}
+
+__global__ __launch_bounds__(256) void f_phi_bwd_dz_kernel(const float* __restrict__ gout, const float* __restrict__ out,
+                                                           const float* __restrict__ f2, const float* __restrict__ f1,
+                                                           const float* __restrict__ W1, const float* __restrict__ W2,
+                                                           const float* __restrict__ W3, const float* __restrict__ mask,
+                                                           float* __restrict__ dz3, float* __restrict__ dz2, float* __restrict__ dz1,
+                                                           float* __restrict__ dxg, int B, int G, int F1, int F2, int A) {
+  __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW];
+  const int t = threadIdx.x, r0 = blockIdx.x * FP_RB;
+  if (t < FP_RB) {
+    const int b = r0 + t;
+    float s = 0.f;
+    if (b < B)
+      for (int a = 0; a < A; ++a) s += gout[(long)b * A + a];
+    for (int a = 0; a < A; ++a) {
+      const float v = (b < B) ? gout[(long)b * A + a] - expf(out[(long)b * A + a]) * s : 0.f;
+      sa[t * FP_MAXW + a] = v;
+      if (b < B) dz3[(long)b * A + a] = v;
+    }
+  }
+  __syncthreads();
+  float acc[FP_RB];
+  for (int j = t; j < F2; j += 256) {
+    fp_layer_cols(W3, sa, A, F2, j, acc);
+#pragma unroll
+    for (int r = 0; r < FP_RB; ++r) {
+      const bool ok = r0 + r < B;
+      float v = 0.f;
+      if (ok) {
+        const long o = (long)(r0 + r) * F2 + j;
+        v = (f2[o] > 0.f) ? acc[r] * (mask ? mask[o] : 1.f) : 0.f;
+        dz2[o] = v;
+      }
+      sb[r * FP_MAXW + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int j = t; j < F1; j += 256) {
+    fp_layer_cols(W2, sb, F2, F1, j, acc);
+#pragma unroll
+    for (int r = 0; r < FP_RB; ++r) {
+      const bool ok = r0 + r < B;
+      float v = 0.f;
+      if (ok) {
+        const long o = (long)(r0 + r) * F1 + j;
+        v = (f1[o] > 0.f) ? acc[r] : 0.f;
+        dz1[o] = v;
+      }
+      sa[r * FP_MAXW + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int j = t; j < G; j += 256) {
+    fp_layer_cols(W1, sa, F1, G, j, acc);
+#pragma unroll
+    for (int r = 0; r < FP_RB; ++r)
+      if (r0 + r < B) dxg[(long)(r0 + r) * G + j] = acc[r];
+  }
+}
+
+// block = one output row i of dW1 (F1 rows) | dW2 (F2) | dW3 (A): dW[i][j] = sum_b dz[b][i] * act[b][j]; db[i] = sum_b dz[b][i]
+__global__ __launch_bounds__(256) void f_phi_bwd_grads_kernel(const float* __restrict__ dz1, const float* __restrict__ dz2,
+                                                              const float* __restrict__ dz3, const float* __restrict__ xg,
+                                                              const float* __restrict__ f1, const float* __restrict__ f2,
+                                                              float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
+                                                              float* __restrict__ db2, float* __restrict__ dW3, float* __restrict__ db3,
+                                                              int B, int G, int F1, int F2, int A) {
+  __shared__ float dzs[1024];
+  int i = blockIdx.x;
+  const float *dz, *act;
+  float *dW, *db;
+  int I, J;
+  if (i < F1) { dz = dz1; act = xg; dW = dW1; db = db1; I = F1; J = G; }
+  else if (i < F1 + F2) { i -= F1; dz = dz2; act = f1; dW = dW2; db = db2; I = F2; J = F1; }
+  else { i -= F1 + F2; dz = dz3; act = f2; dW = dW3; db = db3; I = A; J = F2; }
+  for (int b = threadIdx.x; b < B; b += 256) dzs[b] = dz[(long)b * I + i];
+  __syncthreads();
+  for (int j = threadIdx.x; j < J; j += 256) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s = fmaf(dzs[b], act[(long)b * J + j], s);
+    dW[(long)i * J + j] = s;
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dzs[b];
+    db[i] = s;
+  }
+}
+
+static int fp_check(const char* who, int B, int G, int F1, int F2, int A) {
+  RN_CHECK_ARG(B > 0 && B <= 1024 && G > 0 && F1 > 0 && F2 > 0 && A > 0, "%s: bad sizes", who);
+  RN_CHECK_ARG(G <= FP_MAXW && F1 <= FP_MAXW && F2 <= FP_MAXW && A <= FP_MAXW && G % 4 == 0 && F1 % 4 == 0 && F2 % 4 == 0,
+               "%s: widths must be multiples of 4 and <= %d (G=%d F1=%d F2=%d A=%d)", who, FP_MAXW, G, F1, F2, A);
+  return 0;
+}
+
+extern "C" int rn_f_phi_fwd(const float* xg, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                            const float* b3, const float* mask, float* f1, float* f2, float* out, int B, int G, int F1, int F2,
+                            int A, void* stream) {
+  RN_CHECK_ARG(xg && W1 && b1 && W2 && b2 && W3 && b3 && f1 && f2 && out, "rn_f_phi_fwd: NULL pointer");
+  if (int rc = fp_check("rn_f_phi_fwd", B, G, F1, F2, A)) return rc;
+  RN_CHECK_ARG(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)W3) % 16 == 0, "rn_f_phi_fwd: weights must be 16-byte aligned");
+  f_phi_fwd_kernel<<<cdiv(B, FP_RB), 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A);
+  RN_LAUNCH_CHECK("rn_f_phi_fwd");
+  return 0;
+}
+
+extern "C" size_t rn_f_phi_bwd_ws_bytes(int B, int F1, int F2, int A) { return (size_t)B * (F1 + F2 + A) * sizeof(float); }
+
+extern "C" int rn_f_phi_bwd(const float* gout, const float* out, const float* f2, const float* f1, const float* xg, const float* W1,
+                            const float* W2, const float* W3, const float* mask, float* dW1, float* db1, float* dW2, float* db2,
+                            float* dW3, float* db3, float* dxg, void* ws, int B, int G, int F1, int F2, int A, void* stream) {
+  RN_CHECK_ARG(gout && out && f2 && f1 && xg && W1 && W2 && W3 && dW1 && db1 && dW2 && db2 && dW3 && db3 && dxg && ws, "rn_f_phi_bwd: NULL pointer");
+  if (int rc = fp_check("rn_f_phi_bwd", B, G, F1, F2, A)) return rc;
+  float* dz1 = (float*)ws;
+  float* dz2 = dz1 + (size_t)B * F1;
+  float* dz3 = dz2 + (size_t)B * F2;
+  hipStream_t s = (hipStream_t)stream;
+  f_phi_bwd_dz_kernel<<<cdiv(B, FP_RB), 256, 0, s>>>(gout, out, f2, f1, W1, W2, W3, mask, dz3, dz2, dz1, dxg, B, G, F1, F2, A);
+  f_phi_bwd_grads_kernel<<<F1 + F2 + A, 256, 0, s>>>(dz1, dz2, dz3, xg, f1, f2, dW1, db1, dW2, db2, dW3, db3, B, G, F1, F2, A);
+  RN_LAUNCH_CHECK("rn_f_phi_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------- clip + Adam on the flat gradient
+// The tail of a training step (train.py:45-48: clip_grad_norm, Adam with coupled weight decay) as two launches over
+// the flat gradient buffer of the data-parallel bucket instead of ~25 small ones:
+//   1. per-block sums of squares of the (already all-reduced) gradient;
+//   2. every block adds the partials up in the same fixed order (-> the same norm everywhere), forms the
+//      torch.nn.utils.clip_grad_norm_ coefficient min(1, max_norm / (norm + 1e-6)) and applies torch.optim.Adam
+//      (amsgrad=False) to its chunk.  Parameters stay separate tensors: a chunk table maps flat ranges to them.
+namespace {
+constexpr int OPT_NB = 256;        // blocks of the norm pass
+constexpr int OPT_CHUNK = 1024;    // elements per chunk of the update pass (a chunk never crosses a parameter)
+}  // namespace
+struct RnAdamChunk { float* param; long flat_off; int count; int pad; };
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, double* __restrict__ partial) {
+  __shared__ double red[4];
+  float a = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a = fmaf(g[i], g[i], a);
+  double x = (double)a;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(const RnAdamChunk* __restrict__ chunks, float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        const double* __restrict__ partial, int npartial, float max_norm,
+                                                        float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                                        float bc2_sqrt, float* __restrict__ norm_out) {
+  __shared__ float coef_s;
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < npartial; ++i) s += partial[i];
+    const float total = (float)sqrt(s);
+    float c = 1.f;
+    if (max_norm > 0.f) {
+      c = max_norm / (total + 1e-6f);
+      c = c < 1.f ? c : 1.f;
+    }
+    coef_s = c;
+    if (blockIdx.x == 0 && norm_out) norm_out[0] = total;
+  }
+  __syncthreads();
+  const float coef = coef_s;
+  const RnAdamChunk c = chunks[blockIdx.x];
+  const float step = lr / bc1;
+  for (int i = threadIdx.x; i < c.count; i += 256) {
+    const long f = c.flat_off + i;
+    const float gc = g[f] * coef;                          // clipped gradient (left in the buffer, like clip_grad_norm_)
+    g[f] = gc;
+    const float p = c.param[i];
+    const float gd = fmaf(wd, p, gc);                      // coupled L2 weight decay
+    const float mn = fmaf(beta1, m[f], (1.f - beta1) * gd);
+    const float vn = fmaf(beta2, v[f], (1.f - beta2) * gd * gd);
+    m[f] = mn;
+    v[f] = vn;
+    c.param[i] = p - step * mn / (sqrtf(vn) / bc2_sqrt + eps);
+  }
+}
+
+extern "C" int rn_clip_adam_chunk(void) { return OPT_CHUNK; }
+extern "C" size_t rn_clip_adam_ws_bytes(void) { return OPT_NB * sizeof(double); }
+
+extern "C" int rn_clip_adam_step(const void* chunks, int nchunks, float* g, float* m, float* v, long n, void* ws, float max_norm,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* norm_out,
+                                 void* stream) {
+  RN_CHECK_ARG(chunks && nchunks > 0 && g && m && v && n > 0 && ws && step >= 1, "rn_clip_adam_step: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  sumsq_partial_kernel<<<OPT_NB, 256, 0, s>>>(g, n, (double*)ws);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  clip_adam_kernel<<<nchunks, 256, 0, s>>>((const RnAdamChunk*)chunks, g, m, v, (const double*)ws, OPT_NB, max_norm, lr, beta1, beta2,
+                                           eps, weight_decay, (float)bc1, (float)sqrt(bc2), norm_out);
+  RN_LAUNCH_CHECK("rn_clip_adam_step");
+  return 0;
+}

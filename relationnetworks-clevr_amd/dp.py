@@ -14,6 +14,8 @@ backward (the bucket is complete only when backward ends: the g_theta weight gra
 bulk of the bytes, are produced last-layer-first but conv/LSTM grads arrive at the very end)."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -103,6 +105,62 @@ def broadcast_module_state(module, src: int = 0, group=None):
             dist.broadcast(t.data, src=src, group=group)
 
 
+class FusedClipAdam:
+    """clip_grad_norm_ + torch.optim.Adam (amsgrad=False, one parameter group) on the bucket's flat gradient: two HIP
+    launches (rn_clip_adam_step) instead of the norm / clamp / scale / multi-tensor-Adam sequence.  Hyper-parameters
+    are read from the torch optimizer's param_group at every step, so LR schedulers keep working; the moment
+    buffers live here (the reference checkpoints model weights only, train.py:364)."""
+
+    def __init__(self, bucket: "FlatGradBucket", optimizer):
+        import numpy as np
+        from . import rn_hip as H
+        self.H, self.bucket, self.opt = H, bucket, optimizer
+        dev = bucket.flat.device
+        ch = H.load().rn_clip_adam_chunk()
+        rec = []
+        off = 0
+        for p in bucket.params:
+            n, done = p.numel(), 0
+            while done < n:
+                c = min(ch, n - done)
+                rec.append((p.data_ptr() + 4 * done, off + done, c, 0))
+                done += c
+            off += n
+        arr = np.array(rec, dtype=np.dtype([("p", "<u8"), ("o", "<i8"), ("c", "<i4"), ("z", "<i4")]))
+        self.chunks = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
+        self.nchunks = len(rec)
+        self.ptrs = [p.data_ptr() for p in bucket.params]
+        self.m = torch.zeros_like(bucket.flat)
+        self.v = torch.zeros_like(bucket.flat)
+        self.ws = torch.empty(H.load().rn_clip_adam_ws_bytes(), dtype=torch.uint8, device=dev)
+        self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.t = 0
+
+    @staticmethod
+    def supports(bucket, optimizer):
+        if os.environ.get("RN_NO_FUSED_ADAM", "0") == "1" or type(optimizer) is not torch.optim.Adam:
+            return False
+        if len(optimizer.param_groups) != 1 or not bucket.flat.is_cuda:
+            return False
+        g = optimizer.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
+            return False
+        ids = {id(p) for p in g["params"]}
+        return ids == {id(p) for p in bucket.params} and all(p.is_contiguous() for p in bucket.params)
+
+    def step(self, clip_norm):
+        if [p.data_ptr() for p in self.bucket.params] != self.ptrs:
+            raise RuntimeError("a parameter's storage moved since the trainer was built (load_state_dict copies in place; .data = ... does not)")
+        g = self.opt.param_groups[0]
+        self.t += 1
+        self.H.clip_adam_step(self.chunks, self.nchunks, self.bucket.flat, self.m, self.v, self.ws, clip_norm, g["lr"], g["betas"][0],
+                              g["betas"][1], g["eps"], g["weight_decay"], self.t, self.norm)
+        # the kernel wrote the parameters behind autograd's back: bump their version counters (the relational layer
+        # keys its packed-weight cache on them)
+        torch.autograd.graph.increment_version(self.bucket.params)
+        return self.norm
+
+
 class DataParallelTrainer:
     """model + optimizer + flat bucket: step(batch) = zero -> fwd -> nll -> bwd -> all-reduce -> clip -> Adam
     (the loop body of the reference's train(), train.py:36-48).
@@ -119,6 +177,7 @@ class DataParallelTrainer:
         self.use_graph = use_graph
         self._graph = None
         self._static = None
+        self._fused_opt = FusedClipAdam(self.bucket, optimizer) if FusedClipAdam.supports(self.bucket, optimizer) else None
 
     def _fwd_bwd(self, img, qst, label):
         self.bucket.detach_()
@@ -155,7 +214,10 @@ class DataParallelTrainer:
         else:
             loss = self._fwd_bwd(img, qst, label)
         self.bucket.all_reduce_mean(self.group)
-        if self.clip_norm:
-            self.bucket.clip_grad_norm_(self.clip_norm)
-        self.opt.step()
+        if self._fused_opt is not None:
+            self._fused_opt.step(self.clip_norm)          # clip + Adam: two launches on the flat gradient
+        else:
+            if self.clip_norm:
+                self.bucket.clip_grad_norm_(self.clip_norm)
+            self.opt.step()
         return loss

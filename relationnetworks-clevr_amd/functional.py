@@ -69,6 +69,7 @@ class PackedWeights:
         dev = g_w[0].device
         self.fwd, self.bwd, self.hi, self.lo, self.frag, self.fragT = [], [], [], [], [], []
         rr = rr_chain_ok(plan, code)
+        frag_jobs = []
         for l, w in enumerate(g_w):
             N, kt = w.shape
             assert kt == plan.ktrue[l] and N == plan.widths[l], (w.shape, plan.ktrue[l], plan.widths[l])
@@ -83,7 +84,7 @@ class PackedWeights:
                 self.fwd.append(wp)
             if rr:
                 wf = torch.empty(256 * 256, dtype=dt, device=dev)
-                H.pack_matrix_frag(wc, kt, 1, N, kt, wf, l == 0)
+                frag_jobs.append((wc, kt, 1, N, kt, wf, l == 0))
                 self.frag.append(wf)
             if split:
                 hi = torch.empty(N, plan.kpad[l], dtype=torch.float16, device=dev)
@@ -102,7 +103,9 @@ class PackedWeights:
             self.fragT = list(torch.empty(plan.L - 1, 256 * 256, dtype=dt, device=dev))     # equally spaced (rn_g_chain_bwd_rr)
             for st, wf in enumerate(self.fragT):
                 wc = g_w[plan.L - 1 - st].detach().contiguous()
-                H.pack_matrix_frag(wc, 1, wc.shape[1], 256, 256, wf, st == 0)      # element (in, out) = W[out][in]
+                frag_jobs.append((wc, 1, wc.shape[1], 256, 256, wf, st == 0))      # element (in, out) = W[out][in]
+        if frag_jobs:
+            H.pack_matrix_frag_many(frag_jobs)                                     # one launch for all images
         self.key = key
         return self.fwd, self.bwd
 
@@ -246,19 +249,15 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
 
 
 def f_phi_forward(xg, fw, fb, mask):
-    """f_phi + log_softmax (model.py:155-162): fc1 -> relu -> fc2 -> dropout mask -> relu -> fc3, all fp32
-    on the fp32 MFMA.  Returns (f1, f2, log_probs)."""
+    """f_phi + log_softmax (model.py:155-162): fc1 -> relu -> fc2 -> dropout mask -> relu -> fc3 -> log_softmax,
+    fp32.  Returns (f1, f2, log_probs)."""
     B, G = xg.shape
     dev = xg.device
     F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
     f1 = torch.empty(B, F1, dtype=torch.float32, device=dev)
-    H.gemm_f32(xg, G, 1, fw[0], 1, G, f1, F1, B, F1, G, bias=fb[0], flags=H.RN_RELU)
     f2 = torch.empty(B, F2, dtype=torch.float32, device=dev)
-    H.gemm_f32(f1, F1, 1, fw[1], 1, F1, f2, F2, B, F2, F1, bias=fb[1], mul=mask, ldmul=F2, flags=H.RN_RELU)
-    z3 = torch.empty(B, A, dtype=torch.float32, device=dev)
-    H.gemm_f32(f2, F2, 1, fw[2], 1, F2, z3, A, B, A, F2, bias=fb[2])
     out = torch.empty(B, A, dtype=torch.float32, device=dev)
-    H.log_softmax_fwd(z3, out, B, A)
+    H.f_phi_fwd(xg, fw, fb, mask, f1, f2, out)          # one launch (rn_small.hip)
     return f1, f2, out
 
 
@@ -319,24 +318,12 @@ class RelationalFunction(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         gout = gout.float().contiguous()
         fw = ctx.fw
-        # ---- f_phi backward (fp32)
-        dz3 = torch.empty(B, A, **f32)
-        H.log_softmax_bwd(out, gout, dz3, B, A)
+        # ---- f_phi backward (fp32): two launches (dz chain incl. log_softmax; all weight / bias gradients)
         dW3 = torch.empty(A, F2, **f32); db3 = torch.empty(A, **f32)
-        H.gemm_f32(dz3, 1, A, f2, F2, 1, dW3, F2, A, F2, B)                 # dz3^T @ f2
-        H.colsum_f32(dz3, A, db3, B, A)
-        dz2 = torch.empty(B, F2, **f32)
-        H.gemm_f32(dz3, A, 1, fw[2], F2, 1, dz2, F2, B, F2, A, mul=ctx.mask, ldmul=F2, gate=f2, ldgate=F2)
         dW2 = torch.empty(F2, F1, **f32); db2 = torch.empty(F2, **f32)
-        H.gemm_f32(dz2, 1, F2, f1, F1, 1, dW2, F1, F2, F1, B)
-        H.colsum_f32(dz2, F2, db2, B, F2)
-        dz1 = torch.empty(B, F1, **f32)
-        H.gemm_f32(dz2, F2, 1, fw[1], F1, 1, dz1, F1, B, F1, F2, gate=f1, ldgate=F1)
         dW1 = torch.empty(F1, G, **f32); db1 = torch.empty(F1, **f32)
-        H.gemm_f32(dz1, 1, F1, xg, G, 1, dW1, G, F1, G, B)
-        H.colsum_f32(dz1, F1, db1, B, F1)
         dxg = torch.empty(B, G, **f32)
-        H.gemm_f32(dz1, F1, 1, fw[0], G, 1, dxg, G, B, G, F1)
+        H.f_phi_bwd(gout, out, f2, f1, xg, fw, ctx.mask, (dW1, dW2, dW3), (db1, db2, db3), dxg)
         # ---- g_theta backward
         dt = H.torch_dtype(code)
         inputs, wbwd, g_w = ctx.inputs, ctx.wbwd, ctx.g_w
@@ -425,3 +412,61 @@ def relational_forward(x, q, mask, plan, packed, precision, g_w, g_b, f_w, f_b):
     if precision not in PRECISIONS:
         raise ValueError("precision must be one of %r" % (PRECISIONS,))
     return RelationalFunction.apply(x, q, mask, plan, packed, precision, *g_w, *g_b, *f_w, *f_b)
+
+
+_ZEROS = {}
+
+
+def _zeros_like_cached(n, ref):
+    """A shared read-only zero vector (the conv-bias gradient): no fill kernel per step."""
+    key = (n, ref.dtype, ref.device)
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+    return z
+
+
+class ConvBNReLUFunction(torch.autograd.Function):
+    """relu(batch_norm(conv2d(x))) of the reference's ConvInputModel block (model.py:22-35): the convolution is
+    MIOpen's (aten.convolution, run WITHOUT its bias), batch norm + ReLU and their backward are the fused
+    two-pass kernels of rn_convnorm.hip.  A bias in front of a batch norm only shifts the batch mean -- it is
+    added to the running mean and its gradient is identically zero (returned as zeros)."""
+
+    @staticmethod
+    def forward(ctx, inp, conv_w, conv_b, gamma, beta, running_mean, running_var, num_batches, training, momentum, eps, stride, padding):
+        H._dev(inp, "img")
+        x = torch.ops.aten.convolution(inp, conv_w, None, stride, padding, (1, 1), False, (0, 0), 1)
+        x = x.contiguous()
+        Cc = x.shape[1]
+        y = torch.empty_like(x)
+        f32 = dict(dtype=torch.float32, device=x.device)
+        g, bt = gamma.detach().contiguous(), beta.detach().contiguous()
+        if training:
+            mean = torch.empty(Cc, **f32); invstd = torch.empty(Cc, **f32)
+            H.bn_relu_fwd(x, y, g, bt, conv_b.detach() if conv_b is not None else None, running_mean, running_var, num_batches,
+                          mean, invstd, eps, momentum)
+        else:
+            mean = running_mean - (conv_b.detach() if conv_b is not None else 0)
+            invstd = torch.rsqrt(running_var + eps)
+            H.bn_relu_apply(x, y, g, bt, mean.contiguous(), invstd.contiguous())
+        ctx.trained = training
+        if training and any(ctx.needs_input_grad):
+            ctx.save_for_backward(inp, conv_w, x, g, bt, mean, invstd)
+            ctx.conv_args = (stride, padding)
+            ctx.has_bias = conv_b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.trained:         # ConvInputModel.forward keeps evaluation-mode graphs on the stock ops
+            raise RuntimeError("ConvBNReLUFunction: backward through evaluation-mode batch norm is not implemented")
+        inp, conv_w, x, g, bt, mean, invstd = ctx.saved_tensors
+        stride, padding = ctx.conv_args
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(g); dbeta = torch.empty_like(bt)
+        H.bn_relu_bwd(dy, x, dx, g, bt, mean, invstd, dgamma, dbeta)
+        din, dw, _ = torch.ops.aten.convolution_backward(dx, inp, conv_w, None, stride, padding, (1, 1), False, (0, 0), 1,
+                                                         [ctx.needs_input_grad[0], True, False])
+        db = _zeros_like_cached(conv_w.shape[0], conv_w) if ctx.has_bias else None
+        return din, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None

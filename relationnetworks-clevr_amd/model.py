@@ -55,8 +55,17 @@ class ConvInputModel(nn.Module):
 
     def forward(self, img):
         x = img
+        fused = (img.is_cuda and img.dtype == torch.float32 and os.environ.get("RN_NO_FUSED_BN", "0") != "1"
+                 and not (torch.is_grad_enabled() and not self.training))
         for i in range(1, 5):
-            x = F.relu(self._modules["batchNorm%d" % i](self._modules["conv%d" % i](x)))
+            conv, bn = self._modules["conv%d" % i], self._modules["batchNorm%d" % i]
+            hw = ((x.shape[2] + 2 * conv.padding[0] - 3) // conv.stride[0] + 1) * ((x.shape[3] + 2 * conv.padding[1] - 3) // conv.stride[1] + 1)
+            if fused and hw % 4 == 0 and bn.track_running_stats and bn.momentum is not None:
+                # MIOpen convolution + the fused batch-norm / ReLU kernels (rn_convnorm.hip)
+                x = RF.ConvBNReLUFunction.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                                bn.num_batches_tracked, self.training, bn.momentum, bn.eps, conv.stride, conv.padding)
+            else:
+                x = F.relu(bn(conv(x)))
         return x
 
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     "rn_g_chain_fwd_rr": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pack_matrix_frag": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
+    "rn_pack_matrix_frag_many": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "rn_g_chain_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_pair_sum_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_sum_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
@@ -50,6 +51,16 @@ SIGNATURES = {
     "rn_log_softmax_fwd": (_I, [_P, _P, _I, _I, _P]),
     "rn_log_softmax_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "rn_colsum_f32": (_I, [_P, _L, _P, _I, _I, _P]),
+    "rn_f_phi_fwd": (_I, [_P] * 11 + [_I] * 5 + [_P]),
+    "rn_f_phi_bwd_ws_bytes": (_Z, [_I, _I, _I, _I]),
+    "rn_f_phi_bwd": (_I, [_P] * 17 + [_I] * 5 + [_P]),
+    "rn_clip_adam_chunk": (_I, []),
+    "rn_clip_adam_ws_bytes": (_Z, []),
+    "rn_clip_adam_step": (_I, [_P, _I, _P, _P, _P, _L, _P] + [C.c_float] * 6 + [_I, _P, _P]),
+    "rn_bn_relu_ws_bytes": (_Z, [_I, _I, _I]),
+    "rn_bn_relu_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _I, _I, _P]),
+    "rn_bn_relu_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "rn_bn_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rn_probe_tr16": (_I, [_P, _P, _P]),
 }
 
@@ -212,6 +223,15 @@ def pack_matrix_frag(src, sr, sc, R, Cc, dst, natural, src_offset=0):
            "rn_pack_matrix_frag")
 
 
+def pack_matrix_frag_many(jobs):
+    """jobs: list of (src, sr, sc, R, C, dst, natural) -- one launch."""
+    n = len(jobs)
+    _check(load().rn_pack_matrix_frag_many((C.c_void_p * n)(*[j[0].data_ptr() for j in jobs]), (C.c_long * n)(*[j[1] for j in jobs]),
+                                           (C.c_long * n)(*[j[2] for j in jobs]), (C.c_int * n)(*[j[3] for j in jobs]),
+                                           (C.c_int * n)(*[j[4] for j in jobs]), (C.c_void_p * n)(*[j[5].data_ptr() for j in jobs]),
+                                           (C.c_int * n)(*[int(j[6]) for j in jobs]), n, _stream()), "rn_pack_matrix_frag_many")
+
+
 @_timed("g_fwd")
 def g_chain_fwd_rr(P, ldp, Wfs, biases, Hs, masks, K0, xg_part, M, G):
     """Register-resident forward chain.  Hs: None or 4 entries (the last may be None when masks are given);
@@ -324,3 +344,58 @@ def log_softmax_bwd(out, gout, dz, B, A):
 
 def colsum_f32(src, ld, out, R, Cc):
     _check(load().rn_colsum_f32(src.data_ptr(), ld, out.data_ptr(), R, Cc, _stream()), "rn_colsum_f32")
+
+
+# ------------------------------------------------------------------ conv stack: BatchNorm2d + ReLU
+@_timed("bn_relu")
+def bn_relu_fwd(x, y, gamma, beta, conv_bias, running_mean, running_var, num_batches, mean, invstd, eps, momentum):
+    N, Cc, Hh, Ww = x.shape
+    lib = load()
+    ws = torch.empty(max(lib.rn_bn_relu_ws_bytes(N, Cc, Hh * Ww), 16), dtype=torch.uint8, device=x.device)
+    _check(lib.rn_bn_relu_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(conv_bias), _ptr(running_mean),
+                              _ptr(running_var), _ptr(num_batches), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), eps, momentum,
+                              N, Cc, Hh * Ww, _stream()), "rn_bn_relu_fwd")
+
+
+@_timed("bn_relu")
+def bn_relu_apply(x, y, gamma, beta, mean, invstd):
+    N, Cc, Hh, Ww = x.shape
+    _check(load().rn_bn_relu_apply(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                   N, Cc, Hh * Ww, _stream()), "rn_bn_relu_apply")
+
+
+@_timed("bn_relu")
+def bn_relu_bwd(dy, x, dx, gamma, beta, mean, invstd, dgamma, dbeta):
+    N, Cc, Hh, Ww = x.shape
+    lib = load()
+    ws = torch.empty(max(lib.rn_bn_relu_ws_bytes(N, Cc, Hh * Ww), 16), dtype=torch.uint8, device=x.device)
+    _check(lib.rn_bn_relu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                              invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), N, Cc, Hh * Ww, _stream()), "rn_bn_relu_bwd")
+
+
+# ------------------------------------------------------------------ fused f_phi
+@_timed("f_phi")
+def f_phi_fwd(xg, fw, fb, mask, f1, f2, out):
+    B, G = xg.shape
+    F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
+    _check(load().rn_f_phi_fwd(xg.data_ptr(), fw[0].data_ptr(), fb[0].data_ptr(), fw[1].data_ptr(), fb[1].data_ptr(), fw[2].data_ptr(),
+                               fb[2].data_ptr(), _ptr(mask), f1.data_ptr(), f2.data_ptr(), out.data_ptr(), B, G, F1, F2, A, _stream()),
+           "rn_f_phi_fwd")
+
+
+@_timed("f_phi")
+def f_phi_bwd(gout, out, f2, f1, xg, fw, mask, dW, db, dxg):
+    B, G = xg.shape
+    F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
+    lib = load()
+    ws = torch.empty(max(lib.rn_f_phi_bwd_ws_bytes(B, F1, F2, A), 16), dtype=torch.uint8, device=xg.device)
+    _check(lib.rn_f_phi_bwd(gout.data_ptr(), out.data_ptr(), f2.data_ptr(), f1.data_ptr(), xg.data_ptr(), fw[0].data_ptr(), fw[1].data_ptr(),
+                            fw[2].data_ptr(), _ptr(mask), dW[0].data_ptr(), db[0].data_ptr(), dW[1].data_ptr(), db[1].data_ptr(),
+                            dW[2].data_ptr(), db[2].data_ptr(), dxg.data_ptr(), ws.data_ptr(), B, G, F1, F2, A, _stream()), "rn_f_phi_bwd")
+
+
+# ------------------------------------------------------------------ clip + Adam on the flat gradient
+def clip_adam_step(chunks, nchunks, g, m, v, ws, max_norm, lr, beta1, beta2, eps, wd, step, norm_out=None):
+    _check(load().rn_clip_adam_step(chunks.data_ptr(), nchunks, g.data_ptr(), m.data_ptr(), v.data_ptr(), g.numel(), ws.data_ptr(),
+                                    float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step),
+                                    _ptr(norm_out), _stream()), "rn_clip_adam_step")

@@ -515,3 +515,46 @@ def test_argument_errors_are_loud(H):
         H.pair_build_fwd(x, None, P, 0, 1, 4, 3, 0, 100)
     with pytest.raises(RuntimeError, match="GPU"):
         H.pair_build_fwd(x.cpu(), None, P, 0, 1, 4, 3, 0, 128)
+
+
+# ----------------------------------------------------------------------------- conv stack: fused BatchNorm2d + ReLU
+@pytest.mark.parametrize("N,hw", [(64, 128), (3, 32)])
+def test_conv_bn_relu_block(N, hw):
+    """ConvInputModel with the fused batch-norm / ReLU kernels (rn_convnorm.hip) against the same module run through
+    the stock torch ops (reference model.py:22-35): outputs, running statistics, every gradient.  fp32 tolerance:
+    only summation order differs (1e-4 relative in max-norm; the conv-bias gradient is rounding noise around zero
+    in the stock path and exactly zero here)."""
+    import relationnetworks_clevr_amd as pkg
+    torch.manual_seed(5)
+    a = pkg.ConvInputModel().cuda().train()
+    b = pkg.ConvInputModel().cuda().train()
+    b.load_state_dict(a.state_dict())
+    img = torch.rand(N, 3, hw, hw, device="cuda")
+    tgt = torch.randn(N, 24, hw // 16, hw // 16, device="cuda")
+    os.environ["RN_NO_FUSED_BN"] = "1"
+    try:
+        ya = a(img)
+    finally:
+        os.environ.pop("RN_NO_FUSED_BN")
+    yb = b(img)
+    assert rel(yb.detach().cpu().numpy(), ya.detach().cpu().numpy()) <= F32_TOL
+    (ya * tgt).sum().backward()
+    (yb * tgt).sum().backward()
+    for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        ga, gb = pa.grad.cpu().numpy(), pb.grad.cpu().numpy()
+        if na.startswith("conv") and na.endswith("bias"):
+            assert np.all(gb == 0) and np.abs(ga).max() <= 1e-3 * max(np.abs(a._modules[na.split(".")[0]].weight.grad.cpu().numpy()).max(), 1e-30)
+        else:
+            assert rel(gb, ga) <= 5 * F32_TOL, (na, rel(gb, ga))
+    for (na, ba), (nb, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert rel(bb.float().cpu().numpy(), ba.float().cpu().numpy()) <= F32_TOL, na
+    # evaluation mode: running statistics
+    a.eval(); b.eval()
+    with torch.no_grad():
+        os.environ["RN_NO_FUSED_BN"] = "1"
+        try:
+            ea = a(img)
+        finally:
+            os.environ.pop("RN_NO_FUSED_BN")
+        eb = b(img)
+    assert rel(eb.cpu().numpy(), ea.cpu().numpy()) <= F32_TOL

@@ -99,8 +99,11 @@ def test_log_lines_parse_with_plot_regexes(T):
 
 
 @pytest.mark.gpu
-def test_training_trajectory_matches_reference(T):
-    """G-traj: 4 reference training steps (Adam 1e-4 / wd 1e-4 / clip 50, train-mode BN, dropout 0) recorded on
+@pytest.mark.parametrize("fused_opt", [False, True])
+def test_training_trajectory_matches_reference(T, fused_opt):
+    """fused_opt: clip + Adam through rn_clip_adam_step (the trainer's default) instead of torch's clip_grad_norm_ /
+    optim.Adam.
+    G-traj: 4 reference training steps (Adam 1e-4 / wd 1e-4 / clip 50, train-mode BN, dropout 0) recorded on
     the CPU reference; the MI355X trainer in fp32 precision must reproduce the losses to 1e-3 and the
     pre-clip gradient norms to 1e-2 (the first step exactly tests forward + all gradients)."""
     import relationnetworks_clevr_amd as pkg
@@ -126,8 +129,12 @@ def test_training_trajectory_matches_reference(T):
                  "answer": torch.from_numpy(formula.hash_ints((meta["b"], 1), seed + 3, 1, formula.ADICT + 1))}
         img, q, y = T.load_tensor_data(batch, "cuda", invert_questions=True)
         loss = tr._fwd_bwd(img, q, y)
-        norms.append(float(tr.bucket.clip_grad_norm_(50.0)))
-        opt.step()
+        if fused_opt:
+            assert tr._fused_opt is not None
+            norms.append(float(tr._fused_opt.step(50.0)))
+        else:
+            norms.append(float(tr.bucket.clip_grad_norm_(50.0)))
+            opt.step()
         losses.append(float(loss.detach()))
     print("losses", losses, "ref", g["losses"].tolist(), "norms", norms, g["grad_norms"].tolist())
     assert np.allclose(losses, g["losses"], rtol=1e-3)

@@ -26,6 +26,9 @@ print("window %.3f ms for %d steps -> %.3f ms/step; sum of kernel time %.3f ms/s
     (t1 - t0) / 1e6, n, (t1 - t0) / 1e6 / n, busy / 1e6 / n, union / 1e6 / n))
 agg = collections.defaultdict(lambda: [0, 0])
 for s, e, nme in win:
-    a = agg[nme.split("(")[0][-60:]]; a[0] += e - s; a[1] += 1
-for k, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:28]:
-    print("  %-62s %7.1f us/step  x%d" % (k, t / 1e3 / n, c // n))
+    import re as _re
+    key = _re.sub(r"^void ", "", nme)
+    key = key.replace("at::native::", "").replace("(anonymous namespace)::", "")
+    a = agg[key[:100]]; a[0] += e - s; a[1] += 1
+for k, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(sys.argv[3]) if len(sys.argv) > 3 else 28]:
+    print("  %-100s %7.1f us/step  x%d" % (k, t / 1e3 / n, c // n))
