@@ -228,6 +228,22 @@ size_t rn_clip_adam_ws_bytes(void);
 int rn_clip_adam_step(const void* chunks, int nchunks, float* g, float* m, float* v, long n, void* ws, float max_norm, float lr,
                       float beta1, float beta2, float eps, float weight_decay, int step, float* norm_out, void* stream);
 
+/* Question encoder (reference model.py:39-58): embedding lookup + 1-layer LSTM (E = 32 -> H = 128, gate order
+ * i, f, g, o, zero initial state) as ONE launch per direction (rn_lstm.hip), fp32.
+ *   fwd: idx (B, T) int64 tokens (clamped to [0, V)); emb (V, E); W_ih (4H, E), W_hh (4H, H), b_ih, b_hh (4H).
+ *        Training (xs, gates, cs non-NULL): xs (T, B, E) embedded tokens, gates (T, B, 4H) activated gates,
+ *        cs (T, B, H) cell states, hs (T+1, B, H) hidden states with hs[0] = 0 -- the final state is hs[T].
+ *        Inference (xs == gates == cs == NULL): hs is (B, H) and receives the final hidden state only.
+ *   bwd: dhn (B, H) = gradient of the final hidden state -> dgates (T, B, 4H), the gradient of the pre-activation
+ *        gates; the parameter gradients are plain products of the saved matrices: dW_hh = dgates^T hs[:T],
+ *        dW_ih = dgates^T xs, db_ih = db_hh = column sums, d xs = dgates W_ih.
+ *   rn_embedding_bwd: demb[v] = sum of dx[t*B + b] over the positions holding token v (deterministic order). */
+int rn_lstm_fwd(const long long* idx, const float* emb, const float* W_ih, const float* W_hh, const float* b_ih, const float* b_hh,
+                float* xs, float* gates, float* cs, float* hs, int B, int T, int V, int E, int H, void* stream);
+int rn_lstm_bwd(const float* dhn, const float* gates, const float* cs, const float* W_hh, float* dgates, int B, int T, int H,
+                void* stream);
+int rn_embedding_bwd(const long long* idx, const float* dx, float* demb, int B, int T, int V, int E, void* stream);
+
 /* BatchNorm2d + ReLU of the conv stack in front of the relation layer (reference model.py:22-35), fused into two
  * HBM passes per direction (rn_convnorm.hip).  x: (N, C, H, W) fp32 contiguous conv output computed WITHOUT the
  * conv bias (a bias in front of a batch norm shifts the batch mean by itself and drops out; conv_bias is only added

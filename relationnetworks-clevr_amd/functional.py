@@ -470,3 +470,46 @@ class ConvBNReLUFunction(torch.autograd.Function):
                                                          [ctx.needs_input_grad[0], True, False])
         db = _zeros_like_cached(conv_w.shape[0], conv_w) if ctx.has_bias else None
         return din, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+class QuestionLSTMFunction(torch.autograd.Function):
+    """Embedding + 1-layer LSTM -> final hidden state (reference model.py:51-58) through rn_lstm.hip: the recurrence is
+    one launch per direction; the parameter gradients are three small matrix products over the saved per-step
+    matrices (rocBLAS) plus a deterministic embedding gather-add."""
+
+    @staticmethod
+    def forward(ctx, idx, emb, W_ih, W_hh, b_ih, b_hh):
+        H._dev(idx, "question")
+        idx = idx.long().contiguous()
+        B, T = idx.shape
+        E, Hh = emb.shape[1], W_hh.shape[1]
+        f32 = dict(dtype=torch.float32, device=idx.device)
+        ws = [t.detach().contiguous() for t in (emb, W_ih, W_hh, b_ih, b_hh)]
+        train = any(ctx.needs_input_grad)
+        if train:
+            xs = torch.empty(T, B, E, **f32); gates = torch.empty(T, B, 4 * Hh, **f32)
+            cs = torch.empty(T, B, Hh, **f32); hs = torch.empty(T + 1, B, Hh, **f32)
+            H.lstm_fwd(idx, *ws, xs, gates, cs, hs)
+            ctx.save_for_backward(idx, xs, gates, cs, hs, ws[1], ws[2])
+            ctx.vocab = emb.shape[0]
+            return hs[T].clone()
+        hn = torch.empty(B, Hh, **f32)
+        H.lstm_fwd(idx, *ws, None, None, None, hn)
+        return hn
+
+    @staticmethod
+    def backward(ctx, dhn):
+        idx, xs, gates, cs, hs, W_ih, W_hh = ctx.saved_tensors
+        T, B, G4 = gates.shape
+        dgates = torch.empty_like(gates)
+        H.lstm_bwd(dhn.float().contiguous(), gates, cs, W_hh, dgates)
+        dg = dgates.view(T * B, G4)
+        dW_hh = dg.t().mm(hs[:T].reshape(T * B, -1))
+        dW_ih = dg.t().mm(xs.view(T * B, -1))
+        db = dg.sum(0)
+        demb = None
+        if ctx.needs_input_grad[1]:
+            dx = dg.mm(W_ih)
+            demb = torch.empty(ctx.vocab, xs.shape[2], dtype=torch.float32, device=dg.device)
+            H.embedding_bwd(idx, dx, demb)
+        return None, demb, dW_ih, dW_hh, db, db

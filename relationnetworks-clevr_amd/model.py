@@ -80,6 +80,12 @@ class QuestionEmbedModel(nn.Module):
         self.hidden = hidden
 
     def forward(self, question):
+        l = self.lstm
+        if (question.is_cuda and os.environ.get("RN_NO_FUSED_LSTM", "0") != "1" and l.num_layers == 1 and not l.bidirectional
+                and l.batch_first and l.bias and getattr(l, "proj_size", 0) == 0 and l.input_size == 32 and l.hidden_size == 128
+                and self.wembedding.padding_idx is None and self.wembedding.max_norm is None and l.weight_ih_l0.dtype == torch.float32):
+            # embedding + the whole recurrence in one launch per direction (rn_lstm.hip)
+            return RF.QuestionLSTMFunction.apply(question, self.wembedding.weight, l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0)
         _, (h_n, _c_n) = self.lstm(self.wembedding(question))
         return h_n[0]
 

@@ -54,6 +54,9 @@ SIGNATURES = {
     "rn_f_phi_fwd": (_I, [_P] * 11 + [_I] * 5 + [_P]),
     "rn_f_phi_bwd_ws_bytes": (_Z, [_I, _I, _I, _I]),
     "rn_f_phi_bwd": (_I, [_P] * 17 + [_I] * 5 + [_P]),
+    "rn_lstm_fwd": (_I, [_P] * 10 + [_I] * 5 + [_P]),
+    "rn_lstm_bwd": (_I, [_P] * 5 + [_I] * 3 + [_P]),
+    "rn_embedding_bwd": (_I, [_P] * 3 + [_I] * 4 + [_P]),
     "rn_clip_adam_chunk": (_I, []),
     "rn_clip_adam_ws_bytes": (_Z, []),
     "rn_clip_adam_step": (_I, [_P, _I, _P, _P, _P, _L, _P] + [C.c_float] * 6 + [_I, _P, _P]),
@@ -399,3 +402,26 @@ def clip_adam_step(chunks, nchunks, g, m, v, ws, max_norm, lr, beta1, beta2, eps
     _check(load().rn_clip_adam_step(chunks.data_ptr(), nchunks, g.data_ptr(), m.data_ptr(), v.data_ptr(), g.numel(), ws.data_ptr(),
                                     float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step),
                                     _ptr(norm_out), _stream()), "rn_clip_adam_step")
+
+
+# ------------------------------------------------------------------ question encoder (embedding + LSTM)
+@_timed("lstm")
+def lstm_fwd(idx, emb, W_ih, W_hh, b_ih, b_hh, xs, gates, cs, hs):
+    B, T = idx.shape
+    _check(load().rn_lstm_fwd(idx.data_ptr(), emb.data_ptr(), W_ih.data_ptr(), W_hh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(),
+                              _ptr(xs), _ptr(gates), _ptr(cs), hs.data_ptr(), B, T, emb.shape[0], emb.shape[1], W_hh.shape[1], _stream()),
+           "rn_lstm_fwd")
+
+
+@_timed("lstm")
+def lstm_bwd(dhn, gates, cs, W_hh, dgates):
+    T, B = gates.shape[0], gates.shape[1]
+    _check(load().rn_lstm_bwd(dhn.data_ptr(), gates.data_ptr(), cs.data_ptr(), W_hh.data_ptr(), dgates.data_ptr(), B, T, W_hh.shape[1],
+                              _stream()), "rn_lstm_bwd")
+
+
+@_timed("lstm")
+def embedding_bwd(idx, dx, demb):
+    B, T = idx.shape
+    _check(load().rn_embedding_bwd(idx.data_ptr(), dx.data_ptr(), demb.data_ptr(), B, T, demb.shape[0], demb.shape[1], _stream()),
+           "rn_embedding_bwd")

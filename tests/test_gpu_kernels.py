@@ -558,3 +558,30 @@ def test_conv_bn_relu_block(N, hw):
             os.environ.pop("RN_NO_FUSED_BN")
         eb = b(img)
     assert rel(eb.cpu().numpy(), ea.cpu().numpy()) <= F32_TOL
+
+
+# ----------------------------------------------------------------------------- question encoder: embedding + LSTM
+@pytest.mark.parametrize("B,T", [(64, 20), (5, 7)])
+def test_question_lstm(B, T):
+    """QuestionEmbedModel through rn_lstm.hip against the stock torch.nn.Embedding + nn.LSTM path (reference
+    model.py:39-58): final hidden state and every parameter gradient, fp32 (summation order only: 1e-4 in max-norm)."""
+    import relationnetworks_clevr_amd as pkg
+    torch.manual_seed(11)
+    a = pkg.QuestionEmbedModel(formula.QDICT, 32, 128).cuda()
+    b = pkg.QuestionEmbedModel(formula.QDICT, 32, 128).cuda()
+    b.load_state_dict(a.state_dict())
+    q = torch.from_numpy(formula.hash_ints((B, T), 900, 0, formula.QDICT + 1)).cuda()
+    tgt = torch.randn(B, 128, device="cuda")
+    os.environ["RN_NO_FUSED_LSTM"] = "1"
+    try:
+        ha = a(q)
+    finally:
+        os.environ.pop("RN_NO_FUSED_LSTM")
+    hb = b(q)
+    assert rel(hb.detach().cpu().numpy(), ha.detach().cpu().numpy()) <= F32_TOL
+    (ha * tgt).sum().backward()
+    (hb * tgt).sum().backward()
+    for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert rel(pb.grad.cpu().numpy(), pa.grad.cpu().numpy()) <= 5 * F32_TOL, na
+    with torch.no_grad():
+        assert rel(b(q).cpu().numpy(), ha.detach().cpu().numpy()) <= F32_TOL     # inference entry (nothing saved)
