@@ -113,10 +113,10 @@ class PackedWeights:
 _SIDE_STREAMS = {}
 
 
-def _side_stream(dev):
-    s = _SIDE_STREAMS.get(dev)
+def _side_stream(dev, which=0):
+    s = _SIDE_STREAMS.get((dev, which))
     if s is None:
-        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        s = _SIDE_STREAMS[(dev, which)] = torch.cuda.Stream(device=dev)
     return s
 
 
@@ -466,8 +466,26 @@ class ConvBNReLUFunction(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma = torch.empty_like(g); dbeta = torch.empty_like(bt)
         H.bn_relu_bwd(dy, x, dx, g, bt, mean, invstd, dgamma, dbeta)
-        din, dw, _ = torch.ops.aten.convolution_backward(dx, inp, conv_w, None, stride, padding, (1, 1), False, (0, 0), 1,
-                                                         [ctx.needs_input_grad[0], True, False])
+        conv_bwd = lambda mask: torch.ops.aten.convolution_backward(dx, inp, conv_w, None, stride, padding, (1, 1), False, (0, 0), 1, mask)
+        if ctx.needs_input_grad[0] and os.environ.get("RN_NO_WGRAD_OVERLAP", "0") != "1":
+            # only the input gradient is on the dependency chain of the backward pass: the weight gradient (MIOpen's
+            # wrw kernel plus its layout transposes, ~half of the conv backward) goes to the side stream and overlaps the
+            # next layers' backward; the main stream re-joins at the end of the backward pass
+            main, side = torch.cuda.current_stream(), _side_stream(dx.device, 1)     # (stream 0 carries the g_theta wgrads)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dw = conv_bwd([False, True, False])[1]
+            keep = [dx, inp]
+            for t in keep:
+                t.record_stream(side)
+
+            def _join():
+                torch.cuda.current_stream().wait_stream(side)
+                keep.clear()
+            torch.autograd.Variable._execution_engine.queue_callback(_join)
+            din = conv_bwd([True, False, False])[0]
+        else:
+            din, dw, _ = conv_bwd([ctx.needs_input_grad[0], True, False])
         db = _zeros_like_cached(conv_w.shape[0], conv_w) if ctx.has_bias else None
         return din, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
 
