@@ -8,10 +8,11 @@ synthetic 128x128 images + random 20-token questions, random-init weights.
          bench.py --gpus N --steps K --warmup W
 
 One JSON line on rank 0.  `value` = whole-job questions/s (all ranks, max-over-ranks time).
-`roofline` prices the dominant kernels -- the g_theta GEMMs (forward, dgrad, wgrad launches) --
-in ALGORITHMIC flops (3 x 2*M*sum(K_l*G), padding not counted) against the
-dense bf16 MFMA peak, with durations taken live from HIP events on the launch stream inside the
-timed steps.  `pair_build` reports the K1 HBM roofline the same way.  `cpu_baseline` times the
+`roofline` prices the dominant kernel -- the forward g_theta chain, one launch per step -- in
+ALGORITHMIC flops (2*M*sum(K_l*G), padding not counted) against the dense bf16
+MFMA peak, with the duration taken live from HIP events on the launch stream; `roofline.kernels`
+holds the same for the backward chain and the wgrad launches, `roofline.all_g_theta` their sum
+(3 x the forward flops).  `pair_build` reports the K1 HBM roofline the same way.  `cpu_baseline` times the
 oracle's un-fused fp32 CPU restatement of the reference model on this host (rank 0, N=1 only)."""
 import argparse
 import json
@@ -211,13 +212,27 @@ def main():
             "loss": float(loss.detach()),
         }
         if ksum:
-            g_ms = sum(ksum.get(kk, (0, 0.0))[1] for kk in ("g_fwd", "g_dgrad", "g_wgrad")) / args.steps
+            # dominant kernel = the forward g_theta chain (the "g_theta batched-pair GEMM" of BASELINE.json's north_star): algorithmic
+            # flops of one launch / its average duration from the HIP-event brackets; the other g_theta kernels follow in `kernels`
+            per = {kk: (ksum[kk][1] / args.steps) for kk in ("g_fwd", "g_dgrad", "g_wgrad") if kk in ksum}
+            g_ms = sum(per.values())
             g_launch = sum(ksum.get(kk, (0, 0.0))[0] for kk in ("g_fwd", "g_dgrad", "g_wgrad")) // args.steps
-            ach = 3 * fwd / (g_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
-                               "frac": ach / PEAK_TFLOPS[args.precision], "traffic": None,
-                               "kernel": "g_theta GEMMs: gemm_rowtile_kernel (fwd+dgrad) + wgrad_kernel, %d launches/step" % g_launch,
-                               "algorithmic_flops_per_step": 3 * fwd, "ms_per_step": g_ms,
+            peak = PEAK_TFLOPS[args.precision]
+            fl = {"g_fwd": fwd, "g_dgrad": fwd * (1.0 - g_flops_fwd(M, dict(hyp, g_layers=hyp["g_layers"][:1]), k) / fwd), "g_wgrad": fwd}
+            kern = {kk: {"algorithmic_flops": fl[kk], "ms": per[kk], "achieved_tflops": fl[kk] / (per[kk] * 1e-3) / 1e12,
+                         "frac": fl[kk] / (per[kk] * 1e-3) / 1e12 / peak} for kk in per}
+            rr = args.precision == "bf16" and args.config == "original-fp" and args.hw == 128
+            ach = kern["g_fwd"]["achieved_tflops"]
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                               # HBM bytes of one launch of that kernel from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE at this
+                               # very shape: profiles/r01_final_pmc_hbm_traffic.txt (algorithmic: 100.7 MB read + 444.6 MB written)
+                               "traffic": (137.8e6 + 479.0e6) if rr and B == 64 else None,
+                               "kernel": ("g_chain_rr_kernel (rn_chain_rr.hip): 4-layer g_theta forward chain, 1 launch/step" if rr else
+                                          "g_theta forward kernels (%s path)" % args.precision),
+                               "algorithmic_flops_per_launch": fwd, "ms_per_launch": per["g_fwd"],
+                               "kernels": kern,
+                               "all_g_theta": {"algorithmic_flops_per_step": 3 * fwd, "ms_per_step": g_ms, "launches_per_step": g_launch,
+                                               "achieved": 3 * fwd / (g_ms * 1e-3) / 1e12, "frac": 3 * fwd / (g_ms * 1e-3) / 1e12 / peak},
                                "breakdown_ms_per_step": {kk: v[1] / args.steps for kk, v in sorted(ksum.items())}}
             pb = ksum.get("pair_build")
             if pb:
