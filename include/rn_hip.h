@@ -138,7 +138,8 @@ int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* con
  * src: fp32, element (r, c) at src[r * sr + c * sc] (model.py:96-99 nn.Linear weight: sr = in, sc = 1). */
 int rn_pack_matrix_frag(const float* src, long sr, long sc, int R, int C, void* dst, int natural, void* stream);
 
-/* `count` (<= 8) rn_pack_matrix_frag calls in one launch; all arguments are HOST arrays of `count` entries. */
+/* `count` (<= 12) rn_pack_matrix_frag calls in one launch; all arguments are HOST arrays of `count` entries.
+ * natural[i] == 2 selects a plain fp32 TRANSPOSE instead: dst (C, R) fp32 row-major = src^T (the f_phi weights). */
 int rn_pack_matrix_frag_many(const float* const* src, const long* sr, const long* sc, const int* R, const int* C,
                              void* const* dst, const int* natural, int count, void* stream);
 
@@ -206,12 +207,13 @@ int rn_colsum_f32(const float* src, long ld, float* out, int R, int C, void* str
 
 /* f_phi + log_softmax (model.py:155-162) in one launch, its backward in two (rn_small.hip; fp32 FMA):
  *   f1 = relu(xg W1^T + b1) (B, F1);  f2 = relu((f1 W2^T + b2) * mask) (B, F2);  out = log_softmax(f2 W3^T + b3) (B, A)
- * W_l: nn.Linear layout (out, in) row-major; mask: (B, F2) dropout mask already scaled by 1/(1-p), or NULL.
+ * W_l: nn.Linear layout (out, in) row-major -- or, with transposed != 0 in the forward call, (in, out) copies (fp32 transpose
+ * mode of rn_pack_matrix_frag_many: coalesced weight reads, 41 -> ~12 us); mask: (B, F2) dropout mask already scaled by 1/(1-p), or NULL.
  * Backward: gout = d loss / d out; writes dW_l, db_l and dxg (B, G); ws: rn_f_phi_bwd_ws_bytes(B, F1, F2, A) bytes.
  * Widths are multiples of 4 (A excepted) and <= 1024, B <= 1024. */
 int rn_f_phi_fwd(const float* xg, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
-                 const float* b3, const float* mask, float* f1, float* f2, float* out, int B, int G, int F1, int F2, int A,
-                 void* stream);
+                 const float* b3, const float* mask, float* f1, float* f2, float* out, int transposed, int B, int G, int F1,
+                 int F2, int A, void* stream);
 size_t rn_f_phi_bwd_ws_bytes(int B, int F1, int F2, int A);
 int rn_f_phi_bwd(const float* gout, const float* out, const float* f2, const float* f1, const float* xg, const float* W1,
                  const float* W2, const float* W3, const float* mask, float* dW1, float* db1, float* dW2, float* db2,

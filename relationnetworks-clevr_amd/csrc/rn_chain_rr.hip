@@ -171,12 +171,20 @@ extern "C" int rn_pack_matrix_frag(const float* src, long sr, long sc, int R, in
 
 // all fragment-major images of a step in ONE launch (7 per training step: 4 forward + 3 transposed)
 namespace {
-constexpr int RR_MAXPACK = 8;
+constexpr int RR_MAXPACK = 12;
 struct PackMany { const float* src[RR_MAXPACK]; long sr[RR_MAXPACK], sc[RR_MAXPACK]; int R[RR_MAXPACK], C[RR_MAXPACK], natural[RR_MAXPACK]; bf16* dst[RR_MAXPACK]; };
 }  // namespace
 __global__ __launch_bounds__(256) void pack_frag_many_kernel(PackMany a) {
   const int i = blockIdx.y;
   const int g = blockIdx.x * 256 + threadIdx.x;
+  if (a.natural[i] == 2) {                               // fp32 transpose: dst[c][r] = src[r][c]
+    const int R = a.R[i], Cc = a.C[i];
+    if (g < R * Cc) {
+      const int c = g / R, r = g - c * R;
+      reinterpret_cast<float*>(a.dst[i])[g] = a.src[i][(long)r * a.sr[i] + (long)c * a.sc[i]];
+    }
+    return;
+  }
   const int e = g & 7, lane = (g >> 3) & 63, ks = (g >> 9) & 15, ob = g >> 13;
   const int h = lane >> 5, m = 32 * ob + (lane & 31);
   const int kidx = a.natural[i] ? 16 * ks + 8 * h + e : 32 * (ks >> 1) + 4 * h + 8 * (2 * (ks & 1) + (e >> 2)) + (e & 3);

@@ -148,12 +148,12 @@ __global__ __launch_bounds__(256) void emb_bwd_kernel(const long long* __restric
   __shared__ float red[8][LS_E];
   const int v = blockIdx.x, k = threadIdx.x & 31, seg = threadIdx.x >> 5;
   float a = 0.f;
-  const int P = B * T;
-  for (int p = seg; p < P; p += 8) {
-    const int t = p / B, b = p - t * B;
-    long long tok = idx[(long)b * T + t];
-    tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
-    if (tok == v) a += dx[(long)p * LS_E + k];
+  for (int b = seg; b < B; b += 8) {                       // fixed (b, t) order per segment -> deterministic
+    for (int t = 0; t < T; ++t) {
+      long long tok = idx[(long)b * T + t];
+      tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+      if (tok == v) a += dx[((long)t * B + b) * LS_E + k];
+    }
   }
   red[seg][k] = a;
   __syncthreads();

@@ -170,11 +170,26 @@ __device__ __forceinline__ void fp_layer_rows(const float* __restrict__ W, const
     }
   }
 }
-// out[r][j] = sum_i in[r][i] * W[i][j]; thread = column j (coalesced over the workgroup)
+// out[r][j] = sum_i in[r][i] * W[i][j]; thread = column j (coalesced over the workgroup).  16 independent loads are
+// issued before their FMAs: the loop is a chain of L2 round trips otherwise.
 __device__ __forceinline__ void fp_layer_cols(const float* __restrict__ W, const float* in_s, int I, int J, int j, float (&acc)[FP_RB]) {
 #pragma unroll
   for (int r = 0; r < FP_RB; ++r) acc[r] = 0.f;
-  for (int i = 0; i < I; ++i) {
+  int i = 0;
+  for (; i + 16 <= I; i += 16) {
+    float w[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) w[u] = W[(long)(i + u) * J + j];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+#pragma unroll
+      for (int r = 0; r < FP_RB; ++r) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(in_s + r * FP_MAXW + i + u);
+        acc[r] = fmaf(x[3], w[u + 3], fmaf(x[2], w[u + 2], fmaf(x[1], w[u + 1], fmaf(x[0], w[u], acc[r]))));
+      }
+    }
+  }
+  for (; i < I; ++i) {
     const float w = W[(long)i * J + j];
 #pragma unroll
     for (int r = 0; r < FP_RB; ++r) acc[r] = fmaf(in_s[r * FP_MAXW + i], w, acc[r]);
@@ -182,12 +197,24 @@ __device__ __forceinline__ void fp_layer_cols(const float* __restrict__ W, const
 }
 }  // namespace
 
+// TR: W_l are given TRANSPOSED, (in, out) row-major -- the thread-per-output-feature walk is then coalesced
+template <bool TR>
 __global__ __launch_bounds__(256) void f_phi_fwd_kernel(const float* __restrict__ xg, const float* __restrict__ W1,
                                                         const float* __restrict__ b1, const float* __restrict__ W2,
                                                         const float* __restrict__ b2, const float* __restrict__ W3,
                                                         const float* __restrict__ b3, const float* __restrict__ mask,
                                                         float* __restrict__ f1, float* __restrict__ f2, float* __restrict__ out,
                                                         int B, int G, int F1, int F2, int A) {
+  auto layer = [&](const float* W, const float* bias, const float* in_s, int K, int N, int f, float (&acc)[FP_RB]) {
+    if constexpr (TR) {
+      fp_layer_cols(W, in_s, K, N, f, acc);
+      const float b = bias[f];
+#pragma unroll
+      for (int r = 0; r < FP_RB; ++r) acc[r] += b;
+    } else {
+      fp_layer_rows(W, bias, in_s, K, f, acc);
+    }
+  };
   __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW];
   const int t = threadIdx.x, r0 = blockIdx.x * FP_RB;
   for (int c = t; c < FP_RB * G; c += 256) {
@@ -197,7 +224,7 @@ __global__ __launch_bounds__(256) void f_phi_fwd_kernel(const float* __restrict_
   __syncthreads();
   float acc[FP_RB];
   for (int f = t; f < F1; f += 256) {
-    fp_layer_rows(W1, b1, sa, G, f, acc);
+    layer(W1, b1, sa, G, F1, f, acc);
 #pragma unroll
     for (int r = 0; r < FP_RB; ++r) {
       const float v = fmaxf(acc[r], 0.f);
@@ -207,7 +234,7 @@ __global__ __launch_bounds__(256) void f_phi_fwd_kernel(const float* __restrict_
   }
   __syncthreads();
   for (int f = t; f < F2; f += 256) {
-    fp_layer_rows(W2, b2, sb, F1, f, acc);
+    layer(W2, b2, sb, F1, F2, f, acc);
 #pragma unroll
     for (int r = 0; r < FP_RB; ++r) {
       const bool ok = r0 + r < B;
@@ -219,7 +246,7 @@ __global__ __launch_bounds__(256) void f_phi_fwd_kernel(const float* __restrict_
   }
   __syncthreads();
   for (int f = t; f < A; f += 256) {
-    fp_layer_rows(W3, b3, sa, F2, f, acc);
+    layer(W3, b3, sa, F2, A, f, acc);
 #pragma unroll
     for (int r = 0; r < FP_RB; ++r) sb[r * FP_MAXW + f] = acc[r];
   }
@@ -331,12 +358,13 @@ static int fp_check(const char* who, int B, int G, int F1, int F2, int A) {
 }
 
 extern "C" int rn_f_phi_fwd(const float* xg, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
-                            const float* b3, const float* mask, float* f1, float* f2, float* out, int B, int G, int F1, int F2,
-                            int A, void* stream) {
+                            const float* b3, const float* mask, float* f1, float* f2, float* out, int transposed, int B, int G, int F1,
+                            int F2, int A, void* stream) {
   RN_CHECK_ARG(xg && W1 && b1 && W2 && b2 && W3 && b3 && f1 && f2 && out, "rn_f_phi_fwd: NULL pointer");
   if (int rc = fp_check("rn_f_phi_fwd", B, G, F1, F2, A)) return rc;
   RN_CHECK_ARG(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)W3) % 16 == 0, "rn_f_phi_fwd: weights must be 16-byte aligned");
-  f_phi_fwd_kernel<<<cdiv(B, FP_RB), 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A);
+  if (transposed) f_phi_fwd_kernel<true><<<cdiv(B, FP_RB), 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A);
+  else f_phi_fwd_kernel<false><<<cdiv(B, FP_RB), 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A);
   RN_LAUNCH_CHECK("rn_f_phi_fwd");
   return 0;
 }

@@ -54,13 +54,14 @@ class PackedWeights:
         self.key = None
         self.fwd, self.bwd = [], []
         self.hi, self.lo = [], []                  # fp16 split copies for the f16s forward
+        self.fT = None                             # transposed fp32 copies of the f_phi weights
         self.frag = []                             # fragment-major copies for the register-resident chains:
         self.fragT = []                            #   forward W_l, backward step s -> W_{L-1-s}^T
 
-    def get(self, plan: LayerPlan, g_w, code, split=False, bwd_images=True, rr_only=False):
+    def get(self, plan: LayerPlan, g_w, code, split=False, bwd_images=True, rr_only=False, f_w=None):
         """rr_only: the call is known to run the register-resident chains in both directions -- only their
         fragment-major images are packed (the row-major copies feed the other kernels)."""
-        key = (code, split, bwd_images, rr_only, tuple((w.data_ptr(), w._version) for w in g_w))
+        key = (code, split, bwd_images, rr_only, tuple((w.data_ptr(), w._version) for w in list(g_w) + list(f_w or ())))
         # while a hipGraph is being captured the pack kernels must be part of it (a replay sees
         # new weights every step), so the cache is bypassed
         if key == self.key and not torch.cuda.is_current_stream_capturing():
@@ -104,6 +105,13 @@ class PackedWeights:
             for st, wf in enumerate(self.fragT):
                 wc = g_w[plan.L - 1 - st].detach().contiguous()
                 frag_jobs.append((wc, 1, wc.shape[1], 256, 256, wf, st == 0))      # element (in, out) = W[out][in]
+        # f_phi weights as (in, out) fp32 copies: the forward kernel's thread-per-output-feature walk is then coalesced
+        self.fT = None
+        if f_w is not None and all(max(w.shape) <= 256 for w in f_w):
+            self.fT = [torch.empty(w.shape[1], w.shape[0], dtype=torch.float32, device=dev) for w in f_w]
+            for w, wt in zip(f_w, self.fT):
+                wc = w.detach().contiguous()
+                frag_jobs.append((wc, wc.shape[1], 1, wc.shape[0], wc.shape[1], wt, 2))
         if frag_jobs:
             H.pack_matrix_frag_many(frag_jobs)                                     # one launch for all images
         self.key = key
@@ -248,7 +256,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
     return inputs, cur, None
 
 
-def f_phi_forward(xg, fw, fb, mask):
+def f_phi_forward(xg, fw, fb, mask, wT=None):
     """f_phi + log_softmax (model.py:155-162): fc1 -> relu -> fc2 -> dropout mask -> relu -> fc3 -> log_softmax,
     fp32.  Returns (f1, f2, log_probs)."""
     B, G = xg.shape
@@ -257,7 +265,10 @@ def f_phi_forward(xg, fw, fb, mask):
     f1 = torch.empty(B, F1, dtype=torch.float32, device=dev)
     f2 = torch.empty(B, F2, dtype=torch.float32, device=dev)
     out = torch.empty(B, A, dtype=torch.float32, device=dev)
-    H.f_phi_fwd(xg, fw, fb, mask, f1, f2, out)          # one launch (rn_small.hip)
+    if wT is not None:
+        H.f_phi_fwd(xg, wT, fb, mask, f1, f2, out, transposed=True)      # one launch (rn_small.hip), coalesced weight reads
+    else:
+        H.f_phi_fwd(xg, fw, fb, mask, f1, f2, out)
     return f1, f2, out
 
 
@@ -282,7 +293,7 @@ class RelationalFunction(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         rr_only = (not f16s and rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0 and (n * n) % 32 == 0
                    and os.environ.get("RN_NO_RR_MASKS", "0") != "1")
-        wfwd, wbwd = packed.get(plan, g_w, code, split=f16s, bwd_images=need_grad, rr_only=rr_only)
+        wfwd, wbwd = packed.get(plan, g_w, code, split=f16s, bwd_images=need_grad, rr_only=rr_only, f_w=f_w)
         gb = [b.detach().contiguous() for b in g_b]
         inputs, HL, xg = g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad,
                                          split=(packed.hi, packed.lo) if f16s else None,
@@ -296,7 +307,7 @@ class RelationalFunction(torch.autograd.Function):
         F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
         if mask is not None:
             mask = mask.float().contiguous()
-        f1, f2, out = f_phi_forward(xg, fw, fb, mask)
+        f1, f2, out = f_phi_forward(xg, fw, fb, mask, wT=packed.fT)
         if need_grad:
             ctx.plan, ctx.code, ctx.dims = plan, code, (B, n, k, Q, M, G, F1, F2, A)
             ctx.inputs, ctx.HL, ctx.wbwd = inputs, HL, wbwd

@@ -51,7 +51,7 @@ SIGNATURES = {
     "rn_log_softmax_fwd": (_I, [_P, _P, _I, _I, _P]),
     "rn_log_softmax_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "rn_colsum_f32": (_I, [_P, _L, _P, _I, _I, _P]),
-    "rn_f_phi_fwd": (_I, [_P] * 11 + [_I] * 5 + [_P]),
+    "rn_f_phi_fwd": (_I, [_P] * 11 + [_I] * 6 + [_P]),
     "rn_f_phi_bwd_ws_bytes": (_Z, [_I, _I, _I, _I]),
     "rn_f_phi_bwd": (_I, [_P] * 17 + [_I] * 5 + [_P]),
     "rn_lstm_fwd": (_I, [_P] * 10 + [_I] * 5 + [_P]),
@@ -378,12 +378,13 @@ def bn_relu_bwd(dy, x, dx, gamma, beta, mean, invstd, dgamma, dbeta):
 
 # ------------------------------------------------------------------ fused f_phi
 @_timed("f_phi")
-def f_phi_fwd(xg, fw, fb, mask, f1, f2, out):
+def f_phi_fwd(xg, fw, fb, mask, f1, f2, out, transposed=False):
+    """fw: the three weights as (out, in), or with transposed=True their (in, out) copies."""
     B, G = xg.shape
-    F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
+    F1, F2, A = (fw[0].shape[1], fw[1].shape[1], fw[2].shape[1]) if transposed else (fw[0].shape[0], fw[1].shape[0], fw[2].shape[0])
     _check(load().rn_f_phi_fwd(xg.data_ptr(), fw[0].data_ptr(), fb[0].data_ptr(), fw[1].data_ptr(), fb[1].data_ptr(), fw[2].data_ptr(),
-                               fb[2].data_ptr(), _ptr(mask), f1.data_ptr(), f2.data_ptr(), out.data_ptr(), B, G, F1, F2, A, _stream()),
-           "rn_f_phi_fwd")
+                               fb[2].data_ptr(), _ptr(mask), f1.data_ptr(), f2.data_ptr(), out.data_ptr(), int(transposed), B, G, F1, F2, A,
+                               _stream()), "rn_f_phi_fwd")
 
 
 @_timed("f_phi")
