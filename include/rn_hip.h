@@ -122,6 +122,13 @@ size_t rn_g_chain_rr_mask_bytes(int M);
 int rn_g_chain_fwd_rr(const void* P, int ldp, const void* const* Wf, const float* const* bias, void* const* H,
                       void* const* mask, int K0, float* xg_part, int M, int L, int G, void* stream);
 
+/* f16s forward in the register-resident mapping: P16 (M, ldp) fp16; Whi/Wlo[l]: fragment-major fp16 images of the
+ * hi / lo halves of W_l (rn_pack_matrix_frag_many modes 4|natural and 8|natural); every product runs against both
+ * (fp32 accumulate), fp16 activations saturate at 65504.  H (bf16 copies) / mask / xg_part as rn_g_chain_fwd_rr;
+ * supported output sets: inference (no H), training (H[0..2] + masks + xg_part), all four H without masks. */
+int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, const void* const* Wlo, const float* const* bias,
+                           void* const* H, void* const* mask, int K0, float* xg_part, int M, int L, int G, void* stream);
+
 /* Backward (pair-sum broadcast + ReLU gates + the three dgrad steps):
  *   dZ[0]   = dxg[b] * gate_3                         b = question of the pair row
  *   dZ[s+1] = (dZ[s] @ W_{3-s}) * gate_{2-s}          s = 0, 1, 2
@@ -138,8 +145,9 @@ int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* con
  * src: fp32, element (r, c) at src[r * sr + c * sc] (model.py:96-99 nn.Linear weight: sr = in, sc = 1). */
 int rn_pack_matrix_frag(const float* src, long sr, long sc, int R, int C, void* dst, int natural, void* stream);
 
-/* `count` (<= 12) rn_pack_matrix_frag calls in one launch; all arguments are HOST arrays of `count` entries.
- * natural[i] == 2 selects a plain fp32 TRANSPOSE instead: dst (C, R) fp32 row-major = src^T (the f_phi weights). */
+/* `count` (<= 16) rn_pack_matrix_frag calls in one launch; all arguments are HOST arrays of `count` entries.
+ * natural[i] == 2 selects a plain fp32 TRANSPOSE instead: dst (C, R) fp32 row-major = src^T (the f_phi weights);
+ * natural[i] == 4 | n / 8 | n (n = 0, 1) write the fp16 hi = fp16(w) / lo = fp16(w - hi) image in K order n. */
 int rn_pack_matrix_frag_many(const float* const* src, const long* sr, const long* sc, const int* R, const int* C,
                              void* const* dst, const int* natural, int count, void* stream);
 
@@ -224,10 +232,11 @@ int rn_f_phi_bwd(const float* gout, const float* out, const float* f2, const flo
  * (amsgrad=False, coupled weight_decay) in two launches.  g / m / v: flat fp32 buffers of n elements; `chunks`:
  * DEVICE array of nchunks records {float* param; long flat_off; int count; int pad} (count <= rn_clip_adam_chunk(),
  * a chunk never crosses a parameter) mapping flat ranges to the parameter tensors; step: 1-based update count;
- * ws: rn_clip_adam_ws_bytes() bytes; norm_out: optional device float receiving the gradient norm. */
+ * grad_scale multiplies the gradient first (1 / world after a SUM all-reduce; 1 otherwise);
+ * ws: rn_clip_adam_ws_bytes() bytes; norm_out: optional device float receiving the (scaled) gradient norm. */
 int rn_clip_adam_chunk(void);
 size_t rn_clip_adam_ws_bytes(void);
-int rn_clip_adam_step(const void* chunks, int nchunks, float* g, float* m, float* v, long n, void* ws, float max_norm, float lr,
+int rn_clip_adam_step(const void* chunks, int nchunks, float* g, float* m, float* v, long n, void* ws, float grad_scale, float max_norm, float lr,
                       float beta1, float beta2, float eps, float weight_decay, int step, float* norm_out, void* stream);
 
 /* Question encoder (reference model.py:39-58): embedding lookup + 1-layer LSTM (E = 32 -> H = 128, gate order

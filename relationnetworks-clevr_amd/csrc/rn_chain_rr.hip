@@ -116,6 +116,19 @@ struct RRCore {
                  : "v"(lane16), "s"(ub), "s"(dst)
                  : "memory");
   }
+  // the same two operations with explicit geometry (the f16s kernel: 32-KB stages = hi | lo images)
+  __device__ __forceinline__ void dma_at(const void* uniform_src, int lds_off) const {
+    unsigned z = 0;
+    asm volatile("" : "+s"(z));
+    const unsigned char* ub = reinterpret_cast<const unsigned char*>(uniform_src) + z;
+    const unsigned dst = (unsigned)(size_t)(lds_u8*)lds + (z + lds_off);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane16), "s"(ub), "s"(dst)
+                 : "memory");
+  }
+  __device__ __forceinline__ Frag rd_at(int abs) const { return *reinterpret_cast<lds_frag*>(rbase[abs >> 16] + (abs & 0xffff)); }
   __device__ __forceinline__ Frag rd_frag(int slot, int ks) const {
     const int abs = RR_OFF_RING + slot * RR_STAGE + ks * 1024, r = abs >> 16;
     return *reinterpret_cast<lds_frag*>(rbase[r] + (abs & 0xffff));
@@ -171,7 +184,7 @@ extern "C" int rn_pack_matrix_frag(const float* src, long sr, long sc, int R, in
 
 // all fragment-major images of a step in ONE launch (7 per training step: 4 forward + 3 transposed)
 namespace {
-constexpr int RR_MAXPACK = 12;
+constexpr int RR_MAXPACK = 16;
 struct PackMany { const float* src[RR_MAXPACK]; long sr[RR_MAXPACK], sc[RR_MAXPACK]; int R[RR_MAXPACK], C[RR_MAXPACK], natural[RR_MAXPACK]; bf16* dst[RR_MAXPACK]; };
 }  // namespace
 __global__ __launch_bounds__(256) void pack_frag_many_kernel(PackMany a) {
@@ -187,9 +200,15 @@ __global__ __launch_bounds__(256) void pack_frag_many_kernel(PackMany a) {
   }
   const int e = g & 7, lane = (g >> 3) & 63, ks = (g >> 9) & 15, ob = g >> 13;
   const int h = lane >> 5, m = 32 * ob + (lane & 31);
-  const int kidx = a.natural[i] ? 16 * ks + 8 * h + e : 32 * (ks >> 1) + 4 * h + 8 * (2 * (ks & 1) + (e >> 2)) + (e & 3);
+  const int mode = a.natural[i];
+  const int kidx = (mode & 1) ? 16 * ks + 8 * h + e : 32 * (ks >> 1) + 4 * h + 8 * (2 * (ks & 1) + (e >> 2)) + (e & 3);
   const float v = (m < a.R[i] && kidx < a.C[i]) ? a.src[i][(long)m * a.sr[i] + (long)kidx * a.sc[i]] : 0.f;
-  a.dst[i][g] = (bf16)v;
+  if (mode & 12) {                                       // fp16 split halves of the f16s mode: hi = fp16(v), lo = fp16(v - hi)
+    const f16 hi = (f16)v;
+    reinterpret_cast<f16*>(a.dst[i])[g] = (mode & 4) ? hi : (f16)(v - (float)hi);
+  } else {
+    a.dst[i][g] = (bf16)v;
+  }
 }
 
 extern "C" int rn_pack_matrix_frag_many(const float* const* src, const long* sr, const long* sc, const int* R, const int* C,
@@ -463,6 +482,266 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
   if constexpr (MASK) asm volatile("s_dcache_wb" ::: "memory");
 }
 
+// ================================================================================================ forward, f16s
+// The parity-grade arithmetic of rn_g_chain_fwd_f16s in the register-resident mapping: fp16 activations in the operand
+// registers, every product twice -- against the hi and the lo half of the fp16-split weights (fp32 accumulate) -- so
+// the weight rounding error that keeps single-pass bf16 at ~1e-2 of the fp32 reference drops out.  Same structure as
+// g_chain_rr_kernel; a stage is hi | lo = 32 KB (4 ring slots, 3 stages ahead), the stored activation copies and the
+// masks are the bf16 kernel's (the backward pass is shared).
+namespace {
+constexpr int F_STAGE = 32 * 1024, F_NSLOT = 4, F_LA = 3, F_DPW = 32 / RR_NW, F_RDK = 2;
+static_assert(F_NSLOT * F_STAGE == RR_NSLOT * RR_STAGE, "same ring bytes");
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+struct RRArgsF {
+  const f16* Whi[RR_L];
+  const f16* Wlo[RR_L];
+  const float* bias[RR_L];
+  bf16* out[RR_L];
+  u64* mask[RR_L];
+};
+__device__ __forceinline__ unsigned relu_pack_f16(float a, float b) {     // saturate instead of overflowing fp16 to inf
+  const f32x2 f = {fminf(a, 65504.f), fminf(b, 65504.f)};
+  s16x2 x = __builtin_bit_cast(s16x2, __builtin_convertvector(f, f16x2));
+  const s16x2 z = {0, 0};
+  x = __builtin_elementwise_max(x, z);
+  return __builtin_bit_cast(unsigned, x);
+}
+template <int NK0, bool STORE, bool ST3, bool XG>
+struct F16Vm {
+  static constexpr int PF_PER = (NK0 + 7) / 8;
+  static constexpr int ops(int sidx) {
+    int k = F_DPW;
+    if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += 2;
+    if ((sidx >> 3) == RR_L - 1)
+      for (int c = 0; c < PF_PER; ++c) k += ((sidx & 7) * PF_PER + c < NK0) ? 1 : 0;
+    return k;
+  }
+  static constexpr int tail() { return (STORE && ST3 ? 4 : 0) + (XG ? 8 : 0); }
+  // weights of stage s+1 were requested in stage s+1-F_LA: younger are the stages s-(F_LA-2) .. s-1
+  static constexpr int younger(int sidx, bool first) {
+    int k = 0;
+    for (int t = sidx - (F_LA - 2); t < sidx; ++t) k += t >= 0 ? ops(t) : (first ? 0 : ops(t + 8 * RR_L));
+    if (sidx < F_LA - 2 && !first) k += tail();
+    if (first && sidx <= F_LA - 2) k += F_DPW * (F_LA - 2 - sidx) + NK0;
+    return k < 63 ? k : 63;
+  }
+};
+}  // namespace
+
+template <int NK0, bool STORE, bool ST3, bool MASK, bool XG>
+__global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __restrict__ P, int ldp, RRArgsF a,
+                                                                float* __restrict__ xg_part, int ntiles) {
+  typedef F16Vm<NK0, STORE, ST3, XG> Vm;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
+  RRCore k;
+  k.init(lds);
+  const int t = threadIdx.x, lane = k.lane, w = k.w, n = k.n, h = k.h;
+  unsigned char* const stg = lds + RR_OFF_STG + w * RR_STG;
+  float* const bias_s = reinterpret_cast<float*>(lds + RR_OFF_BIAS);
+  const unsigned prow_off = (unsigned)(n * ldp + 8 * h) * 2u;
+  auto load_row_frag = [&](long m0w, int ks) -> Frag {
+    gbl_cu8* base = (gbl_cu8*)reinterpret_cast<const unsigned char*>(P + m0w * ldp);
+    asm volatile("" : "+s"(base));
+    return *reinterpret_cast<__attribute__((address_space(1))) const Frag*>(base + prow_off + 32 * ks);
+  };
+  // piece q = 4 w + i of a stage: image q / 16 (hi, lo) -- wave-uniform: waves 0..3 fetch hi, 4..7 lo
+  auto dma_piece = [&](int l2, int ob2, int slot, int i) {
+    const int q = F_DPW * w + i;
+    const f16* img = (q >> 4) ? a.Wlo[l2] : a.Whi[l2];
+    k.dma_at(reinterpret_cast<const unsigned char*>(img) + ob2 * RR_STAGE + (q & 15) * 1024, RR_OFF_RING + slot * F_STAGE + q * 1024);
+  };
+  auto rd = [&](int slot, int ks, int p) -> Frag { return k.rd_at(RR_OFF_RING + slot * F_STAGE + p * RR_STAGE + ks * 1024); };
+
+  Frag actA[16], actB[16], ring[F_RDK][2];
+  f32x16 acc[2];
+  u32x4 co[2];
+  f32x16 cinit;
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+#pragma unroll
+  for (int s = 0; s < F_LA; ++s)
+#pragma unroll
+    for (int i = 0; i < F_DPW; ++i) dma_piece(0, s, s, i);
+#pragma unroll
+  for (int ks = 0; ks < NK0; ++ks) actA[ks] = load_row_frag((long)tile * RR_TM + RR_WR * w, ks);
+  if (t < RR_G) {
+#pragma unroll
+    for (int l = 0; l < RR_L; ++l) bias_s[l * RR_G + t] = a.bias[l][t];
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < F_RDK; ++r)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) ring[r][p] = rd(0, r, p);
+  bool first = true;
+
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long m0w = (long)tile * RR_TM + RR_WR * w;
+    const long wt = (long)tile * RR_NW + w;
+    const int tnext = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
+    const long m0n = (long)tnext * RR_TM + RR_WR * w;
+    float xs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xs[i] = 0.f;
+
+    auto bias_read = [&](int l, int ob) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + l * RR_G + 32 * ob + 8 * j + 4 * h);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cinit[4 * j + r] = b[r];
+      }
+    };
+    auto mask_out = [&](int pl, int pob, int j, float x0, float x1, float x2, float x3) {
+      if constexpr (MASK) mask_store4(a.mask[pl] + (wt * 8 + pob) * 16 + 4 * j, __ballot(x0 > 0.f), __ballot(x1 > 0.f),
+                                      __ballot(x2 > 0.f), __ballot(x3 > 0.f));
+    };
+    // phases of group j: 0 masks, 1 fp16 operand of the next layer, 2 bf16 copy for HBM, 3 staging write
+    auto epi_group = [&](int pl, int pob, int j, int ph, Frag* dst, u32x2 (&pk)[4]) {
+      const f32x16& c = acc[pob & 1];
+      if (ph == 0) mask_out(pl, pob, j, c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]);
+      if (ph == 1 && dst) {
+        dst[2 * pob + (j >> 1)][(j & 1) * 2 + 0] = relu_pack_f16(c[4 * j + 0], c[4 * j + 1]);
+        dst[2 * pob + (j >> 1)][(j & 1) * 2 + 1] = relu_pack_f16(c[4 * j + 2], c[4 * j + 3]);
+      }
+      if (ph == 2 && STORE) {
+        pk[j][0] = relu_pack_bf16(c[4 * j + 0], c[4 * j + 1]);
+        pk[j][1] = relu_pack_bf16(c[4 * j + 2], c[4 * j + 3]);
+      }
+      if (ph == 3 && STORE) *reinterpret_cast<u32x2*>(stg + n * RR_SRS + 16 * j + 8 * h) = pk[j];
+    };
+    auto co_read = [&]() {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) co[q] = *reinterpret_cast<const u32x4*>(stg + (16 * q + (lane >> 2)) * RR_SRS + (lane & 3) * 16);
+    };
+    const unsigned orow_off = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
+    auto co_store = [&](int cl, int cob, int q) {
+      gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.out[cl] + m0w * RR_G);
+      asm volatile("" : "+s"(base));
+      __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2));
+    };
+    float b3 = 0.f;
+    auto epi3_group = [&](int pob, int j, int ph, f32x4 (&v)[4]) {
+      if (ph == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[j][r] = fmaxf(acc[pob & 1][4 * j + r] + b3, 0.f);
+      }
+      if (ph == 1) {
+        if constexpr (XG) xs[pob] += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        mask_out(RR_L - 1, pob, j, v[j][0], v[j][1], v[j][2], v[j][3]);
+      }
+      if (ph == 2) {
+        if constexpr (STORE && ST3) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(stg + (8 * j + 4 * h + r) * RR_SRS + n * 2) = (bf16)v[j][r];
+        }
+      }
+    };
+    auto stage = [&](auto lc, auto obc, Frag (&in)[16], Frag (&out)[16]) {
+      constexpr int l = decltype(lc)::value, ob = decltype(obc)::value;
+      constexpr int NK = (l == 0) ? NK0 : 16;
+      constexpr int CPG = 2 * NK / 4;                                  // MFMA gaps per epilogue group (8 / 6)
+      constexpr int sidx = l * 8 + ob;
+      constexpr bool has_prev = sidx > 0;
+      constexpr int pl = ob ? l : l - 1, pob = ob ? ob - 1 : 7;
+      constexpr int cl = (sidx - 2) >> 3, cob = (sidx - 2) & 7;
+      constexpr bool has_co = STORE && sidx >= 2 && (cl < RR_L - 1 || ST3);
+      constexpr int didx = sidx + F_LA;
+      constexpr int dl = (didx >> 3) & 3, dob = didx & 7;
+      constexpr int slot = ob & 3, nslot = (ob + 1) & 3, dslot = (ob + F_LA) & 3;
+      if (l < RR_L - 1) bias_read(l, ob);
+      if (has_prev && pl == RR_L - 1) b3 = bias_s[pl * RR_G + 32 * pob + n];
+      if (Vm::younger(sidx, true) != Vm::younger(sidx, false)) {
+        if (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Vm::younger(sidx, true)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Vm::younger(sidx, false)) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Vm::younger(sidx, false)) : "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (has_co) co_read();
+      __builtin_amdgcn_sched_barrier(0);
+      Frag* dst = nullptr;
+      if (has_prev && pl < RR_L - 1) dst = ob ? out : in;
+      f32x4 v[4];
+      u32x2 pk[4];
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int c = 2 * ks + p;
+          const f16x8 fw = __builtin_bit_cast(f16x8, ring[ks % F_RDK][p]), fx = __builtin_bit_cast(f16x8, in[ks]);
+          const f16x8 fa = (l == RR_L - 1) ? fx : fw, fb = (l == RR_L - 1) ? fw : fx;
+          if (c == 0 && l < RR_L - 1) {
+            acc[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, cinit, 0, 0, 0);
+          } else if (c == 0) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, z, 0, 0, 0);
+          } else {
+            acc[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[ob & 1], 0, 0, 0);
+          }
+          {
+            const int f = ks + F_RDK;
+            if (f < NK) ring[ks % F_RDK][p] = rd(slot, f, p);
+            else ring[ks % F_RDK][p] = rd(nslot, f - NK, p);
+          }
+          if ((c & 1) && (c >> 1) < F_DPW) dma_piece(dl, dob, dslot, c >> 1);
+          if (has_prev) {
+            const int j = c / CPG, ph = c % CPG;
+            if (pl == RR_L - 1) {
+              if (ph < 3) epi3_group(pob, j, ph, v);
+            } else if (ph < 4) {
+              epi_group(pl, pob, j, ph, dst, pk);
+            }
+          }
+          if (has_co && (c == 4 || c == 8)) co_store(cl, cob, (c >> 2) - 1);
+          if (l == RR_L - 1 && (c & 1) == 0 && (c >> 1) < Vm::PF_PER) {
+            const int i = ob * Vm::PF_PER + (c >> 1);
+            if (i < NK0) out[i] = load_row_frag(m0n, i);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    RN_LAYER(0, actA, actB);
+    RN_LAYER(1, actB, actA);
+    RN_LAYER(2, actA, actB);
+    RN_LAYER(3, actB, actA);
+    first = false;
+    {
+      f32x4 v[4];
+      if constexpr (STORE && ST3) {
+        co_read();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) co_store(RR_L - 1, 6, q);
+      }
+      b3 = bias_s[(RR_L - 1) * RR_G + 32 * 7 + n];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        epi3_group(7, j, 0, v);
+        epi3_group(7, j, 1, v);
+        epi3_group(7, j, 2, v);
+      }
+      if constexpr (STORE && ST3) {
+        co_read();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) co_store(RR_L - 1, 7, q);
+      }
+      if constexpr (XG) {
+#pragma unroll
+        for (int ob = 0; ob < 8; ++ob) {
+          const float tot = xs[ob] + __shfl_xor(xs[ob], 32);
+          if (h == 0) xg_part[((long)tile * RR_NW + w) * RR_G + 32 * ob + n] = tot;
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if constexpr (MASK) asm volatile("s_dcache_wb" ::: "memory");
+}
+
 // ================================================================================================== backward
 // dZ[0] = dxg[b] * (H_3 > 0);  dZ[s+1] = (dZ[s] @ W_{3-s}) * (H_{2-s} > 0), s = 0..2 -- the ReLU gates come from the
 // forward kernel's lane masks (32 bytes per pair row and layer instead of a 512-byte activation row).
@@ -698,6 +977,54 @@ extern "C" int rn_g_chain_fwd_rr(const void* P, int ldp, const void* const* Wf, 
   if (K0 == 192) rr_fwd_launch<12>(grid, (hipStream_t)stream, (const bf16*)P, ldp, a, xg_part, ntiles, nh > 0, nh == RR_L, nm > 0);
   else rr_fwd_launch<16>(grid, (hipStream_t)stream, (const bf16*)P, ldp, a, xg_part, ntiles, nh > 0, nh == RR_L, nm > 0);
   RN_LAUNCH_CHECK("rn_g_chain_fwd_rr");
+  return 0;
+}
+
+extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, const void* const* Wlo, const float* const* bias,
+                                      void* const* H, void* const* mask, int K0, float* xg_part, int M, int L, int G, void* stream) {
+  RN_CHECK_ARG(P16 && Whi && Wlo && bias && M > 0, "rn_g_chain_fwd_rr_f16s: bad pointer/size");
+  RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_fwd_rr_f16s: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
+  RN_CHECK_ARG(M % RR_TM == 0, "rn_g_chain_fwd_rr_f16s: M=%d must be a multiple of %d", M, RR_TM);
+  RN_CHECK_ARG(K0 == 192 || K0 == 256, "rn_g_chain_fwd_rr_f16s: layer-0 reduction length %d unsupported (192 or 256)", K0);
+  RN_CHECK_ARG(ldp % 8 == 0 && ldp >= K0 && ((uintptr_t)P16 % 16 == 0), "rn_g_chain_fwd_rr_f16s: bad P layout");
+  RRArgsF a;
+  memset(&a, 0, sizeof(a));
+  int nh = 0, nm = 0;
+  for (int l = 0; l < RR_L; ++l) {
+    RN_CHECK_ARG(Whi[l] && Wlo[l] && bias[l], "rn_g_chain_fwd_rr_f16s: layer %d weight/bias is NULL", l);
+    RN_CHECK_ARG(((uintptr_t)Whi[l] | (uintptr_t)Wlo[l] | (uintptr_t)bias[l] | (uintptr_t)(H ? H[l] : nullptr) | (uintptr_t)(mask ? mask[l] : nullptr)) % 16 == 0,
+                 "rn_g_chain_fwd_rr_f16s: layer %d pointers must be 16-byte aligned", l);
+    a.Whi[l] = (const f16*)Whi[l];
+    a.Wlo[l] = (const f16*)Wlo[l];
+    a.bias[l] = bias[l];
+    a.out[l] = H ? (bf16*)H[l] : nullptr;
+    a.mask[l] = mask ? (u64*)mask[l] : nullptr;
+    nh += a.out[l] != nullptr;
+    nm += a.mask[l] != nullptr;
+  }
+  const bool h012 = nh == 3 && !a.out[RR_L - 1] && nm == RR_L;
+  RN_CHECK_ARG(nh == 0 || nh == RR_L || h012, "rn_g_chain_fwd_rr_f16s: H must hold none, all, or (with masks) all but the last activation");
+  RN_CHECK_ARG(nm == 0 || (nm == RR_L && nh >= 3), "rn_g_chain_fwd_rr_f16s: masks come as a full set together with the stored activations");
+  RN_CHECK_ARG(nh || xg_part, "rn_g_chain_fwd_rr_f16s: nothing to compute (no H, no xg_part)");
+  RN_CHECK_ARG(nh == 0 || h012 || (nh == RR_L && nm == 0), "rn_g_chain_fwd_rr_f16s: supported outputs: inference, training (H_0..2 + masks), all four H");
+  const int ntiles = M / RR_TM;
+  const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
+  hipStream_t s = (hipStream_t)stream;
+  const f16* Pp = (const f16*)P16;
+#define RN_GO(NK0_, ST, S3, MK, XG_) g_chain_rr_f16s_kernel<NK0_, ST, S3, MK, XG_><<<grid, RR_NT, 0, s>>>(Pp, ldp, a, xg_part, ntiles)
+#define RN_SEL(NK0_)                                                        \
+  do {                                                                      \
+    if (nh == 0) RN_GO(NK0_, false, false, false, true);                    \
+    else if (h012 && xg_part) RN_GO(NK0_, true, false, true, true);         \
+    else if (h012) { rn_set_error("rn_g_chain_fwd_rr_f16s: training output set needs xg_part"); return -1; } \
+    else if (xg_part) RN_GO(NK0_, true, true, false, true);                 \
+    else RN_GO(NK0_, true, true, false, false);                             \
+  } while (0)
+  if (K0 == 192) RN_SEL(12);
+  else RN_SEL(16);
+#undef RN_SEL
+#undef RN_GO
+  RN_LAUNCH_CHECK("rn_g_chain_fwd_rr_f16s");
   return 0;
 }
 

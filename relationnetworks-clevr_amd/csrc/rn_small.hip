@@ -413,14 +413,14 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void clip_adam_kernel(const RnAdamChunk* __restrict__ chunks, float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v,
-                                                        const double* __restrict__ partial, int npartial, float max_norm,
-                                                        float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                                        const double* __restrict__ partial, int npartial, float gscale,
+                                                        float max_norm, float lr, float beta1, float beta2, float eps, float wd, float bc1,
                                                         float bc2_sqrt, float* __restrict__ norm_out) {
   __shared__ float coef_s;
   if (threadIdx.x == 0) {
     double s = 0.0;
     for (int i = 0; i < npartial; ++i) s += partial[i];
-    const float total = (float)sqrt(s);
+    const float total = gscale * (float)sqrt(s);           // norm of the SCALED gradient (gscale = 1 / world after a sum all-reduce)
     float c = 1.f;
     if (max_norm > 0.f) {
       c = max_norm / (total + 1e-6f);
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const RnAdamChunk* __res
     if (blockIdx.x == 0 && norm_out) norm_out[0] = total;
   }
   __syncthreads();
-  const float coef = coef_s;
+  const float coef = coef_s * gscale;
   const RnAdamChunk c = chunks[blockIdx.x];
   const float step = lr / bc1;
   for (int i = threadIdx.x; i < c.count; i += 256) {
@@ -450,14 +450,14 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const RnAdamChunk* __res
 extern "C" int rn_clip_adam_chunk(void) { return OPT_CHUNK; }
 extern "C" size_t rn_clip_adam_ws_bytes(void) { return OPT_NB * sizeof(double); }
 
-extern "C" int rn_clip_adam_step(const void* chunks, int nchunks, float* g, float* m, float* v, long n, void* ws, float max_norm,
-                                 float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* norm_out,
+extern "C" int rn_clip_adam_step(const void* chunks, int nchunks, float* g, float* m, float* v, long n, void* ws, float grad_scale,
+                                 float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* norm_out,
                                  void* stream) {
   RN_CHECK_ARG(chunks && nchunks > 0 && g && m && v && n > 0 && ws && step >= 1, "rn_clip_adam_step: bad argument");
   hipStream_t s = (hipStream_t)stream;
   sumsq_partial_kernel<<<OPT_NB, 256, 0, s>>>(g, n, (double*)ws);
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  clip_adam_kernel<<<nchunks, 256, 0, s>>>((const RnAdamChunk*)chunks, g, m, v, (const double*)ws, OPT_NB, max_norm, lr, beta1, beta2,
+  clip_adam_kernel<<<nchunks, 256, 0, s>>>((const RnAdamChunk*)chunks, g, m, v, (const double*)ws, OPT_NB, grad_scale, max_norm, lr, beta1, beta2,
                                            eps, weight_decay, (float)bc1, (float)sqrt(bc2), norm_out);
   RN_LAUNCH_CHECK("rn_clip_adam_step");
   return 0;

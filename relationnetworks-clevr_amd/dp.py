@@ -79,13 +79,17 @@ class FlatGradBucket:
             if g is None or g.untyped_storage().data_ptr() != self.flat.untyped_storage().data_ptr():
                 raise RuntimeError("a .grad left the flat bucket (zero_grad(set_to_none=True) was called?)")
 
-    def all_reduce_mean(self, group=None):
-        """sum over ranks, then scale by 1/world -> gradient of the global-batch mean loss."""
+    def all_reduce_mean(self, group=None, scale=True):
+        """sum over ranks, then scale by 1/world -> gradient of the global-batch mean loss.  scale=False leaves the
+        1/world factor to the caller (the fused clip + Adam kernel applies it); returns that factor."""
         if dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(group)
             if world > 1:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-                self.flat.mul_(1.0 / world)
+                if scale:
+                    self.flat.mul_(1.0 / world)
+                return 1.0 / world
+        return 1.0
 
     def clip_grad_norm_(self, max_norm: float, eps: float = 1e-6):
         """Global L2 clip (train.py:45-46, torch clip_grad_norm semantics) on the flat buffer:
@@ -148,13 +152,13 @@ class FusedClipAdam:
         ids = {id(p) for p in g["params"]}
         return ids == {id(p) for p in bucket.params} and all(p.is_contiguous() for p in bucket.params)
 
-    def step(self, clip_norm):
+    def step(self, clip_norm, grad_scale=1.0):
         if [p.data_ptr() for p in self.bucket.params] != self.ptrs:
             raise RuntimeError("a parameter's storage moved since the trainer was built (load_state_dict copies in place; .data = ... does not)")
         g = self.opt.param_groups[0]
         self.t += 1
         self.H.clip_adam_step(self.chunks, self.nchunks, self.bucket.flat, self.m, self.v, self.ws, clip_norm, g["lr"], g["betas"][0],
-                              g["betas"][1], g["eps"], g["weight_decay"], self.t, self.norm)
+                              g["betas"][1], g["eps"], g["weight_decay"], self.t, self.norm, grad_scale)
         # the kernel wrote the parameters behind autograd's back: bump their version counters (the relational layer
         # keys its packed-weight cache on them)
         torch.autograd.graph.increment_version(self.bucket.params)
@@ -213,10 +217,11 @@ class DataParallelTrainer:
             loss = self._loss
         else:
             loss = self._fwd_bwd(img, qst, label)
-        self.bucket.all_reduce_mean(self.group)
         if self._fused_opt is not None:
-            self._fused_opt.step(self.clip_norm)          # clip + Adam: two launches on the flat gradient
+            gs = self.bucket.all_reduce_mean(self.group, scale=False)
+            self._fused_opt.step(self.clip_norm, gs)      # (1/world) + clip + Adam: two launches on the flat gradient
         else:
+            self.bucket.all_reduce_mean(self.group)
             if self.clip_norm:
                 self.bucket.clip_grad_norm_(self.clip_norm)
             self.opt.step()

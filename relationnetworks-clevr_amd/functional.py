@@ -55,6 +55,7 @@ class PackedWeights:
         self.fwd, self.bwd = [], []
         self.hi, self.lo = [], []                  # fp16 split copies for the f16s forward
         self.fT = None                             # transposed fp32 copies of the f_phi weights
+        self.frag_hi, self.frag_lo = [], []        # fragment-major fp16 hi / lo images (f16s on the register-resident chain)
         self.frag = []                             # fragment-major copies for the register-resident chains:
         self.fragT = []                            #   forward W_l, backward step s -> W_{L-1-s}^T
 
@@ -69,6 +70,7 @@ class PackedWeights:
         dt = H.torch_dtype(code)
         dev = g_w[0].device
         self.fwd, self.bwd, self.hi, self.lo, self.frag, self.fragT = [], [], [], [], [], []
+        self.frag_hi, self.frag_lo = [], []
         rr = rr_chain_ok(plan, code)
         frag_jobs = []
         for l, w in enumerate(g_w):
@@ -83,11 +85,18 @@ class PackedWeights:
                 wp = torch.empty(N, plan.kpad[l], dtype=dt, device=dev)
                 H.pack_matrix(wc, kt, 1, N, kt, wp, code, plan.kpad[l], N)
                 self.fwd.append(wp)
-            if rr:
+            if rr and split:
+                wh = torch.empty(256 * 256, dtype=torch.float16, device=dev)
+                wl = torch.empty(256 * 256, dtype=torch.float16, device=dev)
+                frag_jobs.append((wc, kt, 1, N, kt, wh, 4 | int(l == 0)))
+                frag_jobs.append((wc, kt, 1, N, kt, wl, 8 | int(l == 0)))
+                self.frag_hi.append(wh)
+                self.frag_lo.append(wl)
+            elif rr:
                 wf = torch.empty(256 * 256, dtype=dt, device=dev)
                 frag_jobs.append((wc, kt, 1, N, kt, wf, l == 0))
                 self.frag.append(wf)
-            if split:
+            if split and not (rr and rr_only):
                 hi = torch.empty(N, plan.kpad[l], dtype=torch.float16, device=dev)
                 lo = torch.empty(N, plan.kpad[l], dtype=torch.float16, device=dev)
                 H.pack_matrix_split(wc, kt, 1, N, kt, hi, lo, plan.kpad[l], N)
@@ -180,6 +189,22 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
         if keep_inputs:
             P = torch.empty(M, ld0, dtype=dt, device=dev)
             H.pair_build_fwd(x, q, P, code, B, n, k, Q, ld0)
+        if (wfrag is not None and len(wfrag) == 2 and len(wfrag[0]) == L and rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0
+                and (n * n) % 32 == 0 and os.environ.get("RN_NO_RR_MASKS", "0") != "1"):
+            # register-resident mapping: fp16 operand registers, hi + lo weight fragments; bf16 copies + lane masks for the
+            # (shared, bf16) backward chain
+            R = 32
+            masks = Hs = None
+            if keep_inputs:
+                Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L - 1)] + [None]
+                masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
+            part = torch.empty(M // R, G, dtype=torch.float32, device=dev)
+            H.g_chain_fwd_rr_f16s(P16, ld0, wfrag[0], wfrag[1], g_b, Hs, masks, ld0, part, M, G)
+            xg = torch.empty(B, G, dtype=torch.float32, device=dev)
+            H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // R, G)
+            if Hs is None:
+                return [P, None, None, None], None, xg
+            return [P] + Hs[:-1], RRMasks(masks), xg
         whole = (n * n) % T == 0
         Hs = [torch.empty(M, G, dtype=dt, device=dev) if (keep_inputs or (l == L - 1 and not whole)) else None
               for l in range(L)]
@@ -291,13 +316,13 @@ class RelationalFunction(torch.autograd.Function):
         dev = x.device
         f16s = precision == "f16s"
         need_grad = any(ctx.needs_input_grad)
-        rr_only = (not f16s and rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0 and (n * n) % 32 == 0
+        rr_only = (rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0 and (n * n) % 32 == 0
                    and os.environ.get("RN_NO_RR_MASKS", "0") != "1")
         wfwd, wbwd = packed.get(plan, g_w, code, split=f16s, bwd_images=need_grad, rr_only=rr_only, f_w=f_w)
         gb = [b.detach().contiguous() for b in g_b]
         inputs, HL, xg = g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad,
                                          split=(packed.hi, packed.lo) if f16s else None,
-                                         wfrag=None if f16s else packed.frag)
+                                         wfrag=(packed.frag_hi, packed.frag_lo) if f16s else packed.frag)
         G = plan.widths[-1]
         if xg is None:
             xg = torch.empty(B, G, dtype=torch.float32, device=dev)

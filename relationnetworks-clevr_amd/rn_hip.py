@@ -35,6 +35,7 @@ SIGNATURES = {
     "rn_g_chain_rr_tile": (_I, []),
     "rn_g_chain_rr_mask_bytes": (_Z, [_I]),
     "rn_g_chain_fwd_rr": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "rn_g_chain_fwd_rr_f16s": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pack_matrix_frag": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
     "rn_pack_matrix_frag_many": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
@@ -59,7 +60,7 @@ SIGNATURES = {
     "rn_embedding_bwd": (_I, [_P] * 3 + [_I] * 4 + [_P]),
     "rn_clip_adam_chunk": (_I, []),
     "rn_clip_adam_ws_bytes": (_Z, []),
-    "rn_clip_adam_step": (_I, [_P, _I, _P, _P, _P, _L, _P] + [C.c_float] * 6 + [_I, _P, _P]),
+    "rn_clip_adam_step": (_I, [_P, _I, _P, _P, _P, _L, _P] + [C.c_float] * 7 + [_I, _P, _P]),
     "rn_bn_relu_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_bn_relu_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _I, _I, _P]),
     "rn_bn_relu_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -247,6 +248,18 @@ def g_chain_fwd_rr(P, ldp, Wfs, biases, Hs, masks, K0, xg_part, M, G):
     _check(load().rn_g_chain_fwd_rr(P.data_ptr(), ldp, wp, bp, hp, mp, K0, _ptr(xg_part), M, L, G, _stream()), "rn_g_chain_fwd_rr")
 
 
+@_timed("g_fwd")
+def g_chain_fwd_rr_f16s(P16, ldp, Whis, Wlos, biases, Hs, masks, K0, xg_part, M, G):
+    """f16s forward in the register-resident mapping (fp16 pair matrix, fragment-major hi / lo fp16 weight images)."""
+    L = len(Whis)
+    hp = (C.c_void_p * L)(*[w.data_ptr() for w in Whis])
+    lp = (C.c_void_p * L)(*[w.data_ptr() for w in Wlos])
+    bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
+    op = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
+    mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
+    _check(load().rn_g_chain_fwd_rr_f16s(P16.data_ptr(), ldp, hp, lp, bp, op, mp, K0, _ptr(xg_part), M, L, G, _stream()), "rn_g_chain_fwd_rr_f16s")
+
+
 def g_chain_rr_mask_bytes(M) -> int:
     return load().rn_g_chain_rr_mask_bytes(M)
 
@@ -399,9 +412,9 @@ def f_phi_bwd(gout, out, f2, f1, xg, fw, mask, dW, db, dxg):
 
 
 # ------------------------------------------------------------------ clip + Adam on the flat gradient
-def clip_adam_step(chunks, nchunks, g, m, v, ws, max_norm, lr, beta1, beta2, eps, wd, step, norm_out=None):
+def clip_adam_step(chunks, nchunks, g, m, v, ws, max_norm, lr, beta1, beta2, eps, wd, step, norm_out=None, grad_scale=1.0):
     _check(load().rn_clip_adam_step(chunks.data_ptr(), nchunks, g.data_ptr(), m.data_ptr(), v.data_ptr(), g.numel(), ws.data_ptr(),
-                                    float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step),
+                                    float(grad_scale), float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step),
                                     _ptr(norm_out), _stream()), "rn_clip_adam_step")
 
 

@@ -299,6 +299,50 @@ def test_g_chain_fwd_rr(H, K0, K0true, mode, M):
     assert rel(part.cpu().numpy(), ref.reshape(M // 32, 32, G).sum(1)) <= tol
 
 
+@pytest.mark.parametrize("mode,M", [("train", 256 * 290), ("infer", 256 * 5)])
+def test_g_chain_fwd_rr_f16s(H, mode, M):
+    """f16s on the register-resident chain: against a float64 emulation that rounds the operand to fp16 after every
+    layer (the kernel's operand registers) with hi + lo split weights; the stored bf16 copies agree in max-norm
+    (1 bf16 ulp of the largest value), the pair sums to 1e-3, and the result is within 3e-4 of the EXACT fp32 chain --
+    what single-pass bf16 cannot reach.  The masks must be the gates of the kernel's own pre-activations."""
+    L, G, K0, K0true = 4, 256, 192, 180
+    f16r = lambda a: np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+    P = np.zeros((M, K0), np.float32); P[:, :K0true] = formula.hash_uniform((M, K0true), 300, -1, 1)
+    P = f16r(P)
+    Ws, bs, his, los = [], [], [], []
+    jobs = []
+    for l in range(L):
+        kt = K0true if l == 0 else G
+        W = formula.hash_uniform((G, kt), 310 + l, -0.15, 0.15).astype(np.float32)
+        Ws.append(W); bs.append(formula.hash_uniform((G,), 320 + l, -0.3, 0.3))
+        hi = torch.empty(65536, dtype=torch.float16, device="cuda"); lo = torch.empty(65536, dtype=torch.float16, device="cuda")
+        wd = dev(W)
+        jobs += [(wd, kt, 1, G, kt, hi, 4 | int(l == 0)), (wd, kt, 1, G, kt, lo, 8 | int(l == 0))]
+        his.append(hi); los.append(lo)
+    H.pack_matrix_frag_many(jobs)
+    train = mode == "train"
+    Hs = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3)] + [None] if train else None
+    masks = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda")) if train else None
+    part = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
+    H.g_chain_fwd_rr_f16s(dev(P).half(), K0, his, los, [dev(b) for b in bs], Hs, masks, K0, part, M, G)
+    torch.cuda.synchronize()
+    prev = P[:, :K0true].astype(np.float64)
+    exact = prev
+    for l in range(L):
+        wh = f16r(Ws[l]); wl = f16r(Ws[l] - wh)
+        z = prev @ (wh.astype(np.float64) + wl.astype(np.float64)).T + bs[l]
+        ref = np.maximum(z, 0)
+        exact = np.maximum(exact @ Ws[l].astype(np.float64).T + bs[l], 0)
+        if train and l < 3:
+            assert rel(Hs[l].float().cpu().numpy(), bf16_round(ref)) <= BF16_ULP, l
+        if train:
+            bad = rr_mask_decode(masks[l], M, l) != (z > 0)
+            assert np.abs(z[bad]).max(initial=0.0) <= 2e-3 * np.abs(z).max() and bad.mean() <= 2e-3, (l, bad.sum())
+        prev = f16r(ref).astype(np.float64)
+    assert rel(part.cpu().numpy(), ref.reshape(M // 32, 32, G).sum(1)) <= 1e-3
+    assert rel(part.cpu().numpy(), exact.reshape(M // 32, 32, G).sum(1)) <= 3e-4
+
+
 @pytest.mark.parametrize("B,npairs", [(2, 512), (24, 32 * 100)])
 def test_g_chain_bwd_rr(H, B, npairs):
     """Register-resident backward chain on the masks of a real forward call: dZ[0] = bf16(dxg) where gate_3; every
