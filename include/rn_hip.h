@@ -196,6 +196,17 @@ size_t rn_pair_reduce_ws_bytes(int B, int n, int G);
 int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri, float* Rq, void* ws, int dtype, int B,
                        int n, int G, void* stream);
 
+/* Layer-0 weight gradient from the pair reductions (the question injected at layer 0: P = [x_j | x_i | q]):
+ *   dW0[:, 0:k] = Rj^T X,  dW0[:, k:2k] = Ri^T X,  dW0[:, 2k:2k+Q] = Rq^T q,  db0 = sum_b Rq[b]
+ * with X = x viewed as (B*n, k) -- identical to dZ_0^T P (rounding aside: x enters in fp32 instead of P's storage
+ * dtype) without reading dZ_0 or P.  Rj, Ri (B*n, N), Rq (B, N) fp32 from rn_pair_reduce_bwd; x (B, n, k) element
+ * strides; q (B, Q) row stride sqb; dW0 (N, 2k+Q), db0 (N); k <= 32; ws: rn_wgrad0_ws_bytes(B, n, N) bytes.
+ * Q == 0 (no question at layer 0): Rq / q may be NULL, db0 is then left to the caller. */
+size_t rn_wgrad0_ws_bytes(int B, int n, int N);
+int rn_wgrad0_from_reductions(const float* Rj, const float* Ri, const float* Rq, const float* x, long sxb, long sxn, long sxk,
+                              const float* q, long sqb, float* dW0, float* db0, void* ws, int B, int n, int k, int Q, int N,
+                              void* stream);
+
 /* K4 -- small fp32 GEMM on the fp32 MFMA, used for f_phi (model.py:155-160), its backward
  * and the (B*n x G) tail of the pair backward:
  *   C[m,n] (+)= epi( sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] )

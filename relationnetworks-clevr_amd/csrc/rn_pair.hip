@@ -455,3 +455,96 @@ extern "C" int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri
   }
   return 0;
 }
+
+// ------------------------------------------ layer-0 weight gradient from the pair reductions
+// Layer 0 reads the pair matrix P = [x_j | x_i | q]; its weight gradient dZ_0^T P therefore factors through the
+// reductions the input gradient needs anyway:
+//   dW0[:, 0:k] = Rj^T X,  dW0[:, k:2k] = Ri^T X,  dW0[:, 2k:2k+Q] = Rq^T Q,  db0 = sum_b Rq[b]
+// with X = x as a (B*n, k) matrix -- 55 MFLOP on (B*n)-row fp32 matrices instead of a 235 MB pass over dZ_0 and P.
+// Kernel 1: workgroup (feature block of 32, part j|i, row split): partial (32 x k) products over 256 rows, X tile in LDS;
+// kernel 2: fixed-order sum of the row splits + the (tiny) question part and the bias.  Deterministic.
+namespace {
+constexpr int W0_RS = 256;          // rows per split
+constexpr int W0_CMAX = 32;         // k <= 32 columns per x part
+}
+__global__ __launch_bounds__(256) void wgrad0_part_kernel(const float* __restrict__ Rj, const float* __restrict__ Ri,
+                                                          const float* __restrict__ x, long sxb, long sxn, long sxk,
+                                                          float* __restrict__ part, int n, int k, int N, int rows) {
+  __shared__ float xs[W0_RS][W0_CMAX + 1];
+  const int fb = blockIdx.x, pt = blockIdx.y, ks = blockIdx.z;
+  const int t = threadIdx.x, f = fb * 32 + (t & 31), cg = t >> 5;
+  const int r0 = ks * W0_RS;
+  const int nr = (rows - r0) < W0_RS ? (rows - r0) : W0_RS;
+  for (int i = t; i < W0_RS * k; i += 256) {
+    const int r = i / k, c = i - r * k;
+    float v = 0.f;
+    if (r < nr) {
+      const int row = r0 + r, b = row / n, j = row - b * n;
+      v = x[b * sxb + j * sxn + c * sxk];
+    }
+    xs[r][c] = v;
+  }
+  __syncthreads();
+  const float* R = (pt ? Ri : Rj) + (long)r0 * N + f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int r = 0;
+  for (; r + 8 <= nr; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = R[(long)(r + u) * N];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaf(v[u], xs[r + u][cg + 8 * e], acc[e]);
+  }
+  for (; r < nr; ++r) {
+    const float v = R[(long)r * N];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = fmaf(v, xs[r][cg + 8 * e], acc[e]);
+  }
+  // part[ks][pt][f][c]
+  float* o = part + (((long)ks * 2 + pt) * N + f) * W0_CMAX;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[cg + 8 * e] = acc[e];
+}
+
+// block = feature f; thread = output column of dW0 (2k + Q of them) or the bias
+__global__ __launch_bounds__(256) void wgrad0_finish_kernel(const float* __restrict__ part, int nks, const float* __restrict__ Rq,
+                                                            const float* __restrict__ q, long sqb, float* __restrict__ dW0,
+                                                            float* __restrict__ db0, int B, int k, int Q, int N, int kt) {
+  const int f = blockIdx.x;
+  for (int c = threadIdx.x; c <= kt; c += 256) {
+    float s = 0.f;
+    if (c == kt) {
+      if (Rq)
+        for (int b = 0; b < B; ++b) s += Rq[(long)b * N + f];
+      if (db0) db0[f] = s;
+    } else if (c < 2 * k) {
+      const int pt = c / k, cc = c - pt * k;
+      for (int z = 0; z < nks; ++z) s += part[(((long)z * 2 + pt) * N + f) * W0_CMAX + cc];
+      dW0[(long)f * kt + c] = s;
+    } else {
+      const int qc = c - 2 * k;
+      for (int b = 0; b < B; ++b) s = fmaf(Rq[(long)b * N + f], q[b * sqb + qc], s);
+      dW0[(long)f * kt + c] = s;
+    }
+  }
+}
+
+extern "C" size_t rn_wgrad0_ws_bytes(int B, int n, int N) {
+  return (size_t)cdiv((long)B * n, W0_RS) * 2 * N * W0_CMAX * sizeof(float);
+}
+
+extern "C" int rn_wgrad0_from_reductions(const float* Rj, const float* Ri, const float* Rq, const float* x, long sxb, long sxn,
+                                         long sxk, const float* q, long sqb, float* dW0, float* db0, void* ws, int B, int n, int k,
+                                         int Q, int N, void* stream) {
+  RN_CHECK_ARG(Rj && Ri && x && dW0 && db0 && ws && B > 0 && n > 0, "rn_wgrad0_from_reductions: bad pointer/size");
+  RN_CHECK_ARG(k > 0 && k <= W0_CMAX && N % 32 == 0 && (Q == 0 || (Rq && q)), "rn_wgrad0_from_reductions: k=%d (<= %d), N=%d (%% 32), Q=%d unsupported", k, W0_CMAX, N, Q);
+  RN_CHECK_ARG(Rq || Q == 0, "rn_wgrad0_from_reductions: Rq is required for the bias when the question is injected");
+  const int rows = B * n, nks = cdiv(rows, W0_RS), kt = 2 * k + Q;
+  hipStream_t s = (hipStream_t)stream;
+  wgrad0_part_kernel<<<dim3(N / 32, 2, nks), 256, 0, s>>>(Rj, Ri, x, sxb, sxn, sxk, (float*)ws, n, k, N, rows);
+  wgrad0_finish_kernel<<<N, 256, 0, s>>>((const float*)ws, nks, Rq, q, sqb, dW0, db0, B, k, Q, N, kt);
+  RN_LAUNCH_CHECK("rn_wgrad0_from_reductions");
+  return 0;
+}

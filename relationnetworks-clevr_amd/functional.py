@@ -390,12 +390,19 @@ class RelationalFunction(torch.autograd.Function):
         # None (assign, not accumulate: autograd then launches no kernel on these tensors before the join).
         overlap = (fused_bwd and os.environ.get("RN_NO_WGRAD_OVERLAP", "0") != "1"
                    and all(p.grad is None for p in ctx.param_refs))
+        # Layer 0 reads the pair matrix P = [x_j | x_i | q]: its weight gradient dZ_0^T P factors through the pair
+        # reductions the input gradient needs anyway -- dW_0 = [Rj^T X | Ri^T X | Rq^T Q], db_0 = sum_b Rq -- three tiny
+        # products on (B*n)-row matrices instead of a 235 MB pass over dZ_0 and P (and with fp32 x instead of P's
+        # rounded copy).  RN_NO_ALGEBRAIC_WGRAD0=1 keeps the kernel.
+        alg0 = plan.inject == 0 and k <= 32 and os.environ.get("RN_NO_ALGEBRAIC_WGRAD0", "0") != "1"
         if overlap:
             main, side = torch.cuda.current_stream(), _side_stream(dev)
             side.wait_stream(main)
             keep = [list(dZs), list(inputs)]                       # keep operands alive until the join
             with torch.cuda.stream(side):
                 for l in range(L):
+                    if l == 0 and alg0:
+                        continue                                   # layer 0: from the pair reductions, below
                     N, kt, kp = plan.widths[l], plan.ktrue[l], plan.kpad[l]
                     gW[l] = torch.empty(N, kt, **f32)
                     gB[l] = torch.empty(N, **f32)
@@ -411,7 +418,7 @@ class RelationalFunction(torch.autograd.Function):
             kt, kp = plan.ktrue[l], plan.kpad[l]
             if fused_bwd:
                 dZ = dZ_of.pop(l)
-            if not overlap:
+            if not overlap and not (l == 0 and alg0):
                 gW[l] = torch.empty(N, kt, **f32)
                 gB[l] = torch.empty(N, **f32)
                 H.g_linear_bwd_wgrad(dZ, N, A_l, kp, gW[l], gB[l], code, M, N, kp, kt)
@@ -428,6 +435,18 @@ class RelationalFunction(torch.autograd.Function):
             elif l == 0:
                 Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32)
                 H.pair_reduce_bwd(dZ, N, Rj, Ri, None, code, B, n, N)
+            if l == 0 and alg0:
+                def _wgrad0():
+                    gW[0] = torch.empty(N, kt, **f32)
+                    gB[0] = torch.empty(N, **f32)
+                    H.wgrad0_from_reductions(Rj, Ri, Rq, x, q, gW[0], gB[0])
+                if overlap:                                        # off the critical path: onto the wgrad stream
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        _wgrad0()
+                    keep.append([Rj, Ri, Rq])
+                else:
+                    _wgrad0()
             if l == 0:
                 dx = torch.empty(B, n, k, **f32)
                 H.gemm_f32(Rj, N, 1, wl, kt, 1, dx, k, B * n, k, N)                        # Rj @ W0[:, 0:k]

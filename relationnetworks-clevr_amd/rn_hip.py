@@ -48,6 +48,8 @@ SIGNATURES = {
     "rn_g_linear_bwd_wgrad": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_pair_reduce_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_reduce_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_wgrad0_ws_bytes": (_Z, [_I, _I, _I]),
+    "rn_wgrad0_from_reductions": (_I, [_P, _P, _P, _P, _L, _L, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_gemm_f32": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _P, _L, _P, _L, _I, _P]),
     "rn_log_softmax_fwd": (_I, [_P, _P, _I, _I, _P]),
     "rn_log_softmax_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
@@ -340,6 +342,18 @@ def pair_reduce_bwd(dZ, lddz, Rj, Ri, Rq, code, B, n, G):
     ws = torch.empty(max(lib.rn_pair_reduce_ws_bytes(B, n, G), 16), dtype=torch.uint8, device=dZ.device)
     _check(lib.rn_pair_reduce_bwd(dZ.data_ptr(), lddz, _ptr(Rj), _ptr(Ri), _ptr(Rq), ws.data_ptr(), code, B, n, G, _stream()),
            "rn_pair_reduce_bwd")
+
+
+@_timed("g_wgrad")
+def wgrad0_from_reductions(Rj, Ri, Rq, x, q, dW0, db0):
+    B, n, k = x.shape
+    N, Q = Rj.shape[1], q.shape[1]
+    lib = load()
+    ws = torch.empty(max(lib.rn_wgrad0_ws_bytes(B, n, N), 16), dtype=torch.uint8, device=Rj.device)
+    sx = x.stride()
+    _check(lib.rn_wgrad0_from_reductions(Rj.data_ptr(), Ri.data_ptr(), Rq.data_ptr(), x.data_ptr(), sx[0], sx[1], sx[2], q.data_ptr(),
+                                         q.stride(0), dW0.data_ptr(), db0.data_ptr(), ws.data_ptr(), B, n, k, Q, N, _stream()),
+           "rn_wgrad0_from_reductions")
 
 
 def gemm_f32(A, sam, sak, Bm, sbk, sbn, Cm, ldc, M, N, K, bias=None, mul=None, ldmul=0, gate=None, ldgate=0, flags=0,

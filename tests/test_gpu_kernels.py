@@ -496,6 +496,27 @@ def test_g_linear_bwd_wgrad(H, code, M, N, K, Ktrue, no_tr):
         os.environ.pop("RN_WGRAD_STREAM_192", None)
 
 
+@pytest.mark.parametrize("B,n,k,Q", [(64, 64, 26, 128), (3, 12, 7, 256), (2, 196, 26, 128)])
+def test_wgrad0_from_reductions(H, B, n, k, Q):
+    """dW_0 = [Rj^T X | Ri^T X | Rq^T q], db_0 = sum_b Rq: must equal dZ_0^T P / column sums of dZ_0 computed directly
+    from a pair matrix (fp64), for a strided x view as RN.forward produces it."""
+    N = 256
+    xs = formula.hash_uniform((B, k, n), 80, -1, 1)                      # (B, k, n) storage, (B, n, k) view
+    q = formula.hash_uniform((B, Q), 81, -1, 1)
+    dZ = formula.hash_uniform((B * n * n, N), 82, -1, 1).astype(np.float64)
+    x = np.transpose(xs, (0, 2, 1))
+    d4 = dZ.reshape(B, n, n, N)
+    Rj, Ri, Rq = d4.sum(1).reshape(B * n, N), d4.sum(2).reshape(B * n, N), d4.sum((1, 2))
+    P = np.concatenate([np.broadcast_to(x[:, None, :, :], (B, n, n, k)), np.broadcast_to(x[:, :, None, :], (B, n, n, k)),
+                        np.broadcast_to(q[:, None, None, :], (B, n, n, Q))], -1).reshape(B * n * n, 2 * k + Q)
+    ref = dZ.T @ P
+    dW = torch.full((N, 2 * k + Q), 9.0, device="cuda"); db = torch.full((N,), 9.0, device="cuda")
+    H.wgrad0_from_reductions(dev(Rj.astype(np.float32)), dev(Ri.astype(np.float32)), dev(Rq.astype(np.float32)),
+                             dev(xs).permute(0, 2, 1), dev(q), dW, db)
+    torch.cuda.synchronize()
+    assert rel(dW.cpu().numpy(), ref) <= F32_TOL and rel(db.cpu().numpy(), dZ.sum(0)) <= F32_TOL
+
+
 # ----------------------------------------------------------------------------- pair reduce
 @pytest.mark.parametrize("code", [0, 1])
 @pytest.mark.parametrize("B,n,G", [(3, 64, 256), (2, 12, 512), (1, 196, 256)])
