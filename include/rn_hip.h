@@ -134,7 +134,7 @@ int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, con
  *   dZ[s+1] = (dZ[s] @ W_{3-s}) * gate_{2-s}          s = 0, 1, 2
  * gate_l = mask[l] of the forward call.  Wtf[s]: fragment-major image of W_{3-s}^T, i.e.
  * rn_pack_matrix_frag(W, 1, in_features, 256, 256, dst, natural = (s == 0)).  All four dZ (M, 256) bf16 are
- * written (wgrad and the pair reduction consume them).  rows_per_question (= n*n) % 32 == 0. */
+ * written (wgrad and the pair reduction consume them).  rows_per_question = n*n (any value dividing M). */
 int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M,
                       int rows_per_question, int L, int G, void* stream);
 

@@ -775,7 +775,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
   for (; tile < ntiles; tile += gridDim.x) {
     const long m0w = (long)tile * RR_TM + RR_WR * w;
     const long wt = (long)tile * RR_NW + w;
-    const long b = m0w / a.rows_per_b;                                // a wave's 32 rows lie in one question
+    const long b = (m0w + n) / a.rows_per_b;                          // question of THIS lane's pair row (a wave may straddle two)
     auto co_read = [&]() {
 #pragma unroll
       for (int q = 0; q < 2; ++q) co[q] = *reinterpret_cast<const u32x4*>(stg + (16 * q + (lane >> 2)) * RR_SRS + (lane & 3) * 16);
@@ -1032,8 +1032,8 @@ extern "C" int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, cons
                                  int rows_per_question, int L, int G, void* stream) {
   RN_CHECK_ARG(dxg && mask && Wtf && dZ && M > 0, "rn_g_chain_bwd_rr: bad pointer/size");
   RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_bwd_rr: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
-  RN_CHECK_ARG(M % RR_TM == 0 && rows_per_question > 0 && rows_per_question % RR_WR == 0 && M % rows_per_question == 0,
-               "rn_g_chain_bwd_rr: M=%d must be a multiple of %d, rows per question=%d of %d", M, RR_TM, rows_per_question, RR_WR);
+  RN_CHECK_ARG(M % RR_TM == 0 && rows_per_question > 0 && M % rows_per_question == 0,
+               "rn_g_chain_bwd_rr: M=%d must be a multiple of %d and of rows per question=%d", M, RR_TM, rows_per_question);
   RRBwdArgs a;
   memset(&a, 0, sizeof(a));
   for (int l = 0; l < RR_L; ++l) {

@@ -231,9 +231,10 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
             Hs = None
             if keep_inputs:
                 Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L)]
-                if whole and os.environ.get("RN_NO_RR_MASKS", "0") != "1":
+                if os.environ.get("RN_NO_RR_MASKS", "0") != "1":
                     masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
-                    Hs[-1] = None
+                    if whole:
+                        Hs[-1] = None                       # (waves straddling questions: the pair sum needs the stored H_3)
             part = torch.empty(M // R, G, dtype=torch.float32, device=dev) if whole else None
             H.g_chain_fwd_rr(P, ld0, wfrag, g_b, Hs, masks, ld0, part, M, G)
             xg = torch.empty(B, G, dtype=torch.float32, device=dev)
@@ -316,7 +317,7 @@ class RelationalFunction(torch.autograd.Function):
         dev = x.device
         f16s = precision == "f16s"
         need_grad = any(ctx.needs_input_grad)
-        rr_only = (rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0 and (n * n) % 32 == 0
+        rr_only = (rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0 and ((n * n) % 32 == 0 or not f16s)
                    and os.environ.get("RN_NO_RR_MASKS", "0") != "1")
         wfwd, wbwd = packed.get(plan, g_w, code, split=f16s, bwd_images=need_grad, rr_only=rr_only, f_w=f_w)
         gb = [b.detach().contiguous() for b in g_b]

@@ -343,10 +343,11 @@ def test_g_chain_fwd_rr_f16s(H, mode, M):
     assert rel(part.cpu().numpy(), exact.reshape(M // 32, 32, G).sum(1)) <= 3e-4
 
 
-@pytest.mark.parametrize("B,npairs", [(2, 512), (24, 32 * 100)])
+@pytest.mark.parametrize("B,npairs", [(2, 512), (24, 32 * 100), (16, 144)])
 def test_g_chain_bwd_rr(H, B, npairs):
     """Register-resident backward chain on the masks of a real forward call: dZ[0] = bf16(dxg) where gate_3; every
-    further dZ equals one un-fused dgrad step on the kernel's OWN previous dZ (<= 1 bf16 ulp), zero where gated."""
+    further dZ equals one un-fused dgrad step on the kernel's OWN previous dZ (<= 1 bf16 ulp), zero where gated.
+    (16, 144): a wave's 32 rows straddle two questions."""
     G, L, K0 = 256, 4, 192
     M = B * npairs
     P, Ws, bs, Wf = rr_setup(H, M, K0, 180)
