@@ -224,6 +224,13 @@ int rn_log_softmax_bwd(const float* out, const float* gout, float* dz, int B, in
 /* column sums: out[c] = sum_r src[r*ld + c]  (bias gradients of f_phi). */
 int rn_colsum_f32(const float* src, long ld, float* out, int R, int C, void* stream);
 
+/* R-CBIR pair features (reference extract.py:60-71): for the INPUT of a g layer, A (B*npairs, lda)
+ * in `dtype`, first F columns (the question columns of an injection layer excluded by the caller's F):
+ * L2-normalise every pair row (F.normalize semantics, eps 1e-12), then maxf / avgf (B, F) fp32 = maximum / mean over the
+ * npairs rows of each question.  One pass over A.  F % 64 == 0, F <= 512; ws: rn_pair_features_ws_bytes(B, npairs, F). */
+size_t rn_pair_features_ws_bytes(int B, int npairs, int F);
+int rn_pair_features(const void* A, int lda, int F, float* maxf, float* avgf, void* ws, int dtype, int B, int npairs, void* stream);
+
 /* f_phi + log_softmax (model.py:155-162) in one launch, its backward in two (rn_small.hip; fp32 FMA):
  *   f1 = relu(xg W1^T + b1) (B, F1);  f2 = relu((f1 W2^T + b2) * mask) (B, F2);  out = log_softmax(f2 W3^T + b3) (B, A)
  * W_l: nn.Linear layout (out, in) row-major -- or, with transposed != 0 in the forward call, (in, out) copies (fp32 transpose

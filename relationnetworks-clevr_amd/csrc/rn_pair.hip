@@ -548,3 +548,82 @@ extern "C" int rn_wgrad0_from_reductions(const float* Rj, const float* Ri, const
   RN_LAUNCH_CHECK("rn_wgrad0_from_reductions");
   return 0;
 }
+
+// ------------------------------------------ R-CBIR pair features (extract.py:60-71)
+// For the INPUT of a g layer, A (B*npairs, lda), first F columns: L2-normalise every pair row (F.normalize, eps 1e-12),
+// then the maximum and the mean over the npairs rows of every question -- one pass over A, nothing is materialised in
+// fp32.  A wave walks rows (lane = F/64 consecutive columns: one coalesced row read), the row norm is a wave all-reduce;
+// per-(question, slice) partials are combined by a finish kernel in a fixed order.
+template <typename T, int VPL>   // VPL columns per lane (F = 64 * VPL)
+__global__ __launch_bounds__(256) void pair_features_kernel(const T* __restrict__ A, int lda, float* __restrict__ pmax,
+                                                            float* __restrict__ psum, int npairs, int S) {
+  __shared__ float red[2][4][64 * VPL];
+  const int b = blockIdx.y, s = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int rows_per = (npairs + S - 1) / S;
+  const int r0 = s * rows_per, r1 = (r0 + rows_per) < npairs ? (r0 + rows_per) : npairs;
+  float mx[VPL], sm[VPL];
+#pragma unroll
+  for (int e = 0; e < VPL; ++e) { mx[e] = -3.0e38f; sm[e] = 0.f; }
+  for (int r = r0 + w; r < r1; r += 4) {
+    const T* row = A + ((long)b * npairs + r) * lda + lane * VPL;
+    float v[VPL], ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) { v[e] = Elem<T>::to_f32(row[e]); ss = fmaf(v[e], v[e], ss); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) { const float u = v[e] * inv; mx[e] = fmaxf(mx[e], u); sm[e] += u; }
+  }
+#pragma unroll
+  for (int e = 0; e < VPL; ++e) { red[0][w][lane * VPL + e] = mx[e]; red[1][w][lane * VPL + e] = sm[e]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 64 * VPL; c += 256) {
+    const float m = fmaxf(fmaxf(red[0][0][c], red[0][1][c]), fmaxf(red[0][2][c], red[0][3][c]));
+    const float t = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    pmax[((long)b * S + s) * 64 * VPL + c] = m;
+    psum[((long)b * S + s) * 64 * VPL + c] = t;
+  }
+}
+__global__ __launch_bounds__(256) void pair_features_finish_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+                                                                   float* __restrict__ maxf, float* __restrict__ avgf, int F, int S,
+                                                                   float inv_n) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < F; c += 256) {
+    float m = -3.0e38f, t = 0.f;
+    for (int s = 0; s < S; ++s) {
+      m = fmaxf(m, pmax[((long)b * S + s) * F + c]);
+      t += psum[((long)b * S + s) * F + c];
+    }
+    maxf[(long)b * F + c] = m;
+    avgf[(long)b * F + c] = t * inv_n;
+  }
+}
+
+static int pf_slices(int npairs) {
+  int s = npairs / 64;
+  return s < 1 ? 1 : (s > 64 ? 64 : s);
+}
+extern "C" size_t rn_pair_features_ws_bytes(int B, int npairs, int F) { return (size_t)2 * B * pf_slices(npairs) * F * sizeof(float); }
+
+extern "C" int rn_pair_features(const void* A, int lda, int F, float* maxf, float* avgf, void* ws, int dtype, int B, int npairs,
+                                void* stream) {
+  RN_CHECK_ARG(A && maxf && avgf && ws && B > 0 && npairs > 0, "rn_pair_features: bad pointer/size");
+  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "rn_pair_features: bad dtype %d", dtype);
+  RN_CHECK_ARG(F > 0 && F % 64 == 0 && F <= 512 && lda >= F, "rn_pair_features: F=%d must be a multiple of 64, <= 512 and <= lda=%d", F, lda);
+  const int S = pf_slices(npairs), vpl = F / 64;
+  float* pmax = (float*)ws;
+  float* psum = pmax + (size_t)B * S * F;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(S, B);
+#define RN_PF(T, V) pair_features_kernel<T, V><<<grid, 256, 0, s>>>((const T*)A, lda, pmax, psum, npairs, S)
+#define RN_PFV(T)                                                                                                     \
+  switch (vpl) { case 1: RN_PF(T, 1); break; case 2: RN_PF(T, 2); break; case 3: RN_PF(T, 3); break; case 4: RN_PF(T, 4); break; \
+                 case 5: RN_PF(T, 5); break; case 6: RN_PF(T, 6); break; case 7: RN_PF(T, 7); break; default: RN_PF(T, 8); break; }
+  if (dtype == RN_BF16) { RN_PFV(bf16) } else { RN_PFV(float) }
+#undef RN_PFV
+#undef RN_PF
+  pair_features_finish_kernel<<<B, 256, 0, s>>>(pmax, psum, maxf, avgf, F, S, 1.f / (float)npairs);
+  RN_LAUNCH_CHECK("rn_pair_features");
+  return 0;
+}

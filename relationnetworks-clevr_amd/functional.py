@@ -164,7 +164,7 @@ def fused_chain_ok(plan: LayerPlan, code, B, n):
             and all(kp == 256 for kp in plan.kpad[1:]) and (B * n * n) % H.g_chain_tile() == 0 and plan.L <= 8)
 
 
-def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None, split=None, wfrag=None):
+def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None, split=None, wfrag=None, stop_at=None):
     """K1 + K2 chain (+ K3).  Returns (inputs, H_L, xg): the list of layer INPUT buffers
     [A_0 .. A_{L-1}], the last activation H_L and -- when the fused chain ran -- the pair sum xg
     (else None).  layer_hook(l, A_l, H_out) is called after every layer (hook-compat path; forces
@@ -218,7 +218,9 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
         return [P] + Hs[:-1], Hs[-1], xg
     P = torch.empty(M, ld0, dtype=dt, device=dev)
     H.pair_build_fwd(x, q if inj == 0 else None, P, code, B, n, k, Q if inj == 0 else 0, ld0)
-    if layer_hook is None and fused_chain_ok(plan, code, B, n):
+    if stop_at == 0:
+        return [P], None, None
+    if stop_at is None and layer_hook is None and fused_chain_ok(plan, code, B, n):
         G = plan.widths[-1]
         L = plan.L
         R = 32                                      # pair rows per wave of the register-resident chain
@@ -274,6 +276,8 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
             H.qst_broadcast(q, out, code, B, n, Q, N, ldh)
         if layer_hook is not None:
             layer_hook(l, cur, out)
+        if stop_at is not None and l + 1 == stop_at:         # the caller wants the INPUT of layer stop_at only
+            return inputs + [out], None, None
         if l + 1 < plan.L:
             inputs.append(out)
         if not keep_inputs and l >= 1:

@@ -175,6 +175,28 @@ class RelationalLayer(RelationalLayerBase):
         return RF.relational_forward(x, qst, mask, plan, self._packed, prec, g_w, g_b, f_w, f_b)
 
     @torch.no_grad()
+    def extract_features(self, x, qst, layer_idx):
+        """R-CBIR features of extract.py:49-74 without a hook: the input of g layer `layer_idx` is L2-normalised per
+        pair and reduced to (max, mean) over each question's pairs on the GPU (rn_pair_features; the question columns of
+        an injection layer are excluded, extract.py:66-67).  Returns two (B, F) fp32 tensors.  The g chain stops at that
+        layer; nothing is materialised in fp32 (the hook-compatible path stays available)."""
+        b, d, k = x.size()
+        plan = self._plan(k)
+        if not 0 <= layer_idx < plan.L:
+            raise ValueError("layer_idx must be in [0, %d)" % plan.L)
+        code = H.dtype_code("fp32" if self.precision == "fp32" else "bf16")
+        H._dev(x, "x")
+        wfwd, _ = self._packed.get(plan, [l.weight for l in self.g_layers], code, bwd_images=False)
+        gb = [l.bias.detach().contiguous() for l in self.g_layers]
+        inputs, _, _ = RF.g_chain_forward(x.float(), qst.float().contiguous(), plan, gb, wfwd, code, keep_inputs=True,
+                                          stop_at=layer_idx)
+        A = inputs[layer_idx]
+        F_ = plan.ktrue[layer_idx] - (qst.shape[1] if layer_idx == plan.inject else 0)
+        if F_ % 64:
+            raise RuntimeError("feature width %d of layer %d is not a multiple of 64 (layer 0 of the *-fp configs: use the hook path)" % (F_, layer_idx))
+        return H.pair_features(A, A.shape[1], F_, code, b, d * d)
+
+    @torch.no_grad()
     def _forward_hook_compat(self, x, qst, plan):
         """extract.py registers forward hooks on g_layers[k] and reads the layer *input*
         (B*n*n, in) (extract.py:43,64-68).  When hooks (or extraction=True) are present the
@@ -278,6 +300,23 @@ class RN(nn.Module):
             cur.wait_stream(side)
             qst.record_stream(cur)
         return self.rl(x, qst)
+
+    @torch.no_grad()
+    def extract_features(self, img, qst_idxs, layer_idx):
+        """extract.py's R-CBIR features (max / mean over pairs of the L2-normalised input of g layer `layer_idx`) through the
+        native op instead of a forward hook: RelationalLayer.extract_features."""
+        if self.state_desc:
+            x = img
+        else:
+            x = self.conv(img)
+            b, k, d, _ = x.size()
+            key = (b, d, x.device)
+            if self.coord_tensor is None or self._coord_key != key:
+                self.build_coord_tensor(b, d, x.device)
+                self.coord_tensor = self.coord_tensor.view(b, 2, d * d)
+                self._coord_key = key
+            x = torch.cat([x.view(b, k, d * d), self.coord_tensor], 1).permute(0, 2, 1)
+        return self.rl.extract_features(x, self.text(qst_idxs), layer_idx)
 
     def cuda(self, device=None):
         self.on_gpu = True

@@ -54,6 +54,8 @@ SIGNATURES = {
     "rn_log_softmax_fwd": (_I, [_P, _P, _I, _I, _P]),
     "rn_log_softmax_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "rn_colsum_f32": (_I, [_P, _L, _P, _I, _I, _P]),
+    "rn_pair_features_ws_bytes": (_Z, [_I, _I, _I]),
+    "rn_pair_features": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "rn_f_phi_fwd": (_I, [_P] * 11 + [_I] * 6 + [_P]),
     "rn_f_phi_bwd_ws_bytes": (_Z, [_I, _I, _I, _I]),
     "rn_f_phi_bwd": (_I, [_P] * 17 + [_I] * 5 + [_P]),
@@ -453,3 +455,15 @@ def embedding_bwd(idx, dx, demb):
     B, T = idx.shape
     _check(load().rn_embedding_bwd(idx.data_ptr(), dx.data_ptr(), demb.data_ptr(), B, T, demb.shape[0], demb.shape[1], _stream()),
            "rn_embedding_bwd")
+
+
+# ------------------------------------------------------------------ R-CBIR pair features (extract.py)
+def pair_features(A, lda, F, code, B, npairs):
+    """(maxf, avgf), each (B, F) fp32: L2-normalised pair rows of A[:, :F], max / mean over each question's pairs."""
+    lib = load()
+    maxf = torch.empty(B, F, dtype=torch.float32, device=A.device)
+    avgf = torch.empty(B, F, dtype=torch.float32, device=A.device)
+    ws = torch.empty(max(lib.rn_pair_features_ws_bytes(B, npairs, F), 16), dtype=torch.uint8, device=A.device)
+    _check(lib.rn_pair_features(A.data_ptr(), lda, F, maxf.data_ptr(), avgf.data_ptr(), ws.data_ptr(), code, B, npairs, _stream()),
+           "rn_pair_features")
+    return maxf, avgf

@@ -204,6 +204,23 @@ def test_extraction_hooks(pkg):
     assert gold.rel_err(got["max"], g["max"]) <= 1e-4 and gold.rel_err(got["avg"], g["avg"]) <= 1e-4
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 2e-2)])
+def test_extraction_native_op(pkg, precision, tol):
+    """the same features from the native op (RelationalLayer.extract_features -> rn_pair_features), no hook,
+    nothing materialised in fp32.  bf16 tolerance: the activations themselves carry bf16 rounding (2^-8 relative per element)."""
+    g = gold.load("G-extract")
+    meta = g["meta"]
+    hyp = dict(formula.HYP[meta["cfg"]], precision=precision)
+    b, n, k, Q = meta["b"], 64, hyp["rl_in_size"] // 2, hyp["lstm_hidden"]
+    rl = pkg.RelationalLayer(hyp["rl_in_size"], formula.ADICT, Q, hyp, extraction=True)
+    rl.load_state_dict({k_: torch.from_numpy(v) for k_, v in formula.formula_rl_state(hyp, meta["seed"]).items()})
+    rl.cuda().eval()
+    x = torch.from_numpy(formula.formula_objects(b, n, k, meta["seed"] + 1)).cuda()
+    mx, av = rl.extract_features(x, torch.zeros(b, Q, device="cuda"), meta["layer_idx"])
+    assert mx.shape == g["max"].shape
+    assert gold.rel_err(mx.cpu().numpy(), g["max"]) <= tol and gold.rel_err(av.cpu().numpy(), g["avg"]) <= tol
+
+
 def test_changing_batch_size_and_eval_train(pkg):
     """quirk C1 fixed: a different batch size after the first forward must work."""
     hyp = dict(formula.HYP["original-fp"])
