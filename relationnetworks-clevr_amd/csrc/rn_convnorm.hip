@@ -6,7 +6,8 @@
 // trip over the 25 MB layer-1 activation.  The arithmetic is a per-channel reduction plus a point-wise map:
 //
 //   forward   pass 1: per-channel sum / sum of squares of the conv output x            (read x)
-//             pass 2: y = relu((x - mean) * invstd * gamma + beta)                     (read x, write y)
+//             pass 2: mean / invstd from the slice sums (+ running statistics), y = relu((x - mean) * invstd * gamma + beta)
+//                                                                                      (read x, write y)
 //   backward  pass 1: S1 = sum dz, S2 = sum dz * x with dz = dy * (y > 0)              (read dy, x)
 //             pass 2: dx = gamma * invstd * (dz - S1/n - xhat * dgamma/n)              (read dy, x, write dx)
 //
@@ -61,41 +62,48 @@ __global__ __launch_bounds__(CN_T) void cn_stats_kernel(const f32x4* __restrict_
   }
 }
 
-// per channel: mean / invstd from the slice sums; scale / shift of the affine map; running statistics
-// (torch.nn.BatchNorm2d semantics: biased variance normalises, unbiased variance goes to running_var)
-__global__ void cn_finalize_kernel(const double* __restrict__ part, int S, double count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, const float* __restrict__ conv_bias, float eps, float momentum,
-                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, long long* __restrict__ num_batches, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && num_batches) num_batches[0] += 1;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int s = 0; s < S; ++s) {
-    s0 += part[((long)c * S + s) * 2];
-    s1 += part[((long)c * S + s) * 2 + 1];
-  }
-  const double m = s0 / count;
-  double var = s1 / count - m * m;
-  if (var < 0.0) var = 0.0;
-  mean[c] = (float)m;
-  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) {
-    const double mb = m + (conv_bias ? (double)conv_bias[c] : 0.0);      // the conv ran without its bias
-    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mb);
-    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
-  }
-}
-
-// y = relu(x * scale[c] + shift[c]) with scale = gamma * invstd, shift = beta - mean * scale (training) or the
-// running-statistics equivalent prepared by the caller (evaluation)
+// y = relu((x - mean) * invstd * gamma + beta).  FROM_PART (training): every block first adds up the channel's slice
+// sums (fixed order) to mean / invstd; block (0, c) also publishes them for the backward pass and updates the running
+// statistics (torch.nn.BatchNorm2d semantics: biased variance normalises, unbiased variance goes to running_var;
+// the conv ran without its bias, so the bias is added to the running mean here).  !FROM_PART (evaluation): mean / invstd
+// are caller-prepared.
+template <bool FROM_PART>
 __global__ __launch_bounds__(CN_T) void cn_apply_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y,
-                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int C,
-                                                        int hw4, long n4) {
+                                                        const double* __restrict__ part, int S, double count,
+                                                        float* __restrict__ mean, float* __restrict__ invstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ conv_bias, float eps, float momentum,
+                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                        long long* __restrict__ num_batches, int C, int hw4, long n4) {
   const int c = blockIdx.y;
-  const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+  float m, is;
+  if constexpr (FROM_PART) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int s = 0; s < S; ++s) {
+      s0 += part[((long)c * S + s) * 2];
+      s1 += part[((long)c * S + s) * 2 + 1];
+    }
+    const double md = s0 / count;
+    double var = s1 / count - md * md;
+    if (var < 0.0) var = 0.0;
+    m = (float)md;
+    is = (float)(1.0 / sqrt(var + (double)eps));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      mean[c] = m;
+      invstd[c] = is;
+      if (running_mean) {
+        const double mb = md + (conv_bias ? (double)conv_bias[c] : 0.0);
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mb);
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+      }
+      if (c == 0 && num_batches) num_batches[0] += 1;
+    }
+  } else {
+    m = mean[c];
+    is = invstd[c];
+  }
+  const float sc = gamma[c] * is, sh = beta[c] - m * sc;
   for (long q = (long)blockIdx.x * CN_T + threadIdx.x; q < n4; q += (long)gridDim.x * CN_T) {
     const long a = cn_addr4(q, c, C, hw4);
     const f32x4 v = x[a];
@@ -194,11 +202,10 @@ extern "C" int rn_bn_relu_fwd(const float* x, float* y, const float* gamma, cons
   const int S = cn_slices(n4), hw4 = HW / 4;
   hipStream_t s = (hipStream_t)stream;
   cn_stats_kernel<<<dim3(S, C), CN_T, 0, s>>>((const f32x4*)x, (double*)ws, C, hw4, n4, S);
-  cn_finalize_kernel<<<cdiv(C, 64), 64, 0, s>>>((const double*)ws, S, (double)N * HW, gamma, beta, conv_bias, eps, momentum, mean,
-                                                invstd, running_mean, running_var, num_batches, C);
   int gx = (int)((n4 + CN_T * 4 - 1) / (CN_T * 4));
   if (gx < 1) gx = 1;
-  cn_apply_kernel<<<dim3(gx, C), CN_T, 0, s>>>((const f32x4*)x, (f32x4*)y, mean, invstd, gamma, beta, C, hw4, n4);
+  cn_apply_kernel<true><<<dim3(gx, C), CN_T, 0, s>>>((const f32x4*)x, (f32x4*)y, (const double*)ws, S, (double)N * HW, mean, invstd, gamma,
+                                                     beta, conv_bias, eps, momentum, running_mean, running_var, num_batches, C, hw4, n4);
   RN_LAUNCH_CHECK("rn_bn_relu_fwd");
   return 0;
 }
@@ -211,7 +218,9 @@ extern "C" int rn_bn_relu_apply(const float* x, float* y, const float* gamma, co
   const long n4 = (long)N * HW / 4;
   int gx = (int)((n4 + CN_T * 4 - 1) / (CN_T * 4));
   if (gx < 1) gx = 1;
-  cn_apply_kernel<<<dim3(gx, C), CN_T, 0, (hipStream_t)stream>>>((const f32x4*)x, (f32x4*)y, mean, invstd, gamma, beta, C, HW / 4, n4);
+  cn_apply_kernel<false><<<dim3(gx, C), CN_T, 0, (hipStream_t)stream>>>((const f32x4*)x, (f32x4*)y, nullptr, 0, 1.0, const_cast<float*>(mean),
+                                                                        const_cast<float*>(invstd), gamma, beta, nullptr, 0.f, 0.f, nullptr, nullptr,
+                                                                        nullptr, C, HW / 4, n4);
   RN_LAUNCH_CHECK("rn_bn_relu_apply");
   return 0;
 }
