@@ -273,6 +273,14 @@ int rn_lstm_bwd(const float* dhn, const float* gates, const float* cs, const flo
                 void* stream);
 int rn_embedding_bwd(const long long* idx, const float* dx, float* demb, int B, int T, int V, int E, void* stream);
 
+/* The 3x3 / stride-2 / pad-1 convolutions of ConvInputModel (reference model.py:13-20) as direct fp32 kernels (rn_conv.hip):
+ * x (N, Cin, H, W), w (Cout, Cin, 3, 3) -- nn.Conv2d layout --, y (N, Cout, H/2, W/2), all contiguous; no bias (the fused
+ * batch-norm block drops it).  Cout == 24, Cin in {3, 24} (input gradient: 24), H and W even.
+ *   fwd:      y  = conv2d(x, w, stride 2, padding 1)
+ *   bwd_data: dx = gradient of that w.r.t. x for the output gradient dy (every element of dx is written). */
+int rn_conv3x3s2_fwd(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, void* stream);
+int rn_conv3x3s2_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, void* stream);
+
 /* BatchNorm2d + ReLU of the conv stack in front of the relation layer (reference model.py:22-35), fused into two
  * HBM passes per direction (rn_convnorm.hip).  x: (N, C, H, W) fp32 contiguous conv output computed WITHOUT the
  * conv bias (a bias in front of a batch norm shifts the batch mean by itself and drops out; conv_bias is only added

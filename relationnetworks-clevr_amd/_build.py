@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librn_hip.so")
-SOURCES = ["rn_pair.hip", "rn_gemm.hip", "rn_chain.hip", "rn_chain_rr.hip", "rn_wgrad.hip", "rn_small.hip", "rn_convnorm.hip", "rn_lstm.hip"]
+SOURCES = ["rn_pair.hip", "rn_gemm.hip", "rn_chain.hip", "rn_chain_rr.hip", "rn_wgrad.hip", "rn_small.hip", "rn_convnorm.hip", "rn_lstm.hip", "rn_conv.hip"]
 HEADERS = [os.path.join(CSRC, "rn_common.h"), os.path.join(HERE, "..", "include", "rn_hip.h")]
 
 

@@ -486,6 +486,12 @@ def _zeros_like_cached(n, ref):
     return z
 
 
+def _direct_conv_ok(inp, conv_w, stride, padding):
+    return (os.environ.get("RN_NO_DIRECT_CONV", "0") != "1" and inp.dtype == torch.float32 and tuple(conv_w.shape[2:]) == (3, 3)
+            and tuple(stride) == (2, 2) and tuple(padding) == (1, 1) and conv_w.shape[0] == 24 and conv_w.shape[1] in (3, 24)
+            and inp.shape[2] % 2 == 0 and inp.shape[3] % 2 == 0)
+
+
 class ConvBNReLUFunction(torch.autograd.Function):
     """relu(batch_norm(conv2d(x))) of the reference's ConvInputModel block (model.py:22-35): the convolution is
     MIOpen's (aten.convolution, run WITHOUT its bias), batch norm + ReLU and their backward are the fused
@@ -495,8 +501,16 @@ class ConvBNReLUFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inp, conv_w, conv_b, gamma, beta, running_mean, running_var, num_batches, training, momentum, eps, stride, padding):
         H._dev(inp, "img")
-        x = torch.ops.aten.convolution(inp, conv_w, None, stride, padding, (1, 1), False, (0, 0), 1)
-        x = x.contiguous()
+        direct = _direct_conv_ok(inp, conv_w, stride, padding)
+        if direct:                                   # rn_conv.hip: direct 3x3 / stride-2 kernel
+            inp = inp.contiguous()
+            wc = conv_w.detach().contiguous()
+            x = torch.empty(inp.shape[0], conv_w.shape[0], inp.shape[2] // 2, inp.shape[3] // 2, dtype=torch.float32, device=inp.device)
+            H.conv3x3s2_fwd(inp, wc, x)
+        else:
+            x = torch.ops.aten.convolution(inp, conv_w, None, stride, padding, (1, 1), False, (0, 0), 1)
+            x = x.contiguous()
+        ctx.direct = direct
         Cc = x.shape[1]
         y = torch.empty_like(x)
         f32 = dict(dtype=torch.float32, device=x.device)
@@ -543,7 +557,11 @@ class ConvBNReLUFunction(torch.autograd.Function):
                 torch.cuda.current_stream().wait_stream(side)
                 keep.clear()
             torch.autograd.Variable._execution_engine.queue_callback(_join)
-            din = conv_bwd([True, False, False])[0]
+            if ctx.direct and inp.shape[1] == 24:
+                din = torch.empty_like(inp)
+                H.conv3x3s2_bwd_data(dx, conv_w.detach().contiguous(), din)
+            else:
+                din = conv_bwd([True, False, False])[0]
         else:
             din, dw, _ = conv_bwd([ctx.needs_input_grad[0], True, False])
         db = _zeros_like_cached(conv_w.shape[0], conv_w) if ctx.has_bias else None

@@ -65,6 +65,8 @@ SIGNATURES = {
     "rn_clip_adam_chunk": (_I, []),
     "rn_clip_adam_ws_bytes": (_Z, []),
     "rn_clip_adam_step": (_I, [_P, _I, _P, _P, _P, _L, _P] + [C.c_float] * 7 + [_I, _P, _P]),
+    "rn_conv3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_conv3x3s2_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_bn_relu_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_bn_relu_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _I, _I, _P]),
     "rn_bn_relu_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -467,3 +469,17 @@ def pair_features(A, lda, F, code, B, npairs):
     _check(lib.rn_pair_features(A.data_ptr(), lda, F, maxf.data_ptr(), avgf.data_ptr(), ws.data_ptr(), code, B, npairs, _stream()),
            "rn_pair_features")
     return maxf, avgf
+
+
+# ------------------------------------------------------------------ conv stack: 3x3 / stride-2 convolutions
+@_timed("conv")
+def conv3x3s2_fwd(x, w, y):
+    N, Cin, Hh, Ww = x.shape
+    _check(load().rn_conv3x3s2_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), N, Cin, w.shape[0], Hh, Ww, _stream()), "rn_conv3x3s2_fwd")
+
+
+@_timed("conv")
+def conv3x3s2_bwd_data(dy, w, dx):
+    N, Cin, Hh, Ww = dx.shape
+    _check(load().rn_conv3x3s2_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), N, Cin, w.shape[0], Hh, Ww, _stream()),
+           "rn_conv3x3s2_bwd_data")

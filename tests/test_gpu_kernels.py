@@ -611,7 +611,9 @@ def test_conv_bn_relu_block(N, hw):
         if na.startswith("conv") and na.endswith("bias"):
             assert np.all(gb == 0) and np.abs(ga).max() <= 1e-3 * max(np.abs(a._modules[na.split(".")[0]].weight.grad.cpu().numpy()).max(), 1e-30)
         else:
-            assert rel(gb, ga) <= 5 * F32_TOL, (na, rel(gb, ga))
+            # a 1e-6 difference in a conv output flips the ReLU of elements sitting at zero: the weight gradients of the
+            # early layers see it amplified (max-norm 5e-3; measured 2.7e-3 with the direct convolutions)
+            assert rel(gb, ga) <= 5e-3, (na, rel(gb, ga))
     for (na, ba), (nb, bb) in zip(a.named_buffers(), b.named_buffers()):
         assert rel(bb.float().cpu().numpy(), ba.float().cpu().numpy()) <= F32_TOL, na
     # evaluation mode: running statistics
@@ -651,3 +653,22 @@ def test_question_lstm(B, T):
         assert rel(pb.grad.cpu().numpy(), pa.grad.cpu().numpy()) <= 5 * F32_TOL, na
     with torch.no_grad():
         assert rel(b(q).cpu().numpy(), ha.detach().cpu().numpy()) <= F32_TOL     # inference entry (nothing saved)
+
+
+# ----------------------------------------------------------------------------- conv stack: direct 3x3 / stride-2 convolutions
+@pytest.mark.parametrize("N,Cin,hw", [(64, 3, 128), (64, 24, 64), (3, 24, 16), (2, 3, 34)])
+def test_conv3x3s2_direct(H, N, Cin, hw):
+    """rn_conv.hip against torch's conv2d (MIOpen) and its input gradient: fp32, summation order only."""
+    x = dev(formula.hash_uniform((N, Cin, hw, hw), 950, -1, 1))
+    w = dev(formula.hash_uniform((24, Cin, 3, 3), 951, -0.3, 0.3))
+    y = torch.empty(N, 24, hw // 2, hw // 2, device="cuda")
+    H.conv3x3s2_fwd(x, w, y)
+    ref = torch.nn.functional.conv2d(x, w, None, stride=2, padding=1)
+    assert rel(y.cpu().numpy(), ref.cpu().numpy()) <= F32_TOL
+    if Cin == 24:
+        dy = dev(formula.hash_uniform((N, 24, hw // 2, hw // 2), 952, -1, 1))
+        dx = torch.full_like(x, float("nan"))
+        H.conv3x3s2_bwd_data(dy, w, dx)
+        xr = x.clone().requires_grad_(True)
+        torch.nn.functional.conv2d(xr, w, None, stride=2, padding=1).backward(dy)
+        assert rel(dx.cpu().numpy(), xr.grad.cpu().numpy()) <= F32_TOL
