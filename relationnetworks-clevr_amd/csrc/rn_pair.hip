@@ -403,18 +403,30 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const T* __restrict__ 
   }
 }
 
-// Ri = sum over the j-block partial slabs (element-wise, fully parallel)
+// Ri = sum over the j-block partial slabs; Rq[b] = sum_i Ri[b,i].  Block = (question b, group of 64 float4 columns);
+// thread = (i-lane of 4, float4 column): walks i = lane, lane + 4, ... (fixed order), the 4 i-lanes combine their Rq
+// partials through LDS -> deterministic.
 __global__ __launch_bounds__(256) void pair_reduce_finish_kernel(const f32x4* __restrict__ ri_part, long part_stride4, int njb,
-                                                                 f32x4* __restrict__ Ri, long total4) {
-  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total4; g += (long)gridDim.x * 256) {
-    f32x4 r = ri_part[g];
-    for (int p = 1; p < njb; ++p) r += ri_part[p * part_stride4 + g];
-    Ri[g] = r;
+                                                                 f32x4* __restrict__ Ri, f32x4* __restrict__ Rq, int n, int G4) {
+  __shared__ f32x4 red[3][64];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), il = threadIdx.x >> 6;
+  f32x4 q = {0.f, 0.f, 0.f, 0.f};
+  if (c < G4) {
+    for (int i = il; i < n; i += 4) {
+      const long o = ((long)b * n + i) * G4 + c;
+      f32x4 r = ri_part[o];
+      for (int p = 1; p < njb; ++p) r += ri_part[p * part_stride4 + o];
+      if (Ri) Ri[o] = r;
+      q += r;
+    }
   }
+  if (il > 0) red[il - 1][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (il == 0 && c < G4 && Rq) Rq[(long)b * G4 + c] = ((q + red[0][threadIdx.x]) + red[1][threadIdx.x]) + red[2][threadIdx.x];
 }
 
 extern "C" size_t rn_pair_reduce_ws_bytes(int B, int n, int G) {
-  return ((size_t)cdiv(n, 16) + 1) * B * n * G * sizeof(float);      // Ri partials, one slab per block of 16 j, + Ri itself
+  return (size_t)cdiv(n, 16) * B * n * G * sizeof(float);            // Ri partials, one slab per block of 16 j
 }
 
 extern "C" int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri, float* Rq, void* ws, int dtype, int B,
@@ -441,17 +453,10 @@ extern "C" int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri
 #undef RN_PR
   RN_LAUNCH_CHECK("rn_pair_reduce_bwd");
   if (Ri || Rq) {
-    float* ri = Ri ? Ri : part + (size_t)njb * part_stride;
-    const long total4 = part_stride / 4;
-    int blocks = cdiv(total4, 256);
-    if (blocks > 4096) blocks = 4096;
-    pair_reduce_finish_kernel<<<blocks, 256, 0, s>>>((const f32x4*)part, total4, njb, (f32x4*)ri, total4);
+    RN_CHECK_ARG(G % 4 == 0, "rn_pair_reduce_bwd: G=%d must be a multiple of 4", G);
+    const int G4 = G / 4;
+    pair_reduce_finish_kernel<<<dim3(cdiv(G4, 64), B), 256, 0, s>>>((const f32x4*)part, part_stride / 4, njb, (f32x4*)Ri, (f32x4*)Rq, n, G4);
     RN_LAUNCH_CHECK("rn_pair_reduce_bwd(finish)");
-    if (Rq) {
-      // Rq[b] = sum_i Ri[b,i]: fp32 segmented sum over n rows
-      RN_CHECK_ARG(G % 4 == 0 && G / 4 <= 256 && n <= 256, "rn_pair_reduce_bwd: G=%d / n=%d unsupported for Rq", G, n);
-      return segsum_launch(ri, G, Rq, nullptr, RN_F32, B, n, G, s, "rn_pair_reduce_bwd(Rq)");
-    }
   }
   return 0;
 }
