@@ -245,6 +245,12 @@ int rn_f_phi_bwd(const float* gout, const float* out, const float* f2, const flo
                  const float* W2, const float* W3, const float* mask, float* dW1, float* db1, float* dW2, float* db2,
                  float* dW3, float* db3, float* dxg, void* ws, int B, int G, int F1, int F2, int A, void* stream);
 
+/* F.nll_loss(log_probs, label), mean reduction (train.py:41): loss[0] = -mean_b logp[b, label[b]];
+ * backward: gout (B, A) = -gloss[0] / B at (b, label[b]), 0 elsewhere (the whole tensor is written).
+ * label: int64 (B), values clamped to [0, A). */
+int rn_nll_mean_fwd(const float* logp, const long long* label, float* loss, int B, int A, void* stream);
+int rn_nll_mean_bwd(const long long* label, const float* gloss, float* gout, int B, int A, void* stream);
+
 /* Tail of the training step (reference train.py:45-48) on the flat gradient buffer of the data-parallel bucket:
  * torch.nn.utils.clip_grad_norm_(params, max_norm) (max_norm <= 0: no clip) followed by torch.optim.Adam
  * (amsgrad=False, coupled weight_decay) in two launches.  g / m / v: flat fp32 buffers of n elements; `chunks`:

@@ -462,3 +462,47 @@ extern "C" int rn_clip_adam_step(const void* chunks, int nchunks, float* g, floa
   RN_LAUNCH_CHECK("rn_clip_adam_step");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ mean NLL loss
+// F.nll_loss(log_probs, label) of the training loop (train.py:41), mean reduction: forward one launch, backward one
+// launch that writes the WHOLE (B, A) gradient (-g / B at the label, 0 elsewhere) -- the stock path spends four launches
+// (gather-reduce, two fills, scatter) on the critical path between the forward and the backward chain.
+__global__ __launch_bounds__(256) void nll_mean_fwd_kernel(const float* __restrict__ logp, const long long* __restrict__ label,
+                                                           float* __restrict__ loss, int B, int A) {
+  __shared__ double red[4];
+  double a = 0.0;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    long long y = label[b];
+    y = y < 0 ? 0 : (y >= A ? A - 1 : y);
+    a -= (double)logp[(long)b * A + y];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / B);
+}
+__global__ __launch_bounds__(256) void nll_mean_bwd_kernel(const long long* __restrict__ label, const float* __restrict__ gloss,
+                                                           float* __restrict__ gout, int B, int A) {
+  const float g = -gloss[0] / (float)B;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)B * A; i += (long)gridDim.x * 256) {
+    const int b = (int)(i / A), c = (int)(i - (long)b * A);
+    long long y = label[b];
+    y = y < 0 ? 0 : (y >= A ? A - 1 : y);
+    gout[i] = (c == y) ? g : 0.f;
+  }
+}
+extern "C" int rn_nll_mean_fwd(const float* logp, const long long* label, float* loss, int B, int A, void* stream) {
+  RN_CHECK_ARG(logp && label && loss && B > 0 && A > 0, "rn_nll_mean_fwd: bad pointer/size");
+  nll_mean_fwd_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logp, label, loss, B, A);
+  RN_LAUNCH_CHECK("rn_nll_mean_fwd");
+  return 0;
+}
+extern "C" int rn_nll_mean_bwd(const long long* label, const float* gloss, float* gout, int B, int A, void* stream) {
+  RN_CHECK_ARG(label && gloss && gout && B > 0 && A > 0, "rn_nll_mean_bwd: bad pointer/size");
+  int blocks = cdiv((long)B * A, 256);
+  if (blocks > 256) blocks = 256;
+  nll_mean_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(label, gloss, gout, B, A);
+  RN_LAUNCH_CHECK("rn_nll_mean_bwd");
+  return 0;
+}

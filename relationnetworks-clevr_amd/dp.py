@@ -19,6 +19,11 @@ import os
 import torch
 import torch.distributed as dist
 
+try:
+    from . import functional as RF
+except ImportError:                                   # imported through the top-level shim
+    from relationnetworks_clevr_amd import functional as RF          # type: ignore
+
 
 class FlatGradBucket:
     """One contiguous fp32 buffer holding every parameter's gradient (the all-reduce message).
@@ -186,7 +191,7 @@ class DataParallelTrainer:
     def _fwd_bwd(self, img, qst, label):
         self.bucket.detach_()
         out = self.model(img, qst)
-        loss = torch.nn.functional.nll_loss(out, label)
+        loss = RF.nll_loss_mean(out, label)                # F.nll_loss (mean), one launch each way on the GPU
         loss.backward()
         self.bucket.gather_()
         return loss

@@ -620,3 +620,32 @@ class QuestionLSTMFunction(torch.autograd.Function):
             demb = torch.empty(ctx.vocab, xs.shape[2], dtype=torch.float32, device=dg.device)
             H.embedding_bwd(idx, dx, demb)
         return None, demb, dW_ih, dW_hh, db, db
+
+
+class NllMeanFunction(torch.autograd.Function):
+    """F.nll_loss(log_probs, label) with mean reduction (train.py:41): one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, logp, label):
+        H._dev(logp, "log-probs")
+        logp = logp.float().contiguous()
+        label = label.long().contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=logp.device)
+        H.nll_mean_fwd(logp, label, loss)
+        ctx.save_for_backward(label)
+        ctx.shape = logp.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (label,) = ctx.saved_tensors
+        gout = torch.empty(ctx.shape, dtype=torch.float32, device=label.device)
+        H.nll_mean_bwd(label, gloss.float().reshape(1).contiguous(), gout)
+        return gout, None
+
+
+def nll_loss_mean(logp, label):
+    """Drop-in for F.nll_loss(logp, label) (mean) on GPU tensors; falls back to torch elsewhere."""
+    if logp.is_cuda and logp.dim() == 2 and os.environ.get("RN_NO_FUSED_NLL", "0") != "1":
+        return NllMeanFunction.apply(logp, label)
+    return torch.nn.functional.nll_loss(logp, label)

@@ -62,6 +62,8 @@ SIGNATURES = {
     "rn_lstm_fwd": (_I, [_P] * 10 + [_I] * 5 + [_P]),
     "rn_lstm_bwd": (_I, [_P] * 5 + [_I] * 3 + [_P]),
     "rn_embedding_bwd": (_I, [_P] * 3 + [_I] * 4 + [_P]),
+    "rn_nll_mean_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
+    "rn_nll_mean_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "rn_clip_adam_chunk": (_I, []),
     "rn_clip_adam_ws_bytes": (_Z, []),
     "rn_clip_adam_step": (_I, [_P, _I, _P, _P, _P, _L, _P] + [C.c_float] * 7 + [_I, _P, _P]),
@@ -483,3 +485,12 @@ def conv3x3s2_bwd_data(dy, w, dx):
     N, Cin, Hh, Ww = dx.shape
     _check(load().rn_conv3x3s2_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), N, Cin, w.shape[0], Hh, Ww, _stream()),
            "rn_conv3x3s2_bwd_data")
+
+
+# ------------------------------------------------------------------ mean NLL loss
+def nll_mean_fwd(logp, label, loss):
+    _check(load().rn_nll_mean_fwd(logp.data_ptr(), label.data_ptr(), loss.data_ptr(), logp.shape[0], logp.shape[1], _stream()), "rn_nll_mean_fwd")
+
+
+def nll_mean_bwd(label, gloss, gout):
+    _check(load().rn_nll_mean_bwd(label.data_ptr(), gloss.data_ptr(), gout.data_ptr(), gout.shape[0], gout.shape[1], _stream()), "rn_nll_mean_bwd")

@@ -672,3 +672,17 @@ def test_conv3x3s2_direct(H, N, Cin, hw):
         xr = x.clone().requires_grad_(True)
         torch.nn.functional.conv2d(xr, w, None, stride=2, padding=1).backward(dy)
         assert rel(dx.cpu().numpy(), xr.grad.cpu().numpy()) <= F32_TOL
+
+
+# ----------------------------------------------------------------------------- mean NLL loss
+def test_nll_mean():
+    """NllMeanFunction against F.nll_loss (mean): value and gradient (exact up to the final rounding)."""
+    from relationnetworks_clevr_amd import functional as RF
+    torch.manual_seed(3)
+    logp = torch.log_softmax(torch.randn(64, 28, device="cuda"), 1)
+    y = torch.randint(0, 28, (64,), device="cuda")
+    a = logp.clone().requires_grad_(True); b = logp.clone().requires_grad_(True)
+    la = torch.nn.functional.nll_loss(a, y); lb = RF.nll_loss_mean(b, y)
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la))
+    (la * 3).backward(); (lb * 3).backward()
+    assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=0)
