@@ -196,6 +196,11 @@ size_t rn_pair_reduce_ws_bytes(int B, int n, int G);
 int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri, float* Rq, void* ws, int dtype, int B,
                        int n, int G, void* stream);
 
+/* Input gradients of the pair expansion from the reductions, one launch (question injected at layer 0; W0 (N, 2k+Q) fp32):
+ *   dx (B, n, k) contiguous = Rj W0[:, 0:k] + Ri W0[:, k:2k];   dq (B, Q) = Rq W0[:, 2k:2k+Q]   (Q == 0: Rq / dq may be NULL). */
+int rn_pair_dx_dq(const float* Rj, const float* Ri, const float* Rq, const float* W0, float* dx, float* dq, int B, int n, int k,
+                  int Q, int N, void* stream);
+
 /* Layer-0 weight gradient from the pair reductions (the question injected at layer 0: P = [x_j | x_i | q]):
  *   dW0[:, 0:k] = Rj^T X,  dW0[:, k:2k] = Ri^T X,  dW0[:, 2k:2k+Q] = Rq^T q,  db0 = sum_b Rq[b]
  * with X = x viewed as (B*n, k) -- identical to dZ_0^T P (rounding aside: x enters in fp32 instead of P's storage
@@ -308,6 +313,10 @@ int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const float* gamm
 
 /* Diagnostics used by the GPU tests: raw lane mapping of ds_read_b64_tr_b16. */
 int rn_probe_tr16(const unsigned short* in4096, unsigned short* out256, void* stream);
+
+/* Diagnostics: a one-thread kernel that stores the constant-rate wall clock (wall_clock64) into *slot, in stream order.
+ * Captured between the kernels of the step's hipGraph it yields a concurrent multi-stream timeline (tools/step_timeline.py). */
+int rn_debug_stamp(unsigned long long* slot, void* stream);
 
 #ifdef __cplusplus
 }

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const T* __restrict__ 
   constexpr int CH = 4;                                               // columns per thread: 64 Rj accumulators, 16 small loads in flight
   constexpr int JB = 16;
   typedef typename Piece4<T>::Raw Raw;
-  extern __shared__ __attribute__((aligned(16))) float red[];        // [NIL-1][JB][G] fp32 (Rj hand-over)
+  extern __shared__ __attribute__((aligned(16))) float red[];        // [JB][G] fp32 (Rj hand-over, one i-lane per round)
   const int cpr = G / CH;                                             // threads per row (<= 256)
   const int NIL = 256 / cpr;                                          // i-lanes
   const int t = threadIdx.x, c = t % cpr, il = t / cpr;
@@ -382,20 +382,26 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const T* __restrict__ 
     }
   }
   if constexpr (WANT_RJ) {
-    // i-lanes 1 .. NIL-1 hand their sums to lane 0 through LDS
-    if (il >= 1 && il < NIL) {
+    // i-lanes 1 .. NIL-1 hand their sums to lane 0 through LDS, one lane per round through ONE (JB x G) fp32 buffer:
+    // 16 KB instead of (NIL-1) x 16 KB keeps the workgroup resident NEXT TO a wgrad workgroup (128 KB of the CU's
+    // 160 KB) -- with the 48-KB version this kernel only ran in the gaps between the wgrad launches of the side stream.
+    for (int l = 1; l < NIL; ++l) {
+      if (il == l) {
 #pragma unroll
-      for (int j = 0; j < JB; ++j)
-        *reinterpret_cast<f32x4*>(red + ((long)(il - 1) * JB + j) * G + c * CH) = f32x4{rj[j][0], rj[j][1], rj[j][2], rj[j][3]};
-    }
-    __syncthreads();
-    if (il == 0) {
-      for (int l = 0; l + 1 < NIL; ++l)
+        for (int j = 0; j < JB; ++j)
+          *reinterpret_cast<f32x4*>(red + (long)j * G + c * CH) = f32x4{rj[j][0], rj[j][1], rj[j][2], rj[j][3]};
+      }
+      __syncthreads();
+      if (il == 0) {
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
-          const f32x4 r = *reinterpret_cast<const f32x4*>(red + ((long)l * JB + j) * G + c * CH);
+          const f32x4 r = *reinterpret_cast<const f32x4*>(red + (long)j * G + c * CH);
           rj[j][0] += r[0]; rj[j][1] += r[1]; rj[j][2] += r[2]; rj[j][3] += r[3];
         }
+      }
+      __syncthreads();
+    }
+    if (il == 0) {
 #pragma unroll
       for (int j = 0; j < JB; ++j)
         if (j < nj) *reinterpret_cast<f32x4*>(Rj + ((long)b * n + j0 + j) * G + c * CH) = f32x4{rj[j][0], rj[j][1], rj[j][2], rj[j][3]};
@@ -437,11 +443,11 @@ extern "C" int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri
   RN_CHECK_ARG(G % CH == 0 && G / CH <= 256 && 256 % (G / CH) == 0 && lddz % (dtype == RN_BF16 ? 8 : 4) == 0, "rn_pair_reduce_bwd: G=%d unsupported", G);
   RN_CHECK_ARG(((uintptr_t)dZ | (uintptr_t)Rj | (uintptr_t)Ri | (uintptr_t)Rq | (uintptr_t)ws) % 16 == 0, "rn_pair_reduce_bwd: pointers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  const int njb = cdiv(n, 16), NIL = 256 / (G / CH);
+  const int njb = cdiv(n, 16);
   const long part_stride = (long)B * n * G;
   float* part = (float*)ws;
   dim3 grid(njb, B);
-  const size_t shm = Rj ? (size_t)(NIL > 1 ? NIL - 1 : 1) * 16 * G * sizeof(float) : 0;
+  const size_t shm = Rj ? (size_t)16 * G * sizeof(float) : 0;
   RN_CHECK_ARG(shm <= 160 * 1024, "rn_pair_reduce_bwd: G=%d needs %zu bytes of LDS", G, shm);
 #define RN_PR(T, RJ)                                                                                                   \
   do {                                                                                                                 \
@@ -469,7 +475,7 @@ extern "C" int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri
 // Kernel 1: workgroup (feature block of 32, part j|i, row split): partial (32 x k) products over 256 rows, X tile in LDS;
 // kernel 2: fixed-order sum of the row splits + the (tiny) question part and the bias.  Deterministic.
 namespace {
-constexpr int W0_RS = 256;          // rows per split
+constexpr int W0_RS = 192;          // rows per split (24 KB of LDS: fits next to a 128-KB wgrad workgroup)
 constexpr int W0_CMAX = 32;         // k <= 32 columns per x part
 }
 __global__ __launch_bounds__(256) void wgrad0_part_kernel(const float* __restrict__ Rj, const float* __restrict__ Ri,
@@ -630,5 +636,80 @@ extern "C" int rn_pair_features(const void* A, int lda, int F, float* maxf, floa
 #undef RN_PF
   pair_features_finish_kernel<<<B, 256, 0, s>>>(pmax, psum, maxf, avgf, F, S, 1.f / (float)npairs);
   RN_LAUNCH_CHECK("rn_pair_features");
+  return 0;
+}
+
+// ------------------------------------------ input gradients of the pair expansion from the reductions
+// dx[b,j,:] = Rj[b,j,:] W0[:, 0:k] + Ri[b,j,:] W0[:, k:2k]     dq[b,:] = Rq[b,:] W0[:, 2k:2k+Q]      (W0: (N, kt) row-major)
+// One launch instead of three small GEMMs on the critical path of the backward pass (dx feeds the conv stack, dq the
+// question encoder).  Block = a 16-row x 32-column output tile (x blocks: both products; q blocks: one); the feature
+// axis is walked in chunks of 64 staged in LDS, the next chunk's global loads issued before the current chunk's FMAs.
+constexpr int DXQ_FC = 64;
+__global__ __launch_bounds__(512) void pair_dx_dq_kernel(const float* __restrict__ Rj, const float* __restrict__ Ri,
+                                                         const float* __restrict__ Rq, const float* __restrict__ W0, int kt,
+                                                         float* __restrict__ dx, float* __restrict__ dq, int rows, int B, int k,
+                                                         int Q, int N, int xblocks, int qcol_tiles) {
+  __shared__ float rs[2][16][DXQ_FC];
+  __shared__ float ws[2][DXQ_FC][32];
+  const int t = threadIdx.x;
+  const float *R1, *R2;
+  float* out;
+  int off1, off2, ncols, nrows, r0, ld;
+  if ((int)blockIdx.x < xblocks) {
+    R1 = Rj; R2 = Ri; off1 = 0; off2 = k; ncols = k; nrows = rows; r0 = blockIdx.x * 16; out = dx; ld = k;
+  } else {
+    const int qb = blockIdx.x - xblocks, ct = qb % qcol_tiles;
+    R1 = Rq; R2 = nullptr; off1 = 2 * k + 32 * ct; off2 = 0; ncols = min(32, Q - 32 * ct); nrows = B; r0 = (qb / qcol_tiles) * 16;
+    out = dq + 32 * ct; ld = Q;
+  }
+  // staging roles: rows -> 2 floats per thread per operand, weights -> 4 floats per thread per operand
+  const int sr = t >> 5, sf = (t & 31) * 2;          // rs[.][sr][sf..sf+1]
+  const int wc = t & 31, wf = t >> 5;                // ws[.][wf + 16 u][wc], u = 0..3
+  const bool srow_ok = r0 + sr < nrows, wcol_ok = wc < ncols;
+  float pr1[2], pr2[2], pw1[4], pw2[4];
+  auto fetch = [&](int f0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int f = f0 + sf + u;
+      const bool ok = srow_ok && f < N;
+      pr1[u] = ok ? R1[(long)(r0 + sr) * N + f] : 0.f;
+      pr2[u] = (ok && R2) ? R2[(long)(r0 + sr) * N + f] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = f0 + wf + 16 * u;
+      const bool ok = wcol_ok && f < N;
+      pw1[u] = ok ? W0[(long)f * kt + off1 + wc] : 0.f;
+      pw2[u] = (ok && R2) ? W0[(long)f * kt + off2 + wc] : 0.f;
+    }
+  };
+  const int r = t >> 5, c = t & 31;
+  float a0 = 0.f, a1 = 0.f;
+  fetch(0);
+  for (int f0 = 0; f0 < N; f0 += DXQ_FC) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { rs[0][sr][sf + u] = pr1[u]; rs[1][sr][sf + u] = pr2[u]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { ws[0][wf + 16 * u][wc] = pw1[u]; ws[1][wf + 16 * u][wc] = pw2[u]; }
+    __syncthreads();
+    if (f0 + DXQ_FC < N) fetch(f0 + DXQ_FC);
+#pragma unroll 16
+    for (int f = 0; f < DXQ_FC; ++f) {
+      a0 = fmaf(rs[0][r][f], ws[0][f][c], a0);
+      a1 = fmaf(rs[1][r][f], ws[1][f][c], a1);
+    }
+  }
+  if (c < ncols && r0 + r < nrows) out[(long)(r0 + r) * ld + c] = a0 + a1;
+}
+
+extern "C" int rn_pair_dx_dq(const float* Rj, const float* Ri, const float* Rq, const float* W0, float* dx, float* dq, int B, int n,
+                             int k, int Q, int N, void* stream) {
+  RN_CHECK_ARG(Rj && Ri && W0 && dx && B > 0 && n > 0 && N > 0, "rn_pair_dx_dq: bad pointer/size");
+  RN_CHECK_ARG(k > 0 && k <= 32 && (Q == 0 || (Rq && dq)), "rn_pair_dx_dq: k=%d (<= 32), Q=%d unsupported", k, Q);
+  const int rows = B * n, xblocks = cdiv(rows, 16), qct = cdiv(Q, 32), qblocks = Q ? cdiv(B, 16) * qct : 0;
+  pair_dx_dq_kernel<<<xblocks + qblocks, 512, 0, (hipStream_t)stream>>>(Rj, Ri, Rq, W0, 2 * k + Q, dx, dq, rows, B, k, Q, N, xblocks,
+                                                                         qct ? qct : 1);
+  RN_LAUNCH_CHECK("rn_pair_dx_dq");
   return 0;
 }

@@ -153,13 +153,11 @@ extern "C" int rn_colsum_f32(const float* src, long ld, float* out, int R, int C
 namespace {
 constexpr int FP_RB = 4;          // rows per workgroup
 constexpr int FP_MAXW = 1024;     // widest activation the LDS staging holds
+constexpr int FP_KS = 4;          // k-slices per output feature with transposed weights (block = FP_KS * 256 threads)
+static_assert(FP_KS == FP_RB, "the slice-k thread finalises row k");
 
-// out[r][f] = bias[f] + sum_k W[f][k] * in[r][k]; thread = output feature; the rows' inputs sit in LDS
-__device__ __forceinline__ void fp_layer_rows(const float* __restrict__ W, const float* __restrict__ bias, const float* in_s, int K,
-                                              int f, float (&acc)[FP_RB]) {
-  const float b = bias[f];
-#pragma unroll
-  for (int r = 0; r < FP_RB; ++r) acc[r] = b;
+// acc[r] += sum_k W[f][k] * in[r][k]; thread = output feature, W (out, in) row-major; the rows' inputs sit in LDS
+__device__ __forceinline__ void fp_rows(const float* __restrict__ W, const float* in_s, int K, int f, float (&acc)[FP_RB]) {
   const float* wr = W + (long)f * K;
   for (int k = 0; k < K; k += 4) {
     const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
@@ -170,18 +168,16 @@ __device__ __forceinline__ void fp_layer_rows(const float* __restrict__ W, const
     }
   }
 }
-// out[r][j] = sum_i in[r][i] * W[i][j]; thread = column j (coalesced over the workgroup).  16 independent loads are
-// issued before their FMAs: the loop is a chain of L2 round trips otherwise.
-__device__ __forceinline__ void fp_layer_cols(const float* __restrict__ W, const float* in_s, int I, int J, int j, float (&acc)[FP_RB]) {
+// acc[r] += sum_{i0 <= i < i1} in[r][i] * W[i][j]; thread = column j (coalesced over the workgroup), W (in, out)
+// row-major.  The loop is a chain of L2 round trips: 32 independent loads are issued before their FMAs.
+__device__ __forceinline__ void fp_cols(const float* __restrict__ W, const float* in_s, int i0, int i1, int J, int j, float (&acc)[FP_RB]) {
+  int i = i0;
+  for (; i + 32 <= i1; i += 32) {
+    float w[32];
 #pragma unroll
-  for (int r = 0; r < FP_RB; ++r) acc[r] = 0.f;
-  int i = 0;
-  for (; i + 16 <= I; i += 16) {
-    float w[16];
+    for (int u = 0; u < 32; ++u) w[u] = W[(long)(i + u) * J + j];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) w[u] = W[(long)(i + u) * J + j];
-#pragma unroll
-    for (int u = 0; u < 16; u += 4) {
+    for (int u = 0; u < 32; u += 4) {
 #pragma unroll
       for (int r = 0; r < FP_RB; ++r) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(in_s + r * FP_MAXW + i + u);
@@ -189,67 +185,87 @@ __device__ __forceinline__ void fp_layer_cols(const float* __restrict__ W, const
       }
     }
   }
-  for (; i < I; ++i) {
+  for (; i + 4 <= i1; i += 4) {
+    float w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] = W[(long)(i + u) * J + j];
+#pragma unroll
+    for (int r = 0; r < FP_RB; ++r) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(in_s + r * FP_MAXW + i);
+      acc[r] = fmaf(x[3], w[3], fmaf(x[2], w[2], fmaf(x[1], w[1], fmaf(x[0], w[0], acc[r]))));
+    }
+  }
+  for (; i < i1; ++i) {
     const float w = W[(long)i * J + j];
 #pragma unroll
     for (int r = 0; r < FP_RB; ++r) acc[r] = fmaf(in_s[r * FP_MAXW + i], w, acc[r]);
+  }
+}
+
+// One layer on the block's FP_RB rows: v[r][f] = bias[f] + sum_k in[r][k] * Wop[k][f], handed to epi(r, f, v).
+// TR (transposed weights, (in, out) row-major): blockDim = FP_KS * 256, thread (ks, f) sums its quarter of k, the
+// partials meet in LDS and thread (ks, f) finalises row ks -- four times fewer dependent L2 round trips per layer.
+// !TR: blockDim = 256, thread = feature over the whole k range.
+template <bool TR, class Epi>
+__device__ __forceinline__ void fp_layer_pass(const float* __restrict__ W, const float* __restrict__ bias, const float* in_s, int K,
+                                              int N, float* red, Epi epi) {
+  const int tf = threadIdx.x & 255, ks = threadIdx.x >> 8;
+  for (int fb = 0; fb < N; fb += 256) {
+    const int f = fb + tf;
+    float acc[FP_RB];
+#pragma unroll
+    for (int r = 0; r < FP_RB; ++r) acc[r] = 0.f;
+    if constexpr (TR) {
+      const int chunk = ((K + FP_KS - 1) / FP_KS + 3) & ~3, i0 = min(K, ks * chunk), i1 = min(K, i0 + chunk);
+      if (f < N) fp_cols(W, in_s, i0, i1, N, f, acc);
+#pragma unroll
+      for (int r = 0; r < FP_RB; ++r) red[(ks * FP_RB + r) * 256 + tf] = acc[r];
+      __syncthreads();
+      if (f < N) {
+        float v = red[ks * 256 + tf];
+#pragma unroll
+        for (int q = 1; q < FP_KS; ++q) v += red[(q * FP_RB + ks) * 256 + tf];
+        epi(ks, f, v + (bias ? bias[f] : 0.f));
+      }
+      __syncthreads();
+    } else if (f < N) {
+      fp_rows(W, in_s, K, f, acc);
+      const float b = bias ? bias[f] : 0.f;
+#pragma unroll
+      for (int r = 0; r < FP_RB; ++r) epi(r, f, acc[r] + b);
+    }
   }
 }
 }  // namespace
 
 // TR: W_l are given TRANSPOSED, (in, out) row-major -- the thread-per-output-feature walk is then coalesced
 template <bool TR>
-__global__ __launch_bounds__(256) void f_phi_fwd_kernel(const float* __restrict__ xg, const float* __restrict__ W1,
-                                                        const float* __restrict__ b1, const float* __restrict__ W2,
-                                                        const float* __restrict__ b2, const float* __restrict__ W3,
-                                                        const float* __restrict__ b3, const float* __restrict__ mask,
-                                                        float* __restrict__ f1, float* __restrict__ f2, float* __restrict__ out,
-                                                        int B, int G, int F1, int F2, int A) {
-  auto layer = [&](const float* W, const float* bias, const float* in_s, int K, int N, int f, float (&acc)[FP_RB]) {
-    if constexpr (TR) {
-      fp_layer_cols(W, in_s, K, N, f, acc);
-      const float b = bias[f];
-#pragma unroll
-      for (int r = 0; r < FP_RB; ++r) acc[r] += b;
-    } else {
-      fp_layer_rows(W, bias, in_s, K, f, acc);
-    }
-  };
-  __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW];
+__global__ __launch_bounds__(TR ? FP_KS * 256 : 256) void f_phi_fwd_kernel(
+    const float* __restrict__ xg, const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+    const float* __restrict__ b2, const float* __restrict__ W3, const float* __restrict__ b3, const float* __restrict__ mask,
+    float* __restrict__ f1, float* __restrict__ f2, float* __restrict__ out, int B, int G, int F1, int F2, int A) {
+  __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW], red[FP_KS * FP_RB * 256];
   const int t = threadIdx.x, r0 = blockIdx.x * FP_RB;
-  for (int c = t; c < FP_RB * G; c += 256) {
+  for (int c = t; c < FP_RB * G; c += blockDim.x) {
     const int r = c / G, k = c - r * G;
     sa[r * FP_MAXW + k] = (r0 + r < B) ? xg[(long)(r0 + r) * G + k] : 0.f;
   }
   __syncthreads();
-  float acc[FP_RB];
-  for (int f = t; f < F1; f += 256) {
-    layer(W1, b1, sa, G, F1, f, acc);
-#pragma unroll
-    for (int r = 0; r < FP_RB; ++r) {
-      const float v = fmaxf(acc[r], 0.f);
-      sb[r * FP_MAXW + f] = v;
-      if (r0 + r < B) f1[(long)(r0 + r) * F1 + f] = v;
-    }
-  }
+  fp_layer_pass<TR>(W1, b1, sa, G, F1, red, [&](int r, int f, float z) {
+    const float v = fmaxf(z, 0.f);
+    sb[r * FP_MAXW + f] = v;
+    if (r0 + r < B) f1[(long)(r0 + r) * F1 + f] = v;
+  });
   __syncthreads();
-  for (int f = t; f < F2; f += 256) {
-    layer(W2, b2, sb, F1, F2, f, acc);
-#pragma unroll
-    for (int r = 0; r < FP_RB; ++r) {
-      const bool ok = r0 + r < B;
-      const float m = (mask && ok) ? mask[(long)(r0 + r) * F2 + f] : 1.f;
-      const float v = fmaxf(acc[r] * m, 0.f);
-      sa[r * FP_MAXW + f] = v;
-      if (ok) f2[(long)(r0 + r) * F2 + f] = v;
-    }
-  }
+  fp_layer_pass<TR>(W2, b2, sb, F1, F2, red, [&](int r, int f, float z) {
+    const bool ok = r0 + r < B;
+    const float m = (mask && ok) ? mask[(long)(r0 + r) * F2 + f] : 1.f;
+    const float v = fmaxf(z * m, 0.f);
+    sa[r * FP_MAXW + f] = v;
+    if (ok) f2[(long)(r0 + r) * F2 + f] = v;
+  });
   __syncthreads();
-  for (int f = t; f < A; f += 256) {
-    layer(W3, b3, sa, F2, A, f, acc);
-#pragma unroll
-    for (int r = 0; r < FP_RB; ++r) sb[r * FP_MAXW + f] = acc[r];
-  }
+  fp_layer_pass<TR>(W3, b3, sa, F2, A, red, [&](int r, int f, float z) { sb[r * FP_MAXW + f] = z; });
   __syncthreads();
   if (t < FP_RB && r0 + t < B) {                       // log_softmax of one row (A <= 1024 logits in LDS)
     const float* z = sb + t * FP_MAXW;
@@ -262,13 +278,14 @@ __global__ __launch_bounds__(256) void f_phi_fwd_kernel(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void f_phi_bwd_dz_kernel(const float* __restrict__ gout, const float* __restrict__ out,
+// W_l natural (out, in) row-major: exactly the (in, out) operand of the backward products
+__global__ __launch_bounds__(FP_KS * 256) void f_phi_bwd_dz_kernel(const float* __restrict__ gout, const float* __restrict__ out,
                                                            const float* __restrict__ f2, const float* __restrict__ f1,
                                                            const float* __restrict__ W1, const float* __restrict__ W2,
                                                            const float* __restrict__ W3, const float* __restrict__ mask,
                                                            float* __restrict__ dz3, float* __restrict__ dz2, float* __restrict__ dz1,
                                                            float* __restrict__ dxg, int B, int G, int F1, int F2, int A) {
-  __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW];
+  __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW], red[FP_KS * FP_RB * 256];
   const int t = threadIdx.x, r0 = blockIdx.x * FP_RB;
   if (t < FP_RB) {
     const int b = r0 + t;
@@ -282,43 +299,29 @@ __global__ __launch_bounds__(256) void f_phi_bwd_dz_kernel(const float* __restri
     }
   }
   __syncthreads();
-  float acc[FP_RB];
-  for (int j = t; j < F2; j += 256) {
-    fp_layer_cols(W3, sa, A, F2, j, acc);
-#pragma unroll
-    for (int r = 0; r < FP_RB; ++r) {
-      const bool ok = r0 + r < B;
-      float v = 0.f;
-      if (ok) {
-        const long o = (long)(r0 + r) * F2 + j;
-        v = (f2[o] > 0.f) ? acc[r] * (mask ? mask[o] : 1.f) : 0.f;
-        dz2[o] = v;
-      }
-      sb[r * FP_MAXW + j] = v;
+  fp_layer_pass<true>(W3, nullptr, sa, A, F2, red, [&](int r, int j, float z) {
+    float v = 0.f;
+    if (r0 + r < B) {
+      const long o = (long)(r0 + r) * F2 + j;
+      v = (f2[o] > 0.f) ? z * (mask ? mask[o] : 1.f) : 0.f;
+      dz2[o] = v;
     }
-  }
+    sb[r * FP_MAXW + j] = v;
+  });
   __syncthreads();
-  for (int j = t; j < F1; j += 256) {
-    fp_layer_cols(W2, sb, F2, F1, j, acc);
-#pragma unroll
-    for (int r = 0; r < FP_RB; ++r) {
-      const bool ok = r0 + r < B;
-      float v = 0.f;
-      if (ok) {
-        const long o = (long)(r0 + r) * F1 + j;
-        v = (f1[o] > 0.f) ? acc[r] : 0.f;
-        dz1[o] = v;
-      }
-      sa[r * FP_MAXW + j] = v;
+  fp_layer_pass<true>(W2, nullptr, sb, F2, F1, red, [&](int r, int j, float z) {
+    float v = 0.f;
+    if (r0 + r < B) {
+      const long o = (long)(r0 + r) * F1 + j;
+      v = (f1[o] > 0.f) ? z : 0.f;
+      dz1[o] = v;
     }
-  }
+    sa[r * FP_MAXW + j] = v;
+  });
   __syncthreads();
-  for (int j = t; j < G; j += 256) {
-    fp_layer_cols(W1, sa, F1, G, j, acc);
-#pragma unroll
-    for (int r = 0; r < FP_RB; ++r)
-      if (r0 + r < B) dxg[(long)(r0 + r) * G + j] = acc[r];
-  }
+  fp_layer_pass<true>(W1, nullptr, sa, F1, G, red, [&](int r, int j, float z) {
+    if (r0 + r < B) dxg[(long)(r0 + r) * G + j] = z;
+  });
 }
 
 // block = one output row i of dW1 (F1 rows) | dW2 (F2) | dW3 (A): dW[i][j] = sum_b dz[b][i] * act[b][j]; db[i] = sum_b dz[b][i]
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(256) void f_phi_bwd_grads_kernel(const float* __res
   __syncthreads();
   for (int j = threadIdx.x; j < J; j += 256) {
     float s = 0.f;
+#pragma unroll 16
     for (int b = 0; b < B; ++b) s = fmaf(dzs[b], act[(long)b * J + j], s);
     dW[(long)i * J + j] = s;
   }
@@ -363,7 +367,7 @@ extern "C" int rn_f_phi_fwd(const float* xg, const float* W1, const float* b1, c
   RN_CHECK_ARG(xg && W1 && b1 && W2 && b2 && W3 && b3 && f1 && f2 && out, "rn_f_phi_fwd: NULL pointer");
   if (int rc = fp_check("rn_f_phi_fwd", B, G, F1, F2, A)) return rc;
   RN_CHECK_ARG(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)W3) % 16 == 0, "rn_f_phi_fwd: weights must be 16-byte aligned");
-  if (transposed) f_phi_fwd_kernel<true><<<cdiv(B, FP_RB), 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A);
+  if (transposed) f_phi_fwd_kernel<true><<<cdiv(B, FP_RB), FP_KS * 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A);
   else f_phi_fwd_kernel<false><<<cdiv(B, FP_RB), 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A);
   RN_LAUNCH_CHECK("rn_f_phi_fwd");
   return 0;
@@ -380,7 +384,7 @@ extern "C" int rn_f_phi_bwd(const float* gout, const float* out, const float* f2
   float* dz2 = dz1 + (size_t)B * F1;
   float* dz3 = dz2 + (size_t)B * F2;
   hipStream_t s = (hipStream_t)stream;
-  f_phi_bwd_dz_kernel<<<cdiv(B, FP_RB), 256, 0, s>>>(gout, out, f2, f1, W1, W2, W3, mask, dz3, dz2, dz1, dxg, B, G, F1, F2, A);
+  f_phi_bwd_dz_kernel<<<cdiv(B, FP_RB), FP_KS * 256, 0, s>>>(gout, out, f2, f1, W1, W2, W3, mask, dz3, dz2, dz1, dxg, B, G, F1, F2, A);
   f_phi_bwd_grads_kernel<<<F1 + F2 + A, 256, 0, s>>>(dz1, dz2, dz3, xg, f1, f2, dW1, db1, dW2, db2, dW3, db3, B, G, F1, F2, A);
   RN_LAUNCH_CHECK("rn_f_phi_bwd");
   return 0;
@@ -504,5 +508,18 @@ extern "C" int rn_nll_mean_bwd(const long long* label, const float* gloss, float
   if (blocks > 256) blocks = 256;
   nll_mean_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(label, gloss, gout, B, A);
   RN_LAUNCH_CHECK("rn_nll_mean_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ diagnostics
+// One-thread kernel that writes the constant-rate wall clock into *slot: captured into the step's hipGraph between
+// the real kernels it gives a concurrent multi-stream timeline (tools/step_timeline.py) -- rocprofv3's kernel trace
+// serialises the queues and cannot.
+__global__ void debug_stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+
+extern "C" int rn_debug_stamp(unsigned long long* slot, void* stream) {
+  RN_CHECK_ARG(slot, "rn_debug_stamp: NULL slot");
+  debug_stamp_kernel<<<1, 1, 0, (hipStream_t)stream>>>(slot);
+  RN_LAUNCH_CHECK("rn_debug_stamp");
   return 0;
 }

@@ -435,7 +435,9 @@ extern "C" int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, in
   float* part = (float*)ws;
   hipStream_t s = (hipStream_t)stream;
   if (wgrad_stream_ok(dtype, M, N, K, lddz, lda)) {
-    const int NB = K == 256 ? 4 : 6, Zs = 256 / NB, S = M / 64;     // (2 n halves) x (2 | 3 k blocks); M-split so that ~256 workgroups run
+    const char* ze = getenv("RN_WGRAD_ZS");
+    const int NB = K == 256 ? 4 : 6, S = M / 64;                     // (2 n halves) x (2 | 3 k blocks); M-split so that ~256 workgroups run
+    const int Zs = ze ? atoi(ze) : 256 / NB;
     float* part_db = part + (size_t)Zs * N * K;
     const int grid = 8 * NB * cdiv(Zs, 8);
     const char* ae = getenv("RN_WGRAD_ABL");

@@ -64,7 +64,8 @@ class PackedWeights:
         fragment-major images are packed (the row-major copies feed the other kernels)."""
         key = (code, split, bwd_images, rr_only, tuple((w.data_ptr(), w._version) for w in list(g_w) + list(f_w or ())))
         # while a hipGraph is being captured the pack kernels must be part of it (a replay sees
-        # new weights every step), so the cache is bypassed
+        # new weights every step), so the cache is bypassed.  (Packing ahead of time on a side stream at the start of
+        # the forward pass was measured: the extra fork/join costs more than the 11 us it hides.)
         if key == self.key and not torch.cuda.is_current_stream_capturing():
             return self.fwd, self.bwd
         dt = H.torch_dtype(code)
@@ -400,9 +401,10 @@ class RelationalFunction(torch.autograd.Function):
         # products on (B*n)-row matrices instead of a 235 MB pass over dZ_0 and P (and with fp32 x instead of P's
         # rounded copy).  RN_NO_ALGEBRAIC_WGRAD0=1 keeps the kernel.
         alg0 = plan.inject == 0 and k <= 32 and os.environ.get("RN_NO_ALGEBRAIC_WGRAD0", "0") != "1"
-        # RN_WGRAD_LATE=1 starts the (HBM-bound) wgrad stream only after the pair reduction; measured slower (1.28 vs 1.25 ms):
-        # the side stream then finishes last
-        wgrad_late = alg0 and os.environ.get("RN_WGRAD_LATE", "0") == "1"
+        # RN_WGRAD_LATE=1 / 2 starts the (HBM-bound) wgrad stream only after the pair reduction / after dx, dq: measured
+        # slower (1.246 / 1.266 vs 1.222 ms) -- the window after the backward chain runs at the HBM roofline (~4 TB/s over
+        # wgrad + pair reduction, tools/step_timeline.py) wherever the wgrads are put, and later they slow the conv backward
+        wgrad_late = int(os.environ.get("RN_WGRAD_LATE", "0")) if alg0 else 0
         if overlap:
             main, side = torch.cuda.current_stream(), _side_stream(dev)
             keep = [list(dZs), list(inputs)]                       # keep operands alive until the join
@@ -437,6 +439,7 @@ class RelationalFunction(torch.autograd.Function):
                 gB[l] = torch.empty(N, **f32)
                 H.g_linear_bwd_wgrad(dZ, N, A_l, kp, gW[l], gB[l], code, M, N, kp, kt)
             wl = g_w[l] if g_w[l].is_contiguous() else g_w[l].contiguous()
+            fused_tail = l == 0 and plan.inject == 0 and k <= 32 and os.environ.get("RN_NO_FUSED_PAIR_TAIL", "0") != "1"
             if l == plan.inject:
                 Rq = torch.empty(B, N, **f32)
                 if l == 0:
@@ -445,11 +448,12 @@ class RelationalFunction(torch.autograd.Function):
                 else:
                     H.pair_reduce_bwd(dZ, N, None, None, Rq, code, B, n, N)
                 dq = torch.empty(B, Q, **f32)
-                H.gemm_f32(Rq, N, 1, wl, kt, 1, dq, Q, B, Q, N, b_off=kt - Q)   # Rq @ W[:, -Q:]
+                if not fused_tail:
+                    H.gemm_f32(Rq, N, 1, wl, kt, 1, dq, Q, B, Q, N, b_off=kt - Q)   # Rq @ W[:, -Q:]
             elif l == 0:
                 Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32)
                 H.pair_reduce_bwd(dZ, N, Rj, Ri, None, code, B, n, N)
-            if l == 0 and overlap and wgrad_late:
+            if l == 0 and overlap and wgrad_late == 1:
                 _launch_wgrads()
             if l == 0 and alg0:
                 def _wgrad0():
@@ -463,7 +467,12 @@ class RelationalFunction(torch.autograd.Function):
                     keep.append([Rj, Ri, Rq])
                 else:
                     _wgrad0()
-            if l == 0:
+            if l == 0 and fused_tail:
+                dx = torch.empty(B, n, k, **f32)
+                H.pair_dx_dq(Rj, Ri, Rq, wl, dx, dq, B, n, k, Q, N)                        # dx and dq in one launch
+                if overlap and wgrad_late == 2:
+                    _launch_wgrads()
+            elif l == 0:
                 dx = torch.empty(B, n, k, **f32)
                 H.gemm_f32(Rj, N, 1, wl, kt, 1, dx, k, B * n, k, N)                        # Rj @ W0[:, 0:k]
                 H.gemm_f32(Ri, N, 1, wl, kt, 1, dx, k, B * n, k, N, b_off=k, flags=H.RN_ACCUMULATE)   # + Ri @ W0[:, k:2k]

@@ -48,6 +48,8 @@ SIGNATURES = {
     "rn_g_linear_bwd_wgrad": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_pair_reduce_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_reduce_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_pair_dx_dq": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_debug_stamp": (_I, [_P, _P]),
     "rn_wgrad0_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_wgrad0_from_reductions": (_I, [_P, _P, _P, _P, _L, _L, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_gemm_f32": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _P, _L, _P, _L, _I, _P]),
@@ -186,6 +188,11 @@ def _timed(name):
 
 
 # ------------------------------------------------------------------ wrappers
+def debug_stamp(buf, slot):
+    """Store the device wall clock into buf[slot] (int64 tensor), in stream order (diagnostics only)."""
+    _check(load().rn_debug_stamp(buf.data_ptr() + 8 * slot, _stream()), "rn_debug_stamp")
+
+
 @_timed("pair_build")
 def pair_build_fwd(x, q, P, code, B, n, k, Q, ld):
     _dev(x, "x")
@@ -348,6 +355,12 @@ def pair_reduce_bwd(dZ, lddz, Rj, Ri, Rq, code, B, n, G):
     ws = torch.empty(max(lib.rn_pair_reduce_ws_bytes(B, n, G), 16), dtype=torch.uint8, device=dZ.device)
     _check(lib.rn_pair_reduce_bwd(dZ.data_ptr(), lddz, _ptr(Rj), _ptr(Ri), _ptr(Rq), ws.data_ptr(), code, B, n, G, _stream()),
            "rn_pair_reduce_bwd")
+
+
+@_timed("pair_reduce")
+def pair_dx_dq(Rj, Ri, Rq, W0, dx, dq, B, n, k, Q, N):
+    _check(load().rn_pair_dx_dq(Rj.data_ptr(), Ri.data_ptr(), _ptr(Rq), W0.data_ptr(), dx.data_ptr(), _ptr(dq), B, n, k, Q, N, _stream()),
+           "rn_pair_dx_dq")
 
 
 @_timed("g_wgrad")

@@ -497,6 +497,19 @@ def test_g_linear_bwd_wgrad(H, code, M, N, K, Ktrue, no_tr):
         os.environ.pop("RN_WGRAD_STREAM_192", None)
 
 
+@pytest.mark.parametrize("B,n,k,Q,N", [(64, 64, 26, 128, 256), (3, 12, 7, 256, 512), (5, 9, 32, 40, 100)])
+def test_pair_dx_dq(H, B, n, k, Q, N):
+    """dx = Rj W0[:, :k] + Ri W0[:, k:2k], dq = Rq W0[:, 2k:] in one launch, against float64."""
+    Rj = formula.hash_uniform((B * n, N), 90, -1, 1); Ri = formula.hash_uniform((B * n, N), 91, -1, 1)
+    Rq = formula.hash_uniform((B, N), 92, -1, 1); W0 = formula.hash_uniform((N, 2 * k + Q), 93, -0.2, 0.2)
+    dx = torch.full((B, n, k), 9.0, device="cuda"); dq = torch.full((B, Q), 9.0, device="cuda")
+    H.pair_dx_dq(dev(Rj), dev(Ri), dev(Rq), dev(W0), dx, dq, B, n, k, Q, N)
+    torch.cuda.synchronize()
+    W = W0.astype(np.float64)
+    assert rel(dx.cpu().numpy().reshape(B * n, k), Rj @ W[:, :k] + Ri @ W[:, k:2 * k]) <= F32_TOL
+    assert rel(dq.cpu().numpy(), Rq @ W[:, 2 * k:]) <= F32_TOL
+
+
 @pytest.mark.parametrize("B,n,k,Q", [(64, 64, 26, 128), (3, 12, 7, 256), (2, 196, 26, 128)])
 def test_wgrad0_from_reductions(H, B, n, k, Q):
     """dW_0 = [Rj^T X | Ri^T X | Rq^T q], db_0 = sum_b Rq: must equal dZ_0^T P / column sums of dZ_0 computed directly
