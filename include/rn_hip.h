@@ -314,6 +314,19 @@ int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const float* gamm
 /* Diagnostics used by the GPU tests: raw lane mapping of ds_read_b64_tr_b16. */
 int rn_probe_tr16(const unsigned short* in4096, unsigned short* out256, void* stream);
 
+/* The first g layer factored through the pair structure (question injected at layer 0; model.py:130-139 builds the pair
+ * matrix [x_j | x_i | q] and multiplies it by W0): W0 [x_j | x_i | q] + b0 = W0a x_j + (W0b x_i + W0c q + b0).
+ *   rn_pair_tables: Xp (B*n, 64) bf16 = x[b, j, 0:k] zero padded;  Vc (B*n, N) fp32 = b0 + W0b x[b, i] + W0c q[b]
+ *     (W0T = W0 transposed, (2k+Q, N) fp32; x (B, n, k) with element strides; k <= 32).
+ *   rn_g_chain_fwd_rr_alg0: the register-resident forward chain on those tables -- layer 0 is a K = 64 product on the
+ *     object rows with the Vc row of (question, i) as its bias; the pair matrix never exists.  Wf[0] is the fragment-major
+ *     image of W0[:, 0:k] (natural layout), Wf[1..3] as for rn_g_chain_fwd_rr.  n % 32 == 0, M = B*n*n.  H / mask: both NULL
+ *     (inference) or H_0..2 (H[3] NULL) + the four masks (training); xg_part (M/32, 256) fp32 as for rn_g_chain_fwd_rr. */
+int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* q, long ldq, const float* W0T, const float* b0,
+                   void* Xp, float* Vc, int B, int n, int k, int Q, int N, void* stream);
+int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, const void* const* Wf, const float* const* bias, void* const* H,
+                           void* const* mask, float* xg_part, int M, int L, int G, void* stream);
+
 /* Diagnostics: a one-thread kernel that stores the constant-rate wall clock (wall_clock64) into *slot, in stream order.
  * Captured between the kernels of the step's hipGraph it yields a concurrent multi-stream timeline (tools/step_timeline.py). */
 int rn_debug_stamp(unsigned long long* slot, void* stream);

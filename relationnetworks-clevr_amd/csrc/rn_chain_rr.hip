@@ -37,7 +37,8 @@ constexpr int RR_SRS = 80;                             // staging row stride: 64
 constexpr int RR_STG = RR_WR * RR_SRS;                 // per wave
 // small tables first: every ds_* address is then one of a few lane-constant VGPRs + a 16-bit immediate
 constexpr int RR_OFF_BIAS = 0;
-constexpr int RR_OFF_STG = RR_OFF_BIAS + RR_L * RR_G * 4;
+constexpr int RR_OFF_VC = RR_OFF_BIAS + RR_L * RR_G * 4;     // per-wave layer-0 bias row of the factored first layer (ALG0)
+constexpr int RR_OFF_STG = RR_OFF_VC + RR_NW * RR_G * 4;
 constexpr int RR_OFF_RING = RR_OFF_STG + RR_NW * RR_STG;
 constexpr int RR_LDS = RR_OFF_RING + RR_NSLOT * RR_STAGE;
 static_assert(RR_LDS <= 160 * 1024, "LDS budget");
@@ -231,14 +232,16 @@ extern "C" int rn_pack_matrix_frag_many(const float* const* src, const long* sr,
 // stay in flight: the requests of the five stages in between plus whatever else those stages issue (stores,
 // next-tile row loads).  The models below give a LOWER bound of that number per site -- waiting for more than
 // necessary is always safe, waiting for less is a race.
-template <int NK0, bool STORE, bool ST3, bool XG>
+template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false>
 struct FwdVm {
   static constexpr int PF_PER = (NK0 + 7) / 8;                       // next-tile row loads per stage of the last layer
+  static constexpr int VC_STAGE = (RR_L - 1) * 8 + 4;                // ALG0: the stage that requests the next tile's bias row
   static constexpr int ops(int sidx) {                                // VMEM operations a stage issues (per wave)
     int k = RR_DPW;
     if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += 2;
     if ((sidx >> 3) == RR_L - 1)
       for (int c = 0; c < PF_PER; ++c) k += ((sidx & 7) * PF_PER + c < NK0) ? 1 : 0;
+    if (ALG0 && sidx == VC_STAGE) k += 1;
     return k;
   }
   static constexpr int tail() { return (STORE && ST3 ? 4 : 0) + (XG ? 8 : 0); }
@@ -246,7 +249,7 @@ struct FwdVm {
     int k = 0;
     for (int t = sidx - 5; t < sidx; ++t) k += t >= 0 ? ops(t) : (first ? 0 : ops(t + 8 * RR_L));
     if (sidx < 5 && !first) k += tail();
-    if (first && sidx <= 5) k += RR_DPW * (5 - sidx) + NK0;          // the prologue's later requests and the first pair rows
+    if (first && sidx <= 5) k += RR_DPW * (5 - sidx) + NK0 + (ALG0 ? 1 : 0);   // the prologue's later requests and the first pair rows
     return k < 63 ? k : 63;
   }
 };
@@ -260,11 +263,17 @@ struct BwdVm {
 };
 
 // =================================================================================================== forward
-template <int NK0, bool STORE, bool ST3, bool MASK, bool XG>
+// ALG0 -- the first layer factored through the pair structure (question injected at layer 0, n % 32 == 0):
+//   W0 [x_j | x_i | q] + b0 = W0a x_j + (W0b x_i + W0c q + b0): the bracket is constant over a wave's 32 pair rows (same
+//   question, same i) and comes in as the layer's BIAS row -- Vc[b*n + i][256], fp32, from rn_pair_tables; only the
+//   x_j part is left as an MFMA, K = 64 (P = the packed object rows Xp[b*n + j][64], a 0.5 MB table that lives in L2)
+//   instead of K = 192 on a 138 MB pair matrix that then never exists.
+template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restrict__ P, int ldp, RRArgs a,
-                                                           float* __restrict__ xg_part, int ntiles) {
+                                                           float* __restrict__ xg_part, int ntiles,
+                                                           const float* __restrict__ Vc = nullptr, int n_obj = 0) {
   static_assert(NK0 % 4 == 0 && NK0 >= 4 && NK0 <= 16, "layer-0 reduction length");
-  typedef FwdVm<NK0, STORE, ST3, XG> Vm;
+  typedef FwdVm<NK0, STORE, ST3, XG, ALG0> Vm;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
   k.init(lds);
@@ -279,6 +288,20 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
     return *reinterpret_cast<__attribute__((address_space(1))) const Frag*>(base + prow_off + 32 * ks);
   };
 
+  // ALG0: pair row m = (b, i, j) -> object row b*n + j of Xp (a wave's 32 rows share b and i) and bias row b*n + i of Vc
+  auto op_row = [&](long m0w_) -> long {
+    if constexpr (!ALG0) return m0w_;
+    const int nn = n_obj * n_obj, b = (int)(m0w_ / nn), r = (int)(m0w_ - (long)b * nn), i = r / n_obj;
+    return (long)b * n_obj + (r - i * n_obj);
+  };
+  auto vc_row = [&](long m0w_) -> long {
+    const int nn = n_obj * n_obj, b = (int)(m0w_ / nn), r = (int)(m0w_ - (long)b * nn);
+    return (long)b * n_obj + r / n_obj;
+  };
+  float* const vc_s = reinterpret_cast<float*>(lds + RR_OFF_VC) + w * RR_G;
+  auto vc_load = [&](long m0w_) -> f32x4 { return *reinterpret_cast<const f32x4*>(Vc + vc_row(m0w_) * RR_G + lane * 4); };
+  f32x4 vcreg = {0.f, 0.f, 0.f, 0.f};
+
   Frag actA[16], actB[16], ring[RR_RD];
   f32x16 acc[2];
   u32x4 co[2];
@@ -291,7 +314,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
 #pragma unroll
     for (int i = 0; i < RR_DPW; ++i) k.dma_piece(a.W[0], s, s, i);
 #pragma unroll
-  for (int ks = 0; ks < NK0; ++ks) actA[ks] = load_row_frag((long)tile * RR_TM + RR_WR * w, ks);
+  for (int ks = 0; ks < NK0; ++ks) actA[ks] = load_row_frag(op_row((long)tile * RR_TM + RR_WR * w), ks);
+  if constexpr (ALG0) *reinterpret_cast<f32x4*>(vc_s + lane * 4) = vc_load((long)tile * RR_TM + RR_WR * w);
   if (t < RR_G) {
 #pragma unroll
     for (int l = 0; l < RR_L; ++l) bias_s[l * RR_G + t] = a.bias[l][t];
@@ -315,7 +339,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
     auto bias_read = [&](int l, int ob) {                             // -> C operand of the block's first MFMA
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + l * RR_G + 32 * ob + 8 * j + 4 * h);
+        const float* src = (ALG0 && l == 0) ? vc_s : bias_s + l * RR_G;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(src + 32 * ob + 8 * j + 4 * h);
 #pragma unroll
         for (int r = 0; r < 4; ++r) cinit[4 * j + r] = b[r];
       }
@@ -435,11 +460,14 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
             epi_group(pl, pob, j, 0, 2, dst, pk);
           }
         }
-        if (has_co && (c == 4 || c == 8)) co_store(cl, cob, (c >> 2) - 1);
+        constexpr int CO1 = NK >= 12 ? 4 : NK / 4, CO2 = NK >= 12 ? 8 : NK - 1;   // the two copy-out stores of the stage
+        if (has_co && c == CO1) co_store(cl, cob, 0);
+        if (has_co && c == CO2) co_store(cl, cob, 1);
         if (l == RR_L - 1 && (c & 1) == 0 && (c >> 1) < Vm::PF_PER) {   // next tile's pair rows -> the idle half of the ping-pong
           const int i = ob * Vm::PF_PER + (c >> 1);
-          if (i < NK0) out[i] = load_row_frag(m0n, i);
+          if (i < NK0) out[i] = load_row_frag(op_row(m0n), i);
         }
+        if (ALG0 && sidx == Vm::VC_STAGE && c == 1) vcreg = vc_load(m0n);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -476,6 +504,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
           if (h == 0) xg_part[((long)tile * RR_NW + w) * RR_G + 32 * ob + n] = tot;
         }
       }
+      if constexpr (ALG0) *reinterpret_cast<f32x4*>(vc_s + lane * 4) = vcreg;   // wave-private row: LDS is in order per wave
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // trailing (unused) weight requests, scalar stores
@@ -977,6 +1006,39 @@ extern "C" int rn_g_chain_fwd_rr(const void* P, int ldp, const void* const* Wf, 
   if (K0 == 192) rr_fwd_launch<12>(grid, (hipStream_t)stream, (const bf16*)P, ldp, a, xg_part, ntiles, nh > 0, nh == RR_L, nm > 0);
   else rr_fwd_launch<16>(grid, (hipStream_t)stream, (const bf16*)P, ldp, a, xg_part, ntiles, nh > 0, nh == RR_L, nm > 0);
   RN_LAUNCH_CHECK("rn_g_chain_fwd_rr");
+  return 0;
+}
+
+// The forward chain with the first layer factored through the pair structure (see g_chain_rr_kernel, ALG0).
+extern "C" int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, const void* const* Wf, const float* const* bias,
+                                      void* const* H, void* const* mask, float* xg_part, int M, int L, int G, void* stream) {
+  RN_CHECK_ARG(Xp && Vc && Wf && bias && M > 0 && xg_part, "rn_g_chain_fwd_rr_alg0: bad pointer/size");
+  RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_fwd_rr_alg0: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
+  RN_CHECK_ARG(n > 0 && n % RR_WR == 0 && M % ((long)n * n) == 0 && M % RR_TM == 0,
+               "rn_g_chain_fwd_rr_alg0: needs n %% %d == 0 and M a multiple of n*n and of %d (n=%d M=%d)", RR_WR, RR_TM, n, M);
+  RN_CHECK_ARG(((uintptr_t)Xp | (uintptr_t)Vc) % 16 == 0, "rn_g_chain_fwd_rr_alg0: tables must be 16-byte aligned");
+  RRArgs a;
+  memset(&a, 0, sizeof(a));
+  int nh = 0, nm = 0;
+  for (int l = 0; l < RR_L; ++l) {
+    RN_CHECK_ARG(Wf[l] && bias[l], "rn_g_chain_fwd_rr_alg0: layer %d weight/bias is NULL", l);
+    RN_CHECK_ARG(((uintptr_t)Wf[l] | (uintptr_t)bias[l] | (uintptr_t)(H ? H[l] : nullptr) | (uintptr_t)(mask ? mask[l] : nullptr)) % 16 == 0,
+                 "rn_g_chain_fwd_rr_alg0: layer %d pointers must be 16-byte aligned", l);
+    a.W[l] = (const bf16*)Wf[l];
+    a.bias[l] = bias[l];
+    a.out[l] = H ? (bf16*)H[l] : nullptr;
+    a.mask[l] = mask ? (u64*)mask[l] : nullptr;
+    nh += a.out[l] != nullptr;
+    nm += a.mask[l] != nullptr;
+  }
+  const bool h012 = nh == 3 && !a.out[RR_L - 1] && nm == RR_L;
+  RN_CHECK_ARG((nh == 0 && nm == 0) || h012, "rn_g_chain_fwd_rr_alg0: H / masks: none (inference) or H_0..2 + all four masks (training)");
+  const int ntiles = M / RR_TM;
+  const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
+  hipStream_t s = (hipStream_t)stream;
+  if (nh == 0) g_chain_rr_kernel<4, false, false, false, true, true><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n);
+  else g_chain_rr_kernel<4, true, false, true, true, true><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n);
+  RN_LAUNCH_CHECK("rn_g_chain_fwd_rr_alg0");
   return 0;
 }
 

@@ -713,3 +713,64 @@ extern "C" int rn_pair_dx_dq(const float* Rj, const float* Ri, const float* Rq, 
   RN_LAUNCH_CHECK("rn_pair_dx_dq");
   return 0;
 }
+
+// ------------------------------------------ tables of the factored first layer (rn_g_chain_fwd_rr_alg0)
+// With the question injected at layer 0 the first g layer is W0 [x_j | x_i | q] + b0 = W0a x_j + (W0b x_i + W0c q + b0):
+//   Xp[b*n + j][0:64]  = x[b, j, 0:k] as bf16, zero padded          (the only MFMA operand left, K = 64)
+//   Vc[b*n + i][0:N]   = b0 + W0b x[b, i] + W0c q[b]   in fp32      (constant over the pairs (i, .) of a wave: its bias row)
+// W0T = W0 transposed, (2k + Q, N) fp32 (pack mode 2), so that thread = feature reads it coalesced.  Block = (16 objects,
+// question); replaces the (B n^2, 192) pair matrix of rn_pair_build_fwd: 138 MB written and read back at the headline shape.
+__global__ __launch_bounds__(256) void pair_tables_kernel(const float* __restrict__ x, long sxb, long sxn, long sxk,
+                                                          const float* __restrict__ q, long ldq, const float* __restrict__ W0T,
+                                                          const float* __restrict__ b0, bf16* __restrict__ Xp, float* __restrict__ Vc,
+                                                          int n, int k, int Q, int N) {
+  __shared__ float xs[16][32];
+  __shared__ float qs[1024];
+  const int t = threadIdx.x, b = blockIdx.y, i0 = blockIdx.x * 16;
+  for (int c = t; c < 16 * 32; c += 256) {
+    const int r = c >> 5, cc = c & 31;
+    xs[r][cc] = (i0 + r < n && cc < k) ? x[b * sxb + (long)(i0 + r) * sxn + cc * sxk] : 0.f;
+  }
+  for (int c = t; c < Q; c += 256) qs[c] = q[b * ldq + c];
+  __syncthreads();
+  {                                                                  // packed object rows: 16 x 64 bf16, 4 per thread
+    const int r = t >> 4, c4 = (t & 15) * 4;
+    if (i0 + r < n) {
+      bf16* dst = Xp + ((long)b * n + i0 + r) * 64 + c4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[e] = (bf16)(c4 + e < 32 ? xs[r][c4 + e] : 0.f);
+    }
+  }
+  for (int f = t; f < N; f += 256) {
+    float cq = b0[f];
+    int qq = 0;
+    for (; qq + 32 <= Q; qq += 32) {
+      float wv[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) wv[u] = W0T[(long)(2 * k + qq + u) * N + f];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) cq = fmaf(wv[u], qs[qq + u], cq);
+    }
+    for (; qq < Q; ++qq) cq = fmaf(W0T[(long)(2 * k + qq) * N + f], qs[qq], cq);
+    float wi[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) wi[c] = c < k ? W0T[(long)(k + c) * N + f] : 0.f;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+      if (i0 + r >= n) break;
+      float v = cq;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) v = fmaf(wi[c], xs[r][c], v);
+      Vc[((long)b * n + i0 + r) * N + f] = v;
+    }
+  }
+}
+
+extern "C" int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* q, long ldq, const float* W0T,
+                              const float* b0, void* Xp, float* Vc, int B, int n, int k, int Q, int N, void* stream) {
+  RN_CHECK_ARG(x && q && W0T && b0 && Xp && Vc && B > 0 && n > 0, "rn_pair_tables: bad pointer/size");
+  RN_CHECK_ARG(k > 0 && k <= 32 && Q > 0 && Q <= 1024 && N > 0, "rn_pair_tables: k=%d (<= 32), Q=%d (<= 1024), N=%d unsupported", k, Q, N);
+  pair_tables_kernel<<<dim3(cdiv(n, 16), B), 256, 0, (hipStream_t)stream>>>(x, sxb, sxn, sxk, q, ldq, W0T, b0, (bf16*)Xp, Vc, n, k, Q, N);
+  RN_LAUNCH_CHECK("rn_pair_tables");
+  return 0;
+}

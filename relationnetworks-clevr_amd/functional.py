@@ -55,14 +55,17 @@ class PackedWeights:
         self.fwd, self.bwd = [], []
         self.hi, self.lo = [], []                  # fp16 split copies for the f16s forward
         self.fT = None                             # transposed fp32 copies of the f_phi weights
+        self.w0T = None                            # W_0^T in fp32: the table kernel of the factored first layer
         self.frag_hi, self.frag_lo = [], []        # fragment-major fp16 hi / lo images (f16s on the register-resident chain)
         self.frag = []                             # fragment-major copies for the register-resident chains:
         self.fragT = []                            #   forward W_l, backward step s -> W_{L-1-s}^T
 
-    def get(self, plan: LayerPlan, g_w, code, split=False, bwd_images=True, rr_only=False, f_w=None):
+    def get(self, plan: LayerPlan, g_w, code, split=False, bwd_images=True, rr_only=False, f_w=None, alg0_k=0):
         """rr_only: the call is known to run the register-resident chains in both directions -- only their
-        fragment-major images are packed (the row-major copies feed the other kernels)."""
-        key = (code, split, bwd_images, rr_only, tuple((w.data_ptr(), w._version) for w in list(g_w) + list(f_w or ())))
+        fragment-major images are packed (the row-major copies feed the other kernels).  alg0_k > 0: the forward
+        chain runs with the factored first layer (rn_g_chain_fwd_rr_alg0): the layer-0 image holds W0[:, 0:k] only and
+        W0^T is kept in fp32 for the table kernel (self.w0T)."""
+        key = (code, split, bwd_images, rr_only, alg0_k, tuple((w.data_ptr(), w._version) for w in list(g_w) + list(f_w or ())))
         # while a hipGraph is being captured the pack kernels must be part of it (a replay sees
         # new weights every step), so the cache is bypassed.  (Packing ahead of time on a side stream at the start of
         # the forward pass was measured: the extra fork/join costs more than the 11 us it hides.)
@@ -95,7 +98,7 @@ class PackedWeights:
                 self.frag_lo.append(wl)
             elif rr:
                 wf = torch.empty(256 * 256, dtype=dt, device=dev)
-                frag_jobs.append((wc, kt, 1, N, kt, wf, l == 0))
+                frag_jobs.append((wc, kt, 1, N, alg0_k if (l == 0 and alg0_k) else kt, wf, l == 0))
                 self.frag.append(wf)
             if split and not (rr and rr_only):
                 hi = torch.empty(N, plan.kpad[l], dtype=torch.float16, device=dev)
@@ -115,6 +118,11 @@ class PackedWeights:
             for st, wf in enumerate(self.fragT):
                 wc = g_w[plan.L - 1 - st].detach().contiguous()
                 frag_jobs.append((wc, 1, wc.shape[1], 256, 256, wf, st == 0))      # element (in, out) = W[out][in]
+        self.w0T = None
+        if rr and alg0_k:
+            w0 = g_w[0].detach().contiguous()
+            self.w0T = torch.empty(w0.shape[1], w0.shape[0], dtype=torch.float32, device=dev)
+            frag_jobs.append((w0, w0.shape[1], 1, w0.shape[0], w0.shape[1], self.w0T, 2))
         # f_phi weights as (in, out) fp32 copies: the forward kernel's thread-per-output-feature walk is then coalesced
         self.fT = None
         if f_w is not None and all(max(w.shape) <= 256 for w in f_w):
@@ -165,7 +173,16 @@ def fused_chain_ok(plan: LayerPlan, code, B, n):
             and all(kp == 256 for kp in plan.kpad[1:]) and (B * n * n) % H.g_chain_tile() == 0 and plan.L <= 8)
 
 
-def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None, split=None, wfrag=None, stop_at=None):
+def alg0_forward_ok(plan, code, n, k, M):
+    """The factored first layer (rn_g_chain_fwd_rr_alg0): bf16 register-resident chains, question injected at layer 0,
+    whole waves per (question, i) and the algebraic layer-0 weight gradient in the backward pass (nothing reads P)."""
+    return (rr_chain_ok(plan, code) and plan.inject == 0 and k <= 32 and n % 32 == 0 and M % H.g_chain_rr_tile() == 0
+            and os.environ.get("RN_NO_RR_MASKS", "0") != "1" and os.environ.get("RN_NO_ALGEBRAIC_WGRAD0", "0") != "1"
+            and os.environ.get("RN_NO_ALGEBRAIC_FWD0", "0") != "1")
+
+
+def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None, split=None, wfrag=None, stop_at=None,
+                    w0T=None):
     """K1 + K2 chain (+ K3).  Returns (inputs, H_L, xg): the list of layer INPUT buffers
     [A_0 .. A_{L-1}], the last activation H_L and -- when the fused chain ran -- the pair sum xg
     (else None).  layer_hook(l, A_l, H_out) is called after every layer (hook-compat path; forces
@@ -217,6 +234,23 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
         else:
             H.pair_sum_fwd(Hs[-1], G, xg, code, B, n * n, G)
         return [P] + Hs[:-1], Hs[-1], xg
+    if w0T is not None and stop_at is None and layer_hook is None and wfrag is not None and len(wfrag) == plan.L:
+        # factored first layer: two small tables instead of the pair matrix, K = 64 instead of 192 in layer 0
+        G, L, R = plan.widths[-1], plan.L, 32
+        Xp = torch.empty(B * n, 64, dtype=dt, device=dev)
+        Vc = torch.empty(B * n, G, dtype=torch.float32, device=dev)
+        H.pair_tables(x, q, w0T, g_b[0], Xp, Vc, B, n, k, Q, G)
+        masks = Hs = None
+        if keep_inputs:
+            Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L - 1)] + [None]
+            masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
+        part = torch.empty(M // R, G, dtype=torch.float32, device=dev)
+        H.g_chain_fwd_rr_alg0(Xp, Vc, n, wfrag, g_b, Hs, masks, part, M, G)
+        xg = torch.empty(B, G, dtype=torch.float32, device=dev)
+        H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // R, G)
+        if Hs is None:
+            return [None] * L, None, xg
+        return [None] + Hs[:-1], RRMasks(masks), xg
     P = torch.empty(M, ld0, dtype=dt, device=dev)
     H.pair_build_fwd(x, q if inj == 0 else None, P, code, B, n, k, Q if inj == 0 else 0, ld0)
     if stop_at == 0:
@@ -324,11 +358,14 @@ class RelationalFunction(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         rr_only = (rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0 and ((n * n) % 32 == 0 or not f16s)
                    and os.environ.get("RN_NO_RR_MASKS", "0") != "1")
-        wfwd, wbwd = packed.get(plan, g_w, code, split=f16s, bwd_images=need_grad, rr_only=rr_only, f_w=f_w)
+        alg_fwd = rr_only and not f16s and alg0_forward_ok(plan, code, n, k, M)
+        wfwd, wbwd = packed.get(plan, g_w, code, split=f16s, bwd_images=need_grad, rr_only=rr_only, f_w=f_w,
+                                alg0_k=k if alg_fwd else 0)
         gb = [b.detach().contiguous() for b in g_b]
         inputs, HL, xg = g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad,
                                          split=(packed.hi, packed.lo) if f16s else None,
-                                         wfrag=(packed.frag_hi, packed.frag_lo) if f16s else packed.frag)
+                                         wfrag=(packed.frag_hi, packed.frag_lo) if f16s else packed.frag,
+                                         w0T=packed.w0T if alg_fwd else None)
         G = plan.widths[-1]
         if xg is None:
             xg = torch.empty(B, G, dtype=torch.float32, device=dev)

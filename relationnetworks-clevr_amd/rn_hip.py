@@ -36,6 +36,8 @@ SIGNATURES = {
     "rn_g_chain_rr_mask_bytes": (_Z, [_I]),
     "rn_g_chain_fwd_rr": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_f16s": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "rn_g_chain_fwd_rr_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pack_matrix_frag": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
     "rn_pack_matrix_frag_many": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
@@ -261,6 +263,27 @@ def g_chain_fwd_rr(P, ldp, Wfs, biases, Hs, masks, K0, xg_part, M, G):
     hp = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
     _check(load().rn_g_chain_fwd_rr(P.data_ptr(), ldp, wp, bp, hp, mp, K0, _ptr(xg_part), M, L, G, _stream()), "rn_g_chain_fwd_rr")
+
+
+@_timed("pair_build")
+def pair_tables(x, q, W0T, b0, Xp, Vc, B, n, k, Q, N):
+    """Tables of the factored first layer: Xp (B*n, 64) bf16 object rows, Vc (B*n, N) fp32 bias rows (rn_pair_tables)."""
+    _dev(x, "x")
+    sx = x.stride()
+    _check(load().rn_pair_tables(x.data_ptr(), sx[0], sx[1], sx[2], q.data_ptr(), q.stride(0), W0T.data_ptr(), b0.data_ptr(),
+                                 Xp.data_ptr(), Vc.data_ptr(), B, n, k, Q, N, _stream()), "rn_pair_tables")
+
+
+@_timed("g_fwd")
+def g_chain_fwd_rr_alg0(Xp, Vc, n, Wfs, biases, Hs, masks, xg_part, M, G):
+    """Register-resident forward chain with the first layer factored through the pair structure (no pair matrix)."""
+    L = len(Wfs)
+    wp = (C.c_void_p * L)(*[w.data_ptr() for w in Wfs])
+    bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
+    hp = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
+    mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
+    _check(load().rn_g_chain_fwd_rr_alg0(Xp.data_ptr(), Vc.data_ptr(), n, wp, bp, hp, mp, xg_part.data_ptr(), M, L, G, _stream()),
+           "rn_g_chain_fwd_rr_alg0")
 
 
 @_timed("g_fwd")

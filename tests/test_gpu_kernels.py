@@ -299,6 +299,65 @@ def test_g_chain_fwd_rr(H, K0, K0true, mode, M):
     assert rel(part.cpu().numpy(), ref.reshape(M // 32, 32, G).sum(1)) <= tol
 
 
+@pytest.mark.parametrize("mode,B,n", [("train", 19, 64), ("infer", 3, 32), ("train", 2, 96)])
+def test_g_chain_fwd_rr_alg0(H, mode, B, n):
+    """The factored first layer: W0 [x_j | x_i | q] + b0 = W0a x_j + (W0b x_i + W0c q + b0).  rn_pair_tables must give the
+    packed object rows and the fp32 bias rows; the chain on them must reproduce layer 0 of the pair formula (x_j product
+    on bf16 operands, the bracket exact), then behave like rn_g_chain_fwd_rr: every stored activation one un-fused
+    layer of the kernel's own previous one, masks = gates, partials = column sums of the un-rounded last activation.
+    19 * 64 * 64 / 256 = 304 tiles > 256 CUs (persistent loop + prefetch seams); n = 96: three waves per (b, i)."""
+    L, G, k, Q = 4, 256, 26, 128
+    M, kt = B * n * n, 2 * 26 + 128
+    x = formula.hash_uniform((B, n, k), 400, -1, 1).astype(np.float32)
+    q = formula.hash_uniform((B, Q), 401, -1, 1).astype(np.float32)
+    Ws = [formula.hash_uniform((G, kt if l == 0 else G), 410 + l, -0.15, 0.15).astype(np.float32) for l in range(L)]
+    Ws = [Ws[0]] + [bf16_round(w) for w in Ws[1:]]
+    bs = [formula.hash_uniform((G,), 420 + l, -0.3, 0.3).astype(np.float32) for l in range(L)]
+    w0d = dev(Ws[0])
+    w0T = torch.empty(kt, G, device="cuda")
+    Wf = [torch.empty(65536, dtype=torch.bfloat16, device="cuda") for _ in range(L)]
+    jobs = [(w0d, kt, 1, G, k, Wf[0], 1), (w0d, kt, 1, G, kt, w0T, 2)]
+    jobs += [(dev(Ws[l]), G, 1, G, G, Wf[l], 0) for l in range(1, L)]
+    H.pack_matrix_frag_many(jobs)
+    Xp = torch.full((B * n, 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+    Vc = torch.full((B * n, G), float("nan"), device="cuda")
+    H.pair_tables(dev(x), dev(q), w0T, dev(bs[0]), Xp, Vc, B, n, k, Q, G)
+    train = mode == "train"
+    Hs = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3)] + [None] if train else None
+    masks = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda")) if train else None
+    part = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
+    H.g_chain_fwd_rr_alg0(Xp, Vc, n, Wf, [dev(b) for b in bs], Hs, masks, part, M, G)
+    torch.cuda.synchronize()
+    # tables
+    xp = Xp.float().cpu().numpy()
+    assert np.array_equal(xp[:, :k], bf16_round(x.reshape(B * n, k))) and not xp[:, k:].any()
+    W0 = Ws[0].astype(np.float64)
+    vc_ref = bs[0] + x.reshape(B * n, k).astype(np.float64) @ W0[:, k:2 * k].T + np.repeat(q.astype(np.float64) @ W0[:, 2 * k:].T, n, axis=0)
+    assert rel(Vc.cpu().numpy(), vc_ref) <= F32_TOL
+    # layer 0 of the pair formula: pair row (b, i, j) = W0a x_j (bf16 operands) + Vc[b, i]
+    uj = bf16_round(x.reshape(B * n, k)).astype(np.float64) @ bf16_round(Ws[0][:, :k]).astype(np.float64).T     # (B n, G)
+    pre = uj.reshape(B, 1, n, G) + vc_ref.reshape(B, n, 1, G)
+    ref = np.maximum(pre, 0).reshape(M, G)
+    prev = None
+    for l in range(L):
+        if l:
+            ref = np.maximum(prev.astype(np.float64) @ Ws[l].astype(np.float64).T + bs[l], 0)
+        if Hs is not None and Hs[l] is not None:
+            got = Hs[l].float().cpu().numpy()
+            err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
+            assert err.max() <= BF16_ULP, (l, err.max())
+            prev = got
+        else:
+            prev = bf16_round(ref)
+        if masks is not None:
+            gate = rr_mask_decode(masks[l], M, l)
+            bad = gate != (ref > 0)
+            assert np.abs(ref[bad]).max(initial=0.0) <= 1e-4 * np.abs(ref).max(), (l, bad.sum())
+            assert bad.mean() <= 1e-4
+    tol = F32_TOL if train else 2e-3
+    assert rel(part.cpu().numpy(), ref.reshape(M // 32, 32, G).sum(1)) <= tol
+
+
 @pytest.mark.parametrize("mode,M", [("train", 256 * 290), ("infer", 256 * 5)])
 def test_g_chain_fwd_rr_f16s(H, mode, M):
     """f16s on the register-resident chain: against a float64 emulation that rounds the operand to fp16 after every
