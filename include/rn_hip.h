@@ -291,6 +291,11 @@ int rn_embedding_bwd(const long long* idx, const float* dx, float* demb, int B, 
  *   bwd_data: dx = gradient of that w.r.t. x for the output gradient dy (every element of dx is written). */
 int rn_conv3x3s2_fwd(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, void* stream);
 int rn_conv3x3s2_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, void* stream);
+/* Weight gradient of the same convolution (autograd of model.py:13-20): dw (24, Cin, 3, 3) fp32 =
+ * sum_{n,oy,ox} dy[n][co][oy][ox] * x[n][ci][2 oy + ky - 1][2 ox + kx - 1], on the fp32 matrix pipe; ws =
+ * rn_conv3x3s2_bwd_weight_ws_bytes(N, Cin, H, W) bytes (per-block partials, summed in a fixed order). */
+size_t rn_conv3x3s2_bwd_weight_ws_bytes(int N, int Cin, int H, int W);
+int rn_conv3x3s2_bwd_weight(const float* x, const float* dy, float* dw, void* ws, int N, int Cin, int Cout, int H, int W, void* stream);
 
 /* BatchNorm2d + ReLU of the conv stack in front of the relation layer (reference model.py:22-35), fused into two
  * HBM passes per direction (rn_convnorm.hip).  x: (N, C, H, W) fp32 contiguous conv output computed WITHOUT the

@@ -4,7 +4,7 @@
 // them -- 0.22 ms on the critical path of a 1.3 ms training step.  Here a thread owns one output pixel (forward) or
 // one 2x2 input block (input gradient) for ALL channels: COUT (x 4) accumulators, the 3x3xCIN weights are broadcast
 // from LDS (every lane reads the same 16 bytes), 9 * CIN * COUT FMAs per thread against 9 * CIN (4 * COUT) loads.
-// The weight gradient stays with MIOpen (it is off the dependency chain, on a side stream).
+// The weight gradient is a (24 x 9 CIN) x positions product on the fp32 matrix pipe (conv3x3s2_wgrad_kernel below).
 // NCHW fp32, H and W even.
 #include "rn_common.h"
 
@@ -159,5 +159,162 @@ extern "C" int rn_conv3x3s2_bwd_data(const float* dy, const float* w, float* dx,
   const int gx = (int)((px + CV_T - 1) / CV_T);
   conv3x3s2_bwd_data_kernel<24, 24, 8><<<dim3(gx, 3), CV_T, 0, (hipStream_t)stream>>>(dy, w, dx, N, H, W);
   RN_LAUNCH_CHECK("rn_conv3x3s2_bwd_data");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dw[co][ci][ky][kx] = sum_{n,oy,ox} dy[n][co][oy][ox] * x[n][ci][2 oy + ky - 1][2 ox + kx - 1]
+// = a (24 x 9 CIN) x (N Ho Wo) matrix product with the positions as the reduction axis: v_mfma_f32_32x32x2_f32 (a
+// k-ordered fp32 FMA chain per output, like the scalar loop), M = co padded to 32, N = (ci, ky, kx) in tiles of 32,
+// K = two neighbouring output pixels per instruction.  The library needs 80-90 us per layer for this (layout transposes
+// + an implicit-GEMM kernel); the last one sits at the very end of the backward pass.
+// Unit of work = (image, 4 output rows): the 9 input rows (zero padded, column index + 1) and the 4 dy rows of all channels
+// are staged in LDS row by row (a wave per row: no index arithmetic per element).  One A read (dy) and one B read (an x
+// tap: a per-lane gather at a compile-time offset per step) per MFMA.
+//   CIN = 24: 7 waves, wave = one 32-column tile of (ci, ky, kx) over all 4 rows -- nothing to combine across waves;
+//   CIN = 3 : 4 waves, wave = one output row of the single tile; the four partial sums meet in LDS at the end.
+// Blocks are persistent over units; one partial per block goes to the workspace and conv_wgrad_reduce_kernel sums the
+// partials in a fixed order.
+namespace {
+typedef __attribute__((ext_vector_type(16))) float cv_f32x16;
+}
+template <int CIN>
+__global__ __launch_bounds__(CIN == 3 ? 256 : 448) void conv3x3s2_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                               float* __restrict__ part, int H, int W, int units, int cpi) {
+  constexpr int NC = CIN * 9, NW = CIN == 3 ? 4 : 7;
+  constexpr bool NSPLIT = CIN != 3;                     // waves split the (ci, ky, kx) tiles, not the rows
+  extern __shared__ __attribute__((aligned(16))) float cw_smem[];
+  const int Ho = H / 2, Wo = W / 2, CS = W + 2, DS = 4 * Wo + 1;
+  float* xs = cw_smem;                                  // [CIN][9][CS]
+  float* dys = cw_smem + CIN * 9 * CS;                  // [32][DS]
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, ncol = l & 31, half = l >> 5;
+  const int col = NSPLIT ? 32 * w + ncol : ncol;
+  const int boff = col < NC ? (col / 9) * 9 * CS + ((col % 9) / 3) * CS + col % 3 + 2 * half : 0;
+  const int aoff = ncol * DS + half;
+  for (int i = t; i < CIN * 9 * CS + 32 * DS; i += NW * 64) cw_smem[i] = 0.f;      // pads (and channels 24..31 of dy) stay zero
+  cv_f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int n = u / cpi, oy0 = 4 * (u - n * cpi);
+    __syncthreads();                                    // the previous unit's reads (or the zero fill) are done
+    // rows in batches of 8 per wave: the 8 loads are issued back to back (one HBM round trip per batch, not per row)
+    for (int row0 = w; row0 < CIN * 9; row0 += 8 * NW)
+      for (int c = l; c < W; c += 64) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int row = row0 + q * NW, ci = row / 9, iy = 2 * oy0 - 1 + (row - ci * 9);
+          const bool ok = row < CIN * 9 && iy >= 0 && iy < H;
+          v[q] = ok ? x[(((long)n * CIN + ci) * H + iy) * W + c] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (row0 + q * NW < CIN * 9) xs[(row0 + q * NW) * CS + 1 + c] = v[q];
+      }
+    for (int row0 = w; row0 < 24 * 4; row0 += 8 * NW)
+      for (int c = l; c < Wo; c += 64) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int row = row0 + q * NW, co = row >> 2, rr = row & 3;
+          v[q] = (row < 24 * 4 && oy0 + rr < Ho) ? dy[(((long)n * 24 + co) * Ho + oy0 + rr) * Wo + c] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int row = row0 + q * NW;
+          if (row < 24 * 4) dys[(row >> 2) * DS + (row & 3) * Wo + c] = v[q];
+        }
+      }
+    __syncthreads();
+    if constexpr (NSPLIT) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll 4
+        for (int ox0 = 0; ox0 < Wo; ox0 += 4) {         // two independent accumulators: even / odd pixel pairs
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dys[aoff + rr * Wo + ox0], xs[boff + 2 * rr * CS + 2 * ox0], acc[0], 0, 0, 0);
+          if (ox0 + 2 < Wo)
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dys[aoff + rr * Wo + ox0 + 2], xs[boff + 2 * rr * CS + 2 * ox0 + 4], acc[1], 0, 0, 0);
+        }
+    } else {
+#pragma unroll 4
+      for (int ox0 = 0; ox0 < Wo; ox0 += 4) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dys[aoff + w * Wo + ox0], xs[boff + 2 * w * CS + 2 * ox0], acc[0], 0, 0, 0);
+        if (ox0 + 2 < Wo)
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dys[aoff + w * Wo + ox0 + 2], xs[boff + 2 * w * CS + 2 * ox0 + 4], acc[1], 0, 0, 0);
+      }
+    }
+  }
+  // D row co = 8 (i / 4) + 4 half + i % 4 (i < 12 for the 24 real channels), D column = this lane's (ci, ky, kx)
+  float* dst = part + (long)blockIdx.x * 24 * NC;
+  if constexpr (NSPLIT) {
+    if (col < NC) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) dst[(8 * (i >> 2) + 4 * half + (i & 3)) * NC + col] = acc[0][i] + acc[1][i];
+    }
+  } else {
+    __syncthreads();
+    float* red = cw_smem;                               // [4 waves][12][64]
+#pragma unroll
+    for (int i = 0; i < 12; ++i) red[(w * 12 + i) * 64 + l] = acc[0][i] + acc[1][i];
+    __syncthreads();
+    for (int idx = t; idx < 12 * 64; idx += 256) {
+      const int i = idx >> 6, ln = idx & 63, c = ln & 31, co = 8 * (i >> 2) + 4 * (ln >> 5) + (i & 3);
+      if (c < NC) dst[co * NC + c] = ((red[idx] + red[12 * 64 + idx]) + red[2 * 12 * 64 + idx]) + red[3 * 12 * 64 + idx];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nout, int nparts) {
+  __shared__ float red[3][64];
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63), s = threadIdx.x >> 6;
+  float a = 0.f;
+  if (o < nout) {
+#pragma unroll 8
+    for (int b = s; b < nparts; b += 4) a += part[(long)b * nout + o];
+  }
+  if (s) red[s - 1][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (s == 0 && o < nout) dw[o] = ((a + red[0][threadIdx.x]) + red[1][threadIdx.x]) + red[2][threadIdx.x];
+}
+
+namespace {
+struct CwPlan { int units, cpi, grid; size_t shm; };
+static CwPlan cw_plan(int N, int Cin, int H, int W) {
+  CwPlan p;
+  const int Ho = H / 2, Wo = W / 2;
+  p.cpi = (Ho + 3) / 4;
+  p.units = N * p.cpi;
+  p.grid = p.units < 512 ? p.units : 512;
+  p.shm = ((size_t)Cin * 9 * (W + 2) + 32 * (4 * Wo + 1)) * sizeof(float);
+  if (p.shm < 4 * 12 * 64 * sizeof(float)) p.shm = 4 * 12 * 64 * sizeof(float);
+  return p;
+}
+}  // namespace
+
+extern "C" size_t rn_conv3x3s2_bwd_weight_ws_bytes(int N, int Cin, int H, int W) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0) return 0;
+  return (size_t)cw_plan(N, Cin, H, W).grid * 24 * Cin * 9 * sizeof(float);
+}
+
+extern "C" int rn_conv3x3s2_bwd_weight(const float* x, const float* dy, float* dw, void* ws, int N, int Cin, int Cout, int H, int W,
+                                       void* stream) {
+  if (int rc = cv_check("rn_conv3x3s2_bwd_weight", x, dy, dw, N, Cin, Cout, H, W)) return rc;
+  RN_CHECK_ARG(ws, "rn_conv3x3s2_bwd_weight: NULL workspace");
+  const CwPlan p = cw_plan(N, Cin, H, W);
+  RN_CHECK_ARG(p.shm <= 160 * 1024, "rn_conv3x3s2_bwd_weight: W=%d needs %zu bytes of LDS", W, p.shm);
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)ws;
+  if (Cin == 3) {
+    if (p.shm > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv3x3s2_wgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.shm);
+    conv3x3s2_wgrad_kernel<3><<<p.grid, 256, p.shm, s>>>(x, dy, part, H, W, p.units, p.cpi);
+  } else {
+    if (p.shm > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv3x3s2_wgrad_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.shm);
+    conv3x3s2_wgrad_kernel<24><<<p.grid, 448, p.shm, s>>>(x, dy, part, H, W, p.units, p.cpi);
+  }
+  RN_LAUNCH_CHECK("rn_conv3x3s2_bwd_weight");
+  const int nout = 24 * Cin * 9;
+  conv_wgrad_reduce_kernel<<<(nout + 63) / 64, 256, 0, s>>>(part, dw, nout, p.grid);
+  RN_LAUNCH_CHECK("rn_conv3x3s2_bwd_weight(reduce)");
   return 0;
 }

@@ -605,7 +605,11 @@ class ConvBNReLUFunction(torch.autograd.Function):
             main, side = torch.cuda.current_stream(), _side_stream(dx.device, 1)     # (stream 0 carries the g_theta wgrads)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                dw = conv_bwd([False, True, False])[1]
+                if ctx.direct and os.environ.get("RN_NO_DIRECT_CONV_WGRAD", "0") != "1":
+                    dw = torch.empty_like(conv_w)
+                    H.conv3x3s2_bwd_weight(inp, dx, dw)                # fp32 matrix pipe, no layout transposes
+                else:
+                    dw = conv_bwd([False, True, False])[1]
             keep = [dx, inp]
             for t in keep:
                 t.record_stream(side)
@@ -619,6 +623,10 @@ class ConvBNReLUFunction(torch.autograd.Function):
                 H.conv3x3s2_bwd_data(dx, conv_w.detach().contiguous(), din)
             else:
                 din = conv_bwd([True, False, False])[0]
+        elif ctx.direct and not ctx.needs_input_grad[0] and os.environ.get("RN_NO_DIRECT_CONV_WGRAD", "0") != "1":
+            din = None                                                 # first layer (the image needs no gradient): the END of
+            dw = torch.empty_like(conv_w)                              # the backward pass, nothing left to overlap with
+            H.conv3x3s2_bwd_weight(inp, dx, dw)
         else:
             din, dw, _ = conv_bwd([ctx.needs_input_grad[0], True, False])
         db = _zeros_like_cached(conv_w.shape[0], conv_w) if ctx.has_bias else None

@@ -73,6 +73,8 @@ SIGNATURES = {
     "rn_clip_adam_step": (_I, [_P, _I, _P, _P, _P, _L, _P] + [C.c_float] * 7 + [_I, _P, _P]),
     "rn_conv3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_conv3x3s2_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_conv3x3s2_bwd_weight_ws_bytes": (_Z, [_I, _I, _I, _I]),
+    "rn_conv3x3s2_bwd_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_bn_relu_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_bn_relu_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _I, _I, _P]),
     "rn_bn_relu_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -521,6 +523,15 @@ def conv3x3s2_bwd_data(dy, w, dx):
     N, Cin, Hh, Ww = dx.shape
     _check(load().rn_conv3x3s2_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), N, Cin, w.shape[0], Hh, Ww, _stream()),
            "rn_conv3x3s2_bwd_data")
+
+
+@_timed("conv")
+def conv3x3s2_bwd_weight(x, dy, dw):
+    """dw (24, Cin, 3, 3) of the 3x3 / stride-2 / pad-1 convolution from x (N, Cin, H, W) and dy (N, 24, H/2, W/2)."""
+    N, Cin, Hh, Ww = x.shape
+    ws = torch.empty(max(load().rn_conv3x3s2_bwd_weight_ws_bytes(N, Cin, Hh, Ww), 16), dtype=torch.uint8, device=x.device)
+    _check(load().rn_conv3x3s2_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), N, Cin, dy.shape[1], Hh, Ww, _stream()),
+           "rn_conv3x3s2_bwd_weight")
 
 
 # ------------------------------------------------------------------ mean NLL loss

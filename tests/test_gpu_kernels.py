@@ -728,6 +728,19 @@ def test_question_lstm(B, T):
 
 
 # ----------------------------------------------------------------------------- conv stack: direct 3x3 / stride-2 convolutions
+@pytest.mark.parametrize("N,Cin,Hh,Ww", [(64, 3, 128, 128), (64, 24, 64, 64), (5, 24, 32, 32), (3, 24, 16, 16), (2, 3, 12, 20), (2, 24, 6, 4)])
+def test_conv3x3s2_bwd_weight(H, N, Cin, Hh, Ww):
+    """The MFMA weight gradient of the conv stack against the library's (fp32, summation order differs)."""
+    x = dev(formula.hash_uniform((N, Cin, Hh, Ww), 70, -1, 1))
+    dy = dev(formula.hash_uniform((N, 24, Hh // 2, Ww // 2), 71, -1, 1))
+    dw = torch.full((24, Cin, 3, 3), float("nan"), device="cuda")
+    H.conv3x3s2_bwd_weight(x, dy, dw)
+    torch.cuda.synchronize()
+    ref = torch.ops.aten.convolution_backward(dy.double(), x.double(), torch.zeros(24, Cin, 3, 3, dtype=torch.float64, device="cuda"), None,
+                                              (2, 2), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])[1]
+    assert rel(dw.cpu().numpy(), ref.cpu().numpy()) <= 2e-6
+
+
 @pytest.mark.parametrize("N,Cin,hw", [(64, 3, 128), (64, 24, 64), (3, 24, 16), (2, 3, 34)])
 def test_conv3x3s2_direct(H, N, Cin, hw):
     """rn_conv.hip against torch's conv2d (MIOpen) and its input gradient: fp32, summation order only."""
