@@ -137,6 +137,13 @@ int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, con
  * written (wgrad and the pair reduction consume them).  rows_per_question = n*n (any value dividing M). */
 int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M,
                       int rows_per_question, int L, int G, void* stream);
+/* Weight gradient of the LAST g layer without its gradient matrix: dZ_3[(b, pair), f] = gate ? bf16(dxg[b][f]) : 0 is
+ * rebuilt on the fly from the forward kernel's layer-3 lane masks (mask: rn_g_chain_rr_mask_bytes(M) bytes) and dxg
+ * (M / rows_per_question, 256) fp32 -- bitwise the matrix rn_g_chain_bwd_rr stores as dZ[0], which may then be passed as
+ * NULL there (nothing else reads it).  dW (256, 256) = dZ_3^T A, db = column sums; A = H_2 (M, lda) bf16;
+ * ws = rn_wgrad_ws_bytes(M, 256, 256).  rows_per_question % 64 == 0. */
+int rn_g_linear_bwd_wgrad_gated(const void* mask, const float* dxg, int rows_per_question, const void* A, int lda, float* dW,
+                                float* db, void* ws, int M, int N, int K, void* stream);
 
 /* MFMA-fragment-major weight image for rn_g_chain_fwd_rr: dst (65536 bf16) gets, for output block ob,
  * K16 step ks, lane, element e:  src[32 ob + lane % 32][kidx] (0 beyond R rows / C columns) with

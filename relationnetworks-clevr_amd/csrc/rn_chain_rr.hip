@@ -253,10 +253,11 @@ struct FwdVm {
     return k < 63 ? k : 63;
   }
 };
+template <bool SKIP0>
 struct BwdVm {
   static constexpr int ops(int sidx) { return RR_DPW + (sidx >= 2 ? 2 : 0); }
-  static constexpr int younger(int sidx) {                            // the tile prologue (56 operations) is younger too
-    int k = sidx < 5 ? 40 : 0;
+  static constexpr int younger(int sidx) {                            // the tile prologue (56 operations; 40 without the dZ[0] copy) is younger too
+    int k = sidx < 5 ? (SKIP0 ? 32 : 40) : 0;
     for (int t = sidx - 5 > 0 ? sidx - 5 : 0; t < sidx; ++t) k += ops(t);
     return k < 63 ? k : 63;
   }
@@ -774,7 +775,9 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
 // ================================================================================================== backward
 // dZ[0] = dxg[b] * (H_3 > 0);  dZ[s+1] = (dZ[s] @ W_{3-s}) * (H_{2-s} > 0), s = 0..2 -- the ReLU gates come from the
 // forward kernel's lane masks (32 bytes per pair row and layer instead of a 512-byte activation row).
-template <int ABL>
+// SKIP0: dZ[0] (the last layer's gradient) is not copied to HBM -- rn_g_linear_bwd_wgrad_gated rebuilds it from the
+// masks and dxg, the only consumer besides this kernel's own first step.
+template <int ABL, bool SKIP0 = false>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int ntiles) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
@@ -842,11 +845,13 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
             const unsigned t1 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 16 * s + 2 * p + 1, 1);
             actA[ks][p] = u & ((t0 & 0xffffu) | (t1 & 0xffff0000u));
           }
-          *reinterpret_cast<u32x4*>(stg + n * RR_SRS + 32 * s + 16 * h) = actA[ks];
+          if constexpr (!SKIP0) *reinterpret_cast<u32x4*>(stg + n * RR_SRS + 32 * s + 16 * h) = actA[ks];
         }
-        co_read();
+        if constexpr (!SKIP0) {
+          co_read();
 #pragma unroll
-        for (int q = 0; q < 2; ++q) co_store(0, ob, q);
+          for (int q = 0; q < 2; ++q) co_store(0, ob, q);
+        }
       }
     }
     // ---- one stage = one 32-feature block of one dgrad step ---------------------------------------------------
@@ -867,10 +872,10 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
       if (has_prev && !(ABL & 2)) mask_wait(gp[0], gp[1]);
       if (!(ABL & 2)) mask_load(a.mask + (NS - 1 - s) * a.mask_stride + (wt * 8 + ob) * 16, gn[0], gn[1]);
       if (ABL & 16) {                                                 // timing only: 16 more operations may stay in flight (a race)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BwdVm::younger(sidx) + 16 < 63 ? BwdVm::younger(sidx) + 16 : 63) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BwdVm<SKIP0>::younger(sidx) + 16 < 63 ? BwdVm<SKIP0>::younger(sidx) + 16 : 63) : "memory");
         __builtin_amdgcn_s_barrier();
       } else if (!(ABL & 8)) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BwdVm::younger(sidx)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BwdVm<SKIP0>::younger(sidx)) : "memory");
         __builtin_amdgcn_s_barrier();
       }
       asm volatile("" ::: "memory");
@@ -1098,20 +1103,21 @@ extern "C" int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, cons
                "rn_g_chain_bwd_rr: M=%d must be a multiple of %d and of rows per question=%d", M, RR_TM, rows_per_question);
   RRBwdArgs a;
   memset(&a, 0, sizeof(a));
+  const bool skip0 = dZ[0] == nullptr;                     // the last layer's gradient is not stored (rn_g_linear_bwd_wgrad_gated rebuilds it)
   for (int l = 0; l < RR_L; ++l) {
-    RN_CHECK_ARG(mask[l] && dZ[l] && (l == RR_L - 1 || Wtf[l]), "rn_g_chain_bwd_rr: entry %d has a NULL pointer", l);
+    RN_CHECK_ARG(mask[l] && (dZ[l] || (l == 0 && skip0)) && (l == RR_L - 1 || Wtf[l]), "rn_g_chain_bwd_rr: entry %d has a NULL pointer", l);
     RN_CHECK_ARG(((uintptr_t)mask[l] | (uintptr_t)dZ[l] | (uintptr_t)(l < RR_L - 1 ? Wtf[l] : nullptr)) % 16 == 0,
                  "rn_g_chain_bwd_rr: entry %d pointers must be 16-byte aligned", l);
   }
   // the kernel addresses the per-layer buffers as base + l * stride (three pointers instead of eleven)
   a.mask = (const u64*)mask[0];
-  a.dZ = (bf16*)dZ[0];
+  a.dz_stride = (bf16*)dZ[2] - (bf16*)dZ[1];
+  a.dZ = (bf16*)dZ[1] - a.dz_stride;
   a.W = (const bf16*)Wtf[0];
   a.mask_stride = (const u64*)mask[1] - (const u64*)mask[0];
-  a.dz_stride = (bf16*)dZ[1] - (bf16*)dZ[0];
   a.w_stride = (const bf16*)Wtf[1] - (const bf16*)Wtf[0];
   for (int l = 0; l < RR_L; ++l) {
-    RN_CHECK_ARG((const u64*)mask[l] == a.mask + l * a.mask_stride && (bf16*)dZ[l] == a.dZ + l * a.dz_stride &&
+    RN_CHECK_ARG((const u64*)mask[l] == a.mask + l * a.mask_stride && ((l == 0 && skip0) || (bf16*)dZ[l] == a.dZ + l * a.dz_stride) &&
                      (l == RR_L - 1 || (const bf16*)Wtf[l] == a.W + l * a.w_stride),
                  "rn_g_chain_bwd_rr: mask / dZ / Wtf buffers must be equally spaced (slices of one allocation each)");
   }
@@ -1121,6 +1127,11 @@ extern "C" int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, cons
   const int ntiles = M / RR_TM;
   const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
   const char* ae = getenv("RN_RR_ABL");                    // diagnostics: timing-only ablations (results are wrong)
+  if (skip0) {
+    g_chain_rr_bwd_kernel<0, true><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles);
+    RN_LAUNCH_CHECK("rn_g_chain_bwd_rr");
+    return 0;
+  }
   switch (ae ? atoi(ae) : 0) {
     case 1: g_chain_rr_bwd_kernel<1><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
     case 2: g_chain_rr_bwd_kernel<2><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;

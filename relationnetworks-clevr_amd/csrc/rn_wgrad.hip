@@ -220,16 +220,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //   * the linear LDS image LDS-DMA writes is made conflict-free for ds_read_b64_tr_b16 by an XOR swizzle of the
 //     16-byte chunks, applied to the per-lane SOURCE address (the rows of a 4-row group land 64 B apart mod 256 B).
 // Same partial-tile format and the same fixed-order reduction as wgrad_kernel -> bitwise deterministic.
-template <int KTW>   // 32-wide k tiles per wave: 2 -> KB = 128, 1 -> KB = 64
+// GEN -- the LAST g layer's gradient operand is not read but generated: dZ_3 = (ReLU gate of layer 3) x dxg[question]
+// (model.py:151-152: the pair sum broadcasts one gradient row to all pairs of a question), so the 134 MB bf16 matrix the
+// backward chain would write and this kernel read back is replaced by the forward kernel's lane masks (1 KB per 64-row
+// step and column half, LDS-DMA into an 8-slot ring three steps ahead of their use) + the question's dxg row: every
+// thread builds two 16-byte chunks of the step's dZ tile (8 mask bits select among 8 pre-rounded bf16 values) and writes
+// them to the swizzled position the LDS-DMA would have used.  The A operand (H_2) streams as before.
+template <int KTW, bool GEN = false>   // 32-wide k tiles per wave: 2 -> KB = 128, 1 -> KB = 64
 __global__ __launch_bounds__(512) void wgrad_stream_kernel(const bf16* __restrict__ dZ, int lddz, const bf16* __restrict__ A,
                                                            int lda, float* __restrict__ part, float* __restrict__ part_db,
-                                                           int S, int Z, int NB, int Kpad, int abl) {
+                                                           int S, int Z, int NB, int Kpad, int abl,
+                                                           const unsigned* __restrict__ gmask = nullptr,
+                                                           const float* __restrict__ dxg = nullptr, int steps_per_q = 1) {
+  static_assert(!GEN || KTW == 2, "generated operand: K == 256 only");
   constexpr int KB = KTW * 64;                             // k block width
   constexpr int ZB = 64 * 256, AB = 64 * KB * 2;           // bytes per stage: dZ tile (64 x 128 cols), A tile (64 x KB cols)
   constexpr int STG = ZB + AB, NSTG = 4, LA = 3;           // three stages (96 KB) in flight; a 5-stage ring measured slower
-  constexpr int PPW = (ZB + AB) / 1024 / 8;                // 1-KB LDS-DMA pieces per wave and stage (4 / 3)
+  constexpr int PPW = GEN ? AB / 1024 / 8 : (ZB + AB) / 1024 / 8;   // 1-KB LDS-DMA pieces per wave and stage (4 / 3; GEN: 2 + a mask slice)
   constexpr int RBA = KB * 2;                              // A tile row bytes (256 / 128)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[NSTG * STG];
+  constexpr int MSLOTS = 8, MLA = LA + 3;                  // GEN: mask ring, requested MLA steps ahead of the step that multiplies them
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NSTG * STG + (GEN ? MSLOTS * 1024 : 0)];
   typedef __attribute__((address_space(3))) unsigned char lds_u8;
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const bf16* __restric
     const unsigned sb = ldsb + (unsigned)(s % NSTG) * STG;
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      const int q = w * PPW + i;                           // wave-uniform
+      const int q = GEN ? 16 + w * PPW + i : w * PPW + i;  // wave-uniform (GEN: the 16 A pieces only)
       const unsigned char* ub;
       unsigned off;
       if (q < 16) {                                        // dZ piece: rows 4q .. 4q+3, 256 B each
@@ -272,6 +282,65 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const bf16* __restric
                    : "=&s"(keep)
                    : "v"(off), "s"(ub), "s"(dst)
                    : "memory");
+    }
+  };
+
+  // ---- GEN: lane masks by LDS-DMA (8 lanes x 16 B per wave = 128 B of the step's 1 KB), tile generation
+  // mask image of layer 3 (un-swapped epilogue of the forward kernel): per 32-row block and 32-feature block 32 dwords,
+  // dword 2 (4 (r / 8) + r % 4) + (r / 4) % 2 = the 32 feature bits of row r
+  auto issue_mask = [&](long x) {
+    const unsigned char* ub = reinterpret_cast<const unsigned char*>(gmask) + x * 2048 + (w >> 2) * 1024 + nh * 512 + (w & 3) * 128;
+    const unsigned dst = ldsb + (unsigned)(NSTG * STG) + (unsigned)(x % MSLOTS) * 1024 + w * 128;
+    const unsigned off = (unsigned)lane * 16u;
+    unsigned keep;
+    unsigned long long ex;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_mov_b64 exec, 0xff\n\t"
+                 "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(ex)
+                 : "v"(off), "s"(ub), "s"(dst)
+                 : "memory");
+  };
+  const int gc = t & 15, gr = t >> 4;                      // this thread's chunk column and row (rows gr and gr + 32)
+  const int gdw = 2 * (4 * (gr >> 3) + (gr & 3)) + ((gr >> 2) & 1);
+  unsigned dxbf[4] = {0u, 0u, 0u, 0u};                     // bf16 pairs of dxg[question][nh * 128 + 8 gc + 0..7]
+  int cur_q = -1, q_left = 0;                              // steps are generated in order: the question changes every steps_per_q
+  auto gen_load = [&](long x, unsigned (&mb)[2]) {         // the two mask dwords of this thread's rows gr and gr + 32
+    const unsigned char* ms = lds + NSTG * STG + ((unsigned)x % MSLOTS) * 1024 + (gc >> 2) * 128 + gdw * 4;
+    mb[0] = *reinterpret_cast<const unsigned*>(ms);
+    mb[1] = *reinterpret_cast<const unsigned*>(ms + 512);
+  };
+  auto gen_store = [&](long x, const unsigned (&mb)[2]) {
+    if (q_left == 0) {
+      if (cur_q < 0) {
+        cur_q = (int)(x / steps_per_q);
+        q_left = steps_per_q - (int)(x - (long)cur_q * steps_per_q);
+      } else {
+        ++cur_q;
+        q_left = steps_per_q;
+      }
+      const float* dp = dxg + (long)cur_q * 256 + nh * 128 + 8 * gc;
+      const f32x4 d0 = *reinterpret_cast<const f32x4*>(dp), d1 = *reinterpret_cast<const f32x4*>(dp + 4);
+      typedef __attribute__((ext_vector_type(2))) float f32x2_;
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+      const f32x2_ p0 = {d0[0], d0[1]}, p1 = {d0[2], d0[3]}, p2 = {d1[0], d1[1]}, p3 = {d1[2], d1[3]};
+      dxbf[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(p0, bf16x2_));
+      dxbf[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(p1, bf16x2_));
+      dxbf[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(p2, bf16x2_));
+      dxbf[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(p3, bf16x2_));
+    }
+    --q_left;
+    unsigned char* zt = lds + ((unsigned)x % NSTG) * STG;
+#pragma unroll
+    for (int blk2 = 0; blk2 < 2; ++blk2) {
+      const unsigned bits = mb[blk2] >> (8 * (gc & 3));
+      u32x4 o;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const unsigned t0 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 2 * p, 1), t1 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 2 * p + 1, 1);
+        o[p] = dxbf[p] & ((t0 & 0xffffu) | (t1 & 0xffff0000u));      // v_bfe_i32 x2, v_bfi_b32, v_and_b32
+      }
+      const int R = 32 * blk2 + gr;
+      *reinterpret_cast<u32x4*>(zt + R * 256 + ((gc ^ (4 * (R & 3))) * 16)) = o;
     }
   };
 
@@ -302,17 +371,45 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const bf16* __restric
   for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
   const bool do_db = (kb == 0) && (kg == 0);
 
-  if (!(abl & 2))
+  if constexpr (GEN) {
+    for (long x = s0; x < s0 + MLA && x < s1; ++x) issue_mask(x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (long x = s0; x < s0 + LA && x < s1; ++x) {
+      unsigned mb[2];
+      gen_load(x, mb);
+      gen_store(x, mb);
+      issue(x);
+    }
+  } else if (!(abl & 2)) {
     for (long s = s0; s < s0 + LA && s < s1; ++s) issue(s);
+  }
   for (long s = s0; s < s1; ++s) {
     // stage s has landed when at most the requests of the younger stages in flight are outstanding
-    const long younger = (s1 - 1 - s) < (LA - 1) ? (s1 - 1 - s) : (LA - 1);
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (GEN) {
+      // per step and wave: [mask slice of step s+MLA][2 A pieces of step s+LA]; needed now: the A pieces of step s and the
+      // mask slice of step s+LA (requested BEFORE them) -- both older than the last two steps' 3 + 3 requests; the first
+      // two steps see only the prologue's A pieces behind theirs (2 + 2); the last five steps (whose predecessors issued
+      // fewer requests) drain
+      if (s + 5 >= s1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (s < s0 + 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      const long younger = (s1 - 1 - s) < (LA - 1) ? (s1 - 1 - s) : (LA - 1);
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                          // ... for every wave's pieces; and slot (s-1) % NSTG is free
     asm volatile("" ::: "memory");
-    if (s + LA < s1 && !(abl & 2)) issue(s + LA);
+    unsigned mb[2] = {0u, 0u};
+    if constexpr (GEN) {
+      // order per step and wave: [mask slice of step s+MLA] ... [2 A pieces of step s+LA]; the tile of step s+LA is built
+      // between them, its mask read ahead of and its VALU work + writes behind this step's transpose reads (the LDS
+      // returns in order: the build then rides on the read latency instead of preceding it)
+      if (s + MLA < s1 && !(abl & 8)) issue_mask(s + MLA);
+      if (s + LA < s1 && !(abl & 16)) gen_load(s + LA, mb);
+    } else if (s + LA < s1 && !(abl & 2)) issue(s + LA);
     const unsigned char* st = lds + (s % NSTG) * STG;
     typedef __attribute__((address_space(3))) s16x4* lptr;
     if (abl & 1) continue;                                 // diagnostics: stream only
@@ -328,6 +425,13 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const bf16* __restric
       for (int kt = 0; kt < KTW; ++kt) {
         ua[kk][kt].s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(st + kk * 16 * RBA + aaddr[kt]));
         ua[kk][kt].s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(st + kk * 16 * RBA + 4 * RBA + aaddr[kt]));
+      }
+    }
+    if constexpr (GEN) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + LA < s1) {
+        if (!(abl & 4)) gen_store(s + LA, mb);
+        issue(s + LA);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -388,6 +492,30 @@ static bool wgrad_stream_ok(int dtype, int M, int N, int K, int lddz, int lda) {
   const char* k192 = getenv("RN_WGRAD_STREAM_192");          // K == 192 (three 64-wide k blocks) measured slower than the general kernel
   if (K == 192 && !(k192 && k192[0] == '1')) return false;
   return dtype == RN_BF16 && N == 256 && (K == 256 || K == 192) && M % 64 == 0 && M / 64 >= 64 && lddz % 8 == 0 && lda % 8 == 0;
+}
+
+// Weight gradient of the LAST g layer from the forward kernel's lane masks (see wgrad_stream_kernel, GEN): dW = dZ^T A,
+// db = colsum(dZ) with dZ[(b, pair), f] = (mask bit) ? bf16(dxg[b][f]) : 0 -- bitwise what rn_g_chain_bwd_rr would store.
+extern "C" int rn_g_linear_bwd_wgrad_gated(const void* mask, const float* dxg, int rows_per_question, const void* A, int lda,
+                                           float* dW, float* db, void* ws, int M, int N, int K, void* stream) {
+  RN_CHECK_ARG(mask && dxg && A && dW && db && ws && M > 0, "rn_g_linear_bwd_wgrad_gated: bad pointer/size");
+  RN_CHECK_ARG(N == 256 && K == 256 && M % 64 == 0 && M / 64 >= 64 && lda % 8 == 0 && lda >= K,
+               "rn_g_linear_bwd_wgrad_gated: needs N == K == 256, M %% 64 == 0, M >= 4096 (M=%d N=%d K=%d)", M, N, K);
+  RN_CHECK_ARG(rows_per_question > 0 && rows_per_question % 64 == 0 && M % rows_per_question == 0,
+               "rn_g_linear_bwd_wgrad_gated: rows_per_question=%d must be a multiple of 64 dividing M", rows_per_question);
+  RN_CHECK_ARG(((uintptr_t)mask | (uintptr_t)dxg | (uintptr_t)A) % 16 == 0, "rn_g_linear_bwd_wgrad_gated: pointers must be 16-byte aligned");
+  const int NB = 4, S = M / 64, Zs = 256 / NB;
+  float* part = (float*)ws;
+  float* part_db = part + (size_t)Zs * N * K;
+  hipStream_t s = (hipStream_t)stream;
+  const char* ae = getenv("RN_WGRAD_ABL");
+  wgrad_stream_kernel<2, true><<<8 * NB * cdiv(Zs, 8), 512, 0, s>>>(nullptr, 0, (const bf16*)A, lda, part, part_db, S, Zs, NB, K, ae ? atoi(ae) : 0,
+                                                                    (const unsigned*)mask, dxg, rows_per_question / 64);
+  RN_LAUNCH_CHECK("rn_g_linear_bwd_wgrad_gated(stream)");
+  const int nbw = cdiv((long)N * K / 4, 16), nbb = cdiv(N / 4, 16);
+  wgrad_reduce_kernel<<<nbw + nbb, 256, 0, s>>>(part, part_db, dW, db, N, K, K, Zs, nbw);
+  RN_LAUNCH_CHECK("rn_g_linear_bwd_wgrad_gated(reduce)");
+  return 0;
 }
 
 // USE_TR can be turned off (RN_WGRAD_NO_TR=1) to fall back to scalar LDS column reads.

@@ -410,7 +410,16 @@ class RelationalFunction(torch.autograd.Function):
         if isinstance(ctx.HL, RRMasks):
             # register-resident backward chain on the forward kernel's gates (one launch, no activation is re-read)
             fused_bwd = True
-            dZs = list(torch.empty(L, M, G, dtype=dt, device=dev))                 # dZs[s] belongs to layer L-1-s
+            # the last layer's gradient dZ_{L-1} = gate x dxg[question] is never stored: its only reader besides the chain
+            # itself, the layer's wgrad, rebuilds it from the masks (rn_g_linear_bwd_wgrad_gated) -- 134 MB less written
+            # by the chain and 134 MB less read by the wgrad at the headline shape
+            gated_mask = None
+            if ((n * n) % 64 == 0 and M // 64 >= 64 and plan.widths[-2] == 256 and G == 256
+                    and os.environ.get("RN_NO_GATED_WGRAD", "0") != "1"):
+                gated_mask = ctx.HL.masks[L - 1]
+                dZs = [None] + list(torch.empty(L - 1, M, G, dtype=dt, device=dev))
+            else:
+                dZs = list(torch.empty(L, M, G, dtype=dt, device=dev))             # dZs[s] belongs to layer L-1-s
             H.g_chain_bwd_rr(dxg, ctx.HL.masks, ctx.fragT, dZs, M, n * n, G)
             dZ_of = {L - 1 - s: dZs[s] for s in range(L)}
         elif fused_bwd:
@@ -422,10 +431,21 @@ class RelationalFunction(torch.autograd.Function):
         else:
             dZ = torch.empty(M, G, dtype=dt, device=dev)
             H.pair_sum_bwd(dxg, ctx.HL, G, dZ, G, code, B, n * n, G)
+        if not isinstance(ctx.HL, RRMasks):
+            gated_mask = None
         ctx.HL = None
         gW, gB = [None] * L, [None] * L
         dq = None
         dx = None
+
+        def _wgrad(l, dz, a_l):
+            N_, kt_, kp_ = plan.widths[l], plan.ktrue[l], plan.kpad[l]
+            gW[l] = torch.empty(N_, kt_, **f32)
+            gB[l] = torch.empty(N_, **f32)
+            if dz is None:                                             # last layer on the masks
+                H.g_linear_bwd_wgrad_gated(gated_mask, dxg, n * n, a_l, kp_, gW[l], gB[l], M, N_, kp_)
+            else:
+                H.g_linear_bwd_wgrad(dz, N_, a_l, kp_, gW[l], gB[l], code, M, N_, kp_, kt_)
         # The weight gradients are not needed by anything upstream: with the fused chain all dZ_l exist now, so
         # the L wgrad launches go to a side stream and overlap the rest of this backward AND the conv / LSTM
         # backward that autograd runs next (small kernels that leave the chip mostly empty).  The main stream
@@ -444,7 +464,7 @@ class RelationalFunction(torch.autograd.Function):
         wgrad_late = int(os.environ.get("RN_WGRAD_LATE", "0")) if alg0 else 0
         if overlap:
             main, side = torch.cuda.current_stream(), _side_stream(dev)
-            keep = [list(dZs), list(inputs)]                       # keep operands alive until the join
+            keep = [list(dZs), list(inputs), gated_mask, dxg]      # keep operands alive until the join
             dz_all = dict(dZ_of)
 
             def _launch_wgrads():
@@ -453,10 +473,7 @@ class RelationalFunction(torch.autograd.Function):
                     for l in range(L):
                         if l == 0 and alg0:
                             continue                               # layer 0: from the pair reductions, below
-                        N_, kt_, kp_ = plan.widths[l], plan.ktrue[l], plan.kpad[l]
-                        gW[l] = torch.empty(N_, kt_, **f32)
-                        gB[l] = torch.empty(N_, **f32)
-                        H.g_linear_bwd_wgrad(dz_all[l], N_, inputs_all[l], kp_, gW[l], gB[l], code, M, N_, kp_, kt_)
+                        _wgrad(l, dz_all[l], inputs_all[l])
             inputs_all = list(inputs)
             if not wgrad_late:
                 _launch_wgrads()
@@ -472,9 +489,7 @@ class RelationalFunction(torch.autograd.Function):
             if fused_bwd:
                 dZ = dZ_of.pop(l)
             if not overlap and not (l == 0 and alg0):
-                gW[l] = torch.empty(N, kt, **f32)
-                gB[l] = torch.empty(N, **f32)
-                H.g_linear_bwd_wgrad(dZ, N, A_l, kp, gW[l], gB[l], code, M, N, kp, kt)
+                _wgrad(l, dZ, A_l)
             wl = g_w[l] if g_w[l].is_contiguous() else g_w[l].contiguous()
             fused_tail = l == 0 and plan.inject == 0 and k <= 32 and os.environ.get("RN_NO_FUSED_PAIR_TAIL", "0") != "1"
             if l == plan.inject:

@@ -38,6 +38,7 @@ SIGNATURES = {
     "rn_g_chain_fwd_rr_f16s": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_g_linear_bwd_wgrad_gated": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pack_matrix_frag": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
     "rn_pack_matrix_frag_many": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
@@ -310,7 +311,7 @@ def g_chain_bwd_rr(dxg, masks, Wtfs, dZs, M, rows_per_question, G):
     L = len(dZs)
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks])
     wp = (C.c_void_p * (L - 1))(*[w.data_ptr() for w in Wtfs])
-    zp = (C.c_void_p * L)(*[z.data_ptr() for z in dZs])
+    zp = (C.c_void_p * L)(*[(z.data_ptr() if z is not None else None) for z in dZs])     # dZs[0] None: not stored
     _check(load().rn_g_chain_bwd_rr(dxg.data_ptr(), mp, wp, zp, M, rows_per_question, L, G, _stream()), "rn_g_chain_bwd_rr")
 
 
@@ -372,6 +373,15 @@ def g_linear_bwd_wgrad(dZ, lddz, A, lda, dW, db, code, M, N, K, Ktrue):
     ws = torch.empty(nb, dtype=torch.uint8, device=dW.device)
     _check(lib.rn_g_linear_bwd_wgrad(dZ.data_ptr(), lddz, A.data_ptr(), lda, dW.data_ptr(), _ptr(db), ws.data_ptr(), code,
                                      M, N, K, Ktrue, _stream()), "rn_g_linear_bwd_wgrad")
+
+
+@_timed("g_wgrad")
+def g_linear_bwd_wgrad_gated(mask, dxg, rows_per_question, A, lda, dW, db, M, N, K):
+    """Last g layer: weight gradient from the layer-3 lane masks + dxg instead of a stored dZ_3 (rn_g_linear_bwd_wgrad_gated)."""
+    lib = load()
+    ws = torch.empty(lib.rn_wgrad_ws_bytes(M, N, K), dtype=torch.uint8, device=dW.device)
+    _check(lib.rn_g_linear_bwd_wgrad_gated(mask.data_ptr(), dxg.data_ptr(), rows_per_question, A.data_ptr(), lda, dW.data_ptr(),
+                                           db.data_ptr(), ws.data_ptr(), M, N, K, _stream()), "rn_g_linear_bwd_wgrad_gated")
 
 
 @_timed("pair_reduce")

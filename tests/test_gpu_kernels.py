@@ -402,6 +402,36 @@ def test_g_chain_fwd_rr_f16s(H, mode, M):
     assert rel(part.cpu().numpy(), exact.reshape(M // 32, 32, G).sum(1)) <= 3e-4
 
 
+def test_wgrad_gated_and_bwd_skip0(H):
+    """The last g layer without its gradient matrix: rn_g_chain_bwd_rr with dZ[0] = NULL must give the same dZ[1..3] as
+    the full call, and rn_g_linear_bwd_wgrad_gated (operand rebuilt from the masks + dxg) the same dW / db -- bitwise --
+    as rn_g_linear_bwd_wgrad on the stored dZ[0].  B = 17 questions of 64 x 64 pairs: 272 tiles > 256 CUs, and the 64
+    row splits of the wgrad straddle questions (17 * 64 steps / 64 splits)."""
+    B, n, L, G = 17, 64, 4, 256
+    M = B * n * n
+    g = torch.Generator(device="cuda").manual_seed(5)
+    masks = list(torch.randint(0, 256, (L, H.g_chain_rr_mask_bytes(M)), dtype=torch.uint8, device="cuda", generator=g))
+    dxg = (torch.rand(B, G, device="cuda", generator=g) - 0.5)
+    Wt = list(torch.empty(L - 1, 65536, dtype=torch.bfloat16, device="cuda"))
+    for st in range(L - 1):
+        W = dev(bf16_round(formula.hash_uniform((G, G), 330 + st, -0.15, 0.15)))
+        H.pack_matrix_frag(W, 1, G, G, G, Wt[st], st == 0)
+    full = list(torch.zeros(L, M, G, dtype=torch.bfloat16, device="cuda"))
+    H.g_chain_bwd_rr(dxg, masks, Wt, full, M, n * n, G)
+    part = [None] + list(torch.zeros(L - 1, M, G, dtype=torch.bfloat16, device="cuda"))
+    H.g_chain_bwd_rr(dxg, masks, Wt, part, M, n * n, G)
+    torch.cuda.synchronize()
+    for s in range(1, L):
+        assert torch.equal(full[s], part[s]), s
+    A = (torch.rand(M, G, device="cuda", generator=g) - 0.5).bfloat16()
+    dW0 = torch.empty(G, G, device="cuda"); db0 = torch.empty(G, device="cuda")
+    H.g_linear_bwd_wgrad(full[0], G, A, G, dW0, db0, H.RN_BF16, M, G, G, G)
+    dW1 = torch.full((G, G), float("nan"), device="cuda"); db1 = torch.full((G,), float("nan"), device="cuda")
+    H.g_linear_bwd_wgrad_gated(masks[L - 1], dxg, n * n, A, G, dW1, db1, M, G, G)
+    torch.cuda.synchronize()
+    assert torch.equal(dW0, dW1) and torch.equal(db0, db1)
+
+
 @pytest.mark.parametrize("B,npairs", [(2, 512), (24, 32 * 100), (16, 144)])
 def test_g_chain_bwd_rr(H, B, npairs):
     """Register-resident backward chain on the masks of a real forward call: dZ[0] = bf16(dxg) where gate_3; every
