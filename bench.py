@@ -223,13 +223,19 @@ def main():
                          "frac": fl[kk] / (per[kk] * 1e-3) / 1e12 / peak} for kk in per}
             rr = args.precision == "bf16" and args.config == "original-fp" and args.hw == 128
             ach = kern["g_fwd"]["achieved_tflops"]
+            # the headline kernel runs the first layer factored through the pair structure (K = 64 instead of 180 on chip): the
+            # algorithmic count stays the reference formulation's (model.py:130-152), the executed count is disclosed next to it
+            executed = fwd - 2.0 * M * hyp["g_layers"][0] * (2 * k + hyp["lstm_hidden"] - 64) if rr else fwd
+            # HBM bytes of one launch of that kernel from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE at this very
+            # shape: profiles/r01_final_pmc_hbm_traffic.txt (algorithmic: 3 x 134.2 MB activations + 33.6 MB masks written,
+            # 4.7 MB of tables + 0.5 MB of weights read)
+            traffic = (14.0e6 + 475.0e6) if rr and B == 64 else None
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                               # HBM bytes of one launch of that kernel from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE at this
-                               # very shape: profiles/r01_final_pmc_hbm_traffic.txt (algorithmic: 100.7 MB read + 444.6 MB written)
-                               "traffic": (137.8e6 + 479.0e6) if rr and B == 64 else None,
-                               "kernel": ("g_chain_rr_kernel (rn_chain_rr.hip): 4-layer g_theta forward chain, 1 launch/step" if rr else
+                               "traffic": traffic,
+                               "hbm_frac": (traffic / (per["g_fwd"] * 1e-3) / 1e9 / PEAK_HBM_GBS) if traffic else None,
+                               "kernel": ("g_chain_rr_kernel<ALG0> (rn_chain_rr.hip): 4-layer g_theta forward chain, 1 launch/step" if rr else
                                           "g_theta forward kernels (%s path)" % args.precision),
-                               "algorithmic_flops_per_launch": fwd, "ms_per_launch": per["g_fwd"],
+                               "algorithmic_flops_per_launch": fwd, "executed_flops_per_launch": executed, "ms_per_launch": per["g_fwd"],
                                "kernels": kern,
                                "all_g_theta": {"algorithmic_flops_per_step": 3 * fwd, "ms_per_step": g_ms, "launches_per_step": g_launch,
                                                "achieved": 3 * fwd / (g_ms * 1e-3) / 1e12, "frac": 3 * fwd / (g_ms * 1e-3) / 1e12 / peak},
@@ -239,6 +245,8 @@ def main():
                 esz = 4 if args.precision == "fp32" else 2
                 Q = hyp["lstm_hidden"] if hyp["question_injection_position"] == 0 else 0
                 nbytes = M * (2 * k + Q) * esz + B * n * k * 4 + B * Q * 4
+                if rr:                                     # rn_pair_tables instead of the pair matrix: object rows + bias rows
+                    nbytes = B * n * (64 * 2 + hyp["g_layers"][0] * 4) + B * n * k * 4 + B * Q * 4 + (2 * k + Q) * hyp["g_layers"][0] * 4
                 gbs = nbytes / (pb[1] / pb[0] * 1e-3) / 1e9
                 out["pair_build"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                      "frac": gbs / PEAK_HBM_GBS, "bytes_per_launch": nbytes, "us_per_launch": 1e3 * pb[1] / pb[0]}

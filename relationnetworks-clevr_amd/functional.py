@@ -173,6 +173,11 @@ def fused_chain_ok(plan: LayerPlan, code, B, n):
             and all(kp == 256 for kp in plan.kpad[1:]) and (B * n * n) % H.g_chain_tile() == 0 and plan.L <= 8)
 
 
+def alg0_wgrad_ok(plan, k):
+    """Layer-0 weight gradient from the pair reductions (rn_wgrad0_from_reductions) instead of a pass over dZ_0 and P."""
+    return plan.inject == 0 and k <= 32 and os.environ.get("RN_NO_ALGEBRAIC_WGRAD0", "0") != "1"
+
+
 def alg0_forward_ok(plan, code, n, k, M):
     """The factored first layer (rn_g_chain_fwd_rr_alg0): bf16 register-resident chains, question injected at layer 0,
     whole waves per (question, i) and the algebraic layer-0 weight gradient in the backward pass (nothing reads P)."""
@@ -204,7 +209,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
         P16 = torch.empty(M, ld0, dtype=torch.float16, device=dev)
         H.pair_build_fwd(x, q, P16, H.RN_F16, B, n, k, Q, ld0)
         P = None
-        if keep_inputs:
+        if keep_inputs and not alg0_wgrad_ok(plan, k):     # (the algebraic layer-0 weight gradient never reads P)
             P = torch.empty(M, ld0, dtype=dt, device=dev)
             H.pair_build_fwd(x, q, P, code, B, n, k, Q, ld0)
         if (wfrag is not None and len(wfrag) == 2 and len(wfrag[0]) == L and rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0
@@ -457,7 +462,7 @@ class RelationalFunction(torch.autograd.Function):
         # reductions the input gradient needs anyway -- dW_0 = [Rj^T X | Ri^T X | Rq^T Q], db_0 = sum_b Rq -- three tiny
         # products on (B*n)-row matrices instead of a 235 MB pass over dZ_0 and P (and with fp32 x instead of P's
         # rounded copy).  RN_NO_ALGEBRAIC_WGRAD0=1 keeps the kernel.
-        alg0 = plan.inject == 0 and k <= 32 and os.environ.get("RN_NO_ALGEBRAIC_WGRAD0", "0") != "1"
+        alg0 = alg0_wgrad_ok(plan, k)
         # RN_WGRAD_LATE=1 / 2 starts the (HBM-bound) wgrad stream only after the pair reduction / after dx, dq: measured
         # slower (1.246 / 1.266 vs 1.222 ms) -- the window after the backward chain runs at the HBM roofline (~4 TB/s over
         # wgrad + pair reduction, tools/step_timeline.py) wherever the wgrads are put, and later they slow the conv backward

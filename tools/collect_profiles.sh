@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collect the round's rocprofv3 evidence on the GPU box into gpurun_out/prof_final/ (copied to profiles/ afterwards).
+# usage (through gpurun): bash tools/collect_profiles.sh
+R=$PWD
+OUT=$R/gpurun_out/prof_final
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+# 1. kernel trace of the bench command (eager launches: per-kernel durations; the timed bench line itself uses the hipGraph)
+rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-kernel-timing --no-graph > $OUT/kt.log 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/p_kt -name "*.db" | head -1) 13 > $OUT/kernel_stats.csv
+# 2. HBM traffic + SQ counters of the hot-path kernels, one counter set per pass
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/p_$c -o p -- python $R/tools/run_kernels_once.py all > $OUT/pmc_$c.log 2>&1
+  python $R/tools/pmc_table.py $(find /tmp/p_$c -name "*counter_collection.csv" | head -1) > $OUT/pmc_$c.txt
+done
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/p_sq1 -o p -- python $R/tools/run_kernels_once.py all > $OUT/pmc_sq1.log 2>&1
+python $R/tools/pmc_table.py $(find /tmp/p_sq1 -name "*counter_collection.csv" | head -1) > $OUT/pmc_sq1.txt
+rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d /tmp/p_sq2 -o p -- python $R/tools/run_kernels_once.py all > $OUT/pmc_sq2.log 2>&1
+python $R/tools/pmc_table.py $(find /tmp/p_sq2 -name "*counter_collection.csv" | head -1) > $OUT/pmc_sq2.txt
+# 3. the bench line (default command) and the concurrent timeline
+cd $R
+python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
+python tools/step_timeline.py > $OUT/step_timeline.txt 2>&1
+ls -la $OUT
