@@ -56,6 +56,8 @@ class PackedWeights:
         self.hi, self.lo = [], []                  # fp16 split copies for the f16s forward
         self.fT = None                             # transposed fp32 copies of the f_phi weights
         self.w0T = None                            # W_0^T in fp32: the table kernel of the factored first layer
+        self._last = None                          # arguments of the previous get(): what repack_ahead() repeats
+        self._ahead = None                         # key of an ahead-of-time pack not consumed yet
         self.frag_hi, self.frag_lo = [], []        # fragment-major fp16 hi / lo images (f16s on the register-resident chain)
         self.frag = []                             # fragment-major copies for the register-resident chains:
         self.fragT = []                            #   forward W_l, backward step s -> W_{L-1-s}^T
@@ -66,11 +68,33 @@ class PackedWeights:
         chain runs with the factored first layer (rn_g_chain_fwd_rr_alg0): the layer-0 image holds W0[:, 0:k] only and
         W0^T is kept in fp32 for the table kernel (self.w0T)."""
         key = (code, split, bwd_images, rr_only, alg0_k, tuple((w.data_ptr(), w._version) for w in list(g_w) + list(f_w or ())))
+        self._last = (plan, tuple(g_w), code, split, bwd_images, rr_only, tuple(f_w) if f_w is not None else None, alg0_k)
+        if self._ahead == key:                              # packed by repack_ahead() earlier in this forward pass
+            self._ahead = None
+            return self.fwd, self.bwd
+        self._ahead = None
         # while a hipGraph is being captured the pack kernels must be part of it (a replay sees
-        # new weights every step), so the cache is bypassed.  (Packing ahead of time on a side stream at the start of
-        # the forward pass was measured: the extra fork/join costs more than the 11 us it hides.)
+        # new weights every step), so the cache is bypassed
         if key == self.key and not torch.cuda.is_current_stream_capturing():
             return self.fwd, self.bwd
+        return self._pack(key, plan, g_w, code, split, bwd_images, rr_only, f_w, alg0_k)
+
+    def repack_ahead(self):
+        """Repeat the previous get()'s pack NOW, on the caller's current stream -- RN.forward calls this on the question
+        encoder's side stream, whose fork and join around the conv stack exist anyway (a fork / join of its own costs
+        more than the 11 us it hides: measured).  The next get() with the same arguments returns the images without
+        launching anything; the caller's join orders it after this stream."""
+        if self._last is None or os.environ.get("RN_NO_PACK_AHEAD", "0") == "1":
+            return
+        plan, g_w, code, split, bwd_images, rr_only, f_w, alg0_k = self._last
+        if not torch.is_grad_enabled():
+            bwd_images = False
+        key = (code, split, bwd_images, rr_only, alg0_k, tuple((w.data_ptr(), w._version) for w in list(g_w) + list(f_w or ())))
+        if key != self.key or torch.cuda.is_current_stream_capturing():
+            self._pack(key, plan, g_w, code, split, bwd_images, rr_only, f_w, alg0_k)
+        self._ahead = key
+
+    def _pack(self, key, plan, g_w, code, split, bwd_images, rr_only, f_w, alg0_k):
         dt = H.torch_dtype(code)
         dev = g_w[0].device
         self.fwd, self.bwd, self.hi, self.lo, self.frag, self.fragT = [], [], [], [], [], []

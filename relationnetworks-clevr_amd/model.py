@@ -275,6 +275,7 @@ class RN(nn.Module):
         side = self._side_stream
         side.wait_stream(cur)
         with torch.cuda.stream(side):
+            self.rl._packed.repack_ahead()                      # this step's weight images: off the critical path, same fork/join
             qst = self.text(qst_idxs)
         return qst, side
 
