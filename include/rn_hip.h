@@ -256,6 +256,17 @@ size_t rn_f_phi_bwd_ws_bytes(int B, int F1, int F2, int A);
 int rn_f_phi_bwd(const float* gout, const float* out, const float* f2, const float* f1, const float* xg, const float* W1,
                  const float* W2, const float* W3, const float* mask, float* dW1, float* db1, float* dW2, float* db2,
                  float* dW3, float* db3, float* dxg, void* ws, int B, int G, int F1, int F2, int A, void* stream);
+/* The same with the mean negative log-likelihood of the batch (F.nll_loss(output, label), train.py:41) folded in:
+ * the forward also writes loss[0] = -mean_b out[b][label[b]] (label: int64, 0 <= label < A), the backward takes
+ * gloss = d L / d loss (one device float) instead of a log-prob gradient.  sync_ws: rn_f_phi_nll_ws_bytes(B) bytes that the
+ * caller zeroes ONCE; afterwards it belongs to these calls (block partials + a self re-arming completion counter). */
+size_t rn_f_phi_nll_ws_bytes(int B);
+int rn_f_phi_fwd_nll(const float* xg, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                     const float* b3, const float* mask, const long long* label, float* f1, float* f2, float* out, float* loss,
+                     void* sync_ws, int transposed, int B, int G, int F1, int F2, int A, void* stream);
+int rn_f_phi_bwd_nll(const float* gloss, const long long* label, const float* out, const float* f2, const float* f1, const float* xg,
+                     const float* W1, const float* W2, const float* W3, const float* mask, float* dW1, float* db1, float* dW2,
+                     float* db2, float* dW3, float* db3, float* dxg, void* ws, int B, int G, int F1, int F2, int A, void* stream);
 
 /* F.nll_loss(log_probs, label), mean reduction (train.py:41): loss[0] = -mean_b logp[b, label[b]];
  * backward: gout (B, A) = -gloss[0] / B at (b, label[b]), 0 elsewhere (the whole tensor is written).

@@ -243,8 +243,11 @@ template <bool TR>
 __global__ __launch_bounds__(TR ? FP_KS * 256 : 256) void f_phi_fwd_kernel(
     const float* __restrict__ xg, const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
     const float* __restrict__ b2, const float* __restrict__ W3, const float* __restrict__ b3, const float* __restrict__ mask,
-    float* __restrict__ f1, float* __restrict__ f2, float* __restrict__ out, int B, int G, int F1, int F2, int A) {
+    float* __restrict__ f1, float* __restrict__ f2, float* __restrict__ out, int B, int G, int F1, int F2, int A,
+    const long long* __restrict__ label = nullptr, float* __restrict__ loss = nullptr, float* loss_part = nullptr,
+    unsigned* done_count = nullptr) {
   __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW], red[FP_KS * FP_RB * 256];
+  __shared__ float lrow[FP_RB];
   const int t = threadIdx.x, r0 = blockIdx.x * FP_RB;
   for (int c = t; c < FP_RB * G; c += blockDim.x) {
     const int r = c / G, k = c - r * G;
@@ -275,6 +278,25 @@ __global__ __launch_bounds__(TR ? FP_KS * 256 : 256) void f_phi_fwd_kernel(
     for (int a = 0; a < A; ++a) s += expf(z[a] - mx);
     const float ls = mx + logf(s);
     for (int a = 0; a < A; ++a) out[(long)(r0 + t) * A + a] = z[a] - ls;
+    if (label) lrow[t] = -(z[label[r0 + t]] - ls);
+  } else if (t < FP_RB) {
+    lrow[t] = 0.f;
+  }
+  // mean NLL of the batch (train.py:41) in the same launch: block partials in a fixed order, combined by whichever
+  // block finishes last (also in a fixed order: deterministic); the counter re-arms itself for the next launch
+  if (label) {
+    __syncthreads();
+    if (t == 0) {
+      loss_part[blockIdx.x] = ((lrow[0] + lrow[1]) + lrow[2]) + lrow[3];
+      __threadfence();
+      if (atomicAdd(done_count, 1u) == gridDim.x - 1) {
+        __threadfence();
+        float tot = 0.f;
+        for (unsigned i = 0; i < gridDim.x; ++i) tot += reinterpret_cast<volatile float*>(loss_part)[i];
+        *loss = tot / (float)B;
+        *done_count = 0u;
+      }
+    }
   }
 }
 
@@ -284,16 +306,22 @@ __global__ __launch_bounds__(FP_KS * 256) void f_phi_bwd_dz_kernel(const float* 
                                                            const float* __restrict__ W1, const float* __restrict__ W2,
                                                            const float* __restrict__ W3, const float* __restrict__ mask,
                                                            float* __restrict__ dz3, float* __restrict__ dz2, float* __restrict__ dz1,
-                                                           float* __restrict__ dxg, int B, int G, int F1, int F2, int A) {
+                                                           float* __restrict__ dxg, int B, int G, int F1, int F2, int A,
+                                                           const long long* __restrict__ label = nullptr,
+                                                           const float* __restrict__ gloss = nullptr) {
   __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW], red[FP_KS * FP_RB * 256];
   const int t = threadIdx.x, r0 = blockIdx.x * FP_RB;
   if (t < FP_RB) {
     const int b = r0 + t;
-    float s = 0.f;
-    if (b < B)
+    // label mode: gout = d(mean NLL)/d out = -gloss / B at the label, 0 elsewhere -- never materialised
+    const float gl = label ? -gloss[0] / (float)B : 0.f;
+    const int lb = (label && b < B) ? (int)label[b] : -1;
+    float s = label ? gl : 0.f;
+    if (b < B && !label)
       for (int a = 0; a < A; ++a) s += gout[(long)b * A + a];
     for (int a = 0; a < A; ++a) {
-      const float v = (b < B) ? gout[(long)b * A + a] - expf(out[(long)b * A + a]) * s : 0.f;
+      const float go = label ? (a == lb ? gl : 0.f) : (b < B ? gout[(long)b * A + a] : 0.f);
+      const float v = (b < B) ? go - expf(out[(long)b * A + a]) * s : 0.f;
       sa[t * FP_MAXW + a] = v;
       if (b < B) dz3[(long)b * A + a] = v;
     }
@@ -373,6 +401,24 @@ extern "C" int rn_f_phi_fwd(const float* xg, const float* W1, const float* b1, c
   return 0;
 }
 
+// f_phi + log_softmax + mean NLL (train.py:40-41) in one launch.  sync_ws: rn_f_phi_nll_ws_bytes(B) bytes, ZEROED ONCE by the
+// caller and then owned by these calls (block partials + a completion counter that re-arms itself).
+extern "C" size_t rn_f_phi_nll_ws_bytes(int B) { return B > 0 ? ((size_t)cdiv(B, FP_RB) + 4) * sizeof(float) : 0; }
+
+extern "C" int rn_f_phi_fwd_nll(const float* xg, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                                const float* b3, const float* mask, const long long* label, float* f1, float* f2, float* out,
+                                float* loss, void* sync_ws, int transposed, int B, int G, int F1, int F2, int A, void* stream) {
+  RN_CHECK_ARG(xg && W1 && b1 && W2 && b2 && W3 && b3 && f1 && f2 && out && label && loss && sync_ws, "rn_f_phi_fwd_nll: NULL pointer");
+  if (int rc = fp_check("rn_f_phi_fwd_nll", B, G, F1, F2, A)) return rc;
+  RN_CHECK_ARG(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)W3) % 16 == 0, "rn_f_phi_fwd_nll: weights must be 16-byte aligned");
+  unsigned* cnt = (unsigned*)sync_ws;
+  float* part = (float*)sync_ws + 4;
+  if (transposed) f_phi_fwd_kernel<true><<<cdiv(B, FP_RB), FP_KS * 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A, label, loss, part, cnt);
+  else f_phi_fwd_kernel<false><<<cdiv(B, FP_RB), 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A, label, loss, part, cnt);
+  RN_LAUNCH_CHECK("rn_f_phi_fwd_nll");
+  return 0;
+}
+
 extern "C" size_t rn_f_phi_bwd_ws_bytes(int B, int F1, int F2, int A) { return (size_t)B * (F1 + F2 + A) * sizeof(float); }
 
 extern "C" int rn_f_phi_bwd(const float* gout, const float* out, const float* f2, const float* f1, const float* xg, const float* W1,
@@ -387,6 +433,24 @@ extern "C" int rn_f_phi_bwd(const float* gout, const float* out, const float* f2
   f_phi_bwd_dz_kernel<<<cdiv(B, FP_RB), FP_KS * 256, 0, s>>>(gout, out, f2, f1, W1, W2, W3, mask, dz3, dz2, dz1, dxg, B, G, F1, F2, A);
   f_phi_bwd_grads_kernel<<<F1 + F2 + A, 256, 0, s>>>(dz1, dz2, dz3, xg, f1, f2, dW1, db1, dW2, db2, dW3, db3, B, G, F1, F2, A);
   RN_LAUNCH_CHECK("rn_f_phi_bwd");
+  return 0;
+}
+
+// Backward of rn_f_phi_fwd_nll: gloss = d L / d loss (one device float); the log-prob gradient -gloss/B at the labels is
+// formed inside the first kernel.
+extern "C" int rn_f_phi_bwd_nll(const float* gloss, const long long* label, const float* out, const float* f2, const float* f1,
+                                const float* xg, const float* W1, const float* W2, const float* W3, const float* mask, float* dW1,
+                                float* db1, float* dW2, float* db2, float* dW3, float* db3, float* dxg, void* ws, int B, int G, int F1,
+                                int F2, int A, void* stream) {
+  RN_CHECK_ARG(gloss && label && out && f2 && f1 && xg && W1 && W2 && W3 && dW1 && db1 && dW2 && db2 && dW3 && db3 && dxg && ws, "rn_f_phi_bwd_nll: NULL pointer");
+  if (int rc = fp_check("rn_f_phi_bwd_nll", B, G, F1, F2, A)) return rc;
+  float* dz1 = (float*)ws;
+  float* dz2 = dz1 + (size_t)B * F1;
+  float* dz3 = dz2 + (size_t)B * F2;
+  hipStream_t s = (hipStream_t)stream;
+  f_phi_bwd_dz_kernel<<<cdiv(B, FP_RB), FP_KS * 256, 0, s>>>(nullptr, out, f2, f1, W1, W2, W3, mask, dz3, dz2, dz1, dxg, B, G, F1, F2, A, label, gloss);
+  f_phi_bwd_grads_kernel<<<F1 + F2 + A, 256, 0, s>>>(dz1, dz2, dz3, xg, f1, f2, dW1, db1, dW2, db2, dW3, db3, B, G, F1, F2, A);
+  RN_LAUNCH_CHECK("rn_f_phi_bwd_nll");
   return 0;
 }
 

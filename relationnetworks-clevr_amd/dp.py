@@ -190,8 +190,11 @@ class DataParallelTrainer:
 
     def _fwd_bwd(self, img, qst, label):
         self.bucket.detach_()
-        out = self.model(img, qst)
-        loss = RF.nll_loss_mean(out, label)                # F.nll_loss (mean), one launch each way on the GPU
+        if hasattr(self.model, "forward_loss") and img.is_cuda and os.environ.get("RN_NO_FUSED_LOSS", "0") != "1":
+            _, loss = self.model.forward_loss(img, qst, label)     # F.nll_loss (mean) inside the f_phi launches
+        else:
+            out = self.model(img, qst)
+            loss = RF.nll_loss_mean(out, label)            # F.nll_loss (mean), one launch each way on the GPU
         loss.backward()
         self.bucket.gather_()
         return loss

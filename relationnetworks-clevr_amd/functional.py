@@ -350,15 +350,19 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
     return inputs, cur, None
 
 
-def f_phi_forward(xg, fw, fb, mask, wT=None):
+def f_phi_forward(xg, fw, fb, mask, wT=None, label=None):
     """f_phi + log_softmax (model.py:155-162): fc1 -> relu -> fc2 -> dropout mask -> relu -> fc3 -> log_softmax,
-    fp32.  Returns (f1, f2, log_probs)."""
+    fp32.  Returns (f1, f2, log_probs), with `label` (int64 (B,)) also the mean NLL as a fourth element (same launch)."""
     B, G = xg.shape
     dev = xg.device
     F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
     f1 = torch.empty(B, F1, dtype=torch.float32, device=dev)
     f2 = torch.empty(B, F2, dtype=torch.float32, device=dev)
     out = torch.empty(B, A, dtype=torch.float32, device=dev)
+    if label is not None:
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        H.f_phi_fwd_nll(xg, wT if wT is not None else fw, fb, mask, label, f1, f2, out, loss, transposed=wT is not None)
+        return f1, f2, out, loss
     if wT is not None:
         H.f_phi_fwd(xg, wT, fb, mask, f1, f2, out, transposed=True)      # one launch (rn_small.hip), coalesced weight reads
     else:
@@ -367,10 +371,12 @@ def f_phi_forward(xg, fw, fb, mask, wT=None):
 
 
 class RelationalFunction(torch.autograd.Function):
-    """(x, q, dropout_mask | None, plan, packed, precision, g_w.., g_b.., f_w.., f_b..) -> log-probs (B, A)."""
+    """(x, q, dropout_mask | None, plan, packed, precision, label | None, g_w.., g_b.., f_w.., f_b..) -> log-probs (B, A),
+    or with `label` (int64 (B,)) -> (log-probs, mean NLL): the loss of train.py:41 rides in the f_phi launches."""
 
     @staticmethod
-    def forward(ctx, x, q, mask, plan, packed, precision, *params):
+    def forward(ctx, x, q, mask, plan, packed, precision, label, *params):
+        ctx.set_materialize_grads(False)
         L = plan.L
         g_w, g_b = params[0:L], params[L:2 * L]
         f_w, f_b = params[2 * L:2 * L + 3], params[2 * L + 3:2 * L + 6]
@@ -404,7 +410,13 @@ class RelationalFunction(torch.autograd.Function):
         F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
         if mask is not None:
             mask = mask.float().contiguous()
-        f1, f2, out = f_phi_forward(xg, fw, fb, mask, wT=packed.fT)
+        loss = None
+        if label is not None:
+            label = label.long().contiguous()
+            f1, f2, out, loss = f_phi_forward(xg, fw, fb, mask, wT=packed.fT, label=label)
+        else:
+            f1, f2, out = f_phi_forward(xg, fw, fb, mask, wT=packed.fT)
+        ctx.label = label
         if need_grad:
             ctx.plan, ctx.code, ctx.dims = plan, code, (B, n, k, Q, M, G, F1, F2, A)
             ctx.inputs, ctx.HL, ctx.wbwd = inputs, HL, wbwd
@@ -414,24 +426,37 @@ class RelationalFunction(torch.autograd.Function):
             ctx.fw = fw
             ctx.mask = mask
             ctx.save_for_backward(x, q, xg, f1, f2, out)
-        return out
+        return out if label is None else (out, loss)
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, gloss=None):
         plan, code = ctx.plan, ctx.code
         B, n, k, Q, M, G, F1, F2, A = ctx.dims
         x, q, xg, f1, f2, out = ctx.saved_tensors
         dev = x.device
         L = plan.L
         f32 = dict(dtype=torch.float32, device=dev)
-        gout = gout.float().contiguous()
+        label = ctx.label
+        if gout is not None and gloss is not None:          # both outputs were used: fold the loss term into the log-prob gradient
+            gout = gout.float().clone()
+            gout[torch.arange(B, device=dev), label] -= gloss.float() / B
+            gloss = None
+        if gout is None and gloss is None:
+            gout = torch.zeros(B, A, **f32)
+        if gout is not None:
+            gout = gout.float().contiguous()
+        else:
+            gloss = gloss.float().contiguous()
         fw = ctx.fw
         # ---- f_phi backward (fp32): two launches (dz chain incl. log_softmax; all weight / bias gradients)
         dW3 = torch.empty(A, F2, **f32); db3 = torch.empty(A, **f32)
         dW2 = torch.empty(F2, F1, **f32); db2 = torch.empty(F2, **f32)
         dW1 = torch.empty(F1, G, **f32); db1 = torch.empty(F1, **f32)
         dxg = torch.empty(B, G, **f32)
-        H.f_phi_bwd(gout, out, f2, f1, xg, fw, ctx.mask, (dW1, dW2, dW3), (db1, db2, db3), dxg)
+        if gout is None:
+            H.f_phi_bwd_nll(gloss, label, out, f2, f1, xg, fw, ctx.mask, (dW1, dW2, dW3), (db1, db2, db3), dxg)
+        else:
+            H.f_phi_bwd(gout, out, f2, f1, xg, fw, ctx.mask, (dW1, dW2, dW3), (db1, db2, db3), dxg)
         # ---- g_theta backward
         dt = H.torch_dtype(code)
         inputs, wbwd, g_w = ctx.inputs, ctx.wbwd, ctx.g_w
@@ -564,15 +589,16 @@ class RelationalFunction(torch.autograd.Function):
                 dZ = dZp
             inputs[l] = None
         ctx.inputs = None
-        grads = [dx if ctx.needs_input_grad[0] else None, dq if ctx.needs_input_grad[1] else None, None, None, None, None]
+        grads = [dx if ctx.needs_input_grad[0] else None, dq if ctx.needs_input_grad[1] else None, None, None, None, None, None]
         grads += gW + gB + [dW1, dW2, dW3, db1, db2, db3]
         return tuple(grads)
 
 
-def relational_forward(x, q, mask, plan, packed, precision, g_w, g_b, f_w, f_b):
+def relational_forward(x, q, mask, plan, packed, precision, g_w, g_b, f_w, f_b, label=None):
+    """-> log-probs, or (log-probs, mean NLL) when `label` is given."""
     if precision not in PRECISIONS:
         raise ValueError("precision must be one of %r" % (PRECISIONS,))
-    return RelationalFunction.apply(x, q, mask, plan, packed, precision, *g_w, *g_b, *f_w, *f_b)
+    return RelationalFunction.apply(x, q, mask, plan, packed, precision, label, *g_w, *g_b, *f_w, *f_b)
 
 
 _ZEROS = {}

@@ -147,7 +147,17 @@ class RelationalLayer(RelationalLayerBase):
             self._plan_cache[key] = RF.LayerPlan(k, self.qst_size, self.g_layers_size, self.quest_inject_position)
         return self._plan_cache[key]
 
+    def draw_dropout_ahead(self, b, device):
+        """Draw this forward pass's dropout mask NOW (RN.forward: on the question encoder's side stream, instead of three
+        small launches between the conv stack and the g chain).  The mask is the pass's only RNG draw either way."""
+        self._mask_ahead = None
+        if self.forced_dropout_mask is None and self.training and self.dropout.p > 0 and not self._hooked():
+            self._mask_ahead = (b, self._dropout_mask(b, device))
+
     def _dropout_mask(self, b, device):
+        ahead, self._mask_ahead = getattr(self, "_mask_ahead", None), None
+        if ahead is not None and ahead[0] == b and ahead[1].device == device:
+            return ahead[1]
         if self.forced_dropout_mask is not None:
             return self.forced_dropout_mask.to(device=device, dtype=torch.float32)
         if self.training and self.dropout.p > 0:
@@ -158,11 +168,14 @@ class RelationalLayer(RelationalLayerBase):
     def _hooked(self):
         return self.extraction or any(len(l._forward_hooks) for l in self.g_layers)
 
-    def forward(self, x, qst):
+    def forward(self, x, qst, label=None):
+        """label (int64 (B,), optional, not part of the reference signature): also return the mean NLL of train.py:41,
+        computed inside the f_phi launches -> (log_probs, loss)."""
         b, d, k = x.size()
         plan = self._plan(k)
         if self._hooked():
-            return self._forward_hook_compat(x, qst, plan)
+            out = self._forward_hook_compat(x, qst, plan)
+            return out if label is None else (out, RF.nll_loss_mean(out, label))
         g_w = [l.weight for l in self.g_layers]
         g_b = [l.bias for l in self.g_layers]
         f_w = [self.f_fc1.weight, self.f_fc2.weight, self.f_fc3.weight]
@@ -172,7 +185,7 @@ class RelationalLayer(RelationalLayerBase):
         if prec == "auto":
             fused = RF.fused_chain_ok(plan, H.RN_BF16, b, d)
             prec = "f16s" if fused else "bf16"
-        return RF.relational_forward(x, qst, mask, plan, self._packed, prec, g_w, g_b, f_w, f_b)
+        return RF.relational_forward(x, qst, mask, plan, self._packed, prec, g_w, g_b, f_w, f_b, label=label)
 
     @torch.no_grad()
     def extract_features(self, x, qst, layer_idx):
@@ -276,10 +289,15 @@ class RN(nn.Module):
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             self.rl._packed.repack_ahead()                      # this step's weight images: off the critical path, same fork/join
+            self.rl.draw_dropout_ahead(qst_idxs.shape[0], qst_idxs.device)
             qst = self.text(qst_idxs)
         return qst, side
 
-    def forward(self, img, qst_idxs):
+    def forward_loss(self, img, qst_idxs, label):
+        """forward + F.nll_loss(output, label) (train.py:40-41) with the loss folded into the f_phi kernels: -> (log_probs, loss)."""
+        return self.forward(img, qst_idxs, label=label)
+
+    def forward(self, img, qst_idxs, label=None):
         side = None
         if self.overlap_streams and qst_idxs.is_cuda and not self.state_desc:
             qst, side = self._text_on_side_stream(qst_idxs)
@@ -300,7 +318,10 @@ class RN(nn.Module):
             cur = torch.cuda.current_stream()
             cur.wait_stream(side)
             qst.record_stream(cur)
-        return self.rl(x, qst)
+            ahead = getattr(self.rl, "_mask_ahead", None)
+            if ahead is not None:
+                ahead[1].record_stream(cur)
+        return self.rl(x, qst) if label is None else self.rl(x, qst, label=label)
 
     @torch.no_grad()
     def extract_features(self, img, qst_idxs, layer_idx):

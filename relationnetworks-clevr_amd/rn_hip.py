@@ -63,6 +63,9 @@ SIGNATURES = {
     "rn_pair_features": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "rn_f_phi_fwd": (_I, [_P] * 11 + [_I] * 6 + [_P]),
     "rn_f_phi_bwd_ws_bytes": (_Z, [_I, _I, _I, _I]),
+    "rn_f_phi_nll_ws_bytes": (_Z, [_I]),
+    "rn_f_phi_fwd_nll": (_I, [_P] * 14 + [_I] * 6 + [_P]),
+    "rn_f_phi_bwd_nll": (_I, [_P] * 18 + [_I] * 5 + [_P]),
     "rn_f_phi_bwd": (_I, [_P] * 17 + [_I] * 5 + [_P]),
     "rn_lstm_fwd": (_I, [_P] * 10 + [_I] * 5 + [_P]),
     "rn_lstm_bwd": (_I, [_P] * 5 + [_I] * 3 + [_P]),
@@ -466,6 +469,41 @@ def f_phi_fwd(xg, fw, fb, mask, f1, f2, out, transposed=False):
     _check(load().rn_f_phi_fwd(xg.data_ptr(), fw[0].data_ptr(), fb[0].data_ptr(), fw[1].data_ptr(), fb[1].data_ptr(), fw[2].data_ptr(),
                                fb[2].data_ptr(), _ptr(mask), f1.data_ptr(), f2.data_ptr(), out.data_ptr(), int(transposed), B, G, F1, F2, A,
                                _stream()), "rn_f_phi_fwd")
+
+
+_NLL_WS = {}
+
+
+def _nll_sync_ws(B, device):
+    """The zeroed-once workspace of rn_f_phi_fwd_nll (block partials + completion counter), one per (device, B)."""
+    key = (device, B)
+    ws = _NLL_WS.get(key)
+    if ws is None:
+        ws = _NLL_WS[key] = torch.zeros(max(load().rn_f_phi_nll_ws_bytes(B), 16), dtype=torch.uint8, device=device)
+    return ws
+
+
+@_timed("f_phi")
+def f_phi_fwd_nll(xg, fw, fb, mask, label, f1, f2, out, loss, transposed=False):
+    """f_phi + log_softmax + mean NLL in one launch (rn_f_phi_fwd_nll); label: int64 (B,)."""
+    B, G = xg.shape
+    F1, F2, A = (fw[0].shape[1], fw[1].shape[1], fw[2].shape[1]) if transposed else (fw[0].shape[0], fw[1].shape[0], fw[2].shape[0])
+    _check(load().rn_f_phi_fwd_nll(xg.data_ptr(), fw[0].data_ptr(), fb[0].data_ptr(), fw[1].data_ptr(), fb[1].data_ptr(), fw[2].data_ptr(),
+                                   fb[2].data_ptr(), _ptr(mask), label.data_ptr(), f1.data_ptr(), f2.data_ptr(), out.data_ptr(),
+                                   loss.data_ptr(), _nll_sync_ws(B, xg.device).data_ptr(), int(transposed), B, G, F1, F2, A, _stream()),
+           "rn_f_phi_fwd_nll")
+
+
+@_timed("f_phi")
+def f_phi_bwd_nll(gloss, label, out, f2, f1, xg, fw, mask, dW, db, dxg):
+    B, G = xg.shape
+    F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
+    lib = load()
+    ws = torch.empty(max(lib.rn_f_phi_bwd_ws_bytes(B, F1, F2, A), 16), dtype=torch.uint8, device=xg.device)
+    _check(lib.rn_f_phi_bwd_nll(gloss.data_ptr(), label.data_ptr(), out.data_ptr(), f2.data_ptr(), f1.data_ptr(), xg.data_ptr(),
+                                fw[0].data_ptr(), fw[1].data_ptr(), fw[2].data_ptr(), _ptr(mask), dW[0].data_ptr(), db[0].data_ptr(),
+                                dW[1].data_ptr(), db[1].data_ptr(), dW[2].data_ptr(), db[2].data_ptr(), dxg.data_ptr(), ws.data_ptr(),
+                                B, G, F1, F2, A, _stream()), "rn_f_phi_bwd_nll")
 
 
 @_timed("f_phi")

@@ -789,6 +789,37 @@ def test_conv3x3s2_direct(H, N, Cin, hw):
         assert rel(dx.cpu().numpy(), xr.grad.cpu().numpy()) <= F32_TOL
 
 
+def test_f_phi_nll_fused(H):
+    """f_phi + log_softmax + mean NLL in one launch each way: loss and every gradient must equal the two-step path
+    (rn_f_phi_fwd + rn_nll_mean_*); the completion counter must re-arm (second call)."""
+    B, G, F1, F2, A = 37, 256, 256, 256, 28
+    xg = dev(formula.hash_uniform((B, G), 500, -1, 1))
+    fw = [dev(formula.hash_uniform(sh, 501 + i, -0.1, 0.1)) for i, sh in enumerate([(F1, G), (F2, F1), (A, F2)])]
+    fb = [dev(formula.hash_uniform((n_,), 505 + i, -0.1, 0.1)) for i, n_ in enumerate([F1, F2, A])]
+    mask = dev((formula.hash_uniform((B, F2), 509, 0, 1) > 0.5).astype(np.float32) * 2)
+    label = torch.tensor(formula.hash_uniform((B,), 510, 0, A).astype(np.int64).clip(0, A - 1), device="cuda")
+    wT = [w.t().contiguous() for w in fw]
+    f32 = dict(dtype=torch.float32, device="cuda")
+    for rep in range(2):
+        f1 = torch.empty(B, F1, **f32); f2 = torch.empty(B, F2, **f32); out = torch.empty(B, A, **f32); loss = torch.full((), 9.0, **f32)
+        H.f_phi_fwd_nll(xg, wT, fb, mask, label, f1, f2, out, loss, transposed=True)
+        r1 = torch.empty(B, F1, **f32); r2 = torch.empty(B, F2, **f32); ro = torch.empty(B, A, **f32)
+        H.f_phi_fwd(xg, wT, fb, mask, r1, r2, ro, transposed=True)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ro) and torch.equal(f2, r2)
+        ref_loss = -ro[torch.arange(B), label].double().mean()
+        assert abs(float(loss) - float(ref_loss)) <= 1e-6 * abs(float(ref_loss))
+    gl = torch.tensor(0.7, **f32)
+    gout = torch.zeros(B, A, **f32); gout[torch.arange(B), label] = -0.7 / B
+    mk = lambda: ([torch.empty_like(w) for w in fw], [torch.empty_like(b) for b in fb], torch.empty(B, G, **f32))
+    dWa, dba, dxa = mk(); dWb, dbb, dxb = mk()
+    H.f_phi_bwd_nll(gl, label, out, f2, f1, xg, fw, mask, dWa, dba, dxa)
+    H.f_phi_bwd(gout, out, f2, f1, xg, fw, mask, dWb, dbb, dxb)
+    torch.cuda.synchronize()
+    for a, b in zip(dWa + dba + [dxa], dWb + dbb + [dxb]):
+        assert rel(a.cpu().numpy(), b.cpu().numpy()) <= 1e-6
+
+
 # ----------------------------------------------------------------------------- mean NLL loss
 def test_nll_mean():
     """NllMeanFunction against F.nll_loss (mean): value and gradient (exact up to the final rounding)."""
