@@ -6,10 +6,13 @@
 // from LDS (every lane reads the same 16 bytes), 9 * CIN * COUT FMAs per thread against 9 * CIN (4 * COUT) loads.
 // The weight gradient is a (24 x 9 CIN) x positions product on the fp32 matrix pipe (conv3x3s2_wgrad_kernel below).
 // NCHW fp32, H and W even.
+#include <stdlib.h>
+
 #include "rn_common.h"
 
 namespace {
 constexpr int CV_T = 256;
+constexpr long CV_KS_MAX = 100000;   // up to this many output pixels (2x2 input blocks) the reduction axis is split over the waves
 }
 
 // y[n][co][oy][ox] = sum_{ci,ky,kx} w[co][ci][ky][kx] * x[n][ci][2 oy + ky - 1][2 ox + kx - 1]
@@ -132,6 +135,144 @@ __global__ __launch_bounds__(CV_T) void conv3x3s2_bwd_data_kernel(const float* _
   }
 }
 
+// ---- the small layers (16x16 and 8x8 outputs at the headline shape): with one thread per pixel there are only 16-64
+// workgroups of single-wave-per-SIMD code whose channel loop is a serial chain of loads and FMAs (19 us for 0.04 GFLOP).
+// Here the reduction axis is split over the 4 waves of a workgroup: 64 pixels x 4 channel quarters, partial sums meet in
+// LDS, wave q finalises a quarter of the outputs.  4x the workgroups, a quarter of the chain per thread.
+template <int CIN, int COUT, int CG>
+__global__ __launch_bounds__(CV_T) void conv3x3s2_fwd_ks_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                float* __restrict__ y, int N, int H, int W) {
+  constexpr int KS = 4, CQ = CIN / KS;
+  static_assert(CIN % KS == 0 && CG % KS == 0, "quarters");
+  __shared__ __attribute__((aligned(16))) float ws[CIN * 9 * CG];            // [ci][tap][co in group]
+  __shared__ float red[KS][CG][64];
+  const int g0 = blockIdx.y * CG;
+  for (int i = threadIdx.x; i < CIN * 9 * CG; i += CV_T) {
+    const int co = i % CG, ct = i / CG;
+    ws[i] = w[(long)(g0 + co) * CIN * 9 + ct];
+  }
+  __syncthreads();
+  const int OH = H >> 1, OW = W >> 1;
+  const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6;
+  const long p = (long)blockIdx.x * 64 + lane;
+  const bool live = p < (long)N * OH * OW;
+  const long pp = live ? p : 0;
+  const int ox = (int)(pp % OW), oy = (int)((pp / OW) % OH), n = (int)(pp / ((long)OW * OH));
+  float acc[CG];
+#pragma unroll
+  for (int c = 0; c < CG; ++c) acc[c] = 0.f;
+  const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+  const float* xn = x + ((long)n * CIN + kq * CQ) * H * W;
+  int off[9];
+  bool ok[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = iy0 + ky, ix = ix0 + kx;
+      ok[ky * 3 + kx] = iy >= 0 && ix >= 0;
+      off[ky * 3 + kx] = ok[ky * 3 + kx] ? iy * W + ix : 0;
+    }
+  float t[CQ][9];                                                            // all of this quarter's taps in flight at once
+#pragma unroll
+  for (int c = 0; c < CQ; ++c)
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) t[c][tp] = ok[tp] ? xn[(long)c * H * W + off[tp]] : 0.f;
+#pragma unroll
+  for (int c = 0; c < CQ; ++c) {
+    const float* wc = ws + (kq * CQ + c) * 9 * CG;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+      for (int o = 0; o < CG; o += 4) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wc + tp * CG + o);
+        acc[o] = fmaf(wv[0], t[c][tp], acc[o]);
+        acc[o + 1] = fmaf(wv[1], t[c][tp], acc[o + 1]);
+        acc[o + 2] = fmaf(wv[2], t[c][tp], acc[o + 2]);
+        acc[o + 3] = fmaf(wv[3], t[c][tp], acc[o + 3]);
+      }
+  }
+#pragma unroll
+  for (int o = 0; o < CG; ++o) red[kq][o][lane] = acc[o];
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int o = kq * (CG / KS); o < (kq + 1) * (CG / KS); ++o)
+      y[((long)n * COUT + g0 + o) * OH * OW + (long)oy * OW + ox] = ((red[0][o][lane] + red[1][o][lane]) + red[2][o][lane]) + red[3][o][lane];
+  }
+}
+
+template <int CIN, int COUT, int CG>
+__global__ __launch_bounds__(CV_T) void conv3x3s2_bwd_data_ks_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                     float* __restrict__ dx, int N, int H, int W) {
+  constexpr int KS = 4, CQ = COUT / KS;
+  static_assert(COUT % KS == 0 && CG % KS == 0, "quarters");
+  __shared__ __attribute__((aligned(16))) float ws[COUT * 9 * CG];           // [co][tap][ci in group]
+  __shared__ float red[KS][4 * CG][64];
+  const int g0 = blockIdx.y * CG;
+  for (int i = threadIdx.x; i < COUT * 9 * CG; i += CV_T) {
+    const int ci = i % CG, r = i / CG, tap = r % 9, co = r / 9;
+    ws[i] = w[((long)co * CIN + g0 + ci) * 9 + tap];
+  }
+  __syncthreads();
+  const int OH = H >> 1, OW = W >> 1;
+  const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6;
+  const long p = (long)blockIdx.x * 64 + lane;
+  const bool live = p < (long)N * OH * OW;
+  const long pp = live ? p : 0;
+  const int b = (int)(pp % OW), a = (int)((pp / OW) % OH), n = (int)(pp / ((long)OW * OH));
+  float a00[CG], a01[CG], a10[CG], a11[CG];
+#pragma unroll
+  for (int c = 0; c < CG; ++c) a00[c] = a01[c] = a10[c] = a11[c] = 0.f;
+  const bool ra = a + 1 < OH, rb = b + 1 < OW;
+  const float* dn = dy + ((long)n * COUT + kq * CQ) * OH * OW + (long)a * OW + b;
+  const int o01 = rb ? 1 : 0, o10 = ra ? OW : 0, o11 = (ra && rb) ? OW + 1 : 0;
+  float d[CQ][4];
+#pragma unroll
+  for (int c = 0; c < CQ; ++c) {
+    const float* dc = dn + (long)c * OH * OW;
+    d[c][0] = dc[0];
+    d[c][1] = rb ? dc[o01] : 0.f;
+    d[c][2] = ra ? dc[o10] : 0.f;
+    d[c][3] = (ra && rb) ? dc[o11] : 0.f;
+  }
+#pragma unroll
+  for (int cc = 0; cc < CQ; ++cc) {
+    const float d00 = d[cc][0], d01 = d[cc][1], d10 = d[cc][2], d11 = d[cc][3];
+    const float* wc = ws + (kq * CQ + cc) * 9 * CG;
+#pragma unroll
+    for (int c = 0; c < CG; c += 4) {
+      f32x4 wv[9];
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) wv[tp] = *reinterpret_cast<const f32x4*>(wc + tp * CG + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a00[c + e] = fmaf(wv[4][e], d00, a00[c + e]);
+        a01[c + e] = fmaf(wv[3][e], d01, fmaf(wv[5][e], d00, a01[c + e]));
+        a10[c + e] = fmaf(wv[1][e], d10, fmaf(wv[7][e], d00, a10[c + e]));
+        a11[c + e] = fmaf(wv[0][e], d11, fmaf(wv[2][e], d10, fmaf(wv[6][e], d01, fmaf(wv[8][e], d00, a11[c + e]))));
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CG; ++c) {
+    red[kq][4 * c + 0][lane] = a00[c]; red[kq][4 * c + 1][lane] = a01[c];
+    red[kq][4 * c + 2][lane] = a10[c]; red[kq][4 * c + 3][lane] = a11[c];
+  }
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int c = kq * (CG / KS); c < (kq + 1) * (CG / KS); ++c) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ((red[0][4 * c + e][lane] + red[1][4 * c + e][lane]) + red[2][4 * c + e][lane]) + red[3][4 * c + e][lane];
+      float* xc = dx + ((long)n * CIN + g0 + c) * H * W + (long)(2 * a) * W + 2 * b;
+      *reinterpret_cast<u32x2*>(xc) = u32x2{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1])};
+      *reinterpret_cast<u32x2*>(xc + W) = u32x2{__builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
+    }
+  }
+}
+
 static int cv_check(const char* who, const void* a, const void* b, const void* c, int N, int Cin, int Cout, int H, int W) {
   RN_CHECK_ARG(a && b && c && N > 0 && H > 0 && W > 0, "%s: bad pointer/size", who);
   RN_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && Cout == 24 && (Cin == 3 || Cin == 24),
@@ -147,7 +288,8 @@ extern "C" int rn_conv3x3s2_fwd(const float* x, const float* w, float* y, int N,
   // big layers: 24 channels per thread (fewest input reads); small ones: 8 per thread, 3x the waves
   if (Cin == 3) conv3x3s2_fwd_kernel<3, 24, 24><<<dim3(gx, 1), CV_T, 0, (hipStream_t)stream>>>(x, w, y, N, H, W);
   else if (px >= 200000) conv3x3s2_fwd_kernel<24, 24, 24><<<dim3(gx, 1), CV_T, 0, (hipStream_t)stream>>>(x, w, y, N, H, W);
-  else conv3x3s2_fwd_kernel<24, 24, 8><<<dim3(gx, 3), CV_T, 0, (hipStream_t)stream>>>(x, w, y, N, H, W);
+  else if (px >= CV_KS_MAX) conv3x3s2_fwd_kernel<24, 24, 8><<<dim3(gx, 3), CV_T, 0, (hipStream_t)stream>>>(x, w, y, N, H, W);
+  else conv3x3s2_fwd_ks_kernel<24, 24, 8><<<dim3((int)((px + 63) / 64), 3), CV_T, 0, (hipStream_t)stream>>>(x, w, y, N, H, W);
   RN_LAUNCH_CHECK("rn_conv3x3s2_fwd");
   return 0;
 }
@@ -157,7 +299,8 @@ extern "C" int rn_conv3x3s2_bwd_data(const float* dy, const float* w, float* dx,
   RN_CHECK_ARG(Cin == 24 && (uintptr_t)dx % 8 == 0, "rn_conv3x3s2_bwd_data: built for 24 input channels");
   const long px = (long)N * (H / 2) * (W / 2);
   const int gx = (int)((px + CV_T - 1) / CV_T);
-  conv3x3s2_bwd_data_kernel<24, 24, 8><<<dim3(gx, 3), CV_T, 0, (hipStream_t)stream>>>(dy, w, dx, N, H, W);
+  if (px >= CV_KS_MAX) conv3x3s2_bwd_data_kernel<24, 24, 8><<<dim3(gx, 3), CV_T, 0, (hipStream_t)stream>>>(dy, w, dx, N, H, W);
+  else conv3x3s2_bwd_data_ks_kernel<24, 24, 8><<<dim3((int)((px + 63) / 64), 3), CV_T, 0, (hipStream_t)stream>>>(dy, w, dx, N, H, W);
   RN_LAUNCH_CHECK("rn_conv3x3s2_bwd_data");
   return 0;
 }
