@@ -176,6 +176,162 @@ __global__ __launch_bounds__(CN_T) void cn_bwd_apply_kernel(const f32x4* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------ one launch per direction
+// Layers whose channel holds <= 64 Ki elements (everything but the first conv block at the headline shape): ONE workgroup of
+// 1024 threads per channel does statistics AND apply -- the data of a channel (<= 256 KB) sit in the threads' registers
+// (NV float4 each) between the two passes, or are re-read from L2 (backward of the largest such layer).  Two launches
+// and a workspace round trip per direction and layer become one launch; the small layers are pure launch latency.
+namespace {
+constexpr int CF_T = 1024;
+template <int NV>
+__device__ __forceinline__ void cf_block_reduce(double (&v)[NV], double* red) {   // 16 waves, fixed order -> deterministic
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double x = v[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+    if (lane == 0) red[w * NV + i] = x;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < CF_T / 64; ++k) s += red[k * NV + i];
+    v[i] = s;
+  }
+  __syncthreads();
+}
+}  // namespace
+
+template <int NV, bool KEEP>
+__global__ __launch_bounds__(CF_T) void cn_fwd_fused_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, double count,
+                                                            float* __restrict__ mean, float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ conv_bias, float eps, float momentum,
+                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                            long long* __restrict__ num_batches, int C, int hw4, long n4) {
+  __shared__ double red[2 * CF_T / 64];
+  const int c = blockIdx.x, t = threadIdx.x;
+  f32x4 v[KEEP ? NV : 1];
+  float a0 = 0.f, a1 = 0.f;
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const long q = (long)i * CF_T + t;
+      v[i] = q < n4 ? x[cn_addr4(q, c, C, hw4)] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      a0 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      a1 += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+    }
+  } else {
+#pragma unroll 4
+    for (long q = t; q < n4; q += CF_T) {
+      const f32x4 u = x[cn_addr4(q, c, C, hw4)];
+      a0 += (u[0] + u[1]) + (u[2] + u[3]);
+      a1 += (u[0] * u[0] + u[1] * u[1]) + (u[2] * u[2] + u[3] * u[3]);
+    }
+  }
+  double s[2] = {(double)a0, (double)a1};
+  cf_block_reduce<2>(s, red);
+  const double md = s[0] / count;
+  double var = s[1] / count - md * md;
+  if (var < 0.0) var = 0.0;
+  const float m = (float)md, is = (float)(1.0 / sqrt(var + (double)eps));
+  if (t == 0) {
+    mean[c] = m;
+    invstd[c] = is;
+    if (running_mean) {
+      const double mb = md + (conv_bias ? (double)conv_bias[c] : 0.0);
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mb);
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+    if (c == 0 && num_batches) num_batches[0] += 1;
+  }
+  const float sc = gamma[c] * is, sh = beta[c] - m * sc;
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const long q = (long)i * CF_T + t;
+      if (q < n4) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(v[i][e] * sc + sh, 0.f);
+        y[cn_addr4(q, c, C, hw4)] = o;
+      }
+    }
+  } else {
+#pragma unroll 4
+    for (long q = t; q < n4; q += CF_T) {
+      const long a = cn_addr4(q, c, C, hw4);
+      const f32x4 u = x[a];
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(u[e] * sc + sh, 0.f);
+      y[a] = o;
+    }
+  }
+}
+
+template <int NV, bool KEEP>
+__global__ __launch_bounds__(CF_T) void cn_bwd_fused_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x,
+                                                            f32x4* __restrict__ dx, double count, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int C, int hw4, long n4) {
+  __shared__ double red[2 * CF_T / 64];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const float m = mean[c], is = invstd[c], ga = gamma[c];
+  const float sc = ga * is, sh = beta[c] - m * sc;
+  f32x4 v[KEEP ? NV : 1], g[KEEP ? NV : 1];
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll(KEEP ? NV : 2)
+  for (int i = 0; i < (KEEP ? NV : (int)((n4 + CF_T - 1) / CF_T)); ++i) {
+    const long q = (long)i * CF_T + t;
+    f32x4 vv = {0.f, 0.f, 0.f, 0.f}, gg = {0.f, 0.f, 0.f, 0.f};
+    if (q < n4) {
+      const long a = cn_addr4(q, c, C, hw4);
+      vv = x[a];
+      gg = dy[a];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float dz = (vv[e] * sc + sh > 0.f) ? gg[e] : 0.f;
+      a0 += dz;
+      a1 += dz * vv[e];
+    }
+    if constexpr (KEEP) { v[i] = vv; g[i] = gg; }
+  }
+  double s[2] = {(double)a0, (double)a1};
+  cf_block_reduce<2>(s, red);
+  const float dga = (float)((double)is * (s[1] - (double)m * s[0]));
+  if (t == 0) {
+    dgamma[c] = dga;
+    dbeta[c] = (float)s[0];
+  }
+  const float k0 = (float)(s[0] / count), k1 = (float)((double)dga * is / count);
+#pragma unroll(KEEP ? NV : 2)
+  for (int i = 0; i < (KEEP ? NV : (int)((n4 + CF_T - 1) / CF_T)); ++i) {
+    const long q = (long)i * CF_T + t;
+    if (q < n4) {
+      const long a = cn_addr4(q, c, C, hw4);
+      f32x4 vv, gg;
+      if constexpr (KEEP) { vv = v[i]; gg = g[i]; } else { vv = x[a]; gg = dy[a]; }
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dz = (vv[e] * sc + sh > 0.f) ? gg[e] : 0.f;
+        o[e] = sc * (dz - k0 - (vv[e] - m) * k1);
+      }
+      dx[a] = o;
+    }
+  }
+}
+
 static int cn_slices(long n4) {          // workgroups per channel of the reduction passes
   long s = n4 / (CN_T * 8);
   if (s < 1) s = 1;
@@ -201,6 +357,16 @@ extern "C" int rn_bn_relu_fwd(const float* x, float* y, const float* gamma, cons
   const long n4 = (long)N * HW / 4;
   const int S = cn_slices(n4), hw4 = HW / 4;
   hipStream_t s = (hipStream_t)stream;
+  if (n4 <= 16 * CF_T) {                                   // one workgroup per channel: statistics + apply in one launch
+#define RN_CF(NV_, KEEP_) cn_fwd_fused_kernel<NV_, KEEP_><<<C, CF_T, 0, s>>>((const f32x4*)x, (f32x4*)y, (double)N * HW, mean, invstd, gamma, beta, conv_bias, \
+                                                               eps, momentum, running_mean, running_var, num_batches, C, hw4, n4)
+    if (n4 <= CF_T) RN_CF(1, true);
+    else if (n4 <= 4 * CF_T) RN_CF(4, true);
+    else RN_CF(16, false);
+#undef RN_CF
+    RN_LAUNCH_CHECK("rn_bn_relu_fwd(fused)");
+    return 0;
+  }
   cn_stats_kernel<<<dim3(S, C), CN_T, 0, s>>>((const f32x4*)x, (double*)ws, C, hw4, n4, S);
   int gx = (int)((n4 + CN_T * 4 - 1) / (CN_T * 4));
   if (gx < 1) gx = 1;
@@ -232,6 +398,14 @@ extern "C" int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const 
   const long n4 = (long)N * HW / 4;
   const int S = cn_slices(n4), hw4 = HW / 4;
   hipStream_t s = (hipStream_t)stream;
+  if (n4 <= 16 * CF_T) {
+    const double cnt = (double)N * HW;
+    if (n4 <= CF_T) cn_bwd_fused_kernel<1, true><<<C, CF_T, 0, s>>>((const f32x4*)dy, (const f32x4*)x, (f32x4*)dx, cnt, mean, invstd, gamma, beta, dgamma, dbeta, C, hw4, n4);
+    else if (n4 <= 4 * CF_T) cn_bwd_fused_kernel<4, true><<<C, CF_T, 0, s>>>((const f32x4*)dy, (const f32x4*)x, (f32x4*)dx, cnt, mean, invstd, gamma, beta, dgamma, dbeta, C, hw4, n4);
+    else cn_bwd_fused_kernel<16, false><<<C, CF_T, 0, s>>>((const f32x4*)dy, (const f32x4*)x, (f32x4*)dx, cnt, mean, invstd, gamma, beta, dgamma, dbeta, C, hw4, n4);
+    RN_LAUNCH_CHECK("rn_bn_relu_bwd(fused)");
+    return 0;
+  }
   cn_bwd_sums_kernel<<<dim3(S, C), CN_T, 0, s>>>((const f32x4*)dy, (const f32x4*)x, mean, invstd, gamma, beta, (double*)ws, C, hw4, n4, S);
   int gx = (int)((n4 + CN_T * 4 - 1) / (CN_T * 4));
   if (gx < 1) gx = 1;

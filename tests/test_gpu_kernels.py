@@ -686,7 +686,7 @@ def test_argument_errors_are_loud(H):
 
 
 # ----------------------------------------------------------------------------- conv stack: fused BatchNorm2d + ReLU
-@pytest.mark.parametrize("N,hw", [(64, 128), (3, 32)])
+@pytest.mark.parametrize("N,hw", [(64, 128), (3, 32), (64, 64), (64, 32), (7, 96)])
 def test_conv_bn_relu_block(N, hw):
     """ConvInputModel with the fused batch-norm / ReLU kernels (rn_convnorm.hip) against the same module run through
     the stock torch ops (reference model.py:22-35): outputs, running statistics, every gradient.  fp32 tolerance:
