@@ -513,7 +513,7 @@ class RelationalFunction(torch.autograd.Function):
         # rounded copy).  RN_NO_ALGEBRAIC_WGRAD0=1 keeps the kernel.
         alg0 = alg0_wgrad_ok(plan, k)
         # RN_WGRAD_LATE=1 / 2 starts the (HBM-bound) wgrad stream only after the pair reduction / after dx, dq: measured
-        # slower (1.246 / 1.266 vs 1.222 ms) -- the window after the backward chain runs at the HBM roofline (~4 TB/s over
+        # slower (1.102 / 1.137 vs 1.092 ms; all wgrads serially at the very end of the backward pass: 1.165) -- the window after the backward chain runs at the HBM roofline (~4 TB/s over
         # wgrad + pair reduction, tools/step_timeline.py) wherever the wgrads are put, and later they slow the conv backward
         wgrad_late = int(os.environ.get("RN_WGRAD_LATE", "0")) if alg0 else 0
         if overlap:
