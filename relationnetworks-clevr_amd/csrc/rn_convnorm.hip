@@ -15,6 +15,8 @@
 // is read back.  The convolution bias drops out of a batch-normalised output (it shifts the batch mean by the
 // same amount) -- the conv runs without it, the running mean gets it added, and its gradient is identically zero.
 // NCHW fp32; a channel's data are N planes of HW contiguous floats (HW % 4 == 0).
+#include <stdlib.h>
+
 #include "rn_common.h"
 
 namespace {
@@ -177,10 +179,11 @@ __global__ __launch_bounds__(CN_T) void cn_bwd_apply_kernel(const f32x4* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ one launch per direction
-// Layers whose channel holds <= 64 Ki elements (everything but the first conv block at the headline shape): ONE workgroup of
-// 1024 threads per channel does statistics AND apply -- the data of a channel (<= 256 KB) sit in the threads' registers
-// (NV float4 each) between the two passes, or are re-read from L2 (backward of the largest such layer).  Two launches
-// and a workspace round trip per direction and layer become one launch; the small layers are pure launch latency.
+// Layers whose channel holds <= 16 Ki elements (the last two conv blocks at the headline shape): ONE workgroup of 1024
+// threads per channel does statistics AND apply -- the data of a channel (<= 64 KB) sit in the threads' registers (NV
+// float4 each) between the two passes.  Two launches and a workspace round trip per direction and layer become one
+// launch; these layers are pure launch latency.  (One workgroup per channel on the 64 Ki-element layer -- re-reading from
+// L2 -- measured slower than the two-launch path: 24 workgroups do not pull 12 MB fast enough.)
 namespace {
 constexpr int CF_T = 1024;
 template <int NV>
@@ -357,12 +360,11 @@ extern "C" int rn_bn_relu_fwd(const float* x, float* y, const float* gamma, cons
   const long n4 = (long)N * HW / 4;
   const int S = cn_slices(n4), hw4 = HW / 4;
   hipStream_t s = (hipStream_t)stream;
-  if (n4 <= 16 * CF_T) {                                   // one workgroup per channel: statistics + apply in one launch
+  if (n4 <= 4 * CF_T) {                                   // one workgroup per channel: statistics + apply in one launch
 #define RN_CF(NV_, KEEP_) cn_fwd_fused_kernel<NV_, KEEP_><<<C, CF_T, 0, s>>>((const f32x4*)x, (f32x4*)y, (double)N * HW, mean, invstd, gamma, beta, conv_bias, \
                                                                eps, momentum, running_mean, running_var, num_batches, C, hw4, n4)
     if (n4 <= CF_T) RN_CF(1, true);
-    else if (n4 <= 4 * CF_T) RN_CF(4, true);
-    else RN_CF(16, false);
+    else RN_CF(4, true);
 #undef RN_CF
     RN_LAUNCH_CHECK("rn_bn_relu_fwd(fused)");
     return 0;
@@ -398,11 +400,10 @@ extern "C" int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const 
   const long n4 = (long)N * HW / 4;
   const int S = cn_slices(n4), hw4 = HW / 4;
   hipStream_t s = (hipStream_t)stream;
-  if (n4 <= 16 * CF_T) {
+  if (n4 <= 4 * CF_T) {
     const double cnt = (double)N * HW;
     if (n4 <= CF_T) cn_bwd_fused_kernel<1, true><<<C, CF_T, 0, s>>>((const f32x4*)dy, (const f32x4*)x, (f32x4*)dx, cnt, mean, invstd, gamma, beta, dgamma, dbeta, C, hw4, n4);
-    else if (n4 <= 4 * CF_T) cn_bwd_fused_kernel<4, true><<<C, CF_T, 0, s>>>((const f32x4*)dy, (const f32x4*)x, (f32x4*)dx, cnt, mean, invstd, gamma, beta, dgamma, dbeta, C, hw4, n4);
-    else cn_bwd_fused_kernel<16, false><<<C, CF_T, 0, s>>>((const f32x4*)dy, (const f32x4*)x, (f32x4*)dx, cnt, mean, invstd, gamma, beta, dgamma, dbeta, C, hw4, n4);
+    else cn_bwd_fused_kernel<4, true><<<C, CF_T, 0, s>>>((const f32x4*)dy, (const f32x4*)x, (f32x4*)dx, cnt, mean, invstd, gamma, beta, dgamma, dbeta, C, hw4, n4);
     RN_LAUNCH_CHECK("rn_bn_relu_bwd(fused)");
     return 0;
   }
