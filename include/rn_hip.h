@@ -346,7 +346,11 @@ int rn_probe_tr16(const unsigned short* in4096, unsigned short* out256, void* st
  *     image of W0[:, 0:k] (natural layout), Wf[1..3] as for rn_g_chain_fwd_rr.  n % 32 == 0, M = B*n*n.  H / mask: both NULL
  *     (inference) or H_0..2 (H[3] NULL) + the four masks (training); xg_part (M/32, 256) fp32 as for rn_g_chain_fwd_rr. */
 int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* q, long ldq, const float* W0T, const float* b0,
-                   void* Xp, float* Vc, int B, int n, int k, int Q, int N, void* stream);
+                   void* Xp, int xp_dtype /* RN_BF16 | RN_F16 */, float* Vc, int B, int n, int k, int Q, int N, void* stream);
+/* ... and in the f16s arithmetic (fp16 object rows; Whi / Wlo as for rn_g_chain_fwd_rr_f16s, layer 0 = W0[:, 0:k] natural) */
+int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, const void* const* Whi, const void* const* Wlo,
+                                const float* const* bias, void* const* H, void* const* mask, float* xg_part, int M, int L, int G,
+                                void* stream);
 int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, const void* const* Wf, const float* const* bias, void* const* H,
                            void* const* mask, float* xg_part, int M, int L, int G, void* stream);
 

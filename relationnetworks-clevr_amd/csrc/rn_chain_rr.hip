@@ -536,14 +536,16 @@ __device__ __forceinline__ unsigned relu_pack_f16(float a, float b) {     // sat
   x = __builtin_elementwise_max(x, z);
   return __builtin_bit_cast(unsigned, x);
 }
-template <int NK0, bool STORE, bool ST3, bool XG>
+template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false>
 struct F16Vm {
   static constexpr int PF_PER = (NK0 + 7) / 8;
+  static constexpr int VC_STAGE = (RR_L - 1) * 8 + 4;                // ALG0: the stage that requests the next tile's bias row
   static constexpr int ops(int sidx) {
     int k = F_DPW;
     if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += 2;
     if ((sidx >> 3) == RR_L - 1)
       for (int c = 0; c < PF_PER; ++c) k += ((sidx & 7) * PF_PER + c < NK0) ? 1 : 0;
+    if (ALG0 && sidx == VC_STAGE) k += 1;
     return k;
   }
   static constexpr int tail() { return (STORE && ST3 ? 4 : 0) + (XG ? 8 : 0); }
@@ -552,16 +554,18 @@ struct F16Vm {
     int k = 0;
     for (int t = sidx - (F_LA - 2); t < sidx; ++t) k += t >= 0 ? ops(t) : (first ? 0 : ops(t + 8 * RR_L));
     if (sidx < F_LA - 2 && !first) k += tail();
-    if (first && sidx <= F_LA - 2) k += F_DPW * (F_LA - 2 - sidx) + NK0;
+    if (first && sidx <= F_LA - 2) k += F_DPW * (F_LA - 2 - sidx) + NK0 + (ALG0 ? 1 : 0);
     return k < 63 ? k : 63;
   }
 };
 }  // namespace
 
-template <int NK0, bool STORE, bool ST3, bool MASK, bool XG>
+// ALG0: as in g_chain_rr_kernel -- P = the packed fp16 object rows (K = 64), layer-0 bias row = Vc[b*n + i].
+template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __restrict__ P, int ldp, RRArgsF a,
-                                                                float* __restrict__ xg_part, int ntiles) {
-  typedef F16Vm<NK0, STORE, ST3, XG> Vm;
+                                                                float* __restrict__ xg_part, int ntiles,
+                                                                const float* __restrict__ Vc = nullptr, int n_obj = 0) {
+  typedef F16Vm<NK0, STORE, ST3, XG, ALG0> Vm;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
   k.init(lds);
@@ -582,6 +586,19 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
   };
   auto rd = [&](int slot, int ks, int p) -> Frag { return k.rd_at(RR_OFF_RING + slot * F_STAGE + p * RR_STAGE + ks * 1024); };
 
+  auto op_row = [&](long m0w_) -> long {
+    if constexpr (!ALG0) return m0w_;
+    const int nn = n_obj * n_obj, b = (int)(m0w_ / nn), r = (int)(m0w_ - (long)b * nn), i = r / n_obj;
+    return (long)b * n_obj + (r - i * n_obj);
+  };
+  auto vc_row = [&](long m0w_) -> long {
+    const int nn = n_obj * n_obj, b = (int)(m0w_ / nn), r = (int)(m0w_ - (long)b * nn);
+    return (long)b * n_obj + r / n_obj;
+  };
+  float* const vc_s = reinterpret_cast<float*>(lds + RR_OFF_VC) + w * RR_G;
+  auto vc_load = [&](long m0w_) -> f32x4 { return *reinterpret_cast<const f32x4*>(Vc + vc_row(m0w_) * RR_G + lane * 4); };
+  f32x4 vcreg = {0.f, 0.f, 0.f, 0.f};
+
   Frag actA[16], actB[16], ring[F_RDK][2];
   f32x16 acc[2];
   u32x4 co[2];
@@ -594,7 +611,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
 #pragma unroll
     for (int i = 0; i < F_DPW; ++i) dma_piece(0, s, s, i);
 #pragma unroll
-  for (int ks = 0; ks < NK0; ++ks) actA[ks] = load_row_frag((long)tile * RR_TM + RR_WR * w, ks);
+  for (int ks = 0; ks < NK0; ++ks) actA[ks] = load_row_frag(op_row((long)tile * RR_TM + RR_WR * w), ks);
+  if constexpr (ALG0) *reinterpret_cast<f32x4*>(vc_s + lane * 4) = vc_load((long)tile * RR_TM + RR_WR * w);
   if (t < RR_G) {
 #pragma unroll
     for (int l = 0; l < RR_L; ++l) bias_s[l * RR_G + t] = a.bias[l][t];
@@ -619,7 +637,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
     auto bias_read = [&](int l, int ob) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + l * RR_G + 32 * ob + 8 * j + 4 * h);
+        const float* src = (ALG0 && l == 0) ? vc_s : bias_s + l * RR_G;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(src + 32 * ob + 8 * j + 4 * h);
 #pragma unroll
         for (int r = 0; r < 4; ++r) cinit[4 * j + r] = b[r];
       }
@@ -722,15 +741,21 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
             const int j = c / CPG, ph = c % CPG;
             if (pl == RR_L - 1) {
               if (ph < 3) epi3_group(pob, j, ph, v);
-            } else if (ph < 4) {
-              epi_group(pl, pob, j, ph, dst, pk);
+            } else if (CPG >= 4) {
+              if (ph < 4) epi_group(pl, pob, j, ph, dst, pk);
+            } else {                                                  // NK = 4: two gaps per group, two phases per gap
+              epi_group(pl, pob, j, 2 * ph, dst, pk);
+              epi_group(pl, pob, j, 2 * ph + 1, dst, pk);
             }
           }
-          if (has_co && (c == 4 || c == 8)) co_store(cl, cob, (c >> 2) - 1);
+          constexpr int CO2 = 2 * NK > 8 ? 8 : 2 * NK - 1;
+          if (has_co && c == 4) co_store(cl, cob, 0);
+          if (has_co && c == CO2) co_store(cl, cob, 1);
           if (l == RR_L - 1 && (c & 1) == 0 && (c >> 1) < Vm::PF_PER) {
             const int i = ob * Vm::PF_PER + (c >> 1);
-            if (i < NK0) out[i] = load_row_frag(m0n, i);
+            if (i < NK0) out[i] = load_row_frag(op_row(m0n), i);
           }
+          if (ALG0 && sidx == Vm::VC_STAGE && c == 1) vcreg = vc_load(m0n);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -766,6 +791,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
           if (h == 0) xg_part[((long)tile * RR_NW + w) * RR_G + 32 * ob + n] = tot;
         }
       }
+      if constexpr (ALG0) *reinterpret_cast<f32x4*>(vc_s + lane * 4) = vcreg;
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1092,6 +1118,41 @@ extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* cons
 #undef RN_SEL
 #undef RN_GO
   RN_LAUNCH_CHECK("rn_g_chain_fwd_rr_f16s");
+  return 0;
+}
+
+// f16s arithmetic on the factored first layer (see g_chain_rr_kernel, ALG0): Xp16 = fp16 object rows (B*n, 64).
+extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, const void* const* Whi, const void* const* Wlo,
+                                           const float* const* bias, void* const* H, void* const* mask, float* xg_part, int M, int L,
+                                           int G, void* stream) {
+  RN_CHECK_ARG(Xp16 && Vc && Whi && Wlo && bias && M > 0 && xg_part, "rn_g_chain_fwd_rr_f16s_alg0: bad pointer/size");
+  RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_fwd_rr_f16s_alg0: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
+  RN_CHECK_ARG(n > 0 && n % RR_WR == 0 && M % ((long)n * n) == 0 && M % RR_TM == 0,
+               "rn_g_chain_fwd_rr_f16s_alg0: needs n %% %d == 0 and M a multiple of n*n and of %d (n=%d M=%d)", RR_WR, RR_TM, n, M);
+  RN_CHECK_ARG(((uintptr_t)Xp16 | (uintptr_t)Vc) % 16 == 0, "rn_g_chain_fwd_rr_f16s_alg0: tables must be 16-byte aligned");
+  RRArgsF a;
+  memset(&a, 0, sizeof(a));
+  int nh = 0, nm = 0;
+  for (int l = 0; l < RR_L; ++l) {
+    RN_CHECK_ARG(Whi[l] && Wlo[l] && bias[l], "rn_g_chain_fwd_rr_f16s_alg0: layer %d weight/bias is NULL", l);
+    RN_CHECK_ARG(((uintptr_t)Whi[l] | (uintptr_t)Wlo[l] | (uintptr_t)bias[l] | (uintptr_t)(H ? H[l] : nullptr) | (uintptr_t)(mask ? mask[l] : nullptr)) % 16 == 0,
+                 "rn_g_chain_fwd_rr_f16s_alg0: layer %d pointers must be 16-byte aligned", l);
+    a.Whi[l] = (const f16*)Whi[l];
+    a.Wlo[l] = (const f16*)Wlo[l];
+    a.bias[l] = bias[l];
+    a.out[l] = H ? (bf16*)H[l] : nullptr;
+    a.mask[l] = mask ? (u64*)mask[l] : nullptr;
+    nh += a.out[l] != nullptr;
+    nm += a.mask[l] != nullptr;
+  }
+  const bool h012 = nh == 3 && !a.out[RR_L - 1] && nm == RR_L;
+  RN_CHECK_ARG((nh == 0 && nm == 0) || h012, "rn_g_chain_fwd_rr_f16s_alg0: H / masks: none (inference) or H_0..2 + all four masks (training)");
+  const int ntiles = M / RR_TM;
+  const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
+  hipStream_t s = (hipStream_t)stream;
+  if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
+  else g_chain_rr_f16s_kernel<4, true, false, true, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
+  RN_LAUNCH_CHECK("rn_g_chain_fwd_rr_f16s_alg0");
   return 0;
 }
 

@@ -720,9 +720,10 @@ extern "C" int rn_pair_dx_dq(const float* Rj, const float* Ri, const float* Rq, 
 //   Vc[b*n + i][0:N]   = b0 + W0b x[b, i] + W0c q[b]   in fp32      (constant over the pairs (i, .) of a wave: its bias row)
 // W0T = W0 transposed, (2k + Q, N) fp32 (pack mode 2), so that thread = feature reads it coalesced.  Block = (16 objects,
 // question); replaces the (B n^2, 192) pair matrix of rn_pair_build_fwd: 138 MB written and read back at the headline shape.
+template <typename TX>   // bf16 (bf16 chain) or f16 (f16s chain) object rows
 __global__ __launch_bounds__(256) void pair_tables_kernel(const float* __restrict__ x, long sxb, long sxn, long sxk,
                                                           const float* __restrict__ q, long ldq, const float* __restrict__ W0T,
-                                                          const float* __restrict__ b0, bf16* __restrict__ Xp, float* __restrict__ Vc,
+                                                          const float* __restrict__ b0, TX* __restrict__ Xp, float* __restrict__ Vc,
                                                           int n, int k, int Q, int N) {
   __shared__ float xs[16][32];
   __shared__ float qs[1024];
@@ -736,9 +737,9 @@ __global__ __launch_bounds__(256) void pair_tables_kernel(const float* __restric
   {                                                                  // packed object rows: 16 x 64 bf16, 4 per thread
     const int r = t >> 4, c4 = (t & 15) * 4;
     if (i0 + r < n) {
-      bf16* dst = Xp + ((long)b * n + i0 + r) * 64 + c4;
+      TX* dst = Xp + ((long)b * n + i0 + r) * 64 + c4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dst[e] = (bf16)(c4 + e < 32 ? xs[r][c4 + e] : 0.f);
+      for (int e = 0; e < 4; ++e) dst[e] = (TX)(c4 + e < 32 ? xs[r][c4 + e] : 0.f);
     }
   }
   for (int f = t; f < N; f += 256) {
@@ -767,10 +768,12 @@ __global__ __launch_bounds__(256) void pair_tables_kernel(const float* __restric
 }
 
 extern "C" int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* q, long ldq, const float* W0T,
-                              const float* b0, void* Xp, float* Vc, int B, int n, int k, int Q, int N, void* stream) {
+                              const float* b0, void* Xp, int xp_dtype, float* Vc, int B, int n, int k, int Q, int N, void* stream) {
   RN_CHECK_ARG(x && q && W0T && b0 && Xp && Vc && B > 0 && n > 0, "rn_pair_tables: bad pointer/size");
   RN_CHECK_ARG(k > 0 && k <= 32 && Q > 0 && Q <= 1024 && N > 0, "rn_pair_tables: k=%d (<= 32), Q=%d (<= 1024), N=%d unsupported", k, Q, N);
-  pair_tables_kernel<<<dim3(cdiv(n, 16), B), 256, 0, (hipStream_t)stream>>>(x, sxb, sxn, sxk, q, ldq, W0T, b0, (bf16*)Xp, Vc, n, k, Q, N);
+  RN_CHECK_ARG(xp_dtype == RN_BF16 || xp_dtype == RN_F16, "rn_pair_tables: object rows are bf16 or fp16 (dtype %d)", xp_dtype);
+  if (xp_dtype == RN_F16) pair_tables_kernel<f16><<<dim3(cdiv(n, 16), B), 256, 0, (hipStream_t)stream>>>(x, sxb, sxn, sxk, q, ldq, W0T, b0, (f16*)Xp, Vc, n, k, Q, N);
+  else pair_tables_kernel<bf16><<<dim3(cdiv(n, 16), B), 256, 0, (hipStream_t)stream>>>(x, sxb, sxn, sxk, q, ldq, W0T, b0, (bf16*)Xp, Vc, n, k, Q, N);
   RN_LAUNCH_CHECK("rn_pair_tables");
   return 0;
 }

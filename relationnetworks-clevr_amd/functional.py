@@ -116,8 +116,9 @@ class PackedWeights:
             if rr and split:
                 wh = torch.empty(256 * 256, dtype=torch.float16, device=dev)
                 wl = torch.empty(256 * 256, dtype=torch.float16, device=dev)
-                frag_jobs.append((wc, kt, 1, N, kt, wh, 4 | int(l == 0)))
-                frag_jobs.append((wc, kt, 1, N, kt, wl, 8 | int(l == 0)))
+                kc = alg0_k if (l == 0 and alg0_k) else kt          # factored first layer: W0[:, 0:k] only
+                frag_jobs.append((wc, kt, 1, N, kc, wh, 4 | int(l == 0)))
+                frag_jobs.append((wc, kt, 1, N, kc, wl, 8 | int(l == 0)))
                 self.frag_hi.append(wh)
                 self.frag_lo.append(wl)
             elif rr:
@@ -230,6 +231,23 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
             raise RuntimeError('precision "f16s" needs the fused chain (bf16-class storage, all g widths 256, question '
                                'injected at layer 0, B*n*n a multiple of 128, no forward hooks); use "bf16" or "fp32" here')
         G, L, T = plan.widths[-1], plan.L, H.g_chain_tile()
+        if w0T is not None and wfrag is not None and len(wfrag) == 2 and len(wfrag[0]) == L:
+            # factored first layer in the f16s arithmetic: fp16 object rows + fp32 bias rows, no pair matrix
+            R = 32
+            Xp = torch.empty(B * n, 64, dtype=torch.float16, device=dev)
+            Vc = torch.empty(B * n, G, dtype=torch.float32, device=dev)
+            H.pair_tables(x, q, w0T, g_b[0], Xp, Vc, B, n, k, Q, G)
+            masks = Hs = None
+            if keep_inputs:
+                Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L - 1)] + [None]
+                masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
+            part = torch.empty(M // R, G, dtype=torch.float32, device=dev)
+            H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, wfrag[0], wfrag[1], g_b, Hs, masks, part, M, G)
+            xg = torch.empty(B, G, dtype=torch.float32, device=dev)
+            H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // R, G)
+            if Hs is None:
+                return [None] * L, None, xg
+            return [None] + Hs[:-1], RRMasks(masks), xg
         P16 = torch.empty(M, ld0, dtype=torch.float16, device=dev)
         H.pair_build_fwd(x, q, P16, H.RN_F16, B, n, k, Q, ld0)
         P = None
@@ -393,7 +411,7 @@ class RelationalFunction(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         rr_only = (rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0 and ((n * n) % 32 == 0 or not f16s)
                    and os.environ.get("RN_NO_RR_MASKS", "0") != "1")
-        alg_fwd = rr_only and not f16s and alg0_forward_ok(plan, code, n, k, M)
+        alg_fwd = rr_only and alg0_forward_ok(plan, code, n, k, M)
         wfwd, wbwd = packed.get(plan, g_w, code, split=f16s, bwd_images=need_grad, rr_only=rr_only, f_w=f_w,
                                 alg0_k=k if alg_fwd else 0)
         gb = [b.detach().contiguous() for b in g_b]

@@ -37,7 +37,8 @@ SIGNATURES = {
     "rn_g_chain_fwd_rr": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_f16s": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rn_g_linear_bwd_wgrad_gated": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pack_matrix_frag": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
@@ -276,8 +277,9 @@ def pair_tables(x, q, W0T, b0, Xp, Vc, B, n, k, Q, N):
     """Tables of the factored first layer: Xp (B*n, 64) bf16 object rows, Vc (B*n, N) fp32 bias rows (rn_pair_tables)."""
     _dev(x, "x")
     sx = x.stride()
+    xdt = RN_F16 if Xp.dtype == torch.float16 else RN_BF16
     _check(load().rn_pair_tables(x.data_ptr(), sx[0], sx[1], sx[2], q.data_ptr(), q.stride(0), W0T.data_ptr(), b0.data_ptr(),
-                                 Xp.data_ptr(), Vc.data_ptr(), B, n, k, Q, N, _stream()), "rn_pair_tables")
+                                 Xp.data_ptr(), xdt, Vc.data_ptr(), B, n, k, Q, N, _stream()), "rn_pair_tables")
 
 
 @_timed("g_fwd")
@@ -290,6 +292,19 @@ def g_chain_fwd_rr_alg0(Xp, Vc, n, Wfs, biases, Hs, masks, xg_part, M, G):
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
     _check(load().rn_g_chain_fwd_rr_alg0(Xp.data_ptr(), Vc.data_ptr(), n, wp, bp, hp, mp, xg_part.data_ptr(), M, L, G, _stream()),
            "rn_g_chain_fwd_rr_alg0")
+
+
+@_timed("g_fwd")
+def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlos, biases, Hs, masks, xg_part, M, G):
+    """f16s forward chain with the factored first layer (fp16 object rows, no pair matrix)."""
+    L = len(Whis)
+    hp = (C.c_void_p * L)(*[w.data_ptr() for w in Whis])
+    lp = (C.c_void_p * L)(*[w.data_ptr() for w in Wlos])
+    bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
+    op = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
+    mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
+    _check(load().rn_g_chain_fwd_rr_f16s_alg0(Xp16.data_ptr(), Vc.data_ptr(), n, hp, lp, bp, op, mp, xg_part.data_ptr(), M, L, G, _stream()),
+           "rn_g_chain_fwd_rr_f16s_alg0")
 
 
 @_timed("g_fwd")

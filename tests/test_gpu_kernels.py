@@ -358,6 +358,50 @@ def test_g_chain_fwd_rr_alg0(H, mode, B, n):
     assert rel(part.cpu().numpy(), ref.reshape(M // 32, 32, G).sum(1)) <= tol
 
 
+@pytest.mark.parametrize("mode,B,n", [("train", 19, 64), ("infer", 2, 32)])
+def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
+    """f16s arithmetic on the factored first layer: must agree with rn_g_chain_fwd_rr_f16s on the explicitly built fp16 pair
+    matrix to fp16-operand accuracy (layer 0 differs only in that the x_i / q / bias part is now exact fp32): pair sums to
+    2e-3, stored bf16 copies to 1 bf16 ulp of the largest value, masks on all but rounding-noise elements."""
+    L, G, k, Q = 4, 256, 26, 128
+    M, kt, K0 = B * n * n, 2 * 26 + 128, 192
+    x = formula.hash_uniform((B, n, k), 400, -1, 1).astype(np.float32)
+    q = formula.hash_uniform((B, Q), 401, -1, 1).astype(np.float32)
+    Ws = [formula.hash_uniform((G, kt if l == 0 else G), 410 + l, -0.15, 0.15).astype(np.float32) for l in range(L)]
+    bs = [formula.hash_uniform((G,), 420 + l, -0.3, 0.3).astype(np.float32) for l in range(L)]
+    wd = [dev(w) for w in Ws]
+    mk = lambda: [torch.empty(65536, dtype=torch.float16, device="cuda") for _ in range(L)]
+    hiA, loA, hiP, loP = mk(), mk(), mk(), mk()
+    w0T = torch.empty(kt, G, device="cuda")
+    jobs = [(wd[0], kt, 1, G, k, hiA[0], 4 | 1), (wd[0], kt, 1, G, k, loA[0], 8 | 1), (wd[0], kt, 1, G, kt, w0T, 2),
+            (wd[0], kt, 1, G, kt, hiP[0], 4 | 1), (wd[0], kt, 1, G, kt, loP[0], 8 | 1)]
+    for l in range(1, L):
+        jobs += [(wd[l], G, 1, G, G, hiA[l], 4), (wd[l], G, 1, G, G, loA[l], 8)]
+        hiP[l], loP[l] = hiA[l], loA[l]
+    H.pack_matrix_frag_many(jobs)
+    Xp = torch.empty(B * n, 64, dtype=torch.float16, device="cuda"); Vc = torch.empty(B * n, G, device="cuda")
+    H.pair_tables(dev(x), dev(q), w0T, dev(bs[0]), Xp, Vc, B, n, k, Q, G)
+    P16 = torch.zeros(M, K0, dtype=torch.float16, device="cuda")
+    H.pair_build_fwd(dev(x), dev(q), P16, H.RN_F16, B, n, k, Q, K0)
+    train = mode == "train"
+    def outs():
+        Hs = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3)] + [None] if train else None
+        masks = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda")) if train else None
+        return Hs, masks, torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
+    HsA, mA, pA = outs(); HsP, mP, pP = outs()
+    bd = [dev(b) for b in bs]
+    H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, HsA, mA, pA, M, G)
+    H.g_chain_fwd_rr_f16s(P16, K0, hiP, loP, bd, HsP, mP, K0, pP, M, G)
+    torch.cuda.synchronize()
+    assert rel(pA.cpu().numpy(), pP.cpu().numpy()) <= 2e-3
+    if train:
+        for l in range(3):
+            a, b = HsA[l].float().cpu().numpy(), HsP[l].float().cpu().numpy()
+            assert np.abs(a - b).max() <= 2 * BF16_ULP * np.abs(b).max(), l
+        for l in range(L):
+            assert (mA[l] != mP[l]).float().mean().item() <= 2e-3, l
+
+
 @pytest.mark.parametrize("mode,M", [("train", 256 * 290), ("infer", 256 * 5)])
 def test_g_chain_fwd_rr_f16s(H, mode, M):
     """f16s on the register-resident chain: against a float64 emulation that rounds the operand to fp16 after every
