@@ -77,10 +77,10 @@ def cpu_baseline(cfg, B, hw, steps=3):
 def parity_mode_rate(pkg, dp, hyp, A, dev, img, qst, lab, B, steps=8):
     """The same train step in the two precisions whose log-probs meet the 1e-3 bar against the reference
     (tests/test_gpu_parity.py): "f16s" (fp16 tile x split fp16 weights forward, bf16 backward; measured
-    1e-5..2.3e-4) and "fp32" (fp32 MFMA everywhere; <= 5e-7).  The headline bf16 mode is at 4e-4..1e-2."""
+    2e-6..7.4e-5) and "fp32" (fp32 MFMA everywhere; <= 5e-7).  The headline bf16 mode is at 4e-4..1e-2."""
     import io, contextlib
     res = {}
-    for prec, err in (("f16s", "1e-5..2.3e-4"), ("fp32", "<=5e-7")):
+    for prec, err in (("f16s", "2e-6..7.4e-5"), ("fp32", "<=5e-7")):
         torch.manual_seed(42)
         with contextlib.redirect_stdout(io.StringIO()):
             model = pkg.RN(A, dict(hyp, precision=prec))
