@@ -237,3 +237,57 @@ def test_changing_batch_size_and_eval_train(pkg):
         assert abs(float(out.exp().sum(1).mean()) - 1.0) < 1e-4
     out.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+# ----------------------------------------------------------------------------- full BASELINE size: size-independent properties
+def _full_rl(pkg, precision, seed=11):
+    hyps = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "relationnetworks-clevr_amd", "config.json")))["hyperparams"]
+    hyp = dict(hyps["original-fp"], precision=precision)
+    torch.manual_seed(seed)
+    rl = pkg.RelationalLayer(hyp["rl_in_size"], formula.ADICT, hyp["lstm_hidden"], hyp).cuda().eval()
+    return rl, hyp
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16s", "fp32"])
+def test_full_size_properties(pkg, precision):
+    """BASELINE.json configs[1] (original-fp, B=64, n=64: M = 262144 pair rows) is too large for the oracle; what the
+    relation layer must satisfy at ANY size is checked there instead:
+      * permutation invariance -- the answer is a sum over all object pairs (model.py:151-152): permuting a question's
+        objects changes only the fp32 summation order;
+      * batch independence -- question b's output and input gradients do not depend on the other questions (no
+        cross-question arithmetic anywhere on the path): a 4-question slice reproduces its rows of the 64-question run;
+      * the three arithmetic modes agree with each other to their documented accuracy."""
+    B, n, k, Q = 64, 64, 26, 128
+    rl, hyp = _full_rl(pkg, precision)
+    x = torch.from_numpy(formula.hash_uniform((B, n, k), 900, -1, 1).astype(np.float32)).cuda()
+    q = torch.from_numpy(formula.hash_uniform((B, Q), 901, -1, 1).astype(np.float32)).cuda()
+    lab = torch.from_numpy(formula.hash_uniform((B,), 902, 0, formula.ADICT).astype(np.int64).clip(0, formula.ADICT - 1)).cuda()
+
+    def run(xx, qq, ll):
+        xx = xx.clone().requires_grad_(True); qq = qq.clone().requires_grad_(True)
+        lp = rl(xx, qq)
+        torch.nn.functional.nll_loss(lp, ll, reduction="sum").backward()
+        return lp.detach(), xx.grad.detach(), qq.grad.detach()
+
+    lp, dx, dq = run(x, q, lab)
+    assert torch.isfinite(lp).all() and torch.isfinite(dx).all() and torch.isfinite(dq).all()
+    assert torch.allclose(lp.exp().sum(1), torch.ones(B, device="cuda"), atol=1e-5)          # log-probabilities
+    # permutation of the objects of every question
+    perm = torch.from_numpy(np.random.RandomState(3).permutation(n)).cuda()
+    lp_p, dx_p, dq_p = run(x[:, perm].contiguous(), q, lab)
+    tol = 2e-6 if precision == "fp32" else 2e-5
+    assert gold.rel_err(lp_p.cpu().numpy(), lp.cpu().numpy()) <= tol
+    assert l2rel(dx_p.cpu().numpy(), dx[:, perm].cpu().numpy()) <= (1e-5 if precision == "fp32" else 2e-2)
+    assert l2rel(dq_p.cpu().numpy(), dq.cpu().numpy()) <= (1e-5 if precision == "fp32" else 2e-2)
+    # a slice of the batch on its own
+    sl = slice(20, 24)
+    lp_s, dx_s, dq_s = run(x[sl].contiguous(), q[sl].contiguous(), lab[sl])
+    assert gold.rel_err(lp_s.cpu().numpy(), lp[sl].cpu().numpy()) <= tol
+    assert l2rel(dx_s.cpu().numpy(), dx[sl].cpu().numpy()) <= (1e-5 if precision == "fp32" else 2e-2)
+    assert l2rel(dq_s.cpu().numpy(), dq[sl].cpu().numpy()) <= (1e-5 if precision == "fp32" else 2e-2)
+    # against the exact fp32 mode of the same weights
+    if precision != "fp32":
+        ref, _ = _full_rl(pkg, "fp32")
+        ref.load_state_dict(rl.state_dict())
+        lp_r = ref(x, q).detach()
+        assert gold.rel_err(lp.cpu().numpy(), lp_r.cpu().numpy()) <= (1e-3 if precision == "f16s" else 3e-2)
