@@ -334,9 +334,6 @@ int rn_bn_relu_apply(const float* x, float* y, const float* gamma, const float* 
 int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const float* gamma, const float* beta, const float* mean,
                    const float* invstd, float* dgamma, float* dbeta, void* ws, int N, int C, int HW, void* stream);
 
-/* Diagnostics used by the GPU tests: raw lane mapping of ds_read_b64_tr_b16. */
-int rn_probe_tr16(const unsigned short* in4096, unsigned short* out256, void* stream);
-
 /* The first g layer factored through the pair structure (question injected at layer 0; model.py:130-139 builds the pair
  * matrix [x_j | x_i | q] and multiplies it by W0): W0 [x_j | x_i | q] + b0 = W0a x_j + (W0b x_i + W0c q + b0).
  *   rn_pair_tables: Xp (B*n, 64) bf16 = x[b, j, 0:k] zero padded;  Vc (B*n, N) fp32 = b0 + W0b x[b, i] + W0c q[b]
@@ -353,10 +350,6 @@ int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, const 
                                 void* stream);
 int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, const void* const* Wf, const float* const* bias, void* const* H,
                            void* const* mask, float* xg_part, int M, int L, int G, void* stream);
-
-/* Diagnostics: a one-thread kernel that stores the constant-rate wall clock (wall_clock64) into *slot, in stream order.
- * Captured between the kernels of the step's hipGraph it yields a concurrent multi-stream timeline (tools/step_timeline.py). */
-int rn_debug_stamp(unsigned long long* slot, void* stream);
 
 #ifdef __cplusplus
 }

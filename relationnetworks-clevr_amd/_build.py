@@ -1,39 +1,62 @@
 """Build the C-ABI HIP library (librn_hip.so) in-tree with hipcc for gfx950.
 
-No JIT cache, no torch cpp_extension: one explicit hipcc invocation so the .so
-sits next to the sources and travels with the tree to the GPU box."""
+No JIT cache, no torch cpp_extension: explicit hipcc invocations so the .so sits next to the
+sources and travels with the tree to the GPU box.  Each source is compiled to its own object under
+build/ (git-ignored; only stale objects are rebuilt, in parallel), then linked."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "librn_hip.so")
 SOURCES = ["rn_pair.hip", "rn_gemm.hip", "rn_chain.hip", "rn_chain_rr.hip", "rn_wgrad.hip", "rn_small.hip", "rn_convnorm.hip", "rn_lstm.hip", "rn_conv.hip"]
-HEADERS = [os.path.join(CSRC, "rn_common.h"), os.path.join(HERE, "..", "include", "rn_hip.h")]
+HEADERS = [os.path.join(CSRC, "rn_common.h"), os.path.join(HERE, "..", "include", "rn_hip.h"), os.path.join(HERE, "..", "include", "rn_hip_debug.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
+def _stale(target, deps):
+    t = _mtime(target)
+    return t == 0.0 or any(_mtime(d) > t for d in deps)
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+
+
+def _hipcc():
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    return hipcc if os.path.exists(hipcc) else "hipcc"
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if not os.path.exists(hipcc):
-        hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB + ".tmp"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o"))
+        if force or _stale(obj, [src] + HEADERS):
+            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(len(jobs), 1))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc] + FLAGS + ["-shared", "-o", LIB + ".tmp"] + [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES])
     os.replace(LIB + ".tmp", LIB)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -38,6 +38,18 @@ void rn_set_error(const char* fmt, ...);
     }                                                                            \
   } while (0)
 
+// gfx950: 160 KiB of LDS per workgroup; dynamic allocations above 64 KiB must be opted into per kernel
+#define RN_LDS_MAX (160 * 1024)
+#define RN_LDS_OPT_IN(kernel, name)                                                                              \
+  do {                                                                                                           \
+    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel),                                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, RN_LDS_MAX);                 \
+    if (e_ != hipSuccess) {                                                                                      \
+      rn_set_error("%s: cannot raise the dynamic LDS limit: %s", name, hipGetErrorString(e_));                   \
+      return (int)e_;                                                                                            \
+    }                                                                                                            \
+  } while (0)
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- element traits ----------------------------------------------------------

@@ -89,12 +89,18 @@ extern "C" int rn_pair_build_fwd(const float* x, long sxb, long sxn, long sxk, c
   hipStream_t s = (hipStream_t)stream;
   if (dtype == RN_BF16 || dtype == RN_F16) {
     size_t lds = ((size_t)n * ((k + 7) / 8 * 8) + ld) * sizeof(bf16);
-    RN_CHECK_ARG(lds <= 64 * 1024, "rn_pair_build_fwd: n*k too large for LDS staging");
-    if (dtype == RN_BF16) pair_build_kernel<bf16><<<grid, 256, lds, s>>>(x, sxb, sxn, sxk, q, sqb, (bf16*)P, n, k, Q, ld, IB);
-    else pair_build_kernel<f16><<<grid, 256, lds, s>>>(x, sxb, sxn, sxk, q, sqb, (f16*)P, n, k, Q, ld, IB);
+    RN_CHECK_ARG(lds <= RN_LDS_MAX, "rn_pair_build_fwd: n*k too large for LDS staging (%zu B > %d B)", lds, RN_LDS_MAX);
+    if (dtype == RN_BF16) {
+      if (lds > 64 * 1024) RN_LDS_OPT_IN(pair_build_kernel<bf16>, "rn_pair_build_fwd");
+      pair_build_kernel<bf16><<<grid, 256, lds, s>>>(x, sxb, sxn, sxk, q, sqb, (bf16*)P, n, k, Q, ld, IB);
+    } else {
+      if (lds > 64 * 1024) RN_LDS_OPT_IN(pair_build_kernel<f16>, "rn_pair_build_fwd");
+      pair_build_kernel<f16><<<grid, 256, lds, s>>>(x, sxb, sxn, sxk, q, sqb, (f16*)P, n, k, Q, ld, IB);
+    }
   } else {
     size_t lds = ((size_t)n * ((k + 3) / 4 * 4) + ld) * sizeof(float);
-    RN_CHECK_ARG(lds <= 64 * 1024, "rn_pair_build_fwd: n*k too large for LDS staging");
+    RN_CHECK_ARG(lds <= RN_LDS_MAX, "rn_pair_build_fwd: n*k too large for LDS staging (%zu B > %d B)", lds, RN_LDS_MAX);
+    if (lds > 64 * 1024) RN_LDS_OPT_IN(pair_build_kernel<float>, "rn_pair_build_fwd");
     pair_build_kernel<float><<<grid, 256, lds, s>>>(x, sxb, sxn, sxk, q, sqb, (float*)P, n, k, Q, ld, IB);
   }
   RN_LAUNCH_CHECK("rn_pair_build_fwd");

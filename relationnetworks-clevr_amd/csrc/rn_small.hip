@@ -4,6 +4,7 @@
 // (v_mfma_f32_32x32x2_f32 = a k-ordered fp32 fmaf chain) so f_phi stays bit-comparable with an
 // fp32 reference, one wave per 32x32 output tile, operands straight from global (L2-resident).
 #include "rn_common.h"
+#include "../../include/rn_hip_debug.h"
 
 // One workgroup (4 waves) per 32x32 output tile; the 4 waves split K (each runs a k-ordered fp32
 // fmaf chain over its quarter), partial tiles are combined through LDS in a fixed order.
@@ -155,6 +156,11 @@ constexpr int FP_RB = 4;          // rows per workgroup
 constexpr int FP_MAXW = 1024;     // widest activation the LDS staging holds
 constexpr int FP_KS = 4;          // k-slices per output feature with transposed weights (block = FP_KS * 256 threads)
 static_assert(FP_KS == FP_RB, "the slice-k thread finalises row k");
+// Labels outside [0, A) are CLAMPED to the nearest class, in every kernel that reads a label (these fused ones, the
+// stand-alone nll kernels, the LSTM's token lookup): a device kernel cannot raise like F.nll_loss / nn.Embedding do
+// without a host synchronisation per step.  The host wrappers document it; train.py's load_tensor_data produces
+// 0-based labels in range by construction (utils.py:149).  There is no ignore_index.
+__device__ __forceinline__ int fp_label(long long l, int A) { return l < 0 ? 0 : (l >= A ? A - 1 : (int)l); }
 
 // acc[r] += sum_k W[f][k] * in[r][k]; thread = output feature, W (out, in) row-major; the rows' inputs sit in LDS
 __device__ __forceinline__ void fp_rows(const float* __restrict__ W, const float* in_s, int K, int f, float (&acc)[FP_RB]) {
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(TR ? FP_KS * 256 : 256) void f_phi_fwd_kernel(
     for (int a = 0; a < A; ++a) s += expf(z[a] - mx);
     const float ls = mx + logf(s);
     for (int a = 0; a < A; ++a) out[(long)(r0 + t) * A + a] = z[a] - ls;
-    if (label) lrow[t] = -(z[label[r0 + t]] - ls);
+    if (label) lrow[t] = -(z[fp_label(label[r0 + t], A)] - ls);
   } else if (t < FP_RB) {
     lrow[t] = 0.f;
   }
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(FP_KS * 256) void f_phi_bwd_dz_kernel(const float* 
     const int b = r0 + t;
     // label mode: gout = d(mean NLL)/d out = -gloss / B at the label, 0 elsewhere -- never materialised
     const float gl = label ? -gloss[0] / (float)B : 0.f;
-    const int lb = (label && b < B) ? (int)label[b] : -1;
+    const int lb = (label && b < B) ? fp_label(label[b], A) : -1;
     float s = label ? gl : 0.f;
     if (b < B && !label)
       for (int a = 0; a < A; ++a) s += gout[(long)b * A + a];
@@ -359,7 +365,8 @@ __global__ __launch_bounds__(256) void f_phi_bwd_grads_kernel(const float* __res
                                                               float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
                                                               float* __restrict__ db2, float* __restrict__ dW3, float* __restrict__ db3,
                                                               int B, int G, int F1, int F2, int A) {
-  __shared__ float dzs[1024];
+  constexpr int BT = 1024;                 // batch rows staged per pass (any B: the passes accumulate in registers)
+  __shared__ float dzs[BT];
   int i = blockIdx.x;
   const float *dz, *act;
   float *dW, *db;
@@ -367,23 +374,38 @@ __global__ __launch_bounds__(256) void f_phi_bwd_grads_kernel(const float* __res
   if (i < F1) { dz = dz1; act = xg; dW = dW1; db = db1; I = F1; J = G; }
   else if (i < F1 + F2) { i -= F1; dz = dz2; act = f1; dW = dW2; db = db2; I = F2; J = F1; }
   else { i -= F1 + F2; dz = dz3; act = f2; dW = dW3; db = db3; I = A; J = F2; }
-  for (int b = threadIdx.x; b < B; b += 256) dzs[b] = dz[(long)b * I + i];
-  __syncthreads();
-  for (int j = threadIdx.x; j < J; j += 256) {
-    float s = 0.f;
+  constexpr int JT = FP_MAXW / 256;        // columns per thread (J <= FP_MAXW)
+  float acc[JT], sb = 0.f;
+#pragma unroll
+  for (int u = 0; u < JT; ++u) acc[u] = 0.f;
+  for (int b0 = 0; b0 < B; b0 += BT) {
+    const int nb = B - b0 < BT ? B - b0 : BT;
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += 256) dzs[b] = dz[(long)(b0 + b) * I + i];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < JT; ++u) {
+      const int j = threadIdx.x + 256 * u;
+      if (j < J) {
+        float s = acc[u];
 #pragma unroll 16
-    for (int b = 0; b < B; ++b) s = fmaf(dzs[b], act[(long)b * J + j], s);
-    dW[(long)i * J + j] = s;
+        for (int b = 0; b < nb; ++b) s = fmaf(dzs[b], act[(long)(b0 + b) * J + j], s);
+        acc[u] = s;
+      }
+    }
+    if (threadIdx.x == 0)
+      for (int b = 0; b < nb; ++b) sb += dzs[b];
   }
-  if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dzs[b];
-    db[i] = s;
+#pragma unroll
+  for (int u = 0; u < JT; ++u) {
+    const int j = threadIdx.x + 256 * u;
+    if (j < J) dW[(long)i * J + j] = acc[u];
   }
+  if (threadIdx.x == 0) db[i] = sb;
 }
 
 static int fp_check(const char* who, int B, int G, int F1, int F2, int A) {
-  RN_CHECK_ARG(B > 0 && B <= 1024 && G > 0 && F1 > 0 && F2 > 0 && A > 0, "%s: bad sizes", who);
+  RN_CHECK_ARG(B > 0 && G > 0 && F1 > 0 && F2 > 0 && A > 0, "%s: bad sizes", who);
   RN_CHECK_ARG(G <= FP_MAXW && F1 <= FP_MAXW && F2 <= FP_MAXW && A <= FP_MAXW && G % 4 == 0 && F1 % 4 == 0 && F2 % 4 == 0,
                "%s: widths must be multiples of 4 and <= %d (G=%d F1=%d F2=%d A=%d)", who, FP_MAXW, G, F1, F2, A);
   return 0;

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include "rn_common.h"
+#include "../../include/rn_hip_debug.h"
 
 template <typename T> struct WG;
 template <> struct WG<bf16> { static constexpr int ROWS = 64; };

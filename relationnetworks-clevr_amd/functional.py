@@ -409,8 +409,10 @@ class RelationalFunction(torch.autograd.Function):
         dev = x.device
         f16s = precision == "f16s"
         need_grad = any(ctx.needs_input_grad)
-        rr_only = (rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0 and ((n * n) % 32 == 0 or not f16s)
-                   and os.environ.get("RN_NO_RR_MASKS", "0") != "1")
+        # exactly g_chain_forward's condition for the register-resident branches (they consume only the fragment-major
+        # images): f16s needs whole waves per question, bf16 needs them only when nothing is kept for a backward pass
+        rr_only = (rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0 and os.environ.get("RN_NO_RR_MASKS", "0") != "1"
+                   and ((n * n) % 32 == 0 or (need_grad and not f16s)))
         alg_fwd = rr_only and alg0_forward_ok(plan, code, n, k, M)
         wfwd, wbwd = packed.get(plan, g_w, code, split=f16s, bwd_images=need_grad, rr_only=rr_only, f_w=f_w,
                                 alg0_k=k if alg_fwd else 0)
@@ -524,7 +526,7 @@ class RelationalFunction(torch.autograd.Function):
         # re-joins at the end of the backward pass (engine callback).  Only when every parameter's .grad is
         # None (assign, not accumulate: autograd then launches no kernel on these tensors before the join).
         overlap = (fused_bwd and os.environ.get("RN_NO_WGRAD_OVERLAP", "0") != "1"
-                   and all(p.grad is None for p in ctx.param_refs))
+                   and all(_assign_only(p) for p in ctx.param_refs))
         # Layer 0 reads the pair matrix P = [x_j | x_i | q]: its weight gradient dZ_0^T P factors through the pair
         # reductions the input gradient needs anyway -- dW_0 = [Rj^T X | Ri^T X | Rq^T Q], db_0 = sum_b Rq -- three tiny
         # products on (B*n)-row matrices instead of a 235 MB pass over dZ_0 and P (and with fp32 x instead of P's
@@ -637,6 +639,18 @@ def _direct_conv_ok(inp, conv_w, stride, padding):
             and inp.shape[2] % 2 == 0 and inp.shape[3] % 2 == 0)
 
 
+def _assign_only(p):
+    """True when autograd will only ASSIGN the gradient it is handed for leaf `p` -- no accumulation kernel, no hook --
+    so that a gradient still being written on a side stream is not touched before the end-of-backward join.  With an
+    existing .grad (FlatGradBucket's accumulate mode, zero_grad(set_to_none=False), micro-batch accumulation) or any
+    hook, AccumulateGrad runs `grad += dw` / the hook on the main stream: the producer must then run there too."""
+    if p is None or p.grad is not None:
+        return False
+    if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+        return False
+    return True
+
+
 class ConvBNReLUFunction(torch.autograd.Function):
     """relu(batch_norm(conv2d(x))) of the reference's ConvInputModel block (model.py:22-35): the convolution is
     MIOpen's (aten.convolution, run WITHOUT its bias), batch norm + ReLU and their backward are the fused
@@ -673,6 +687,7 @@ class ConvBNReLUFunction(torch.autograd.Function):
             ctx.save_for_backward(inp, conv_w, x, g, bt, mean, invstd)
             ctx.conv_args = (stride, padding)
             ctx.has_bias = conv_b is not None
+            ctx.w_ref = conv_w                   # the leaf itself: backward looks at .grad / hooks (see _assign_only)
         return y
 
     @staticmethod
@@ -686,7 +701,7 @@ class ConvBNReLUFunction(torch.autograd.Function):
         dgamma = torch.empty_like(g); dbeta = torch.empty_like(bt)
         H.bn_relu_bwd(dy, x, dx, g, bt, mean, invstd, dgamma, dbeta)
         conv_bwd = lambda mask: torch.ops.aten.convolution_backward(dx, inp, conv_w, None, stride, padding, (1, 1), False, (0, 0), 1, mask)
-        if ctx.needs_input_grad[0] and os.environ.get("RN_NO_WGRAD_OVERLAP", "0") != "1":
+        if ctx.needs_input_grad[0] and os.environ.get("RN_NO_WGRAD_OVERLAP", "0") != "1" and _assign_only(ctx.w_ref):
             # only the input gradient is on the dependency chain of the backward pass: the weight gradient (MIOpen's
             # wrw kernel plus its layout transposes, ~half of the conv backward) goes to the side stream and overlaps the
             # next layers' backward; the main stream re-joins at the end of the backward pass
@@ -701,6 +716,7 @@ class ConvBNReLUFunction(torch.autograd.Function):
             keep = [dx, inp]
             for t in keep:
                 t.record_stream(side)
+            dw.record_stream(main)               # allocated on the side stream, handed to autograd on the main one
 
             def _join():
                 torch.cuda.current_stream().wait_stream(side)

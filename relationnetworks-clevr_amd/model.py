@@ -12,8 +12,9 @@ The conv stack and the LSTM are ordinary torch.nn modules (MIOpen on ROCm); they
 are ~1 % of the step's flops and outside the hot path.
 
 Deliberate deviations from reference quirks:
-  C1  the coordinate tensor is cached per (batch, grid, device) instead of "first batch
-      size forever" -- a different later batch size works instead of raising.
+  C1  the coordinate tensor is cached per (batch, grid, device), every entry kept for the life of
+      the module, instead of "first batch size forever" -- a different later batch size works
+      instead of raising, and a captured hipGraph's entry is never freed under it.
   C2  .cuda() returns self (the reference returns None; callers ignore the value).
 """
 from __future__ import annotations
@@ -252,7 +253,7 @@ class RN(nn.Module):
     def __init__(self, args, hyp, extraction=False):
         super().__init__()
         self.coord_tensor = None
-        self._coord_key = None
+        self._coord_cache = {}                 # (b, d, device) -> (b, 2, d*d); entries are never evicted (see _coords)
         self._side_stream = None
         self.overlap_streams = os.environ.get("RN_OVERLAP_STREAMS", "1") != "0"
         self.on_gpu = False
@@ -276,6 +277,17 @@ class RN(nn.Module):
         elif self.on_gpu:
             ct = ct.cuda()
         self.coord_tensor = ct
+        return ct
+
+    def _coords(self, b, d, device):
+        """The (b, 2, d*d) coordinate channels, one tensor per (batch, grid, device) for the life of the module: a
+        captured hipGraph bakes the pointer in, so an entry must never be freed while the module lives (an eval batch of
+        another size between two replays allocates ITS OWN entry instead of replacing the training one)."""
+        key = (b, d, device)
+        ct = self._coord_cache.get(key)
+        if ct is None:
+            ct = self._coord_cache[key] = self.build_coord_tensor(b, d, device).view(b, 2, d * d)
+        self.coord_tensor = ct                 # the reference's attribute: the tensor of the latest forward
         return ct
 
     def _text_on_side_stream(self, qst_idxs):
@@ -306,12 +318,7 @@ class RN(nn.Module):
         else:
             x = self.conv(img)                                  # (B, 24, d, d)
             b, k, d, _ = x.size()
-            key = (b, d, x.device)
-            if self.coord_tensor is None or self._coord_key != key:
-                self.build_coord_tensor(b, d, x.device)
-                self.coord_tensor = self.coord_tensor.view(b, 2, d * d)
-                self._coord_key = key
-            x = torch.cat([x.view(b, k, d * d), self.coord_tensor], 1).permute(0, 2, 1)   # (B, d*d, 26) strided view
+            x = torch.cat([x.view(b, k, d * d), self._coords(b, d, x.device)], 1).permute(0, 2, 1)   # (B, d*d, 26) strided view
         if side is None:
             qst = self.text(qst_idxs)
         else:
@@ -332,12 +339,7 @@ class RN(nn.Module):
         else:
             x = self.conv(img)
             b, k, d, _ = x.size()
-            key = (b, d, x.device)
-            if self.coord_tensor is None or self._coord_key != key:
-                self.build_coord_tensor(b, d, x.device)
-                self.coord_tensor = self.coord_tensor.view(b, 2, d * d)
-                self._coord_key = key
-            x = torch.cat([x.view(b, k, d * d), self.coord_tensor], 1).permute(0, 2, 1)
+            x = torch.cat([x.view(b, k, d * d), self._coords(b, d, x.device)], 1).permute(0, 2, 1)
         return self.rl.extract_features(x, self.text(qst_idxs), layer_idx)
 
     def cuda(self, device=None):

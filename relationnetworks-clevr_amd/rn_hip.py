@@ -53,7 +53,6 @@ SIGNATURES = {
     "rn_pair_reduce_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_reduce_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_dx_dq": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "rn_debug_stamp": (_I, [_P, _P]),
     "rn_wgrad0_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_wgrad0_from_reductions": (_I, [_P, _P, _P, _P, _L, _L, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_gemm_f32": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _P, _L, _P, _L, _I, _P]),
@@ -84,6 +83,10 @@ SIGNATURES = {
     "rn_bn_relu_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _I, _I, _P]),
     "rn_bn_relu_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rn_bn_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+}
+# diagnostics (include/rn_hip_debug.h): tests / tools only, not part of the product ABI
+DEBUG_SIGNATURES = {
+    "rn_debug_stamp": (_I, [_P, _P]),
     "rn_probe_tr16": (_I, [_P, _P, _P]),
 }
 
@@ -99,7 +102,7 @@ def load(path: str | None = None):
             "HIP extension %s not found: build it with `python __graft_entry__.py build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % p)
     lib = C.CDLL(p)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.restype, fn.argtypes = res, args
     v = lib.rn_abi_version()

@@ -152,25 +152,143 @@ def train_epoch(loader, trainer, epoch, device, log_interval=10, invert_question
             running, n_run = None, 0
 
 
+# CLEVR's answer vocabulary by question family (dataset facts; the reference keeps the same table in utils.py:9-16)
+ANSWER_CLASSES = {
+    "number": [str(i) for i in range(11)],
+    "material": ["rubber", "metal"],
+    "color": ["cyan", "blue", "yellow", "purple", "red", "green", "gray", "brown"],
+    "shape": ["sphere", "cube", "cylinder"],
+    "size": ["large", "small"],
+    "exist": ["yes", "no"],
+}
+
+
+def default_dictionaries(adict_size=28, qdict_size=82):
+    """A (quest_to_ix, answ_to_ix, answ_ix_to_class) triple shaped like utils.build_dictionaries' result (utils.py:18-59)
+    for runs without the dataset: 1-based indices, the 28 CLEVR answers in ANSWER_CLASSES order (any further index gets
+    the class 'other')."""
+    answers = [(a, c) for c, vals in ANSWER_CLASSES.items() for a in vals]
+    answ_to_ix, ix_to_class = {}, {}
+    for i in range(adict_size):
+        a, c = answers[i] if i < len(answers) else ("answer%d" % i, "other")
+        answ_to_ix[a] = i + 1
+        ix_to_class[i + 1] = c
+    quest_to_ix = {"w%d" % i: i for i in range(1, qdict_size + 1)}
+    return quest_to_ix, answ_to_ix, ix_to_class
+
+
+class EvalBookkeeper:
+    """The bookkeeping of the reference's test() (train.py:69-158) with the per-sample Python loops replaced by device
+    tensors: per batch ONE bincount into an (A, A) [label, prediction] confusion matrix plus the
+    prediction / label vectors kept on the device; everything the reference reports is derived at the end --
+      class_corrects / class_invalids / class_total_samples per answer class (train.py:71-80, 107-115; an "invalid" is
+      a prediction whose class differs from the label's class), the global counters (train.py:121-125), the two
+      per-sample confusion lists in sample order (train.py:116-118) and the label strings (train.py:92-94).
+    Deviation, on purpose: the reference orders the confusion axes by Python's per-process-randomised hash() of the class
+    name (train.py:86), here classes are ordered by name -- 'number' answers numerically, as there -- so the order is
+    reproducible; and 'global_accuracy' is the global accuracy (the reference's variable has been overwritten by the last
+    class's accuracy when it is dumped, train.py:139-157)."""
+
+    def __init__(self, dictionaries, adict_size, device):
+        _, answ_to_ix, ix_to_class = dictionaries
+        self.A, self.device = adict_size, device
+        inv = {v: k for k, v in answ_to_ix.items()}                                 # 1-based index -> answer string
+        self.class_of = [ix_to_class.get(a + 1, "other") for a in range(adict_size)]   # 0-based answer -> class name
+        self.class_names = list(dict.fromkeys(ix_to_class[k] for k in ix_to_class))  # insertion order, like the reference's dicts
+        if "other" in self.class_of and "other" not in self.class_names:
+            self.class_names.append("other")
+
+        def order(a):                       # position of 0-based answer a on the confusion axes
+            c = self.class_of[a]
+            return (c, int(inv[a + 1]) if c == "number" else a)
+        self.sorted_classes = sorted(range(adict_size), key=order)                    # axis position -> 0-based answer
+        self.sorted_labels = [inv.get(a + 1, str(a)) for a in self.sorted_classes]
+        pos = [0] * adict_size
+        for p_, a in enumerate(self.sorted_classes):
+            pos[a] = p_
+        self.axis_pos = torch.tensor(pos, dtype=torch.long, device=device)            # 0-based answer -> axis position
+        self.conf = torch.zeros(adict_size, adict_size, dtype=torch.long, device=device)   # [label, prediction]
+        self.loss_sum = torch.zeros((), dtype=torch.float32, device=device)
+        self.preds, self.labels = [], []
+        self.n_batches = 0
+
+    @torch.no_grad()
+    def update(self, log_probs, label):
+        """One batch: no host synchronisation."""
+        pred = log_probs.argmax(1)
+        self.conf += torch.bincount(label * self.A + pred, minlength=self.A * self.A).view(self.A, self.A)
+        self.loss_sum += torch.nn.functional.nll_loss(log_probs, label)               # mean per batch (train.py:104, 127)
+        self.preds.append(pred)
+        self.labels.append(label)
+        self.n_batches += 1
+
+    def finalize(self):
+        """-> dict: the seven test.pickle keys (train.py:149-157) + 'corrects', 'invalids', 'n_samples', 'avg_loss',
+        'confusion' (the (A, A) matrix).  One device -> host transfer."""
+        conf = self.conf.cpu()
+        n = int(conf.sum())
+        same_class = torch.tensor([[self.class_of[l] == self.class_of[p] for p in range(self.A)] for l in range(self.A)])
+        corrects_per_label = conf.diag()
+        invalid_per_label = (conf * (~same_class)).sum(1)
+        total_per_label = conf.sum(1)
+        cc, ci, cn = {}, {}, {}
+        for c in self.class_names:
+            rows = torch.tensor([self.class_of[a] == c for a in range(self.A)])
+            cc[c] = int(corrects_per_label[rows].sum())
+            ci[c] = int(invalid_per_label[rows].sum())
+            cn[c] = int(total_per_label[rows].sum())
+        corrects, invalids = int(corrects_per_label.sum()), int(invalid_per_label.sum())
+        if self.preds:
+            pred = self.axis_pos[torch.cat(self.preds)].cpu().tolist()
+            targ = self.axis_pos[torch.cat(self.labels)].cpu().tolist()
+        else:
+            pred, targ = [], []
+        return {"class_corrects": cc, "class_invalids": ci, "class_total_samples": cn,
+                "confusion_matrix_target": targ, "confusion_matrix_pred": pred, "confusion_matrix_labels": self.sorted_labels,
+                "global_accuracy": corrects / max(n, 1),
+                "corrects": corrects, "invalids": invalids, "n_samples": n,
+                "avg_loss": float(self.loss_sum) / max(self.n_batches, 1), "confusion": conf}
+
+
+PICKLE_KEYS = ("class_corrects", "class_invalids", "class_total_samples", "confusion_matrix_target", "confusion_matrix_pred",
+               "confusion_matrix_labels", "global_accuracy")
+
+
+def format_test_log(epoch, res):
+    """The lines the reference prints after an evaluation pass (train.py:138-145); plot.py:59,80 parse
+    'Accuracy = <x>%' / 'Invalids = <x>%' / 'Test loss = <x>' and plot.py:63 '<class> -- acc: <x>%'."""
+    n = max(res["n_samples"], 1)
+    lines = ["Test Epoch {}: Accuracy = {:.2%} ({:g}/{}); Invalids = {:.2%} ({:g}/{}); Test loss = {}".format(
+        epoch, res["corrects"] / n, float(res["corrects"]), res["n_samples"], res["invalids"] / n, float(res["invalids"]),
+        res["n_samples"], res["avg_loss"])]
+    for c, tot in res["class_total_samples"].items():
+        acc = res["class_corrects"][c] / tot if tot else 0
+        inv = res["class_invalids"][c] / tot if tot else 0
+        lines.append("{} -- acc: {:.2%} ({}/{}); invalid: {:.2%} ({}/{})".format(c, acc, res["class_corrects"][c], tot, inv,
+                                                                                  res["class_invalids"][c], tot))
+    return lines
+
+
 @torch.no_grad()
-def test_epoch(loader, model, epoch, device, adict_size, invert_questions=True, log=print):
-    """Accuracy + per-answer confusion counts kept ON the device (row N4): one bincount per batch
-    instead of the reference's per-sample Python loops (train.py:98-127)."""
+def test_epoch(loader, model, epoch, device, adict_size, invert_questions=True, log=print, dictionaries=None,
+               results_dir=None):
+    """The reference's test() (train.py:66-159): eval-mode forward over the loader, accuracy / invalids / per-class
+    figures, the log lines plot.py parses and -- with results_dir -- `test.pickle` with the reference's seven keys.
+    Returns (average per-batch loss, result dict)."""
+    import pickle
     model.eval()
-    conf = torch.zeros(adict_size, adict_size, dtype=torch.long, device=device)       # [label, prediction]
-    loss_sum = torch.zeros((), device=device)
-    n = 0
+    book = EvalBookkeeper(dictionaries or default_dictionaries(adict_size), adict_size, device)
     for batch in loader:
         img, qst, label = load_tensor_data(batch, device, invert_questions)
-        out = model(img, qst)
-        loss_sum += torch.nn.functional.nll_loss(out, label, reduction="sum")
-        pred = out.argmax(1)
-        conf += torch.bincount(label * adict_size + pred, minlength=adict_size * adict_size).view(adict_size, adict_size)
-        n += label.shape[0]
-    correct = int(conf.diag().sum())
-    acc = 100.0 * correct / max(n, 1)
-    log("Test Epoch {}: Accuracy = {:.3f}% ({}/{}); Test loss = {}".format(epoch, acc, correct, n, float(loss_sum) / max(n, 1)))
-    return acc, conf.cpu()
+        book.update(model(img, qst), label)
+    res = book.finalize()
+    for line in format_test_log(epoch, res):
+        log(line)
+    if results_dir is not None:
+        os.makedirs(results_dir, exist_ok=True)
+        with open(os.path.join(results_dir, "test.pickle"), "wb") as f:
+            pickle.dump({k: res[k] for k in PICKLE_KEYS}, f)
+    return res["avg_loss"], res
 
 
 # -------------------------------------------------------------------------------------------- CLI
@@ -193,7 +311,9 @@ def build_argparser():
     ap.add_argument("--no-invert-questions", action="store_true")
     ap.add_argument("--dropout", type=float, default=-1.0)
     ap.add_argument("--question-injection", type=int, default=-1)
-    ap.add_argument("--precision", default=None, choices=[None, "bf16", "fp32"])
+    ap.add_argument("--precision", default=None, choices=[None, "auto", "f16s", "bf16", "fp32"],
+                    help='g_theta arithmetic (DESIGN.md section 2); default "auto" = f16s where the fused chain applies')
+    ap.add_argument("--test-results-dir", default="./test_results", help="where test.pickle goes (train.py:232)")
     ap.add_argument("--model-dir", default="model_checkpoints")
     ap.add_argument("--synthetic", type=int, default=6400, help="samples per epoch of synthetic data (no CLEVR here)")
     ap.add_argument("--qdict-size", type=int, default=82)
@@ -249,7 +369,8 @@ def main(argv=None):
         log("Epoch {} done in {:.1f} s".format(epoch, time.time() - t0))
         test = SyntheticClevr(min(args.synthetic, 4 * args.test_batch_size) // world, max(args.test_batch_size // world, 1),
                               hyp["state_description"], args.qdict_size, args.adict_size, seed=args.seed + 7)
-        test_epoch(test, model, epoch, device, args.adict_size, not args.no_invert_questions, log)
+        test_epoch(test, model, epoch, device, args.adict_size, not args.no_invert_questions, log,
+                   results_dir=args.test_results_dir if rank == 0 else None)
         if rank == 0:
             save_checkpoint(model, os.path.join(args.model_dir, args.model), epoch)
     if world > 1:

@@ -33,6 +33,12 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in sorted(declared):
         assert hasattr(lib, name), "librn_hip.so does not export %s" % name
     assert declared == set(pkg.rn_hip.SIGNATURES), declared ^ set(pkg.rn_hip.SIGNATURES)
+    # diagnostics live in their own header, outside the product ABI
+    dbg = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rn_hip_debug.h")).read(), flags=re.S)
+    dbg_declared = set(re.findall(r"\b(rn_[a-z0-9_]+)\s*\(", dbg))
+    assert dbg_declared == set(pkg.rn_hip.DEBUG_SIGNATURES) and not (dbg_declared & declared)
+    for name in sorted(dbg_declared):
+        assert hasattr(lib, name), "librn_hip.so does not export %s" % name
     loaded = pkg.rn_hip.load()
     assert loaded.rn_abi_version() == 1
     # pure host entry points (no device work) are callable without a GPU

@@ -163,5 +163,131 @@ def test_graph_trainer_overfits_one_batch(T):
     for _ in range(40):
         last = float(tr.step(img, q, y).detach())
     assert np.isfinite(last) and last < 0.5 * first, (first, last)
-    acc, conf = T.test_epoch([batch], m, 1, torch.device("cuda"), 28, log=lambda *a: None)
-    assert conf.sum() == 16 and 0 <= acc <= 100
+    lines = []
+    loss, res = T.test_epoch([batch], m, 1, torch.device("cuda"), 28, log=lines.append)
+    assert res["n_samples"] == 16 and res["confusion"].sum() == 16 and 0 <= res["global_accuracy"] <= 1
+    assert re.search(r".* Accuracy = (\d+\.\d+)%", lines[0]) and re.search(r".* Invalids = (\d+\.\d+)%", lines[0])
+
+
+# ------------------------------------------------------------------------------------------ N4: evaluation bookkeeping
+def eval_loop_restatement(preds, labels, dictionaries):
+    """The per-sample loops of the reference's test() (train.py:69-127) restated: the checker for EvalBookkeeper.
+    preds / labels: lists of 0-based answer indices.  The confusion axes use the build's documented deterministic order
+    (classes by name, 'number' answers numerically) instead of the reference's hash() order (train.py:86)."""
+    _, answ_to_ix, ix_to_class = dictionaries
+    cc = {c: 0 for c in ix_to_class.values()}
+    ci = {c: 0 for c in ix_to_class.values()}
+    cn = {c: 0 for c in ix_to_class.values()}
+    inv = {v: k for k, v in answ_to_ix.items()}
+    order = sorted(ix_to_class.items(), key=lambda x: (x[1], int(inv[x[0]]) if x[1] == "number" else x[0] - 1))
+    order = [c[0] - 1 for c in order]
+    target, pred_l = [], []
+    corrects = 0
+    for p_, l in zip(preds, labels):
+        pc, rc = ix_to_class[p_ + 1], ix_to_class[l + 1]
+        cc[rc] += int(p_ == l)
+        cn[rc] += 1
+        ci[rc] += int(pc != rc)
+        target.append(order.index(l))
+        pred_l.append(order.index(p_))
+        corrects += int(p_ == l)
+    return dict(class_corrects=cc, class_invalids=ci, class_total_samples=cn, confusion_matrix_target=target,
+                confusion_matrix_pred=pred_l, confusion_matrix_labels=[inv[a + 1] for a in order],
+                corrects=corrects, invalids=sum(ci.values()), n_samples=len(labels))
+
+
+def _hand_dictionaries():
+    """A hand-built 7-answer vocabulary in 'first seen' order, two number answers out of numeric order."""
+    answ_to_ix = {"yes": 1, "10": 2, "cube": 3, "2": 4, "no": 5, "sphere": 6, "metal": 7}
+    ix_to_class = {1: "exist", 2: "number", 3: "shape", 4: "number", 5: "exist", 6: "shape", 7: "material"}
+    return {}, answ_to_ix, ix_to_class
+
+
+def _check_book(T, device):
+    d = _hand_dictionaries()
+    A = 7
+    book = T.EvalBookkeeper(d, A, torch.device(device))
+    rs = np.random.RandomState(5)
+    all_p, all_l = [], []
+    for nb in (5, 9, 1):
+        lp = torch.from_numpy(rs.randn(nb, A).astype(np.float32)).log_softmax(1).to(device)
+        lab = torch.from_numpy(rs.randint(0, A, nb)).to(device)
+        book.update(lp, lab)
+        all_p += lp.argmax(1).cpu().tolist()
+        all_l += lab.cpu().tolist()
+    res = book.finalize()
+    ref = eval_loop_restatement(all_p, all_l, d)
+    for k, v in ref.items():
+        assert res[k] == v, (k, res[k], v)
+    # numbers sit in numeric order on the axis: "2" before "10"
+    labs = res["confusion_matrix_labels"]
+    assert labs.index("2") < labs.index("10") and sorted(labs) == sorted(d[1])
+    assert set(T.PICKLE_KEYS) <= set(res) and len(T.PICKLE_KEYS) == 7
+    assert res["global_accuracy"] == pytest.approx(ref["corrects"] / 15)
+    return res
+
+
+def test_eval_bookkeeping_matches_loop_restatement_cpu(T, tmp_path):
+    res = _check_book(T, "cpu")
+    lines = T.format_test_log(3, res)
+    # the regexes of the reference's plot.py:59,80,63 and the Test-loss one (plot.py:43)
+    m = re.search(r".* Accuracy = (\d+\.\d+)%", lines[0])
+    assert m and float(m.group(1)) == pytest.approx(100 * res["global_accuracy"], abs=0.006)
+    m = re.search(r".* Invalids = (\d+\.\d+)%", lines[0])
+    assert m and float(m.group(1)) == pytest.approx(100 * res["invalids"] / res["n_samples"], abs=0.006)
+    assert re.search(r"Test loss = (.*)", lines[0])
+    for c in ("exist", "number", "shape", "material"):
+        assert any(re.search(r"{} -- acc: (\d+\.\d+)%".format(c), ln) for ln in lines[1:])
+
+    class Tiny(torch.nn.Module):                     # test_epoch end to end on the CPU with a stand-in model
+        def forward(self, img, qst):
+            return (img.flatten(1)[:, :28] + 0.01 * qst[:, :1].float()).log_softmax(1)
+
+    ds = T.SyntheticClevr(12, 4, seed=1, hw=8)
+    loss, res2 = T.test_epoch(ds, Tiny(), 1, torch.device("cpu"), 28, log=lambda *a: None, results_dir=str(tmp_path))
+    import pickle
+    dumped = pickle.load(open(os.path.join(str(tmp_path), "test.pickle"), "rb"))
+    assert set(dumped) == set(T.PICKLE_KEYS) and len(dumped["confusion_matrix_target"]) == 12
+    assert set(dumped["class_total_samples"]) == set(T.ANSWER_CLASSES) and sum(dumped["class_total_samples"].values()) == 12
+    assert np.isfinite(loss) and len(dumped["confusion_matrix_labels"]) == 28
+
+
+@pytest.mark.gpu
+def test_eval_bookkeeping_matches_loop_restatement_gpu(T):
+    _check_book(T, "cuda")
+
+
+@pytest.mark.gpu
+def test_graph_replay_survives_an_eval_batch_of_another_size(T):
+    """the coordinate tensor of the captured training shape must stay alive (and unchanged) when an eager
+    evaluation pass with a different batch size runs between two replays."""
+    import relationnetworks_clevr_amd as pkg
+    from relationnetworks_clevr_amd import dp
+
+    class A:
+        qdict_size, adict_size = 82, 28
+
+    def run(with_eval):
+        torch.manual_seed(0)
+        m = pkg.RN(A, dict(formula.HYP["original-fp"], dropout=0.0)).cuda()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-4)
+        tr = dp.DataParallelTrainer(m, opt, clip_norm=50.0, use_graph=True)
+        batch = next(iter(T.SyntheticClevr(8, 8, seed=3)))
+        img, q, y = T.load_tensor_data(batch, "cuda")
+        losses = []
+        for it in range(4):
+            m.train()
+            losses.append(float(tr.step(img, q, y).detach()))
+            if with_eval:
+                m.eval()
+                with torch.no_grad():
+                    for b in (3, 5, 16):
+                        m(torch.rand(b, 3, 128, 128, device="cuda"), torch.randint(1, 83, (b, 20), device="cuda"))
+                junk = [torch.full((8, 2, 64), float(it), device="cuda") for _ in range(64)]   # reuse freed blocks, if any
+                del junk
+        return losses, m._coords(8, 8, img.device).clone()
+
+    a, ca = run(False)
+    b, cb = run(True)
+    assert np.allclose(a, b, rtol=1e-6), (a, b)
+    assert torch.equal(ca, cb)
