@@ -198,6 +198,11 @@ def fused_chain_ok(plan: LayerPlan, code, B, n):
             and all(kp == 256 for kp in plan.kpad[1:]) and (B * n * n) % H.g_chain_tile() == 0 and plan.L <= 8)
 
 
+def f16s_ok(plan: LayerPlan, B, n):
+    """Shapes the "f16s" arithmetic (fp16 activations x split fp16 weights) has a kernel for."""
+    return fused_chain_ok(plan, H.RN_BF16, B, n)
+
+
 def alg0_wgrad_ok(plan, k):
     """Layer-0 weight gradient from the pair reductions (rn_wgrad0_from_reductions) instead of a pass over dZ_0 and P."""
     return plan.inject == 0 and k <= 32 and os.environ.get("RN_NO_ALGEBRAIC_WGRAD0", "0") != "1"

@@ -182,11 +182,14 @@ class RelationalLayer(RelationalLayerBase):
         f_w = [self.f_fc1.weight, self.f_fc2.weight, self.f_fc3.weight]
         f_b = [self.f_fc1.bias, self.f_fc2.bias, self.f_fc3.bias]
         mask = self._dropout_mask(b, x.device)
-        prec = self.precision
-        if prec == "auto":
-            fused = RF.fused_chain_ok(plan, H.RN_BF16, b, d)
-            prec = "f16s" if fused else "bf16"
-        return RF.relational_forward(x, qst, mask, plan, self._packed, prec, g_w, g_b, f_w, f_b, label=label)
+        return RF.relational_forward(x, qst, mask, plan, self._packed, self.resolved_precision(b, d, k), g_w, g_b, f_w, f_b, label=label)
+
+    def resolved_precision(self, b, d, k):
+        """The arithmetic mode a forward pass on (b, d, k) objects runs in: `self.precision`, with "auto" resolved to
+        "f16s" (meets the 1e-3 log-prob bar) wherever a kernel for it exists for this shape, else "bf16"."""
+        if self.precision != "auto":
+            return self.precision
+        return "f16s" if RF.f16s_ok(self._plan(k), b, d) else "bf16"
 
     @torch.no_grad()
     def extract_features(self, x, qst, layer_idx):

@@ -58,7 +58,7 @@ def record_rl(tag, cfg, b, n, seed, **kw):
         seed += 1000
 
 
-def _record_rl(tag, cfg, b, n, seed, strided=False, train_dropout=False, full=False, full_grads=False, extra=None):
+def _record_rl(tag, cfg, b, n, seed, strided=False, train_dropout=False, full=False, full_grads=False, extra=None, light=False):
     rl, hyp = build_ref_rl(cfg, seed)
     k, Q = hyp["rl_in_size"] // 2, hyp["lstm_hidden"]
     x_np = formula.formula_objects(b, n, k, seed + 1, from_pixels=not hyp["state_description"])
@@ -99,7 +99,14 @@ def _record_rl(tag, cfg, b, n, seed, strided=False, train_dropout=False, full=Fa
     out["x_g"] = hL.view(b, n * n, -1).sum(1).numpy()
     out["log_probs"] = lp.detach().numpy()
     out["loss"] = np.array(loss.item(), dtype=np.float32)
-    out["dx"] = x.grad.numpy().copy()
+    if light:   # big-shape record kept KB-sized (SURVEY 8c "norms at B=32"): norm + sampled entries instead of the full dx
+        dxn = x.grad.numpy()
+        idx = sample_idx(dxn.shape, seed + 23, 4096)
+        out["dx_norm"] = np.array(np.linalg.norm(dxn.astype(np.float64)), dtype=np.float64)
+        out["dx_sample_idx"] = idx
+        out["dx_sample"] = dxn.reshape(-1)[idx].copy()
+    else:
+        out["dx"] = x.grad.numpy().copy()
     out["dq"] = q.grad.numpy().copy()
     for name, p in rl.named_parameters():
         gnp = p.grad.numpy()
@@ -232,6 +239,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "traj":
         record_train_traj("G-traj", "original-fp", 8, 4, seed=91)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "stress":
+        # BASELINE.json configs[4] at its real size (B=32, 14x14 grid: M = 1,229,312 pair rows; ~12 GB, ~1 min on 8 cores)
+        record_rl("G-fp196-b32", "original-fp", 32, 196, seed=52, light=True)
+        sys.exit(0)
     record_rl("G-sd4", "original-sd", 4, 12, seed=11, full=True)
     record_rl("G-irsd4", "ir-sd", 4, 12, seed=12, full=True)
     record_rl("G-fp-small", "original-fp", 2, 64, seed=21, strided=True, full=True, full_grads=True)
@@ -239,6 +250,7 @@ if __name__ == "__main__":
     record_rl("G-fp64", "original-fp", 64, 64, seed=31)
     record_rl("G-ir64", "ir-fp", 64, 64, seed=41)
     record_rl("G-fp196", "original-fp", 2, 196, seed=51)
+    record_rl("G-fp196-b32", "original-fp", 32, 196, seed=52, light=True)
     record_rl("G-drop", "original-fp", 4, 64, seed=61, train_dropout=True, full=True)
     record_e2e("G-e2e", "original-fp", 4, seed=71)
     record_e2e("G-e2e-ir", "ir-fp", 4, seed=72)

@@ -32,15 +32,24 @@ def _data(B=4):
     return x, q, y
 
 
-def _worker(rank, world, port, steps, out_path):
+def _opt(model, kind):
+    if kind == "sgd":      # (plain Adam turns 1e-9 round-off on zero-gradient weights into +-lr steps: its eps is raised below)
+        return torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    # the reference's optimiser (train.py:330): Adam with coupled weight decay.  eps = 1e-4 keeps a weight whose true
+    # gradient is 0 (summation-order noise of 1e-9) from moving by a full lr in a rank-dependent direction.
+    return torch.optim.Adam(model.parameters(), lr=1e-3, eps=1e-4, weight_decay=1e-4)
+
+
+def _worker(rank, world, port, steps, out_path, kind="sgd"):
     import relationnetworks_clevr_amd as pkg
     from relationnetworks_clevr_amd import dp
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     model = _make(seed=3 + rank)          # different init per rank: broadcast must fix it
-    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)   # (Adam turns 1e-9 round-off on zero-gradient weights into +-lr steps)
-    tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0)
+    opt = _opt(model, kind)
+    tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0, use_graph=False)
+    assert tr._fused_opt is None          # CPU tensors: the torch optimiser branch of DataParallelTrainer.step
     x, q, y = _data()
     sh = x.shape[0] // world
     sl = slice(rank * sh, (rank + 1) * sh)
@@ -56,16 +65,17 @@ def _worker(rank, world, port, steps, out_path):
     dist.destroy_process_group()
 
 
-def test_two_rank_dp_equals_single_process(tmp_path):
+@pytest.mark.parametrize("kind", ["sgd", "adam"])
+def test_two_rank_dp_equals_single_process(tmp_path, kind):
     from relationnetworks_clevr_amd import dp
     steps = 3
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_worker, args=(2, _free_port(), steps, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), steps, out, kind), nprocs=2, join=True)
     got = torch.load(out)
     # single process, full batch, same trainer (no process group -> all-reduce is the identity)
     model = _make(seed=3)
-    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)   # (Adam turns 1e-9 round-off on zero-gradient weights into +-lr steps)
-    tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0)
+    opt = _opt(model, kind)
+    tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0, use_graph=False)
     x, q, y = _data()
     ref_loss = [float(tr.step(x, q, y).detach()) for _ in range(steps)]
     assert np.allclose(got["loss"], ref_loss, rtol=1e-5, atol=1e-6)
@@ -105,3 +115,24 @@ def test_flat_bucket_semantics():
     torch.optim.SGD(m.parameters(), lr=0.1).zero_grad(set_to_none=True)
     with pytest.raises(RuntimeError, match="left the flat bucket"):
         b.check_attached()
+
+
+def test_bench_launch_plumbing_dry_run_two_ranks():
+    """bench.py under torch.distributed.run with 2 ranks, exactly as the driver launches the N > 1 bench, with the train
+    step replaced by a sleep (RN_BENCH_DRY=1) and gloo instead of RCCL: WORLD_SIZE / RANK / MASTER_* parsing, process-group
+    init, barrier-bracketed timed region, MAX-over-ranks time, one JSON line from rank 0 only."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, RN_BENCH_DRY="1", RN_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["config"]["global_batch"] == 128
+    assert d["ms_per_step"] >= 2.0          # rank 1 sleeps 2 ms per step, rank 0 only 1 ms: the MAX over ranks won
+    assert abs(d["value"] - 2 * 64 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]

@@ -1,0 +1,138 @@
+"""GPU: the N > 1 code path of the data-parallel trainer on the hardware that is available (ONE MI355X).
+
+  * FusedClipAdam.step(clip, grad_scale=1/world) on a world-times-summed bucket == the single-rank step, and both ==
+    torch's clip_grad_norm_ + Adam (the `world > 1` branch of DataParallelTrainer.step, dp.py);
+  * two processes on the same GPU, `gloo` carrying the CUDA bucket (RCCL refuses two ranks on one device): hipGraph
+    replay of forward + backward, eager all-reduce, bucket re-attachment, fused (1/world + clip + Adam) -- the seam
+    `bench.py --gpus N` / train.py run with N ranks -- against one process on the concatenated batch.
+The 8-GPU RCCL run itself is the driver's (SCALE_rNN.json)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import formula
+
+pytestmark = pytest.mark.gpu
+
+
+class A:
+    qdict_size, adict_size = formula.QDICT, formula.ADICT
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_fused_clip_adam_grad_scale_equals_single_rank_and_torch():
+    import relationnetworks_clevr_amd as pkg
+    from relationnetworks_clevr_amd import dp
+    pkg.rn_hip.load()
+    torch.manual_seed(1)
+
+    def make():
+        torch.manual_seed(5)
+        return torch.nn.Sequential(torch.nn.Linear(300, 257), torch.nn.ReLU(), torch.nn.Linear(257, 31)).cuda()
+
+    grads = None
+    results = {}
+    for tag, world in (("one", 1), ("two", 2), ("torch", 0)):
+        m = make()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4)
+        bucket = dp.FlatGradBucket(m.parameters())
+        if grads is None:
+            grads = [torch.randn(3, bucket.numel, device="cuda") * s for s in (0.01, 5.0, 40.0)]      # un-clipped and clipped steps
+        if tag == "torch":
+            for g in grads:
+                for step_g in g:
+                    bucket.flat.copy_(step_g)
+                    torch.nn.utils.clip_grad_norm_(m.parameters(), 50.0)
+                    opt.step()
+        else:
+            assert dp.FusedClipAdam.supports(bucket, opt)
+            f = dp.FusedClipAdam(bucket, opt)
+            for g in grads:
+                for step_g in g:
+                    bucket.flat.copy_(step_g * world)             # what a SUM all-reduce over `world` identical ranks leaves
+                    f.step(50.0, grad_scale=1.0 / world)
+        torch.cuda.synchronize()
+        results[tag] = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu().numpy()
+    assert np.allclose(results["one"], results["two"], rtol=0, atol=1e-7)       # x2 and x0.5 are exact in fp32
+    assert np.allclose(results["one"], results["torch"], rtol=2e-5, atol=2e-7)
+
+
+def _model(cfg, seed):
+    import io, contextlib
+    import relationnetworks_clevr_amd as pkg
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = pkg.RN(A, dict(formula.HYP[cfg], dropout=0.0))
+    m.cuda()
+    m.train()
+    if cfg.endswith("-fp"):
+        m.conv.eval()          # batch statistics are per replica by design (train.py:256-258: no SyncBN): running stats here, so
+    return m                   # that two shards of 4 ARE one batch of 8
+
+
+def _data(cfg, B):
+    if cfg.endswith("-sd"):
+        x = torch.from_numpy(formula.formula_objects(B, 12, 7, 5, from_pixels=False))
+    else:
+        x = torch.from_numpy(formula.hash_uniform((B, 3, 128, 128), 5, 0.0, 1.0))
+    q = torch.from_numpy(formula.hash_ints((B, 12), 6, 1, formula.QDICT + 1))
+    y = torch.from_numpy(formula.hash_ints((B,), 7, 0, formula.ADICT))
+    return x.cuda(), q.cuda(), y.cuda()
+
+
+def _worker(rank, world, port, cfg, steps, out_path):
+    from relationnetworks_clevr_amd import dp
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _model(cfg, seed=3 + rank)                  # different init per rank: the broadcast must fix it
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, eps=1e-4, weight_decay=1e-4)
+    tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0, use_graph=True)
+    assert tr._fused_opt is not None
+    x, q, y = _data(cfg, 8)
+    sh = x.shape[0] // world
+    sl = slice(rank * sh, (rank + 1) * sh)
+    losses = []
+    for _ in range(steps):
+        losses.append(float(tr.step(x[sl].contiguous(), q[sl].contiguous(), y[sl].contiguous()).detach()))
+        tr.bucket.check_attached()
+    lt = torch.tensor(losses, dtype=torch.float64)
+    dist.all_reduce(lt)
+    if rank == 0:
+        torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "loss": (lt / world).tolist()}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg", ["original-sd", "original-fp"])
+def test_two_ranks_on_one_gpu_equal_one_rank_on_the_whole_batch(tmp_path, cfg):
+    from relationnetworks_clevr_amd import dp
+    steps = 3
+    out = str(tmp_path / "dp.pt")
+    try:
+        mp.spawn(_worker, args=(2, _free_port(), cfg, steps, out), nprocs=2, join=True)
+    except Exception as e:                                 # gloo built without device-tensor support: nothing to test here
+        if "gloo" in str(e).lower() and ("cuda" in str(e).lower() or "device" in str(e).lower()):
+            pytest.skip("gloo cannot carry GPU tensors in this build: %s" % str(e)[:200])
+        raise
+    got = torch.load(out)
+    model = _model(cfg, seed=3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, eps=1e-4, weight_decay=1e-4)
+    tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0, use_graph=True)
+    x, q, y = _data(cfg, 8)
+    ref_loss = [float(tr.step(x, q, y).detach()) for _ in range(steps)]
+    # bf16 / f16s arithmetic: the two shards round like the whole batch row for row (no cross-question arithmetic), the
+    # gradients differ only by the fp32 summation order over questions
+    assert np.allclose(got["loss"], ref_loss, rtol=2e-4, atol=1e-5), (got["loss"], ref_loss)
+    for k, v in model.state_dict().items():
+        a, b = got["sd"][k].float(), v.cpu().float()
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-5), (k, float((a - b).abs().max()))

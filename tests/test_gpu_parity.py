@@ -1,21 +1,23 @@
 """GPU: the drop-in module (RelationalLayer / RN on HIP kernels) against the golden vectors
 recorded from the reference (tests/golden/*.npz).
 
-Tolerances:
-  precision="fp32" (fp32 MFMA, the parity mode): log-probs <= 1e-4 max-norm relative (the north
-      star asks for 1e-3); parameter grads <= 1e-3; input grads <= 2e-4 in relative L2 and <= 5e-3
-      max-norm: among the 10^7..10^8 g_theta ReLU units of a batch a handful sit within fp32
-      round-off of zero and gate differently under a different (equally valid) fp32 summation
-      order; one flipped unit moves one object's dx by ~1e-3 of max|dx| (measured: sparse (b, j)
-      rows at 6e-4..1.3e-3, everything else at 1e-6);
-  precision="bf16" (bf16 MFMA, the throughput mode): log-probs <= 3e-2 max-norm relative -- single
-      pass bf16 cannot reach 1e-3 (SURVEY.md appendix B measured 0.4e-2..1.3e-2; here 0.4e-3..1.5e-3
-      with formula weights, 0.8e-2..1e-2 with the released checkpoints); gradients are compared in
-      relative L2 norm (<= 0.25; measured 0.4e-2..0.18) because a bf16-sized perturbation of x_g
-      flips f_phi ReLU units that sit near zero, which switches a whole sample's gradient
-      contribution discontinuously (worst for the B=2 fixtures).  The per-kernel bf16 tests in
-      test_gpu_kernels.py are the tight ones (<= 1 bf16 ulp against an oracle on the same operands).
-Measured values are appended to gpurun_out/parity_report.json."""
+Tolerances (every bound is <= ~2x what was measured on MI355X; measured values are appended to
+gpurun_out/parity_report.jsonl by every run):
+  precision="fp32" (fp32 MFMA): log-probs <= 1e-4 max-norm relative (the north star asks for 1e-3; measured
+      <= 5e-7); parameter grads <= 1e-3; input grads <= 2e-4 in relative L2 and <= 5e-3 max-norm: among the
+      10^7..10^8 g_theta ReLU units of a batch a handful sit within fp32 round-off of zero and gate differently
+      under a different (equally valid) fp32 summation order; one flipped unit moves one object's dx by ~1e-3 of
+      max|dx| (measured: sparse (b, j) rows at 6e-4..1.3e-3, everything else at 1e-6);
+  precision="f16s" / "auto" (the HEADLINE mode: fp16 activations x split fp16 weights, bf16 backward): log-probs
+      <= 2e-4 (measured 2e-6..7.4e-5; the bar is 1e-3), argmax agreement with the reference = 1.0, gradients
+      <= 1.2e-2 in relative L2 (measured 2e-3..5e-3: bf16 storage of dZ / H in the backward pass);
+  precision="bf16" (single-pass bf16, the throughput mode -- NOT the headline): log-probs <= 3e-3 with formula
+      weights (measured 0.4e-3..1.5e-3) and <= 2e-2 on the released checkpoints (measured 0.9e-2..1e-2: the
+      systematic weight-rounding error SURVEY.md appendix B predicted; this mode misses the 1e-3 bar and says so);
+      gradients per fixture in BF16_GRAD_L2 (a bf16-sized perturbation of x_g flips f_phi / g_theta ReLU units that
+      sit near zero, which switches whole gradient contributions discontinuously -- worst on the small-batch
+      fixtures that run the per-layer kernels).  The per-kernel bf16 tests in test_gpu_kernels.py are the tight ones
+      (<= 1 bf16 ulp against an oracle on the same operands)."""
 import json
 import os
 
@@ -29,6 +31,9 @@ from oracle import formula
 pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 RL_TAGS = ["G-sd4", "G-irsd4", "G-fp-small", "G-ir-small", "G-fp64", "G-ir64", "G-fp196", "G-drop"]
+# relative-L2 gradient bounds of the bf16 mode, ~2x the measured value per fixture (dx, dq, bias grads)
+BF16_GRAD_L2 = {"G-drop": 3e-2, "G-fp-small": 3e-2, "G-fp196": 3e-2, "G-fp64": 8e-2, "G-sd4": 8e-2, "G-irsd4": 0.12,
+                "G-ir64": 0.14, "G-ir-small": 0.3}
 
 
 def report(tag, **kw):
@@ -102,8 +107,9 @@ def test_relational_layer_bf16_parity(pkg, tag):
     report(tag, precision="bf16", log_probs=e_lp, dx_l2=e_dx, dq_l2=e_dq, params_l2=e_b,
            dx_max=gold.rel_err(dx, g["dx"]), argmax_agree=float((lp.argmax(1) == g["log_probs"].argmax(1)).mean()))
     assert np.isfinite(lp).all()
-    assert e_lp <= 3e-2
-    assert e_dx <= 0.25 and e_dq <= 0.25 and e_b <= 0.25
+    assert e_lp <= 3e-3
+    bound = BF16_GRAD_L2[tag]
+    assert e_dx <= bound and e_dq <= bound and e_b <= bound, (e_dx, e_dq, e_b, bound)
 
 
 @pytest.mark.parametrize("tag", ["G-fp-small", "G-fp64", "G-drop"])
@@ -116,9 +122,25 @@ def test_relational_layer_f16s_parity(pkg, tag):
     e_lp = gold.rel_err(lp, g["log_probs"])
     e_dx, e_dq = l2rel(dx, g["dx"]), l2rel(dq, g["dq"])
     e_b = max(l2rel(grads[k[5:]], g[k]) for k in g if k.startswith("grad/"))
-    report(tag, precision="f16s", log_probs=e_lp, dx_l2=e_dx, dq_l2=e_dq, params_l2=e_b)
-    assert e_lp <= 1e-3
-    assert e_dx <= 0.25 and e_dq <= 0.25 and e_b <= 0.25
+    agree = float((lp.argmax(1) == g["log_probs"].argmax(1)).mean())
+    report(tag, precision="f16s", log_probs=e_lp, dx_l2=e_dx, dq_l2=e_dq, params_l2=e_b, argmax_agree=agree)
+    assert e_lp <= 2e-4
+    assert agree == 1.0
+    assert e_dx <= 1.2e-2 and e_dq <= 1.2e-2 and e_b <= 1.2e-2, (e_dx, e_dq, e_b)
+
+
+@pytest.mark.parametrize("tag", ["G-fp64", "G-fp-small", "G-drop"])
+def test_headline_mode_is_the_module_default_and_meets_the_bar(pkg, tag):
+    """precision="auto" -- what a user who touches nothing gets, and what bench.py reports as `value` -- resolves to
+    the parity-clean mode on the headline shape family: log-probs within 2e-4 of the reference (bar: 1e-3), same answers."""
+    g = gold.load(tag)
+    hyp = formula.HYP[g["meta"]["cfg"]]
+    rl = pkg.RelationalLayer(hyp["rl_in_size"], formula.ADICT, hyp["lstm_hidden"], dict(hyp))
+    assert rl.precision == "auto" and rl.resolved_precision(g["meta"]["b"], g["meta"]["n"], hyp["rl_in_size"] // 2) == "f16s"
+    lp, loss, dx, dq, grads = run_rl(pkg, g, "auto")
+    e_lp = gold.rel_err(lp, g["log_probs"])
+    report(tag, precision="auto", log_probs=e_lp)
+    assert e_lp <= 2e-4 and (lp.argmax(1) == g["log_probs"].argmax(1)).all()
 
 
 def test_f16s_refuses_unsupported_shapes(pkg):
@@ -140,7 +162,7 @@ def build_full(pkg, g, precision):
 
 
 @pytest.mark.parametrize("tag", ["G-e2e", "G-e2e-ir"])
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 3e-2), ("f16s", 1e-3)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("bf16", 3e-3), ("f16s", 1e-4)])
 def test_full_model_e2e(pkg, tag, precision, tol):
     if precision == "f16s" and tag.endswith("-ir"):
         pytest.skip("f16s covers question injection at layer 0 only")
@@ -162,9 +184,9 @@ def test_full_model_e2e(pkg, tag, precision, tol):
     assert e <= tol
 
 
-@pytest.mark.parametrize("tag,precision,tol", [("pretrained_original_fp", "fp32", 1e-3), ("pretrained_ir_fp", "fp32", 1e-3),
-                                               ("pretrained_original_fp", "bf16", 3e-2), ("pretrained_ir_fp", "bf16", 3e-2),
-                                               ("pretrained_original_fp", "f16s", 1e-3)])
+@pytest.mark.parametrize("tag,precision,tol", [("pretrained_original_fp", "fp32", 2e-6), ("pretrained_ir_fp", "fp32", 2e-6),
+                                               ("pretrained_original_fp", "bf16", 2e-2), ("pretrained_ir_fp", "bf16", 2e-2),
+                                               ("pretrained_original_fp", "f16s", 2e-4), ("pretrained_original_fp", "auto", 2e-4)])
 def test_released_checkpoints_load_and_match(pkg, tag, precision, tol):
     """README.md:86-95 checkpoints (as arrays): strict key match + log-probs."""
     g = gold.load(tag)
@@ -178,8 +200,11 @@ def test_released_checkpoints_load_and_match(pkg, tag, precision, tol):
     with torch.no_grad():
         lp = m(img, qst).cpu().numpy()
     e = gold.rel_err(lp, g["log_probs"])
-    report(tag, precision=precision, log_probs=e)
+    agree = float((lp.argmax(1) == g["log_probs"].argmax(1)).mean())
+    report(tag, precision=precision, log_probs=e, argmax_agree=agree)
     assert e <= tol
+    if precision != "bf16":
+        assert agree == 1.0
 
 
 def test_extraction_hooks(pkg):
@@ -290,4 +315,64 @@ def test_full_size_properties(pkg, precision):
         ref, _ = _full_rl(pkg, "fp32")
         ref.load_state_dict(rl.state_dict())
         lp_r = ref(x, q).detach()
-        assert gold.rel_err(lp.cpu().numpy(), lp_r.cpu().numpy()) <= (1e-3 if precision == "f16s" else 3e-2)
+        assert gold.rel_err(lp.cpu().numpy(), lp_r.cpu().numpy()) <= (2e-4 if precision == "f16s" else 1e-2)
+
+
+# ----------------------------------------------------------------------------- BASELINE configs[4] at its real size
+@pytest.mark.parametrize("precision", ["auto", "bf16", "f16s", "fp32"])
+def test_stress_config_real_dispatch(pkg, precision):
+    """original-fp stress: 14x14 grid (n = 196), B = 32 -- M = 1,229,312 pair rows, n*n % 32 != 0: the register-resident chain
+    runs on a pair matrix with waves that straddle two questions, H_3 is stored for the stand-alone pair sum, the last
+    wgrad reads a stored dZ_3 ("auto"/"f16s": the LDS-resident split-weight chain).  Checked against G-fp196-b32, recorded
+    from the reference at this very size (make_golden.py stress): log-probs, loss, dq, dx (norm + 4096 sampled entries),
+    bias gradients, weight-gradient norms + samples; plus the size-independent properties (object permutation, batch slice)."""
+    g = gold.load("G-fp196-b32")
+    meta = g["meta"]
+    assert meta["b"] == 32 and meta["n"] == 196
+    hyp, sd, x, q, lab = gold.rl_case(meta)
+    rl = pkg.RelationalLayer(hyp["rl_in_size"], formula.ADICT, hyp["lstm_hidden"], dict(hyp, precision=precision))
+    rl.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    rl = rl.cuda().eval()
+    labt = torch.from_numpy(lab).cuda()
+
+    def run(xn, qn, ll):
+        xt = torch.from_numpy(xn).cuda().requires_grad_(True)
+        qt = torch.from_numpy(qn).cuda().requires_grad_(True)
+        lp = rl(xt, qt)
+        loss = torch.nn.functional.nll_loss(lp, ll)
+        loss.backward()
+        torch.cuda.synchronize()
+        return lp.detach().cpu().numpy(), float(loss.detach()), xt.grad.cpu().numpy(), qt.grad.cpu().numpy()
+
+    for p_ in rl.parameters():
+        p_.grad = None
+    lp, loss, dx, dq = run(x, q, labt)
+    grads = {n_: p_.grad.detach().cpu().numpy() for n_, p_ in rl.named_parameters()}
+    e_lp = gold.rel_err(lp, g["log_probs"])
+    e_dq = l2rel(dq, g["dq"])
+    e_dxs = l2rel(dx.reshape(-1)[g["dx_sample_idx"]], g["dx_sample"])
+    e_dxn = abs(float(np.linalg.norm(dx.astype(np.float64))) - float(g["dx_norm"])) / float(g["dx_norm"])
+    e_b = max(l2rel(grads[k_[5:]], g[k_]) for k_ in g if k_.startswith("grad/"))
+    e_wn = max(abs(float(np.linalg.norm(grads[k_[9:]].astype(np.float64))) - float(g[k_])) / max(float(g[k_]), 1e-30)
+               for k_ in g if k_.startswith("gradnorm/"))
+    agree = float((lp.argmax(1) == g["log_probs"].argmax(1)).mean())
+    report("G-fp196-b32", precision=precision, resolved=rl.resolved_precision(32, 196, 26), log_probs=e_lp, loss=abs(loss - float(g["loss"])) / float(g["loss"]),
+           dq_l2=e_dq, dx_sample_l2=e_dxs, dx_norm=e_dxn, bias_l2=e_b, wnorm=e_wn, argmax_agree=agree)
+    lp_tol, g_tol = {"fp32": (1e-5, 1e-3), "f16s": (2e-4, 2e-2), "auto": (2e-4, 2e-2), "bf16": (5e-3, 0.1)}[precision]
+    assert np.isfinite(lp).all() and e_lp <= lp_tol
+    assert abs(loss - float(g["loss"])) <= max(lp_tol, 1e-6) * 10 * abs(float(g["loss"]))
+    assert e_dq <= g_tol and e_dxs <= g_tol and e_dxn <= g_tol and e_b <= g_tol and e_wn <= g_tol
+    if precision != "bf16":
+        assert agree == 1.0
+    # size-independent properties at the full size: a slice of the batch on its own reproduces its rows
+    sl = slice(8, 12)
+    lp_s, _, dx_s, dq_s = run(np.ascontiguousarray(x[sl]), np.ascontiguousarray(q[sl]), labt[sl])
+    ptol = 2e-6 if precision == "fp32" else 5e-5
+    assert gold.rel_err(lp_s, lp[sl]) <= ptol
+    gt = 1e-5 if precision == "fp32" else 3e-2
+    assert l2rel(dx_s * (4 / 32), dx[sl]) <= gt and l2rel(dq_s * (4 / 32), dq[sl]) <= gt       # (mean-loss scaling)
+    # ... and permuting every question's objects changes only summation order
+    perm = np.random.RandomState(4).permutation(196)
+    lp_p, _, dx_p, dq_p = run(np.ascontiguousarray(x[:, perm]), q, labt)
+    assert gold.rel_err(lp_p, lp) <= ptol
+    assert l2rel(dx_p, dx[:, perm]) <= gt and l2rel(dq_p, dq) <= gt
