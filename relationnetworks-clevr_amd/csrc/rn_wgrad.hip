@@ -505,7 +505,8 @@ extern "C" int rn_g_linear_bwd_wgrad_gated(const void* mask, const float* dxg, i
   RN_CHECK_ARG(rows_per_question > 0 && rows_per_question % 64 == 0 && M % rows_per_question == 0,
                "rn_g_linear_bwd_wgrad_gated: rows_per_question=%d must be a multiple of 64 dividing M", rows_per_question);
   RN_CHECK_ARG(((uintptr_t)mask | (uintptr_t)dxg | (uintptr_t)A) % 16 == 0, "rn_g_linear_bwd_wgrad_gated: pointers must be 16-byte aligned");
-  const int NB = 4, S = M / 64, Zs = 256 / NB;
+  const char* ze = getenv("RN_WGRAD_ZS");                   // diagnostics: M-split (workgroups = 4 x Zs); default fills the chip
+  const int NB = 4, S = M / 64, Zs = (ze && atoi(ze) > 0 && atoi(ze) <= 256 / NB) ? atoi(ze) : 256 / NB;
   float* part = (float*)ws;
   float* part_db = part + (size_t)Zs * N * K;
   hipStream_t s = (hipStream_t)stream;

@@ -595,7 +595,10 @@ class RelationalFunction(torch.autograd.Function):
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
                         _wgrad0()
-                    keep.append([Rj, Ri, Rq])
+                    # x and q too: they are alive only through this node's saved tensors, which autograd releases as soon as
+                    # backward() returns -- the caching allocator would hand their blocks to the conv / LSTM backward that the
+                    # main stream runs next while this side-stream kernel still reads them (seen as a wrong dW_0 on a busy GPU)
+                    keep.append([Rj, Ri, Rq, x, q])
                 else:
                     _wgrad0()
             if l == 0 and fused_tail:

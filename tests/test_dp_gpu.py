@@ -79,6 +79,15 @@ def _model(cfg, seed):
     return m                   # that two shards of 4 ARE one batch of 8
 
 
+# eps far above the gradient scale makes Adam's update ~ lr * g / eps, i.e. LINEAR in the gradient, and the clip is active:
+# a wrong 1/world factor, a stale bucket or a clip on the un-scaled norm all show up in the parameters
+CLIP = 0.5
+
+
+def _adam(model):
+    return torch.optim.Adam(model.parameters(), lr=1e-3, eps=1e-1, weight_decay=1e-4)
+
+
 def _data(cfg, B):
     if cfg.endswith("-sd"):
         x = torch.from_numpy(formula.formula_objects(B, 12, 7, 5, from_pixels=False))
@@ -95,8 +104,8 @@ def _worker(rank, world, port, cfg, steps, out_path):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     model = _model(cfg, seed=3 + rank)                  # different init per rank: the broadcast must fix it
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, eps=1e-4, weight_decay=1e-4)
-    tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0, use_graph=True)
+    opt = _adam(model)
+    tr = dp.DataParallelTrainer(model, opt, clip_norm=CLIP, use_graph=True)
     assert tr._fused_opt is not None
     x, q, y = _data(cfg, 8)
     sh = x.shape[0] // world
@@ -126,13 +135,24 @@ def test_two_ranks_on_one_gpu_equal_one_rank_on_the_whole_batch(tmp_path, cfg):
         raise
     got = torch.load(out)
     model = _model(cfg, seed=3)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, eps=1e-4, weight_decay=1e-4)
-    tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0, use_graph=True)
+    init = {k: v.detach().cpu().float().clone() for k, v in model.state_dict().items()}
+    opt = _adam(model)
+    tr = dp.DataParallelTrainer(model, opt, clip_norm=CLIP, use_graph=True)
     x, q, y = _data(cfg, 8)
     ref_loss = [float(tr.step(x, q, y).detach()) for _ in range(steps)]
-    # bf16 / f16s arithmetic: the two shards round like the whole batch row for row (no cross-question arithmetic), the
-    # gradients differ only by the fp32 summation order over questions
-    assert np.allclose(got["loss"], ref_loss, rtol=2e-4, atol=1e-5), (got["loss"], ref_loss)
+    # The two shards compute what the whole batch computes question for question (no cross-question arithmetic), up to the
+    # bf16-level noise of kernels that tile a 4-question and an 8-question problem differently, and the fp32 summation
+    # order of the gradients.  Compared: the losses and every tensor's UPDATE (final - initial) in relative L2.
+    assert np.allclose(got["loss"], ref_loss, rtol=2e-3, atol=1e-5), (got["loss"], ref_loss)
+    errs = {}
     for k, v in model.state_dict().items():
-        a, b = got["sd"][k].float(), v.cpu().float()
-        assert torch.allclose(a, b, rtol=2e-3, atol=2e-5), (k, float((a - b).abs().max()))
+        if not v.dtype.is_floating_point:
+            continue
+        da, db = got["sd"][k].float() - init[k], v.cpu().float() - init[k]
+        if float(db.norm()) < 1e-9:                          # untouched tensor (conv stack of the *-sd model, BN buffers in eval)
+            assert float(da.norm()) < 1e-9, k
+            continue
+        e = float((da - db).norm() / db.norm())
+        errs[k] = (e, float(db.norm()), float(da.norm()))
+    bad = {k: v for k, v in errs.items() if v[0] > 3e-2}
+    assert not bad, "relative update error (err, |ref update|, |2-rank update|): %r" % (sorted(errs.items(), key=lambda kv: -kv[1][0])[:8],)

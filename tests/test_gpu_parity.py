@@ -364,13 +364,14 @@ def test_stress_config_real_dispatch(pkg, precision):
     assert e_dq <= g_tol and e_dxs <= g_tol and e_dxn <= g_tol and e_b <= g_tol and e_wn <= g_tol
     if precision != "bf16":
         assert agree == 1.0
-    # size-independent properties at the full size: a slice of the batch on its own reproduces its rows
-    sl = slice(8, 12)
+    # size-independent properties at the full size: a slice of the batch on its own reproduces its rows (8 questions:
+    # M = 8 * 196^2 stays a multiple of 128, so that "auto" / "f16s" run the same kernels on the slice)
+    sl = slice(8, 16)
     lp_s, _, dx_s, dq_s = run(np.ascontiguousarray(x[sl]), np.ascontiguousarray(q[sl]), labt[sl])
     ptol = 2e-6 if precision == "fp32" else 5e-5
     assert gold.rel_err(lp_s, lp[sl]) <= ptol
     gt = 1e-5 if precision == "fp32" else 3e-2
-    assert l2rel(dx_s * (4 / 32), dx[sl]) <= gt and l2rel(dq_s * (4 / 32), dq[sl]) <= gt       # (mean-loss scaling)
+    assert l2rel(dx_s * (8 / 32), dx[sl]) <= gt and l2rel(dq_s * (8 / 32), dq[sl]) <= gt       # (mean-loss scaling)
     # ... and permuting every question's objects changes only summation order
     perm = np.random.RandomState(4).permutation(196)
     lp_p, _, dx_p, dq_p = run(np.ascontiguousarray(x[:, perm]), q, labt)

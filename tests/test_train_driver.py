@@ -291,3 +291,42 @@ def test_graph_replay_survives_an_eval_batch_of_another_size(T):
     b, cb = run(True)
     assert np.allclose(a, b, rtol=1e-6), (a, b)
     assert torch.equal(ca, cb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_train_step_is_bitwise_reproducible_with_a_poisoned_allocator(T, use_graph):
+    """No kernel of the step may read memory it (or a predecessor) has not written: with every free block of the caching
+    allocator filled with NaN (then 1e30) before each step, losses and the complete flat gradient are BITWISE what a clean
+    run gives -- in the module-default arithmetic, eager and graph-replayed.  (Also pins run-to-run determinism: fixed-order
+    reductions everywhere, no atomics.)"""
+    import relationnetworks_clevr_amd as pkg
+    from relationnetworks_clevr_amd import dp
+
+    class A:
+        qdict_size, adict_size = 82, 28
+
+    def poison(val):
+        junk = [torch.full(((1 << s_) // 4,), val, device="cuda") for s_ in range(9, 29) for _ in range(4)]
+        torch.cuda.synchronize()
+        del junk
+
+    def run(val):
+        torch.manual_seed(0)
+        m = pkg.RN(A, dict(formula.HYP["original-fp"], dropout=0.0)).cuda()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-4)
+        tr = dp.DataParallelTrainer(m, opt, clip_norm=50.0, use_graph=use_graph)
+        img, q, y = T.load_tensor_data(next(iter(T.SyntheticClevr(8, 8, seed=3))), "cuda")
+        out = []
+        for _ in range(3):
+            if val is not None:
+                poison(val)
+            loss = tr.step(img, q, y)
+            torch.cuda.synchronize()
+            out.append((float(loss.detach()), tr.bucket.flat.clone()))
+        return out
+
+    base = run(None)
+    for val in (float("nan"), 1e30):
+        for (la, ga), (lb, gb) in zip(base, run(val)):
+            assert la == lb and torch.equal(ga, gb)

@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/prof_final
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace of the bench command (eager launches: per-kernel durations; the timed bench line itself uses the hipGraph)
-rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-kernel-timing --no-graph > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-modes --no-parity --no-kernel-timing --no-graph > $OUT/kt.log 2>&1
 python $R/tools/rocpd_stats.py $(find /tmp/p_kt -name "*.db" | head -1) 13 > $OUT/kernel_stats.csv
 # 2. HBM traffic + SQ counters of the hot-path kernels, one counter set per pass
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -6,8 +6,8 @@ for r in csv.DictReader(open(sys.argv[1])):
     acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     m = {c: sum(v) / len(v) for c, v in d.items()}
-    name = k.split("(")[0][-48:]
-    line = "%-48s" % name
+    name = k.split("(")[0][-72:]
+    line = "%-72s" % name
     wc = m.get("SQ_WAVE_CYCLES", 0)
     for c in sorted(m):
         line += " %s=%.3g" % (c.replace("SQ_", ""), m[c])

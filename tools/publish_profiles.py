@@ -4,7 +4,7 @@ usage: python tools/publish_profiles.py [tag]   (tag defaults to r01_final)"""
 import csv, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_final")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 dst = lambda n: os.path.join(ROOT, "profiles", "%s_%s" % (tag, n))
 shutil.copy(os.path.join(src, "kernel_stats.csv"), dst("kernel_stats_rocprofv3.csv"))
 shutil.copy(os.path.join(src, "bench_line.json"), dst("bench_line.json"))
@@ -31,7 +31,7 @@ with open(dst("hot_path_kernels.txt"), "w") as f:
 with open(dst("pmc_hbm_traffic.txt"), "w") as f:
     f.write("# HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB units, mean of 3 launches;\n"
             "# FETCH_SIZE is doubled when quoted in DESIGN.md / bench.py, as MI355X_MICROARCH.md prescribes for gfx950)\n"
-            "# shape: original-fp B=64 n=64 (M=262144), bf16; command: rocprofv3 --pmc <counter> --kernel-trace -- python tools/run_kernels_once.py all\n")
+            "# shape: original-fp B=64 n=64 (M=262144), forward chain in the module-default f16s arithmetic; command: rocprofv3 --pmc <counter> --kernel-trace -- python tools/run_kernels_once.py all\n")
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         f.write(open(os.path.join(src, "pmc_%s.txt" % c)).read())
 with open(dst("pmc_sq_counters.txt"), "w") as f:

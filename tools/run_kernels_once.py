@@ -8,6 +8,7 @@ import torch
 import relationnetworks_clevr_amd as pkg
 H = pkg.rn_hip; H.load()
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
+mode = sys.argv[2] if len(sys.argv) > 2 else "f16s"        # forward arithmetic: "f16s" (the module default) or "bf16"
 B, n, k, Q, G = 64, 64, 26, 128, 256
 M = B * n * n; kt = 2 * k + Q
 x = torch.randn(B, n, k, device='cuda'); q = torch.randn(B, Q, device='cuda')
@@ -19,7 +20,10 @@ w0T = torch.empty(kt, G, device='cuda')
 H.pack_matrix_frag_many([(Ws[0], kt, 1, G, k, Wf[0], 1), (Ws[0], kt, 1, G, kt, w0T, 2)]
                         + [(Ws[l], G, 1, G, G, Wf[l], 0) for l in range(1, 4)]
                         + [(Ws[3 - s], 1, G, G, G, f, s == 0) for s, f in enumerate(Wtf)])
-Xp = torch.empty(B * n, 64, dtype=torch.bfloat16, device='cuda'); Vc = torch.empty(B * n, G, device='cuda')
+Xp = torch.empty(B * n, 64, dtype=torch.float16 if mode == "f16s" else torch.bfloat16, device='cuda'); Vc = torch.empty(B * n, G, device='cuda')
+Whi = list(torch.empty(4, 65536, dtype=torch.float16, device='cuda')); Wlo = list(torch.empty(4, 65536, dtype=torch.float16, device='cuda'))
+H.pack_matrix_frag_many([(Ws[l], Ws[l].shape[1], 1, G, k if l == 0 else G, Whi[l], 4 | int(l == 0)) for l in range(4)]
+                        + [(Ws[l], Ws[l].shape[1], 1, G, k if l == 0 else G, Wlo[l], 8 | int(l == 0)) for l in range(4)])
 Hs = list(torch.empty(3, M, G, dtype=torch.bfloat16, device='cuda')) + [None]
 masks = list(torch.empty(4, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device='cuda'))
 part = torch.empty(M // 32, G, device='cuda')
@@ -30,7 +34,9 @@ Rj = torch.empty(B * n, G, device='cuda'); Ri = torch.empty(B * n, G, device='cu
 dx = torch.empty(B, n, k, device='cuda'); dq = torch.empty(B, Q, device='cuda')
 for it in range(3):
     if which in ("all", "build"): H.pair_tables(x, q, w0T, bs[0], Xp, Vc, B, n, k, Q, G)
-    if which in ("all", "chain"): H.g_chain_fwd_rr_alg0(Xp, Vc, n, Wf, bs, Hs, masks, part, M, G)
+    if which in ("all", "chain"):
+        if mode == "f16s": H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, Whi, Wlo, bs, Hs, masks, part, M, G)
+        else: H.g_chain_fwd_rr_alg0(Xp, Vc, n, Wf, bs, Hs, masks, part, M, G)
     if which in ("all", "bwd"): H.g_chain_bwd_rr(dxg, masks, Wtf, dZs, M, n * n, G)
     if which in ("all", "wgrad"):
         H.g_linear_bwd_wgrad(dZs[1], G, Hs[1], G, dW, db, 0, M, G, G, G)

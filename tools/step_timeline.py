@@ -25,7 +25,7 @@ SKIP = ("load", "tile", "bytes", "ok", "supported", "available", "chunk", "debug
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--precision", default="auto")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--hw", type=int, default=128)
     args = ap.parse_args()
