@@ -345,11 +345,15 @@ int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const float* gamm
 int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* q, long ldq, const float* W0T, const float* b0,
                    void* Xp, int xp_dtype /* RN_BF16 | RN_F16 */, float* Vc, int B, int n, int k, int Q, int N, void* stream);
 /* ... and in the f16s arithmetic (fp16 object rows; Whi / Wlo as for rn_g_chain_fwd_rr_f16s, layer 0 = W0[:, 0:k] natural) */
+/* inject_layer = 0: the question is part of the tables (Q > 0 in rn_pair_tables).  inject_layer = 2 (the "IR" variants,
+ * model.py:131-142; tables built with Q = 0): layer 2's input is [H_1 | q[b]], i.e. W_2 [H_1 | q] + b_2 =
+ * W_2[:, 0:256] H_1 + Vq[b] with Vq (B, 256) fp32 = W_2[:, 256:] q[b] + b_2 prepared by the caller (one small rn_gemm_f32);
+ * Wf[2] / Whi[2], Wlo[2] hold W_2[:, 0:256] only, bias[2] is ignored.  Needs n*n % 256 == 0. */
 int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, const void* const* Whi, const void* const* Wlo,
-                                const float* const* bias, void* const* H, void* const* mask, float* xg_part, int M, int L, int G,
-                                void* stream);
+                                const float* const* bias, void* const* H, void* const* mask, float* xg_part, const float* Vq,
+                                int inject_layer, int M, int L, int G, void* stream);
 int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, const void* const* Wf, const float* const* bias, void* const* H,
-                           void* const* mask, float* xg_part, int M, int L, int G, void* stream);
+                           void* const* mask, float* xg_part, const float* Vq, int inject_layer, int M, int L, int G, void* stream);
 
 #ifdef __cplusplus
 }

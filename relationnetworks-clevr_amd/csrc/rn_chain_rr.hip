@@ -232,16 +232,18 @@ extern "C" int rn_pack_matrix_frag_many(const float* const* src, const long* sr,
 // stay in flight: the requests of the five stages in between plus whatever else those stages issue (stores,
 // next-tile row loads).  The models below give a LOWER bound of that number per site -- waiting for more than
 // necessary is always safe, waiting for less is a race.
-template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false>
+template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false, int INJ = 0>
 struct FwdVm {
   static constexpr int PF_PER = (NK0 + 7) / 8;                       // next-tile row loads per stage of the last layer
   static constexpr int VC_STAGE = (RR_L - 1) * 8 + 4;                // ALG0: the stage that requests the next tile's bias row
+  static constexpr int VQ_STAGE = (RR_L - 1) * 8 + 2;                // INJ: ... and the next tile's question row of layer INJ
   static constexpr int ops(int sidx) {                                // VMEM operations a stage issues (per wave)
     int k = RR_DPW;
     if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += 2;
     if ((sidx >> 3) == RR_L - 1)
       for (int c = 0; c < PF_PER; ++c) k += ((sidx & 7) * PF_PER + c < NK0) ? 1 : 0;
     if (ALG0 && sidx == VC_STAGE) k += 1;
+    if (INJ > 0 && sidx == VQ_STAGE) k += 1;
     return k;
   }
   static constexpr int tail() { return (STORE && ST3 ? 4 : 0) + (XG ? 8 : 0); }
@@ -269,12 +271,19 @@ struct BwdVm {
 //   question, same i) and comes in as the layer's BIAS row -- Vc[b*n + i][256], fp32, from rn_pair_tables; only the
 //   x_j part is left as an MFMA, K = 64 (P = the packed object rows Xp[b*n + j][64], a 0.5 MB table that lives in L2)
 //   instead of K = 192 on a 138 MB pair matrix that then never exists.
-template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false>
+// INJ > 0 -- the question injected at layer INJ (the reference's "IR" variants, model.py:131-142): the layer's input is
+//   [H_{INJ-1} | q[b]], so W_INJ [H | q] + b = W_INJ[:, 0:256] H + (W_INJ[:, 256:] q[b] + b): the bracket is a per-QUESTION
+//   constant -- Vq[b][256], fp32, one small product on the host side -- and takes the place of the layer's bias row in LDS
+//   for the tile (a 256-row tile lies inside one question: n*n % 256 == 0).  The row of the next tile is fetched during the
+//   last layer and written at the tile's tail, when no wave reads the old one any more.
+template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restrict__ P, int ldp, RRArgs a,
                                                            float* __restrict__ xg_part, int ntiles,
-                                                           const float* __restrict__ Vc = nullptr, int n_obj = 0) {
+                                                           const float* __restrict__ Vc = nullptr, int n_obj = 0,
+                                                           const float* __restrict__ Vq = nullptr, int rows_per_b = 1) {
   static_assert(NK0 % 4 == 0 && NK0 >= 4 && NK0 <= 16, "layer-0 reduction length");
-  typedef FwdVm<NK0, STORE, ST3, XG, ALG0> Vm;
+  static_assert(INJ >= 0 && INJ < RR_L - 1, "the injected layer is one of the swapped-operand layers");
+  typedef FwdVm<NK0, STORE, ST3, XG, ALG0, INJ> Vm;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
   k.init(lds);
@@ -302,6 +311,10 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
   float* const vc_s = reinterpret_cast<float*>(lds + RR_OFF_VC) + w * RR_G;
   auto vc_load = [&](long m0w_) -> f32x4 { return *reinterpret_cast<const f32x4*>(Vc + vc_row(m0w_) * RR_G + lane * 4); };
   f32x4 vcreg = {0.f, 0.f, 0.f, 0.f};
+  f32x4 vqreg = {0.f, 0.f, 0.f, 0.f};
+  auto vq_load = [&](int tile_) -> f32x4 {
+    return *reinterpret_cast<const f32x4*>(Vq + (long)(((long)tile_ * RR_TM) / rows_per_b) * RR_G + lane * 4);
+  };
 
   Frag actA[16], actB[16], ring[RR_RD];
   f32x16 acc[2];
@@ -319,7 +332,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
   if constexpr (ALG0) *reinterpret_cast<f32x4*>(vc_s + lane * 4) = vc_load((long)tile * RR_TM + RR_WR * w);
   if (t < RR_G) {
 #pragma unroll
-    for (int l = 0; l < RR_L; ++l) bias_s[l * RR_G + t] = a.bias[l][t];
+    for (int l = 0; l < RR_L; ++l)
+      bias_s[l * RR_G + t] = (INJ > 0 && l == INJ) ? Vq[(long)(((long)tile * RR_TM) / rows_per_b) * RR_G + t] : a.bias[l][t];
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
@@ -469,6 +483,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
           if (i < NK0) out[i] = load_row_frag(op_row(m0n), i);
         }
         if (ALG0 && sidx == Vm::VC_STAGE && c == 1) vcreg = vc_load(m0n);
+        if (INJ > 0 && sidx == Vm::VQ_STAGE && c == 1) vqreg = vq_load(tnext);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -506,6 +521,14 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
         }
       }
       if constexpr (ALG0) *reinterpret_cast<f32x4*>(vc_s + lane * 4) = vcreg;   // wave-private row: LDS is in order per wave
+      if constexpr (INJ > 0) {
+        // shared row: every wave is past its last read of the old one (barrier of stage (INJ+1, 0)); the write must have
+        // landed before the other waves read it 8 * INJ + ... barriers from now -- this wave drains its LDS queue here
+        if (w == 0) {
+          *reinterpret_cast<f32x4*>(bias_s + INJ * RR_G + lane * 4) = vqreg;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // trailing (unused) weight requests, scalar stores
@@ -536,16 +559,18 @@ __device__ __forceinline__ unsigned relu_pack_f16(float a, float b) {     // sat
   x = __builtin_elementwise_max(x, z);
   return __builtin_bit_cast(unsigned, x);
 }
-template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false>
+template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false, int INJ = 0>
 struct F16Vm {
   static constexpr int PF_PER = (NK0 + 7) / 8;
   static constexpr int VC_STAGE = (RR_L - 1) * 8 + 4;                // ALG0: the stage that requests the next tile's bias row
+  static constexpr int VQ_STAGE = (RR_L - 1) * 8 + 2;                // INJ: ... and the next tile's question row of layer INJ
   static constexpr int ops(int sidx) {
     int k = F_DPW;
     if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += 2;
     if ((sidx >> 3) == RR_L - 1)
       for (int c = 0; c < PF_PER; ++c) k += ((sidx & 7) * PF_PER + c < NK0) ? 1 : 0;
     if (ALG0 && sidx == VC_STAGE) k += 1;
+    if (INJ > 0 && sidx == VQ_STAGE) k += 1;
     return k;
   }
   static constexpr int tail() { return (STORE && ST3 ? 4 : 0) + (XG ? 8 : 0); }
@@ -561,11 +586,13 @@ struct F16Vm {
 }  // namespace
 
 // ALG0: as in g_chain_rr_kernel -- P = the packed fp16 object rows (K = 64), layer-0 bias row = Vc[b*n + i].
-template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false>
+template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __restrict__ P, int ldp, RRArgsF a,
                                                                 float* __restrict__ xg_part, int ntiles,
-                                                                const float* __restrict__ Vc = nullptr, int n_obj = 0) {
-  typedef F16Vm<NK0, STORE, ST3, XG, ALG0> Vm;
+                                                                const float* __restrict__ Vc = nullptr, int n_obj = 0,
+                                                                const float* __restrict__ Vq = nullptr, int rows_per_b = 1) {
+  static_assert(INJ >= 0 && INJ < RR_L - 1, "the injected layer is one of the swapped-operand layers");
+  typedef F16Vm<NK0, STORE, ST3, XG, ALG0, INJ> Vm;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
   k.init(lds);
@@ -598,6 +625,10 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
   float* const vc_s = reinterpret_cast<float*>(lds + RR_OFF_VC) + w * RR_G;
   auto vc_load = [&](long m0w_) -> f32x4 { return *reinterpret_cast<const f32x4*>(Vc + vc_row(m0w_) * RR_G + lane * 4); };
   f32x4 vcreg = {0.f, 0.f, 0.f, 0.f};
+  f32x4 vqreg = {0.f, 0.f, 0.f, 0.f};
+  auto vq_load = [&](int tile_) -> f32x4 {
+    return *reinterpret_cast<const f32x4*>(Vq + (long)(((long)tile_ * RR_TM) / rows_per_b) * RR_G + lane * 4);
+  };
 
   Frag actA[16], actB[16], ring[F_RDK][2];
   f32x16 acc[2];
@@ -615,7 +646,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
   if constexpr (ALG0) *reinterpret_cast<f32x4*>(vc_s + lane * 4) = vc_load((long)tile * RR_TM + RR_WR * w);
   if (t < RR_G) {
 #pragma unroll
-    for (int l = 0; l < RR_L; ++l) bias_s[l * RR_G + t] = a.bias[l][t];
+    for (int l = 0; l < RR_L; ++l)
+      bias_s[l * RR_G + t] = (INJ > 0 && l == INJ) ? Vq[(long)(((long)tile * RR_TM) / rows_per_b) * RR_G + t] : a.bias[l][t];
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
@@ -756,6 +788,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
             if (i < NK0) out[i] = load_row_frag(op_row(m0n), i);
           }
           if (ALG0 && sidx == Vm::VC_STAGE && c == 1) vcreg = vc_load(m0n);
+          if (INJ > 0 && sidx == Vm::VQ_STAGE && c == 1) vqreg = vq_load(tnext);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -792,6 +825,12 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
         }
       }
       if constexpr (ALG0) *reinterpret_cast<f32x4*>(vc_s + lane * 4) = vcreg;
+      if constexpr (INJ > 0) {
+        if (w == 0) {
+          *reinterpret_cast<f32x4*>(bias_s + INJ * RR_G + lane * 4) = vqreg;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1041,9 +1080,18 @@ extern "C" int rn_g_chain_fwd_rr(const void* P, int ldp, const void* const* Wf, 
 }
 
 // The forward chain with the first layer factored through the pair structure (see g_chain_rr_kernel, ALG0).
+static int rr_check_inject(const char* who, const float* Vq, int inj, int n) {
+  RN_CHECK_ARG(inj == 0 || inj == 2, "%s: the question can be injected at layer 0 (tables) or 2 (got %d)", who, inj);
+  RN_CHECK_ARG(inj == 0 || (Vq && ((uintptr_t)Vq % 16 == 0)), "%s: injection at layer %d needs the 16-byte aligned question rows Vq", who, inj);
+  RN_CHECK_ARG(inj == 0 || ((long)n * n) % RR_TM == 0, "%s: injection at layer %d needs n*n %% %d == 0 (n=%d)", who, inj, RR_TM, n);
+  return 0;
+}
+
 extern "C" int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, const void* const* Wf, const float* const* bias,
-                                      void* const* H, void* const* mask, float* xg_part, int M, int L, int G, void* stream) {
+                                      void* const* H, void* const* mask, float* xg_part, const float* Vq, int inject_layer,
+                                      int M, int L, int G, void* stream) {
   RN_CHECK_ARG(Xp && Vc && Wf && bias && M > 0 && xg_part, "rn_g_chain_fwd_rr_alg0: bad pointer/size");
+  if (int rc = rr_check_inject("rn_g_chain_fwd_rr_alg0", Vq, inject_layer, n)) return rc;
   RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_fwd_rr_alg0: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
   RN_CHECK_ARG(n > 0 && n % RR_WR == 0 && M % ((long)n * n) == 0 && M % RR_TM == 0,
                "rn_g_chain_fwd_rr_alg0: needs n %% %d == 0 and M a multiple of n*n and of %d (n=%d M=%d)", RR_WR, RR_TM, n, M);
@@ -1067,8 +1115,14 @@ extern "C" int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, co
   const int ntiles = M / RR_TM;
   const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
   hipStream_t s = (hipStream_t)stream;
-  if (nh == 0) g_chain_rr_kernel<4, false, false, false, true, true><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n);
-  else g_chain_rr_kernel<4, true, false, true, true, true><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n);
+  const int rpb = n * n;
+  if (inject_layer == 2) {
+    if (nh == 0) g_chain_rr_kernel<4, false, false, false, true, true, 2><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
+    else g_chain_rr_kernel<4, true, false, true, true, true, 2><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
+  } else {
+    if (nh == 0) g_chain_rr_kernel<4, false, false, false, true, true><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n);
+    else g_chain_rr_kernel<4, true, false, true, true, true><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n);
+  }
   RN_LAUNCH_CHECK("rn_g_chain_fwd_rr_alg0");
   return 0;
 }
@@ -1123,9 +1177,10 @@ extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* cons
 
 // f16s arithmetic on the factored first layer (see g_chain_rr_kernel, ALG0): Xp16 = fp16 object rows (B*n, 64).
 extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, const void* const* Whi, const void* const* Wlo,
-                                           const float* const* bias, void* const* H, void* const* mask, float* xg_part, int M, int L,
-                                           int G, void* stream) {
+                                           const float* const* bias, void* const* H, void* const* mask, float* xg_part,
+                                           const float* Vq, int inject_layer, int M, int L, int G, void* stream) {
   RN_CHECK_ARG(Xp16 && Vc && Whi && Wlo && bias && M > 0 && xg_part, "rn_g_chain_fwd_rr_f16s_alg0: bad pointer/size");
+  if (int rc = rr_check_inject("rn_g_chain_fwd_rr_f16s_alg0", Vq, inject_layer, n)) return rc;
   RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_fwd_rr_f16s_alg0: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
   RN_CHECK_ARG(n > 0 && n % RR_WR == 0 && M % ((long)n * n) == 0 && M % RR_TM == 0,
                "rn_g_chain_fwd_rr_f16s_alg0: needs n %% %d == 0 and M a multiple of n*n and of %d (n=%d M=%d)", RR_WR, RR_TM, n, M);
@@ -1150,8 +1205,14 @@ extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, in
   const int ntiles = M / RR_TM;
   const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
   hipStream_t s = (hipStream_t)stream;
-  if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
-  else g_chain_rr_f16s_kernel<4, true, false, true, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
+  const int rpb = n * n;
+  if (inject_layer == 2) {
+    if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true, 2><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
+    else g_chain_rr_f16s_kernel<4, true, false, true, true, true, 2><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
+  } else {
+    if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
+    else g_chain_rr_f16s_kernel<4, true, false, true, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
+  }
   RN_LAUNCH_CHECK("rn_g_chain_fwd_rr_f16s_alg0");
   return 0;
 }

@@ -775,8 +775,9 @@ __global__ __launch_bounds__(256) void pair_tables_kernel(const float* __restric
 
 extern "C" int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* q, long ldq, const float* W0T,
                               const float* b0, void* Xp, int xp_dtype, float* Vc, int B, int n, int k, int Q, int N, void* stream) {
-  RN_CHECK_ARG(x && q && W0T && b0 && Xp && Vc && B > 0 && n > 0, "rn_pair_tables: bad pointer/size");
-  RN_CHECK_ARG(k > 0 && k <= 32 && Q > 0 && Q <= 1024 && N > 0, "rn_pair_tables: k=%d (<= 32), Q=%d (<= 1024), N=%d unsupported", k, Q, N);
+  RN_CHECK_ARG(x && W0T && b0 && Xp && Vc && B > 0 && n > 0, "rn_pair_tables: bad pointer/size");
+  RN_CHECK_ARG(k > 0 && k <= 32 && Q >= 0 && Q <= 1024 && (Q == 0 || q) && N > 0,
+               "rn_pair_tables: k=%d (<= 32), Q=%d (0 .. 1024; q required when Q > 0), N=%d unsupported", k, Q, N);
   RN_CHECK_ARG(xp_dtype == RN_BF16 || xp_dtype == RN_F16, "rn_pair_tables: object rows are bf16 or fp16 (dtype %d)", xp_dtype);
   if (xp_dtype == RN_F16) pair_tables_kernel<f16><<<dim3(cdiv(n, 16), B), 256, 0, (hipStream_t)stream>>>(x, sxb, sxn, sxk, q, ldq, W0T, b0, (f16*)Xp, Vc, n, k, Q, N);
   else pair_tables_kernel<bf16><<<dim3(cdiv(n, 16), B), 256, 0, (hipStream_t)stream>>>(x, sxb, sxn, sxk, q, ldq, W0T, b0, (bf16*)Xp, Vc, n, k, Q, N);

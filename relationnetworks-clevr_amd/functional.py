@@ -62,13 +62,14 @@ class PackedWeights:
         self.frag = []                             # fragment-major copies for the register-resident chains:
         self.fragT = []                            #   forward W_l, backward step s -> W_{L-1-s}^T
 
-    def get(self, plan: LayerPlan, g_w, code, split=False, bwd_images=True, rr_only=False, f_w=None, alg0_k=0):
+    def get(self, plan: LayerPlan, g_w, code, split=False, bwd_images=True, rr_only=False, f_w=None, alg0_k=0, inj=0):
         """rr_only: the call is known to run the register-resident chains in both directions -- only their
         fragment-major images are packed (the row-major copies feed the other kernels).  alg0_k > 0: the forward
         chain runs with the factored first layer (rn_g_chain_fwd_rr_alg0): the layer-0 image holds W0[:, 0:k] only and
-        W0^T is kept in fp32 for the table kernel (self.w0T)."""
-        key = (code, split, bwd_images, rr_only, alg0_k, tuple((w.data_ptr(), w._version) for w in list(g_w) + list(f_w or ())))
-        self._last = (plan, tuple(g_w), code, split, bwd_images, rr_only, tuple(f_w) if f_w is not None else None, alg0_k)
+        W0^T is kept in fp32 for the table kernel (self.w0T).  inj > 0: the chain runs with the question injected at layer
+        `inj` as a bias row (inj_chain_ok): that layer's image holds W[:, 0:256] (the H columns) only."""
+        key = (code, split, bwd_images, rr_only, alg0_k, inj, tuple((w.data_ptr(), w._version) for w in list(g_w) + list(f_w or ())))
+        self._last = (plan, tuple(g_w), code, split, bwd_images, rr_only, tuple(f_w) if f_w is not None else None, alg0_k, inj)
         if self._ahead == key:                              # packed by repack_ahead() earlier in this forward pass
             self._ahead = None
             return self.fwd, self.bwd
@@ -77,7 +78,7 @@ class PackedWeights:
         # new weights every step), so the cache is bypassed
         if key == self.key and not torch.cuda.is_current_stream_capturing():
             return self.fwd, self.bwd
-        return self._pack(key, plan, g_w, code, split, bwd_images, rr_only, f_w, alg0_k)
+        return self._pack(key, plan, g_w, code, split, bwd_images, rr_only, f_w, alg0_k, inj)
 
     def repack_ahead(self):
         """Repeat the previous get()'s pack NOW, on the caller's current stream -- RN.forward calls this on the question
@@ -86,20 +87,20 @@ class PackedWeights:
         launching anything; the caller's join orders it after this stream."""
         if self._last is None or os.environ.get("RN_NO_PACK_AHEAD", "0") == "1":
             return
-        plan, g_w, code, split, bwd_images, rr_only, f_w, alg0_k = self._last
+        plan, g_w, code, split, bwd_images, rr_only, f_w, alg0_k, inj = self._last
         if not torch.is_grad_enabled():
             bwd_images = False
-        key = (code, split, bwd_images, rr_only, alg0_k, tuple((w.data_ptr(), w._version) for w in list(g_w) + list(f_w or ())))
+        key = (code, split, bwd_images, rr_only, alg0_k, inj, tuple((w.data_ptr(), w._version) for w in list(g_w) + list(f_w or ())))
         if key != self.key or torch.cuda.is_current_stream_capturing():
-            self._pack(key, plan, g_w, code, split, bwd_images, rr_only, f_w, alg0_k)
+            self._pack(key, plan, g_w, code, split, bwd_images, rr_only, f_w, alg0_k, inj)
         self._ahead = key
 
-    def _pack(self, key, plan, g_w, code, split, bwd_images, rr_only, f_w, alg0_k):
+    def _pack(self, key, plan, g_w, code, split, bwd_images, rr_only, f_w, alg0_k, inj=0):
         dt = H.torch_dtype(code)
         dev = g_w[0].device
         self.fwd, self.bwd, self.hi, self.lo, self.frag, self.fragT = [], [], [], [], [], []
         self.frag_hi, self.frag_lo = [], []
-        rr = rr_chain_ok(plan, code)
+        rr = rr_chain_ok(plan, code) or inj > 0
         frag_jobs = []
         for l, w in enumerate(g_w):
             N, kt = w.shape
@@ -107,6 +108,8 @@ class PackedWeights:
             wc = w.detach()
             if not wc.is_contiguous():
                 wc = wc.contiguous()
+            # columns that enter the MFMA image: the factored first layer keeps W0[:, 0:k], an injected layer W[:, 0:G_prev]
+            kimg = alg0_k if (l == 0 and alg0_k) else (plan.widths[l - 1] if (inj and l == inj) else kt)
             if rr and rr_only:
                 self.fwd.append(None)
             else:
@@ -116,14 +119,13 @@ class PackedWeights:
             if rr and split:
                 wh = torch.empty(256 * 256, dtype=torch.float16, device=dev)
                 wl = torch.empty(256 * 256, dtype=torch.float16, device=dev)
-                kc = alg0_k if (l == 0 and alg0_k) else kt          # factored first layer: W0[:, 0:k] only
-                frag_jobs.append((wc, kt, 1, N, kc, wh, 4 | int(l == 0)))
-                frag_jobs.append((wc, kt, 1, N, kc, wl, 8 | int(l == 0)))
+                frag_jobs.append((wc, kt, 1, N, kimg, wh, 4 | int(l == 0)))
+                frag_jobs.append((wc, kt, 1, N, kimg, wl, 8 | int(l == 0)))
                 self.frag_hi.append(wh)
                 self.frag_lo.append(wl)
             elif rr:
                 wf = torch.empty(256 * 256, dtype=dt, device=dev)
-                frag_jobs.append((wc, kt, 1, N, alg0_k if (l == 0 and alg0_k) else kt, wf, l == 0))
+                frag_jobs.append((wc, kt, 1, N, kimg, wf, l == 0))
                 self.frag.append(wf)
             if split and not (rr and rr_only):
                 hi = torch.empty(N, plan.kpad[l], dtype=torch.float16, device=dev)
@@ -198,9 +200,20 @@ def fused_chain_ok(plan: LayerPlan, code, B, n):
             and all(kp == 256 for kp in plan.kpad[1:]) and (B * n * n) % H.g_chain_tile() == 0 and plan.L <= 8)
 
 
+def inj_chain_ok(plan: LayerPlan, code, n, k, M):
+    """The register-resident chains with the question injected at layer 2 (the reference's "IR" variants, config.json
+    ir-fp): the factored first layer without a question term + the per-question bias row W_2[:, 256:] q[b] + b_2 at layer 2
+    (rn_g_chain_fwd_rr*_alg0 with inject_layer = 2).  Four 256-wide layers, whole waves per (question, i), whole 256-row
+    tiles per question."""
+    if os.environ.get("RN_NO_RR_CHAIN", "0") == "1" or os.environ.get("RN_NO_RR_MASKS", "0") == "1" or os.environ.get("RN_NO_INJ_CHAIN", "0") == "1":
+        return False
+    return (code == H.RN_BF16 and plan.L == 4 and all(w == 256 for w in plan.widths) and plan.inject == 2 and k <= 32
+            and plan.ktrue[2] == 256 + plan.Q and n % 32 == 0 and (n * n) % H.g_chain_rr_tile() == 0 and M % H.g_chain_rr_tile() == 0)
+
+
 def f16s_ok(plan: LayerPlan, B, n):
     """Shapes the "f16s" arithmetic (fp16 activations x split fp16 weights) has a kernel for."""
-    return fused_chain_ok(plan, H.RN_BF16, B, n)
+    return fused_chain_ok(plan, H.RN_BF16, B, n) or inj_chain_ok(plan, H.RN_BF16, n, plan.k, B * n * n)
 
 
 def alg0_wgrad_ok(plan, k):
@@ -216,8 +229,25 @@ def alg0_forward_ok(plan, code, n, k, M):
             and os.environ.get("RN_NO_ALGEBRAIC_FWD0", "0") != "1")
 
 
+def _tables(x, q, plan, g_b, w0T, inj_w, xdt, B, n, k, Q, G):
+    """Tables of the factored first layer (+ the question rows of an injected later layer): -> (Xp, Vc, Vq | None, inject)."""
+    dev = x.device
+    Xp = torch.empty(B * n, 64, dtype=xdt, device=dev)
+    Vc = torch.empty(B * n, G, dtype=torch.float32, device=dev)
+    if inj_w is None:
+        H.pair_tables(x, q, w0T, g_b[0], Xp, Vc, B, n, k, Q, G)
+        return Xp, Vc, None, 0
+    inj = plan.inject
+    H.pair_tables(x, None, w0T, g_b[0], Xp, Vc, B, n, k, 0, G)
+    Gp = plan.widths[inj - 1]
+    Vq = torch.empty(B, G, dtype=torch.float32, device=dev)
+    # Vq[b, f] = b_inj[f] + sum_c q[b, c] W_inj[f, Gp + c]   (model.py:135-141: the question is the layer's trailing Q columns)
+    H.gemm_f32(q, Q, 1, inj_w, 1, inj_w.shape[1], Vq, G, B, G, Q, bias=g_b[inj], b_off=Gp)
+    return Xp, Vc, Vq, inj
+
+
 def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None, split=None, wfrag=None, stop_at=None,
-                    w0T=None):
+                    w0T=None, inj_w=None):
     """K1 + K2 chain (+ K3).  Returns (inputs, H_L, xg): the list of layer INPUT buffers
     [A_0 .. A_{L-1}], the last activation H_L and -- when the fused chain ran -- the pair sum xg
     (else None).  layer_hook(l, A_l, H_out) is called after every layer (hook-compat path; forces
@@ -232,22 +262,21 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
     if split is not None:
         # "f16s": fp16 pair matrix + split fp16 weights through the fused chain; the bf16 pair matrix is only
         # needed by the backward pass (layer-0 wgrad)
-        if layer_hook is not None or not fused_chain_ok(plan, code, B, n):
-            raise RuntimeError('precision "f16s" needs the fused chain (bf16-class storage, all g widths 256, question '
-                               'injected at layer 0, B*n*n a multiple of 128, no forward hooks); use "bf16" or "fp32" here')
+        if layer_hook is not None or not (fused_chain_ok(plan, code, B, n) or inj_w is not None):
+            raise RuntimeError('precision "f16s" needs a fused chain (bf16-class storage, all g widths 256, question injected at '
+                               'layer 0 with B*n*n a multiple of 128 -- or at layer 2 with n*n a multiple of 256 --, no forward '
+                               'hooks); use "bf16" or "fp32" here')
         G, L, T = plan.widths[-1], plan.L, H.g_chain_tile()
         if w0T is not None and wfrag is not None and len(wfrag) == 2 and len(wfrag[0]) == L:
             # factored first layer in the f16s arithmetic: fp16 object rows + fp32 bias rows, no pair matrix
             R = 32
-            Xp = torch.empty(B * n, 64, dtype=torch.float16, device=dev)
-            Vc = torch.empty(B * n, G, dtype=torch.float32, device=dev)
-            H.pair_tables(x, q, w0T, g_b[0], Xp, Vc, B, n, k, Q, G)
+            Xp, Vc, Vq, inj_l = _tables(x, q, plan, g_b, w0T, inj_w, torch.float16, B, n, k, Q, G)
             masks = Hs = None
             if keep_inputs:
                 Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L - 1)] + [None]
                 masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
             part = torch.empty(M // R, G, dtype=torch.float32, device=dev)
-            H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, wfrag[0], wfrag[1], g_b, Hs, masks, part, M, G)
+            H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, wfrag[0], wfrag[1], g_b, Hs, masks, part, M, G, Vq=Vq, inject=inj_l)
             xg = torch.empty(B, G, dtype=torch.float32, device=dev)
             H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // R, G)
             if Hs is None:
@@ -289,15 +318,13 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
     if w0T is not None and stop_at is None and layer_hook is None and wfrag is not None and len(wfrag) == plan.L:
         # factored first layer: two small tables instead of the pair matrix, K = 64 instead of 192 in layer 0
         G, L, R = plan.widths[-1], plan.L, 32
-        Xp = torch.empty(B * n, 64, dtype=dt, device=dev)
-        Vc = torch.empty(B * n, G, dtype=torch.float32, device=dev)
-        H.pair_tables(x, q, w0T, g_b[0], Xp, Vc, B, n, k, Q, G)
+        Xp, Vc, Vq, inj_l = _tables(x, q, plan, g_b, w0T, inj_w, dt, B, n, k, Q, G)
         masks = Hs = None
         if keep_inputs:
             Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L - 1)] + [None]
             masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
         part = torch.empty(M // R, G, dtype=torch.float32, device=dev)
-        H.g_chain_fwd_rr_alg0(Xp, Vc, n, wfrag, g_b, Hs, masks, part, M, G)
+        H.g_chain_fwd_rr_alg0(Xp, Vc, n, wfrag, g_b, Hs, masks, part, M, G, Vq=Vq, inject=inj_l)
         xg = torch.empty(B, G, dtype=torch.float32, device=dev)
         H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // R, G)
         if Hs is None:
@@ -419,13 +446,20 @@ class RelationalFunction(torch.autograd.Function):
         rr_only = (rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0 and os.environ.get("RN_NO_RR_MASKS", "0") != "1"
                    and ((n * n) % 32 == 0 or (need_grad and not f16s)))
         alg_fwd = rr_only and alg0_forward_ok(plan, code, n, k, M)
+        inj_fwd = inj_chain_ok(plan, code, n, k, M)        # question injected at layer 2: same chains, per-question bias row
+        if inj_fwd:
+            rr_only = alg_fwd = True
         wfwd, wbwd = packed.get(plan, g_w, code, split=f16s, bwd_images=need_grad, rr_only=rr_only, f_w=f_w,
-                                alg0_k=k if alg_fwd else 0)
+                                alg0_k=k if alg_fwd else 0, inj=plan.inject if inj_fwd else 0)
         gb = [b.detach().contiguous() for b in g_b]
+        inj_w = None
+        if inj_fwd:
+            inj_w = g_w[plan.inject].detach()
+            inj_w = inj_w if inj_w.is_contiguous() else inj_w.contiguous()
         inputs, HL, xg = g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad,
                                          split=(packed.hi, packed.lo) if f16s else None,
                                          wfrag=(packed.frag_hi, packed.frag_lo) if f16s else packed.frag,
-                                         w0T=packed.w0T if alg_fwd else None)
+                                         w0T=packed.w0T if alg_fwd else None, inj_w=inj_w)
         G = plan.widths[-1]
         if xg is None:
             xg = torch.empty(B, G, dtype=torch.float32, device=dev)
@@ -444,6 +478,7 @@ class RelationalFunction(torch.autograd.Function):
         ctx.label = label
         if need_grad:
             ctx.plan, ctx.code, ctx.dims = plan, code, (B, n, k, Q, M, G, F1, F2, A)
+            ctx.inj_path = inj_fwd
             ctx.inputs, ctx.HL, ctx.wbwd = inputs, HL, wbwd
             ctx.fragT = list(packed.fragT)
             ctx.g_w = [w.detach() for w in g_w]
@@ -516,11 +551,20 @@ class RelationalFunction(torch.autograd.Function):
         gW, gB = [None] * L, [None] * L
         dq = None
         dx = None
+        inj = bool(ctx.inj_path)        # the chains ran with the question injected at layer plan.inject > 0 as a bias row
 
         def _wgrad(l, dz, a_l):
             N_, kt_, kp_ = plan.widths[l], plan.ktrue[l], plan.kpad[l]
             gW[l] = torch.empty(N_, kt_, **f32)
             gB[l] = torch.empty(N_, **f32)
+            if inj and l == plan.inject:
+                # the layer's input is [H_{l-1} | q]: dW = [dZ^T H_{l-1} | Rq^T q].  The H part is the ordinary K = 256 product
+                # on the stored activation; the question part follows from the per-question sums Rq (_wgrad_question below)
+                gp = plan.widths[l - 1]
+                tmp = torch.empty(N_, gp, **f32)
+                H.g_linear_bwd_wgrad(dz, N_, a_l, gp, tmp, gB[l], code, M, N_, gp, gp)
+                gW[l][:, :gp].copy_(tmp)
+                return
             if dz is None:                                             # last layer on the masks
                 H.g_linear_bwd_wgrad_gated(gated_mask, dxg, n * n, a_l, kp_, gW[l], gB[l], M, N_, kp_)
             else:
@@ -536,11 +580,11 @@ class RelationalFunction(torch.autograd.Function):
         # reductions the input gradient needs anyway -- dW_0 = [Rj^T X | Ri^T X | Rq^T Q], db_0 = sum_b Rq -- three tiny
         # products on (B*n)-row matrices instead of a 235 MB pass over dZ_0 and P (and with fp32 x instead of P's
         # rounded copy).  RN_NO_ALGEBRAIC_WGRAD0=1 keeps the kernel.
-        alg0 = alg0_wgrad_ok(plan, k)
+        alg0 = alg0_wgrad_ok(plan, k) or (inj and k <= 32)
         # RN_WGRAD_LATE=1 / 2 starts the (HBM-bound) wgrad stream only after the pair reduction / after dx, dq: measured
         # slower (1.102 / 1.137 vs 1.092 ms; all wgrads serially at the very end of the backward pass: 1.165) -- the window after the backward chain runs at the HBM roofline (~4 TB/s over
         # wgrad + pair reduction, tools/step_timeline.py) wherever the wgrads are put, and later they slow the conv backward
-        wgrad_late = int(os.environ.get("RN_WGRAD_LATE", "0")) if alg0 else 0
+        wgrad_late = int(os.environ.get("RN_WGRAD_LATE", "0")) if (alg0 and not inj) else 0
         if overlap:
             main, side = torch.cuda.current_stream(), _side_stream(dev)
             keep = [list(dZs), list(inputs), gated_mask, dxg]      # keep operands alive until the join
@@ -570,7 +614,8 @@ class RelationalFunction(torch.autograd.Function):
             if not overlap and not (l == 0 and alg0):
                 _wgrad(l, dZ, A_l)
             wl = g_w[l] if g_w[l].is_contiguous() else g_w[l].contiguous()
-            fused_tail = l == 0 and plan.inject == 0 and k <= 32 and os.environ.get("RN_NO_FUSED_PAIR_TAIL", "0") != "1"
+            fused_tail = (l == 0 and (plan.inject == 0 or inj) and k <= 32
+                          and os.environ.get("RN_NO_FUSED_PAIR_TAIL", "0") != "1")
             if l == plan.inject:
                 Rq = torch.empty(B, N, **f32)
                 if l == 0:
@@ -581,16 +626,27 @@ class RelationalFunction(torch.autograd.Function):
                 dq = torch.empty(B, Q, **f32)
                 if not fused_tail:
                     H.gemm_f32(Rq, N, 1, wl, kt, 1, dq, Q, B, Q, N, b_off=kt - Q)   # Rq @ W[:, -Q:]
+                if inj and l > 0:
+                    def _wgrad_question(Rq_=Rq, l_=l, kt_=kt, N_=N):               # gW[l][:, G_prev:] = Rq^T q
+                        H.gemm_f32(Rq_, 1, N_, q, Q, 1, gW[l_], kt_, N_, Q, B, c_off=kt_ - Q)
+                    if overlap:
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            _wgrad_question()
+                        keep.append([Rq, q])
+                    else:
+                        _wgrad_question()
             elif l == 0:
                 Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32)
-                H.pair_reduce_bwd(dZ, N, Rj, Ri, None, code, B, n, N)
+                Rq = torch.empty(B, N, **f32) if alg0 else None                   # (all-pairs sums: the layer's bias gradient)
+                H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N)
             if l == 0 and overlap and wgrad_late == 1:
                 _launch_wgrads()
             if l == 0 and alg0:
                 def _wgrad0():
                     gW[0] = torch.empty(N, kt, **f32)
                     gB[0] = torch.empty(N, **f32)
-                    H.wgrad0_from_reductions(Rj, Ri, Rq, x, q, gW[0], gB[0])
+                    H.wgrad0_from_reductions(Rj, Ri, Rq, x, q if plan.inject == 0 else None, gW[0], gB[0])
                 if overlap:                                        # off the critical path: onto the wgrad stream
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
@@ -603,7 +659,10 @@ class RelationalFunction(torch.autograd.Function):
                     _wgrad0()
             if l == 0 and fused_tail:
                 dx = torch.empty(B, n, k, **f32)
-                H.pair_dx_dq(Rj, Ri, Rq, wl, dx, dq, B, n, k, Q, N)                        # dx and dq in one launch
+                if plan.inject == 0:
+                    H.pair_dx_dq(Rj, Ri, Rq, wl, dx, dq, B, n, k, Q, N)                    # dx and dq in one launch
+                else:
+                    H.pair_dx_dq(Rj, Ri, None, wl, dx, None, B, n, k, 0, N)                # (dq came from the injected layer)
                 if overlap and wgrad_late == 2:
                     _launch_wgrads()
             elif l == 0:

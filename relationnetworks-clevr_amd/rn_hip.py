@@ -36,9 +36,9 @@ SIGNATURES = {
     "rn_g_chain_rr_mask_bytes": (_Z, [_I]),
     "rn_g_chain_fwd_rr": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_f16s": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
-    "rn_g_chain_fwd_rr_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "rn_g_chain_fwd_rr_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
-    "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_g_linear_bwd_wgrad_gated": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pack_matrix_frag": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
@@ -281,24 +281,25 @@ def pair_tables(x, q, W0T, b0, Xp, Vc, B, n, k, Q, N):
     _dev(x, "x")
     sx = x.stride()
     xdt = RN_F16 if Xp.dtype == torch.float16 else RN_BF16
-    _check(load().rn_pair_tables(x.data_ptr(), sx[0], sx[1], sx[2], q.data_ptr(), q.stride(0), W0T.data_ptr(), b0.data_ptr(),
-                                 Xp.data_ptr(), xdt, Vc.data_ptr(), B, n, k, Q, N, _stream()), "rn_pair_tables")
+    _check(load().rn_pair_tables(x.data_ptr(), sx[0], sx[1], sx[2], _ptr(q), q.stride(0) if q is not None else 0, W0T.data_ptr(),
+                                 b0.data_ptr(), Xp.data_ptr(), xdt, Vc.data_ptr(), B, n, k, Q, N, _stream()), "rn_pair_tables")
 
 
 @_timed("g_fwd")
-def g_chain_fwd_rr_alg0(Xp, Vc, n, Wfs, biases, Hs, masks, xg_part, M, G):
-    """Register-resident forward chain with the first layer factored through the pair structure (no pair matrix)."""
+def g_chain_fwd_rr_alg0(Xp, Vc, n, Wfs, biases, Hs, masks, xg_part, M, G, Vq=None, inject=0):
+    """Register-resident forward chain with the first layer factored through the pair structure (no pair matrix).
+    inject = 2 + Vq (B, 256) fp32: the question enters layer 2 as a per-question bias row."""
     L = len(Wfs)
     wp = (C.c_void_p * L)(*[w.data_ptr() for w in Wfs])
     bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
     hp = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
-    _check(load().rn_g_chain_fwd_rr_alg0(Xp.data_ptr(), Vc.data_ptr(), n, wp, bp, hp, mp, xg_part.data_ptr(), M, L, G, _stream()),
-           "rn_g_chain_fwd_rr_alg0")
+    _check(load().rn_g_chain_fwd_rr_alg0(Xp.data_ptr(), Vc.data_ptr(), n, wp, bp, hp, mp, xg_part.data_ptr(), _ptr(Vq), inject, M, L, G,
+                                         _stream()), "rn_g_chain_fwd_rr_alg0")
 
 
 @_timed("g_fwd")
-def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlos, biases, Hs, masks, xg_part, M, G):
+def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlos, biases, Hs, masks, xg_part, M, G, Vq=None, inject=0):
     """f16s forward chain with the factored first layer (fp16 object rows, no pair matrix)."""
     L = len(Whis)
     hp = (C.c_void_p * L)(*[w.data_ptr() for w in Whis])
@@ -306,8 +307,8 @@ def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlos, biases, Hs, masks, xg_part
     bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
     op = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
-    _check(load().rn_g_chain_fwd_rr_f16s_alg0(Xp16.data_ptr(), Vc.data_ptr(), n, hp, lp, bp, op, mp, xg_part.data_ptr(), M, L, G, _stream()),
-           "rn_g_chain_fwd_rr_f16s_alg0")
+    _check(load().rn_g_chain_fwd_rr_f16s_alg0(Xp16.data_ptr(), Vc.data_ptr(), n, hp, lp, bp, op, mp, xg_part.data_ptr(), _ptr(Vq), inject,
+                                              M, L, G, _stream()), "rn_g_chain_fwd_rr_f16s_alg0")
 
 
 @_timed("g_fwd")
@@ -422,13 +423,13 @@ def pair_dx_dq(Rj, Ri, Rq, W0, dx, dq, B, n, k, Q, N):
 @_timed("g_wgrad")
 def wgrad0_from_reductions(Rj, Ri, Rq, x, q, dW0, db0):
     B, n, k = x.shape
-    N, Q = Rj.shape[1], q.shape[1]
+    N, Q = Rj.shape[1], (q.shape[1] if q is not None else 0)      # q None: no question columns in layer 0 (Rq still gives db0)
     lib = load()
     ws = torch.empty(max(lib.rn_wgrad0_ws_bytes(B, n, N), 16), dtype=torch.uint8, device=Rj.device)
     sx = x.stride()
-    _check(lib.rn_wgrad0_from_reductions(Rj.data_ptr(), Ri.data_ptr(), Rq.data_ptr(), x.data_ptr(), sx[0], sx[1], sx[2], q.data_ptr(),
-                                         q.stride(0), dW0.data_ptr(), db0.data_ptr(), ws.data_ptr(), B, n, k, Q, N, _stream()),
-           "rn_wgrad0_from_reductions")
+    _check(lib.rn_wgrad0_from_reductions(Rj.data_ptr(), Ri.data_ptr(), _ptr(Rq), x.data_ptr(), sx[0], sx[1], sx[2], _ptr(q),
+                                         q.stride(0) if q is not None else 0, dW0.data_ptr(), db0.data_ptr(), ws.data_ptr(), B, n, k, Q, N,
+                                         _stream()), "rn_wgrad0_from_reductions")
 
 
 def gemm_f32(A, sam, sak, Bm, sbk, sbn, Cm, ldc, M, N, K, bias=None, mul=None, ldmul=0, gate=None, ldgate=0, flags=0,

@@ -112,7 +112,7 @@ def test_relational_layer_bf16_parity(pkg, tag):
     assert e_dx <= bound and e_dq <= bound and e_b <= bound, (e_dx, e_dq, e_b, bound)
 
 
-@pytest.mark.parametrize("tag", ["G-fp-small", "G-fp64", "G-drop"])
+@pytest.mark.parametrize("tag", ["G-fp-small", "G-fp64", "G-drop", "G-ir-small", "G-ir64"])
 def test_relational_layer_f16s_parity(pkg, tag):
     """precision="f16s" (fp16 activations x split fp16 weights, bf16 backward): the FAST mode that meets
     the north-star bar -- log-probs <= 1e-3 max-norm relative (measured 7e-5..2.5e-4); gradients are
@@ -129,7 +129,7 @@ def test_relational_layer_f16s_parity(pkg, tag):
     assert e_dx <= 1.2e-2 and e_dq <= 1.2e-2 and e_b <= 1.2e-2, (e_dx, e_dq, e_b)
 
 
-@pytest.mark.parametrize("tag", ["G-fp64", "G-fp-small", "G-drop"])
+@pytest.mark.parametrize("tag", ["G-fp64", "G-fp-small", "G-drop", "G-ir64", "G-ir-small"])
 def test_headline_mode_is_the_module_default_and_meets_the_bar(pkg, tag):
     """precision="auto" -- what a user who touches nothing gets, and what bench.py reports as `value` -- resolves to
     the parity-clean mode on the headline shape family: log-probs within 2e-4 of the reference (bar: 1e-3), same answers."""
@@ -144,7 +144,7 @@ def test_headline_mode_is_the_module_default_and_meets_the_bar(pkg, tag):
 
 
 def test_f16s_refuses_unsupported_shapes(pkg):
-    g = gold.load("G-ir-small")
+    g = gold.load("G-irsd4")                      # 512-wide g layers: no fused chain
     with pytest.raises(RuntimeError, match="f16s"):
         run_rl(pkg, g, "f16s")
 
@@ -164,8 +164,6 @@ def build_full(pkg, g, precision):
 @pytest.mark.parametrize("tag", ["G-e2e", "G-e2e-ir"])
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("bf16", 3e-3), ("f16s", 1e-4)])
 def test_full_model_e2e(pkg, tag, precision, tol):
-    if precision == "f16s" and tag.endswith("-ir"):
-        pytest.skip("f16s covers question injection at layer 0 only")
     g = gold.load(tag)
     m, meta = build_full(pkg, g, precision)
     shapes = {k: tuple(v) for k, v in json.loads(str(g["state_names"])).items()}
@@ -186,7 +184,8 @@ def test_full_model_e2e(pkg, tag, precision, tol):
 
 @pytest.mark.parametrize("tag,precision,tol", [("pretrained_original_fp", "fp32", 2e-6), ("pretrained_ir_fp", "fp32", 2e-6),
                                                ("pretrained_original_fp", "bf16", 2e-2), ("pretrained_ir_fp", "bf16", 2e-2),
-                                               ("pretrained_original_fp", "f16s", 2e-4), ("pretrained_original_fp", "auto", 2e-4)])
+                                               ("pretrained_original_fp", "f16s", 2e-4), ("pretrained_original_fp", "auto", 2e-4),
+                                               ("pretrained_ir_fp", "f16s", 2e-4), ("pretrained_ir_fp", "auto", 2e-4)])
 def test_released_checkpoints_load_and_match(pkg, tag, precision, tol):
     """README.md:86-95 checkpoints (as arrays): strict key match + log-probs."""
     g = gold.load(tag)
