@@ -375,11 +375,13 @@ def main():
             fl = {"g_fwd": fwd, "g_dgrad": fwd * (1.0 - g_flops_fwd(M, dict(hyp, g_layers=hyp["g_layers"][:1]), k) / fwd), "g_wgrad": fwd}
             kern = {kk: {"algorithmic_flops": fl[kk], "ms": per[kk], "achieved_tflops": fl[kk] / (per[kk] * 1e-3) / 1e12,
                          "frac": fl[kk] / (per[kk] * 1e-3) / 1e12 / peak, "ms_in_step": per_step.get(kk)} for kk in per}
-            alg0 = (prec in ("bf16", "f16s") and hyp["question_injection_position"] == 0 and hyp["g_layers"] == [256] * 4
-                    and n % 32 == 0 and M % 256 == 0 and k <= 32)
-            # executed flops: the factored first layer runs K = 64 instead of 2k+Q on chip; the split-weight mode runs every
-            # product twice (hi + lo).  The algorithmic count stays the reference formulation's (model.py:130-152).
-            executed = fwd - 2.0 * M * hyp["g_layers"][0] * (2 * k + hyp["lstm_hidden"] - 64) if alg0 else float(fwd)
+            inj_l = hyp["question_injection_position"]
+            alg0 = (prec in ("bf16", "f16s") and hyp["g_layers"] == [256] * 4 and n % 32 == 0 and M % 256 == 0 and k <= 32
+                    and (inj_l == 0 or (inj_l == 2 and (n * n) % 256 == 0)))
+            # executed flops: the factored first layer runs K = 64 on chip and the question (wherever it is injected) enters as
+            # a bias row, so every layer is a K = 64 / 256 product; the split-weight mode runs every product twice (hi + lo).
+            # The algorithmic count stays the reference formulation's (model.py:130-152).
+            executed = 2.0 * M * 256 * (64 + 3 * 256) if alg0 else float(fwd)
             if prec == "f16s":
                 executed *= 2.0
             kname = {"bf16": "g_chain_rr_kernel", "f16s": "g_chain_rr_f16s_kernel"}.get(prec) if alg0 else None
@@ -414,6 +416,7 @@ def main():
                 if alg0:                                   # rn_pair_tables instead of the pair matrix: object rows + bias rows
                     nbytes = B * n * (64 * 2 + hyp["g_layers"][0] * 4) + B * n * k * 4 + B * Q * 4 + (2 * k + Q) * hyp["g_layers"][0] * 4
                     key = "pair_tables"
+                    pb = (pb[0], pb[1])
                 gbs = nbytes / (pb[1] / pb[0] * 1e-3) / 1e9
                 out[key] = {"bound": "hbm (latency-bound at this size)", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": gbs / PEAK_HBM_GBS, "bytes_per_launch": nbytes, "us_per_launch": 1e3 * pb[1] / pb[0]}

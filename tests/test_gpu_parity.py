@@ -33,7 +33,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 RL_TAGS = ["G-sd4", "G-irsd4", "G-fp-small", "G-ir-small", "G-fp64", "G-ir64", "G-fp196", "G-drop"]
 # relative-L2 gradient bounds of the bf16 mode, ~2x the measured value per fixture (dx, dq, bias grads)
 BF16_GRAD_L2 = {"G-drop": 3e-2, "G-fp-small": 3e-2, "G-fp196": 3e-2, "G-fp64": 8e-2, "G-sd4": 8e-2, "G-irsd4": 0.12,
-                "G-ir64": 0.14, "G-ir-small": 0.3}
+                "G-ir64": 8e-2, "G-ir-small": 3e-2}
 
 
 def report(tag, **kw):
@@ -357,7 +357,7 @@ def test_stress_config_real_dispatch(pkg, precision):
     agree = float((lp.argmax(1) == g["log_probs"].argmax(1)).mean())
     report("G-fp196-b32", precision=precision, resolved=rl.resolved_precision(32, 196, 26), log_probs=e_lp, loss=abs(loss - float(g["loss"])) / float(g["loss"]),
            dq_l2=e_dq, dx_sample_l2=e_dxs, dx_norm=e_dxn, bias_l2=e_b, wnorm=e_wn, argmax_agree=agree)
-    lp_tol, g_tol = {"fp32": (1e-5, 1e-3), "f16s": (2e-4, 2e-2), "auto": (2e-4, 2e-2), "bf16": (5e-3, 0.1)}[precision]
+    lp_tol, g_tol = {"fp32": (1e-5, 1e-3), "f16s": (2e-4, 1.2e-2), "auto": (2e-4, 1.2e-2), "bf16": (3e-3, 6e-2)}[precision]
     assert np.isfinite(lp).all() and e_lp <= lp_tol
     assert abs(loss - float(g["loss"])) <= max(lp_tol, 1e-6) * 10 * abs(float(g["loss"]))
     assert e_dq <= g_tol and e_dxs <= g_tol and e_dxn <= g_tol and e_b <= g_tol and e_wn <= g_tol

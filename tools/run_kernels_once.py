@@ -34,10 +34,10 @@ Rj = torch.empty(B * n, G, device='cuda'); Ri = torch.empty(B * n, G, device='cu
 dx = torch.empty(B, n, k, device='cuda'); dq = torch.empty(B, Q, device='cuda')
 for it in range(3):
     if which in ("all", "build"): H.pair_tables(x, q, w0T, bs[0], Xp, Vc, B, n, k, Q, G)
-    if which in ("all", "chain"):
+    if which in ("all", "chain", "chainbwd"):
         if mode == "f16s": H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, Whi, Wlo, bs, Hs, masks, part, M, G)
         else: H.g_chain_fwd_rr_alg0(Xp, Vc, n, Wf, bs, Hs, masks, part, M, G)
-    if which in ("all", "bwd"): H.g_chain_bwd_rr(dxg, masks, Wtf, dZs, M, n * n, G)
+    if which in ("all", "bwd", "chainbwd"): H.g_chain_bwd_rr(dxg, masks, Wtf, dZs, M, n * n, G)
     if which in ("all", "wgrad"):
         H.g_linear_bwd_wgrad(dZs[1], G, Hs[1], G, dW, db, 0, M, G, G, G)
         H.g_linear_bwd_wgrad_gated(masks[3], dxg, n * n, Hs[2], G, dW, db, M, G, G)
