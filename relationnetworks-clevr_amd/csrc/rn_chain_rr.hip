@@ -586,7 +586,11 @@ struct F16Vm {
 }  // namespace
 
 // ALG0: as in g_chain_rr_kernel -- P = the packed fp16 object rows (K = 64), layer-0 bias row = Vc[b*n + i].
-template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0>
+// LO3 = false: the LAST layer runs on the hi halves only (one pass).  Its weight-rounding error is the one contribution the
+// later layers cannot amplify, and measured on the released checkpoints it is immaterial for the question-at-layer-0
+// models: worst log-prob error over 24 questions 1.5e-4 with it off vs 1.2e-4 with it on (tools/dbg/emulate_split2.py;
+// the bar is 1e-3) -- while the layer-2-injected ("IR") models go from 5e-5 to 4e-4 and keep the second pass.
+template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0, bool LO3 = true>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __restrict__ P, int ldp, RRArgsF a,
                                                                 float* __restrict__ xg_part, int ntiles,
                                                                 const float* __restrict__ Vc = nullptr, int n_obj = 0,
@@ -723,7 +727,10 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
     auto stage = [&](auto lc, auto obc, Frag (&in)[16], Frag (&out)[16]) {
       constexpr int l = decltype(lc)::value, ob = decltype(obc)::value;
       constexpr int NK = (l == 0) ? NK0 : 16;
-      constexpr int CPG = 2 * NK / 4;                                  // MFMA gaps per epilogue group (8 / 6)
+      constexpr int NP = (l == RR_L - 1 && !LO3) ? 1 : 2;              // passes of this stage: hi (+ lo)
+      constexpr int nl = (l * 8 + ob + 1 == 8 * RR_L) ? 0 : (l * 8 + ob + 1) >> 3;   // layer of the next stage
+      constexpr int NPn = (nl == RR_L - 1 && !LO3) ? 1 : 2;
+      constexpr int CPG = NP * NK / 4;                                 // MFMA gaps per epilogue group (8 / 6 / 4)
       constexpr int sidx = l * 8 + ob;
       constexpr bool has_prev = sidx > 0;
       constexpr int pl = ob ? l : l - 1, pob = ob ? ob - 1 : 7;
@@ -751,8 +758,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
 #pragma unroll
       for (int ks = 0; ks < NK; ++ks) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const int c = 2 * ks + p;
+        for (int p = 0; p < NP; ++p) {
+          const int c = NP * ks + p;
           const f16x8 fw = __builtin_bit_cast(f16x8, ring[ks % F_RDK][p]), fx = __builtin_bit_cast(f16x8, in[ks]);
           const f16x8 fa = (l == RR_L - 1) ? fx : fw, fb = (l == RR_L - 1) ? fw : fx;
           if (c == 0 && l < RR_L - 1) {
@@ -766,7 +773,9 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
           {
             const int f = ks + F_RDK;
             if (f < NK) ring[ks % F_RDK][p] = rd(slot, f, p);
-            else ring[ks % F_RDK][p] = rd(nslot, f - NK, p);
+            else if (p < NPn) ring[ks % F_RDK][p] = rd(nslot, f - NK, p);
+            // a one-pass stage in front of a two-pass one (the next tile's first layer): its lo read-ahead rides here
+            if (NP == 1 && NPn == 2 && f >= NK) ring[ks % F_RDK][1] = rd(nslot, f - NK, 1);
           }
           if ((c & 1) && (c >> 1) < F_DPW) dma_piece(dl, dob, dslot, c >> 1);
           if (has_prev) {
@@ -780,7 +789,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
               epi_group(pl, pob, j, 2 * ph + 1, dst, pk);
             }
           }
-          constexpr int CO2 = 2 * NK > 8 ? 8 : 2 * NK - 1;
+          constexpr int CO2 = NP * NK > 8 ? 8 : NP * NK - 1;
           if (has_co && c == 4) co_store(cl, cob, 0);
           if (has_co && c == CO2) co_store(cl, cob, 1);
           if (l == RR_L - 1 && (c & 1) == 0 && (c >> 1) < Vm::PF_PER) {
@@ -1210,8 +1219,14 @@ extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, in
     if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true, 2><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
     else g_chain_rr_f16s_kernel<4, true, false, true, true, true, 2><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
   } else {
-    if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
-    else g_chain_rr_f16s_kernel<4, true, false, true, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
+    const char* l3 = getenv("RN_F16S_LO3");                            // diagnostics: "1" keeps the second pass on the last layer
+    if (l3 && l3[0] == '1') {
+      if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
+      else g_chain_rr_f16s_kernel<4, true, false, true, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
+    } else {
+      if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true, 0, false><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
+      else g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, false><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
+    }
   }
   RN_LAUNCH_CHECK("rn_g_chain_fwd_rr_f16s_alg0");
   return 0;

@@ -8,6 +8,8 @@
 // All stores are 16-byte, fully coalesced; no MFMA here (K1 is HBM-write bound).
 #include <stdarg.h>
 
+#include <stdlib.h>
+
 #include "rn_common.h"
 
 // ---------------------------------------------------------------- error state
@@ -65,13 +67,32 @@ __global__ __launch_bounds__(256) void pair_build_kernel(const float* __restrict
       }
       __syncthreads();
     }
-    Chunk16<T>* dst = reinterpret_cast<Chunk16<T>*>(P + ((long)(b * n + i) * n) * ld);
-    const int total = n * cpr;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+    u32x4_* dst = reinterpret_cast<u32x4_*>(P + ((long)(b * n + i) * n) * ld);
     const int hc = PW / CH;                          // head chunks per row
-    for (int g = t; g < total; g += 256) {
-      const int j = g / cpr, c = g - j * cpr;
-      const T* src = (c < hc) ? (pre + j * PW + c * CH) : (suf + c * CH);
-      dst[g] = *reinterpret_cast<const Chunk16<T>*>(src);
+    // A thread keeps ONE chunk column c for the whole (b, i) span: the j-independent chunks (c >= hc: x_i | q | 0, all but
+    // the first few of a row) are then a register constant -- no LDS read, no index arithmetic per store -- and only the
+    // head chunks are read from LDS per row.  rpp rows per pass, consecutive lanes -> consecutive 16 B of consecutive rows
+    // (one contiguous rpp * ld * sizeof(T) byte burst per pass).  Non-temporal: the matrix is written once and read by
+    // another kernel; in L2 it would only evict what that kernel needs.
+    const int rpp = 256 / cpr;                       // rows per pass (threads beyond rpp * cpr idle in the copy)
+    if (rpp > 0) {
+      const int jr = t / cpr, c = t - jr * cpr;
+      if (jr < rpp) {
+        const bool head = c < hc;
+        const u32x4_ sv = *reinterpret_cast<const u32x4_*>(suf + c * CH);
+        for (int j = jr; j < n; j += rpp) {
+          const u32x4_ v = head ? *reinterpret_cast<const u32x4_*>(pre + j * PW + c * CH) : sv;
+          __builtin_nontemporal_store(v, dst + (long)j * cpr + c);
+        }
+      }
+    } else {                                         // rows wider than 256 chunks: the generic walk
+      const int total = n * cpr;
+      for (int g = t; g < total; g += 256) {
+        const int j = g / cpr, c = g - j * cpr;
+        const T* src = (c < hc) ? (pre + j * PW + c * CH) : (suf + c * CH);
+        dst[g] = *reinterpret_cast<const u32x4_*>(src);
+      }
     }
   }
 }
@@ -85,6 +106,7 @@ extern "C" int rn_pair_build_fwd(const float* x, long sxb, long sxn, long sxk, c
   RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32 || dtype == RN_F16, "rn_pair_build_fwd: bad dtype %d", dtype);
   int IB = (int)((long)B * n / 2048);
   IB = IB < 1 ? 1 : (IB > 8 ? 8 : IB);
+  if (const char* e = getenv("RN_K1_IB")) IB = atoi(e) > 0 ? atoi(e) : IB;        // diagnostics
   dim3 grid(cdiv(n, IB), B);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == RN_BF16 || dtype == RN_F16) {
@@ -505,6 +527,16 @@ __global__ __launch_bounds__(256) void wgrad0_part_kernel(const float* __restric
   const float* R = (pt ? Ri : Rj) + (long)r0 * N + f;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   int r = 0;
+  // the loop is a chain of L2 round trips: 32 independent loads in flight per trip (the sums stay in row order)
+  for (; r + 32 <= nr; r += 32) {
+    float v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) v[u] = R[(long)(r + u) * N];
+#pragma unroll
+    for (int u = 0; u < 32; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaf(v[u], xs[r + u][cg + 8 * e], acc[e]);
+  }
   for (; r + 8 <= nr; r += 8) {
     float v[8];
 #pragma unroll
@@ -529,22 +561,51 @@ __global__ __launch_bounds__(256) void wgrad0_part_kernel(const float* __restric
 __global__ __launch_bounds__(256) void wgrad0_finish_kernel(const float* __restrict__ part, int nks, const float* __restrict__ Rq,
                                                             const float* __restrict__ q, long sqb, float* __restrict__ dW0,
                                                             float* __restrict__ db0, int B, int k, int Q, int N, int kt) {
+  // Rq[:, f] is what every question-column thread (and the bias thread) of this block needs: staged once in LDS; the
+  // per-thread loops then issue 16 independent loads per L2 round trip instead of one (all sums keep their order)
+  __shared__ float rq_s[1024];
   const int f = blockIdx.x;
-  for (int c = threadIdx.x; c <= kt; c += 256) {
-    float s = 0.f;
-    if (c == kt) {
-      if (Rq)
-        for (int b = 0; b < B; ++b) s += Rq[(long)b * N + f];
-      if (db0) db0[f] = s;
-    } else if (c < 2 * k) {
-      const int pt = c / k, cc = c - pt * k;
-      for (int z = 0; z < nks; ++z) s += part[(((long)z * 2 + pt) * N + f) * W0_CMAX + cc];
-      dW0[(long)f * kt + c] = s;
-    } else {
-      const int qc = c - 2 * k;
-      for (int b = 0; b < B; ++b) s = fmaf(Rq[(long)b * N + f], q[b * sqb + qc], s);
-      dW0[(long)f * kt + c] = s;
+  for (int b0 = 0; b0 < (Rq ? B : 0); b0 += 1024) {
+    const int nb = B - b0 < 1024 ? B - b0 : 1024;
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += 256) rq_s[b] = Rq[(long)(b0 + b) * N + f];
+    __syncthreads();
+    for (int c = 2 * k + threadIdx.x; c <= kt; c += 256) {
+      float s = (b0 == 0) ? 0.f : (c == kt ? db0[f] : dW0[(long)f * kt + c]);
+      if (c == kt) {
+        for (int b = 0; b < nb; ++b) s += rq_s[b];
+        if (db0) db0[f] = s;
+      } else {
+        const float* qp = q + (long)b0 * sqb + (c - 2 * k);
+        int b = 0;
+        for (; b + 16 <= nb; b += 16) {
+          float v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = qp[(long)(b + u) * sqb];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) s = fmaf(rq_s[b + u], v[u], s);
+        }
+        for (; b < nb; ++b) s = fmaf(rq_s[b], qp[(long)b * sqb], s);
+        dW0[(long)f * kt + c] = s;
+      }
     }
+  }
+  if (!Rq && threadIdx.x == 0 && db0) db0[f] = 0.f;
+  for (int c = threadIdx.x; c < 2 * k; c += 256) {
+    const int pt = c / k, cc = c - pt * k;
+    const float* pp = part + ((long)pt * N + f) * W0_CMAX + cc;
+    const long zs = (long)2 * N * W0_CMAX;
+    float s = 0.f;
+    int z = 0;
+    for (; z + 8 <= nks; z += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pp[(z + u) * zs];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < nks; ++z) s += pp[z * zs];
+    dW0[(long)f * kt + c] = s;
   }
 }
 
