@@ -387,7 +387,7 @@ def main():
             kname = {"bf16": "g_chain_rr_kernel", "f16s": "g_chain_rr_f16s_kernel"}.get(prec) if alg0 else None
             traffic, tsrc = (None, None)
             if kname and B == 64 and n == 64:
-                traffic, tsrc = hbm_traffic_from_profiles(kname.replace("g_chain_", "") + "<")
+                traffic, tsrc = hbm_traffic_from_profiles(re.escape(kname) + "<4, true")       # the training variant
             ach = kern["g_fwd"]["achieved_tflops"]
             ach_ex = executed / (per["g_fwd"] * 1e-3) / 1e12
             g_ms, g_ms_step = sum(per.values()), sum(per_step.values())

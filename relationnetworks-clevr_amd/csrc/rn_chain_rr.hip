@@ -28,6 +28,7 @@
 
 namespace {
 constexpr int RR_G = 256, RR_L = 4, RR_TM = 256, RR_NT = 512;
+constexpr int RR_PRIO_DEFAULT = 0;                     // static priority for waves 4..7 (see the kernels): measured, not adopted unless it wins
 constexpr int RR_NW = RR_NT / 64, RR_WR = RR_TM / RR_NW;        // 8 waves, 32 pair rows each
 constexpr int RR_DPW = 16 / RR_NW;                      // LDS-DMA pieces (1 KB) per wave and stage
 constexpr int RR_RD = 4;                                // A-fragment read-ahead (register ring)
@@ -57,6 +58,7 @@ struct RRArgs {
   const float* bias[RR_L];
   bf16* out[RR_L];                                      // H_l (M, 256) or null
   u64* mask[RR_L];                                      // ReLU lane masks of layer l (M * 32 bytes) or null
+  int prio;                                             // 1: the second-dispatched half of the waves raises its issue priority
 };
 struct RRBwdArgs {                                      // the per-layer buffers are equally spaced (checked on the host):
   const bf16* W;                                        // step s: fragment-major W_{3-s}^T at W + s * w_stride
@@ -65,6 +67,7 @@ struct RRBwdArgs {                                      // the per-layer buffers
   long w_stride, mask_stride, dz_stride;                // in elements
   const float* dxg;                                     // (B, 256) fp32
   int rows_per_b;
+  int prio;
 };
 typedef __attribute__((ext_vector_type(16))) unsigned u32x16;
 // 16 lane masks (32 dwords) -> SGPRs.  Inline asm: a compiler-visible scalar load would make every LDS wait a
@@ -323,6 +326,10 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
 
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
+  // Two waves share each SIMD; the hardware arbitrates their issue slots by priority, then age, and the second-dispatched
+  // half loses every stage head.  One static s_setprio for that half evens the pair out (MI355X_MICROARCH.md, "Two waves
+  // per SIMD", item 4).  RN_RR_PRIO=0 turns it off.
+  if (a.prio && k.w >= RR_NW / 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int s = 0; s < RR_LA; ++s)
 #pragma unroll
@@ -551,6 +558,7 @@ struct RRArgsF {
   const float* bias[RR_L];
   bf16* out[RR_L];
   u64* mask[RR_L];
+  int prio;
 };
 __device__ __forceinline__ unsigned relu_pack_f16(float a, float b) {     // saturate instead of overflowing fp16 to inf
   const f32x2 f = {fminf(a, 65504.f), fminf(b, 65504.f)};
@@ -641,6 +649,10 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
 
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
+  // Two waves share each SIMD; the hardware arbitrates their issue slots by priority, then age, and the second-dispatched
+  // half loses every stage head.  One static s_setprio for that half evens the pair out (MI355X_MICROARCH.md, "Two waves
+  // per SIMD", item 4).  RN_RR_PRIO=0 turns it off.
+  if (a.prio && k.w >= RR_NW / 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int s = 0; s < F_LA; ++s)
 #pragma unroll
@@ -867,6 +879,10 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
 
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
+  // Two waves share each SIMD; the hardware arbitrates their issue slots by priority, then age, and the second-dispatched
+  // half loses every stage head.  One static s_setprio for that half evens the pair out (MI355X_MICROARCH.md, "Two waves
+  // per SIMD", item 4).  RN_RR_PRIO=0 turns it off.
+  if (a.prio && k.w >= RR_NW / 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int s = 0; s < RR_LA; ++s)
 #pragma unroll
@@ -1026,6 +1042,11 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
 }
 #undef RN_LAYER
 
+static int rr_prio() {
+  const char* e = getenv("RN_RR_PRIO");
+  return e ? (e[0] != '0') : RR_PRIO_DEFAULT;
+}
+
 static int rr_num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -1062,6 +1083,7 @@ extern "C" int rn_g_chain_fwd_rr(const void* P, int ldp, const void* const* Wf, 
   RN_CHECK_ARG(ldp % 8 == 0 && ldp >= K0 && ((uintptr_t)P % 16 == 0), "rn_g_chain_fwd_rr: bad P layout");
   RRArgs a;
   memset(&a, 0, sizeof(a));
+  a.prio = rr_prio();
   int nh = 0, nm = 0;
   for (int l = 0; l < RR_L; ++l) {
     RN_CHECK_ARG(Wf[l] && bias[l], "rn_g_chain_fwd_rr: layer %d weight/bias is NULL", l);
@@ -1107,6 +1129,7 @@ extern "C" int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, co
   RN_CHECK_ARG(((uintptr_t)Xp | (uintptr_t)Vc) % 16 == 0, "rn_g_chain_fwd_rr_alg0: tables must be 16-byte aligned");
   RRArgs a;
   memset(&a, 0, sizeof(a));
+  a.prio = rr_prio();
   int nh = 0, nm = 0;
   for (int l = 0; l < RR_L; ++l) {
     RN_CHECK_ARG(Wf[l] && bias[l], "rn_g_chain_fwd_rr_alg0: layer %d weight/bias is NULL", l);
@@ -1145,6 +1168,7 @@ extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* cons
   RN_CHECK_ARG(ldp % 8 == 0 && ldp >= K0 && ((uintptr_t)P16 % 16 == 0), "rn_g_chain_fwd_rr_f16s: bad P layout");
   RRArgsF a;
   memset(&a, 0, sizeof(a));
+  a.prio = rr_prio();
   int nh = 0, nm = 0;
   for (int l = 0; l < RR_L; ++l) {
     RN_CHECK_ARG(Whi[l] && Wlo[l] && bias[l], "rn_g_chain_fwd_rr_f16s: layer %d weight/bias is NULL", l);
@@ -1196,6 +1220,7 @@ extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, in
   RN_CHECK_ARG(((uintptr_t)Xp16 | (uintptr_t)Vc) % 16 == 0, "rn_g_chain_fwd_rr_f16s_alg0: tables must be 16-byte aligned");
   RRArgsF a;
   memset(&a, 0, sizeof(a));
+  a.prio = rr_prio();
   int nh = 0, nm = 0;
   for (int l = 0; l < RR_L; ++l) {
     RN_CHECK_ARG(Whi[l] && Wlo[l] && bias[l], "rn_g_chain_fwd_rr_f16s_alg0: layer %d weight/bias is NULL", l);
@@ -1240,6 +1265,7 @@ extern "C" int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, cons
                "rn_g_chain_bwd_rr: M=%d must be a multiple of %d and of rows per question=%d", M, RR_TM, rows_per_question);
   RRBwdArgs a;
   memset(&a, 0, sizeof(a));
+  a.prio = rr_prio();
   const bool skip0 = dZ[0] == nullptr;                     // the last layer's gradient is not stored (rn_g_linear_bwd_wgrad_gated rebuilds it)
   for (int l = 0; l < RR_L; ++l) {
     RN_CHECK_ARG(mask[l] && (dZ[l] || (l == 0 && skip0)) && (l == RR_L - 1 || Wtf[l]), "rn_g_chain_bwd_rr: entry %d has a NULL pointer", l);

@@ -235,7 +235,19 @@ __global__ __launch_bounds__(256) void segsum_kernel(const T* __restrict__ in, i
   const int r1 = (r0 + 256 < seglen) ? r0 + 256 : seglen;
   if (rl < lanes) {
     const T* base = in + ((long)seg * seglen) * ld + c * CH;
-    for (int r = r0 + rl; r < r1; r += lanes) {
+    int r = r0 + rl;
+    // 8 independent 16-byte loads per memory round trip (the kernel is a latency chain between the forward chain and
+    // f_phi); rows are still added in ascending order
+    for (; r + 7 * lanes < r1; r += 8 * lanes) {
+      Chunk16<T> v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const Chunk16<T>*>(base + (long)(r + u * lanes) * ld);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc[e] += Elem<T>::to_f32(v[u].v[e]);
+    }
+    for (; r < r1; r += lanes) {
       const Chunk16<T> v = *reinterpret_cast<const Chunk16<T>*>(base + (long)r * ld);
 #pragma unroll
       for (int e = 0; e < CH; ++e) acc[e] += Elem<T>::to_f32(v.v[e]);
@@ -374,7 +386,8 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const T* __restrict__ 
     // Software pipeline over i: the 16 loads of the NEXT i are in flight while this i is added up (one workgroup per
     // CU: nobody else hides the HBM latency).  All 16 loads are issued back to back -- a short last block re-reads
     // its last row and adds zeros: no branch may sit between the loads.
-    Raw v[2][JB];
+    constexpr int PD = 3;                                           // i's in flight per thread; <= 256 registers so that the workgroup fits NEXT TO a wgrad workgroup
+    Raw v[PD][JB];
     auto issue = [&](Raw (&dst)[JB], int i) {
       const T* base = dZ + (((long)b * n + i) * n + j0) * ld + c * CH;
 #pragma unroll
@@ -395,18 +408,20 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const T* __restrict__ 
       }
       *reinterpret_cast<f32x4*>(ri_part + jb * part_stride + ((long)b * n + i) * G + c * CH) = f32x4{ri[0], ri[1], ri[2], ri[3]};
     };
-    int i = il;
-    if (i < n) issue(v[0], i);
-    while (i < n) {
-      const int i1 = i + NIL, i2 = i + 2 * NIL;
-      if (i1 < n) issue(v[1], i1);
-      __builtin_amdgcn_sched_barrier(0);
-      consume(v[0], i);
-      if (i1 >= n) break;
-      if (i2 < n) issue(v[0], i2);
-      __builtin_amdgcn_sched_barrier(0);
-      consume(v[1], i1);
-      i = i2;
+    // ring of PD stages: stage s holds i = il + (s + PD * round) * NIL; PD - 1 stages are in flight while one is consumed
+#pragma unroll
+    for (int s0 = 0; s0 < PD - 1; ++s0)
+      if (il + s0 * NIL < n) issue(v[s0], il + s0 * NIL);
+    for (int ib = il; ib < n; ib += PD * NIL) {
+#pragma unroll
+      for (int s0 = 0; s0 < PD; ++s0) {
+        const int i = ib + s0 * NIL, inext = i + (PD - 1) * NIL;
+        if (i < n) {
+          if (inext < n) issue(v[(s0 + PD - 1) % PD], inext);
+          __builtin_amdgcn_sched_barrier(0);
+          consume(v[s0], i);
+        }
+      }
     }
   }
   if constexpr (WANT_RJ) {
@@ -446,12 +461,45 @@ __global__ __launch_bounds__(256) void pair_reduce_finish_kernel(const f32x4* __
   const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), il = threadIdx.x >> 6;
   f32x4 q = {0.f, 0.f, 0.f, 0.f};
   if (c < G4) {
-    for (int i = il; i < n; i += 4) {
-      const long o = ((long)b * n + i) * G4 + c;
-      f32x4 r = ri_part[o];
-      for (int p = 1; p < njb; ++p) r += ri_part[p * part_stride4 + o];
-      if (Ri) Ri[o] = r;
-      q += r;
+    // This loop is a chain of L2 / HBM round trips on the critical path of the backward pass (it runs beside the wgrad
+    // stream, where a round trip costs microseconds): four i's x four slabs = 16 independent loads per trip instead of
+    // one.  Every sum keeps its order (slabs ascending per i, i ascending into Rq): bitwise the sequential result.
+    for (int i0 = il; i0 < n; i0 += 16) {
+      long o[4];
+      bool ok[4];
+      f32x4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 4 * u;
+        ok[u] = i < n;
+        o[u] = ((long)b * n + (ok[u] ? i : i0)) * G4 + c;
+      }
+      int p = 0;
+      for (; p + 4 <= njb; p += 4) {
+        f32x4 v[4][4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[w][u] = ri_part[(long)(p + w) * part_stride4 + o[u]];
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) r[u] = (p == 0 && w == 0) ? v[w][u] : r[u] + v[w][u];
+      }
+      for (; p < njb; ++p) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ri_part[(long)p * part_stride4 + o[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = (p == 0) ? v[u] : r[u] + v[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (ok[u]) {
+          if (Ri) Ri[o[u]] = r[u];
+          q += r[u];
+        }
+      }
     }
   }
   if (il > 0) red[il - 1][threadIdx.x & 63] = q;
@@ -752,19 +800,34 @@ __global__ __launch_bounds__(512) void pair_dx_dq_kernel(const float* __restrict
   };
   const int r = t >> 5, c = t & 31;
   float a0 = 0.f, a1 = 0.f;
-  fetch(0);
-  for (int f0 = 0; f0 < N; f0 += DXQ_FC) {
-    __syncthreads();
+  // The kernel sits on the critical path between the pair reduction and the conv backward, beside the wgrad stream: what
+  // counts is the number of dependent memory round trips.  The operands of FOUR feature chunks are requested at once (one
+  // trip per 256 features instead of one per 64); the chunks then pass through LDS one after the other (same FMA order).
+  constexpr int NCH = 4;
+  float qr1[NCH][2], qr2[NCH][2], qw1[NCH][4], qw2[NCH][4];
+  for (int g0 = 0; g0 < N; g0 += NCH * DXQ_FC) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { rs[0][sr][sf + u] = pr1[u]; rs[1][sr][sf + u] = pr2[u]; }
+    for (int ch = 0; ch < NCH; ++ch) {
+      fetch(g0 + ch * DXQ_FC);                                         // (columns beyond N read as zeros)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { ws[0][wf + 16 * u][wc] = pw1[u]; ws[1][wf + 16 * u][wc] = pw2[u]; }
-    __syncthreads();
-    if (f0 + DXQ_FC < N) fetch(f0 + DXQ_FC);
+      for (int u = 0; u < 2; ++u) { qr1[ch][u] = pr1[u]; qr2[ch][u] = pr2[u]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { qw1[ch][u] = pw1[u]; qw2[ch][u] = pw2[u]; }
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (g0 + ch * DXQ_FC >= N) break;                                // uniform
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { rs[0][sr][sf + u] = qr1[ch][u]; rs[1][sr][sf + u] = qr2[ch][u]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { ws[0][wf + 16 * u][wc] = qw1[ch][u]; ws[1][wf + 16 * u][wc] = qw2[ch][u]; }
+      __syncthreads();
 #pragma unroll 16
-    for (int f = 0; f < DXQ_FC; ++f) {
-      a0 = fmaf(rs[0][r][f], ws[0][f][c], a0);
-      a1 = fmaf(rs[1][r][f], ws[1][f][c], a1);
+      for (int f = 0; f < DXQ_FC; ++f) {
+        a0 = fmaf(rs[0][r][f], ws[0][f][c], a0);
+        a1 = fmaf(rs[1][r][f], ws[1][f][c], a1);
+      }
     }
   }
   if (c < ncols && r0 + r < nrows) out[(long)(r0 + r) * ld + c] = a0 + a1;

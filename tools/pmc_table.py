@@ -4,9 +4,12 @@ import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+import os, sys as _s
+_s.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import pretty
 for k, d in acc.items():
     m = {c: sum(v) / len(v) for c, v in d.items()}
-    name = k.split("(")[0][-72:]
+    name = pretty(k)
     line = "%-72s" % name
     wc = m.get("SQ_WAVE_CYCLES", 0)
     for c in sorted(m):

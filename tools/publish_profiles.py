@@ -2,6 +2,8 @@
 """Turn gpurun_out/prof_final/ (tools/collect_profiles.sh) into the tracked summaries under profiles/.
 usage: python tools/publish_profiles.py [tag]   (tag defaults to r01_final)"""
 import csv, os, re, shutil, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import pretty
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_final")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
@@ -9,7 +11,7 @@ dst = lambda n: os.path.join(ROOT, "profiles", "%s_%s" % (tag, n))
 shutil.copy(os.path.join(src, "kernel_stats.csv"), dst("kernel_stats_rocprofv3.csv"))
 shutil.copy(os.path.join(src, "bench_line.json"), dst("bench_line.json"))
 shutil.copy(os.path.join(src, "step_timeline.txt"), dst("step_timeline.txt"))
-OURS = re.compile(r"(rr_kernel|rr_bwd|wgrad|pair_|f_phi|cn_|lstm_|emb_bwd|conv3x3s2|conv_wgrad|clip_adam|sumsq|nll_|segsum|pack_frag|debug_stamp)")
+OURS = re.compile(r"(rr_kernel|rr_f16s|rr_bwd|wgrad|pair_|f_phi|cn_|lstm_|emb_bwd|conv3x3s2|conv_wgrad|clip_adam|sumsq|nll_|segsum|pack_frag|debug_stamp)")
 rows = list(csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))))
 steps = 13.0
 with open(dst("hot_path_kernels.txt"), "w") as f:
@@ -22,7 +24,7 @@ with open(dst("hot_path_kernels.txt"), "w") as f:
         name = r["kernel"]
         if name == "TOTAL" or not OURS.search(name):
             continue
-        short = re.sub(r"^void ", "", name).split("(")[0][:58]
+        short = pretty(name)[-58:]
         per = float(r["calls"]) / steps
         us = float(r["avg_us"])
         tot += per * us
