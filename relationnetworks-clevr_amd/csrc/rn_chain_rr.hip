@@ -1186,7 +1186,9 @@ extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* cons
   RN_CHECK_ARG(nh == 0 || nh == RR_L || h012, "rn_g_chain_fwd_rr_f16s: H must hold none, all, or (with masks) all but the last activation");
   RN_CHECK_ARG(nm == 0 || (nm == RR_L && nh >= 3), "rn_g_chain_fwd_rr_f16s: masks come as a full set together with the stored activations");
   RN_CHECK_ARG(nh || xg_part, "rn_g_chain_fwd_rr_f16s: nothing to compute (no H, no xg_part)");
-  RN_CHECK_ARG(nh == 0 || h012 || (nh == RR_L && nm == 0), "rn_g_chain_fwd_rr_f16s: supported outputs: inference, training (H_0..2 + masks), all four H");
+  const bool h0123m = nh == RR_L && nm == RR_L;                       // waves straddling questions: H_3 stored for the pair sum, masks for the backward chain
+  RN_CHECK_ARG(nh == 0 || h012 || (nh == RR_L && nm == 0) || (h0123m && !xg_part),
+               "rn_g_chain_fwd_rr_f16s: supported outputs: inference, training (H_0..2 + masks + xg_part), all four H, all four H + masks (no xg_part)");
   const int ntiles = M / RR_TM;
   const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
   hipStream_t s = (hipStream_t)stream;
@@ -1197,6 +1199,7 @@ extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* cons
     if (nh == 0) RN_GO(NK0_, false, false, false, true);                    \
     else if (h012 && xg_part) RN_GO(NK0_, true, false, true, true);         \
     else if (h012) { rn_set_error("rn_g_chain_fwd_rr_f16s: training output set needs xg_part"); return -1; } \
+    else if (h0123m) RN_GO(NK0_, true, true, true, false);                  \
     else if (xg_part) RN_GO(NK0_, true, true, false, true);                 \
     else RN_GO(NK0_, true, true, false, false);                             \
   } while (0)

@@ -289,18 +289,23 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
             P = torch.empty(M, ld0, dtype=dt, device=dev)
             H.pair_build_fwd(x, q, P, code, B, n, k, Q, ld0)
         if (wfrag is not None and len(wfrag) == 2 and len(wfrag[0]) == L and rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0
-                and (n * n) % 32 == 0 and os.environ.get("RN_NO_RR_MASKS", "0") != "1"):
+                and ((n * n) % 32 == 0 or keep_inputs) and os.environ.get("RN_NO_RR_MASKS", "0") != "1"):
             # register-resident mapping: fp16 operand registers, hi + lo weight fragments; bf16 copies + lane masks for the
-            # (shared, bf16) backward chain
+            # (shared, bf16) backward chain.  Waves that straddle two questions (n*n % 32 != 0, the 14x14 grid): the pair sum
+            # comes from the stored H_3 instead of the in-lane partials (training only: inference has nowhere to store it)
             R = 32
+            whole = (n * n) % R == 0
             masks = Hs = None
             if keep_inputs:
-                Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L - 1)] + [None]
+                Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L - 1)] + [None if whole else torch.empty(M, G, dtype=dt, device=dev)]
                 masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
-            part = torch.empty(M // R, G, dtype=torch.float32, device=dev)
+            part = torch.empty(M // R, G, dtype=torch.float32, device=dev) if whole else None
             H.g_chain_fwd_rr_f16s(P16, ld0, wfrag[0], wfrag[1], g_b, Hs, masks, ld0, part, M, G)
             xg = torch.empty(B, G, dtype=torch.float32, device=dev)
-            H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // R, G)
+            if whole:
+                H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // R, G)
+            else:
+                H.pair_sum_fwd(Hs[-1], G, xg, code, B, n * n, G)
             if Hs is None:
                 return [P, None, None, None], None, xg
             return [P] + Hs[:-1], RRMasks(masks), xg
@@ -442,9 +447,9 @@ class RelationalFunction(torch.autograd.Function):
         f16s = precision == "f16s"
         need_grad = any(ctx.needs_input_grad)
         # exactly g_chain_forward's condition for the register-resident branches (they consume only the fragment-major
-        # images): f16s needs whole waves per question, bf16 needs them only when nothing is kept for a backward pass
+        # images): whole waves per question, or -- waves straddling questions -- a stored H_3 (training only)
         rr_only = (rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0 and os.environ.get("RN_NO_RR_MASKS", "0") != "1"
-                   and ((n * n) % 32 == 0 or (need_grad and not f16s)))
+                   and ((n * n) % 32 == 0 or need_grad))
         alg_fwd = rr_only and alg0_forward_ok(plan, code, n, k, M)
         inj_fwd = inj_chain_ok(plan, code, n, k, M)        # question injected at layer 2: same chains, per-question bias row
         if inj_fwd:

@@ -876,3 +876,33 @@ def test_nll_mean():
     assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la))
     (la * 3).backward(); (lb * 3).backward()
     assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("B", [1100, 2500])
+def test_f_phi_large_batch_and_label_clamp(H, B):
+    """f_phi + NLL for an evaluation-sized batch (the gradient kernel tiles the batch: B > 1024 used to be
+    refused) against plain torch; labels outside [0, A) are CLAMPED to the nearest class, consistently in the fused forward
+    and backward kernels (documented in INTEGRATION.md: a kernel cannot raise like F.nll_loss without a host sync)."""
+    G, F1, F2, A = 256, 256, 256, 28
+    xg = dev(formula.hash_uniform((B, G), 600, -1, 1))
+    fw = [dev(formula.hash_uniform(sh, 601 + i, -0.1, 0.1)) for i, sh in enumerate([(F1, G), (F2, F1), (A, F2)])]
+    fb = [dev(formula.hash_uniform((n_,), 605 + i, -0.1, 0.1)) for i, n_ in enumerate([F1, F2, A])]
+    label = torch.tensor(formula.hash_uniform((B,), 610, 0, A).astype(np.int64).clip(0, A - 1), device="cuda")
+    label[3], label[7], label[B - 1] = -100, A + 5, -1              # out of range: clamped to 0, A-1, 0
+    clamped = label.clamp(0, A - 1)
+    wT = [w.t().contiguous() for w in fw]
+    f32 = dict(dtype=torch.float32, device="cuda")
+    f1 = torch.empty(B, F1, **f32); f2 = torch.empty(B, F2, **f32); out = torch.empty(B, A, **f32); loss = torch.empty((), **f32)
+    H.f_phi_fwd_nll(xg, wT, fb, None, label, f1, f2, out, loss, transposed=True)
+    ps = [t.clone().requires_grad_(True) for t in [xg] + fw + fb]
+    h = torch.relu(ps[0] @ ps[1].t() + ps[4]); h = torch.relu(h @ ps[2].t() + ps[5])
+    ref = torch.log_softmax(h @ ps[3].t() + ps[6], 1)
+    ref_loss = torch.nn.functional.nll_loss(ref, clamped)
+    (ref_loss * 0.7).backward()
+    assert rel(out.cpu().numpy(), ref.detach().cpu().numpy()) <= 1e-5
+    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+    dW = [torch.empty_like(w) for w in fw]; db = [torch.empty_like(b) for b in fb]; dxg = torch.empty(B, G, **f32)
+    H.f_phi_bwd_nll(torch.tensor(0.7, **f32), label, out, f2, f1, xg, fw, None, dW, db, dxg)
+    torch.cuda.synchronize()
+    for got, want in zip([dxg] + dW + db, [p.grad for p in ps]):
+        assert rel(got.cpu().numpy(), want.cpu().numpy()) <= 2e-4

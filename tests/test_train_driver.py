@@ -330,3 +330,28 @@ def test_train_step_is_bitwise_reproducible_with_a_poisoned_allocator(T, use_gra
     for val in (float("nan"), 1e30):
         for (la, ga), (lb, gb) in zip(base, run(val)):
             assert la == lb and torch.equal(ga, gb)
+
+
+@pytest.mark.gpu
+def test_ir_fp_graph_trainer_matches_eager_and_learns(T):
+    """config.json ir-fp (question injected at layer 2) through the data-parallel trainer: the hipGraph-replayed step gives
+    bitwise the eager step (same kernels, fixed-order reductions), in the module-default arithmetic (f16s on the
+    register-resident chains with the per-question bias row), and the loss on a repeated batch falls."""
+    import relationnetworks_clevr_amd as pkg
+    from relationnetworks_clevr_amd import dp
+
+    class A:
+        qdict_size, adict_size = 82, 28
+
+    def run(use_graph, steps):
+        torch.manual_seed(0)
+        m = pkg.RN(A, dict(formula.HYP["ir-fp"], dropout=0.0)).cuda()
+        assert m.rl.resolved_precision(16, 64, 26) == "f16s"
+        opt = torch.optim.Adam(m.parameters(), lr=3e-4, weight_decay=1e-4)
+        tr = dp.DataParallelTrainer(m, opt, clip_norm=50.0, use_graph=use_graph)
+        img, q, y = T.load_tensor_data(next(iter(T.SyntheticClevr(16, 16, seed=3))), "cuda")
+        return [float(tr.step(img, q, y).detach()) for _ in range(steps)]
+
+    eager, graph = run(False, 6), run(True, 40)
+    assert eager == graph[:6], (eager, graph[:6])
+    assert np.isfinite(graph[-1]) and graph[-1] < 0.5 * graph[0], (graph[0], graph[-1])

@@ -22,3 +22,9 @@ cd $R
 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 python tools/step_timeline.py > $OUT/step_timeline.txt 2>&1
 ls -la $OUT
+# 4. the other BASELINE configs: ir-fp (configs[3]) and the 14x14 / B=32 stress shape (configs[4])
+python bench.py --config ir-fp --no-cpu-baseline > $OUT/bench_ir_fp.json 2>> $OUT/bench.err
+python bench.py --hw 224 --batch 32 --steps 10 --no-cpu-baseline > $OUT/bench_stress_b32_n196.json 2>> $OUT/bench.err
+python tools/time_small.py > $OUT/small_kernels_alone.txt 2>/dev/null
+python tools/time_k1.py > $OUT/k1_alone.txt 2>/dev/null
+ls -la $OUT
