@@ -204,20 +204,24 @@ int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri, float* Rq
                        int n, int G, void* stream);
 
 /* Input gradients of the pair expansion from the reductions, one launch (question injected at layer 0; W0 (N, 2k+Q) fp32):
- *   dx (B, n, k) contiguous = Rj W0[:, 0:k] + Ri W0[:, k:2k];   dq (B, Q) = Rq W0[:, 2k:2k+Q]   (Q == 0: Rq / dq may be NULL). */
-int rn_pair_dx_dq(const float* Rj, const float* Ri, const float* Rq, const float* W0, float* dx, float* dq, int B, int n, int k,
-                  int Q, int N, void* stream);
+ *   dx[b, j, c] = (Rj W0[:, 0:k] + Ri W0[:, k:2k])[b*n + j, c] for c < kout, written at element strides (sdb, sdn, sdk) -- e.g.
+ *   straight into the (B, 24, d, d) layout the conv stack's backward reads, without the two coordinate columns (kout = 24,
+ *   model.py:216: they carry no gradient);   dq (B, Q) = Rq W0[:, 2k:2k+Q]   (Q == 0: Rq / dq may be NULL). */
+int rn_pair_dx_dq(const float* Rj, const float* Ri, const float* Rq, const float* W0, float* dx, long sdb, long sdn, long sdk, int kout,
+                  float* dq, int B, int n, int k, int Q, int N, void* stream);
 
 /* Layer-0 weight gradient from the pair reductions (the question injected at layer 0: P = [x_j | x_i | q]):
  *   dW0[:, 0:k] = Rj^T X,  dW0[:, k:2k] = Ri^T X,  dW0[:, 2k:2k+Q] = Rq^T q,  db0 = sum_b Rq[b]
  * with X = x viewed as (B*n, k) -- identical to dZ_0^T P (rounding aside: x enters in fp32 instead of P's storage
  * dtype) without reading dZ_0 or P.  Rj, Ri (B*n, N), Rq (B, N) fp32 from rn_pair_reduce_bwd; x (B, n, k) element
  * strides; q (B, Q) row stride sqb; dW0 (N, 2k+Q), db0 (N); k <= 32; ws: rn_wgrad0_ws_bytes(B, n, N) bytes.
- * Q == 0 (no question at layer 0): Rq / q may be NULL, db0 is then left to the caller. */
+ * Q == 0 (no question at layer 0): q may be NULL; Rq (all-pairs sums) still gives db0, NULL leaves db0 = 0.
+ * coord != NULL: x supplies only the first kf columns of an object, the rest are the coordinate tags coord (k - kf, n), as in
+ * rn_pair_tables. */
 size_t rn_wgrad0_ws_bytes(int B, int n, int N);
 int rn_wgrad0_from_reductions(const float* Rj, const float* Ri, const float* Rq, const float* x, long sxb, long sxn, long sxk,
-                              const float* q, long sqb, float* dW0, float* db0, void* ws, int B, int n, int k, int Q, int N,
-                              void* stream);
+                              const float* coord, int kf, const float* q, long sqb, float* dW0, float* db0, void* ws, int B, int n,
+                              int k, int Q, int N, void* stream);
 
 /* K4 -- small fp32 GEMM on the fp32 MFMA, used for f_phi (model.py:155-160), its backward
  * and the (B*n x G) tail of the pair backward:
@@ -342,8 +346,13 @@ int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const float* gamm
  *     object rows with the Vc row of (question, i) as its bias; the pair matrix never exists.  Wf[0] is the fragment-major
  *     image of W0[:, 0:k] (natural layout), Wf[1..3] as for rn_g_chain_fwd_rr.  n % 32 == 0, M = B*n*n.  H / mask: both NULL
  *     (inference) or H_0..2 (H[3] NULL) + the four masks (training); xg_part (M/32, 256) fp32 as for rn_g_chain_fwd_rr. */
-int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* q, long ldq, const float* W0T, const float* b0,
-                   void* Xp, int xp_dtype /* RN_BF16 | RN_F16 */, float* Vc, int B, int n, int k, int Q, int N, void* stream);
+/* Coordinate tagging fused (model.py:195-201, 208-218): with coord != NULL the object (b, p) is [x[b, p, 0:kf] | coord[0:k-kf, p]]
+ * -- x is then the conv grid itself, viewed (B, n, kf) at element strides, and coord the (k - kf, n) fp32 table of
+ * RN.build_coord_tensor (channel 0 = x = lin[p % d], channel 1 = y = lin[p / d]); no concatenated tensor exists.
+ * coord == NULL: x carries all k columns (kf ignored).  Q == 0: no question term (q may be NULL). */
+int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* coord, int kf, const float* q, long ldq,
+                   const float* W0T, const float* b0, void* Xp, int xp_dtype /* RN_BF16 | RN_F16 */, float* Vc, int B, int n, int k,
+                   int Q, int N, void* stream);
 /* ... and in the f16s arithmetic (fp16 object rows; Whi / Wlo as for rn_g_chain_fwd_rr_f16s, layer 0 = W0[:, 0:k] natural) */
 /* inject_layer = 0: the question is part of the tables (Q > 0 in rn_pair_tables).  inject_layer = 2 (the "IR" variants,
  * model.py:131-142; tables built with Q = 0): layer 2's input is [H_1 | q[b]], i.e. W_2 [H_1 | q] + b_2 =

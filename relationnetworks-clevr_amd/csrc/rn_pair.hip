@@ -556,7 +556,8 @@ constexpr int W0_CMAX = 32;         // k <= 32 columns per x part
 }
 __global__ __launch_bounds__(256) void wgrad0_part_kernel(const float* __restrict__ Rj, const float* __restrict__ Ri,
                                                           const float* __restrict__ x, long sxb, long sxn, long sxk,
-                                                          float* __restrict__ part, int n, int k, int N, int rows) {
+                                                          float* __restrict__ part, int n, int k, int N, int rows,
+                                                          const float* __restrict__ coord, int kf) {
   __shared__ float xs[W0_RS][W0_CMAX + 1];
   const int fb = blockIdx.x, pt = blockIdx.y, ks = blockIdx.z;
   const int t = threadIdx.x, f = fb * 32 + (t & 31), cg = t >> 5;
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(256) void wgrad0_part_kernel(const float* __restric
     float v = 0.f;
     if (r < nr) {
       const int row = r0 + r, b = row / n, j = row - b * n;
-      v = x[b * sxb + j * sxn + c * sxk];
+      v = c < kf ? x[b * sxb + j * sxn + c * sxk] : coord[(long)(c - kf) * n + j];
     }
     xs[r][c] = v;
   }
@@ -662,14 +663,16 @@ extern "C" size_t rn_wgrad0_ws_bytes(int B, int n, int N) {
 }
 
 extern "C" int rn_wgrad0_from_reductions(const float* Rj, const float* Ri, const float* Rq, const float* x, long sxb, long sxn,
-                                         long sxk, const float* q, long sqb, float* dW0, float* db0, void* ws, int B, int n, int k,
-                                         int Q, int N, void* stream) {
+                                         long sxk, const float* coord, int kf, const float* q, long sqb, float* dW0, float* db0,
+                                         void* ws, int B, int n, int k, int Q, int N, void* stream) {
+  if (!coord) kf = k;
+  RN_CHECK_ARG(kf > 0 && kf <= k, "rn_wgrad0_from_reductions: kf=%d must be in (0, k=%d]", kf, k);
   RN_CHECK_ARG(Rj && Ri && x && dW0 && db0 && ws && B > 0 && n > 0, "rn_wgrad0_from_reductions: bad pointer/size");
   RN_CHECK_ARG(k > 0 && k <= W0_CMAX && N % 32 == 0 && (Q == 0 || (Rq && q)), "rn_wgrad0_from_reductions: k=%d (<= %d), N=%d (%% 32), Q=%d unsupported", k, W0_CMAX, N, Q);
   RN_CHECK_ARG(Rq || Q == 0, "rn_wgrad0_from_reductions: Rq is required for the bias when the question is injected");
   const int rows = B * n, nks = cdiv(rows, W0_RS), kt = 2 * k + Q;
   hipStream_t s = (hipStream_t)stream;
-  wgrad0_part_kernel<<<dim3(N / 32, 2, nks), 256, 0, s>>>(Rj, Ri, x, sxb, sxn, sxk, (float*)ws, n, k, N, rows);
+  wgrad0_part_kernel<<<dim3(N / 32, 2, nks), 256, 0, s>>>(Rj, Ri, x, sxb, sxn, sxk, (float*)ws, n, k, N, rows, coord, kf);
   wgrad0_finish_kernel<<<N, 256, 0, s>>>((const float*)ws, nks, Rq, q, sqb, dW0, db0, B, k, Q, N, kt);
   RN_LAUNCH_CHECK("rn_wgrad0_from_reductions");
   return 0;
@@ -763,7 +766,8 @@ constexpr int DXQ_FC = 64;
 __global__ __launch_bounds__(512) void pair_dx_dq_kernel(const float* __restrict__ Rj, const float* __restrict__ Ri,
                                                          const float* __restrict__ Rq, const float* __restrict__ W0, int kt,
                                                          float* __restrict__ dx, float* __restrict__ dq, int rows, int B, int k,
-                                                         int Q, int N, int xblocks, int qcol_tiles) {
+                                                         int Q, int N, int xblocks, int qcol_tiles, int n, long sdb, long sdn,
+                                                         long sdk, int kout) {
   __shared__ float rs[2][16][DXQ_FC];
   __shared__ float ws[2][DXQ_FC][32];
   const int t = threadIdx.x;
@@ -830,16 +834,24 @@ __global__ __launch_bounds__(512) void pair_dx_dq_kernel(const float* __restrict
       }
     }
   }
-  if (c < ncols && r0 + r < nrows) out[(long)(r0 + r) * ld + c] = a0 + a1;
+  if (c < ncols && r0 + r < nrows) {
+    if ((int)blockIdx.x < xblocks) {                                   // dx[b, j, c] at element strides (sdb, sdn, sdk); columns >= kout
+      const int row = r0 + r, b = row / n, j = row - b * n;           // (the coordinate tags: no gradient, model.py:216) are dropped
+      if (c < kout) dx[b * sdb + j * sdn + c * sdk] = a0 + a1;
+    } else {
+      out[(long)(r0 + r) * ld + c] = a0 + a1;
+    }
+  }
 }
 
-extern "C" int rn_pair_dx_dq(const float* Rj, const float* Ri, const float* Rq, const float* W0, float* dx, float* dq, int B, int n,
-                             int k, int Q, int N, void* stream) {
+extern "C" int rn_pair_dx_dq(const float* Rj, const float* Ri, const float* Rq, const float* W0, float* dx, long sdb, long sdn, long sdk,
+                             int kout, float* dq, int B, int n, int k, int Q, int N, void* stream) {
+  RN_CHECK_ARG(kout > 0 && kout <= k, "rn_pair_dx_dq: kout=%d must be in (0, k=%d]", kout, k);
   RN_CHECK_ARG(Rj && Ri && W0 && dx && B > 0 && n > 0 && N > 0, "rn_pair_dx_dq: bad pointer/size");
   RN_CHECK_ARG(k > 0 && k <= 32 && (Q == 0 || (Rq && dq)), "rn_pair_dx_dq: k=%d (<= 32), Q=%d unsupported", k, Q);
   const int rows = B * n, xblocks = cdiv(rows, 16), qct = cdiv(Q, 32), qblocks = Q ? cdiv(B, 16) * qct : 0;
   pair_dx_dq_kernel<<<xblocks + qblocks, 512, 0, (hipStream_t)stream>>>(Rj, Ri, Rq, W0, 2 * k + Q, dx, dq, rows, B, k, Q, N, xblocks,
-                                                                         qct ? qct : 1);
+                                                                         qct ? qct : 1, n, sdb, sdn, sdk, kout);
   RN_LAUNCH_CHECK("rn_pair_dx_dq");
   return 0;
 }
@@ -854,13 +866,15 @@ template <typename TX>   // bf16 (bf16 chain) or f16 (f16s chain) object rows
 __global__ __launch_bounds__(256) void pair_tables_kernel(const float* __restrict__ x, long sxb, long sxn, long sxk,
                                                           const float* __restrict__ q, long ldq, const float* __restrict__ W0T,
                                                           const float* __restrict__ b0, TX* __restrict__ Xp, float* __restrict__ Vc,
-                                                          int n, int k, int Q, int N) {
+                                                          int n, int k, int Q, int N, const float* __restrict__ coord, int kf) {
   __shared__ float xs[16][32];
   __shared__ float qs[1024];
   const int t = threadIdx.x, b = blockIdx.y, i0 = blockIdx.x * 16;
   for (int c = t; c < 16 * 32; c += 256) {
     const int r = c >> 5, cc = c & 31;
-    xs[r][cc] = (i0 + r < n && cc < k) ? x[b * sxb + (long)(i0 + r) * sxn + cc * sxk] : 0.f;
+    float v = 0.f;
+    if (i0 + r < n && cc < k) v = cc < kf ? x[b * sxb + (long)(i0 + r) * sxn + cc * sxk] : coord[(long)(cc - kf) * n + i0 + r];
+    xs[r][cc] = v;                                                   // columns kf..k-1: the coordinate tags (model.py:195-201)
   }
   for (int c = t; c < Q; c += 256) qs[c] = q[b * ldq + c];
   __syncthreads();
@@ -897,14 +911,17 @@ __global__ __launch_bounds__(256) void pair_tables_kernel(const float* __restric
   }
 }
 
-extern "C" int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* q, long ldq, const float* W0T,
-                              const float* b0, void* Xp, int xp_dtype, float* Vc, int B, int n, int k, int Q, int N, void* stream) {
+extern "C" int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* coord, int kf, const float* q, long ldq,
+                              const float* W0T, const float* b0, void* Xp, int xp_dtype, float* Vc, int B, int n, int k, int Q, int N,
+                              void* stream) {
+  if (!coord) kf = k;
+  RN_CHECK_ARG(kf > 0 && kf <= k, "rn_pair_tables: kf=%d must be in (0, k=%d]", kf, k);
   RN_CHECK_ARG(x && W0T && b0 && Xp && Vc && B > 0 && n > 0, "rn_pair_tables: bad pointer/size");
   RN_CHECK_ARG(k > 0 && k <= 32 && Q >= 0 && Q <= 1024 && (Q == 0 || q) && N > 0,
                "rn_pair_tables: k=%d (<= 32), Q=%d (0 .. 1024; q required when Q > 0), N=%d unsupported", k, Q, N);
   RN_CHECK_ARG(xp_dtype == RN_BF16 || xp_dtype == RN_F16, "rn_pair_tables: object rows are bf16 or fp16 (dtype %d)", xp_dtype);
-  if (xp_dtype == RN_F16) pair_tables_kernel<f16><<<dim3(cdiv(n, 16), B), 256, 0, (hipStream_t)stream>>>(x, sxb, sxn, sxk, q, ldq, W0T, b0, (f16*)Xp, Vc, n, k, Q, N);
-  else pair_tables_kernel<bf16><<<dim3(cdiv(n, 16), B), 256, 0, (hipStream_t)stream>>>(x, sxb, sxn, sxk, q, ldq, W0T, b0, (bf16*)Xp, Vc, n, k, Q, N);
+  if (xp_dtype == RN_F16) pair_tables_kernel<f16><<<dim3(cdiv(n, 16), B), 256, 0, (hipStream_t)stream>>>(x, sxb, sxn, sxk, q, ldq, W0T, b0, (f16*)Xp, Vc, n, k, Q, N, coord, kf);
+  else pair_tables_kernel<bf16><<<dim3(cdiv(n, 16), B), 256, 0, (hipStream_t)stream>>>(x, sxb, sxn, sxk, q, ldq, W0T, b0, (bf16*)Xp, Vc, n, k, Q, N, coord, kf);
   RN_LAUNCH_CHECK("rn_pair_tables");
   return 0;
 }

@@ -229,16 +229,17 @@ def alg0_forward_ok(plan, code, n, k, M):
             and os.environ.get("RN_NO_ALGEBRAIC_FWD0", "0") != "1")
 
 
-def _tables(x, q, plan, g_b, w0T, inj_w, xdt, B, n, k, Q, G):
-    """Tables of the factored first layer (+ the question rows of an injected later layer): -> (Xp, Vc, Vq | None, inject)."""
+def _tables(x, q, plan, g_b, w0T, inj_w, xdt, B, n, k, Q, G, coord=None):
+    """Tables of the factored first layer (+ the question rows of an injected later layer): -> (Xp, Vc, Vq | None, inject).
+    coord (2, n): x is the conv grid itself (kf = k - 2 columns), the coordinate tags are read from the table in the kernel."""
     dev = x.device
     Xp = torch.empty(B * n, 64, dtype=xdt, device=dev)
     Vc = torch.empty(B * n, G, dtype=torch.float32, device=dev)
     if inj_w is None:
-        H.pair_tables(x, q, w0T, g_b[0], Xp, Vc, B, n, k, Q, G)
+        H.pair_tables(x, q, w0T, g_b[0], Xp, Vc, B, n, k, Q, G, coord=coord)
         return Xp, Vc, None, 0
     inj = plan.inject
-    H.pair_tables(x, None, w0T, g_b[0], Xp, Vc, B, n, k, 0, G)
+    H.pair_tables(x, None, w0T, g_b[0], Xp, Vc, B, n, k, 0, G, coord=coord)
     Gp = plan.widths[inj - 1]
     Vq = torch.empty(B, G, dtype=torch.float32, device=dev)
     # Vq[b, f] = b_inj[f] + sum_c q[b, c] W_inj[f, Gp + c]   (model.py:135-141: the question is the layer's trailing Q columns)
@@ -247,12 +248,14 @@ def _tables(x, q, plan, g_b, w0T, inj_w, xdt, B, n, k, Q, G):
 
 
 def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None, split=None, wfrag=None, stop_at=None,
-                    w0T=None, inj_w=None):
+                    w0T=None, inj_w=None, coord=None):
     """K1 + K2 chain (+ K3).  Returns (inputs, H_L, xg): the list of layer INPUT buffers
     [A_0 .. A_{L-1}], the last activation H_L and -- when the fused chain ran -- the pair sum xg
     (else None).  layer_hook(l, A_l, H_out) is called after every layer (hook-compat path; forces
     the per-layer kernels)."""
     B, n, k = x.shape
+    if coord is not None:
+        k += coord.shape[0]
     Q = q.shape[1]
     M = B * n * n
     dt = H.torch_dtype(code)
@@ -270,7 +273,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
         if w0T is not None and wfrag is not None and len(wfrag) == 2 and len(wfrag[0]) == L:
             # factored first layer in the f16s arithmetic: fp16 object rows + fp32 bias rows, no pair matrix
             R = 32
-            Xp, Vc, Vq, inj_l = _tables(x, q, plan, g_b, w0T, inj_w, torch.float16, B, n, k, Q, G)
+            Xp, Vc, Vq, inj_l = _tables(x, q, plan, g_b, w0T, inj_w, torch.float16, B, n, k, Q, G, coord)
             masks = Hs = None
             if keep_inputs:
                 Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L - 1)] + [None]
@@ -323,7 +326,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
     if w0T is not None and stop_at is None and layer_hook is None and wfrag is not None and len(wfrag) == plan.L:
         # factored first layer: two small tables instead of the pair matrix, K = 64 instead of 192 in layer 0
         G, L, R = plan.widths[-1], plan.L, 32
-        Xp, Vc, Vq, inj_l = _tables(x, q, plan, g_b, w0T, inj_w, dt, B, n, k, Q, G)
+        Xp, Vc, Vq, inj_l = _tables(x, q, plan, g_b, w0T, inj_w, dt, B, n, k, Q, G, coord)
         masks = Hs = None
         if keep_inputs:
             Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L - 1)] + [None]
@@ -335,6 +338,8 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
         if Hs is None:
             return [None] * L, None, xg
         return [None] + Hs[:-1], RRMasks(masks), xg
+    if coord is not None:
+        raise RuntimeError("internal: the coordinate table is only taken by the factored-first-layer paths")
     P = torch.empty(M, ld0, dtype=dt, device=dev)
     H.pair_build_fwd(x, q if inj == 0 else None, P, code, B, n, k, Q if inj == 0 else 0, ld0)
     if stop_at == 0:
@@ -426,11 +431,13 @@ def f_phi_forward(xg, fw, fb, mask, wT=None, label=None):
 
 
 class RelationalFunction(torch.autograd.Function):
-    """(x, q, dropout_mask | None, plan, packed, precision, label | None, g_w.., g_b.., f_w.., f_b..) -> log-probs (B, A),
-    or with `label` (int64 (B,)) -> (log-probs, mean NLL): the loss of train.py:41 rides in the f_phi launches."""
+    """(x, q, dropout_mask | None, plan, packed, precision, label | None, coord | None, g_w.., g_b.., f_w.., f_b..) -> log-probs
+    (B, A), or with `label` (int64 (B,)) -> (log-probs, mean NLL): the loss of train.py:41 rides in the f_phi launches.
+    coord (2, n) fp32: x is the conv grid viewed (B, n, k - 2) -- the coordinate tags of model.py:195-201 are applied inside
+    the kernels and the input gradient comes back in the grid's own layout (no concatenation, no slicing)."""
 
     @staticmethod
-    def forward(ctx, x, q, mask, plan, packed, precision, label, *params):
+    def forward(ctx, x, q, mask, plan, packed, precision, label, coord, *params):
         ctx.set_materialize_grads(False)
         L = plan.L
         g_w, g_b = params[0:L], params[L:2 * L]
@@ -441,6 +448,8 @@ class RelationalFunction(torch.autograd.Function):
         x = x.float() if x.dtype != torch.float32 else x
         q = q.float().contiguous() if (q.dtype != torch.float32 or not q.is_contiguous()) else q
         B, n, k = x.shape
+        if coord is not None:
+            k += coord.shape[0]
         Q = q.shape[1]
         M = B * n * n
         dev = x.device
@@ -454,6 +463,8 @@ class RelationalFunction(torch.autograd.Function):
         inj_fwd = inj_chain_ok(plan, code, n, k, M)        # question injected at layer 2: same chains, per-question bias row
         if inj_fwd:
             rr_only = alg_fwd = True
+        if coord is not None and not alg_fwd:
+            raise RuntimeError("internal: a coordinate table was passed but the factored-first-layer path does not apply (grid_fast_path)")
         wfwd, wbwd = packed.get(plan, g_w, code, split=f16s, bwd_images=need_grad, rr_only=rr_only, f_w=f_w,
                                 alg0_k=k if alg_fwd else 0, inj=plan.inject if inj_fwd else 0)
         gb = [b.detach().contiguous() for b in g_b]
@@ -464,7 +475,7 @@ class RelationalFunction(torch.autograd.Function):
         inputs, HL, xg = g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad,
                                          split=(packed.hi, packed.lo) if f16s else None,
                                          wfrag=(packed.frag_hi, packed.frag_lo) if f16s else packed.frag,
-                                         w0T=packed.w0T if alg_fwd else None, inj_w=inj_w)
+                                         w0T=packed.w0T if alg_fwd else None, inj_w=inj_w, coord=coord)
         G = plan.widths[-1]
         if xg is None:
             xg = torch.empty(B, G, dtype=torch.float32, device=dev)
@@ -484,6 +495,7 @@ class RelationalFunction(torch.autograd.Function):
         if need_grad:
             ctx.plan, ctx.code, ctx.dims = plan, code, (B, n, k, Q, M, G, F1, F2, A)
             ctx.inj_path = inj_fwd
+            ctx.coord = coord
             ctx.inputs, ctx.HL, ctx.wbwd = inputs, HL, wbwd
             ctx.fragT = list(packed.fragT)
             ctx.g_w = [w.detach() for w in g_w]
@@ -651,7 +663,7 @@ class RelationalFunction(torch.autograd.Function):
                 def _wgrad0():
                     gW[0] = torch.empty(N, kt, **f32)
                     gB[0] = torch.empty(N, **f32)
-                    H.wgrad0_from_reductions(Rj, Ri, Rq, x, q if plan.inject == 0 else None, gW[0], gB[0])
+                    H.wgrad0_from_reductions(Rj, Ri, Rq, x, q if plan.inject == 0 else None, gW[0], gB[0], coord=ctx.coord)
                 if overlap:                                        # off the critical path: onto the wgrad stream
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
@@ -659,11 +671,16 @@ class RelationalFunction(torch.autograd.Function):
                     # x and q too: they are alive only through this node's saved tensors, which autograd releases as soon as
                     # backward() returns -- the caching allocator would hand their blocks to the conv / LSTM backward that the
                     # main stream runs next while this side-stream kernel still reads them (seen as a wrong dW_0 on a busy GPU)
-                    keep.append([Rj, Ri, Rq, x, q])
+                    keep.append([Rj, Ri, Rq, x, q, ctx.coord])
                 else:
                     _wgrad0()
             if l == 0 and fused_tail:
-                dx = torch.empty(B, n, k, **f32)
+                if ctx.coord is not None:
+                    # the gradient goes straight into the conv grid's layout (B, k - 2, n): the two coordinate columns carry
+                    # none (model.py:216) and autograd's view-backward hands the conv stack a contiguous tensor
+                    dx = torch.empty(B, x.shape[2], n, **f32).permute(0, 2, 1)
+                else:
+                    dx = torch.empty(B, n, k, **f32)
                 if plan.inject == 0:
                     H.pair_dx_dq(Rj, Ri, Rq, wl, dx, dq, B, n, k, Q, N)                    # dx and dq in one launch
                 else:
@@ -681,16 +698,26 @@ class RelationalFunction(torch.autograd.Function):
                 dZ = dZp
             inputs[l] = None
         ctx.inputs = None
-        grads = [dx if ctx.needs_input_grad[0] else None, dq if ctx.needs_input_grad[1] else None, None, None, None, None, None]
+        grads = [dx if ctx.needs_input_grad[0] else None, dq if ctx.needs_input_grad[1] else None, None, None, None, None, None, None]
         grads += gW + gB + [dW1, dW2, dW3, db1, db2, db3]
         return tuple(grads)
 
 
-def relational_forward(x, q, mask, plan, packed, precision, g_w, g_b, f_w, f_b, label=None):
+def relational_forward(x, q, mask, plan, packed, precision, g_w, g_b, f_w, f_b, label=None, coord=None):
     """-> log-probs, or (log-probs, mean NLL) when `label` is given."""
     if precision not in PRECISIONS:
         raise ValueError("precision must be one of %r" % (PRECISIONS,))
-    return RelationalFunction.apply(x, q, mask, plan, packed, precision, label, *g_w, *g_b, *f_w, *f_b)
+    return RelationalFunction.apply(x, q, mask, plan, packed, precision, label, coord, *g_w, *g_b, *f_w, *f_b)
+
+
+def grid_path_ok(plan: LayerPlan, precision, B, n, k):
+    """Shapes / modes whose kernels take the conv grid + the coordinate table directly (the factored-first-layer paths)."""
+    if precision not in ("bf16", "f16s") or os.environ.get("RN_NO_GRID_FAST", "0") == "1":
+        return False
+    code, M = H.RN_BF16, B * n * n
+    if inj_chain_ok(plan, code, n, k, M):
+        return True
+    return (alg0_forward_ok(plan, code, n, k, M) and alg0_wgrad_ok(plan, k) and os.environ.get("RN_NO_FUSED_PAIR_TAIL", "0") != "1")
 
 
 _ZEROS = {}

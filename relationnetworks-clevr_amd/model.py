@@ -169,10 +169,20 @@ class RelationalLayer(RelationalLayerBase):
     def _hooked(self):
         return self.extraction or any(len(l._forward_hooks) for l in self.g_layers)
 
-    def forward(self, x, qst, label=None):
+    def grid_fast_path(self, b, n, k):
+        """True when RN.forward may hand over the conv grid and the coordinate table separately (coordinate tagging inside
+        the kernels, model.py:195-201) instead of the concatenated (B, n, k) objects."""
+        if self._hooked() or 2 * k != self.in_size:
+            return False
+        return RF.grid_path_ok(self._plan(k), self.resolved_precision(b, n, k), b, n, k)
+
+    def forward(self, x, qst, label=None, coord=None):
         """label (int64 (B,), optional, not part of the reference signature): also return the mean NLL of train.py:41,
-        computed inside the f_phi launches -> (log_probs, loss)."""
+        computed inside the f_phi launches -> (log_probs, loss).  coord ((2, n) fp32, optional, only with grid_fast_path):
+        x then holds the conv features only, (B, n, k - 2)."""
         b, d, k = x.size()
+        if coord is not None:
+            k += coord.shape[0]
         plan = self._plan(k)
         if self._hooked():
             out = self._forward_hook_compat(x, qst, plan)
@@ -182,7 +192,8 @@ class RelationalLayer(RelationalLayerBase):
         f_w = [self.f_fc1.weight, self.f_fc2.weight, self.f_fc3.weight]
         f_b = [self.f_fc1.bias, self.f_fc2.bias, self.f_fc3.bias]
         mask = self._dropout_mask(b, x.device)
-        return RF.relational_forward(x, qst, mask, plan, self._packed, self.resolved_precision(b, d, k), g_w, g_b, f_w, f_b, label=label)
+        return RF.relational_forward(x, qst, mask, plan, self._packed, self.resolved_precision(b, d, k), g_w, g_b, f_w, f_b, label=label,
+                                     coord=coord)
 
     def resolved_precision(self, b, d, k):
         """The arithmetic mode a forward pass on (b, d, k) objects runs in: `self.precision`, with "auto" resolved to
@@ -257,6 +268,7 @@ class RN(nn.Module):
         super().__init__()
         self.coord_tensor = None
         self._coord_cache = {}                 # (b, d, device) -> (b, 2, d*d); entries are never evicted (see _coords)
+        self._coord_tables = {}                # (d, device) -> (2, d*d): the batch-independent table the kernels read
         self._side_stream = None
         self.overlap_streams = os.environ.get("RN_OVERLAP_STREAMS", "1") != "0"
         self.on_gpu = False
@@ -293,6 +305,17 @@ class RN(nn.Module):
         self.coord_tensor = ct                 # the reference's attribute: the tensor of the latest forward
         return ct
 
+    def _coord_table(self, d, device):
+        """(2, d*d) fp32: row 0 = x = lin[p % d], row 1 = y = lin[p // d] (build_coord_tensor for one sample), kept for the
+        life of the module (a captured hipGraph reads it)."""
+        key = (d, device)
+        ct = self._coord_tables.get(key)
+        if ct is None:
+            keep = self.coord_tensor
+            ct = self._coord_tables[key] = self.build_coord_tensor(1, d, device).view(2, d * d).contiguous()
+            self.coord_tensor = keep
+        return ct
+
     def _text_on_side_stream(self, qst_idxs):
         """The LSTM is a serial chain of ~20 tiny kernels that leaves the chip empty; fork it onto a
         second HIP stream so it (and, through autograd's stream bookkeeping, its backward) overlaps
@@ -314,6 +337,7 @@ class RN(nn.Module):
 
     def forward(self, img, qst_idxs, label=None):
         side = None
+        coord = None
         if self.overlap_streams and qst_idxs.is_cuda and not self.state_desc:
             qst, side = self._text_on_side_stream(qst_idxs)
         if self.state_desc:
@@ -321,7 +345,14 @@ class RN(nn.Module):
         else:
             x = self.conv(img)                                  # (B, 24, d, d)
             b, k, d, _ = x.size()
-            x = torch.cat([x.view(b, k, d * d), self._coords(b, d, x.device)], 1).permute(0, 2, 1)   # (B, d*d, 26) strided view
+            coord = None
+            if self.rl.grid_fast_path(b, d * d, k + 2):
+                # no concatenation: the relation kernels read the grid through this strided view and tag the coordinates
+                # themselves; the input gradient comes back in the grid's layout
+                coord = self._coord_table(d, x.device)
+                x = x.view(b, k, d * d).permute(0, 2, 1)        # (B, d*d, 24)
+            else:
+                x = torch.cat([x.view(b, k, d * d), self._coords(b, d, x.device)], 1).permute(0, 2, 1)   # (B, d*d, 26) strided view
         if side is None:
             qst = self.text(qst_idxs)
         else:
@@ -331,6 +362,8 @@ class RN(nn.Module):
             ahead = getattr(self.rl, "_mask_ahead", None)
             if ahead is not None:
                 ahead[1].record_stream(cur)
+        if not self.state_desc and coord is not None:
+            return self.rl(x, qst, label=label, coord=coord)
         return self.rl(x, qst) if label is None else self.rl(x, qst, label=label)
 
     @torch.no_grad()

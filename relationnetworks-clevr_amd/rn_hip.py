@@ -37,7 +37,7 @@ SIGNATURES = {
     "rn_g_chain_fwd_rr": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_f16s": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _I, _P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_g_linear_bwd_wgrad_gated": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -52,9 +52,9 @@ SIGNATURES = {
     "rn_g_linear_bwd_wgrad": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_pair_reduce_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_reduce_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "rn_pair_dx_dq": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_pair_dx_dq": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _I, _I, _I, _I, _I, _P]),
     "rn_wgrad0_ws_bytes": (_Z, [_I, _I, _I]),
-    "rn_wgrad0_from_reductions": (_I, [_P, _P, _P, _P, _L, _L, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_wgrad0_from_reductions": (_I, [_P, _P, _P, _P, _L, _L, _L, _P, _I, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_gemm_f32": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _P, _L, _P, _L, _I, _P]),
     "rn_log_softmax_fwd": (_I, [_P, _P, _I, _I, _P]),
     "rn_log_softmax_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
@@ -276,13 +276,14 @@ def g_chain_fwd_rr(P, ldp, Wfs, biases, Hs, masks, K0, xg_part, M, G):
 
 
 @_timed("pair_build")
-def pair_tables(x, q, W0T, b0, Xp, Vc, B, n, k, Q, N):
-    """Tables of the factored first layer: Xp (B*n, 64) bf16 object rows, Vc (B*n, N) fp32 bias rows (rn_pair_tables)."""
+def pair_tables(x, q, W0T, b0, Xp, Vc, B, n, k, Q, N, coord=None):
+    """Tables of the factored first layer: Xp (B*n, 64) bf16 object rows, Vc (B*n, N) fp32 bias rows (rn_pair_tables).
+    coord (k - kf, n) fp32: x holds only the first kf = x.shape[2] columns, the coordinate tags come from the table."""
     _dev(x, "x")
     sx = x.stride()
     xdt = RN_F16 if Xp.dtype == torch.float16 else RN_BF16
-    _check(load().rn_pair_tables(x.data_ptr(), sx[0], sx[1], sx[2], _ptr(q), q.stride(0) if q is not None else 0, W0T.data_ptr(),
-                                 b0.data_ptr(), Xp.data_ptr(), xdt, Vc.data_ptr(), B, n, k, Q, N, _stream()), "rn_pair_tables")
+    _check(load().rn_pair_tables(x.data_ptr(), sx[0], sx[1], sx[2], _ptr(coord), x.shape[2], _ptr(q), q.stride(0) if q is not None else 0,
+                                 W0T.data_ptr(), b0.data_ptr(), Xp.data_ptr(), xdt, Vc.data_ptr(), B, n, k, Q, N, _stream()), "rn_pair_tables")
 
 
 @_timed("g_fwd")
@@ -416,18 +417,22 @@ def pair_reduce_bwd(dZ, lddz, Rj, Ri, Rq, code, B, n, G):
 
 @_timed("pair_reduce")
 def pair_dx_dq(Rj, Ri, Rq, W0, dx, dq, B, n, k, Q, N):
-    _check(load().rn_pair_dx_dq(Rj.data_ptr(), Ri.data_ptr(), _ptr(Rq), W0.data_ptr(), dx.data_ptr(), _ptr(dq), B, n, k, Q, N, _stream()),
-           "rn_pair_dx_dq")
+    """dx: any (B, n, kout <= k) tensor / view -- its strides say where the gradient goes (e.g. a permuted view of a
+    (B, 24, n) buffer: the conv grid's own layout, coordinate columns dropped)."""
+    sd = dx.stride()
+    _check(load().rn_pair_dx_dq(Rj.data_ptr(), Ri.data_ptr(), _ptr(Rq), W0.data_ptr(), dx.data_ptr(), sd[0], sd[1], sd[2], dx.shape[2], _ptr(dq),
+                                B, n, k, Q, N, _stream()), "rn_pair_dx_dq")
 
 
 @_timed("g_wgrad")
-def wgrad0_from_reductions(Rj, Ri, Rq, x, q, dW0, db0):
-    B, n, k = x.shape
+def wgrad0_from_reductions(Rj, Ri, Rq, x, q, dW0, db0, coord=None):
+    B, n, kf = x.shape
+    k = kf + (coord.shape[0] if coord is not None else 0)      # coord (k - kf, n): the coordinate tags are not part of x
     N, Q = Rj.shape[1], (q.shape[1] if q is not None else 0)      # q None: no question columns in layer 0 (Rq still gives db0)
     lib = load()
     ws = torch.empty(max(lib.rn_wgrad0_ws_bytes(B, n, N), 16), dtype=torch.uint8, device=Rj.device)
     sx = x.stride()
-    _check(lib.rn_wgrad0_from_reductions(Rj.data_ptr(), Ri.data_ptr(), _ptr(Rq), x.data_ptr(), sx[0], sx[1], sx[2], _ptr(q),
+    _check(lib.rn_wgrad0_from_reductions(Rj.data_ptr(), Ri.data_ptr(), _ptr(Rq), x.data_ptr(), sx[0], sx[1], sx[2], _ptr(coord), kf, _ptr(q),
                                          q.stride(0) if q is not None else 0, dW0.data_ptr(), db0.data_ptr(), ws.data_ptr(), B, n, k, Q, N,
                                          _stream()), "rn_wgrad0_from_reductions")
 

@@ -376,3 +376,39 @@ def test_stress_config_real_dispatch(pkg, precision):
     lp_p, _, dx_p, dq_p = run(np.ascontiguousarray(x[:, perm]), q, labt)
     assert gold.rel_err(lp_p, lp) <= ptol
     assert l2rel(dx_p, dx[:, perm]) <= gt and l2rel(dq_p, dq) <= gt
+
+
+@pytest.mark.parametrize("cfg", ["original-fp", "ir-fp"])
+@pytest.mark.parametrize("precision", ["auto", "bf16"])
+def test_fused_coordinate_tagging_equals_the_concatenated_path(pkg, cfg, precision):
+    """RN.forward hands the conv grid and the (2, n) coordinate table to the kernels separately (rn_pair_tables /
+    rn_wgrad0_from_reductions tag the coordinates themselves, rn_pair_dx_dq writes the gradient in the grid's layout); with
+    RN_NO_GRID_FAST=1 it concatenates like the reference (model.py:195-201).  Same arithmetic on the same values: log-probs,
+    loss and EVERY gradient must be bitwise equal."""
+    class Args:
+        qdict_size = formula.QDICT
+        adict_size = formula.ADICT
+
+    img = torch.from_numpy(formula.hash_uniform((8, 3, 128, 128), 321, 0.0, 1.0)).cuda()
+    qst = torch.from_numpy(formula.hash_ints((8, 20), 322, 1, formula.QDICT + 1)).cuda()
+    lab = torch.from_numpy(formula.hash_ints((8,), 323, 0, formula.ADICT)).cuda()
+
+    def run(fast):
+        os.environ["RN_NO_GRID_FAST"] = "0" if fast else "1"
+        try:
+            torch.manual_seed(9)
+            m = pkg.RN(Args, dict(formula.HYP[cfg], precision=precision, dropout=0.0)).cuda()
+            m.train()
+            assert m.rl.grid_fast_path(8, 64, 26) == fast
+            lp, loss = m.forward_loss(img, qst, lab)
+            loss.backward()
+            torch.cuda.synchronize()
+            return lp.detach().clone(), float(loss.detach()), {n_: p_.grad.clone() for n_, p_ in m.named_parameters()}
+        finally:
+            os.environ.pop("RN_NO_GRID_FAST", None)
+
+    lp_a, loss_a, g_a = run(True)
+    lp_b, loss_b, g_b = run(False)
+    assert torch.equal(lp_a, lp_b) and loss_a == loss_b
+    for n_ in g_b:
+        assert torch.equal(g_a[n_], g_b[n_]), n_
