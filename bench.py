@@ -284,11 +284,16 @@ def main():
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     if dry:
         return dry_run(args, world, rank, backend)
+    if os.environ.get("RN_BENCH_SAME_GPU", "0") == "1":     # tests: every rank on device 0 (with RN_BENCH_BACKEND=gloo: RCCL refuses that)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend, device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import relationnetworks_clevr_amd as pkg
     from relationnetworks_clevr_amd import dp

@@ -156,3 +156,27 @@ def test_two_ranks_on_one_gpu_equal_one_rank_on_the_whole_batch(tmp_path, cfg):
         errs[k] = (e, float(db.norm()), float(da.norm()))
     bad = {k: v for k, v in errs.items() if v[0] > 3e-2}
     assert not bad, "relative update error (err, |ref update|, |2-rank update|): %r" % (sorted(errs.items(), key=lambda kv: -kv[1][0])[:8],)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The REAL N > 1 path of bench.py -- graph-replayed train step per rank, gradient all-reduce, fused 1/world + clip + Adam,
+    barrier-bracketed timed region, MAX over ranks, kernel-timing passes on every rank, one JSON line from rank 0 -- launched
+    exactly as the driver launches it (torch.distributed.run, 2 ranks), both ranks on this GPU with gloo carrying the bucket
+    (RN_BENCH_SAME_GPU=1, RN_BENCH_BACKEND=gloo).  Throughput of two processes sharing one GPU is meaningless; the line's
+    shape and bookkeeping are what is checked."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, RN_BENCH_SAME_GPU="1", RN_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2" and d["dtype"] == "f16s"
+    assert abs(d["value"] - 2 * 64 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
+    assert np.isfinite(d["loss"]) and "roofline" in d and "cpu_baseline" not in d and "parity" not in d
