@@ -47,7 +47,7 @@ def time_step(tr, batch, steps=30, warm=6):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--precision", default="auto")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--hw", type=int, default=128)
     ap.add_argument("--only", default="")
