@@ -372,6 +372,8 @@ def main():
                                    % (args.config, B, d, d, n, M, args.hw, args.hw),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "precision_requested": args.precision, "precision_resolved": prec,
+                       "wgrad_activation_copies": ("e4m3 (H_0..2 kept for dW_1..3 only; RN_H8=0: 16-bit)"
+                                                   if prec in ("bf16", "f16s") and os.environ.get("RN_H8", "1") != "0" else "as the mode's storage type"),
                        "launch": "hipGraph replay of fwd+bwd, eager all-reduce/clip/Adam" if use_graph else "eager"},
             "loss": float(loss.detach()),
         }

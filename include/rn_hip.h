@@ -35,7 +35,8 @@ extern "C" {
 
 #define RN_ABI_VERSION 1
 
-enum { RN_BF16 = 0, RN_F32 = 1, RN_F16 = 2 };   /* RN_F16: pair matrix / split weights of the f16s forward only */
+enum { RN_BF16 = 0, RN_F32 = 1, RN_F16 = 2, RN_FP8 = 3 };   /* RN_F16: pair matrix / split weights of the f16s forward only;
+                                                             * RN_FP8: OCP e4m3 copies of the stored activations (h_dtype / a_dtype) */
 
 /* rn_gemm_f32 flags */
 enum { RN_RELU = 1, RN_ACCUMULATE = 2 };
@@ -142,8 +143,9 @@ int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* con
  * (M / rows_per_question, 256) fp32 -- bitwise the matrix rn_g_chain_bwd_rr stores as dZ[0], which may then be passed as
  * NULL there (nothing else reads it).  dW (256, 256) = dZ_3^T A, db = column sums; A = H_2 (M, lda) bf16;
  * ws = rn_wgrad_ws_bytes(M, 256, 256).  rows_per_question % 64 == 0. */
-int rn_g_linear_bwd_wgrad_gated(const void* mask, const float* dxg, int rows_per_question, const void* A, int lda, float* dW,
-                                float* db, void* ws, int M, int N, int K, void* stream);
+/* a_dtype = RN_BF16, or RN_FP8: A holds the e4m3 bytes written by rn_g_chain_fwd_rr*_alg0 with h_dtype = RN_FP8 (lda in elements). */
+int rn_g_linear_bwd_wgrad_gated(const void* mask, const float* dxg, int rows_per_question, const void* A, int lda, int a_dtype,
+                                float* dW, float* db, void* ws, int M, int N, int K, void* stream);
 
 /* MFMA-fragment-major weight image for rn_g_chain_fwd_rr: dst (65536 bf16) gets, for output block ob,
  * K16 step ks, lane, element e:  src[32 ob + lane % 32][kidx] (0 beyond R rows / C columns) with
@@ -192,7 +194,9 @@ int rn_g_linear_bwd_dgrad(const void* dZ, int lddz, const void* Wt, int ldwt, co
  * dW: fp32 (N, Ktrue) contiguous (nn.Linear layout); db: fp32 (N).
  * Deterministic: split over M into per-block partials in ws, then an ordered reduction. */
 size_t rn_wgrad_ws_bytes(int M, int N, int K);
-int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, int lda, float* dW, float* db, void* ws,
+/* a_dtype: the type of A -- `dtype` (the type of dZ), or RN_FP8 with dtype = RN_BF16: the e4m3 activation copies of the
+ * forward chains (N == K == Ktrue == 256, M % 64 == 0, M >= 4096; lda in elements = bytes). */
+int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, int lda, int a_dtype, float* dW, float* db, void* ws,
                           int dtype, int M, int N, int K, int Ktrue, void* stream);
 
 /* Backward of the pair expansion, algebraic form: reduce the gradient
@@ -358,11 +362,14 @@ int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* co
  * model.py:131-142; tables built with Q = 0): layer 2's input is [H_1 | q[b]], i.e. W_2 [H_1 | q] + b_2 =
  * W_2[:, 0:256] H_1 + Vq[b] with Vq (B, 256) fp32 = W_2[:, 256:] q[b] + b_2 prepared by the caller (one small rn_gemm_f32);
  * Wf[2] / Whi[2], Wlo[2] hold W_2[:, 0:256] only, bias[2] is ignored.  Needs n*n % 256 == 0. */
+/* h_dtype: the type of the stored H_0..2 rows -- RN_BF16 (M x 256 bf16) or RN_FP8 (M x 256 e4m3 bytes, value = byte value; the
+ * only reader is rn_g_linear_bwd_wgrad(_gated) with a_dtype = RN_FP8).  Ignored when H is NULL. */
 int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, const void* const* Whi, const void* const* Wlo,
-                                const float* const* bias, void* const* H, void* const* mask, float* xg_part, const float* Vq,
-                                int inject_layer, int M, int L, int G, void* stream);
+                                const float* const* bias, void* const* H, int h_dtype, void* const* mask, float* xg_part,
+                                const float* Vq, int inject_layer, int M, int L, int G, void* stream);
 int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, const void* const* Wf, const float* const* bias, void* const* H,
-                           void* const* mask, float* xg_part, const float* Vq, int inject_layer, int M, int L, int G, void* stream);
+                           int h_dtype, void* const* mask, float* xg_part, const float* Vq, int inject_layer, int M, int L, int G,
+                           void* stream);
 
 #ifdef __cplusplus
 }

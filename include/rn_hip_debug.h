@@ -9,6 +9,14 @@ extern "C" {
 /* Raw lane mapping of ds_read_b64_tr_b16 (tests/test_gpu_kernels.py pins the layout the wgrad kernel relies on). */
 int rn_probe_tr16(const unsigned short* in4096, unsigned short* out256, void* stream);
 
+/* ... and of ds_read_b64_tr_b8 (the e4m3 operand of the streaming wgrad): lane l supplies &lds[8 l] of a linear 4096-byte image. */
+int rn_probe_tr8(const unsigned char* in4096, unsigned char* out512, void* stream);
+
+/* The e4m3 conversions of the kernels at a power-of-two `scale`: out8_bf16 / out8_f16 (n bytes each) = the down-conversion of
+ * bf16(in) / fp16(in) (v_cvt_scalef32_pk_fp8_bf16 / _f16), back (n floats) = the up-conversion of out8_bf16
+ * (v_cvt_scalef32_pk_bf16_fp8).  n % 4 == 0. */
+int rn_probe_fp8_cvt(const float* in, float scale, void* out8_bf16, void* out8_f16, float* back, int n, void* stream);
+
 /* A one-thread kernel that stores the constant-rate wall clock (wall_clock64) into *slot, in stream order.
  * Captured between the kernels of the step's hipGraph it yields a concurrent multi-stream timeline (tools/step_timeline.py). */
 int rn_debug_stamp(unsigned long long* slot, void* stream);

@@ -235,14 +235,14 @@ extern "C" int rn_pack_matrix_frag_many(const float* const* src, const long* sr,
 // stay in flight: the requests of the five stages in between plus whatever else those stages issue (stores,
 // next-tile row loads).  The models below give a LOWER bound of that number per site -- waiting for more than
 // necessary is always safe, waiting for less is a race.
-template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false, int INJ = 0>
+template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false>
 struct FwdVm {
   static constexpr int PF_PER = (NK0 + 7) / 8;                       // next-tile row loads per stage of the last layer
   static constexpr int VC_STAGE = (RR_L - 1) * 8 + 4;                // ALG0: the stage that requests the next tile's bias row
   static constexpr int VQ_STAGE = (RR_L - 1) * 8 + 2;                // INJ: ... and the next tile's question row of layer INJ
   static constexpr int ops(int sidx) {                                // VMEM operations a stage issues (per wave)
     int k = RR_DPW;
-    if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += 2;
+    if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += H8 ? (((sidx - 2) & 1) ? 2 : 0) : 2;   // e4m3 copies leave two blocks at a time
     if ((sidx >> 3) == RR_L - 1)
       for (int c = 0; c < PF_PER; ++c) k += ((sidx & 7) * PF_PER + c < NK0) ? 1 : 0;
     if (ALG0 && sidx == VC_STAGE) k += 1;
@@ -279,14 +279,20 @@ struct BwdVm {
 //   constant -- Vq[b][256], fp32, one small product on the host side -- and takes the place of the layer's bias row in LDS
 //   for the tile (a 256-row tile lies inside one question: n*n % 256 == 0).  The row of the next tile is fetched during the
 //   last layer and written at the tile's tail, when no wave reads the old one any more.
-template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0>
+// H8 -- the H_l copies for the weight gradient leave as OCP e4m3 bytes (rn_common.h): the packed bf16 pairs of a group are
+//   converted once more (clamp + two v_cvt_scalef32_pk_fp8_bf16) and TWO blocks share a staging row (64 B) and leave together
+//   after the odd one, in the same two 16-byte stores per lane as a bf16 block -- a row must receive 64 contiguous bytes per
+//   store instruction: 32-byte pieces (one block at a time) ran the kernel at half its speed (270 us instead of 126).
+//   Half the bytes written here and read back by the weight-gradient kernel.
+template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restrict__ P, int ldp, RRArgs a,
                                                            float* __restrict__ xg_part, int ntiles,
                                                            const float* __restrict__ Vc = nullptr, int n_obj = 0,
                                                            const float* __restrict__ Vq = nullptr, int rows_per_b = 1) {
   static_assert(NK0 % 4 == 0 && NK0 >= 4 && NK0 <= 16, "layer-0 reduction length");
   static_assert(INJ >= 0 && INJ < RR_L - 1, "the injected layer is one of the swapped-operand layers");
-  typedef FwdVm<NK0, STORE, ST3, XG, ALG0, INJ> Vm;
+  static_assert(!H8 || (STORE && !ST3), "e4m3 copies: H_0..2 only");
+  typedef FwdVm<NK0, STORE, ST3, XG, ALG0, INJ, H8> Vm;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
   k.init(lds);
@@ -381,7 +387,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
         pk[j][1] = relu_pack_bf16(c[4 * j + 2], c[4 * j + 3]);
       }
       if (phase_lo <= 2 && 2 <= phase_hi) {
-        if constexpr (STORE) *reinterpret_cast<u32x2*>(stg + n * RR_SRS + 16 * j + 8 * h) = pk[j];
+        if constexpr (H8) *reinterpret_cast<unsigned*>(stg + n * RR_SRS + 32 * (pob & 1) + 8 * j + 4 * h) = rn_fp8x4_from_bf16(pk[j][0], pk[j][1]);
+        else if constexpr (STORE) *reinterpret_cast<u32x2*>(stg + n * RR_SRS + 16 * j + 8 * h) = pk[j];
         if (dst) {
           dst[2 * pob + (j >> 1)][(j & 1) * 2 + 0] = pk[j][0];
           dst[2 * pob + (j >> 1)][(j & 1) * 2 + 1] = pk[j][1];
@@ -392,8 +399,14 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
 #pragma unroll
       for (int q = 0; q < 2; ++q) co[q] = *reinterpret_cast<const u32x4*>(stg + (16 * q + (lane >> 2)) * RR_SRS + (lane & 3) * 16);
     };
-    const unsigned orow_off = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
+    const unsigned orow_off = H8 ? (unsigned)((lane >> 2) * RR_G + (lane & 3) * 16) : (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
     auto co_store = [&](int cl, int cob, int q) {
+      if constexpr (H8) {                                             // blocks cob - 1, cob: row 16 q + lane / 4, features 32 (cob - 1) + 16 (lane % 4) .. + 15
+        gbl_u8* base8 = (gbl_u8*)(reinterpret_cast<unsigned char*>(a.out[cl]) + m0w * RR_G);
+        asm volatile("" : "+s"(base8));
+        __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base8 + orow_off + 16 * q * RR_G + 32 * (cob & ~1)));
+        return;
+      }
       gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.out[cl] + m0w * RR_G);
       asm volatile("" : "+s"(base));
       // non-temporal: read back only by the backward pass; in L2 it would evict the weight images
@@ -428,7 +441,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
       constexpr bool has_prev = sidx > 0;                             // (l, ob) == (0, 0): the tail of the last tile did it
       constexpr int pl = ob ? l : l - 1, pob = ob ? ob - 1 : 7;
       constexpr int cl = (sidx - 2) >> 3, cob = (sidx - 2) & 7;
-      constexpr bool has_co = STORE && sidx >= 2 && (cl < RR_L - 1 || ST3);
+      constexpr bool has_co = STORE && sidx >= 2 && (cl < RR_L - 1 || ST3) && (!H8 || (cob & 1));
       constexpr int didx = sidx + RR_LA;                              // stage whose weights are requested now
       constexpr int dl = (didx >> 3) & 3, dob = didx & 7;
       constexpr int nob = (sidx + 1) & 7;                             // next stage (the read-ahead crosses into it)
@@ -567,14 +580,14 @@ __device__ __forceinline__ unsigned relu_pack_f16(float a, float b) {     // sat
   x = __builtin_elementwise_max(x, z);
   return __builtin_bit_cast(unsigned, x);
 }
-template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false, int INJ = 0>
+template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false>
 struct F16Vm {
   static constexpr int PF_PER = (NK0 + 7) / 8;
   static constexpr int VC_STAGE = (RR_L - 1) * 8 + 4;                // ALG0: the stage that requests the next tile's bias row
   static constexpr int VQ_STAGE = (RR_L - 1) * 8 + 2;                // INJ: ... and the next tile's question row of layer INJ
   static constexpr int ops(int sidx) {
     int k = F_DPW;
-    if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += 2;
+    if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += H8 ? (((sidx - 2) & 1) ? 2 : 0) : 2;
     if ((sidx >> 3) == RR_L - 1)
       for (int c = 0; c < PF_PER; ++c) k += ((sidx & 7) * PF_PER + c < NK0) ? 1 : 0;
     if (ALG0 && sidx == VC_STAGE) k += 1;
@@ -598,13 +611,16 @@ struct F16Vm {
 // later layers cannot amplify, and measured on the released checkpoints it is immaterial for the question-at-layer-0
 // models: worst log-prob error over 24 questions 1.5e-4 with it off vs 1.2e-4 with it on (tools/dbg/emulate_split2.py;
 // the bar is 1e-3) -- while the layer-2-injected ("IR") models go from 5e-5 to 4e-4 and keep the second pass.
-template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0, bool LO3 = true>
+// H8: as in g_chain_rr_kernel -- the e4m3 copy is converted from the fp16 operand pair the group has just built (clamp + two
+// v_cvt_scalef32_pk_fp8_f16 instead of the separate bf16 rounding).
+template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0, bool LO3 = true, bool H8 = false>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __restrict__ P, int ldp, RRArgsF a,
                                                                 float* __restrict__ xg_part, int ntiles,
                                                                 const float* __restrict__ Vc = nullptr, int n_obj = 0,
                                                                 const float* __restrict__ Vq = nullptr, int rows_per_b = 1) {
   static_assert(INJ >= 0 && INJ < RR_L - 1, "the injected layer is one of the swapped-operand layers");
-  typedef F16Vm<NK0, STORE, ST3, XG, ALG0, INJ> Vm;
+  static_assert(!H8 || (STORE && !ST3), "e4m3 copies: H_0..2 only");
+  typedef F16Vm<NK0, STORE, ST3, XG, ALG0, INJ, H8> Vm;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
   k.init(lds);
@@ -700,21 +716,36 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
       const f32x16& c = acc[pob & 1];
       if (ph == 0) mask_out(pl, pob, j, c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]);
       if (ph == 1 && dst) {
-        dst[2 * pob + (j >> 1)][(j & 1) * 2 + 0] = relu_pack_f16(c[4 * j + 0], c[4 * j + 1]);
-        dst[2 * pob + (j >> 1)][(j & 1) * 2 + 1] = relu_pack_f16(c[4 * j + 2], c[4 * j + 3]);
+        const unsigned f0 = relu_pack_f16(c[4 * j + 0], c[4 * j + 1]), f1 = relu_pack_f16(c[4 * j + 2], c[4 * j + 3]);
+        dst[2 * pob + (j >> 1)][(j & 1) * 2 + 0] = f0;
+        dst[2 * pob + (j >> 1)][(j & 1) * 2 + 1] = f1;
+        if constexpr (H8) { pk[j][0] = f0; pk[j][1] = f1; }
       }
       if (ph == 2 && STORE) {
-        pk[j][0] = relu_pack_bf16(c[4 * j + 0], c[4 * j + 1]);
-        pk[j][1] = relu_pack_bf16(c[4 * j + 2], c[4 * j + 3]);
+        if constexpr (H8) {
+          pk[j][0] = rn_fp8x4_from_f16(pk[j][0], pk[j][1]);
+        } else {
+          pk[j][0] = relu_pack_bf16(c[4 * j + 0], c[4 * j + 1]);
+          pk[j][1] = relu_pack_bf16(c[4 * j + 2], c[4 * j + 3]);
+        }
       }
-      if (ph == 3 && STORE) *reinterpret_cast<u32x2*>(stg + n * RR_SRS + 16 * j + 8 * h) = pk[j];
+      if (ph == 3 && STORE) {
+        if constexpr (H8) *reinterpret_cast<unsigned*>(stg + n * RR_SRS + 32 * (pob & 1) + 8 * j + 4 * h) = pk[j][0];
+        else *reinterpret_cast<u32x2*>(stg + n * RR_SRS + 16 * j + 8 * h) = pk[j];
+      }
     };
     auto co_read = [&]() {
 #pragma unroll
       for (int q = 0; q < 2; ++q) co[q] = *reinterpret_cast<const u32x4*>(stg + (16 * q + (lane >> 2)) * RR_SRS + (lane & 3) * 16);
     };
-    const unsigned orow_off = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
+    const unsigned orow_off = H8 ? (unsigned)((lane >> 2) * RR_G + (lane & 3) * 16) : (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
     auto co_store = [&](int cl, int cob, int q) {
+      if constexpr (H8) {                                             // blocks cob - 1, cob: row 16 q + lane / 4, features 32 (cob - 1) + 16 (lane % 4) .. + 15
+        gbl_u8* base8 = (gbl_u8*)(reinterpret_cast<unsigned char*>(a.out[cl]) + m0w * RR_G);
+        asm volatile("" : "+s"(base8));
+        __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base8 + orow_off + 16 * q * RR_G + 32 * (cob & ~1)));
+        return;
+      }
       gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.out[cl] + m0w * RR_G);
       asm volatile("" : "+s"(base));
       __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2));
@@ -747,7 +778,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
       constexpr bool has_prev = sidx > 0;
       constexpr int pl = ob ? l : l - 1, pob = ob ? ob - 1 : 7;
       constexpr int cl = (sidx - 2) >> 3, cob = (sidx - 2) & 7;
-      constexpr bool has_co = STORE && sidx >= 2 && (cl < RR_L - 1 || ST3);
+      constexpr bool has_co = STORE && sidx >= 2 && (cl < RR_L - 1 || ST3) && (!H8 || (cob & 1));
       constexpr int didx = sidx + F_LA;
       constexpr int dl = (didx >> 3) & 3, dob = didx & 7;
       constexpr int slot = ob & 3, nslot = (ob + 1) & 3, dslot = (ob + F_LA) & 3;
@@ -1119,9 +1150,11 @@ static int rr_check_inject(const char* who, const float* Vq, int inj, int n) {
 }
 
 extern "C" int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, const void* const* Wf, const float* const* bias,
-                                      void* const* H, void* const* mask, float* xg_part, const float* Vq, int inject_layer,
+                                      void* const* H, int h_dtype, void* const* mask, float* xg_part, const float* Vq, int inject_layer,
                                       int M, int L, int G, void* stream) {
   RN_CHECK_ARG(Xp && Vc && Wf && bias && M > 0 && xg_part, "rn_g_chain_fwd_rr_alg0: bad pointer/size");
+  RN_CHECK_ARG(!H || h_dtype == RN_BF16 || h_dtype == RN_FP8, "rn_g_chain_fwd_rr_alg0: h_dtype must be RN_BF16 or RN_FP8 (got %d)", h_dtype);
+  const bool h8 = H && h_dtype == RN_FP8;
   if (int rc = rr_check_inject("rn_g_chain_fwd_rr_alg0", Vq, inject_layer, n)) return rc;
   RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_fwd_rr_alg0: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
   RN_CHECK_ARG(n > 0 && n % RR_WR == 0 && M % ((long)n * n) == 0 && M % RR_TM == 0,
@@ -1150,9 +1183,11 @@ extern "C" int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, co
   const int rpb = n * n;
   if (inject_layer == 2) {
     if (nh == 0) g_chain_rr_kernel<4, false, false, false, true, true, 2><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
+    else if (h8) g_chain_rr_kernel<4, true, false, true, true, true, 2, true><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
     else g_chain_rr_kernel<4, true, false, true, true, true, 2><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
   } else {
     if (nh == 0) g_chain_rr_kernel<4, false, false, false, true, true><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n);
+    else if (h8) g_chain_rr_kernel<4, true, false, true, true, true, 0, true><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n);
     else g_chain_rr_kernel<4, true, false, true, true, true><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n);
   }
   RN_LAUNCH_CHECK("rn_g_chain_fwd_rr_alg0");
@@ -1213,9 +1248,11 @@ extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* cons
 
 // f16s arithmetic on the factored first layer (see g_chain_rr_kernel, ALG0): Xp16 = fp16 object rows (B*n, 64).
 extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, const void* const* Whi, const void* const* Wlo,
-                                           const float* const* bias, void* const* H, void* const* mask, float* xg_part,
+                                           const float* const* bias, void* const* H, int h_dtype, void* const* mask, float* xg_part,
                                            const float* Vq, int inject_layer, int M, int L, int G, void* stream) {
   RN_CHECK_ARG(Xp16 && Vc && Whi && Wlo && bias && M > 0 && xg_part, "rn_g_chain_fwd_rr_f16s_alg0: bad pointer/size");
+  RN_CHECK_ARG(!H || h_dtype == RN_BF16 || h_dtype == RN_FP8, "rn_g_chain_fwd_rr_f16s_alg0: h_dtype must be RN_BF16 or RN_FP8 (got %d)", h_dtype);
+  const bool h8 = H && h_dtype == RN_FP8;
   if (int rc = rr_check_inject("rn_g_chain_fwd_rr_f16s_alg0", Vq, inject_layer, n)) return rc;
   RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_fwd_rr_f16s_alg0: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
   RN_CHECK_ARG(n > 0 && n % RR_WR == 0 && M % ((long)n * n) == 0 && M % RR_TM == 0,
@@ -1245,14 +1282,17 @@ extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, in
   const int rpb = n * n;
   if (inject_layer == 2) {
     if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true, 2><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
+    else if (h8) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 2, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
     else g_chain_rr_f16s_kernel<4, true, false, true, true, true, 2><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
   } else {
     const char* l3 = getenv("RN_F16S_LO3");                            // diagnostics: "1" keeps the second pass on the last layer
     if (l3 && l3[0] == '1') {
+      RN_CHECK_ARG(!(nh && h8), "rn_g_chain_fwd_rr_f16s_alg0: RN_F16S_LO3=1 (diagnostics) keeps bf16 copies only");
       if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
       else g_chain_rr_f16s_kernel<4, true, false, true, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
     } else {
       if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true, 0, false><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
+      else if (h8) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, false, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
       else g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, false><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
     }
   }

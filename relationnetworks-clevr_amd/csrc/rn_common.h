@@ -77,3 +77,46 @@ template <typename T> __device__ __forceinline__ bool is_pos(T v);
 template <> __device__ __forceinline__ bool is_pos<bf16>(bf16 v) { return (float)v > 0.f; }
 template <> __device__ __forceinline__ bool is_pos<float>(float v) { return v > 0.f; }
 template <> __device__ __forceinline__ bool is_pos<f16>(f16 v) { return (float)v > 0.f; }
+
+// ---- fp8 (OCP e4m3) copies of the stored activations ------------------------------------------------------------
+// The H_l rows the forward chains keep for the weight gradient are read once, by an HBM-bound kernel: one byte per element
+// instead of two.  gfx950's scaled conversions (v_cvt_scalef32_pk_*) take the scale as a power-of-two float: down-conversions
+// divide by it (round to nearest even; beyond 448 the result is the NaN byte 0x7f, not a saturated one), up-conversions
+// multiply (tests/test_gpu_kernels.py pins both).  The callers' values are post-ReLU, i.e. non-negative, so the clamp to
+// 448 * RN_H8_SCALE -- far above what the g layers produce: 11 on the released checkpoints -- is an unsigned 16-bit minimum
+// on the packed pair.
+constexpr float RN_H8_SCALE = 1.0f;
+typedef __attribute__((ext_vector_type(2))) short rn_s16x2;
+typedef __attribute__((ext_vector_type(2))) unsigned short rn_u16x2;
+__device__ __forceinline__ unsigned rn_pk_min_u16(unsigned v, unsigned short cap) {
+  const rn_u16x2 c = {cap, cap};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(rn_u16x2, v), c));   // v_pk_min_u16
+}
+// two packed NON-NEGATIVE bf16 pairs (features f..f+3) -> one dword of four e4m3 bytes
+__device__ __forceinline__ unsigned rn_fp8x4_from_bf16(unsigned lo, unsigned hi) {
+  static_assert(RN_H8_SCALE == 1.0f, "the clamp constants are 448 in bf16 / fp16");
+  lo = rn_pk_min_u16(lo, 0x43E0);
+  hi = rn_pk_min_u16(hi, 0x43E0);
+  rn_s16x2 r = {0, 0};
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, __builtin_bit_cast(bf16x2, lo), RN_H8_SCALE, false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, __builtin_bit_cast(bf16x2, hi), RN_H8_SCALE, true);
+  return __builtin_bit_cast(unsigned, r);
+}
+typedef __attribute__((ext_vector_type(2))) _Float16 rn_f16x2;
+__device__ __forceinline__ unsigned rn_fp8x4_from_f16(unsigned lo, unsigned hi) {
+  lo = rn_pk_min_u16(lo, 0x5F00);
+  hi = rn_pk_min_u16(hi, 0x5F00);
+  rn_s16x2 r = {0, 0};
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(rn_f16x2, lo), RN_H8_SCALE, false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(rn_f16x2, hi), RN_H8_SCALE, true);
+  return __builtin_bit_cast(unsigned, r);
+}
+// eight e4m3 bytes (two dwords, k ascending) -> the bf16x8 MFMA operand
+__device__ __forceinline__ bf16x8 rn_bf16x8_from_fp8(unsigned d0, unsigned d1) {
+  union { bf16x2 p[4]; bf16x8 v; } u;
+  u.p[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, RN_H8_SCALE, false);
+  u.p[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, RN_H8_SCALE, true);
+  u.p[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, RN_H8_SCALE, false);
+  u.p[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, RN_H8_SCALE, true);
+  return u.v;
+}

@@ -227,18 +227,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // step and column half, LDS-DMA into an 8-slot ring three steps ahead of their use) + the question's dxg row: every
 // thread builds two 16-byte chunks of the step's dZ tile (8 mask bits select among 8 pre-rounded bf16 values) and writes
 // them to the swizzled position the LDS-DMA would have used.  The A operand (H_2) streams as before.
-template <int KTW, bool GEN = false>   // 32-wide k tiles per wave: 2 -> KB = 128, 1 -> KB = 64
+// A8 -- the A operand (the stored activations H_{l-1}) arrives as OCP e4m3 bytes (rn_common.h, RN_H8_SCALE): half the bytes
+// of the operand that is two thirds of this kernel's traffic once dZ_3 is generated (GEN) and a third otherwise.  The tile is
+// 64 rows x 128 B; ONE ds_read_b64_tr_b8 hands a lane its column's 8 consecutive rows (the 16 lanes of a group supply an
+// 8-row x 16-byte block), four v_cvt_scalef32_pk_bf16_fp8 turn them into the bf16 MFMA operand -- exact, e4m3 is a subset
+// of bf16.  lda counts BYTES (= elements) then.
+// Measured and dropped (round 2): the same loop software-pipelined by half a step (the transpose reads of a half issued ahead of
+// the previous half's MFMAs, inline-asm reads with hand-placed lgkmcnt waits because hipcc turns its own into full drains at
+// the loop header): 69.5 / 62.6 us (bf16 / e4m3 A) against 64.8 / 62.1 for this loop on the same chip, the generated-operand
+// variant 87 against 70 -- with two waves per SIMD the LDS issue rate, not the read/MFMA phase order, sets the 57 us of
+// compute under the stream, and a fourth stage of look-ahead costs the second readers their L2 hits (84 / 78 us).
+template <int KTW, bool GEN = false, bool A8 = false>   // 32-wide k tiles per wave: 2 -> KB = 128, 1 -> KB = 64
 __global__ __launch_bounds__(512) void wgrad_stream_kernel(const bf16* __restrict__ dZ, int lddz, const bf16* __restrict__ A,
                                                            int lda, float* __restrict__ part, float* __restrict__ part_db,
                                                            int S, int Z, int NB, int Kpad, int abl,
                                                            const unsigned* __restrict__ gmask = nullptr,
                                                            const float* __restrict__ dxg = nullptr, int steps_per_q = 1) {
   static_assert(!GEN || KTW == 2, "generated operand: K == 256 only");
+  static_assert(!A8 || KTW == 2, "fp8 operand: K == 256 only");
   constexpr int KB = KTW * 64;                             // k block width
-  constexpr int ZB = 64 * 256, AB = 64 * KB * 2;           // bytes per stage: dZ tile (64 x 128 cols), A tile (64 x KB cols)
+  constexpr int ES = A8 ? 1 : 2;                           // bytes per A element
+  constexpr int ZB = 64 * 256, AB = 64 * KB * ES;          // bytes per stage: dZ tile (64 x 128 cols), A tile (64 x KB cols)
   constexpr int STG = ZB + AB, NSTG = 4, LA = 3;           // three stages (96 KB) in flight; a 5-stage ring measured slower
   constexpr int PPW = GEN ? AB / 1024 / 8 : (ZB + AB) / 1024 / 8;   // 1-KB LDS-DMA pieces per wave and stage (4 / 3; GEN: 2 + a mask slice)
-  constexpr int RBA = KB * 2;                              // A tile row bytes (256 / 128)
+  constexpr int RBA = KB * ES;                             // A tile row bytes (256 / 128; fp8: 128)
   constexpr int MSLOTS = 8, MLA = LA + 3;                  // GEN: mask ring, requested MLA steps ahead of the step that multiplies them
   __shared__ __attribute__((aligned(16))) unsigned char lds[NSTG * STG + (GEN ? MSLOTS * 1024 : 0)];
   typedef __attribute__((address_space(3))) unsigned char lds_u8;
@@ -255,7 +267,10 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const bf16* __restric
   const int zr = lane >> 4, zc = (lane & 15) ^ (4 * (zr & 3));
   const unsigned zoff = (unsigned)(zr * lddz * 2 + zc * 16);
   unsigned aoff;
-  if (KB == 128) {
+  if (A8) {
+    const int ar = lane >> 3, ac = lane & 7;
+    aoff = (unsigned)(ar * lda + ((((ac >> 1) ^ ((ar >> 1) & 3)) << 1) | (ac & 1)) * 16);
+  } else if (KB == 128) {
     aoff = (unsigned)(zr * lda * 2 + zc * 16);
   } else {
     const int ar = lane >> 3, ac = (lane & 7) ^ (4 * ((ar >> 1) & 1));
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const bf16* __restric
         off = zoff;
       } else {                                             // A piece: 1 KB = 4 rows x 256 B or 8 rows x 128 B
         const int qa = q - 16;
-        ub = reinterpret_cast<const unsigned char*>(A + (s * 64 + qa * (1024 / RBA)) * lda + kb * KB);
+        ub = reinterpret_cast<const unsigned char*>(A) + ((s * 64 + qa * (1024 / RBA)) * lda + kb * KB) * ES;
         off = aoff;
       }
       const unsigned dst = sb + q * 1024;
@@ -354,9 +369,14 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const bf16* __restric
   unsigned aaddr[KTW];
 #pragma unroll
   for (int kt = 0; kt < KTW; ++kt) {
-    const int acol = kg * (KTW * 32) + kt * 32 + cb * 16 + 4 * (i16 & 3);
-    const int sw = KB == 128 ? 4 * (fr & 3) : 4 * ((fr >> 1) & 1);
-    aaddr[kt] = (unsigned)(ZB + fr * RBA + (((acol >> 3) ^ sw) * 16) + (acol & 4) * 2);
+    if constexpr (A8) {
+      const int fr8 = rb * 8 + (i16 >> 1), pair = kg * KTW + kt;
+      aaddr[kt] = (unsigned)(ZB + fr8 * RBA + ((((pair ^ ((fr8 >> 1) & 3)) << 1) | cb) * 16) + 8 * (i16 & 1));
+    } else {
+      const int acol = kg * (KTW * 32) + kt * 32 + cb * 16 + 4 * (i16 & 3);
+      const int sw = KB == 128 ? 4 * (fr & 3) : 4 * ((fr >> 1) & 1);
+      aaddr[kt] = (unsigned)(ZB + fr * RBA + (((acol >> 3) ^ sw) * 16) + (acol & 4) * 2);
+    }
   }
 
   f32x16 acc[KTW];
@@ -393,8 +413,8 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const bf16* __restric
       // two steps see only the prologue's A pieces behind theirs (2 + 2); the last five steps (whose predecessors issued
       // fewer requests) drain
       if (s + 5 >= s1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (s < s0 + 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (s < s0 + 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW + 2) : "memory");
     } else {
       const long younger = (s1 - 1 - s) < (LA - 1) ? (s1 - 1 - s) : (LA - 1);
       if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
@@ -424,8 +444,15 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const bf16* __restric
       uz[kk].s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(st + kk * 16 * 256 + 4 * 256 + zaddr));
 #pragma unroll
       for (int kt = 0; kt < KTW; ++kt) {
-        ua[kk][kt].s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(st + kk * 16 * RBA + aaddr[kt]));
-        ua[kk][kt].s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(st + kk * 16 * RBA + 4 * RBA + aaddr[kt]));
+        if constexpr (A8) {
+          typedef __attribute__((ext_vector_type(2))) int i32x2_;
+          typedef __attribute__((address_space(3))) i32x2_* lptr8;
+          const i32x2_ r8 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lptr8)(st + kk * 16 * RBA + aaddr[kt]));
+          ua[kk][kt].s.a = __builtin_bit_cast(s16x4, r8);
+        } else {
+          ua[kk][kt].s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(st + kk * 16 * RBA + aaddr[kt]));
+          ua[kk][kt].s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(st + kk * 16 * RBA + 4 * RBA + aaddr[kt]));
+        }
       }
     }
     if constexpr (GEN) {
@@ -439,7 +466,14 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const bf16* __restric
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-      for (int kt = 0; kt < KTW; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uz[kk].v, ua[kk][kt].v, acc[kt], 0, 0, 0);
+      for (int kt = 0; kt < KTW; ++kt) {
+        if constexpr (A8) {
+          const u32x2 raw = __builtin_bit_cast(u32x2, ua[kk][kt].s.a);
+          acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uz[kk].v, rn_bf16x8_from_fp8(raw[0], raw[1]), acc[kt], 0, 0, 0);
+        } else {
+          acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uz[kk].v, ua[kk][kt].v, acc[kt], 0, 0, 0);
+        }
+      }
       // db = dZ^T 1: one more MFMA against a tile of ones (every output column carries the column sums)
       if (do_db) acc_db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uz[kk].v, ones, acc_db, 0, 0, 0);
     }
@@ -498,9 +532,10 @@ static bool wgrad_stream_ok(int dtype, int M, int N, int K, int lddz, int lda) {
 // Weight gradient of the LAST g layer from the forward kernel's lane masks (see wgrad_stream_kernel, GEN): dW = dZ^T A,
 // db = colsum(dZ) with dZ[(b, pair), f] = (mask bit) ? bf16(dxg[b][f]) : 0 -- bitwise what rn_g_chain_bwd_rr would store.
 extern "C" int rn_g_linear_bwd_wgrad_gated(const void* mask, const float* dxg, int rows_per_question, const void* A, int lda,
-                                           float* dW, float* db, void* ws, int M, int N, int K, void* stream) {
+                                           int a_dtype, float* dW, float* db, void* ws, int M, int N, int K, void* stream) {
   RN_CHECK_ARG(mask && dxg && A && dW && db && ws && M > 0, "rn_g_linear_bwd_wgrad_gated: bad pointer/size");
-  RN_CHECK_ARG(N == 256 && K == 256 && M % 64 == 0 && M / 64 >= 64 && lda % 8 == 0 && lda >= K,
+  RN_CHECK_ARG(a_dtype == RN_BF16 || a_dtype == RN_FP8, "rn_g_linear_bwd_wgrad_gated: A must be bf16 or e4m3 (a_dtype=%d)", a_dtype);
+  RN_CHECK_ARG(N == 256 && K == 256 && M % 64 == 0 && M / 64 >= 64 && lda % (a_dtype == RN_FP8 ? 16 : 8) == 0 && lda >= K,
                "rn_g_linear_bwd_wgrad_gated: needs N == K == 256, M %% 64 == 0, M >= 4096 (M=%d N=%d K=%d)", M, N, K);
   RN_CHECK_ARG(rows_per_question > 0 && rows_per_question % 64 == 0 && M % rows_per_question == 0,
                "rn_g_linear_bwd_wgrad_gated: rows_per_question=%d must be a multiple of 64 dividing M", rows_per_question);
@@ -511,8 +546,12 @@ extern "C" int rn_g_linear_bwd_wgrad_gated(const void* mask, const float* dxg, i
   float* part_db = part + (size_t)Zs * N * K;
   hipStream_t s = (hipStream_t)stream;
   const char* ae = getenv("RN_WGRAD_ABL");
-  wgrad_stream_kernel<2, true><<<8 * NB * cdiv(Zs, 8), 512, 0, s>>>(nullptr, 0, (const bf16*)A, lda, part, part_db, S, Zs, NB, K, ae ? atoi(ae) : 0,
-                                                                    (const unsigned*)mask, dxg, rows_per_question / 64);
+  if (a_dtype == RN_FP8)
+    wgrad_stream_kernel<2, true, true><<<8 * NB * cdiv(Zs, 8), 512, 0, s>>>(nullptr, 0, (const bf16*)A, lda, part, part_db, S, Zs, NB, K, ae ? atoi(ae) : 0,
+                                                                            (const unsigned*)mask, dxg, rows_per_question / 64);
+  else
+    wgrad_stream_kernel<2, true><<<8 * NB * cdiv(Zs, 8), 512, 0, s>>>(nullptr, 0, (const bf16*)A, lda, part, part_db, S, Zs, NB, K, ae ? atoi(ae) : 0,
+                                                                      (const unsigned*)mask, dxg, rows_per_question / 64);
   RN_LAUNCH_CHECK("rn_g_linear_bwd_wgrad_gated(stream)");
   const int nbw = cdiv((long)N * K / 4, 16), nbb = cdiv(N / 4, 16);
   wgrad_reduce_kernel<<<nbw + nbb, 256, 0, s>>>(part, part_db, dW, db, N, K, K, Zs, nbw);
@@ -551,10 +590,29 @@ static int wgrad_launch_t(const T* dZ, int lddz, const T* A, int lda, float* par
   return 0;
 }
 
-extern "C" int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, int lda, float* dW, float* db, void* ws,
+extern "C" int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, int lda, int a_dtype, float* dW, float* db, void* ws,
                                      int dtype, int M, int N, int K, int Ktrue, void* stream) {
   RN_CHECK_ARG(dZ && A && dW && ws && M > 0, "rn_g_linear_bwd_wgrad: bad pointer/size");
   RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "rn_g_linear_bwd_wgrad: bad dtype %d", dtype);
+  if (a_dtype == RN_FP8) {
+    // e4m3 copy of the activations (the forward chains' h_dtype = RN_FP8): the streaming kernel only
+    RN_CHECK_ARG(dtype == RN_BF16 && N == 256 && K == 256 && Ktrue == K && M % 64 == 0 && M / 64 >= 64 && lddz % 8 == 0 && lddz >= N &&
+                     lda % 16 == 0 && lda >= K && ((uintptr_t)dZ | (uintptr_t)A) % 16 == 0,
+                 "rn_g_linear_bwd_wgrad: an e4m3 A needs bf16 dZ, N == K == 256, M %% 64 == 0, M >= 4096 (M=%d N=%d K=%d)", M, N, K);
+    const char* ze = getenv("RN_WGRAD_ZS");
+    const int NB = 4, S = M / 64, Zs = ze ? atoi(ze) : 256 / NB;
+    float* part = (float*)ws;
+    float* part_db = part + (size_t)Zs * N * K;
+    const char* ae = getenv("RN_WGRAD_ABL");
+    wgrad_stream_kernel<2, false, true><<<8 * NB * cdiv(Zs, 8), 512, 0, (hipStream_t)stream>>>((const bf16*)dZ, lddz, (const bf16*)A, lda, part, part_db, S,
+                                                                                                Zs, NB, K, ae ? atoi(ae) : 0);
+    RN_LAUNCH_CHECK("rn_g_linear_bwd_wgrad(stream, e4m3 A)");
+    const int nbw = cdiv((long)N * K / 4, 16), nbb = cdiv(N / 4, 16);
+    wgrad_reduce_kernel<<<nbw + nbb, 256, 0, (hipStream_t)stream>>>(part, part_db, dW, db, N, K, Ktrue, Zs, nbw);
+    RN_LAUNCH_CHECK("rn_g_linear_bwd_wgrad(reduce)");
+    return 0;
+  }
+  RN_CHECK_ARG(a_dtype == dtype, "rn_g_linear_bwd_wgrad: A must have dZ's type or be e4m3 (a_dtype=%d)", a_dtype);
   const int CH = dtype == RN_BF16 ? 8 : 4;
   RN_CHECK_ARG(N % 256 == 0 && K % 32 == 0 && Ktrue > 0 && Ktrue <= K, "rn_g_linear_bwd_wgrad: N=%d K=%d Ktrue=%d unsupported",
                N, K, Ktrue);
@@ -608,5 +666,59 @@ __global__ void probe_tr16_kernel(const unsigned short* in, unsigned short* out)
 extern "C" int rn_probe_tr16(const unsigned short* in4096, unsigned short* out256, void* stream) {
   probe_tr16_kernel<<<1, 64, 0, (hipStream_t)stream>>>(in4096, out256);
   RN_LAUNCH_CHECK("rn_probe_tr16");
+  return 0;
+}
+
+// ---- diagnostic: raw lane mapping of ds_read_b64_tr_b8 (linear image: lane l supplies &lds[8 l])
+__global__ void probe_tr8_kernel(const unsigned char* in, unsigned char* out) {
+  __shared__ __attribute__((aligned(16))) unsigned char l[4096];
+  for (int i = threadIdx.x; i < 4096; i += 64) l[i] = in[i];
+  __syncthreads();
+  typedef __attribute__((ext_vector_type(2))) int i32x2_;
+  typedef __attribute__((address_space(3))) i32x2_* lptr8;
+  const i32x2_ v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lptr8)(l + threadIdx.x * 8));
+  reinterpret_cast<i32x2_*>(out)[threadIdx.x] = v;
+}
+
+extern "C" int rn_probe_tr8(const unsigned char* in4096, unsigned char* out512, void* stream) {
+  probe_tr8_kernel<<<1, 64, 0, (hipStream_t)stream>>>(in4096, out512);
+  RN_LAUNCH_CHECK("rn_probe_tr8");
+  return 0;
+}
+
+// ---- diagnostic: the e4m3 conversions the kernels use.  in: n floats (n % 4 == 0); out8_*: n bytes through the bf16 / fp16
+// down-conversion at scale `scale`; back: n floats = the up-conversion of out8_bf at the same scale
+__global__ void probe_fp8_cvt_kernel(const float* in, float scale, unsigned* out8_bf, unsigned* out8_h, float* back, int n4) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = reinterpret_cast<const f32x4*>(in)[i];
+  typedef __attribute__((ext_vector_type(2))) float f32x2_;
+  const f32x2_ a = {v[0], v[1]}, b = {v[2], v[3]};
+  const bf16x2 ba = __builtin_convertvector(a, bf16x2), bb = __builtin_convertvector(b, bf16x2);
+  const rn_f16x2 ha = __builtin_convertvector(a, rn_f16x2), hb = __builtin_convertvector(b, rn_f16x2);
+  unsigned q;
+  if (scale == RN_H8_SCALE && v[0] >= 0.f && v[1] >= 0.f && v[2] >= 0.f && v[3] >= 0.f) {   // the kernels' own helpers (with their clamp)
+    q = rn_fp8x4_from_bf16(__builtin_bit_cast(unsigned, ba), __builtin_bit_cast(unsigned, bb));
+    out8_h[i] = rn_fp8x4_from_f16(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+  } else {                                                                                   // the raw instructions
+    rn_s16x2 r = {0, 0};
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, ba, scale, false);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, bb, scale, true);
+    q = __builtin_bit_cast(unsigned, r);
+    rn_s16x2 r2 = {0, 0};
+    r2 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r2, ha, scale, false);
+    r2 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r2, hb, scale, true);
+    out8_h[i] = __builtin_bit_cast(unsigned, r2);
+  }
+  out8_bf[i] = q;
+  const bf16x2 u0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q, scale, false), u1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q, scale, true);
+  f32x4 o = {(float)u0[0], (float)u0[1], (float)u1[0], (float)u1[1]};
+  reinterpret_cast<f32x4*>(back)[i] = o;
+}
+
+extern "C" int rn_probe_fp8_cvt(const float* in, float scale, void* out8_bf16, void* out8_f16, float* back, int n, void* stream) {
+  RN_CHECK_ARG(in && out8_bf16 && out8_f16 && back && n > 0 && n % 4 == 0, "rn_probe_fp8_cvt: bad arguments");
+  probe_fp8_cvt_kernel<<<cdiv(n / 4, 64), 64, 0, (hipStream_t)stream>>>(in, scale, (unsigned*)out8_bf16, (unsigned*)out8_f16, back, n / 4);
+  RN_LAUNCH_CHECK("rn_probe_fp8_cvt");
   return 0;
 }

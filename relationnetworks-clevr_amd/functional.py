@@ -216,6 +216,16 @@ def f16s_ok(plan: LayerPlan, B, n):
     return fused_chain_ok(plan, H.RN_BF16, B, n) or inj_chain_ok(plan, H.RN_BF16, n, plan.k, B * n * n)
 
 
+def _h_copy_dtype(plan, dt, M):
+    """Storage type of the H_0..2 copies the factored-first-layer chains keep for the weight gradient: OCP e4m3 bytes (half the
+    bytes written by the forward chain and read back by the streaming wgrad kernel -- its only reader) when that kernel covers
+    the shape, else the chain's 16-bit type.  RN_H8=0 keeps the 16-bit copies (A/B measurements, error comparisons)."""
+    if (os.environ.get("RN_H8", "1") != "0" and dt == torch.bfloat16 and all(w == 256 for w in plan.widths)
+            and M % 64 == 0 and M // 64 >= 64):
+        return torch.float8_e4m3fn
+    return dt
+
+
 def alg0_wgrad_ok(plan, k):
     """Layer-0 weight gradient from the pair reductions (rn_wgrad0_from_reductions) instead of a pass over dZ_0 and P."""
     return plan.inject == 0 and k <= 32 and os.environ.get("RN_NO_ALGEBRAIC_WGRAD0", "0") != "1"
@@ -276,7 +286,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
             Xp, Vc, Vq, inj_l = _tables(x, q, plan, g_b, w0T, inj_w, torch.float16, B, n, k, Q, G, coord)
             masks = Hs = None
             if keep_inputs:
-                Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L - 1)] + [None]
+                Hs = [torch.empty(M, G, dtype=_h_copy_dtype(plan, dt, M), device=dev) for l in range(L - 1)] + [None]
                 masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
             part = torch.empty(M // R, G, dtype=torch.float32, device=dev)
             H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, wfrag[0], wfrag[1], g_b, Hs, masks, part, M, G, Vq=Vq, inject=inj_l)
@@ -329,7 +339,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
         Xp, Vc, Vq, inj_l = _tables(x, q, plan, g_b, w0T, inj_w, dt, B, n, k, Q, G, coord)
         masks = Hs = None
         if keep_inputs:
-            Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L - 1)] + [None]
+            Hs = [torch.empty(M, G, dtype=_h_copy_dtype(plan, dt, M), device=dev) for l in range(L - 1)] + [None]
             masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
         part = torch.empty(M // R, G, dtype=torch.float32, device=dev)
         H.g_chain_fwd_rr_alg0(Xp, Vc, n, wfrag, g_b, Hs, masks, part, M, G, Vq=Vq, inject=inj_l)

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librn_hip.so")
-RN_BF16, RN_F32, RN_F16 = 0, 1, 2
+RN_BF16, RN_F32, RN_F16, RN_FP8 = 0, 1, 2, 3
 RN_RELU, RN_ACCUMULATE = 1, 2
 ABI_VERSION = 1
 
@@ -36,10 +36,10 @@ SIGNATURES = {
     "rn_g_chain_rr_mask_bytes": (_Z, [_I]),
     "rn_g_chain_fwd_rr": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_f16s": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
-    "rn_g_chain_fwd_rr_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_g_chain_fwd_rr_alg0": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _I, _P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
-    "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "rn_g_linear_bwd_wgrad_gated": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_g_linear_bwd_wgrad_gated": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pack_matrix_frag": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
     "rn_pack_matrix_frag_many": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
@@ -49,7 +49,7 @@ SIGNATURES = {
     "rn_pair_sum_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "rn_g_linear_bwd_dgrad": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "rn_wgrad_ws_bytes": (_Z, [_I, _I, _I]),
-    "rn_g_linear_bwd_wgrad": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_g_linear_bwd_wgrad": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_pair_reduce_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_reduce_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_dx_dq": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _I, _I, _I, _I, _I, _P]),
@@ -88,6 +88,8 @@ SIGNATURES = {
 DEBUG_SIGNATURES = {
     "rn_debug_stamp": (_I, [_P, _P]),
     "rn_probe_tr16": (_I, [_P, _P, _P]),
+    "rn_probe_tr8": (_I, [_P, _P, _P]),
+    "rn_probe_fp8_cvt": (_I, [_P, C.c_float, _P, _P, _P, _I, _P]),
 }
 
 
@@ -121,6 +123,15 @@ def _check(rc: int, name: str):
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+FP8_DTYPES = (torch.float8_e4m3fn, torch.uint8)      # the e4m3 copies of the stored activations (h_dtype / a_dtype = RN_FP8)
+
+
+def _h_code(Hs):
+    if Hs is None:
+        return RN_BF16
+    return RN_FP8 if any(h is not None and h.dtype in FP8_DTYPES for h in Hs) else RN_BF16
 
 
 def _ptr(t):
@@ -295,8 +306,8 @@ def g_chain_fwd_rr_alg0(Xp, Vc, n, Wfs, biases, Hs, masks, xg_part, M, G, Vq=Non
     bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
     hp = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
-    _check(load().rn_g_chain_fwd_rr_alg0(Xp.data_ptr(), Vc.data_ptr(), n, wp, bp, hp, mp, xg_part.data_ptr(), _ptr(Vq), inject, M, L, G,
-                                         _stream()), "rn_g_chain_fwd_rr_alg0")
+    _check(load().rn_g_chain_fwd_rr_alg0(Xp.data_ptr(), Vc.data_ptr(), n, wp, bp, hp, _h_code(Hs), mp, xg_part.data_ptr(), _ptr(Vq), inject,
+                                         M, L, G, _stream()), "rn_g_chain_fwd_rr_alg0")
 
 
 @_timed("g_fwd")
@@ -308,8 +319,8 @@ def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlos, biases, Hs, masks, xg_part
     bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
     op = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
-    _check(load().rn_g_chain_fwd_rr_f16s_alg0(Xp16.data_ptr(), Vc.data_ptr(), n, hp, lp, bp, op, mp, xg_part.data_ptr(), _ptr(Vq), inject,
-                                              M, L, G, _stream()), "rn_g_chain_fwd_rr_f16s_alg0")
+    _check(load().rn_g_chain_fwd_rr_f16s_alg0(Xp16.data_ptr(), Vc.data_ptr(), n, hp, lp, bp, op, _h_code(Hs), mp, xg_part.data_ptr(), _ptr(Vq),
+                                              inject, M, L, G, _stream()), "rn_g_chain_fwd_rr_f16s_alg0")
 
 
 @_timed("g_fwd")
@@ -394,8 +405,8 @@ def g_linear_bwd_wgrad(dZ, lddz, A, lda, dW, db, code, M, N, K, Ktrue):
     if nb == 0:
         raise RuntimeError("rn_wgrad_ws_bytes: unsupported shape M=%d N=%d K=%d" % (M, N, K))
     ws = torch.empty(nb, dtype=torch.uint8, device=dW.device)
-    _check(lib.rn_g_linear_bwd_wgrad(dZ.data_ptr(), lddz, A.data_ptr(), lda, dW.data_ptr(), _ptr(db), ws.data_ptr(), code,
-                                     M, N, K, Ktrue, _stream()), "rn_g_linear_bwd_wgrad")
+    _check(lib.rn_g_linear_bwd_wgrad(dZ.data_ptr(), lddz, A.data_ptr(), lda, RN_FP8 if A.dtype in FP8_DTYPES else code, dW.data_ptr(), _ptr(db),
+                                     ws.data_ptr(), code, M, N, K, Ktrue, _stream()), "rn_g_linear_bwd_wgrad")
 
 
 @_timed("g_wgrad")
@@ -403,8 +414,9 @@ def g_linear_bwd_wgrad_gated(mask, dxg, rows_per_question, A, lda, dW, db, M, N,
     """Last g layer: weight gradient from the layer-3 lane masks + dxg instead of a stored dZ_3 (rn_g_linear_bwd_wgrad_gated)."""
     lib = load()
     ws = torch.empty(lib.rn_wgrad_ws_bytes(M, N, K), dtype=torch.uint8, device=dW.device)
-    _check(lib.rn_g_linear_bwd_wgrad_gated(mask.data_ptr(), dxg.data_ptr(), rows_per_question, A.data_ptr(), lda, dW.data_ptr(),
-                                           db.data_ptr(), ws.data_ptr(), M, N, K, _stream()), "rn_g_linear_bwd_wgrad_gated")
+    _check(lib.rn_g_linear_bwd_wgrad_gated(mask.data_ptr(), dxg.data_ptr(), rows_per_question, A.data_ptr(), lda,
+                                           RN_FP8 if A.dtype in FP8_DTYPES else RN_BF16, dW.data_ptr(), db.data_ptr(), ws.data_ptr(), M, N, K, _stream()),
+           "rn_g_linear_bwd_wgrad_gated")
 
 
 @_timed("pair_reduce")

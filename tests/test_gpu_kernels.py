@@ -65,6 +65,57 @@ def test_probe_tr16_mapping(H):
     assert np.array_equal(got, exp), got[:20]
 
 
+def test_probe_tr8_mapping(H):
+    """ds_read_b64_tr_b8 on a linear image (lane l supplies &lds[8l]): within each 16-lane block the 16 lanes' 8-byte pieces
+    form an 8-row x 16-byte block and lane i receives column i (8 rows, ascending) -- what the e4m3 wgrad operand relies on."""
+    src = (np.arange(4096) % 251).astype(np.uint8)
+    out = torch.zeros(512, dtype=torch.uint8, device="cuda")
+    rc = H.load().rn_probe_tr8(dev(src).data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(64, 8)
+    exp = np.zeros((64, 8), dtype=np.uint8)
+    for lane in range(64):
+        blk, i = lane // 16, lane % 16
+        for j in range(8):
+            exp[lane, j] = src[128 * blk + 16 * j + i]
+    print("tr8 lanes 0..2:", got[:3].tolist(), "lane 17:", got[17].tolist())
+    assert np.array_equal(got, exp), got[:20]
+
+
+@pytest.mark.parametrize("scale", [1.0, 4.0, 0.25])
+def test_probe_fp8_conversions(H, scale):
+    """The e4m3 conversions of the kernels (v_cvt_scalef32_pk_fp8_bf16 / _f16 / v_cvt_scalef32_pk_bf16_fp8): OCP e4m3fn,
+    round to nearest even of value / scale -- the raw instruction turns what rounds beyond 448 into the NaN byte, the kernels'
+    helpers (scale 1, non-negative groups of four) clamp to 448 first; the up-conversion returns byte value * scale exactly."""
+    vals = np.concatenate([formula.hash_uniform((4096,), 77, 0, 12), formula.hash_uniform((2048,), 78, 0, 0.05), formula.hash_uniform((1024,), 79, -3, 0),
+                           np.array([0.0, 448.0, 449.0, 1000.0, 6e4, 2.0 ** -9, 2.0 ** -10, 3 * 2.0 ** -11, 1.0625, 1.1875, 0.9375, 17.0], np.float32)]).astype(np.float32)
+    vals = (vals * scale).astype(np.float32)
+    n = vals.size
+    o_bf = torch.zeros(n, dtype=torch.uint8, device="cuda"); o_h = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    back = torch.zeros(n, device="cuda")
+    rc = H.load().rn_probe_fp8_cvt(dev(vals).data_ptr(), scale, o_bf.data_ptr(), o_h.data_ptr(), back.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    tv = torch.from_numpy(vals)
+    grp_clamped = torch.from_numpy(np.repeat((vals.reshape(-1, 4) >= 0).all(1) & (scale == 1.0), 4))
+    def ref8(t16):
+        v = t16.float() / scale
+        r = v.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+        over = (v.abs() > 464) & ~grp_clamped                        # 464 = the tie between 448 and the next (non-existent) value
+        return torch.where(over, torch.full_like(r, 0x7f) | (r & 0x80), r)
+    for name, got, t16 in (("bf16", o_bf, tv.bfloat16()), ("f16", o_h, tv.half())):
+        exp = ref8(t16).numpy()
+        g = got.cpu().numpy()
+        bad = g != exp
+        # -0 vs +0 is not a difference that matters
+        bad &= ~(((g & 0x7f) == 0) & ((exp & 0x7f) == 0))
+        assert not bad.any(), (name, vals[bad][:8], g[bad][:8], exp[bad][:8])
+    ok = torch.from_numpy((o_bf.cpu().numpy() & 0x7f) != 0x7f)
+    exp_back = o_bf.cpu().view(torch.float8_e4m3fn).float() * scale
+    assert torch.equal(back.cpu()[ok], exp_back[ok])
+
+
 # ----------------------------------------------------------------------------- K1
 @pytest.mark.parametrize("code", [0, 1])
 @pytest.mark.parametrize("B,n,k,Q,strided", [(3, 64, 26, 128, True), (3, 64, 26, 0, False), (4, 12, 7, 256, False),
@@ -299,7 +350,7 @@ def test_g_chain_fwd_rr(H, K0, K0true, mode, M):
     assert rel(part.cpu().numpy(), ref.reshape(M // 32, 32, G).sum(1)) <= tol
 
 
-@pytest.mark.parametrize("mode,B,n", [("train", 19, 64), ("infer", 3, 32), ("train", 2, 96)])
+@pytest.mark.parametrize("mode,B,n", [("train", 19, 64), ("infer", 3, 32), ("train", 2, 96), ("train8", 19, 64), ("train8", 2, 96)])
 def test_g_chain_fwd_rr_alg0(H, mode, B, n):
     """The factored first layer: W0 [x_j | x_i | q] + b0 = W0a x_j + (W0b x_i + W0c q + b0).  rn_pair_tables must give the
     packed object rows and the fp32 bias rows; the chain on them must reproduce layer 0 of the pair formula (x_j product
@@ -322,12 +373,24 @@ def test_g_chain_fwd_rr_alg0(H, mode, B, n):
     Xp = torch.full((B * n, 64), float("nan"), dtype=torch.bfloat16, device="cuda")
     Vc = torch.full((B * n, G), float("nan"), device="cuda")
     H.pair_tables(dev(x), dev(q), w0T, dev(bs[0]), Xp, Vc, B, n, k, Q, G)
-    train = mode == "train"
+    train = mode.startswith("train")
     Hs = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3)] + [None] if train else None
     masks = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda")) if train else None
     part = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
     H.g_chain_fwd_rr_alg0(Xp, Vc, n, Wf, [dev(b) for b in bs], Hs, masks, part, M, G)
     torch.cuda.synchronize()
+    if mode == "train8":
+        # e4m3 copies (h_dtype = RN_FP8): same arithmetic, so masks and pair sums bitwise; the bytes = the e4m3 rounding of the bf16 copies
+        Hs8 = [torch.full((M, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [None]
+        masks8 = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
+        part8 = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
+        H.g_chain_fwd_rr_alg0(Xp, Vc, n, Wf, [dev(b) for b in bs], Hs8, masks8, part8, M, G)
+        torch.cuda.synchronize()
+        assert torch.equal(part, part8)
+        for l in range(L):
+            assert torch.equal(masks[l], masks8[l]), l
+        for l in range(3):
+            assert torch.equal(Hs8[l].view(torch.uint8), Hs[l].float().to(torch.float8_e4m3fn).view(torch.uint8)), l
     # tables
     xp = Xp.float().cpu().numpy()
     assert np.array_equal(xp[:, :k], bf16_round(x.reshape(B * n, k))) and not xp[:, k:].any()
@@ -400,6 +463,22 @@ def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
             assert np.abs(a - b).max() <= 2 * BF16_ULP * np.abs(b).max(), l
         for l in range(L):
             assert (mA[l] != mP[l]).float().mean().item() <= 2e-3, l
+        # e4m3 copies: same arithmetic (masks, pair sums bitwise); the bytes are the e4m3 rounding of the fp16 operand, i.e. of
+        # the value the bf16 copy rounds -- equal to the rounded bf16 copy except where the two 16-bit roundings straddle a tie
+        Hs8 = [torch.full((M, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [None]
+        m8 = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
+        p8 = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
+        H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, Hs8, m8, p8, M, G)
+        torch.cuda.synchronize()
+        assert torch.equal(pA, p8)
+        for l in range(L):
+            assert torch.equal(mA[l], m8[l]), l
+        for l in range(3):
+            ref8 = HsA[l].float().to(torch.float8_e4m3fn)
+            same = (Hs8[l].view(torch.uint8) == ref8.view(torch.uint8)).float().mean().item()
+            assert same >= 0.97, (l, same)
+            d = (Hs8[l].float() - HsA[l].float()).abs()
+            assert bool((d <= HsA[l].float().abs() * 2.0 ** -4 + 2.0 ** -10).all()), l
 
 
 @pytest.mark.parametrize("mode,M", [("train", 256 * 290), ("infer", 256 * 5)])
@@ -474,6 +553,37 @@ def test_wgrad_gated_and_bwd_skip0(H):
     H.g_linear_bwd_wgrad_gated(masks[L - 1], dxg, n * n, A, G, dW1, db1, M, G, G)
     torch.cuda.synchronize()
     assert torch.equal(dW0, dW1) and torch.equal(db0, db1)
+
+
+def test_wgrad_fp8_operand(H):
+    """The activation operand as e4m3 bytes (a_dtype = RN_FP8): every e4m3 value is a bf16 value, so both the plain and the
+    gated streaming kernel must give -- bitwise -- what they give on the same values stored as bf16."""
+    B, n, G = 17, 64, 256
+    M = B * n * n
+    g = torch.Generator(device="cuda").manual_seed(11)
+    A8 = (torch.rand(M, G, device="cuda", generator=g) * 6).clamp_min(0.0)
+    A8 = torch.where(torch.rand(M, G, device="cuda", generator=g) < 0.5, torch.zeros_like(A8), A8).to(torch.float8_e4m3fn)
+    A16 = A8.float().bfloat16()
+    assert torch.equal(A16.float(), A8.float())
+    dZ = ((torch.rand(M, G, device="cuda", generator=g) - 0.5) * 1e-2).bfloat16()
+    out = []
+    for A in (A16, A8):
+        dW = torch.full((G, G), float("nan"), device="cuda"); db = torch.full((G,), float("nan"), device="cuda")
+        H.g_linear_bwd_wgrad(dZ, G, A, G, dW, db, H.RN_BF16, M, G, G, G)
+        out.append((dW, db))
+    torch.cuda.synchronize()
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    ref = dZ.double().t() @ A8.double()
+    assert rel(out[1][0].cpu().numpy(), ref.cpu().numpy()) <= 1e-5
+    masks = torch.randint(0, 256, (H.g_chain_rr_mask_bytes(M),), dtype=torch.uint8, device="cuda", generator=g)
+    dxg = (torch.rand(B, G, device="cuda", generator=g) - 0.5)
+    out = []
+    for A in (A16, A8):
+        dW = torch.full((G, G), float("nan"), device="cuda"); db = torch.full((G,), float("nan"), device="cuda")
+        H.g_linear_bwd_wgrad_gated(masks, dxg, n * n, A, G, dW, db, M, G, G)
+        out.append((dW, db))
+    torch.cuda.synchronize()
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
 
 
 @pytest.mark.parametrize("B,npairs", [(2, 512), (24, 32 * 100), (16, 144)])

@@ -143,6 +143,31 @@ def test_headline_mode_is_the_module_default_and_meets_the_bar(pkg, tag):
     assert e_lp <= 2e-4 and (lp.argmax(1) == g["log_probs"].argmax(1)).all()
 
 
+@pytest.mark.parametrize("tag,precision", [("G-fp64", "f16s"), ("G-fp64", "bf16"), ("G-ir64", "f16s")])
+def test_e4m3_activation_copies_touch_only_the_g_weight_gradients(pkg, tag, precision, monkeypatch):
+    """The factored-first-layer chains keep H_0..2 for the weight gradient as e4m3 bytes (RN_H8=0: 16-bit copies).  Nothing but
+    dW of g layers 1..3 reads them: log-probs, dx, dq, every bias gradient, the f_phi gradients and dW_0 (pair reductions) must
+    be bitwise those of the 16-bit copies, and the three weight gradients within 3e-3 (relative L2; the error against the fp32
+    reference moves inside the mode's own bf16-class band: reported)."""
+    g = gold.load(tag)
+    monkeypatch.setenv("RN_H8", "0")
+    lp0, loss0, dx0, dq0, gr0 = run_rl(pkg, g, precision)
+    monkeypatch.setenv("RN_H8", "1")
+    lp1, loss1, dx1, dq1, gr1 = run_rl(pkg, g, precision)
+    assert np.array_equal(lp0, lp1) and np.array_equal(dx0, dx1) and np.array_equal(dq0, dq1)
+    touched = {"g_layers.%d.weight" % l for l in (1, 2, 3)}
+    rep = {}
+    for k in gr0:
+        if k in touched:
+            d = l2rel(gr1[k], gr0[k])
+            rep[k] = (d, l2rel(gr0[k], g["grad/" + k]), l2rel(gr1[k], g["grad/" + k]))
+            assert 0 < d <= 3e-3, (k, d)
+        else:
+            assert np.array_equal(gr0[k], gr1[k]), k
+    report(tag, precision=precision, e4m3_vs_16bit={k: v[0] for k, v in rep.items()}, ref_err_16bit={k: v[1] for k, v in rep.items()},
+           ref_err_e4m3={k: v[2] for k, v in rep.items()})
+
+
 def test_f16s_refuses_unsupported_shapes(pkg):
     g = gold.load("G-irsd4")                      # 512-wide g layers: no fused chain
     with pytest.raises(RuntimeError, match="f16s"):

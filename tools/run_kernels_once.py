@@ -24,7 +24,7 @@ Xp = torch.empty(B * n, 64, dtype=torch.float16 if mode == "f16s" else torch.bfl
 Whi = list(torch.empty(4, 65536, dtype=torch.float16, device='cuda')); Wlo = list(torch.empty(4, 65536, dtype=torch.float16, device='cuda'))
 H.pack_matrix_frag_many([(Ws[l], Ws[l].shape[1], 1, G, k if l == 0 else G, Whi[l], 4 | int(l == 0)) for l in range(4)]
                         + [(Ws[l], Ws[l].shape[1], 1, G, k if l == 0 else G, Wlo[l], 8 | int(l == 0)) for l in range(4)])
-Hs = list(torch.empty(3, M, G, dtype=torch.bfloat16, device='cuda')) + [None]
+Hs = list(torch.empty(3, M, G, dtype=torch.uint8, device='cuda').view(torch.float8_e4m3fn)) + [None]     # e4m3 copies, as the step keeps them
 masks = list(torch.empty(4, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device='cuda'))
 part = torch.empty(M // 32, G, device='cuda')
 dxg = torch.randn(B, G, device='cuda')

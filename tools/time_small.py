@@ -20,7 +20,7 @@ f1 = torch.empty(B, 256, device=dev); f2 = torch.empty(B, 256, device=dev); out 
 label = torch.randint(0, A, (B,), device=dev); gloss = torch.ones((), device=dev)
 dW = (torch.empty(256, 256, device=dev), torch.empty(256, 256, device=dev), torch.empty(A, 256, device=dev))
 db = (torch.empty(256, device=dev), torch.empty(256, device=dev), torch.empty(A, device=dev)); dxg = torch.empty(B, G, device=dev)
-dZ = torch.randn(M, G, device=dev).bfloat16(); Hh = torch.randn(M, G, device=dev).bfloat16()
+dZ = torch.randn(M, G, device=dev).bfloat16(); Hh = torch.randn(M, G, device=dev).abs().to(torch.float8_e4m3fn)     # e4m3 copies, as the step keeps them
 Rj = torch.empty(B * n, G, device=dev); Ri = torch.empty(B * n, G, device=dev); Rq = torch.empty(B, G, device=dev)
 dx = torch.empty(B, n, k, device=dev); dq = torch.empty(B, Q, device=dev); dW0 = torch.empty(G, kt, device=dev); db0 = torch.empty(G, device=dev)
 gW = torch.empty(G, G, device=dev); gB = torch.empty(G, device=dev)
