@@ -138,6 +138,17 @@ int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, con
  * written (wgrad and the pair reduction consume them).  rows_per_question = n*n (any value dividing M). */
 int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M,
                       int rows_per_question, int L, int G, void* stream);
+/* ... with the pair reduction of the FIRST layer's gradient done on chip (n == 64 objects, rows_per_question = n*n): dZ[3] is
+ * never formed in memory (pass NULL; dZ[0] NULL too: rn_g_linear_bwd_wgrad_gated rebuilds it).  Per 256-row tile (4 i x 64 j)
+ * the kernel leaves rj_part (rn_chain_reduce_part_bytes(M, 0) bytes: the fp32 sum over the tile's 4 i) and per 32-row block
+ * ri_part (rn_chain_reduce_part_bytes(M, 1): column sums of its two 16-row halves); rn_pair_reduce_from_chain adds them into
+ *   Rj[b,j,:] = sum_i dZ_0[(b,i,j),:]   Ri[b,i,:] = sum_j dZ_0[(b,i,j),:]   Rq[b,:] = sum_ij      (fp32; (B*n, 256), (B, 256))
+ * -- what rn_pair_reduce_bwd computes from a stored dZ_0, here from the un-rounded fp32 values.  Deterministic. */
+size_t rn_chain_reduce_part_bytes(int M, int which);
+int rn_g_chain_bwd_rr_reduce(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, float* rj_part,
+                             float* ri_part, int n, int M, int L, int G, void* stream);
+int rn_pair_reduce_from_chain(const float* rj_part, const float* ri_part, float* Rj, float* Ri, float* Rq, int B, int n, int G,
+                              void* stream);
 /* Weight gradient of the LAST g layer without its gradient matrix: dZ_3[(b, pair), f] = gate ? bf16(dxg[b][f]) : 0 is
  * rebuilt on the fly from the forward kernel's layer-3 lane masks (mask: rn_g_chain_rr_mask_bytes(M) bytes) and dxg
  * (M / rows_per_question, 256) fp32 -- bitwise the matrix rn_g_chain_bwd_rr stores as dZ[0], which may then be passed as

@@ -555,13 +555,27 @@ class RelationalFunction(torch.autograd.Function):
             # itself, the layer's wgrad, rebuilds it from the masks (rn_g_linear_bwd_wgrad_gated) -- 134 MB less written
             # by the chain and 134 MB less read by the wgrad at the headline shape
             gated_mask = None
+            red_parts = None
             if ((n * n) % 64 == 0 and M // 64 >= 64 and plan.widths[-2] == 256 and G == 256
                     and os.environ.get("RN_NO_GATED_WGRAD", "0") != "1"):
                 gated_mask = ctx.HL.masks[L - 1]
-                dZs = [None] + list(torch.empty(L - 1, M, G, dtype=dt, device=dev))
+                # RN_CHAIN_REDUCE=1 (opt-in): ... and neither is the FIRST layer's gradient where its only readers are the pair
+                # reductions (layer-0 weight gradient from the reductions, 64 objects): the chain adds each 256-row tile's four i
+                # and every wave's 32 j on chip and leaves 72 MB of fp32 partials instead of the 134 MB bf16 matrix
+                # (rn_g_chain_bwd_rr_reduce).  196 MB less HBM traffic per step, but measured neutral on the step (the chain's
+                # last step turns LDS-bound: +24 us alone, the reduction -21 us; 61.2-61.8 k q/s either way) -- DESIGN.md 6.1
+                if (n == 64 and L == 4 and (alg0_wgrad_ok(plan, k) or (bool(ctx.inj_path) and k <= 32))
+                        and os.environ.get("RN_CHAIN_REDUCE", "0") == "1"):
+                    red_parts = (torch.empty(H.chain_reduce_part_bytes(M, 0) // 4, **f32), torch.empty(H.chain_reduce_part_bytes(M, 1) // 4, **f32))
+                    dZs = [None] + list(torch.empty(L - 2, M, G, dtype=dt, device=dev)) + [None]
+                else:
+                    dZs = [None] + list(torch.empty(L - 1, M, G, dtype=dt, device=dev))
             else:
                 dZs = list(torch.empty(L, M, G, dtype=dt, device=dev))             # dZs[s] belongs to layer L-1-s
-            H.g_chain_bwd_rr(dxg, ctx.HL.masks, ctx.fragT, dZs, M, n * n, G)
+            if red_parts is not None:
+                H.g_chain_bwd_rr_reduce(dxg, ctx.HL.masks, ctx.fragT, dZs, red_parts[0], red_parts[1], n, M, G)
+            else:
+                H.g_chain_bwd_rr(dxg, ctx.HL.masks, ctx.fragT, dZs, M, n * n, G)
             dZ_of = {L - 1 - s: dZs[s] for s in range(L)}
         elif fused_bwd:
             # one launch: dZ_L = dxg * (H_L > 0), then dZ_{l-1} = (dZ_l @ W_l) * (H_{l-1} > 0) for every layer
@@ -574,6 +588,7 @@ class RelationalFunction(torch.autograd.Function):
             H.pair_sum_bwd(dxg, ctx.HL, G, dZ, G, code, B, n * n, G)
         if not isinstance(ctx.HL, RRMasks):
             gated_mask = None
+            red_parts = None
         ctx.HL = None
         gW, gB = [None] * L, [None] * L
         dq = None
@@ -647,7 +662,10 @@ class RelationalFunction(torch.autograd.Function):
                 Rq = torch.empty(B, N, **f32)
                 if l == 0:
                     Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32)
-                    H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N)
+                    if red_parts is not None:
+                        H.pair_reduce_from_chain(red_parts[0], red_parts[1], Rj, Ri, Rq, B, n, N)
+                    else:
+                        H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N)
                 else:
                     H.pair_reduce_bwd(dZ, N, None, None, Rq, code, B, n, N)
                 dq = torch.empty(B, Q, **f32)
@@ -666,7 +684,10 @@ class RelationalFunction(torch.autograd.Function):
             elif l == 0:
                 Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32)
                 Rq = torch.empty(B, N, **f32) if alg0 else None                   # (all-pairs sums: the layer's bias gradient)
-                H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N)
+                if red_parts is not None:
+                    H.pair_reduce_from_chain(red_parts[0], red_parts[1], Rj, Ri, Rq, B, n, N)
+                else:
+                    H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N)
             if l == 0 and overlap and wgrad_late == 1:
                 _launch_wgrads()
             if l == 0 and alg0:

@@ -555,6 +555,46 @@ def test_wgrad_gated_and_bwd_skip0(H):
     assert torch.equal(dW0, dW1) and torch.equal(db0, db1)
 
 
+@pytest.mark.parametrize("B", [17, 3])
+def test_chain_bwd_in_chain_pair_reduction(H, B):
+    """rn_g_chain_bwd_rr_reduce + rn_pair_reduce_from_chain (64 objects): dZ of layers 2 and 1 bitwise those of the plain chain,
+    and Rj / Ri / Rq = the pair reductions of the first layer's gradient -- which is never stored -- against float64 sums of the
+    plain chain's bf16 matrix: the in-chain sums add the UN-rounded fp32 values, so they differ from it by the bf16 rounding of
+    the summands only (<= 2^-9 of the largest summand per term, far less in the sum).  17 questions: 272 tiles > 256 CUs."""
+    n, L, G = 64, 4, 256
+    M = B * n * n
+    g = torch.Generator(device="cuda").manual_seed(21)
+    masks = list(torch.randint(0, 256, (L, H.g_chain_rr_mask_bytes(M)), dtype=torch.uint8, device="cuda", generator=g))
+    dxg = (torch.rand(B, G, device="cuda", generator=g) - 0.5)
+    Wt = list(torch.empty(L - 1, 65536, dtype=torch.bfloat16, device="cuda"))
+    for st in range(L - 1):
+        W = dev(bf16_round(formula.hash_uniform((G, G), 630 + st, -0.15, 0.15)))
+        H.pack_matrix_frag(W, 1, G, G, G, Wt[st], st == 0)
+    full = [None] + list(torch.zeros(L - 1, M, G, dtype=torch.bfloat16, device="cuda"))
+    H.g_chain_bwd_rr(dxg, masks, Wt, full, M, n * n, G)
+    part = [None] + list(torch.zeros(L - 2, M, G, dtype=torch.bfloat16, device="cuda")) + [None]
+    rj_part = torch.full((H.chain_reduce_part_bytes(M, 0) // 4,), float("nan"), device="cuda")
+    ri_part = torch.full((H.chain_reduce_part_bytes(M, 1) // 4,), float("nan"), device="cuda")
+    H.g_chain_bwd_rr_reduce(dxg, masks, Wt, part, rj_part, ri_part, n, M, G)
+    Rj = torch.full((B * n, G), float("nan"), device="cuda"); Ri = torch.full((B * n, G), float("nan"), device="cuda")
+    Rq = torch.full((B, G), float("nan"), device="cuda")
+    H.pair_reduce_from_chain(rj_part, ri_part, Rj, Ri, Rq, B, n, G)
+    torch.cuda.synchronize()
+    assert torch.equal(full[1], part[1]) and torch.equal(full[2], part[2])
+    assert not torch.isnan(rj_part).any() and not torch.isnan(ri_part).any()
+    dz0 = full[3].double().view(B, n, n, G)                             # (b, i, j, f)
+    ref_j, ref_i, ref_q = dz0.sum(1).reshape(B * n, G), dz0.sum(2).reshape(B * n, G), dz0.sum((1, 2))
+    for name, got, ref in (("Rj", Rj, ref_j), ("Ri", Ri, ref_i), ("Rq", Rq, ref_q)):
+        e = float((got.double() - ref).abs().max() / ref.abs().max())
+        print(name, e)
+        assert e <= 1e-3, (name, e)
+    # deterministic
+    rj2 = torch.empty_like(rj_part); ri2 = torch.empty_like(ri_part)
+    H.g_chain_bwd_rr_reduce(dxg, masks, Wt, part, rj2, ri2, n, M, G)
+    torch.cuda.synchronize()
+    assert torch.equal(rj_part, rj2) and torch.equal(ri_part, ri2)
+
+
 def test_wgrad_fp8_operand(H):
     """The activation operand as e4m3 bytes (a_dtype = RN_FP8): every e4m3 value is a bf16 value, so both the plain and the
     gated streaming kernel must give -- bitwise -- what they give on the same values stored as bf16."""

@@ -168,6 +168,33 @@ def test_e4m3_activation_copies_touch_only_the_g_weight_gradients(pkg, tag, prec
            ref_err_e4m3={k: v[2] for k, v in rep.items()})
 
 
+@pytest.mark.parametrize("tag", ["G-fp64", "G-ir64"])
+def test_in_chain_pair_reduction_end_to_end(pkg, tag, monkeypatch):
+    """RN_CHAIN_REDUCE=1: the first layer's gradient matrix is never stored, the backward chain reduces it over the pair axes on
+    chip (rn_g_chain_bwd_rr_reduce).  Log-probs and the gradients of layers 1..3 / f_phi bitwise those of the default path; dx,
+    dq, dW_0, db_0 (all from the reductions) within the mode's band of the reference and within 2e-3 of the default path (the
+    in-chain sums add un-rounded fp32 values instead of the stored bf16 ones)."""
+    g = gold.load(tag)
+    monkeypatch.setenv("RN_CHAIN_REDUCE", "0")
+    lp0, loss0, dx0, dq0, gr0 = run_rl(pkg, g, "f16s")
+    monkeypatch.setenv("RN_CHAIN_REDUCE", "1")
+    lp1, loss1, dx1, dq1, gr1 = run_rl(pkg, g, "f16s")
+    assert np.array_equal(lp0, lp1)
+    from_red = {"g_layers.0.weight", "g_layers.0.bias"}
+    for k in gr0:
+        if k in from_red:
+            assert 0 < l2rel(gr1[k], gr0[k]) <= 2e-3, k
+        else:
+            assert np.array_equal(gr0[k], gr1[k]), k
+    assert 0 < l2rel(dx1, dx0) <= 2e-3
+    if tag == "G-fp64":                                      # (ir: dq comes from the injected layer's reduction, untouched)
+        assert 0 < l2rel(dq1, dq0) <= 2e-3
+    e_dx, e_dq = l2rel(dx1, g["dx"]), l2rel(dq1, g["dq"])
+    e_b = max(l2rel(gr1[k[5:]], g[k]) for k in g if k.startswith("grad/"))
+    report(tag, precision="f16s", chain_reduce=1, dx_l2=e_dx, dq_l2=e_dq, params_l2=e_b, dx_default=l2rel(dx0, g["dx"]))
+    assert e_dx <= 1.2e-2 and e_dq <= 1.2e-2 and e_b <= 1.2e-2, (e_dx, e_dq, e_b)
+
+
 def test_f16s_refuses_unsupported_shapes(pkg):
     g = gold.load("G-irsd4")                      # 512-wide g layers: no fused chain
     with pytest.raises(RuntimeError, match="f16s"):
