@@ -160,7 +160,8 @@ def test_e4m3_activation_copies_touch_only_the_g_weight_gradients(pkg, tag, prec
     for k in gr0:
         if k in touched:
             d = l2rel(gr1[k], gr0[k])
-            rep[k] = (d, l2rel(gr0[k], g["grad/" + k]), l2rel(gr1[k], g["grad/" + k]))
+            ref = g.get("grad/" + k)                              # (the full-size fixtures keep the bias gradients and norms only)
+            rep[k] = (d, l2rel(gr0[k], ref) if ref is not None else None, l2rel(gr1[k], ref) if ref is not None else None)
             assert 0 < d <= 3e-3, (k, d)
         else:
             assert np.array_equal(gr0[k], gr1[k]), k
