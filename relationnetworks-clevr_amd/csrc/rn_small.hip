@@ -156,6 +156,8 @@ constexpr int FP_RB = 4;          // rows per workgroup
 constexpr int FP_MAXW = 1024;     // widest activation the LDS staging holds
 constexpr int FP_KS = 4;          // k-slices per output feature with transposed weights (block = FP_KS * 256 threads)
 static_assert(FP_KS == FP_RB, "the slice-k thread finalises row k");
+constexpr int FP_KQ = 16;         // ... and with 16-byte column loads (N % 4 == 0): 16 k-slices x 64 four-column lanes, the same 1024 threads
+static_assert(FP_KQ * 64 == FP_KS * 256 && FP_RB * 256 == FP_KS * 256, "one block shape for both thread maps");
 // Labels outside [0, A) are CLAMPED to the nearest class, in every kernel that reads a label (these fused ones, the
 // stand-alone nll kernels, the LSTM's token lookup): a device kernel cannot raise like F.nll_loss / nn.Embedding do
 // without a host synchronisation per step.  The host wrappers document it; train.py's load_tensor_data produces
@@ -208,6 +210,48 @@ __device__ __forceinline__ void fp_cols(const float* __restrict__ W, const float
   }
 }
 
+// acc[r][0..3] += sum_{i0 <= i < i1} in[r][i] * W[i][j .. j+3]: thread = FOUR columns, one 16-byte load per weight row -- a wave
+// fetches a whole 1-KB row of a 256-wide layer per instruction, and a thread's share of the layer (K / 16 rows) is ONE batch of
+// independent loads: one L2 round trip per layer instead of two, a quarter of the load instructions.
+__device__ __forceinline__ void fp_cols4(const float* __restrict__ W, const float* in_s, int i0, int i1, int J, int j, f32x4 (&acc)[FP_RB]) {
+  int i = i0;
+  for (; i + 16 <= i1; i += 16) {
+    f32x4 w[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) w[u] = *reinterpret_cast<const f32x4*>(W + (long)(i + u) * J + j);
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+#pragma unroll
+      for (int r = 0; r < FP_RB; ++r) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(in_s + r * FP_MAXW + i + u);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          acc[r][c] = fmaf(x[3], w[u + 3][c], fmaf(x[2], w[u + 2][c], fmaf(x[1], w[u + 1][c], fmaf(x[0], w[u][c], acc[r][c]))));
+      }
+    }
+  }
+  for (; i + 4 <= i1; i += 4) {
+    f32x4 w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const f32x4*>(W + (long)(i + u) * J + j);
+#pragma unroll
+    for (int r = 0; r < FP_RB; ++r) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(in_s + r * FP_MAXW + i);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(x[3], w[3][c], fmaf(x[2], w[2][c], fmaf(x[1], w[1][c], fmaf(x[0], w[0][c], acc[r][c]))));
+    }
+  }
+  for (; i < i1; ++i) {
+    const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long)i * J + j);
+#pragma unroll
+    for (int r = 0; r < FP_RB; ++r) {
+      const float x = in_s[r * FP_MAXW + i];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(x, w[c], acc[r][c]);
+    }
+  }
+}
+
 // One layer on the block's FP_RB rows: v[r][f] = bias[f] + sum_k in[r][k] * Wop[k][f], handed to epi(r, f, v).
 // TR (transposed weights, (in, out) row-major): blockDim = FP_KS * 256, thread (ks, f) sums its quarter of k, the
 // partials meet in LDS and thread (ks, f) finalises row ks -- four times fewer dependent L2 round trips per layer.
@@ -221,7 +265,27 @@ __device__ __forceinline__ void fp_layer_pass(const float* __restrict__ W, const
     float acc[FP_RB];
 #pragma unroll
     for (int r = 0; r < FP_RB; ++r) acc[r] = 0.f;
-    if constexpr (TR) {
+    if (TR && (N & 3) == 0) {
+      // 16 k-slices x 64 lanes of four columns (thread t: slice t / 64, columns 4 (t % 64) ..); the 16 partials of an output meet
+      // in LDS and thread (row t / 256, feature t % 256) adds them in slice order
+      // (the slice is wave-uniform: row addresses are scalar, the lane adds one constant column offset)
+      const int j4 = threadIdx.x & 63, kq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), f0 = fb + 4 * j4;
+      const int chunk = ((K + FP_KQ - 1) / FP_KQ + 3) & ~3, i0 = min(K, kq * chunk), i1 = min(K, i0 + chunk);
+      f32x4 a4[FP_RB];
+#pragma unroll
+      for (int r = 0; r < FP_RB; ++r) a4[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (f0 < N) fp_cols4(W, in_s, i0, i1, N, f0, a4);
+#pragma unroll
+      for (int r = 0; r < FP_RB; ++r) *reinterpret_cast<f32x4*>(red + (kq * FP_RB + r) * 256 + 4 * j4) = a4[r];
+      __syncthreads();
+      if (f < N) {
+        float v = red[ks * 256 + tf];
+#pragma unroll
+        for (int q = 1; q < FP_KQ; ++q) v += red[(q * FP_RB + ks) * 256 + tf];
+        epi(ks, f, v + (bias ? bias[f] : 0.f));
+      }
+      __syncthreads();
+    } else if constexpr (TR) {
       const int chunk = ((K + FP_KS - 1) / FP_KS + 3) & ~3, i0 = min(K, ks * chunk), i1 = min(K, i0 + chunk);
       if (f < N) fp_cols(W, in_s, i0, i1, N, f, acc);
 #pragma unroll
@@ -252,7 +316,7 @@ __global__ __launch_bounds__(TR ? FP_KS * 256 : 256) void f_phi_fwd_kernel(
     float* __restrict__ f1, float* __restrict__ f2, float* __restrict__ out, int B, int G, int F1, int F2, int A,
     const long long* __restrict__ label = nullptr, float* __restrict__ loss = nullptr, float* loss_part = nullptr,
     unsigned* done_count = nullptr) {
-  __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW], red[FP_KS * FP_RB * 256];
+  __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW], red[FP_KQ * FP_RB * 256];
   __shared__ float lrow[FP_RB];
   const int t = threadIdx.x, r0 = blockIdx.x * FP_RB;
   for (int c = t; c < FP_RB * G; c += blockDim.x) {
@@ -315,7 +379,7 @@ __global__ __launch_bounds__(FP_KS * 256) void f_phi_bwd_dz_kernel(const float* 
                                                            float* __restrict__ dxg, int B, int G, int F1, int F2, int A,
                                                            const long long* __restrict__ label = nullptr,
                                                            const float* __restrict__ gloss = nullptr) {
-  __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW], red[FP_KS * FP_RB * 256];
+  __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW], red[FP_KQ * FP_RB * 256];
   const int t = threadIdx.x, r0 = blockIdx.x * FP_RB;
   if (t < FP_RB) {
     const int b = r0 + t;
