@@ -695,23 +695,8 @@ class RelationalFunction(torch.autograd.Function):
                     gW[0] = torch.empty(N, kt, **f32)
                     gB[0] = torch.empty(N, **f32)
                     H.wgrad0_from_reductions(Rj, Ri, Rq, x, q if plan.inject == 0 else None, gW[0], gB[0], coord=ctx.coord)
-                w0_where = os.environ.get("RN_WGRAD0_STREAM", "side")
-                if overlap and w0_where == "main_late":
-                    pass                                           # (experiment: on the main stream, behind dx / dq)
-                elif overlap and w0_where == "side1":              # (experiment: the conv weight-gradient stream)
-                    s1 = _side_stream(dev, 1)
-                    s1.wait_stream(main)
-                    with torch.cuda.stream(s1):
-                        _wgrad0()
-                    for t_ in (Rj, Ri, Rq, x, q, ctx.coord):
-                        if t_ is not None:
-                            t_.record_stream(s1)
-
-                    def _join1():
-                        torch.cuda.current_stream().wait_stream(s1)
-                    torch.autograd.Variable._execution_engine.queue_callback(_join1)
-                    keep.append([Rj, Ri, Rq, x, q, ctx.coord])
-                elif overlap:                                      # off the critical path: onto the wgrad stream
+                # (measured: on the conv weight-gradient stream instead -3.5 %, on the main stream behind dx / dq -1 %)
+                if overlap:                                        # off the critical path: onto the wgrad stream
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
                         _wgrad0()
@@ -734,8 +719,6 @@ class RelationalFunction(torch.autograd.Function):
                     H.pair_dx_dq(Rj, Ri, None, wl, dx, None, B, n, k, 0, N)                # (dq came from the injected layer)
                 if overlap and wgrad_late == 2:
                     _launch_wgrads()
-                if alg0 and overlap and os.environ.get("RN_WGRAD0_STREAM", "side") == "main_late":
-                    _wgrad0()
             elif l == 0:
                 dx = torch.empty(B, n, k, **f32)
                 H.gemm_f32(Rj, N, 1, wl, kt, 1, dx, k, B * n, k, N)                        # Rj @ W0[:, 0:k]
