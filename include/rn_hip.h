@@ -205,6 +205,10 @@ int rn_g_linear_bwd_dgrad(const void* dZ, int lddz, const void* Wt, int ldwt, co
  * dW: fp32 (N, Ktrue) contiguous (nn.Linear layout); db: fp32 (N).
  * Deterministic: split over M into per-block partials in ws, then an ordered reduction. */
 size_t rn_wgrad_ws_bytes(int M, int N, int K);
+/* Row splits Z of the streaming kernel for this product, 0 if the general kernel runs.  Z > 0: after rn_g_linear_bwd_wgrad, ws
+ * holds behind the Z*N*K weight partials Z x N fp32 column sums of dZ over rows [z*M/Z, (z+1)*M/Z) (M / 64 a multiple of Z:
+ * splits of equal size) -- per-question sums of dZ for free when a split never straddles two questions. */
+int rn_wgrad_stream_splits(int dtype, int a_dtype, int M, int N, int K, int lddz, int lda);
 /* a_dtype: the type of A -- `dtype` (the type of dZ), or RN_FP8 with dtype = RN_BF16: the e4m3 activation copies of the
  * forward chains (N == K == Ktrue == 256, M % 64 == 0, M >= 4096; lda in elements = bytes). */
 int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, int lda, int a_dtype, float* dW, float* db, void* ws,

@@ -529,6 +529,21 @@ static bool wgrad_stream_ok(int dtype, int M, int N, int K, int lddz, int lda) {
   return dtype == RN_BF16 && N == 256 && (K == 256 || K == 192) && M % 64 == 0 && M / 64 >= 64 && lddz % 8 == 0 && lda % 8 == 0;
 }
 
+// Number of row splits the streaming kernel uses for this product (0: the general kernel runs instead).  With Z splits the
+// workspace holds, behind the Z x N x K weight partials, Z x N fp32 column sums of dZ over rows [z M / Z, (z + 1) M / Z) -- the
+// bias-gradient partials.  When a split never straddles two questions they are also the per-question sums of dZ that the
+// question-injected layer's backward needs (Rq): no second pass over dZ.
+extern "C" int rn_wgrad_stream_splits(int dtype, int a_dtype, int M, int N, int K, int lddz, int lda) {
+  if (a_dtype == RN_FP8) {
+    if (!(dtype == RN_BF16 && N == 256 && K == 256 && M % 64 == 0 && M / 64 >= 64)) return 0;
+  } else if (!wgrad_stream_ok(dtype, M, N, K, lddz, lda)) {
+    return 0;
+  }
+  const char* ze = getenv("RN_WGRAD_ZS");
+  const int NB = K == 256 ? 4 : 6;
+  return ze ? atoi(ze) : 256 / NB;
+}
+
 // Weight gradient of the LAST g layer from the forward kernel's lane masks (see wgrad_stream_kernel, GEN): dW = dZ^T A,
 // db = colsum(dZ) with dZ[(b, pair), f] = (mask bit) ? bf16(dxg[b][f]) : 0 -- bitwise what rn_g_chain_bwd_rr would store.
 extern "C" int rn_g_linear_bwd_wgrad_gated(const void* mask, const float* dxg, int rows_per_question, const void* A, int lda,

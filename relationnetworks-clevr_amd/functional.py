@@ -604,8 +604,18 @@ class RelationalFunction(torch.autograd.Function):
                 # on the stored activation; the question part follows from the per-question sums Rq (_wgrad_question below)
                 gp = plan.widths[l - 1]
                 tmp = torch.empty(N_, gp, **f32)
-                H.g_linear_bwd_wgrad(dz, N_, a_l, gp, tmp, gB[l], code, M, N_, gp, gp)
+                ws_ = H.g_linear_bwd_wgrad(dz, N_, a_l, gp, tmp, gB[l], code, M, N_, gp, gp, return_ws=True)
                 gW[l][:, :gp].copy_(tmp)
+                if rq_splits:
+                    # Rq (per-question column sums of dZ) = the streaming kernel's bias-gradient partials, one row split or an
+                    # integral number of them per question -- instead of a pass of the pair-reduction kernel over the 134 MB
+                    # of dZ; dq and the question columns of dW follow at once, on this stream
+                    wl_ = g_w[l] if g_w[l].is_contiguous() else g_w[l].contiguous()
+                    rq_ = H.wgrad_db_partials(ws_, rq_splits, N_, gp).view(B, rq_splits // B, N_).sum(1)
+                    dq_ = torch.empty(B, Q, **f32)
+                    H.gemm_f32(rq_, N_, 1, wl_, kt_, 1, dq_, Q, B, Q, N_, b_off=kt_ - Q)          # Rq @ W[:, -Q:]
+                    H.gemm_f32(rq_, 1, N_, q, Q, 1, gW[l], kt_, N_, Q, B, c_off=kt_ - Q)          # gW[l][:, G_prev:] = Rq^T q
+                    inj_out["dq"], inj_out["keep"] = dq_, [ws_, rq_, wl_]
                 return
             if dz is None:                                             # last layer on the masks
                 H.g_linear_bwd_wgrad_gated(gated_mask, dxg, n * n, a_l, kp_, gW[l], gB[l], M, N_, kp_)
@@ -623,6 +633,14 @@ class RelationalFunction(torch.autograd.Function):
         # products on (B*n)-row matrices instead of a 235 MB pass over dZ_0 and P (and with fp32 x instead of P's
         # rounded copy).  RN_NO_ALGEBRAIC_WGRAD0=1 keeps the kernel.
         alg0 = alg0_wgrad_ok(plan, k) or (inj and k <= 32)
+        # question injected at layer > 0: its per-question sums Rq from the wgrad kernel's per-split column sums when no split
+        # straddles two questions (64 splits: B | 64), else from the pair-reduction kernel
+        rq_splits, inj_out = 0, {}
+        if inj and fused_bwd and os.environ.get("RN_NO_RQ_FROM_WGRAD", "0") != "1":
+            li = plan.inject
+            z_ = H.wgrad_stream_splits(dZ_of[li], plan.widths[li], inputs[li], plan.widths[li - 1], code, M, plan.widths[li], plan.widths[li - 1])
+            if z_ > 0 and z_ % B == 0 and (M // 64) % z_ == 0 and (n * n) % (M // z_) == 0:
+                rq_splits = z_
         # RN_WGRAD_LATE=1 / 2 starts the (HBM-bound) wgrad stream only after the pair reduction / after dx, dq: measured
         # slower (1.102 / 1.137 vs 1.092 ms; all wgrads serially at the very end of the backward pass: 1.165) -- the window after the backward chain runs at the HBM roofline (~4 TB/s over
         # wgrad + pair reduction, tools/step_timeline.py) wherever the wgrads are put, and later they slow the conv backward
@@ -635,10 +653,16 @@ class RelationalFunction(torch.autograd.Function):
             def _launch_wgrads():
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    for l in range(L):
+                    order = list(range(L))
+                    if rq_splits:                                  # (its dq is waited for by the main stream: first)
+                        order.remove(plan.inject)
+                        order.insert(0, plan.inject)
+                    for l in order:
                         if l == 0 and alg0:
                             continue                               # layer 0: from the pair reductions, below
                         _wgrad(l, dz_all[l], inputs_all[l])
+                        if rq_splits and l == plan.inject:
+                            inj_out["event"] = side.record_event()
             inputs_all = list(inputs)
             if not wgrad_late:
                 _launch_wgrads()
@@ -658,7 +682,9 @@ class RelationalFunction(torch.autograd.Function):
             wl = g_w[l] if g_w[l].is_contiguous() else g_w[l].contiguous()
             fused_tail = (l == 0 and (plan.inject == 0 or inj) and k <= 32
                           and os.environ.get("RN_NO_FUSED_PAIR_TAIL", "0") != "1")
-            if l == plan.inject:
+            if l == plan.inject and l > 0 and rq_splits:
+                pass                                               # Rq, dq and the question columns of dW: done with the layer's wgrad
+            elif l == plan.inject:
                 Rq = torch.empty(B, N, **f32)
                 if l == 0:
                     Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32)
@@ -730,6 +756,12 @@ class RelationalFunction(torch.autograd.Function):
                 dZ = dZp
             inputs[l] = None
         ctx.inputs = None
+        if rq_splits:
+            dq = inj_out["dq"]
+            if "event" in inj_out:                                 # produced on the wgrad stream
+                torch.cuda.current_stream().wait_event(inj_out["event"])
+                dq.record_stream(torch.cuda.current_stream())
+                keep.append(inj_out["keep"])
         grads = [dx if ctx.needs_input_grad[0] else None, dq if ctx.needs_input_grad[1] else None, None, None, None, None, None, None]
         grads += gW + gB + [dW1, dW2, dW3, db1, db2, db3]
         return tuple(grads)

@@ -52,6 +52,7 @@ SIGNATURES = {
     "rn_pair_sum_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "rn_g_linear_bwd_dgrad": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "rn_wgrad_ws_bytes": (_Z, [_I, _I, _I]),
+    "rn_wgrad_stream_splits": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "rn_g_linear_bwd_wgrad": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_pair_reduce_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_reduce_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -423,7 +424,17 @@ def g_linear_bwd_dgrad(dZ, lddz, Wt, ldwt, Hprev, ldhp, dZprev, lddzp, code, M, 
 
 
 @_timed("g_wgrad")
-def g_linear_bwd_wgrad(dZ, lddz, A, lda, dW, db, code, M, N, K, Ktrue):
+def wgrad_stream_splits(dZ, lddz, A, lda, code, M, N, K):
+    """Row splits of the streaming wgrad kernel for this product (0: general kernel) -- see rn_wgrad_stream_splits."""
+    return load().rn_wgrad_stream_splits(code, RN_FP8 if A.dtype in FP8_DTYPES else code, M, N, K, lddz, lda)
+
+
+def wgrad_db_partials(ws, Z, N, K):
+    """The (Z, N) fp32 column sums of dZ per row split that rn_g_linear_bwd_wgrad left in its workspace."""
+    return ws.view(torch.float32)[Z * N * K: Z * N * K + Z * N].view(Z, N)
+
+
+def g_linear_bwd_wgrad(dZ, lddz, A, lda, dW, db, code, M, N, K, Ktrue, return_ws=False):
     lib = load()
     nb = lib.rn_wgrad_ws_bytes(M, N, K)
     if nb == 0:
@@ -431,6 +442,8 @@ def g_linear_bwd_wgrad(dZ, lddz, A, lda, dW, db, code, M, N, K, Ktrue):
     ws = torch.empty(nb, dtype=torch.uint8, device=dW.device)
     _check(lib.rn_g_linear_bwd_wgrad(dZ.data_ptr(), lddz, A.data_ptr(), lda, RN_FP8 if A.dtype in FP8_DTYPES else code, dW.data_ptr(), _ptr(db),
                                      ws.data_ptr(), code, M, N, K, Ktrue, _stream()), "rn_g_linear_bwd_wgrad")
+    if return_ws:
+        return ws
 
 
 @_timed("g_wgrad")
