@@ -423,7 +423,6 @@ def g_linear_bwd_dgrad(dZ, lddz, Wt, ldwt, Hprev, ldhp, dZprev, lddzp, code, M, 
                                         lddzp, code, M, N, Kin, _stream()), "rn_g_linear_bwd_dgrad")
 
 
-@_timed("g_wgrad")
 def wgrad_stream_splits(dZ, lddz, A, lda, code, M, N, K):
     """Row splits of the streaming wgrad kernel for this product (0: general kernel) -- see rn_wgrad_stream_splits."""
     return load().rn_wgrad_stream_splits(code, RN_FP8 if A.dtype in FP8_DTYPES else code, M, N, K, lddz, lda)
@@ -434,6 +433,7 @@ def wgrad_db_partials(ws, Z, N, K):
     return ws.view(torch.float32)[Z * N * K: Z * N * K + Z * N].view(Z, N)
 
 
+@_timed("g_wgrad")
 def g_linear_bwd_wgrad(dZ, lddz, A, lda, dW, db, code, M, N, K, Ktrue, return_ws=False):
     lib = load()
     nb = lib.rn_wgrad_ws_bytes(M, N, K)
