@@ -374,7 +374,9 @@ def main():
                        "precision_requested": args.precision, "precision_resolved": prec,
                        "wgrad_activation_copies": ("e4m3 (H_0..2 kept for dW_1..3 only; RN_H8=0: 16-bit)"
                                                    if prec in ("bf16", "f16s") and os.environ.get("RN_H8", "1") != "0" else "as the mode's storage type"),
-                       "launch": "hipGraph replay of fwd+bwd, eager all-reduce/clip/Adam" if use_graph else "eager"},
+                       "launch": ("eager" if not use_graph else
+                                  "one hipGraph replay per step: fwd + bwd + clip + Adam" if getattr(trainer, "_opt_in_graph", False) else
+                                  "hipGraph replay of fwd+bwd, eager all-reduce/clip/Adam")},
             "loss": float(loss.detach()),
         }
         if world == 1 and not args.no_parity:

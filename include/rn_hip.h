@@ -308,6 +308,11 @@ int rn_clip_adam_chunk(void);
 size_t rn_clip_adam_ws_bytes(void);
 int rn_clip_adam_step(const void* chunks, int nchunks, float* g, float* m, float* v, long n, void* ws, float grad_scale, float max_norm, float lr,
                       float beta1, float beta2, float eps, float weight_decay, int step, float* norm_out, void* stream);
+/* ... with the per-step scalars in device memory, so that the two launches can be part of a captured hipGraph: hyper = 7 floats
+ * {grad_scale, max_norm, lr, beta1, beta2, eps, weight_decay} (rewritten by the host only when they change), step_dev[0] = the
+ * update count so far (incremented by the call; bias corrections from it, in double, as on the host). */
+int rn_clip_adam_step_dev(const void* chunks, int nchunks, float* g, float* m, float* v, long n, void* ws, const float* hyper,
+                          int* step_dev, float* norm_out, void* stream);
 
 /* Question encoder (reference model.py:39-58): embedding lookup + 1-layer LSTM (E = 32 -> H = 128, gate order
  * i, f, g, o, zero initial state) as ONE launch per direction (rn_lstm.hip), fp32.

@@ -553,8 +553,10 @@ constexpr int OPT_CHUNK = 1024;    // elements per chunk of the update pass (a c
 }  // namespace
 struct RnAdamChunk { float* param; long flat_off; int count; int pad; };
 
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, double* __restrict__ partial,
+                                                            int* __restrict__ step_dev = nullptr) {
   __shared__ double red[4];
+  if (step_dev && blockIdx.x == 0 && threadIdx.x == 0) step_dev[0] += 1;   // device-side update count (rn_clip_adam_step_dev): the next launch reads it
   float a = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a = fmaf(g[i], g[i], a);
   double x = (double)a;
@@ -569,8 +571,22 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const RnAdamChunk* __res
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         const double* __restrict__ partial, int npartial, float gscale,
                                                         float max_norm, float lr, float beta1, float beta2, float eps, float wd, float bc1,
-                                                        float bc2_sqrt, float* __restrict__ norm_out) {
-  __shared__ float coef_s;
+                                                        float bc2_sqrt, float* __restrict__ norm_out, const float* __restrict__ hyper = nullptr,
+                                                        const int* __restrict__ step_dev = nullptr) {
+  __shared__ float coef_s, hs[8];
+  if (hyper) {
+    // hyper-parameters and the update count from device memory: the launch can sit in a captured graph and still follow an LR
+    // schedule.  hyper = {grad_scale, max_norm, lr, beta1, beta2, eps, weight_decay}; bias corrections as on the host (double)
+    if (threadIdx.x == 0) {
+      const double t = (double)step_dev[0];
+      hs[0] = hyper[0]; hs[1] = hyper[1]; hs[2] = hyper[2]; hs[3] = hyper[3]; hs[4] = hyper[4]; hs[5] = hyper[5]; hs[6] = hyper[6];
+      hs[7] = (float)(1.0 - pow((double)hyper[3], t));
+      coef_s = (float)sqrt(1.0 - pow((double)hyper[4], t));
+    }
+    __syncthreads();
+    gscale = hs[0]; max_norm = hs[1]; lr = hs[2]; beta1 = hs[3]; beta2 = hs[4]; eps = hs[5]; wd = hs[6]; bc1 = hs[7]; bc2_sqrt = coef_s;
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     double s = 0.0;
     for (int i = 0; i < npartial; ++i) s += partial[i];
@@ -614,6 +630,20 @@ extern "C" int rn_clip_adam_step(const void* chunks, int nchunks, float* g, floa
   clip_adam_kernel<<<nchunks, 256, 0, s>>>((const RnAdamChunk*)chunks, g, m, v, (const double*)ws, OPT_NB, grad_scale, max_norm, lr, beta1, beta2,
                                            eps, weight_decay, (float)bc1, (float)sqrt(bc2), norm_out);
   RN_LAUNCH_CHECK("rn_clip_adam_step");
+  return 0;
+}
+
+// The same two launches with every per-step scalar in device memory: hyper (7 floats: grad_scale, max_norm, lr, beta1, beta2, eps,
+// weight_decay) and the 1-based update count step_dev[0], which the first launch increments -- capturable in a hipGraph (the
+// host rewrites `hyper` only when a scheduler changes it).
+extern "C" int rn_clip_adam_step_dev(const void* chunks, int nchunks, float* g, float* m, float* v, long n, void* ws, const float* hyper,
+                                     int* step_dev, float* norm_out, void* stream) {
+  RN_CHECK_ARG(chunks && nchunks > 0 && g && m && v && n > 0 && ws && hyper && step_dev, "rn_clip_adam_step_dev: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  sumsq_partial_kernel<<<OPT_NB, 256, 0, s>>>(g, n, (double*)ws, step_dev);
+  clip_adam_kernel<<<nchunks, 256, 0, s>>>((const RnAdamChunk*)chunks, g, m, v, (const double*)ws, OPT_NB, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f,
+                                           norm_out, hyper, step_dev);
+  RN_LAUNCH_CHECK("rn_clip_adam_step_dev");
   return 0;
 }
 

@@ -144,6 +144,11 @@ class FusedClipAdam:
         self.ws = torch.empty(H.load().rn_clip_adam_ws_bytes(), dtype=torch.uint8, device=dev)
         self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.t = 0
+        # in-graph mode (one GPU): every per-step scalar lives in device memory -- hyper = {grad_scale, max_norm, lr, beta1, beta2,
+        # eps, weight_decay}, t_dev = update count -- so the two launches can be captured with the rest of the step
+        self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._hyper_host = None
 
     @staticmethod
     def supports(bucket, optimizer):
@@ -156,6 +161,34 @@ class FusedClipAdam:
             return False
         ids = {id(p) for p in g["params"]}
         return ids == {id(p) for p in bucket.params} and all(p.is_contiguous() for p in bucket.params)
+
+    def sync_hyper(self, clip_norm, grad_scale=1.0):
+        """Host side of the in-graph mode, before every replay: rewrite the device scalars if (and only if) a scheduler or the
+        caller changed them, and bring the device update count in line with the host's (the two modes can be mixed)."""
+        g = self.opt.param_groups[0]
+        cur = (float(grad_scale), float(clip_norm or 0.0), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+               float(g["weight_decay"]), 0.0)
+        if cur != self._hyper_host:
+            self.hyper.copy_(torch.tensor(cur, dtype=torch.float32), non_blocking=False)
+            self._hyper_host = cur
+        if self._t_dev_host != self.t:
+            self.t_dev.fill_(self.t)
+            self._t_dev_host = self.t
+
+    _t_dev_host = 0
+
+    def step_dev(self):
+        """The two launches with device-side scalars (capturable); the caller runs sync_hyper() before and after_step_dev() after
+        every execution."""
+        self.H.clip_adam_step_dev(self.chunks, self.nchunks, self.bucket.flat, self.m, self.v, self.ws, self.hyper, self.t_dev, self.norm)
+
+    def after_step_dev(self):
+        if [p.data_ptr() for p in self.bucket.params] != self.ptrs:
+            raise RuntimeError("a parameter's storage moved since the trainer was built (load_state_dict copies in place; .data = ... does not)")
+        self.t += 1
+        self._t_dev_host = self.t                          # (the kernel incremented its own count)
+        torch.autograd.graph.increment_version(self.bucket.params)
+        return self.norm
 
     def step(self, clip_norm, grad_scale=1.0):
         if [p.data_ptr() for p in self.bucket.params] != self.ptrs:
@@ -187,6 +220,11 @@ class DataParallelTrainer:
         self._graph = None
         self._static = None
         self._fused_opt = FusedClipAdam(self.bucket, optimizer) if FusedClipAdam.supports(self.bucket, optimizer) else None
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        # one GPU: nothing sits between backward and the optimiser, so clip + Adam join the captured step (no eager -> graph
+        # boundary: ~25 us of idle chip per step); with more ranks the all-reduce stays eager and the optimiser follows it
+        self._opt_in_graph = (use_graph and self._fused_opt is not None and world == 1
+                              and os.environ.get("RN_NO_GRAPH_ADAM", "0") != "1")
 
     def _fwd_bwd(self, img, qst, label):
         self.bucket.detach_()
@@ -211,6 +249,8 @@ class DataParallelTrainer:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self._loss = self._fwd_bwd(*self._static)
+            if self._opt_in_graph:
+                self._fused_opt.step_dev()
         self._graph = graph
 
     def step(self, img, qst, label):
@@ -220,9 +260,14 @@ class DataParallelTrainer:
             for dst, src in zip(self._static, (img, qst, label)):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
+            if self._opt_in_graph:
+                self._fused_opt.sync_hyper(self.clip_norm, 1.0)
             self._graph.replay()
             self.bucket.attach_()
             loss = self._loss
+            if self._opt_in_graph:
+                self._fused_opt.after_step_dev()
+                return loss
         else:
             loss = self._fwd_bwd(img, qst, label)
         if self._fused_opt is not None:

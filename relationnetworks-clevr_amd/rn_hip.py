@@ -78,6 +78,7 @@ SIGNATURES = {
     "rn_nll_mean_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "rn_clip_adam_chunk": (_I, []),
     "rn_clip_adam_ws_bytes": (_Z, []),
+    "rn_clip_adam_step_dev": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P]),
     "rn_clip_adam_step": (_I, [_P, _I, _P, _P, _P, _L, _P] + [C.c_float] * 7 + [_I, _P, _P]),
     "rn_conv3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_conv3x3s2_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -595,6 +596,12 @@ def clip_adam_step(chunks, nchunks, g, m, v, ws, max_norm, lr, beta1, beta2, eps
     _check(load().rn_clip_adam_step(chunks.data_ptr(), nchunks, g.data_ptr(), m.data_ptr(), v.data_ptr(), g.numel(), ws.data_ptr(),
                                     float(grad_scale), float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step),
                                     _ptr(norm_out), _stream()), "rn_clip_adam_step")
+
+
+def clip_adam_step_dev(chunks, nchunks, g, m, v, ws, hyper, step_dev, norm_out=None):
+    """clip + Adam with the per-step scalars in device memory (hyper: 7 floats, step_dev: int32 count) -- capturable."""
+    _check(load().rn_clip_adam_step_dev(chunks.data_ptr(), nchunks, g.data_ptr(), m.data_ptr(), v.data_ptr(), g.numel(), ws.data_ptr(),
+                                        hyper.data_ptr(), step_dev.data_ptr(), _ptr(norm_out), _stream()), "rn_clip_adam_step_dev")
 
 
 # ------------------------------------------------------------------ question encoder (embedding + LSTM)

@@ -355,3 +355,46 @@ def test_ir_fp_graph_trainer_matches_eager_and_learns(T):
     eager, graph = run(False, 6), run(True, 40)
     assert eager == graph[:6], (eager, graph[:6])
     assert np.isfinite(graph[-1]) and graph[-1] < 0.5 * graph[0], (graph[0], graph[-1])
+
+
+@pytest.mark.gpu
+def test_in_graph_clip_adam_follows_the_eager_optimiser_and_an_lr_schedule(T, monkeypatch):
+    """One GPU: clip + Adam are part of the captured step (rn_clip_adam_step_dev: hyper-parameters and the update count live in
+    device memory).  Against the same trainer with the optimiser launched eagerly behind the replay (RN_NO_GRAPH_ADAM=1): the
+    same parameters after 6 steps with the learning rate changed by a scheduler after step 3 (bitwise: same kernels, same
+    arithmetic), and the update count / moments stay usable when the modes are mixed."""
+    import relationnetworks_clevr_amd as pkg
+    from relationnetworks_clevr_amd import dp
+
+    class A:
+        qdict_size, adict_size = 82, 28
+
+    batch = next(iter(T.SyntheticClevr(16, 16, seed=5)))
+    img, q, y = T.load_tensor_data(batch, "cuda")
+
+    def run(in_graph):
+        monkeypatch.setenv("RN_NO_GRAPH_ADAM", "0" if in_graph else "1")
+        torch.manual_seed(0)
+        m = pkg.RN(A, dict(formula.HYP["original-fp"], dropout=0.0)).cuda()
+        opt = torch.optim.Adam(m.parameters(), lr=3e-4, weight_decay=1e-4)
+        tr = dp.DataParallelTrainer(m, opt, clip_norm=0.5, use_graph=True)
+        assert tr._opt_in_graph == in_graph
+        losses = []
+        for s in range(6):
+            if s == 3:
+                opt.param_groups[0]["lr"] = 1e-3            # what StepLR / the slow-start schedule does
+            losses.append(float(tr.step(img, q, y).detach()))
+        assert tr._fused_opt.t == 6 and int(tr._fused_opt.t_dev.item()) == (6 if in_graph else 0)
+        return [p.detach().clone() for p in m.parameters()], losses, tr
+
+    pa, la, tra = run(True)
+    pb, lb, trb = run(False)
+    assert la == lb, (la, lb)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+    assert torch.equal(tra._fused_opt.m, trb._fused_opt.m) and torch.equal(tra._fused_opt.v, trb._fused_opt.v)
+    # mixing the modes: one eager optimiser step on the in-graph trainer, then a replay -- the device count follows the host's
+    tra._fused_opt.step(0.5, 1.0)
+    assert tra._fused_opt.t == 7
+    tra.step(img, q, y)
+    assert tra._fused_opt.t == 8 and int(tra._fused_opt.t_dev.item()) == 8
