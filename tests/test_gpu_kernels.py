@@ -1056,3 +1056,48 @@ def test_f_phi_large_batch_and_label_clamp(H, B):
     torch.cuda.synchronize()
     for got, want in zip([dxg] + dW + db, [p.grad for p in ps]):
         assert rel(got.cpu().numpy(), want.cpu().numpy()) <= 2e-4
+
+
+@pytest.mark.parametrize("f16s", [False, True])
+def test_e4m3_copies_saturate_instead_of_turning_into_nan(H, f16s):
+    """Activations beyond the e4m3 range (448) must be stored as 448 (byte 0x7e), never as the NaN byte the raw conversion
+    produces: a layer-0 bias of +600 drives every H_0 value there; the wgrad that reads the copies then stays finite."""
+    B, n, L, G, k, Q = 1, 64, 4, 256, 26, 128
+    M, kt = B * n * n, 2 * 26 + 128
+    x = formula.hash_uniform((B, n, k), 500, -1, 1).astype(np.float32)
+    q = formula.hash_uniform((B, Q), 501, -1, 1).astype(np.float32)
+    Ws = [formula.hash_uniform((G, kt if l == 0 else G), 510 + l, -0.02, 0.02).astype(np.float32) for l in range(L)]
+    bs = [np.full((G,), 600.0 if l == 0 else 0.1, np.float32) for l in range(L)]
+    wd = [dev(w) for w in Ws]
+    w0T = torch.empty(kt, G, device="cuda")
+    dt16 = torch.float16 if f16s else torch.bfloat16
+    Xp = torch.empty(B * n, 64, dtype=dt16, device="cuda"); Vc = torch.empty(B * n, G, device="cuda")
+    Hs8 = [torch.zeros(M, G, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [None]
+    masks = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
+    part = torch.empty(M // 32, G, device="cuda")
+    bd = [dev(b) for b in bs]
+    if f16s:
+        hi = [torch.empty(65536, dtype=torch.float16, device="cuda") for _ in range(L)]; lo = [torch.empty(65536, dtype=torch.float16, device="cuda") for _ in range(L)]
+        jobs = [(wd[0], kt, 1, G, k, hi[0], 4 | 1), (wd[0], kt, 1, G, k, lo[0], 8 | 1), (wd[0], kt, 1, G, kt, w0T, 2)]
+        for l in range(1, L):
+            jobs += [(wd[l], G, 1, G, G, hi[l], 4), (wd[l], G, 1, G, G, lo[l], 8)]
+        H.pack_matrix_frag_many(jobs)
+        H.pair_tables(dev(x), dev(q), w0T, bd[0], Xp, Vc, B, n, k, Q, G)
+        H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hi, lo, bd, Hs8, masks, part, M, G)
+    else:
+        Wf = [torch.empty(65536, dtype=torch.bfloat16, device="cuda") for _ in range(L)]
+        H.pack_matrix_frag_many([(wd[0], kt, 1, G, k, Wf[0], 1), (wd[0], kt, 1, G, kt, w0T, 2)] + [(wd[l], G, 1, G, G, Wf[l], 0) for l in range(1, L)])
+        H.pair_tables(dev(x), dev(q), w0T, bd[0], Xp, Vc, B, n, k, Q, G)
+        H.g_chain_fwd_rr_alg0(Xp, Vc, n, Wf, bd, Hs8, masks, part, M, G)
+    torch.cuda.synchronize()
+    b0 = Hs8[0].view(torch.uint8)
+    assert bool((b0 == 0x7e).all()), torch.unique(b0).tolist()[:8]
+    for l in (1, 2):
+        assert not bool(((Hs8[l].view(torch.uint8) & 0x7f) == 0x7f).any()), l
+    dZ = (torch.rand(M, G, device="cuda") - 0.5).bfloat16()
+    dW = torch.empty(G, G, device="cuda"); db = torch.empty(G, device="cuda")
+    H.g_linear_bwd_wgrad(dZ, G, Hs8[0], G, dW, db, H.RN_BF16, M, G, G, G)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dW).all())
+    ref = (dZ.double().sum(0) * 448.0)[:, None].expand(G, G)
+    assert rel(dW.cpu().numpy(), ref.cpu().numpy()) <= 1e-5
