@@ -149,6 +149,7 @@ class FusedClipAdam:
         self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self._hyper_host = None
+        self._t_dev_host = 0                               # the device count as the host knows it
 
     @staticmethod
     def supports(bucket, optimizer):
@@ -174,8 +175,6 @@ class FusedClipAdam:
         if self._t_dev_host != self.t:
             self.t_dev.fill_(self.t)
             self._t_dev_host = self.t
-
-    _t_dev_host = 0
 
     def step_dev(self):
         """The two launches with device-side scalars (capturable); the caller runs sync_hyper() before and after_step_dev() after
