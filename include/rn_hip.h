@@ -275,6 +275,13 @@ int rn_pair_features(const void* A, int lda, int F, float* maxf, float* avgf, vo
 int rn_f_phi_fwd(const float* xg, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                  const float* b3, const float* mask, float* f1, float* f2, float* out, int transposed, int B, int G, int F1,
                  int F2, int A, void* stream);
+/* rn_f_phi_fwd(_nll) with rn_pair_sum_fwd folded in: xg_part (B * parts_per_row, G) fp32 = the forward chains' partial pair sums
+ * (one row per 256-row tile on the factored-first-layer paths), xg (B, G) is an OUTPUT (the sums, partial rows added in order:
+ * deterministic).  label / loss / sync_ws: all three (loss folded in, as rn_f_phi_fwd_nll) or all NULL. */
+int rn_f_phi_fwd_from_partials(const float* xg_part, int parts_per_row, float* xg, const float* W1, const float* b1, const float* W2,
+                               const float* b2, const float* W3, const float* b3, const float* mask, const long long* label, float* f1,
+                               float* f2, float* out, float* loss, void* sync_ws, int transposed, int B, int G, int F1, int F2, int A,
+                               void* stream);
 size_t rn_f_phi_bwd_ws_bytes(int B, int F1, int F2, int A);
 int rn_f_phi_bwd(const float* gout, const float* out, const float* f2, const float* f1, const float* xg, const float* W1,
                  const float* W2, const float* W3, const float* mask, float* dW1, float* db1, float* dW2, float* db2,
@@ -369,7 +376,9 @@ int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const float* gamm
  *   rn_g_chain_fwd_rr_alg0: the register-resident forward chain on those tables -- layer 0 is a K = 64 product on the
  *     object rows with the Vc row of (question, i) as its bias; the pair matrix never exists.  Wf[0] is the fragment-major
  *     image of W0[:, 0:k] (natural layout), Wf[1..3] as for rn_g_chain_fwd_rr.  n % 32 == 0, M = B*n*n.  H / mask: both NULL
- *     (inference) or H_0..2 (H[3] NULL) + the four masks (training); xg_part (M/32, 256) fp32 as for rn_g_chain_fwd_rr. */
+ *     (inference) or H_0..2 (H[3] NULL) + the four masks (training); xg_part (M/256, 256) fp32: ONE partial pair-sum row per
+ *     256-row tile (the tile's eight waves add their rows on chip; a tile lies inside one question) -- reduce with
+ *     rn_pair_sum_fwd(xg_part, 256, xg, ws, RN_F32, B, n*n/256, 256).  The same for rn_g_chain_fwd_rr_f16s_alg0. */
 /* Coordinate tagging fused (model.py:195-201, 208-218): with coord != NULL the object (b, p) is [x[b, p, 0:kf] | coord[0:k-kf, p]]
  * -- x is then the conv grid itself, viewed (B, n, kf) at element strides, and coord the (k - kf, n) fp32 table of
  * RN.build_coord_tensor (channel 0 = x = lin[p % d], channel 1 = y = lin[p / d]); no concatenated tensor exists.

@@ -251,7 +251,7 @@ struct FwdVm {
     if (INJ > 0 && sidx == VQ_STAGE) k += 1;
     return k;
   }
-  static constexpr int tail() { return (STORE && ST3 ? 4 : 0) + (XG ? 8 : 0); }
+  static constexpr int tail() { return (STORE && ST3 ? 4 : 0) + (XG ? (ALG0 ? 1 : 8) : 0); }
   static constexpr int younger(int sidx, bool first) {
     int k = 0;
     for (int t = sidx - 5; t < sidx; ++t) k += t >= 0 ? ops(t) : (first ? 0 : ops(t + 8 * RR_L));
@@ -535,7 +535,26 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
 #pragma unroll
         for (int q = 0; q < 2; ++q) co_store(RR_L - 1, 7, q);
       }
-      if constexpr (XG) {
+      if constexpr (XG && ALG0) {
+        // the factored-first-layer paths (a tile lies inside one question): the eight waves' partial rows meet in the staging
+        // area, idle since the last copy-out, and ONE row per tile leaves -- (M / 256, 256) instead of (M / 32, 256) for the
+        // reduction launch behind this kernel.  Wave w adds feature block w in wave order (deterministic).
+        float* const xs_s = reinterpret_cast<float*>(lds + RR_OFF_STG);
+#pragma unroll
+        for (int ob = 0; ob < 8; ++ob) {
+          const float tot = xs[ob] + __shfl_xor(xs[ob], 32);          // the two 16-row halves of this wave's 32 rows
+          if (h == 0) xs_s[w * RR_G + 32 * ob + n] = tot;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (h == 0) {
+          float v = xs_s[32 * w + n];
+#pragma unroll
+          for (int q = 1; q < RR_NW; ++q) v += xs_s[q * RR_G + 32 * w + n];
+          xg_part[(long)tile * RR_G + 32 * w + n] = v;
+        }
+      } else if constexpr (XG) {
 #pragma unroll
         for (int ob = 0; ob < 8; ++ob) {
           const float tot = xs[ob] + __shfl_xor(xs[ob], 32);          // the two 16-row halves of this wave's 32 rows
@@ -596,7 +615,7 @@ struct F16Vm {
     if (INJ > 0 && sidx == VQ_STAGE) k += 1;
     return k;
   }
-  static constexpr int tail() { return (STORE && ST3 ? 4 : 0) + (XG ? 8 : 0); }
+  static constexpr int tail() { return (STORE && ST3 ? 4 : 0) + (XG ? (ALG0 ? 1 : 8) : 0); }
   // weights of stage s+1 were requested in stage s+1-F_LA: younger are the stages s-(F_LA-2) .. s-1
   static constexpr int younger(int sidx, bool first) {
     int k = 0;
@@ -871,10 +890,29 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
 #pragma unroll
         for (int q = 0; q < 2; ++q) co_store(RR_L - 1, 7, q);
       }
-      if constexpr (XG) {
+      if constexpr (XG && ALG0) {
+        // the factored-first-layer paths (a tile lies inside one question): the eight waves' partial rows meet in the staging
+        // area, idle since the last copy-out, and ONE row per tile leaves -- (M / 256, 256) instead of (M / 32, 256) for the
+        // reduction launch behind this kernel.  Wave w adds feature block w in wave order (deterministic).
+        float* const xs_s = reinterpret_cast<float*>(lds + RR_OFF_STG);
 #pragma unroll
         for (int ob = 0; ob < 8; ++ob) {
-          const float tot = xs[ob] + __shfl_xor(xs[ob], 32);
+          const float tot = xs[ob] + __shfl_xor(xs[ob], 32);          // the two 16-row halves of this wave's 32 rows
+          if (h == 0) xs_s[w * RR_G + 32 * ob + n] = tot;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (h == 0) {
+          float v = xs_s[32 * w + n];
+#pragma unroll
+          for (int q = 1; q < RR_NW; ++q) v += xs_s[q * RR_G + 32 * w + n];
+          xg_part[(long)tile * RR_G + 32 * w + n] = v;
+        }
+      } else if constexpr (XG) {
+#pragma unroll
+        for (int ob = 0; ob < 8; ++ob) {
+          const float tot = xs[ob] + __shfl_xor(xs[ob], 32);          // the two 16-row halves of this wave's 32 rows
           if (h == 0) xg_part[((long)tile * RR_NW + w) * RR_G + 32 * ob + n] = tot;
         }
       }

@@ -315,13 +315,37 @@ __global__ __launch_bounds__(TR ? FP_KS * 256 : 256) void f_phi_fwd_kernel(
     const float* __restrict__ b2, const float* __restrict__ W3, const float* __restrict__ b3, const float* __restrict__ mask,
     float* __restrict__ f1, float* __restrict__ f2, float* __restrict__ out, int B, int G, int F1, int F2, int A,
     const long long* __restrict__ label = nullptr, float* __restrict__ loss = nullptr, float* loss_part = nullptr,
-    unsigned* done_count = nullptr) {
+    unsigned* done_count = nullptr, const float* __restrict__ xg_part = nullptr, int parts = 0, float* __restrict__ xg_out = nullptr) {
   __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW], red[FP_KQ * FP_RB * 256];
   __shared__ float lrow[FP_RB];
   const int t = threadIdx.x, r0 = blockIdx.x * FP_RB;
-  for (int c = t; c < FP_RB * G; c += blockDim.x) {
-    const int r = c / G, k = c - r * G;
-    sa[r * FP_MAXW + k] = (r0 + r < B) ? xg[(long)(r0 + r) * G + k] : 0.f;
+  if (xg_part) {
+    // the pair sum (model.py:151-152) of this block's rows from the forward chain's per-tile partial rows -- xg_part[(b * parts + p)][G],
+    // added in the order p = 0, 1, ... (deterministic) -- instead of a reduction launch of its own in front of this one (16 partial
+    // rows per question at the headline shape: 64 KB per block).  xg_out gets the sums: the backward pass reads them.
+    for (int c = t; c < FP_RB * G; c += blockDim.x) {
+      const int r = c / G, k = c - r * G;
+      float v = 0.f;
+      if (r0 + r < B) {
+        const float* src = xg_part + (long)(r0 + r) * parts * G + k;
+        int p = 0;
+        for (; p + 8 <= parts; p += 8) {
+          float u[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) u[i] = src[(long)(p + i) * G];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v += u[i];
+        }
+        for (; p < parts; ++p) v += src[(long)p * G];
+        xg_out[(long)(r0 + r) * G + k] = v;
+      }
+      sa[r * FP_MAXW + k] = v;
+    }
+  } else {
+    for (int c = t; c < FP_RB * G; c += blockDim.x) {
+      const int r = c / G, k = c - r * G;
+      sa[r * FP_MAXW + k] = (r0 + r < B) ? xg[(long)(r0 + r) * G + k] : 0.f;
+    }
   }
   __syncthreads();
   fp_layer_pass<TR>(W1, b1, sa, G, F1, red, [&](int r, int f, float z) {
@@ -502,6 +526,24 @@ extern "C" int rn_f_phi_fwd_nll(const float* xg, const float* W1, const float* b
   if (transposed) f_phi_fwd_kernel<true><<<cdiv(B, FP_RB), FP_KS * 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A, label, loss, part, cnt);
   else f_phi_fwd_kernel<false><<<cdiv(B, FP_RB), 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A, label, loss, part, cnt);
   RN_LAUNCH_CHECK("rn_f_phi_fwd_nll");
+  return 0;
+}
+
+// ... and with the pair sum in front (rn_pair_sum_fwd on the forward chains' partial rows folded into this launch): xg (B, G) is an
+// OUTPUT here, xg_part (B * parts_per_row, G) fp32 the chain's partials.  label / loss / sync_ws NULL: no loss.
+extern "C" int rn_f_phi_fwd_from_partials(const float* xg_part, int parts_per_row, float* xg, const float* W1, const float* b1,
+                                          const float* W2, const float* b2, const float* W3, const float* b3, const float* mask,
+                                          const long long* label, float* f1, float* f2, float* out, float* loss, void* sync_ws,
+                                          int transposed, int B, int G, int F1, int F2, int A, void* stream) {
+  RN_CHECK_ARG(xg_part && parts_per_row > 0 && xg && W1 && b1 && W2 && b2 && W3 && b3 && f1 && f2 && out, "rn_f_phi_fwd_from_partials: NULL pointer / bad count");
+  RN_CHECK_ARG((label != nullptr) == (loss != nullptr) && (label != nullptr) == (sync_ws != nullptr), "rn_f_phi_fwd_from_partials: label, loss and sync_ws go together");
+  if (int rc = fp_check("rn_f_phi_fwd_from_partials", B, G, F1, F2, A)) return rc;
+  RN_CHECK_ARG(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)W3) % 16 == 0, "rn_f_phi_fwd_from_partials: weights must be 16-byte aligned");
+  unsigned* cnt = label ? (unsigned*)sync_ws : nullptr;
+  float* part = label ? (float*)sync_ws + 4 : nullptr;
+  if (transposed) f_phi_fwd_kernel<true><<<cdiv(B, FP_RB), FP_KS * 256, 0, (hipStream_t)stream>>>(nullptr, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A, label, loss, part, cnt, xg_part, parts_per_row, xg);
+  else f_phi_fwd_kernel<false><<<cdiv(B, FP_RB), 256, 0, (hipStream_t)stream>>>(nullptr, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A, label, loss, part, cnt, xg_part, parts_per_row, xg);
+  RN_LAUNCH_CHECK("rn_f_phi_fwd_from_partials");
   return 0;
 }
 

@@ -258,7 +258,7 @@ def _tables(x, q, plan, g_b, w0T, inj_w, xdt, B, n, k, Q, G, coord=None):
 
 
 def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None, split=None, wfrag=None, stop_at=None,
-                    w0T=None, inj_w=None, coord=None):
+                    w0T=None, inj_w=None, coord=None, lazy_xg=False):
     """K1 + K2 chain (+ K3).  Returns (inputs, H_L, xg): the list of layer INPUT buffers
     [A_0 .. A_{L-1}], the last activation H_L and -- when the fused chain ran -- the pair sum xg
     (else None).  layer_hook(l, A_l, H_out) is called after every layer (hook-compat path; forces
@@ -282,7 +282,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
         G, L, T = plan.widths[-1], plan.L, H.g_chain_tile()
         if w0T is not None and wfrag is not None and len(wfrag) == 2 and len(wfrag[0]) == L:
             # factored first layer in the f16s arithmetic: fp16 object rows + fp32 bias rows, no pair matrix
-            R = 32
+            R = H.g_chain_rr_tile()                    # (one pair-sum partial row per 256-row tile on these paths)
             Xp, Vc, Vq, inj_l = _tables(x, q, plan, g_b, w0T, inj_w, torch.float16, B, n, k, Q, G, coord)
             masks = Hs = None
             if keep_inputs:
@@ -290,8 +290,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
                 masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
             part = torch.empty(M // R, G, dtype=torch.float32, device=dev)
             H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, wfrag[0], wfrag[1], g_b, Hs, masks, part, M, G, Vq=Vq, inject=inj_l)
-            xg = torch.empty(B, G, dtype=torch.float32, device=dev)
-            H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // R, G)
+            xg = _pair_sum_of(part, B, (n * n) // R, G, lazy_xg)
             if Hs is None:
                 return [None] * L, None, xg
             return [None] + Hs[:-1], RRMasks(masks), xg
@@ -335,7 +334,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
         return [P] + Hs[:-1], Hs[-1], xg
     if w0T is not None and stop_at is None and layer_hook is None and wfrag is not None and len(wfrag) == plan.L:
         # factored first layer: two small tables instead of the pair matrix, K = 64 instead of 192 in layer 0
-        G, L, R = plan.widths[-1], plan.L, 32
+        G, L, R = plan.widths[-1], plan.L, H.g_chain_rr_tile()     # (one pair-sum partial row per 256-row tile)
         Xp, Vc, Vq, inj_l = _tables(x, q, plan, g_b, w0T, inj_w, dt, B, n, k, Q, G, coord)
         masks = Hs = None
         if keep_inputs:
@@ -343,8 +342,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
             masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
         part = torch.empty(M // R, G, dtype=torch.float32, device=dev)
         H.g_chain_fwd_rr_alg0(Xp, Vc, n, wfrag, g_b, Hs, masks, part, M, G, Vq=Vq, inject=inj_l)
-        xg = torch.empty(B, G, dtype=torch.float32, device=dev)
-        H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // R, G)
+        xg = _pair_sum_of(part, B, (n * n) // R, G, lazy_xg)
         if Hs is None:
             return [None] * L, None, xg
         return [None] + Hs[:-1], RRMasks(masks), xg
@@ -420,15 +418,41 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
     return inputs, cur, None
 
 
+class PairSumPartials:
+    """The forward chain's per-tile partial pair sums, not yet added up: (B * parts, G) fp32.  The f_phi launch adds them itself
+    (rn_f_phi_fwd_from_partials) and writes the (B, G) sums into `.xg`."""
+
+    def __init__(self, part, B, parts, G):
+        self.part, self.B, self.parts, self.G = part, B, parts, G
+        self.xg = torch.empty(B, G, dtype=torch.float32, device=part.device)
+
+
+def _pair_sum_of(part, B, parts, G, lazy):
+    if lazy and os.environ.get("RN_NO_FUSED_PAIR_SUM", "0") != "1":
+        return PairSumPartials(part, B, parts, G)
+    xg = torch.empty(B, G, dtype=torch.float32, device=part.device)
+    H.pair_sum_fwd(part, G, xg, H.RN_F32, B, parts, G)
+    return xg
+
+
 def f_phi_forward(xg, fw, fb, mask, wT=None, label=None):
     """f_phi + log_softmax (model.py:155-162): fc1 -> relu -> fc2 -> dropout mask -> relu -> fc3 -> log_softmax,
-    fp32.  Returns (f1, f2, log_probs), with `label` (int64 (B,)) also the mean NLL as a fourth element (same launch)."""
+    fp32.  Returns (f1, f2, log_probs), with `label` (int64 (B,)) also the mean NLL as a fourth element (same launch).
+    xg: the (B, G) pair sums, or PairSumPartials (their summation then rides in the same launch; .xg holds them afterwards)."""
+    lazy = xg if isinstance(xg, PairSumPartials) else None
+    if lazy is not None:
+        xg = lazy.xg
     B, G = xg.shape
     dev = xg.device
     F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
     f1 = torch.empty(B, F1, dtype=torch.float32, device=dev)
     f2 = torch.empty(B, F2, dtype=torch.float32, device=dev)
     out = torch.empty(B, A, dtype=torch.float32, device=dev)
+    if lazy is not None:
+        loss = torch.empty((), dtype=torch.float32, device=dev) if label is not None else None
+        H.f_phi_fwd_from_partials(lazy.part, lazy.parts, xg, wT if wT is not None else fw, fb, mask, label, f1, f2, out, loss,
+                                  transposed=wT is not None)
+        return (f1, f2, out, loss) if label is not None else (f1, f2, out)
     if label is not None:
         loss = torch.empty((), dtype=torch.float32, device=dev)
         H.f_phi_fwd_nll(xg, wT if wT is not None else fw, fb, mask, label, f1, f2, out, loss, transposed=wT is not None)
@@ -485,7 +509,7 @@ class RelationalFunction(torch.autograd.Function):
         inputs, HL, xg = g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad,
                                          split=(packed.hi, packed.lo) if f16s else None,
                                          wfrag=(packed.frag_hi, packed.frag_lo) if f16s else packed.frag,
-                                         w0T=packed.w0T if alg_fwd else None, inj_w=inj_w, coord=coord)
+                                         w0T=packed.w0T if alg_fwd else None, inj_w=inj_w, coord=coord, lazy_xg=True)
         G = plan.widths[-1]
         if xg is None:
             xg = torch.empty(B, G, dtype=torch.float32, device=dev)
@@ -501,6 +525,8 @@ class RelationalFunction(torch.autograd.Function):
             f1, f2, out, loss = f_phi_forward(xg, fw, fb, mask, wT=packed.fT, label=label)
         else:
             f1, f2, out = f_phi_forward(xg, fw, fb, mask, wT=packed.fT)
+        if isinstance(xg, PairSumPartials):
+            xg = xg.xg
         ctx.label = label
         if need_grad:
             ctx.plan, ctx.code, ctx.dims = plan, code, (B, n, k, Q, M, G, F1, F2, A)

@@ -39,6 +39,7 @@ SIGNATURES = {
     "rn_g_chain_fwd_rr_alg0": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _I, _P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_f_phi_fwd_from_partials": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr_reduce": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_chain_reduce_part_bytes": (_Z, [_I, _I]),
     "rn_pair_reduce_from_chain": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -566,6 +567,18 @@ def f_phi_fwd_nll(xg, fw, fb, mask, label, f1, f2, out, loss, transposed=False):
                                    fb[2].data_ptr(), _ptr(mask), label.data_ptr(), f1.data_ptr(), f2.data_ptr(), out.data_ptr(),
                                    loss.data_ptr(), _nll_sync_ws(B, xg.device).data_ptr(), int(transposed), B, G, F1, F2, A, _stream()),
            "rn_f_phi_fwd_nll")
+
+
+@_timed("f_phi")
+def f_phi_fwd_from_partials(xg_part, parts_per_row, xg, fw, fb, mask, label, f1, f2, out, loss, transposed=False):
+    """pair sum of the chain partials + f_phi + log_softmax (+ mean NLL when label is given) in one launch; xg (B, G) is written."""
+    B, G = xg.shape
+    F1, F2, A = (fw[0].shape[1], fw[1].shape[1], fw[2].shape[1]) if transposed else (fw[0].shape[0], fw[1].shape[0], fw[2].shape[0])
+    ws = _nll_sync_ws(B, xg.device).data_ptr() if label is not None else None
+    _check(load().rn_f_phi_fwd_from_partials(xg_part.data_ptr(), parts_per_row, xg.data_ptr(), fw[0].data_ptr(), fb[0].data_ptr(), fw[1].data_ptr(),
+                                             fb[1].data_ptr(), fw[2].data_ptr(), fb[2].data_ptr(), _ptr(mask), _ptr(label), f1.data_ptr(),
+                                             f2.data_ptr(), out.data_ptr(), _ptr(loss), ws, int(transposed), B, G, F1, F2, A, _stream()),
+           "rn_f_phi_fwd_from_partials")
 
 
 @_timed("f_phi")

@@ -376,14 +376,14 @@ def test_g_chain_fwd_rr_alg0(H, mode, B, n):
     train = mode.startswith("train")
     Hs = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3)] + [None] if train else None
     masks = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda")) if train else None
-    part = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
+    part = torch.full((M // 256, G), float("nan"), dtype=torch.float32, device="cuda")
     H.g_chain_fwd_rr_alg0(Xp, Vc, n, Wf, [dev(b) for b in bs], Hs, masks, part, M, G)
     torch.cuda.synchronize()
     if mode == "train8":
         # e4m3 copies (h_dtype = RN_FP8): same arithmetic, so masks and pair sums bitwise; the bytes = the e4m3 rounding of the bf16 copies
         Hs8 = [torch.full((M, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [None]
         masks8 = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
-        part8 = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
+        part8 = torch.full((M // 256, G), float("nan"), dtype=torch.float32, device="cuda")
         H.g_chain_fwd_rr_alg0(Xp, Vc, n, Wf, [dev(b) for b in bs], Hs8, masks8, part8, M, G)
         torch.cuda.synchronize()
         assert torch.equal(part, part8)
@@ -418,7 +418,7 @@ def test_g_chain_fwd_rr_alg0(H, mode, B, n):
             assert np.abs(ref[bad]).max(initial=0.0) <= 1e-4 * np.abs(ref).max(), (l, bad.sum())
             assert bad.mean() <= 1e-4
     tol = F32_TOL if train else 2e-3
-    assert rel(part.cpu().numpy(), ref.reshape(M // 32, 32, G).sum(1)) <= tol
+    assert rel(part.cpu().numpy(), ref.reshape(M // 256, 256, G).sum(1)) <= tol
 
 
 @pytest.mark.parametrize("mode,B,n", [("train", 19, 64), ("infer", 2, 32)])
@@ -447,16 +447,16 @@ def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
     P16 = torch.zeros(M, K0, dtype=torch.float16, device="cuda")
     H.pair_build_fwd(dev(x), dev(q), P16, H.RN_F16, B, n, k, Q, K0)
     train = mode == "train"
-    def outs():
+    def outs(rows):
         Hs = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3)] + [None] if train else None
         masks = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda")) if train else None
-        return Hs, masks, torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
-    HsA, mA, pA = outs(); HsP, mP, pP = outs()
+        return Hs, masks, torch.full((M // rows, G), float("nan"), dtype=torch.float32, device="cuda")
+    HsA, mA, pA = outs(256); HsP, mP, pP = outs(32)       # (one partial row per tile on the factored path, per wave on the other)
     bd = [dev(b) for b in bs]
     H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, HsA, mA, pA, M, G)
     H.g_chain_fwd_rr_f16s(P16, K0, hiP, loP, bd, HsP, mP, K0, pP, M, G)
     torch.cuda.synchronize()
-    assert rel(pA.cpu().numpy(), pP.cpu().numpy()) <= 2e-3
+    assert rel(pA.cpu().numpy(), pP.view(M // 256, 8, G).sum(1).cpu().numpy()) <= 2e-3
     if train:
         for l in range(3):
             a, b = HsA[l].float().cpu().numpy(), HsP[l].float().cpu().numpy()
@@ -467,7 +467,7 @@ def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
         # the value the bf16 copy rounds -- equal to the rounded bf16 copy except where the two 16-bit roundings straddle a tie
         Hs8 = [torch.full((M, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [None]
         m8 = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
-        p8 = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
+        p8 = torch.full((M // 256, G), float("nan"), dtype=torch.float32, device="cuda")
         H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, Hs8, m8, p8, M, G)
         torch.cuda.synchronize()
         assert torch.equal(pA, p8)
@@ -1101,3 +1101,38 @@ def test_e4m3_copies_saturate_instead_of_turning_into_nan(H, f16s):
     assert bool(torch.isfinite(dW).all())
     ref = (dZ.double().sum(0) * 448.0)[:, None].expand(G, G)
     assert rel(dW.cpu().numpy(), ref.cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("B,parts,nll,tr", [(64, 16, True, True), (5, 7, True, True), (9, 16, False, True), (6, 3, True, False)])
+def test_f_phi_from_partials(H, B, parts, nll, tr):
+    """rn_f_phi_fwd_from_partials = rn_pair_sum_fwd + rn_f_phi_fwd(_nll) in one launch: the pair sums it writes agree with a
+    float64 sum of the partial rows to fp32 rounding, and everything downstream -- bitwise -- with the two-launch path on those sums."""
+    G, F1, F2, A = 256, 256, 256, 28
+    g = torch.Generator(device="cuda").manual_seed(3)
+    part = torch.randn(B * parts, G, device="cuda", generator=g)
+    fw = [torch.randn(F1, G, device="cuda", generator=g) * 0.05, torch.randn(F2, F1, device="cuda", generator=g) * 0.05, torch.randn(A, F2, device="cuda", generator=g) * 0.05]
+    w = [x.t().contiguous() for x in fw] if tr else fw
+    fb = [torch.randn(F1, device="cuda", generator=g) * 0.1, torch.randn(F2, device="cuda", generator=g) * 0.1, torch.randn(A, device="cuda", generator=g) * 0.1]
+    mask = (torch.rand(B, F2, device="cuda", generator=g) > 0.5).float() * 2
+    label = torch.randint(0, A, (B,), device="cuda", generator=g) if nll else None
+    mk = lambda *s: torch.full(s, float("nan"), device="cuda")
+    xg, f1, f2, out = mk(B, G), mk(B, F1), mk(B, F2), mk(B, A)
+    loss = mk() if nll else None
+    H.f_phi_fwd_from_partials(part, parts, xg, w, fb, mask, label, f1, f2, out, loss, transposed=tr)
+    torch.cuda.synchronize()
+    ref = part.double().view(B, parts, G).sum(1)
+    assert rel(xg.cpu().numpy(), ref.cpu().numpy()) <= 1e-6
+    f1b, f2b, outb = mk(B, F1), mk(B, F2), mk(B, A)
+    if nll:
+        lossb = mk()
+        H.f_phi_fwd_nll(xg, w, fb, mask, label, f1b, f2b, outb, lossb, transposed=tr)
+    else:
+        H.f_phi_fwd(xg, w, fb, mask, f1b, f2b, outb, transposed=tr)
+    torch.cuda.synchronize()
+    assert torch.equal(f1, f1b) and torch.equal(f2, f2b) and torch.equal(out, outb)
+    if nll:
+        assert torch.equal(loss, lossb)
+    xg2 = mk(B, G)
+    H.f_phi_fwd_from_partials(part, parts, xg2, w, fb, mask, label, mk(B, F1), mk(B, F2), mk(B, A), mk() if nll else None, transposed=tr)
+    torch.cuda.synchronize()
+    assert torch.equal(xg, xg2)

@@ -26,7 +26,7 @@ H.pack_matrix_frag_many([(Ws[l], Ws[l].shape[1], 1, G, k if l == 0 else G, Whi[l
                         + [(Ws[l], Ws[l].shape[1], 1, G, k if l == 0 else G, Wlo[l], 8 | int(l == 0)) for l in range(4)])
 Hs = list(torch.empty(3, M, G, dtype=torch.uint8, device='cuda').view(torch.float8_e4m3fn)) + [None]     # e4m3 copies, as the step keeps them
 masks = list(torch.empty(4, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device='cuda'))
-part = torch.empty(M // 32, G, device='cuda')
+part = torch.empty(M // 256, G, device='cuda')
 dxg = torch.randn(B, G, device='cuda')
 dZs = [None] + list(torch.empty(3, M, G, dtype=torch.bfloat16, device='cuda'))
 dW = torch.empty(G, G, device='cuda'); dW0 = torch.empty(G, kt, device='cuda'); db = torch.empty(G, device='cuda')

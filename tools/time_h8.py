@@ -21,7 +21,7 @@ Xp16 = torch.empty(B * n, 64, dtype=torch.float16, device='cuda'); Xpb = torch.e
 Vc = torch.empty(B * n, G, device='cuda')
 H.pair_tables(x, q, w0T, bs[0], Xp16, Vc, B, n, k, Q, G); H.pair_tables(x, q, w0T, bs[0], Xpb, Vc, B, n, k, Q, G)
 masks = list(torch.empty(4, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device='cuda'))
-part = torch.empty(M // 32, G, device='cuda')
+part = torch.empty(M // 256, G, device='cuda')
 Hb = list(torch.empty(3, M, G, dtype=torch.bfloat16, device='cuda')) + [None]
 H8 = list(torch.empty(3, M, G, dtype=torch.uint8, device='cuda').view(torch.float8_e4m3fn)) + [None]
 dxg = torch.randn(B, G, device='cuda')

@@ -13,7 +13,7 @@ x = torch.randn(B, n, k, device=dev); q = torch.randn(B, Q, device=dev)
 W0 = torch.randn(G, kt, device=dev) * 0.05; b0 = torch.randn(G, device=dev) * 0.1
 w0T = W0.t().contiguous()
 Xp = torch.empty(B * n, 64, dtype=torch.float16, device=dev); Vc = torch.empty(B * n, G, device=dev)
-part = torch.randn(M // 32, G, device=dev); xg = torch.empty(B, G, device=dev)
+part = torch.randn(M // 256, G, device=dev); xg = torch.empty(B, G, device=dev)
 fw = [torch.randn(256, 256, device=dev) * 0.05, torch.randn(256, 256, device=dev) * 0.05, torch.randn(A, 256, device=dev) * 0.05]
 fT = [w.t().contiguous() for w in fw]; fb = [torch.randn(256, device=dev) * 0.1, torch.randn(256, device=dev) * 0.1, torch.randn(A, device=dev) * 0.1]
 f1 = torch.empty(B, 256, device=dev); f2 = torch.empty(B, 256, device=dev); out = torch.empty(B, A, device=dev); loss = torch.empty((), device=dev)
@@ -27,7 +27,7 @@ gW = torch.empty(G, G, device=dev); gB = torch.empty(G, device=dev)
 masks = torch.randint(0, 255, (H.g_chain_rr_mask_bytes(M),), dtype=torch.uint8, device=dev)
 rows = [
     ("pair_tables", lambda: H.pair_tables(x, q, w0T, b0, Xp, Vc, B, n, k, Q, G)),
-    ("pair_sum_fwd (segsum of the chain partials)", lambda: H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // 32, G)),
+    ("pair_sum_fwd (segsum of the chain partials)", lambda: H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // 256, G)),
     ("f_phi_fwd_nll", lambda: H.f_phi_fwd_nll(xg, fT, fb, None, label, f1, f2, out, loss, transposed=True)),
     ("f_phi_bwd_nll (dz + grads)", lambda: H.f_phi_bwd_nll(gloss, label, out, f2, f1, xg, fw, None, dW, db, dxg)),
     ("pair_reduce_bwd (+finish)", lambda: H.pair_reduce_bwd(dZ, G, Rj, Ri, Rq, H.RN_BF16, B, n, G)),
