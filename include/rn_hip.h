@@ -127,8 +127,10 @@ int rn_g_chain_fwd_rr(const void* P, int ldp, const void* const* Wf, const float
  * hi / lo halves of W_l (rn_pack_matrix_frag_many modes 4|natural and 8|natural); every product runs against both
  * (fp32 accumulate), fp16 activations saturate at 65504.  H (bf16 copies) / mask / xg_part as rn_g_chain_fwd_rr;
  * supported output sets: inference (no H), training (H[0..2] + masks + xg_part), all four H without masks. */
+/* h_dtype = RN_FP8 (K0 == 192, the two training output sets): H[0..2] receive e4m3 bytes (as rn_g_chain_fwd_rr_f16s_alg0), a stored
+ * H[3] stays bf16 (rn_pair_sum_fwd reads it). */
 int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, const void* const* Wlo, const float* const* bias,
-                           void* const* H, void* const* mask, int K0, float* xg_part, int M, int L, int G, void* stream);
+                           void* const* H, int h_dtype, void* const* mask, int K0, float* xg_part, int M, int L, int G, void* stream);
 
 /* Backward (pair-sum broadcast + ReLU gates + the three dgrad steps):
  *   dZ[0]   = dxg[b] * gate_3                         b = question of the pair row

@@ -244,7 +244,7 @@ struct FwdVm {
   static constexpr int VQ_STAGE = (RR_L - 1) * 8 + 2;                // INJ: ... and the next tile's question row of layer INJ
   static constexpr int ops(int sidx) {                                // VMEM operations a stage issues (per wave)
     int k = RR_DPW;
-    if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += H8 ? (((sidx - 2) & 1) ? 2 : 0) : 2;   // e4m3 copies leave two blocks at a time
+    if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += (H8 && ((sidx - 2) >> 3) < RR_L - 1) ? (((sidx - 2) & 1) ? 2 : 0) : 2;   // e4m3 copies leave two blocks at a time
     if ((sidx >> 3) == RR_L - 1)
       for (int c = 0; c < PF_PER; ++c) k += ((sidx & 7) * PF_PER + c < NK0) ? 1 : 0;
     if (ALG0 && sidx == VC_STAGE) k += 1;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
                                                            const float* __restrict__ Vq = nullptr, int rows_per_b = 1) {
   static_assert(NK0 % 4 == 0 && NK0 >= 4 && NK0 <= 16, "layer-0 reduction length");
   static_assert(INJ >= 0 && INJ < RR_L - 1, "the injected layer is one of the swapped-operand layers");
-  static_assert(!H8 || (STORE && !ST3), "e4m3 copies: H_0..2 only");
+  static_assert(!H8 || STORE, "e4m3 copies of H_0..2 (a stored H_3 stays bf16: the pair sum reads it)");
   typedef FwdVm<NK0, STORE, ST3, XG, ALG0, INJ, H8> Vm;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
@@ -401,12 +401,13 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
 #pragma unroll
       for (int q = 0; q < 2; ++q) co[q] = *reinterpret_cast<const u32x4*>(stg + (16 * q + (lane >> 2)) * RR_SRS + (lane & 3) * 16);
     };
-    const unsigned orow_off = H8 ? (unsigned)((lane >> 2) * RR_G + (lane & 3) * 16) : (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
+    const unsigned orow_off8 = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 16);
+    const unsigned orow_off = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
     auto co_store = [&](int cl, int cob, int q) {
-      if constexpr (H8) {                                             // blocks cob - 1, cob: row 16 q + lane / 4, features 32 (cob - 1) + 16 (lane % 4) .. + 15
+      if (H8 && cl < RR_L - 1) {                                      // blocks cob - 1, cob: row 16 q + lane / 4, features 32 (cob - 1) + 16 (lane % 4) .. + 15
         gbl_u8* base8 = (gbl_u8*)(reinterpret_cast<unsigned char*>(a.out[cl]) + m0w * RR_G);
         asm volatile("" : "+s"(base8));
-        __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base8 + orow_off + 16 * q * RR_G + 32 * (cob & ~1)));
+        __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base8 + orow_off8 + 16 * q * RR_G + 32 * (cob & ~1)));
         return;
       }
       gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.out[cl] + m0w * RR_G);
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
       constexpr bool has_prev = sidx > 0;                             // (l, ob) == (0, 0): the tail of the last tile did it
       constexpr int pl = ob ? l : l - 1, pob = ob ? ob - 1 : 7;
       constexpr int cl = (sidx - 2) >> 3, cob = (sidx - 2) & 7;
-      constexpr bool has_co = STORE && sidx >= 2 && (cl < RR_L - 1 || ST3) && (!H8 || (cob & 1));
+      constexpr bool has_co = STORE && sidx >= 2 && (cl < RR_L - 1 || ST3) && (!H8 || cl == RR_L - 1 || (cob & 1));
       constexpr int didx = sidx + RR_LA;                              // stage whose weights are requested now
       constexpr int dl = (didx >> 3) & 3, dob = didx & 7;
       constexpr int nob = (sidx + 1) & 7;                             // next stage (the read-ahead crosses into it)
@@ -608,7 +609,7 @@ struct F16Vm {
   static constexpr int VQ_STAGE = (RR_L - 1) * 8 + 2;                // INJ: ... and the next tile's question row of layer INJ
   static constexpr int ops(int sidx) {
     int k = F_DPW;
-    if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += H8 ? (((sidx - 2) & 1) ? 2 : 0) : 2;
+    if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += (H8 && ((sidx - 2) >> 3) < RR_L - 1) ? (((sidx - 2) & 1) ? 2 : 0) : 2;
     if ((sidx >> 3) == RR_L - 1)
       for (int c = 0; c < PF_PER; ++c) k += ((sidx & 7) * PF_PER + c < NK0) ? 1 : 0;
     if (ALG0 && sidx == VC_STAGE) k += 1;
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
                                                                 const float* __restrict__ Vc = nullptr, int n_obj = 0,
                                                                 const float* __restrict__ Vq = nullptr, int rows_per_b = 1) {
   static_assert(INJ >= 0 && INJ < RR_L - 1, "the injected layer is one of the swapped-operand layers");
-  static_assert(!H8 || (STORE && !ST3), "e4m3 copies: H_0..2 only");
+  static_assert(!H8 || STORE, "e4m3 copies of H_0..2 (a stored H_3 stays bf16: the pair sum reads it)");
   typedef F16Vm<NK0, STORE, ST3, XG, ALG0, INJ, H8> Vm;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
@@ -759,12 +760,13 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
 #pragma unroll
       for (int q = 0; q < 2; ++q) co[q] = *reinterpret_cast<const u32x4*>(stg + (16 * q + (lane >> 2)) * RR_SRS + (lane & 3) * 16);
     };
-    const unsigned orow_off = H8 ? (unsigned)((lane >> 2) * RR_G + (lane & 3) * 16) : (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
+    const unsigned orow_off8 = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 16);
+    const unsigned orow_off = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
     auto co_store = [&](int cl, int cob, int q) {
-      if constexpr (H8) {                                             // blocks cob - 1, cob: row 16 q + lane / 4, features 32 (cob - 1) + 16 (lane % 4) .. + 15
+      if (H8 && cl < RR_L - 1) {                                      // blocks cob - 1, cob: row 16 q + lane / 4, features 32 (cob - 1) + 16 (lane % 4) .. + 15
         gbl_u8* base8 = (gbl_u8*)(reinterpret_cast<unsigned char*>(a.out[cl]) + m0w * RR_G);
         asm volatile("" : "+s"(base8));
-        __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base8 + orow_off + 16 * q * RR_G + 32 * (cob & ~1)));
+        __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base8 + orow_off8 + 16 * q * RR_G + 32 * (cob & ~1)));
         return;
       }
       gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.out[cl] + m0w * RR_G);
@@ -799,7 +801,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
       constexpr bool has_prev = sidx > 0;
       constexpr int pl = ob ? l : l - 1, pob = ob ? ob - 1 : 7;
       constexpr int cl = (sidx - 2) >> 3, cob = (sidx - 2) & 7;
-      constexpr bool has_co = STORE && sidx >= 2 && (cl < RR_L - 1 || ST3) && (!H8 || (cob & 1));
+      constexpr bool has_co = STORE && sidx >= 2 && (cl < RR_L - 1 || ST3) && (!H8 || cl == RR_L - 1 || (cob & 1));
       constexpr int didx = sidx + F_LA;
       constexpr int dl = (didx >> 3) & 3, dob = didx & 7;
       constexpr int slot = ob & 3, nslot = (ob + 1) & 3, dslot = (ob + F_LA) & 3;
@@ -1330,8 +1332,11 @@ extern "C" int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, co
 }
 
 extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, const void* const* Wlo, const float* const* bias,
-                                      void* const* H, void* const* mask, int K0, float* xg_part, int M, int L, int G, void* stream) {
+                                      void* const* H, int h_dtype, void* const* mask, int K0, float* xg_part, int M, int L, int G,
+                                      void* stream) {
   RN_CHECK_ARG(P16 && Whi && Wlo && bias && M > 0, "rn_g_chain_fwd_rr_f16s: bad pointer/size");
+  RN_CHECK_ARG(!H || h_dtype == RN_BF16 || h_dtype == RN_FP8, "rn_g_chain_fwd_rr_f16s: h_dtype must be RN_BF16 or RN_FP8 (got %d)", h_dtype);
+  const bool h8 = H && h_dtype == RN_FP8;
   RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_fwd_rr_f16s: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
   RN_CHECK_ARG(M % RR_TM == 0, "rn_g_chain_fwd_rr_f16s: M=%d must be a multiple of %d", M, RR_TM);
   RN_CHECK_ARG(K0 == 192 || K0 == 256, "rn_g_chain_fwd_rr_f16s: layer-0 reduction length %d unsupported (192 or 256)", K0);
@@ -1363,6 +1368,14 @@ extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* cons
   const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
   hipStream_t s = (hipStream_t)stream;
   const f16* Pp = (const f16*)P16;
+  // e4m3 copies of H_0..2 (h_dtype = RN_FP8; a stored H_3 stays bf16): the two training output sets at K0 = 192
+  if (h8) {
+    RN_CHECK_ARG(K0 == 192 && ((h012 && xg_part) || h0123m), "rn_g_chain_fwd_rr_f16s: e4m3 copies need K0 == 192 and a training output set");
+    if (h0123m) g_chain_rr_f16s_kernel<12, true, true, true, false, false, 0, true, true><<<grid, RR_NT, 0, s>>>(Pp, ldp, a, xg_part, ntiles);
+    else g_chain_rr_f16s_kernel<12, true, false, true, true, false, 0, true, true><<<grid, RR_NT, 0, s>>>(Pp, ldp, a, xg_part, ntiles);
+    RN_LAUNCH_CHECK("rn_g_chain_fwd_rr_f16s(e4m3 copies)");
+    return 0;
+  }
 #define RN_GO(NK0_, ST, S3, MK, XG_) g_chain_rr_f16s_kernel<NK0_, ST, S3, MK, XG_><<<grid, RR_NT, 0, s>>>(Pp, ldp, a, xg_part, ntiles)
 #define RN_SEL(NK0_)                                                        \
   do {                                                                      \

@@ -309,7 +309,9 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
             whole = (n * n) % R == 0
             masks = Hs = None
             if keep_inputs:
-                Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L - 1)] + [None if whole else torch.empty(M, G, dtype=dt, device=dev)]
+                # (e4m3 copies of H_0..2 here too when the layer-0 reduction is the 192-column one; a stored H_3 stays 16-bit)
+                hdt = _h_copy_dtype(plan, dt, M) if ld0 == 192 else dt
+                Hs = [torch.empty(M, G, dtype=hdt, device=dev) for l in range(L - 1)] + [None if whole else torch.empty(M, G, dtype=dt, device=dev)]
                 masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
             part = torch.empty(M // R, G, dtype=torch.float32, device=dev) if whole else None
             H.g_chain_fwd_rr_f16s(P16, ld0, wfrag[0], wfrag[1], g_b, Hs, masks, ld0, part, M, G)

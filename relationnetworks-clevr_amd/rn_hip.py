@@ -35,7 +35,7 @@ SIGNATURES = {
     "rn_g_chain_rr_tile": (_I, []),
     "rn_g_chain_rr_mask_bytes": (_Z, [_I]),
     "rn_g_chain_fwd_rr": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
-    "rn_g_chain_fwd_rr_f16s": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "rn_g_chain_fwd_rr_f16s": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_alg0": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _I, _P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -338,7 +338,8 @@ def g_chain_fwd_rr_f16s(P16, ldp, Whis, Wlos, biases, Hs, masks, K0, xg_part, M,
     bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
     op = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
-    _check(load().rn_g_chain_fwd_rr_f16s(P16.data_ptr(), ldp, hp, lp, bp, op, mp, K0, _ptr(xg_part), M, L, G, _stream()), "rn_g_chain_fwd_rr_f16s")
+    _check(load().rn_g_chain_fwd_rr_f16s(P16.data_ptr(), ldp, hp, lp, bp, op, _h_code(Hs[:L - 1] if Hs is not None else None), mp, K0, _ptr(xg_part), M, L, G,
+                                         _stream()), "rn_g_chain_fwd_rr_f16s")
 
 
 def g_chain_rr_mask_bytes(M) -> int:

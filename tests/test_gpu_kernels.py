@@ -523,6 +523,32 @@ def test_g_chain_fwd_rr_f16s(H, mode, M):
         prev = f16r(ref).astype(np.float64)
     assert rel(part.cpu().numpy(), ref.reshape(M // 32, 32, G).sum(1)) <= 1e-3
     assert rel(part.cpu().numpy(), exact.reshape(M // 32, 32, G).sum(1)) <= 3e-4
+    if train:
+        # e4m3 copies (h_dtype = RN_FP8) on the pair-matrix chain: same arithmetic (masks, pair sums bitwise), bytes = the e4m3
+        # rounding of the fp16 operand; with all four activations requested H_3 stays bf16 and bitwise the plain run's
+        Hs8 = [torch.full((M, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [None]
+        m8 = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
+        p8 = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
+        H.g_chain_fwd_rr_f16s(dev(P).half(), K0, his, los, [dev(b) for b in bs], Hs8, m8, K0, p8, M, G)
+        torch.cuda.synchronize()
+        assert torch.equal(part, p8)
+        for l in range(L):
+            assert torch.equal(masks[l], m8[l]), l
+        for l in range(3):
+            same = (Hs8[l].view(torch.uint8) == Hs[l].float().to(torch.float8_e4m3fn).view(torch.uint8)).float().mean().item()
+            assert same >= 0.97, (l, same)
+            assert bool(((Hs8[l].float() - Hs[l].float()).abs() <= Hs[l].float().abs() * 2.0 ** -4 + 2.0 ** -10).all()), l
+        Hs4 = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(4)]
+        m4 = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
+        H.g_chain_fwd_rr_f16s(dev(P).half(), K0, his, los, [dev(b) for b in bs], Hs4, m4, K0, None, M, G)
+        Hs48 = [torch.full((M, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda")]
+        m48 = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
+        H.g_chain_fwd_rr_f16s(dev(P).half(), K0, his, los, [dev(b) for b in bs], Hs48, m48, K0, None, M, G)
+        torch.cuda.synchronize()
+        assert torch.equal(Hs4[3], Hs48[3])
+        for l in range(3):
+            assert torch.equal(Hs48[l].view(torch.uint8), Hs8[l].view(torch.uint8)), l
+            assert torch.equal(m4[l], m48[l])
 
 
 def test_wgrad_gated_and_bwd_skip0(H):
