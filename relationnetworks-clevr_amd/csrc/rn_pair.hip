@@ -953,8 +953,21 @@ __global__ __launch_bounds__(256) void pair_tables_kernel(const float* __restric
     }
   }
   for (int f = t; f < N; f += 256) {
+    // This kernel is a chain of L2 round trips on the critical path in front of the forward chain: the x_i weights and the first
+    // 128 question weights of the thread's column are requested together (160 independent loads, one wave per SIMD: the
+    // registers are there) -- one round trip instead of five for the headline shape (Q = 128).
+    float wi[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) wi[c] = c < k ? W0T[(long)(k + c) * N + f] : 0.f;
     float cq = b0[f];
     int qq = 0;
+    for (; qq + 128 <= Q; qq += 128) {
+      float wv[128];
+#pragma unroll
+      for (int u = 0; u < 128; ++u) wv[u] = W0T[(long)(2 * k + qq + u) * N + f];
+#pragma unroll
+      for (int u = 0; u < 128; ++u) cq = fmaf(wv[u], qs[qq + u], cq);
+    }
     for (; qq + 32 <= Q; qq += 32) {
       float wv[32];
 #pragma unroll
@@ -963,9 +976,6 @@ __global__ __launch_bounds__(256) void pair_tables_kernel(const float* __restric
       for (int u = 0; u < 32; ++u) cq = fmaf(wv[u], qs[qq + u], cq);
     }
     for (; qq < Q; ++qq) cq = fmaf(W0T[(long)(2 * k + qq) * N + f], qs[qq], cq);
-    float wi[32];
-#pragma unroll
-    for (int c = 0; c < 32; ++c) wi[c] = c < k ? W0T[(long)(k + c) * N + f] : 0.f;
 #pragma unroll 4
     for (int r = 0; r < 16; ++r) {
       if (i0 + r >= n) break;
