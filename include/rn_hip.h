@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RN_ABI_VERSION 1
+#define RN_ABI_VERSION 2   /* bumped whenever a signature or a buffer layout of this header changes */
 
 enum { RN_BF16 = 0, RN_F32 = 1, RN_F16 = 2, RN_FP8 = 3 };   /* RN_F16: pair matrix / split weights of the f16s forward only;
                                                              * RN_FP8: OCP e4m3 copies of the stored activations (h_dtype / a_dtype) */
@@ -112,7 +112,8 @@ int rn_g_chain_fwd_f16s(const void* P, int ldp, const void* const* Whi, const vo
  * previous layer's MFMA output).
  * H: NULL / four NULLs (inference; xg_part required), all four (M, 256) bf16 activations, or -- with
  *    mask -- H[0..2] only (H[3] NULL): nobody needs the last activation once its pair sum and its ReLU
- *    mask are produced on chip.
+ *    mask are produced on chip.  H[0..2] are written as ROW-BLOCKED images (see rn_g_wgrad_blocked, their only
+ *    reader); a stored H[3] (read by rn_pair_sum_fwd) is row-major.
  * mask: NULL, or four buffers of rn_g_chain_rr_mask_bytes(M) = 32 M bytes: the ReLU gate (pre-activation
  *    > 0) of every element of layer l as 64-bit LANE masks in the kernel's own accumulator layout
  *    (opaque; the consumer is rn_g_chain_bwd_rr).  Requires H[0..2].
@@ -137,11 +138,13 @@ int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, con
  *   dZ[s+1] = (dZ[s] @ W_{3-s}) * gate_{2-s}          s = 0, 1, 2
  * gate_l = mask[l] of the forward call.  Wtf[s]: fragment-major image of W_{3-s}^T, i.e.
  * rn_pack_matrix_frag(W, 1, in_features, 256, 256, dst, natural = (s == 0)).  All four dZ (M, 256) bf16 are
- * written (wgrad and the pair reduction consume them).  rows_per_question = n*n (any value dividing M). */
+ * written: dZ[0..2] (layers 3..1, read only by rn_g_wgrad_blocked) as ROW-BLOCKED 16-bit images, dZ[3] (layer 0, read by the
+ * pair reduction) row-major.  dZ[0] may be NULL (rn_g_wgrad_blocked's gate job works from the masks instead).  rows_per_question = n*n (any
+ * value dividing M). */
 int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M,
                       int rows_per_question, int L, int G, void* stream);
 /* ... with the pair reduction of the FIRST layer's gradient done on chip (n == 64 objects, rows_per_question = n*n): dZ[3] is
- * never formed in memory (pass NULL; dZ[0] NULL too: rn_g_linear_bwd_wgrad_gated rebuilds it).  Per 256-row tile (4 i x 64 j)
+ * never formed in memory (pass NULL; dZ[0] NULL too: the gate job of rn_g_wgrad_blocked replaces it).  Per 256-row tile (4 i x 64 j)
  * the kernel leaves rj_part (rn_chain_reduce_part_bytes(M, 0) bytes: the fp32 sum over the tile's 4 i) and per 32-row block
  * ri_part (rn_chain_reduce_part_bytes(M, 1): column sums of its two 16-row halves); rn_pair_reduce_from_chain adds them into
  *   Rj[b,j,:] = sum_i dZ_0[(b,i,j),:]   Ri[b,i,:] = sum_j dZ_0[(b,i,j),:]   Rq[b,:] = sum_ij      (fp32; (B*n, 256), (B, 256))
@@ -151,15 +154,6 @@ int rn_g_chain_bwd_rr_reduce(const float* dxg, const void* const* mask, const vo
                              float* ri_part, int n, int M, int L, int G, void* stream);
 int rn_pair_reduce_from_chain(const float* rj_part, const float* ri_part, float* Rj, float* Ri, float* Rq, int B, int n, int G,
                               void* stream);
-/* Weight gradient of the LAST g layer without its gradient matrix: dZ_3[(b, pair), f] = gate ? bf16(dxg[b][f]) : 0 is
- * rebuilt on the fly from the forward kernel's layer-3 lane masks (mask: rn_g_chain_rr_mask_bytes(M) bytes) and dxg
- * (M / rows_per_question, 256) fp32 -- bitwise the matrix rn_g_chain_bwd_rr stores as dZ[0], which may then be passed as
- * NULL there (nothing else reads it).  dW (256, 256) = dZ_3^T A, db = column sums; A = H_2 (M, lda) bf16;
- * ws = rn_wgrad_ws_bytes(M, 256, 256).  rows_per_question % 64 == 0. */
-/* a_dtype = RN_BF16, or RN_FP8: A holds the e4m3 bytes written by rn_g_chain_fwd_rr*_alg0 with h_dtype = RN_FP8 (lda in elements). */
-int rn_g_linear_bwd_wgrad_gated(const void* mask, const float* dxg, int rows_per_question, const void* A, int lda, int a_dtype,
-                                float* dW, float* db, void* ws, int M, int N, int K, void* stream);
-
 /* MFMA-fragment-major weight image for rn_g_chain_fwd_rr: dst (65536 bf16) gets, for output block ob,
  * K16 step ks, lane, element e:  src[32 ob + lane % 32][kidx] (0 beyond R rows / C columns) with
  *   natural != 0:  kidx = 16 ks + 8 (lane / 32) + e
@@ -202,19 +196,48 @@ int rn_pair_sum_bwd(const float* dxg, const void* HL, int ldh, void* dZ, int ldd
 int rn_g_linear_bwd_dgrad(const void* dZ, int lddz, const void* Wt, int ldwt, const void* Hprev, int ldhp,
                           void* dZprev, int lddzp, int dtype, int M, int N, int Kin, void* stream);
 
-/* wgrad of one g layer: dW[n, k] = sum_m dZ[m, n] * A[m, k] (k < Ktrue), db[n] = sum_m dZ[m, n].
- * dZ: (M, lddz) width N (N % 256 == 0); A: (M, lda) with K padded columns (K % 32 == 0);
+/* wgrad of one g layer: dW[n, k] = sum_m dZ[m, n] * A[m, k] (k < Ktrue), db[n] = sum_m dZ[m, n]  (autograd of model.py:141-145).
+ * dZ: (M, lddz) width N (N % 256 == 0); A: (M, lda) with K padded columns (K % 32 == 0), both ROW-MAJOR of `dtype`;
  * dW: fp32 (N, Ktrue) contiguous (nn.Linear layout); db: fp32 (N).
  * Deterministic: split over M into per-block partials in ws, then an ordered reduction. */
 size_t rn_wgrad_ws_bytes(int M, int N, int K);
-/* Row splits Z of the streaming kernel for this product, 0 if the general kernel runs.  Z > 0: after rn_g_linear_bwd_wgrad, ws
- * holds behind the Z*N*K weight partials Z x N fp32 column sums of dZ over rows [z*M/Z, (z+1)*M/Z) (M / 64 a multiple of Z:
- * splits of equal size) -- per-question sums of dZ for free when a split never straddles two questions. */
-int rn_wgrad_stream_splits(int dtype, int a_dtype, int M, int N, int K, int lddz, int lda);
-/* a_dtype: the type of A -- `dtype` (the type of dZ), or RN_FP8 with dtype = RN_BF16: the e4m3 activation copies of the
- * forward chains (N == K == Ktrue == 256, M % 64 == 0, M >= 4096; lda in elements = bytes). */
-int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, int lda, int a_dtype, float* dW, float* db, void* ws,
+int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, int lda, float* dW, float* db, void* ws,
                           int dtype, int M, int N, int K, int Ktrue, void* stream);
+
+/* ROW-BLOCKED operand images.  The register-resident chains (rn_g_chain_fwd_rr*, rn_g_chain_bwd_rr) store what ONLY the weight
+ * gradient reads -- the activation copies H[0..2] and the gradients dZ[0..2] (layers 3..1) -- in the layout that product wants,
+ * 16 bytes = consecutive pair rows of ONE feature (= one lane's MFMA operand when the contraction runs over the rows):
+ *   16-bit image (bf16) of an (M, 256) matrix:  element (m, f) at ((m / 8) * 256 + f) * 8 + m % 8
+ *   e4m3 image (H copies with h_dtype = RN_FP8): byte    (m, f) at ((m / 16) * 256 + f) * 16 + m % 16
+ * Same byte counts as the row-major matrices.  rn_rows_to_blocked converts a row-major (M, 256) matrix (back != 0: the other
+ * way) -- for tests and tools; M % 16 == 0, dtype RN_BF16 or RN_FP8. */
+int rn_rows_to_blocked(const void* src, void* dst, int dtype, int M, int back, void* stream);
+
+/* Weight gradients of up to 4 256-wide g layers in ONE launch (+ one reduction launch) on row-blocked images:
+ *   job j:  dW[j] (256, 256) = dZ[j]^T A[j],  db[j] (256) = column sums of dZ[j]          (model.py:141-145 autograd)
+ * dZ[j]: 16-bit image (dz_dtype[j] = RN_BF16); A[j]: image of the layer's input, a_dtype = RN_BF16 or RN_FP8 (all jobs alike).
+ * dz_dtype[j] = RN_FP8 (needs a_dtype = RN_FP8): a GATE job -- the LAST layer, whose gradient is never stored:
+ * dZ_3[(b, pair), f] = gate[(b, pair), f] * dxg[b][f].  dZ[j] is then the e4m3 {0, 1} image of the gate (rn_relu_gate_image),
+ * multiplied with A[j] on the fp8 matrix pipe (exact products), and each question's sums are scaled by its row of dxg
+ * (M / rows_per_question, 256) fp32 -- un-rounded, i.e. closer to the fp32 reference than a stored bf16 dZ_3 -- when the
+ * question ends; rows_per_question % 64 == 0 then (otherwise it only steers the row splits; 0 = unknown).  M % 64 == 0.
+ * Z = rn_wgrad_blocked_splits(M, rows_per_question) row splits (0: shape not covered), chosen so that no split straddles two
+ * questions whenever B * d <= 64 for a divisor d of the 64-row steps per question (or 64 < B <= 256).
+ * ws: rn_wgrad_blocked_ws_bytes(M, rows_per_question, njobs) bytes.  Afterwards ws holds, at
+ * rn_wgrad_blocked_db_partials_offset(M, rows_per_question, njobs, j), (Z, 4, 256) fp32: four partial column sums of dZ[j] over
+ * the 64-row steps [z*S/Z, (z+1)*S/Z) (S = M / 64) of split z -- per-question sums of dZ for free when no split straddles two
+ * questions.  Deterministic (fixed-order reduction).  dZ / dz_dtype / A / dW / db: HOST arrays. */
+int rn_wgrad_blocked_splits(int M, int rows_per_question);
+size_t rn_wgrad_blocked_ws_bytes(int M, int rows_per_question, int njobs);
+size_t rn_wgrad_blocked_db_partials_offset(int M, int rows_per_question, int njobs, int job);
+int rn_g_wgrad_blocked(const void* const* dZ, const int* dz_dtype, const void* const* A, int a_dtype, const float* dxg,
+                       int rows_per_question, float* const* dW, float* const* db, int njobs, void* ws, int M, void* stream);
+/* The ReLU gate of the last g layer as an e4m3 {0, 1} row-blocked image (M x 256 bytes, byte 0x38 = 1.0) from the layer-3 lane
+ * masks of rn_g_chain_fwd_rr* (rn_g_chain_rr_mask_bytes(M) bytes): the dZ operand of a gate job.  M % 32 == 0. */
+int rn_relu_gate_image(const void* mask, void* img, int M, void* stream);
+/* Rq[b, f] (B, 256) fp32 = sum over the rows of question b of a 16-bit row-blocked image -- the per-question sums of dZ when
+ * the splits above straddle questions.  rows_per_question % 8 == 0. */
+int rn_blocked_question_sums(const void* img, float* Rq, int M, int rows_per_question, void* stream);
 
 /* Backward of the pair expansion, algebraic form: reduce the gradient
  * of a g layer's pre-activation over the pair axes instead of materialising dP:
@@ -393,8 +416,8 @@ int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* co
  * model.py:131-142; tables built with Q = 0): layer 2's input is [H_1 | q[b]], i.e. W_2 [H_1 | q] + b_2 =
  * W_2[:, 0:256] H_1 + Vq[b] with Vq (B, 256) fp32 = W_2[:, 256:] q[b] + b_2 prepared by the caller (one small rn_gemm_f32);
  * Wf[2] / Whi[2], Wlo[2] hold W_2[:, 0:256] only, bias[2] is ignored.  Needs n*n % 256 == 0. */
-/* h_dtype: the type of the stored H_0..2 rows -- RN_BF16 (M x 256 bf16) or RN_FP8 (M x 256 e4m3 bytes, value = byte value; the
- * only reader is rn_g_linear_bwd_wgrad(_gated) with a_dtype = RN_FP8).  Ignored when H is NULL. */
+/* h_dtype: the type of the stored H_0..2 rows -- RN_BF16 (M x 256 bf16) or RN_FP8 (M x 256 e4m3 bytes, value = byte value), both as
+ * ROW-BLOCKED images (the only reader is rn_g_wgrad_blocked).  Ignored when H is NULL. */
 int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, const void* const* Whi, const void* const* Wlo,
                                 const float* const* bias, void* const* H, int h_dtype, void* const* mask, float* xg_part,
                                 const float* Vq, int inject_layer, int M, int L, int G, void* stream);

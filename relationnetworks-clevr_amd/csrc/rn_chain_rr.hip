@@ -35,6 +35,7 @@ constexpr int RR_RD = 4;                                // A-fragment read-ahead
 constexpr int RR_NSLOT = 8, RR_LA = RR_NSLOT - 1;      // ring slots / stages of look-ahead
 constexpr int RR_STAGE = 16 * 1024;                    // one output block of weights: 16 fragments x 1 KB
 constexpr int RR_SRS = 80;                             // staging row stride: 64 B of features + 16
+constexpr int RR_SRS8 = 72;                            // ... of the e4m3 rows (64 B + 8: two-way on the dword writes = free, MI355X_MICROARCH.md)
 constexpr int RR_STG = RR_WR * RR_SRS;                 // per wave
 // small tables first: every ds_* address is then one of a few lane-constant VGPRs + a 16-bit immediate
 constexpr int RR_OFF_BIAS = 0;
@@ -166,6 +167,52 @@ __device__ __forceinline__ unsigned relu_pack_bf16(float a, float b) {
 }
 __device__ __forceinline__ float bf16lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf16hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// ---- copy-out of the rows that only the weight-gradient kernel reads (H_0..2, dZ_1..3): ROW-BLOCKED images (rn_wgrad_blocked.hip)
+//   16-bit: element (m, f) at ((m / 8) * 256 + f) * 8 + m % 8;   e4m3: byte (m, f) at ((m / 16) * 256 + f) * 16 + m % 16
+// i.e. 16 bytes = 8 (16) pair rows of ONE feature = one lane's MFMA operand in the product that contracts over the rows.  The
+// epilogue holds a pair row per lane, so the staged block goes back through the LDS TRANSPOSE reads: a lane receives one
+// feature's column of 4 (tr_b16) / 8 (tr_b8) rows per read, two reads make its 16 bytes, and a store instruction covers 32
+// (16-bit: 512 contiguous bytes per half wave) / 64 (e4m3: 1 KB) consecutive features of one row block.
+typedef __attribute__((address_space(3))) s16x4* lds_tr16;
+typedef __attribute__((ext_vector_type(2))) int rr_i32x2;
+typedef __attribute__((address_space(3))) rr_i32x2* lds_tr8;
+// 16-bit block staged as [32 rows][RR_SRS], 32 features = 64 B per row: -> co[t] = rows 8 rb .. 8 rb + 7 (rb = 2 t + lane / 32) of
+// feature 16 ((lane / 16) % 2) + lane % 16
+__device__ __forceinline__ void co_read_blk16(const unsigned char* stg, int lane, u32x4 (&co)[2]) {
+  const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = 8 * (2 * t + (g >> 1)) + 4 * u + (li >> 2);
+      const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr16)(stg + row * RR_SRS + 32 * (g & 1) + 8 * (li & 3)));
+      const u32x2 rr = __builtin_bit_cast(u32x2, r);
+      co[t][2 * u] = rr[0];
+      co[t][2 * u + 1] = rr[1];
+    }
+}
+// byte offset of this lane's 16 bytes of store t inside the wave's 32 rows of a 16-bit image (32-feature block `cob`)
+__device__ __forceinline__ unsigned co_off_blk16(int lane, int cob, int t) {
+  const int g = lane >> 4;
+  return (unsigned)(((2 * t + (g >> 1)) * RR_G + 32 * cob + 16 * (g & 1) + (lane & 15)) * 16);
+}
+// e4m3 pair of blocks staged as [32 rows][RR_SRS8], 64 features = 64 B per row: -> co[t] = rows 16 t .. 16 t + 15 of feature `lane`
+__device__ __forceinline__ void co_read_blk8(const unsigned char* stg, int lane, u32x4 (&co)[2]) {
+  const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = 16 * t + 8 * u + (li >> 1);
+      const rr_i32x2 r = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_tr8)(stg + row * RR_SRS8 + 16 * g + 8 * (li & 1)));
+      co[t][2 * u] = (unsigned)r[0];
+      co[t][2 * u + 1] = (unsigned)r[1];
+    }
+}
+__device__ __forceinline__ unsigned co_off_blk8(int lane, int cob, int t) {
+  return (unsigned)((t * RR_G + 32 * (cob & ~1) + lane) * 16);
+}
 }  // namespace
 
 // dst[((ob * 16 + ks) * 64 + lane) * 8 + e] = src[32 ob + lane % 32][kidx], 0 beyond (R, C)
@@ -389,7 +436,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
         pk[j][1] = relu_pack_bf16(c[4 * j + 2], c[4 * j + 3]);
       }
       if (phase_lo <= 2 && 2 <= phase_hi) {
-        if constexpr (H8) *reinterpret_cast<unsigned*>(stg + n * RR_SRS + 32 * (pob & 1) + 8 * j + 4 * h) = rn_fp8x4_from_bf16(pk[j][0], pk[j][1]);
+        if constexpr (H8) *reinterpret_cast<unsigned*>(stg + n * RR_SRS8 + 32 * (pob & 1) + 8 * j + 4 * h) = rn_fp8x4_from_bf16(pk[j][0], pk[j][1]);
         else if constexpr (STORE) *reinterpret_cast<u32x2*>(stg + n * RR_SRS + 16 * j + 8 * h) = pk[j];
         if (dst) {
           dst[2 * pob + (j >> 1)][(j & 1) * 2 + 0] = pk[j][0];
@@ -397,17 +444,25 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
         }
       }
     };
-    auto co_read = [&]() {
+    // cl < RR_L - 1: the row-blocked image for the weight gradient (transposing read-back); the last layer's rows (a stored
+    // H_3: the pair sum reads it) stay row-major
+    auto co_read = [&](int cl) {
+      if (cl < RR_L - 1) {
+        if constexpr (H8) co_read_blk8(stg, lane, co);
+        else co_read_blk16(stg, lane, co);
+        return;
+      }
 #pragma unroll
       for (int q = 0; q < 2; ++q) co[q] = *reinterpret_cast<const u32x4*>(stg + (16 * q + (lane >> 2)) * RR_SRS + (lane & 3) * 16);
     };
-    const unsigned orow_off8 = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 16);
     const unsigned orow_off = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
     auto co_store = [&](int cl, int cob, int q) {
-      if (H8 && cl < RR_L - 1) {                                      // blocks cob - 1, cob: row 16 q + lane / 4, features 32 (cob - 1) + 16 (lane % 4) .. + 15
-        gbl_u8* base8 = (gbl_u8*)(reinterpret_cast<unsigned char*>(a.out[cl]) + m0w * RR_G);
-        asm volatile("" : "+s"(base8));
-        __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base8 + orow_off8 + 16 * q * RR_G + 32 * (cob & ~1)));
+      if (cl < RR_L - 1) {
+        // e4m3: blocks cob - 1, cob (one byte per element); 16-bit: block cob.  m0w * 256 elements = the wave's first row block
+        gbl_u8* baseb = (gbl_u8*)(reinterpret_cast<unsigned char*>(a.out[cl]) + m0w * RR_G * (H8 ? 1 : 2));
+        asm volatile("" : "+s"(baseb));
+        const unsigned off = H8 ? co_off_blk8(lane, cob, q) : co_off_blk16(lane, cob, q);
+        __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(baseb + off));
         return;
       }
       gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.out[cl] + m0w * RR_G);
@@ -458,7 +513,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (has_co) co_read();
+      if (has_co) co_read(cl);
       __builtin_amdgcn_sched_barrier(0);
       Frag* dst = nullptr;
       if (has_prev && pl < RR_L - 1) dst = ob ? out : in;
@@ -524,7 +579,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
     {
       f32x4 v[4];
       if constexpr (STORE && ST3) {
-        co_read();
+        co_read(RR_L - 1);
 #pragma unroll
         for (int q = 0; q < 2; ++q) co_store(RR_L - 1, 6, q);
       }
@@ -532,7 +587,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
 #pragma unroll
       for (int j = 0; j < 4; ++j) epi3_group(7, j, 0, 2, v);
       if constexpr (STORE && ST3) {
-        co_read();
+        co_read(RR_L - 1);
 #pragma unroll
         for (int q = 0; q < 2; ++q) co_store(RR_L - 1, 7, q);
       }
@@ -752,21 +807,29 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
         }
       }
       if (ph == 3 && STORE) {
-        if constexpr (H8) *reinterpret_cast<unsigned*>(stg + n * RR_SRS + 32 * (pob & 1) + 8 * j + 4 * h) = pk[j][0];
+        if constexpr (H8) *reinterpret_cast<unsigned*>(stg + n * RR_SRS8 + 32 * (pob & 1) + 8 * j + 4 * h) = pk[j][0];
         else *reinterpret_cast<u32x2*>(stg + n * RR_SRS + 16 * j + 8 * h) = pk[j];
       }
     };
-    auto co_read = [&]() {
+    // cl < RR_L - 1: the row-blocked image for the weight gradient (transposing read-back); the last layer's rows (a stored
+    // H_3: the pair sum reads it) stay row-major
+    auto co_read = [&](int cl) {
+      if (cl < RR_L - 1) {
+        if constexpr (H8) co_read_blk8(stg, lane, co);
+        else co_read_blk16(stg, lane, co);
+        return;
+      }
 #pragma unroll
       for (int q = 0; q < 2; ++q) co[q] = *reinterpret_cast<const u32x4*>(stg + (16 * q + (lane >> 2)) * RR_SRS + (lane & 3) * 16);
     };
-    const unsigned orow_off8 = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 16);
     const unsigned orow_off = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
     auto co_store = [&](int cl, int cob, int q) {
-      if (H8 && cl < RR_L - 1) {                                      // blocks cob - 1, cob: row 16 q + lane / 4, features 32 (cob - 1) + 16 (lane % 4) .. + 15
-        gbl_u8* base8 = (gbl_u8*)(reinterpret_cast<unsigned char*>(a.out[cl]) + m0w * RR_G);
-        asm volatile("" : "+s"(base8));
-        __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base8 + orow_off8 + 16 * q * RR_G + 32 * (cob & ~1)));
+      if (cl < RR_L - 1) {
+        // e4m3: blocks cob - 1, cob (one byte per element); 16-bit: block cob.  m0w * 256 elements = the wave's first row block
+        gbl_u8* baseb = (gbl_u8*)(reinterpret_cast<unsigned char*>(a.out[cl]) + m0w * RR_G * (H8 ? 1 : 2));
+        asm volatile("" : "+s"(baseb));
+        const unsigned off = H8 ? co_off_blk8(lane, cob, q) : co_off_blk16(lane, cob, q);
+        __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(baseb + off));
         return;
       }
       gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.out[cl] + m0w * RR_G);
@@ -815,7 +878,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (has_co) co_read();
+      if (has_co) co_read(cl);
       __builtin_amdgcn_sched_barrier(0);
       Frag* dst = nullptr;
       if (has_prev && pl < RR_L - 1) dst = ob ? out : in;
@@ -876,7 +939,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
     {
       f32x4 v[4];
       if constexpr (STORE && ST3) {
-        co_read();
+        co_read(RR_L - 1);
 #pragma unroll
         for (int q = 0; q < 2; ++q) co_store(RR_L - 1, 6, q);
       }
@@ -888,7 +951,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
         epi3_group(7, j, 2, v);
       }
       if constexpr (STORE && ST3) {
-        co_read();
+        co_read(RR_L - 1);
 #pragma unroll
         for (int q = 0; q < 2; ++q) co_store(RR_L - 1, 7, q);
       }
@@ -980,7 +1043,13 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
     const long m0w = (long)tile * RR_TM + RR_WR * w;
     const long wt = (long)tile * RR_NW + w;
     const long b = (m0w + n) / a.rows_per_b;                          // question of THIS lane's pair row (a wave may straddle two)
-    auto co_read = [&]() {
+    // zi < NS: dZ of layers 3..1 -- read only by the weight gradient: row-blocked image (transposing read-back); zi == NS: dZ of
+    // layer 0, read by the pair reduction: row-major
+    auto co_read = [&](int zi) {
+      if (zi < NS) {
+        co_read_blk16(stg, lane, co);
+        return;
+      }
 #pragma unroll
       for (int q = 0; q < 2; ++q) co[q] = *reinterpret_cast<const u32x4*>(stg + (16 * q + (lane >> 2)) * RR_SRS + (lane & 3) * 16);
     };
@@ -989,6 +1058,10 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
       if (ABL & 4) return;
       gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.dZ + zi * a.dz_stride + ((ABL & 32) ? (long)(blockIdx.x * RR_TM + RR_WR * w) : m0w) * RR_G);
       asm volatile("" : "+s"(base));
+      if (zi < NS) {
+        __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + co_off_blk16(lane, cob, q)));
+        return;
+      }
       // non-temporal: these rows are read back by ANOTHER kernel much later; allocated in L2 they only evict the
       // weight images that every workgroup re-reads for every tile (measured: 222 -> 150 us)
       if (ABL & 64) *reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2) = co[q];
@@ -1053,7 +1126,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
           if constexpr (!SKIP0) *reinterpret_cast<u32x4*>(stg + n * RR_SRS + 32 * s + 16 * h) = actA[ks];
         }
         if constexpr (!SKIP0) {
-          co_read();
+          co_read(0);
 #pragma unroll
           for (int q = 0; q < 2; ++q) co_store(0, ob, q);
         }
@@ -1091,7 +1164,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
       f32x4 rj[4];
       float rv[16];
       if constexpr (red_co) red_read(rj, rv);
-      else if (has_co) co_read();
+      else if (has_co) co_read(cs + 1);
       __builtin_amdgcn_sched_barrier(0);
       Frag* dst = nullptr;
       if (has_prev && ps < NS - 1) dst = ob ? out : in;
@@ -1185,7 +1258,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
       red_store_ri(7, rv);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the next tile's staging writes overlap this area)
     } else {
-      co_read();
+      co_read(NS);
 #pragma unroll
       for (int q = 0; q < 2; ++q) co_store(NS, 6, q);
       u32x16(&gp)[2] = ((NS * 8 - 1) & 1) ? gB : gA;                    // requested in the last stage
@@ -1201,7 +1274,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
         pk[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f1, bf16x2));
         *reinterpret_cast<u32x2*>(stg + n * RR_SRS + 16 * j + 8 * h) = pk;
       }
-      co_read();
+      co_read(NS);
 #pragma unroll
       for (int q = 0; q < 2; ++q) co_store(NS, 7, q);
     }

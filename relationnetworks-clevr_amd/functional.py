@@ -217,11 +217,10 @@ def f16s_ok(plan: LayerPlan, B, n):
 
 
 def _h_copy_dtype(plan, dt, M):
-    """Storage type of the H_0..2 copies the factored-first-layer chains keep for the weight gradient: OCP e4m3 bytes (half the
-    bytes written by the forward chain and read back by the streaming wgrad kernel -- its only reader) when that kernel covers
-    the shape, else the chain's 16-bit type.  RN_H8=0 keeps the 16-bit copies (A/B measurements, error comparisons)."""
-    if (os.environ.get("RN_H8", "1") != "0" and dt == torch.bfloat16 and all(w == 256 for w in plan.widths)
-            and M % 64 == 0 and M // 64 >= 64):
+    """Storage type of the H_0..2 copies the register-resident chains keep for the weight gradient (row-blocked images,
+    rn_g_wgrad_blocked is their only reader): OCP e4m3 bytes -- half the bytes written by the forward chain and read back --
+    or the chain's 16-bit type with RN_H8=0 (A/B measurements, error comparisons)."""
+    if os.environ.get("RN_H8", "1") != "0" and dt == torch.bfloat16 and all(w == 256 for w in plan.widths):
         return torch.float8_e4m3fn
     return dt
 
@@ -576,16 +575,17 @@ class RelationalFunction(torch.autograd.Function):
         dt = H.torch_dtype(code)
         inputs, wbwd, g_w = ctx.inputs, ctx.wbwd, ctx.g_w
         fused_bwd = fused_chain_ok(plan, code, B, n) and L >= 2 and os.environ.get("RN_NO_FUSED_BWD", "0") != "1"
-        if isinstance(ctx.HL, RRMasks):
+        rr_bwd = isinstance(ctx.HL, RRMasks)       # the register-resident chains: H_0..2 / dZ of layers 1..3 are row-blocked images
+        if rr_bwd:
             # register-resident backward chain on the forward kernel's gates (one launch, no activation is re-read)
             fused_bwd = True
             # the last layer's gradient dZ_{L-1} = gate x dxg[question] is never stored: its only reader besides the chain
-            # itself, the layer's wgrad, rebuilds it from the masks (rn_g_linear_bwd_wgrad_gated) -- 134 MB less written
+            # itself, the layer's wgrad, rebuilds it from the masks (rn_g_wgrad_blocked) -- 134 MB less written
             # by the chain and 134 MB less read by the wgrad at the headline shape
             gated_mask = None
             red_parts = None
-            if ((n * n) % 64 == 0 and M // 64 >= 64 and plan.widths[-2] == 256 and G == 256
-                    and os.environ.get("RN_NO_GATED_WGRAD", "0") != "1"):
+            # (needs the e4m3 H_2 image: the gate job runs on the fp8 matrix pipe; with 16-bit copies dZ_3 is stored)
+            if ((n * n) % 64 == 0 and inputs[L - 1].dtype in H.FP8_DTYPES and os.environ.get("RN_NO_GATED_WGRAD", "0") != "1"):
                 gated_mask = ctx.HL.masks[L - 1]
                 # RN_CHAIN_REDUCE=1 (opt-in): ... and neither is the FIRST layer's gradient where its only readers are the pair
                 # reductions (layer-0 weight gradient from the reductions, 64 objects): the chain adds each 256-row tile's four i
@@ -623,32 +623,46 @@ class RelationalFunction(torch.autograd.Function):
         dx = None
         inj = bool(ctx.inj_path)        # the chains ran with the question injected at layer plan.inject > 0 as a bias row
 
-        def _wgrad(l, dz, a_l):
+
+        def _wgrad(l, dz, a_l):                                        # row-major operands: the general kernel
             N_, kt_, kp_ = plan.widths[l], plan.ktrue[l], plan.kpad[l]
             gW[l] = torch.empty(N_, kt_, **f32)
             gB[l] = torch.empty(N_, **f32)
-            if inj and l == plan.inject:
-                # the layer's input is [H_{l-1} | q]: dW = [dZ^T H_{l-1} | Rq^T q].  The H part is the ordinary K = 256 product
-                # on the stored activation; the question part follows from the per-question sums Rq (_wgrad_question below)
-                gp = plan.widths[l - 1]
-                tmp = torch.empty(N_, gp, **f32)
-                ws_ = H.g_linear_bwd_wgrad(dz, N_, a_l, gp, tmp, gB[l], code, M, N_, gp, gp, return_ws=True)
+            H.g_linear_bwd_wgrad(dz, N_, a_l, kp_, gW[l], gB[l], code, M, N_, kp_, kt_)
+
+        def _wgrads_blocked(dz_all, a_all):
+            """Layers 1..L-1 on the register-resident chains' row-blocked images: ONE launch + one reduction launch
+            (rn_g_wgrad_blocked).  The injected layer (input [H_{l-1} | q]): dW = [dZ^T H_{l-1} | Rq^T q] -- the H part is an
+            ordinary job; Rq (per-question column sums of dZ) = the kernel's bias-gradient partials when no row split
+            straddles two questions, dq and the question columns of dW follow at once, on this stream."""
+            order = list(range(1, L))
+            if inj:                                                # (its dq is waited for by the main stream: first)
+                order.remove(plan.inject)
+                order.insert(0, plan.inject)
+            jobs, tmp = [], None
+            for l in order:
+                N_, kt_ = plan.widths[l], plan.ktrue[l]
+                gW[l] = torch.empty(N_, kt_, **f32)
+                gB[l] = torch.empty(N_, **f32)
+                # the last layer without a stored gradient: its gate as an e4m3 {0, 1} image, scaled by dxg per question in the kernel
+                dz_l = dz_all[l] if dz_all[l] is not None else H.relu_gate_image(gated_mask, M)
+                if inj and l == plan.inject:
+                    tmp = torch.empty(N_, plan.widths[l - 1], **f32)
+                    jobs.append((dz_l, a_all[l], tmp, gB[l]))
+                else:
+                    jobs.append((dz_l, a_all[l], gW[l], gB[l]))
+            ws_, parts = H.g_wgrad_blocked(jobs, M, dxg=dxg, rows_per_question=n * n)
+            if tmp is not None:
+                l = plan.inject
+                N_, kt_, gp = plan.widths[l], plan.ktrue[l], plan.widths[l - 1]
                 gW[l][:, :gp].copy_(tmp)
                 if rq_splits:
-                    # Rq (per-question column sums of dZ) = the streaming kernel's bias-gradient partials, one row split or an
-                    # integral number of them per question -- instead of a pass of the pair-reduction kernel over the 134 MB
-                    # of dZ; dq and the question columns of dW follow at once, on this stream
                     wl_ = g_w[l] if g_w[l].is_contiguous() else g_w[l].contiguous()
-                    rq_ = H.wgrad_db_partials(ws_, rq_splits, N_, gp).view(B, rq_splits // B, N_).sum(1)
+                    rq_ = parts[0].view(B, (rq_splits // B) * 4, N_).sum(1)
                     dq_ = torch.empty(B, Q, **f32)
                     H.gemm_f32(rq_, N_, 1, wl_, kt_, 1, dq_, Q, B, Q, N_, b_off=kt_ - Q)          # Rq @ W[:, -Q:]
                     H.gemm_f32(rq_, 1, N_, q, Q, 1, gW[l], kt_, N_, Q, B, c_off=kt_ - Q)          # gW[l][:, G_prev:] = Rq^T q
-                    inj_out["dq"], inj_out["keep"] = dq_, [ws_, rq_, wl_]
-                return
-            if dz is None:                                             # last layer on the masks
-                H.g_linear_bwd_wgrad_gated(gated_mask, dxg, n * n, a_l, kp_, gW[l], gB[l], M, N_, kp_)
-            else:
-                H.g_linear_bwd_wgrad(dz, N_, a_l, kp_, gW[l], gB[l], code, M, N_, kp_, kt_)
+                    inj_out["dq"], inj_out["keep"] = dq_, [ws_, rq_, wl_, tmp]
         # The weight gradients are not needed by anything upstream: with the fused chain all dZ_l exist now, so
         # the L wgrad launches go to a side stream and overlap the rest of this backward AND the conv / LSTM
         # backward that autograd runs next (small kernels that leave the chip mostly empty).  The main stream
@@ -664,9 +678,8 @@ class RelationalFunction(torch.autograd.Function):
         # question injected at layer > 0: its per-question sums Rq from the wgrad kernel's per-split column sums when no split
         # straddles two questions (64 splits: B | 64), else from the pair-reduction kernel
         rq_splits, inj_out = 0, {}
-        if inj and fused_bwd and os.environ.get("RN_NO_RQ_FROM_WGRAD", "0") != "1":
-            li = plan.inject
-            z_ = H.wgrad_stream_splits(dZ_of[li], plan.widths[li], inputs[li], plan.widths[li - 1], code, M, plan.widths[li], plan.widths[li - 1])
+        if inj and rr_bwd and os.environ.get("RN_NO_RQ_FROM_WGRAD", "0") != "1":
+            z_ = H.wgrad_blocked_splits(M, n * n)
             if z_ > 0 and z_ % B == 0 and (M // 64) % z_ == 0 and (n * n) % (M // z_) == 0:
                 rq_splits = z_
         # RN_WGRAD_LATE=1 / 2 starts the (HBM-bound) wgrad stream only after the pair reduction / after dx, dq: measured
@@ -681,16 +694,17 @@ class RelationalFunction(torch.autograd.Function):
             def _launch_wgrads():
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    order = list(range(L))
-                    if rq_splits:                                  # (its dq is waited for by the main stream: first)
-                        order.remove(plan.inject)
-                        order.insert(0, plan.inject)
-                    for l in order:
-                        if l == 0 and alg0:
-                            continue                               # layer 0: from the pair reductions, below
-                        _wgrad(l, dz_all[l], inputs_all[l])
-                        if rq_splits and l == plan.inject:
+                    if rr_bwd:
+                        _wgrads_blocked(dz_all, inputs_all)
+                        if rq_splits:
                             inj_out["event"] = side.record_event()
+                        if not alg0:
+                            _wgrad(0, dz_all[0], inputs_all[0])
+                    else:
+                        for l in range(L):
+                            if l == 0 and alg0:
+                                continue                           # layer 0: from the pair reductions, below
+                            _wgrad(l, dz_all[l], inputs_all[l])
             inputs_all = list(inputs)
             if not wgrad_late:
                 _launch_wgrads()
@@ -705,7 +719,9 @@ class RelationalFunction(torch.autograd.Function):
             kt, kp = plan.ktrue[l], plan.kpad[l]
             if fused_bwd:
                 dZ = dZ_of.pop(l)
-            if not overlap and not (l == 0 and alg0):
+            if not overlap and rr_bwd and l == L - 1:
+                _wgrads_blocked({**dZ_of, l: dZ}, inputs)             # layers 1..L-1 at once (their dZ all exist)
+            if not overlap and not (l == 0 and alg0) and not (rr_bwd and l > 0):
                 _wgrad(l, dZ, A_l)
             wl = g_w[l] if g_w[l].is_contiguous() else g_w[l].contiguous()
             fused_tail = (l == 0 and (plan.inject == 0 or inj) and k <= 32
@@ -720,6 +736,8 @@ class RelationalFunction(torch.autograd.Function):
                         H.pair_reduce_from_chain(red_parts[0], red_parts[1], Rj, Ri, Rq, B, n, N)
                     else:
                         H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N)
+                elif rr_bwd:
+                    H.blocked_question_sums(dZ, Rq, M, n * n)      # (this layer's dZ is a row-blocked image)
                 else:
                     H.pair_reduce_bwd(dZ, N, None, None, Rq, code, B, n, N)
                 dq = torch.empty(B, Q, **f32)

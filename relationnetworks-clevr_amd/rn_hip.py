@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librn_hip.so")
 RN_BF16, RN_F32, RN_F16, RN_FP8 = 0, 1, 2, 3
 RN_RELU, RN_ACCUMULATE = 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -43,7 +43,6 @@ SIGNATURES = {
     "rn_g_chain_bwd_rr_reduce": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_chain_reduce_part_bytes": (_Z, [_I, _I]),
     "rn_pair_reduce_from_chain": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "rn_g_linear_bwd_wgrad_gated": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pack_matrix_frag": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
     "rn_pack_matrix_frag_many": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
@@ -53,8 +52,14 @@ SIGNATURES = {
     "rn_pair_sum_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "rn_g_linear_bwd_dgrad": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "rn_wgrad_ws_bytes": (_Z, [_I, _I, _I]),
-    "rn_wgrad_stream_splits": (_I, [_I, _I, _I, _I, _I, _I, _I]),
-    "rn_g_linear_bwd_wgrad": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_g_linear_bwd_wgrad": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_rows_to_blocked": (_I, [_P, _P, _I, _I, _I, _P]),
+    "rn_wgrad_blocked_splits": (_I, [_I, _I]),
+    "rn_wgrad_blocked_ws_bytes": (_Z, [_I, _I, _I]),
+    "rn_wgrad_blocked_db_partials_offset": (_Z, [_I, _I, _I, _I]),
+    "rn_blocked_question_sums": (_I, [_P, _P, _I, _I, _P]),
+    "rn_g_wgrad_blocked": (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P]),
+    "rn_relu_gate_image": (_I, [_P, _P, _I, _P]),
     "rn_pair_reduce_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_reduce_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_dx_dq": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _I, _I, _I, _I, _I, _P]),
@@ -426,37 +431,75 @@ def g_linear_bwd_dgrad(dZ, lddz, Wt, ldwt, Hprev, ldhp, dZprev, lddzp, code, M, 
                                         lddzp, code, M, N, Kin, _stream()), "rn_g_linear_bwd_dgrad")
 
 
-def wgrad_stream_splits(dZ, lddz, A, lda, code, M, N, K):
-    """Row splits of the streaming wgrad kernel for this product (0: general kernel) -- see rn_wgrad_stream_splits."""
-    return load().rn_wgrad_stream_splits(code, RN_FP8 if A.dtype in FP8_DTYPES else code, M, N, K, lddz, lda)
-
-
-def wgrad_db_partials(ws, Z, N, K):
-    """The (Z, N) fp32 column sums of dZ per row split that rn_g_linear_bwd_wgrad left in its workspace."""
-    return ws.view(torch.float32)[Z * N * K: Z * N * K + Z * N].view(Z, N)
-
-
 @_timed("g_wgrad")
-def g_linear_bwd_wgrad(dZ, lddz, A, lda, dW, db, code, M, N, K, Ktrue, return_ws=False):
+def g_linear_bwd_wgrad(dZ, lddz, A, lda, dW, db, code, M, N, K, Ktrue):
+    """General weight gradient on ROW-MAJOR operands (any N % 256 == 0, K % 32 == 0; bf16 or fp32)."""
     lib = load()
     nb = lib.rn_wgrad_ws_bytes(M, N, K)
     if nb == 0:
         raise RuntimeError("rn_wgrad_ws_bytes: unsupported shape M=%d N=%d K=%d" % (M, N, K))
     ws = torch.empty(nb, dtype=torch.uint8, device=dW.device)
-    _check(lib.rn_g_linear_bwd_wgrad(dZ.data_ptr(), lddz, A.data_ptr(), lda, RN_FP8 if A.dtype in FP8_DTYPES else code, dW.data_ptr(), _ptr(db),
+    _check(lib.rn_g_linear_bwd_wgrad(dZ.data_ptr(), lddz, A.data_ptr(), lda, dW.data_ptr(), _ptr(db),
                                      ws.data_ptr(), code, M, N, K, Ktrue, _stream()), "rn_g_linear_bwd_wgrad")
-    if return_ws:
-        return ws
+
+
+def wgrad_blocked_splits(M, rows_per_question=0):
+    """Row splits of rn_g_wgrad_blocked for M pair rows (0: not covered)."""
+    return load().rn_wgrad_blocked_splits(M, rows_per_question)
+
+
+@_timed("pair_reduce")
+def blocked_question_sums(img, Rq, M, rows_per_question):
+    _check(load().rn_blocked_question_sums(img.data_ptr(), Rq.data_ptr(), M, rows_per_question, _stream()), "rn_blocked_question_sums")
+
+
+def rows_to_blocked(src, back=False):
+    """Row-major (M, 256) bf16 / e4m3 matrix <-> its row-blocked image (tests, tools)."""
+    M = src.numel() // 256
+    dst = torch.empty_like(src)
+    _check(load().rn_rows_to_blocked(src.data_ptr(), dst.data_ptr(), RN_FP8 if src.dtype in FP8_DTYPES else RN_BF16, M, int(back), _stream()),
+           "rn_rows_to_blocked")
+    return dst
 
 
 @_timed("g_wgrad")
-def g_linear_bwd_wgrad_gated(mask, dxg, rows_per_question, A, lda, dW, db, M, N, K):
-    """Last g layer: weight gradient from the layer-3 lane masks + dxg instead of a stored dZ_3 (rn_g_linear_bwd_wgrad_gated)."""
+def relu_gate_image(mask, M):
+    """Layer-3 lane masks of the forward chain -> the e4m3 {0, 1} row-blocked gate image (the dZ operand of a gate job)."""
+    img = torch.empty(M, 256, dtype=torch.float8_e4m3fn, device=mask.device)
+    _check(load().rn_relu_gate_image(mask.data_ptr(), img.data_ptr(), M, _stream()), "rn_relu_gate_image")
+    return img
+
+
+@_timed("g_wgrad")
+def g_wgrad_blocked(jobs, M, dxg=None, rows_per_question=0, abl=0):
+    """Weight gradients of the 256-wide g layers on the chains' row-blocked images, one launch for all `jobs`:
+    jobs = [(dZ, A, dW, db), ...]; a job whose dZ is an e4m3 image is a gate job (the last layer: gate image x dxg per question).
+    -> (ws, [db partials (Z, 4, 256) per job]): the workspace must stay alive while the partials are in use."""
     lib = load()
-    ws = torch.empty(lib.rn_wgrad_ws_bytes(M, N, K), dtype=torch.uint8, device=dW.device)
-    _check(lib.rn_g_linear_bwd_wgrad_gated(mask.data_ptr(), dxg.data_ptr(), rows_per_question, A.data_ptr(), lda,
-                                           RN_FP8 if A.dtype in FP8_DTYPES else RN_BF16, dW.data_ptr(), db.data_ptr(), ws.data_ptr(), M, N, K, _stream()),
-           "rn_g_linear_bwd_wgrad_gated")
+    nj = len(jobs)
+    nb = lib.rn_wgrad_blocked_ws_bytes(M, rows_per_question, nj)
+    if nb == 0:
+        raise RuntimeError("rn_g_wgrad_blocked: unsupported shape M=%d, %d jobs" % (M, nj))
+    a8 = jobs[0][1].dtype in FP8_DTYPES
+    ws = torch.empty(nb, dtype=torch.uint8, device=jobs[0][2].device)
+    zp = (C.c_void_p * nj)(*[j[0].data_ptr() for j in jobs])
+    zt = (C.c_int * nj)(*[(RN_FP8 if j[0].dtype in FP8_DTYPES else RN_BF16) for j in jobs])
+    ap = (C.c_void_p * nj)(*[j[1].data_ptr() for j in jobs])
+    wp = (C.c_void_p * nj)(*[j[2].data_ptr() for j in jobs])
+    bp = (C.c_void_p * nj)(*[j[3].data_ptr() for j in jobs])
+    args = (zp, zt, ap, RN_FP8 if a8 else RN_BF16, _ptr(dxg), rows_per_question, wp, bp, nj, ws.data_ptr(), M, _stream())
+    if abl:                                                   # RN_DIAG builds only (tools/): timing ablations, wrong results
+        fn = lib.rn_diag_wgrad_blocked
+        fn.restype, fn.argtypes = _I, SIGNATURES["rn_g_wgrad_blocked"][1] + [_I]
+        _check(fn(*args, abl), "rn_diag_wgrad_blocked")
+    else:
+        _check(lib.rn_g_wgrad_blocked(*args), "rn_g_wgrad_blocked")
+    Z = lib.rn_wgrad_blocked_splits(M, rows_per_question)
+    parts = []
+    for j in range(nj):
+        off = lib.rn_wgrad_blocked_db_partials_offset(M, rows_per_question, nj, j) // 4
+        parts.append(ws.view(torch.float32)[off: off + Z * 4 * 256].view(Z, 4, 256))
+    return ws, parts
 
 
 @_timed("pair_reduce")

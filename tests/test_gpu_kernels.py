@@ -46,6 +46,33 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+def unblock(t):
+    """Row-blocked image (include/rn_hip.h: what the register-resident chains write for the weight gradient) -> the row-major
+    (M, 256) matrix, in plain torch: 16-bit element (m, f) sits at ((m / 8) * 256 + f) * 8 + m % 8, e4m3 byte (m, f) at
+    ((m / 16) * 256 + f) * 16 + m % 16."""
+    if t is None:
+        return None
+    M = t.numel() // 256
+    rb = 8 if t.element_size() == 2 else 16
+    raw = t.contiguous().view(torch.int16 if rb == 8 else torch.uint8)
+    return raw.view(M // rb, 256, rb).permute(0, 2, 1).reshape(M, 256).contiguous().view(t.dtype)
+
+
+def unblock_h(Hs, upto=3):
+    """H_0..2 (or dZ of layers 3..1) of a chain call are row-blocked images; a stored fourth entry is row-major."""
+    return None if Hs is None else [unblock(h) if i < upto else h for i, h in enumerate(Hs)]
+
+
+def test_rows_to_blocked(H):
+    for dt in (torch.bfloat16, torch.float8_e4m3fn):
+        M = 16 * 37
+        a = (torch.rand(M, 256, device="cuda") * 4).to(dt)
+        img = H.rows_to_blocked(a)
+        torch.cuda.synchronize()
+        assert torch.equal(unblock(img).view(torch.uint8), a.view(torch.uint8))
+        assert torch.equal(H.rows_to_blocked(img, back=True).view(torch.uint8), a.view(torch.uint8))
+
+
 # ----------------------------------------------------------------------------- probe
 def test_probe_tr16_mapping(H):
     """ds_read_b64_tr_b16 on a linear image (lane l supplies &lds[4l]): within each 16-lane block,
@@ -329,6 +356,7 @@ def test_g_chain_fwd_rr(H, K0, K0true, mode, M):
     part = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
     H.g_chain_fwd_rr(dev(P).bfloat16(), K0, Wf, [dev(b) for b in bs], Hs, masks, K0, part, M, G)
     torch.cuda.synchronize()
+    Hs = unblock_h(Hs)
     prev = P[:, :K0true]
     for l in range(L):
         ref = np.maximum(prev.astype(np.float64) @ Ws[l].astype(np.float64).T + bs[l], 0)
@@ -379,6 +407,7 @@ def test_g_chain_fwd_rr_alg0(H, mode, B, n):
     part = torch.full((M // 256, G), float("nan"), dtype=torch.float32, device="cuda")
     H.g_chain_fwd_rr_alg0(Xp, Vc, n, Wf, [dev(b) for b in bs], Hs, masks, part, M, G)
     torch.cuda.synchronize()
+    Hs = unblock_h(Hs)
     if mode == "train8":
         # e4m3 copies (h_dtype = RN_FP8): same arithmetic, so masks and pair sums bitwise; the bytes = the e4m3 rounding of the bf16 copies
         Hs8 = [torch.full((M, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [None]
@@ -386,6 +415,7 @@ def test_g_chain_fwd_rr_alg0(H, mode, B, n):
         part8 = torch.full((M // 256, G), float("nan"), dtype=torch.float32, device="cuda")
         H.g_chain_fwd_rr_alg0(Xp, Vc, n, Wf, [dev(b) for b in bs], Hs8, masks8, part8, M, G)
         torch.cuda.synchronize()
+        Hs8 = unblock_h(Hs8)
         assert torch.equal(part, part8)
         for l in range(L):
             assert torch.equal(masks[l], masks8[l]), l
@@ -456,6 +486,7 @@ def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
     H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, HsA, mA, pA, M, G)
     H.g_chain_fwd_rr_f16s(P16, K0, hiP, loP, bd, HsP, mP, K0, pP, M, G)
     torch.cuda.synchronize()
+    HsA, HsP = unblock_h(HsA), unblock_h(HsP)
     assert rel(pA.cpu().numpy(), pP.view(M // 256, 8, G).sum(1).cpu().numpy()) <= 2e-3
     if train:
         for l in range(3):
@@ -470,6 +501,7 @@ def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
         p8 = torch.full((M // 256, G), float("nan"), dtype=torch.float32, device="cuda")
         H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, Hs8, m8, p8, M, G)
         torch.cuda.synchronize()
+        Hs8 = unblock_h(Hs8)
         assert torch.equal(pA, p8)
         for l in range(L):
             assert torch.equal(mA[l], m8[l]), l
@@ -508,6 +540,7 @@ def test_g_chain_fwd_rr_f16s(H, mode, M):
     part = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
     H.g_chain_fwd_rr_f16s(dev(P).half(), K0, his, los, [dev(b) for b in bs], Hs, masks, K0, part, M, G)
     torch.cuda.synchronize()
+    Hs = unblock_h(Hs)
     prev = P[:, :K0true].astype(np.float64)
     exact = prev
     for l in range(L):
@@ -531,6 +564,7 @@ def test_g_chain_fwd_rr_f16s(H, mode, M):
         p8 = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
         H.g_chain_fwd_rr_f16s(dev(P).half(), K0, his, los, [dev(b) for b in bs], Hs8, m8, K0, p8, M, G)
         torch.cuda.synchronize()
+        Hs8 = unblock_h(Hs8)
         assert torch.equal(part, p8)
         for l in range(L):
             assert torch.equal(masks[l], m8[l]), l
@@ -545,18 +579,37 @@ def test_g_chain_fwd_rr_f16s(H, mode, M):
         m48 = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
         H.g_chain_fwd_rr_f16s(dev(P).half(), K0, his, los, [dev(b) for b in bs], Hs48, m48, K0, None, M, G)
         torch.cuda.synchronize()
+        Hs48 = unblock_h(Hs48)
         assert torch.equal(Hs4[3], Hs48[3])
         for l in range(3):
             assert torch.equal(Hs48[l].view(torch.uint8), Hs8[l].view(torch.uint8)), l
             assert torch.equal(m4[l], m48[l])
 
 
-def test_wgrad_gated_and_bwd_skip0(H):
+def gate_image_ref(mask, M):
+    """e4m3 {0, 1} gate image of the layer-3 masks, from the test's own mask decoder: row-major (M, 256) float 0 / 1."""
+    return torch.from_numpy(rr_mask_decode(mask, M, 3)).cuda()
+
+
+def test_relu_gate_image(H):
+    M = 32 * 77
+    g = torch.Generator(device="cuda").manual_seed(3)
+    mask = torch.randint(0, 256, (H.g_chain_rr_mask_bytes(M),), dtype=torch.uint8, device="cuda", generator=g)
+    img = H.relu_gate_image(mask, M)
+    torch.cuda.synchronize()
+    got = unblock(img).view(torch.uint8)
+    assert torch.equal(got, gate_image_ref(mask, M).to(torch.uint8) * 0x38)
+
+
+@pytest.mark.parametrize("B,n", [(17, 64), (3, 64), (2, 32)])
+def test_wgrad_gated_and_bwd_skip0(H, B, n):
     """The last g layer without its gradient matrix: rn_g_chain_bwd_rr with dZ[0] = NULL must give the same dZ[1..3] as
-    the full call, and rn_g_linear_bwd_wgrad_gated (operand rebuilt from the masks + dxg) the same dW / db -- bitwise --
-    as rn_g_linear_bwd_wgrad on the stored dZ[0].  B = 17 questions of 64 x 64 pairs: 272 tiles > 256 CUs, and the 64
-    row splits of the wgrad straddle questions (17 * 64 steps / 64 splits)."""
-    B, n, L, G = 17, 64, 4, 256
+    the full call; the stored dZ[0] image (row-blocked) = bf16(dxg) where the gate is set; and the GATE job of
+    rn_g_wgrad_blocked (gate image x e4m3 activations on the fp8 pipe, scaled by the un-rounded dxg per question) must give the
+    float64 product gate * dxg -- to fp32 accumulation accuracy, i.e. closer to the reference than the job on the stored,
+    bf16-rounded dZ[0], which is checked against ITS float64 product.  B = 17: 272 tiles > 256 CUs, 34 question-aligned splits;
+    B = 3: 48 splits; (2, 32): 32 steps in all -- fewer than the ring is deep, 16 steps per question."""
+    L, G = 4, 256
     M = B * n * n
     g = torch.Generator(device="cuda").manual_seed(5)
     masks = list(torch.randint(0, 256, (L, H.g_chain_rr_mask_bytes(M)), dtype=torch.uint8, device="cuda", generator=g))
@@ -572,13 +625,67 @@ def test_wgrad_gated_and_bwd_skip0(H):
     torch.cuda.synchronize()
     for s in range(1, L):
         assert torch.equal(full[s], part[s]), s
-    A = (torch.rand(M, G, device="cuda", generator=g) - 0.5).bfloat16()
-    dW0 = torch.empty(G, G, device="cuda"); db0 = torch.empty(G, device="cuda")
-    H.g_linear_bwd_wgrad(full[0], G, A, G, dW0, db0, H.RN_BF16, M, G, G, G)
+    gate = gate_image_ref(masks[L - 1], M)
+    assert torch.equal(unblock(full[0]).float(), dxg.bfloat16().float().repeat_interleave(n * n, 0) * gate)
+    A8 = (torch.rand(M, G, device="cuda", generator=g) * 4).to(torch.float8_e4m3fn)
+    Ab = H.rows_to_blocked(A8)
+    dW0 = torch.full((G, G), float("nan"), device="cuda"); db0 = torch.full((G,), float("nan"), device="cuda")
+    H.g_wgrad_blocked([(full[0], Ab, dW0, db0)], M, rows_per_question=n * n)
     dW1 = torch.full((G, G), float("nan"), device="cuda"); db1 = torch.full((G,), float("nan"), device="cuda")
-    H.g_linear_bwd_wgrad_gated(masks[L - 1], dxg, n * n, A, G, dW1, db1, M, G, G)
+    H.g_wgrad_blocked([(H.relu_gate_image(masks[L - 1], M), Ab, dW1, db1)], M, dxg=dxg, rows_per_question=n * n)
     torch.cuda.synchronize()
-    assert torch.equal(dW0, dW1) and torch.equal(db0, db1)
+    dz_stored = unblock(full[0]).double()
+    dz_exact = dxg.double().repeat_interleave(n * n, 0) * gate
+    for dW, db, dz in ((dW0, db0, dz_stored), (dW1, db1, dz_exact)):
+        assert rel(dW.cpu().numpy(), (dz.t() @ A8.double()).cpu().numpy()) <= 2e-5
+        assert rel(db.cpu().numpy(), dz.sum(0).cpu().numpy()) <= 2e-5
+
+
+@pytest.mark.parametrize("a8", [False, True])
+@pytest.mark.parametrize("B,n", [(16, 64), (5, 64), (1, 32)])
+def test_wgrad_blocked_three_jobs(H, B, n, a8):
+    """The step's three weight gradients as ONE rn_g_wgrad_blocked launch (e4m3 activations: two stored gradients + the gate job;
+    16-bit activations: three stored gradients): every dW / db against a float64 product, bitwise what three single-job launches
+    give (same splits, same order), bitwise repeatable; the db partials add up to per-question column sums of dZ when the splits
+    are question-aligned."""
+    G = 256
+    M = B * n * n
+    g = torch.Generator(device="cuda").manual_seed(17)
+    dZ = [((torch.rand(M, G, device="cuda", generator=g) - 0.5) * 1e-2).bfloat16() for _ in range(3)]
+    Hc = [(torch.rand(M, G, device="cuda", generator=g) * 3).clamp_min(0.0) for _ in range(3)]
+    Hc = [torch.where(torch.rand(M, G, device="cuda", generator=g) < 0.4, torch.zeros_like(h), h) for h in Hc]
+    Hc = [h.to(torch.float8_e4m3fn) if a8 else h.bfloat16() for h in Hc]
+    mask = torch.randint(0, 256, (H.g_chain_rr_mask_bytes(M),), dtype=torch.uint8, device="cuda", generator=g)
+    dxg = (torch.rand(B, G, device="cuda", generator=g) - 0.5)
+    dZb = [H.rows_to_blocked(z) for z in dZ]
+    if a8:
+        dZb[2] = H.relu_gate_image(mask, M)
+    Hb = [H.rows_to_blocked(h) for h in Hc]
+    def run(sel):
+        outs = [(torch.full((G, G), float("nan"), device="cuda"), torch.full((G,), float("nan"), device="cuda")) for _ in sel]
+        ws, parts = H.g_wgrad_blocked([(dZb[j], Hb[j], o[0], o[1]) for j, o in zip(sel, outs)], M, dxg=dxg, rows_per_question=n * n)
+        torch.cuda.synchronize()
+        return outs, [p.clone() for p in parts]
+    all3, parts3 = run([0, 1, 2])
+    again, _ = run([0, 1, 2])
+    dz3 = dxg.double().repeat_interleave(n * n, 0) * gate_image_ref(mask, M)
+    for j in range(3):
+        single, _ = run([j])
+        assert torch.equal(all3[j][0], single[0][0]) and torch.equal(all3[j][1], single[0][1]), j
+        assert torch.equal(all3[j][0], again[j][0]) and torch.equal(all3[j][1], again[j][1]), j
+        dz = dz3 if (a8 and j == 2) else dZ[j].double()
+        eW = rel(all3[j][0].cpu().numpy(), (dz.t() @ Hc[j].double()).cpu().numpy())
+        eb = rel(all3[j][1].cpu().numpy(), dz.sum(0).cpu().numpy())
+        assert eW <= 2e-5 and eb <= 2e-5, (j, eW, eb)
+    Z = H.wgrad_blocked_splits(M, n * n)
+    if Z % B == 0 and (M // 64) % Z == 0:
+        rq = parts3[0].view(B, (Z // B) * 4, G).sum(1)
+        assert rel(rq.cpu().numpy(), dZ[0].double().view(B, n * n, G).sum(1).cpu().numpy()) <= 2e-5
+    # the stand-alone per-question sums of a blocked image
+    Rq = torch.full((B, G), float("nan"), device="cuda")
+    H.blocked_question_sums(dZb[1], Rq, M, n * n)
+    torch.cuda.synchronize()
+    assert rel(Rq.cpu().numpy(), dZ[1].double().view(B, n * n, G).sum(1).cpu().numpy()) <= 2e-5
 
 
 @pytest.mark.parametrize("B", [17, 3])
@@ -622,8 +729,8 @@ def test_chain_bwd_in_chain_pair_reduction(H, B):
 
 
 def test_wgrad_fp8_operand(H):
-    """The activation operand as e4m3 bytes (a_dtype = RN_FP8): every e4m3 value is a bf16 value, so both the plain and the
-    gated streaming kernel must give -- bitwise -- what they give on the same values stored as bf16."""
+    """The activation operand as an e4m3 image (a_dtype = RN_FP8): every e4m3 value is a bf16 value and both images put a pair
+    row into the same MFMA k slot, so the kernel must give -- bitwise -- what it gives on the same values stored as bf16."""
     B, n, G = 17, 64, 256
     M = B * n * n
     g = torch.Generator(device="cuda").manual_seed(11)
@@ -632,24 +739,16 @@ def test_wgrad_fp8_operand(H):
     A16 = A8.float().bfloat16()
     assert torch.equal(A16.float(), A8.float())
     dZ = ((torch.rand(M, G, device="cuda", generator=g) - 0.5) * 1e-2).bfloat16()
+    dZb = H.rows_to_blocked(dZ)
     out = []
     for A in (A16, A8):
         dW = torch.full((G, G), float("nan"), device="cuda"); db = torch.full((G,), float("nan"), device="cuda")
-        H.g_linear_bwd_wgrad(dZ, G, A, G, dW, db, H.RN_BF16, M, G, G, G)
+        H.g_wgrad_blocked([(dZb, H.rows_to_blocked(A), dW, db)], M, rows_per_question=n * n)
         out.append((dW, db))
     torch.cuda.synchronize()
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     ref = dZ.double().t() @ A8.double()
     assert rel(out[1][0].cpu().numpy(), ref.cpu().numpy()) <= 1e-5
-    masks = torch.randint(0, 256, (H.g_chain_rr_mask_bytes(M),), dtype=torch.uint8, device="cuda", generator=g)
-    dxg = (torch.rand(B, G, device="cuda", generator=g) - 0.5)
-    out = []
-    for A in (A16, A8):
-        dW = torch.full((G, G), float("nan"), device="cuda"); db = torch.full((G,), float("nan"), device="cuda")
-        H.g_linear_bwd_wgrad_gated(masks, dxg, n * n, A, G, dW, db, M, G, G)
-        out.append((dW, db))
-    torch.cuda.synchronize()
-    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
 
 
 @pytest.mark.parametrize("B,npairs", [(2, 512), (24, 32 * 100), (16, 144)])
@@ -670,6 +769,7 @@ def test_g_chain_bwd_rr(H, B, npairs):
     dZs = list(torch.full((L, M, G), float("nan"), dtype=torch.bfloat16, device="cuda"))
     H.g_chain_bwd_rr(dev(dxg), masks, Wtf, dZs, M, npairs, G)
     torch.cuda.synchronize()
+    dZs = unblock_h(dZs)                                       # layers 3..1: row-blocked images; layer 0: row-major
     gates = [rr_mask_decode(masks[l], M, l) for l in range(L)]
     got = dZs[0].float().cpu().numpy()
     assert np.array_equal(got, bf16_round(np.repeat(dxg, npairs, axis=0)) * gates[L - 1])
@@ -771,39 +871,27 @@ def test_pair_sum_fwd_bwd(H, code, B, npairs, G):
 
 
 # ----------------------------------------------------------------------------- wgrad
-@pytest.mark.parametrize("no_tr", ["0", "1"])
 @pytest.mark.parametrize("code", [0, 1])
 @pytest.mark.parametrize("M,N,K,Ktrue", [(4096, 256, 192, 180), (576, 512, 320, 270), (5000, 256, 384, 384), (2048, 256, 64, 52),
                                          (64 * 700, 256, 256, 256), (64 * 333, 256, 192, 180)])
-def test_g_linear_bwd_wgrad(H, code, M, N, K, Ktrue, no_tr):
-    """(4096 | 64*700 | 64*333, 256, 256 | 192) in bf16 run the streaming kernel (rn_wgrad.hip), everything else -- and
-    those shapes again under RN_WGRAD_V1=1, the no_tr == "1" leg -- the general one."""
-    if code == 1 and no_tr == "1":
-        pytest.skip("fp32 path has no transpose read")
-    os.environ["RN_WGRAD_NO_TR"] = no_tr
-    os.environ["RN_WGRAD_V1"] = no_tr
-    os.environ["RN_WGRAD_STREAM_192"] = "1"
-    try:
-        dZ = formula.hash_uniform((M, N), 60, -1, 1)
-        A = np.zeros((M, K), np.float32); A[:, :Ktrue] = formula.hash_uniform((M, Ktrue), 61, -1, 1)
-        if code == 0:
-            dZ, A = bf16_round(dZ), bf16_round(A)
-        dW = torch.full((N, Ktrue), 9.0, dtype=torch.float32, device="cuda")
-        db = torch.full((N,), 9.0, dtype=torch.float32, device="cuda")
-        H.g_linear_bwd_wgrad(dev(dZ).to(tdt(code)), N, dev(A).to(tdt(code)), K, dW, db, code, M, N, K, Ktrue)
-        torch.cuda.synchronize()
-        refW = dZ.astype(np.float64).T @ A[:, :Ktrue].astype(np.float64)
-        refb = dZ.sum(0, dtype=np.float64)
-        eW, eb = rel(dW.cpu().numpy(), refW), rel(db.cpu().numpy(), refb)
-        assert eW <= F32_TOL * 5 and eb <= F32_TOL * 5, (eW, eb)
-        # determinism: a second call gives bit-identical results
-        dW2 = torch.empty_like(dW); db2 = torch.empty_like(db)
-        H.g_linear_bwd_wgrad(dev(dZ).to(tdt(code)), N, dev(A).to(tdt(code)), K, dW2, db2, code, M, N, K, Ktrue)
-        assert torch.equal(dW, dW2) and torch.equal(db, db2)
-    finally:
-        os.environ.pop("RN_WGRAD_NO_TR", None)
-        os.environ.pop("RN_WGRAD_V1", None)
-        os.environ.pop("RN_WGRAD_STREAM_192", None)
+def test_g_linear_bwd_wgrad(H, code, M, N, K, Ktrue):
+    """The general weight-gradient kernel on row-major operands (rn_wgrad.hip): bf16 (LDS transpose reads) and fp32."""
+    dZ = formula.hash_uniform((M, N), 60, -1, 1)
+    A = np.zeros((M, K), np.float32); A[:, :Ktrue] = formula.hash_uniform((M, Ktrue), 61, -1, 1)
+    if code == 0:
+        dZ, A = bf16_round(dZ), bf16_round(A)
+    dW = torch.full((N, Ktrue), 9.0, dtype=torch.float32, device="cuda")
+    db = torch.full((N,), 9.0, dtype=torch.float32, device="cuda")
+    H.g_linear_bwd_wgrad(dev(dZ).to(tdt(code)), N, dev(A).to(tdt(code)), K, dW, db, code, M, N, K, Ktrue)
+    torch.cuda.synchronize()
+    refW = dZ.astype(np.float64).T @ A[:, :Ktrue].astype(np.float64)
+    refb = dZ.sum(0, dtype=np.float64)
+    eW, eb = rel(dW.cpu().numpy(), refW), rel(db.cpu().numpy(), refb)
+    assert eW <= F32_TOL * 5 and eb <= F32_TOL * 5, (eW, eb)
+    # determinism: a second call gives bit-identical results
+    dW2 = torch.empty_like(dW); db2 = torch.empty_like(db)
+    H.g_linear_bwd_wgrad(dev(dZ).to(tdt(code)), N, dev(A).to(tdt(code)), K, dW2, db2, code, M, N, K, Ktrue)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
 
 
 @pytest.mark.parametrize("B,n,k,Q,N", [(64, 64, 26, 128, 256), (3, 12, 7, 256, 512), (5, 9, 32, 40, 100)])
@@ -1122,7 +1210,7 @@ def test_e4m3_copies_saturate_instead_of_turning_into_nan(H, f16s):
         assert not bool(((Hs8[l].view(torch.uint8) & 0x7f) == 0x7f).any()), l
     dZ = (torch.rand(M, G, device="cuda") - 0.5).bfloat16()
     dW = torch.empty(G, G, device="cuda"); db = torch.empty(G, device="cuda")
-    H.g_linear_bwd_wgrad(dZ, G, Hs8[0], G, dW, db, H.RN_BF16, M, G, G, G)
+    H.g_wgrad_blocked([(H.rows_to_blocked(dZ), Hs8[0], dW, db)], M)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(dW).all())
     ref = (dZ.double().sum(0) * 448.0)[:, None].expand(G, G)

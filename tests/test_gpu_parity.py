@@ -123,7 +123,12 @@ def test_relational_layer_f16s_parity(pkg, tag):
     e_dx, e_dq = l2rel(dx, g["dx"]), l2rel(dq, g["dq"])
     e_b = max(l2rel(grads[k[5:]], g[k]) for k in g if k.startswith("grad/"))
     agree = float((lp.argmax(1) == g["log_probs"].argmax(1)).mean())
-    report(tag, precision="f16s", log_probs=e_lp, dx_l2=e_dx, dq_l2=e_dq, params_l2=e_b, argmax_agree=agree)
+    # every parameter gradient the fixture pins -- full tensors (grad/), or 64 sampled entries + the norm (gradsample/, gradnorm/:
+    # the full-size fixtures' weight gradients, i.e. what the e4m3 activation copies touch) -- in the max-norm metric of gold.py
+    per = {}
+    e_w = gold.check_grads(g, grads, 3e-2, per)
+    report(tag, precision="f16s", log_probs=e_lp, dx_l2=e_dx, dq_l2=e_dq, params_l2=e_b, argmax_agree=agree, param_grads_max=e_w,
+           g_weight_grads={k: v for k, v in per.items() if k.startswith("g_layers") and k.endswith("weight")})
     assert e_lp <= 2e-4
     assert agree == 1.0
     assert e_dx <= 1.2e-2 and e_dq <= 1.2e-2 and e_b <= 1.2e-2, (e_dx, e_dq, e_b)
@@ -146,23 +151,35 @@ def test_headline_mode_is_the_module_default_and_meets_the_bar(pkg, tag):
 @pytest.mark.parametrize("tag,precision", [("G-fp64", "f16s"), ("G-fp64", "bf16"), ("G-ir64", "f16s")])
 def test_e4m3_activation_copies_touch_only_the_g_weight_gradients(pkg, tag, precision, monkeypatch):
     """The factored-first-layer chains keep H_0..2 for the weight gradient as e4m3 bytes (RN_H8=0: 16-bit copies).  Nothing but
-    dW of g layers 1..3 reads them: log-probs, dx, dq, every bias gradient, the f_phi gradients and dW_0 (pair reductions) must
-    be bitwise those of the 16-bit copies, and the three weight gradients within 3e-3 (relative L2; the error against the fp32
-    reference moves inside the mode's own bf16-class band: reported)."""
+    dW of g layers 1..3 reads them: log-probs, dx, dq, the bias gradients of layers 0..2, the f_phi gradients and dW_0 (pair
+    reductions) must be bitwise those of the 16-bit copies, and the three weight gradients within 3e-3 (relative L2).  The LAST
+    layer's bias gradient moves too (<= 3e-3): with e4m3 copies its gradient matrix is never formed -- the gate job of
+    rn_g_wgrad_blocked scales the gate sums by the un-rounded dxg -- while the 16-bit path stores bf16(dxg) x gate.  The error of
+    every touched tensor against the fp32 reference (sampled entries + norm for the full-size fixtures) is measured and reported,
+    and must stay inside the mode's own band."""
     g = gold.load(tag)
     monkeypatch.setenv("RN_H8", "0")
     lp0, loss0, dx0, dq0, gr0 = run_rl(pkg, g, precision)
     monkeypatch.setenv("RN_H8", "1")
     lp1, loss1, dx1, dq1, gr1 = run_rl(pkg, g, precision)
     assert np.array_equal(lp0, lp1) and np.array_equal(dx0, dx1) and np.array_equal(dq0, dq1)
-    touched = {"g_layers.%d.weight" % l for l in (1, 2, 3)}
+    touched = {"g_layers.%d.weight" % l for l in (1, 2, 3)} | {"g_layers.3.bias"}
     rep = {}
+
+    def ref_err(name, arr):
+        """error against the reference: relative L2 where the fixture keeps the tensor, else worst of (sampled entries, norm)"""
+        if "grad/" + name in g:
+            return l2rel(arr, g["grad/" + name])
+        sub = {k_: v for k_, v in g.items() if k_.endswith("/" + name)}
+        out = {}
+        gold.check_grads(sub, {name: arr}, 1.0, out)
+        return out[name]
     for k in gr0:
         if k in touched:
             d = l2rel(gr1[k], gr0[k])
-            ref = g.get("grad/" + k)                              # (the full-size fixtures keep the bias gradients and norms only)
-            rep[k] = (d, l2rel(gr0[k], ref) if ref is not None else None, l2rel(gr1[k], ref) if ref is not None else None)
+            rep[k] = (d, ref_err(k, gr0[k]), ref_err(k, gr1[k]))
             assert 0 < d <= 3e-3, (k, d)
+            assert rep[k][2] <= max(2.0 * rep[k][1], 4e-3), (k, rep[k])     # e4m3 copies stay in the 16-bit copies' own error class
         else:
             assert np.array_equal(gr0[k], gr1[k]), k
     report(tag, precision=precision, e4m3_vs_16bit={k: v[0] for k, v in rep.items()}, ref_err_16bit={k: v[1] for k, v in rep.items()},

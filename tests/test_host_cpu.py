@@ -40,11 +40,19 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in sorted(dbg_declared):
         assert hasattr(lib, name), "librn_hip.so does not export %s" % name
     loaded = pkg.rn_hip.load()
-    assert loaded.rn_abi_version() == 1
+    # one version number in three places: the header, the library, the binding (bumped whenever a signature or a layout changes)
+    hv = int(re.search(r"#define\s+RN_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "rn_hip.h")).read()).group(1))
+    assert loaded.rn_abi_version() == hv == pkg.rn_hip.ABI_VERSION
     # pure host entry points (no device work) are callable without a GPU
     assert loaded.rn_wgrad_ws_bytes(262144, 256, 256) == (256 * 256 * 256 + 256 * 256) * 4
     assert loaded.rn_wgrad_ws_bytes(100, 100, 256) == 0
     assert loaded.rn_pair_sum_ws_bytes(64, 4096, 256) == 64 * 16 * 256 * 4
+    # row splits of the blocked weight gradient: ~64, question-aligned when the batch allows it
+    assert loaded.rn_wgrad_blocked_splits(64 * 4096, 4096) == 64 and loaded.rn_wgrad_blocked_splits(32 * 4096, 4096) == 64
+    assert loaded.rn_wgrad_blocked_splits(3 * 4096, 4096) == 48 and loaded.rn_wgrad_blocked_splits(128 * 4096, 4096) == 128
+    assert loaded.rn_wgrad_blocked_splits(17 * 4096, 4096) == 34 and loaded.rn_wgrad_blocked_splits(32 * 38416, 38416) == 64
+    assert loaded.rn_wgrad_blocked_splits(2 * 1024, 1024) == 32 and loaded.rn_wgrad_blocked_splits(100, 0) == 0
+    assert loaded.rn_wgrad_blocked_ws_bytes(64 * 4096, 4096, 3) == 3 * (64 * 65536 + 64 * 4 * 256) * 4
 
 
 def test_argument_validation_without_gpu(pkg):

@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
-"""Time rn_g_linear_bwd_wgrad on the headline shape (M = 64 * 4096): general kernel (RN_WGRAD_V1=1) vs streaming kernel."""
+"""Time rn_g_wgrad_blocked on the headline shape (M = 64 * 4096): one stored-gradient job (e4m3 / bf16 activation image), the
+generated-gradient job, the step's three jobs in one launch; and the general row-major kernel for comparison."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
-os.environ["RN_WGRAD_STREAM_192"] = "1"
 import relationnetworks_clevr_amd as pkg
 H = pkg.rn_hip
 H.load()
-M, N = 64 * 4096, 256
+B, n, G = int(os.environ.get("B", 64)), int(os.environ.get("N_OBJ", 64)), 256
+M = B * n * n
 
 
-def timeit(fn, n=10):
-    for _ in range(2):
+def timeit(fn, n=15):
+    for _ in range(3):
         fn()
     ts = []
     for _ in range(n):
@@ -24,19 +25,30 @@ def timeit(fn, n=10):
     return ts[len(ts) // 2]
 
 
-for K, Kt in ((256, 256), (192, 180)):
-    dZ = (torch.rand(M, N, device="cuda") - 0.5).bfloat16()
-    A = (torch.rand(M, K, device="cuda") - 0.5).bfloat16()
-    dW = torch.empty(N, Kt, device="cuda"); db = torch.empty(N, device="cuda")
-    for v1 in ("1", "0"):
-        os.environ["RN_WGRAD_V1"] = v1
-        us = timeit(lambda: H.g_linear_bwd_wgrad(dZ, N, A, K, dW, db, 0, M, N, K, Kt))
-        gb = (M * N + M * K) * 2 / 1e9
-        print("K=%d %s: %7.1f us  (operands %.0f MB -> %.2f TB/s)" % (K, "general  " if v1 == "1" else "streaming", us, gb * 1e3, gb / us * 1e3))
-    os.environ["RN_WGRAD_ABL"] = "1"
-    us = timeit(lambda: H.g_linear_bwd_wgrad(dZ, N, A, K, dW, db, 0, M, N, K, Kt))
-    print("K=%d streaming, stream only: %7.1f us" % (K, us))
-    os.environ["RN_WGRAD_ABL"] = "2"
-    us = timeit(lambda: H.g_linear_bwd_wgrad(dZ, N, A, K, dW, db, 0, M, N, K, Kt))
-    print("K=%d streaming, compute only: %7.1f us" % (K, us))
-    os.environ.pop("RN_WGRAD_ABL")
+dZ = [((torch.rand(M, G, device="cuda") - 0.5) * 1e-2).bfloat16() for _ in range(3)]
+A16 = [(torch.rand(M, G, device="cuda") * 2).bfloat16() for _ in range(3)]
+A8 = [a.to(torch.float8_e4m3fn) for a in A16]
+mask = torch.randint(0, 256, (H.g_chain_rr_mask_bytes(M),), dtype=torch.uint8, device="cuda")
+dxg = torch.rand(B, G, device="cuda") - 0.5
+dW = [torch.empty(G, G, device="cuda") for _ in range(3)]; db = [torch.empty(G, device="cuda") for _ in range(3)]
+gate = H.relu_gate_image(mask, M)
+kw = dict(dxg=dxg, rows_per_question=n * n)
+us = timeit(lambda: H.relu_gate_image(mask, M))
+print("gate image (8 MB masks -> %d MB): %7.1f us" % (M * G / 1e6, us))
+for name, A, z3 in (("e4m3 A", A8, gate), ("bf16 A", A16, dZ[2])):
+    mb = (M * G * 2 + M * G * A[0].element_size()) / 1e6
+    us = timeit(lambda: H.g_wgrad_blocked([(dZ[0], A[0], dW[0], db[0])], M, **kw))
+    print("stored dZ, %s      : %7.1f us  (%.0f MB -> %.2f TB/s)" % (name, us, mb, mb / us))
+    mb = (M * G * z3.element_size() + M * G * A[0].element_size()) / 1e6
+    us = timeit(lambda: H.g_wgrad_blocked([(z3, A[2], dW[2], db[2])], M, **kw))
+    print("last layer (%s), %s: %7.1f us  (%.0f MB -> %.2f TB/s)" % ("gate job" if z3 is gate else "stored", name, us, mb, mb / us))
+    mb = (2 * M * G * 2 + M * G * z3.element_size() + 3 * M * G * A[0].element_size()) / 1e6
+    us = timeit(lambda: H.g_wgrad_blocked([(dZ[0], A[0], dW[0], db[0]), (dZ[1], A[1], dW[1], db[1]), (z3, A[2], dW[2], db[2])], M, **kw))
+    print("three jobs, %s     : %7.1f us  (%.0f MB -> %.2f TB/s; 1.03e11 flop -> %.3f of 2.5 PF)" % (name, us, mb, mb / us, 3 * 2.0 * M * G * G / (us * 1e-6) / 2.5e15))
+us = timeit(lambda: H.g_linear_bwd_wgrad(dZ[0], G, A16[0], G, dW[0], db[0], 0, M, G, G, G))
+print("general row-major kernel: %7.1f us" % us)
+if os.environ.get("RN_DIAG", "0") == "1":
+    for abl, what in ((1, "stream only"), (2, "compute only"), (3, "loop + barriers only"), (66, "compute only, no conversions")):
+        for name, jobs in (("stored, e4m3", [(dZ[0], A8[0], dW[0], db[0])]), ("gate job", [(gate, A8[2], dW[2], db[2])])):
+            us = timeit(lambda: H.g_wgrad_blocked(jobs, M, abl=abl, **kw))
+            print("ABL %3d (%s) %s: %7.1f us" % (abl, what, name, us))
