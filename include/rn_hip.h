@@ -124,13 +124,21 @@ size_t rn_g_chain_rr_mask_bytes(int M);
 int rn_g_chain_fwd_rr(const void* P, int ldp, const void* const* Wf, const float* const* bias, void* const* H,
                       void* const* mask, int K0, float* xg_part, int M, int L, int G, void* stream);
 
-/* f16s forward in the register-resident mapping: P16 (M, ldp) fp16; Whi/Wlo[l]: fragment-major fp16 images of the
- * hi / lo halves of W_l (rn_pack_matrix_frag_many modes 4|natural and 8|natural); every product runs against both
- * (fp32 accumulate), fp16 activations saturate at 65504.  H (bf16 copies) / mask / xg_part as rn_g_chain_fwd_rr;
- * supported output sets: inference (no H), training (H[0..2] + masks + xg_part), all four H without masks. */
+/* f16s forward in the register-resident mapping (the parity-grade fast mode): P16 (M, ldp) fp16, fp16 operand registers
+ * (activations saturate at 65504), fp32 accumulate.
+ *   layer 0:     two MFMA passes, against Whi[0] = fp16(W_0) and Wlo[0] = fp16(W_0 - hi) (fragment-major images,
+ *                rn_pack_matrix_frag_many modes 4 | 1 and 8 | 1);
+ *   layers 1..3: ONE pass on TILE-DITHERED hi images: Whi[l] holds `dither` (1, 2, 4, 8; the module uses 4) images, 65536 fp16
+ *                apart, image d = fp16(W + ((d + 1/2) / dither - 1/2) ulp_fp16(W)) (mode 4 | dither << 8), and 256-row tile t
+ *                multiplies image t mod dither: the weight rounding error no longer has the same sign for all pairs of a
+ *                question and averages out in the pair sum (model.py:151-152) like the activation rounding does.  Wlo[1..3]
+ *                are not read (may be NULL).  Error against the fp32 reference on the released checkpoints: 1.7e-4 / 1.9e-4
+ *                (original-fp / ir-fp; one plain pass: 2.6e-3; the bar is 1e-3).
+ * H (bf16 copies) / mask / xg_part as rn_g_chain_fwd_rr; supported output sets: inference (no H), training (H[0..2] + masks +
+ * xg_part), all four H without masks. */
 /* h_dtype = RN_FP8 (K0 == 192, the two training output sets): H[0..2] receive e4m3 bytes (as rn_g_chain_fwd_rr_f16s_alg0), a stored
  * H[3] stays bf16 (rn_pair_sum_fwd reads it). */
-int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, const void* const* Wlo, const float* const* bias,
+int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, const void* const* Wlo, int dither, const float* const* bias,
                            void* const* H, int h_dtype, void* const* mask, int K0, float* xg_part, int M, int L, int G, void* stream);
 
 /* Backward (pair-sum broadcast + ReLU gates + the three dgrad steps):
@@ -163,7 +171,8 @@ int rn_pack_matrix_frag(const float* src, long sr, long sc, int R, int C, void* 
 
 /* `count` (<= 16) rn_pack_matrix_frag calls in one launch; all arguments are HOST arrays of `count` entries.
  * natural[i] == 2 selects a plain fp32 TRANSPOSE instead: dst (C, R) fp32 row-major = src^T (the f_phi weights);
- * natural[i] == 4 | n / 8 | n (n = 0, 1) write the fp16 hi = fp16(w) / lo = fp16(w - hi) image in K order n. */
+ * natural[i] == 4 | n / 8 | n (n = 0, 1) write the fp16 hi = fp16(w) / lo = fp16(w - hi) image in K order n;
+ * natural[i] == 4 | n | V << 8 (V = 2, 4, 8) writes V tile-dithered hi images, 65536 fp16 apart (see rn_g_chain_fwd_rr_f16s). */
 int rn_pack_matrix_frag_many(const float* const* src, const long* sr, const long* sc, const int* R, const int* C,
                              void* const* dst, const int* natural, int count, void* stream);
 
@@ -418,7 +427,7 @@ int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* co
  * Wf[2] / Whi[2], Wlo[2] hold W_2[:, 0:256] only, bias[2] is ignored.  Needs n*n % 256 == 0. */
 /* h_dtype: the type of the stored H_0..2 rows -- RN_BF16 (M x 256 bf16) or RN_FP8 (M x 256 e4m3 bytes, value = byte value), both as
  * ROW-BLOCKED images (the only reader is rn_g_wgrad_blocked).  Ignored when H is NULL. */
-int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, const void* const* Whi, const void* const* Wlo,
+int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, const void* const* Whi, const void* const* Wlo, int dither,
                                 const float* const* bias, void* const* H, int h_dtype, void* const* mask, float* xg_part,
                                 const float* Vq, int inject_layer, int M, int L, int G, void* stream);
 int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, const void* const* Wf, const float* const* bias, void* const* H,

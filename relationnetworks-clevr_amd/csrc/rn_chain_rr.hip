@@ -257,6 +257,17 @@ __global__ __launch_bounds__(256) void pack_frag_many_kernel(PackMany a) {
   const int kidx = (mode & 1) ? 16 * ks + 8 * h + e : 32 * (ks >> 1) + 4 * h + 8 * (2 * (ks & 1) + (e >> 2)) + (e & 3);
   const float v = (m < a.R[i] && kidx < a.C[i]) ? a.src[i][(long)m * a.sr[i] + (long)kidx * a.sc[i]] : 0.f;
   if (mode & 12) {                                       // fp16 split halves of the f16s mode: hi = fp16(v), lo = fp16(v - hi)
+    const int V = (mode >> 8) & 0xff;
+    if ((mode & 4) && V > 1) {
+      // TILE-DITHERED hi images (layers whose second pass is dropped): image d = RNE(v + ((d + 1/2) / V - 1/2) ulp16(v)).  The
+      // mean of the V roundings is within ulp / (2 V) of v, and the pair sum (model.py:151-152) averages over the 256-row tiles,
+      // each of which multiplies image (tile mod V): the weight rounding error stops being systematic over a question's pairs.
+      const float av = fabsf(v);
+      const int e = av >= 6.103515625e-05f ? ((__builtin_bit_cast(int, av) >> 23) - 127) : -14;     // binade (fp16 subnormals: 2^-14)
+      const float ulp = __builtin_bit_cast(float, (e - 10 + 127) << 23);
+      for (int d = 0; d < V; ++d) reinterpret_cast<f16*>(a.dst[i])[(long)d * RR_G * RR_G + g] = (f16)(v + (((float)d + 0.5f) / (float)V - 0.5f) * ulp);
+      return;
+    }
     const f16 hi = (f16)v;
     reinterpret_cast<f16*>(a.dst[i])[g] = (mode & 4) ? hi : (f16)(v - (float)hi);
   } else {
@@ -639,12 +650,13 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restric
 // g_chain_rr_kernel; a stage is hi | lo = 32 KB (4 ring slots, 3 stages ahead), the stored activation copies and the
 // masks are the bf16 kernel's (the backward pass is shared).
 namespace {
-constexpr int F_STAGE = 32 * 1024, F_NSLOT = 4, F_LA = 3, F_DPW = 32 / RR_NW, F_RDK = 2;
+constexpr int F_STAGE = 32 * 1024, F_NSLOT = 4, F_LA = 3, F_RDK = 2;
 static_assert(F_NSLOT * F_STAGE == RR_NSLOT * RR_STAGE, "same ring bytes");
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 struct RRArgsF {
-  const f16* Whi[RR_L];
-  const f16* Wlo[RR_L];
+  const f16* Whi[RR_L];                                 // layer 0: one image; layers 1..3: vmask + 1 tile-dithered images, 128 KB apart
+  const f16* Wlo[RR_L];                                 // (layer 0 only)
+  int vmask;
   const float* bias[RR_L];
   bf16* out[RR_L];
   u64* mask[RR_L];
@@ -662,8 +674,15 @@ struct F16Vm {
   static constexpr int PF_PER = (NK0 + 7) / 8;
   static constexpr int VC_STAGE = (RR_L - 1) * 8 + 4;                // ALG0: the stage that requests the next tile's bias row
   static constexpr int VQ_STAGE = (RR_L - 1) * 8 + 2;                // INJ: ... and the next tile's question row of layer INJ
+  // Only the fragments a stage's MFMAs read are requested: layer 0 multiplies NK0 of a block's 16 fragments (hi and lo), the
+  // one-pass layers the hi image only (each 1-KB request costs ~100 issue cycles beside the MFMAs: streaming whole 32-KB
+  // stages measured 32 of the kernel's 173 us).
+  static constexpr int nfr(int l) { return l == 0 ? NK0 : 16; }       // fragments per image of a layer-l stage
+  static constexpr int nimg(int l) { return l == 0 ? 2 : 1; }
+  static constexpr int dpw(int l) { return nfr(l) * nimg(l) / RR_NW; }   // requests per wave for a stage of layer l
+  static_assert((NK0 * 2) % RR_NW == 0, "layer-0 requests divide evenly over the waves");
   static constexpr int ops(int sidx) {
-    int k = F_DPW;
+    int k = dpw(((sidx + F_LA) >> 3) & 3);                            // (stage sidx requests the weights of stage sidx + F_LA)
     if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += (H8 && ((sidx - 2) >> 3) < RR_L - 1) ? (((sidx - 2) & 1) ? 2 : 0) : 2;
     if ((sidx >> 3) == RR_L - 1)
       for (int c = 0; c < PF_PER; ++c) k += ((sidx & 7) * PF_PER + c < NK0) ? 1 : 0;
@@ -677,20 +696,27 @@ struct F16Vm {
     int k = 0;
     for (int t = sidx - (F_LA - 2); t < sidx; ++t) k += t >= 0 ? ops(t) : (first ? 0 : ops(t + 8 * RR_L));
     if (sidx < F_LA - 2 && !first) k += tail();
-    if (first && sidx <= F_LA - 2) k += F_DPW * (F_LA - 2 - sidx) + NK0 + (ALG0 ? 1 : 0);
+    if (first && sidx <= F_LA - 2) k += dpw(0) * (F_LA - 2 - sidx) + NK0 + (ALG0 ? 1 : 0);
     return k < 63 ? k : 63;
   }
 };
 }  // namespace
 
 // ALG0: as in g_chain_rr_kernel -- P = the packed fp16 object rows (K = 64), layer-0 bias row = Vc[b*n + i].
-// LO3 = false: the LAST layer runs on the hi halves only (one pass).  Its weight-rounding error is the one contribution the
-// later layers cannot amplify, and measured on the released checkpoints it is immaterial for the question-at-layer-0
-// models: worst log-prob error over 24 questions 1.5e-4 with it off vs 1.2e-4 with it on (tools/dbg/emulate_split2.py;
-// the bar is 1e-3) -- while the layer-2-injected ("IR") models go from 5e-5 to 4e-4 and keep the second pass.
+// Passes.  Layer 0 runs hi + lo (its K = 64 / 192 product is a twelfth .. a quarter of a later layer's).  Layers 1..3 run ONE pass
+// on TILE-DITHERED hi images (rn_pack_matrix_frag_many): tile t multiplies image t mod V, V = 4 roundings of the weights whose
+// mean is within ulp / 8 of the fp32 weight.  What keeps single-pass 16-bit arithmetic at 3e-3 of the fp32 reference is not the
+// size of the weight rounding error (2^-12) but that it is the SAME for all 4096 pairs of a question and survives the pair sum;
+// dithered over the question's tiles it averages out like the activation rounding does.  Measured (CPU emulation of this
+// arithmetic on the released checkpoints, 24 questions, tools/dbg/emulate_lo_sets.py; the bar is 1e-3): hi + lo on layers 0..2
+// (round 2) 1.1e-4 / on all four 5e-5 (ir-fp); one pass everywhere 2.6e-3 / 6.3e-4; THIS scheme 1.7e-4 (original-fp) / 1.9e-4
+// (ir-fp) -- with 448 instead of 704 / 832 MFMAs per wave and tile.
 // H8: as in g_chain_rr_kernel -- the e4m3 copy is converted from the fp16 operand pair the group has just built (clamp + two
 // v_cvt_scalef32_pk_fp8_f16 instead of the separate bf16 rounding).
-template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0, bool LO3 = true, bool H8 = false>
+// ABL (RN_DIAG builds only: timing ablations, WRONG results) -- 1: no bias rows (the block's first MFMA starts from zero), 2: no
+// barriers, 4: no waits for the weight stream, 8: no copy-out (no staging reads, no H stores), 16: no mask stores, 32: no epilogue
+// at all, 64: no weight requests
+template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false, int ABL = 0>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __restrict__ P, int ldp, RRArgsF a,
                                                                 float* __restrict__ xg_part, int ntiles,
                                                                 const float* __restrict__ Vc = nullptr, int n_obj = 0,
@@ -710,11 +736,12 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
     asm volatile("" : "+s"(base));
     return *reinterpret_cast<__attribute__((address_space(1))) const Frag*>(base + prow_off + 32 * ks);
   };
-  // piece q = 4 w + i of a stage: image q / 16 (hi, lo) -- wave-uniform: waves 0..3 fetch hi, 4..7 lo
-  auto dma_piece = [&](int l2, int ob2, int slot, int i) {
-    const int q = F_DPW * w + i;
-    const f16* img = (q >> 4) ? a.Wlo[l2] : a.Whi[l2];
-    k.dma_at(reinterpret_cast<const unsigned char*>(img) + ob2 * RR_STAGE + (q & 15) * 1024, RR_OFF_RING + slot * F_STAGE + q * 1024);
+  // request i of this wave for a stage of layer l2: piece q = dpw w + i of the stage's nimg x nfr fragments -- image q / nfr
+  // (hi, lo; wave-uniform), fragment q % nfr
+  auto dma_piece = [&](int l2, int ob2, int slot, int i, int tile_) {
+    const int q = Vm::dpw(l2) * w + i, im = q / Vm::nfr(l2), fr = q - im * Vm::nfr(l2);
+    const f16* img = l2 == 0 ? (im ? a.Wlo[0] : a.Whi[0]) : a.Whi[l2] + (long)(tile_ & a.vmask) * (RR_G * RR_G);   // (the tile's dithered image)
+    k.dma_at(reinterpret_cast<const unsigned char*>(img) + ob2 * RR_STAGE + fr * 1024, RR_OFF_RING + slot * F_STAGE + im * RR_STAGE + fr * 1024);
   };
   auto rd = [&](int slot, int ks, int p) -> Frag { return k.rd_at(RR_OFF_RING + slot * F_STAGE + p * RR_STAGE + ks * 1024); };
 
@@ -738,7 +765,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
   Frag actA[16], actB[16], ring[F_RDK][2];
   f32x16 acc[2];
   u32x4 co[2];
-  f32x16 cinit;
+  f32x16 cinit = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
@@ -749,7 +776,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
 #pragma unroll
   for (int s = 0; s < F_LA; ++s)
 #pragma unroll
-    for (int i = 0; i < F_DPW; ++i) dma_piece(0, s, s, i);
+    for (int i = 0; i < Vm::dpw(0); ++i) dma_piece(0, s, s, i, tile);
 #pragma unroll
   for (int ks = 0; ks < NK0; ++ks) actA[ks] = load_row_frag(op_row((long)tile * RR_TM + RR_WR * w), ks);
   if constexpr (ALG0) *reinterpret_cast<f32x4*>(vc_s + lane * 4) = vc_load((long)tile * RR_TM + RR_WR * w);
@@ -785,8 +812,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
       }
     };
     auto mask_out = [&](int pl, int pob, int j, float x0, float x1, float x2, float x3) {
-      if constexpr (MASK) mask_store4(a.mask[pl] + (wt * 8 + pob) * 16 + 4 * j, __ballot(x0 > 0.f), __ballot(x1 > 0.f),
-                                      __ballot(x2 > 0.f), __ballot(x3 > 0.f));
+      if constexpr (MASK && !(ABL & 16)) mask_store4(a.mask[pl] + (wt * 8 + pob) * 16 + 4 * j, __ballot(x0 > 0.f), __ballot(x1 > 0.f),
+                                                     __ballot(x2 > 0.f), __ballot(x3 > 0.f));
     };
     // phases of group j: 0 masks, 1 fp16 operand of the next layer, 2 bf16 copy for HBM, 3 staging write
     auto epi_group = [&](int pl, int pob, int j, int ph, Frag* dst, u32x2 (&pk)[4]) {
@@ -856,27 +883,28 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
     auto stage = [&](auto lc, auto obc, Frag (&in)[16], Frag (&out)[16]) {
       constexpr int l = decltype(lc)::value, ob = decltype(obc)::value;
       constexpr int NK = (l == 0) ? NK0 : 16;
-      constexpr int NP = (l == RR_L - 1 && !LO3) ? 1 : 2;              // passes of this stage: hi (+ lo)
+      constexpr int NP = l == 0 ? 2 : 1;                               // passes of this stage: hi (+ lo)
       constexpr int nl = (l * 8 + ob + 1 == 8 * RR_L) ? 0 : (l * 8 + ob + 1) >> 3;   // layer of the next stage
-      constexpr int NPn = (nl == RR_L - 1 && !LO3) ? 1 : 2;
+      constexpr int NPn = nl == 0 ? 2 : 1;
       constexpr int CPG = NP * NK / 4;                                 // MFMA gaps per epilogue group (8 / 6 / 4)
       constexpr int sidx = l * 8 + ob;
       constexpr bool has_prev = sidx > 0;
       constexpr int pl = ob ? l : l - 1, pob = ob ? ob - 1 : 7;
       constexpr int cl = (sidx - 2) >> 3, cob = (sidx - 2) & 7;
-      constexpr bool has_co = STORE && sidx >= 2 && (cl < RR_L - 1 || ST3) && (!H8 || cl == RR_L - 1 || (cob & 1));
+      constexpr bool has_co = !(ABL & 8) && STORE && sidx >= 2 && (cl < RR_L - 1 || ST3) && (!H8 || cl == RR_L - 1 || (cob & 1));
       constexpr int didx = sidx + F_LA;
       constexpr int dl = (didx >> 3) & 3, dob = didx & 7;
       constexpr int slot = ob & 3, nslot = (ob + 1) & 3, dslot = (ob + F_LA) & 3;
-      if (l < RR_L - 1) bias_read(l, ob);
+      if (l < RR_L - 1 && !(ABL & 1)) bias_read(l, ob);
       if (has_prev && pl == RR_L - 1) b3 = bias_s[pl * RR_G + 32 * pob + n];
-      if (Vm::younger(sidx, true) != Vm::younger(sidx, false)) {
+      if (ABL & 4) {
+      } else if (Vm::younger(sidx, true) != Vm::younger(sidx, false)) {
         if (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Vm::younger(sidx, true)) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Vm::younger(sidx, false)) : "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Vm::younger(sidx, false)) : "memory");
       }
-      __builtin_amdgcn_s_barrier();
+      if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (has_co) co_read(cl);
       __builtin_amdgcn_sched_barrier(0);
@@ -906,8 +934,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
             // a one-pass stage in front of a two-pass one (the next tile's first layer): its lo read-ahead rides here
             if (NP == 1 && NPn == 2 && f >= NK) ring[ks % F_RDK][1] = rd(nslot, f - NK, 1);
           }
-          if ((c & 1) && (c >> 1) < F_DPW) dma_piece(dl, dob, dslot, c >> 1);
-          if (has_prev) {
+          if ((c & 1) && (c >> 1) < Vm::dpw(dl) && !(ABL & 64)) dma_piece(dl, dob, dslot, c >> 1, didx >= 8 * RR_L ? tnext : tile);
+          if (has_prev && !(ABL & 32)) {
             const int j = c / CPG, ph = c % CPG;
             if (pl == RR_L - 1) {
               if (ph < 3) epi3_group(pob, j, ph, v);
@@ -1283,6 +1311,10 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
 }
 #undef RN_LAYER
 
+#ifdef RN_DIAG
+static int g_diag_abl = 0;
+extern "C" int rn_diag_set_abl(int v) { g_diag_abl = v; return 0; }
+#endif
 static int rr_prio() {
   const char* e = getenv("RN_RR_PRIO");
   return e ? (e[0] != '0') : RR_PRIO_DEFAULT;
@@ -1404,7 +1436,33 @@ extern "C" int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, co
   return 0;
 }
 
-extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, const void* const* Wlo, const float* const* bias,
+// Shared argument checks of the two f16s entry points: Whi[0] / Wlo[0] = the two fragment-major fp16 images of layer 0,
+// Whi[1..3] = `dither` tile-dithered hi images each (128 KB apart); Wlo[1..3] are not read.
+static int rr_f16s_args(const char* who, RRArgsF& a, const void* const* Whi, const void* const* Wlo, int dither, const float* const* bias,
+                        void* const* H, void* const* mask, int* nh_, int* nm_) {
+  RN_CHECK_ARG(dither == 1 || dither == 2 || dither == 4 || dither == 8, "%s: dither (hi images per layer >= 1) must be 1, 2, 4 or 8 (got %d)", who, dither);
+  memset(&a, 0, sizeof(a));
+  a.prio = rr_prio();
+  a.vmask = dither - 1;
+  int nh = 0, nm = 0;
+  for (int l = 0; l < RR_L; ++l) {
+    RN_CHECK_ARG(Whi[l] && (l > 0 || Wlo[0]) && bias[l], "%s: layer %d weight/bias is NULL", who, l);
+    RN_CHECK_ARG(((uintptr_t)Whi[l] | (uintptr_t)(l == 0 ? Wlo[0] : nullptr) | (uintptr_t)bias[l] | (uintptr_t)(H ? H[l] : nullptr) | (uintptr_t)(mask ? mask[l] : nullptr)) % 16 == 0,
+                 "%s: layer %d pointers must be 16-byte aligned", who, l);
+    a.Whi[l] = (const f16*)Whi[l];
+    a.Wlo[l] = l == 0 ? (const f16*)Wlo[0] : nullptr;
+    a.bias[l] = bias[l];
+    a.out[l] = H ? (bf16*)H[l] : nullptr;
+    a.mask[l] = mask ? (u64*)mask[l] : nullptr;
+    nh += a.out[l] != nullptr;
+    nm += a.mask[l] != nullptr;
+  }
+  *nh_ = nh;
+  *nm_ = nm;
+  return 0;
+}
+
+extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, const void* const* Wlo, int dither, const float* const* bias,
                                       void* const* H, int h_dtype, void* const* mask, int K0, float* xg_part, int M, int L, int G,
                                       void* stream) {
   RN_CHECK_ARG(P16 && Whi && Wlo && bias && M > 0, "rn_g_chain_fwd_rr_f16s: bad pointer/size");
@@ -1415,21 +1473,8 @@ extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* cons
   RN_CHECK_ARG(K0 == 192 || K0 == 256, "rn_g_chain_fwd_rr_f16s: layer-0 reduction length %d unsupported (192 or 256)", K0);
   RN_CHECK_ARG(ldp % 8 == 0 && ldp >= K0 && ((uintptr_t)P16 % 16 == 0), "rn_g_chain_fwd_rr_f16s: bad P layout");
   RRArgsF a;
-  memset(&a, 0, sizeof(a));
-  a.prio = rr_prio();
   int nh = 0, nm = 0;
-  for (int l = 0; l < RR_L; ++l) {
-    RN_CHECK_ARG(Whi[l] && Wlo[l] && bias[l], "rn_g_chain_fwd_rr_f16s: layer %d weight/bias is NULL", l);
-    RN_CHECK_ARG(((uintptr_t)Whi[l] | (uintptr_t)Wlo[l] | (uintptr_t)bias[l] | (uintptr_t)(H ? H[l] : nullptr) | (uintptr_t)(mask ? mask[l] : nullptr)) % 16 == 0,
-                 "rn_g_chain_fwd_rr_f16s: layer %d pointers must be 16-byte aligned", l);
-    a.Whi[l] = (const f16*)Whi[l];
-    a.Wlo[l] = (const f16*)Wlo[l];
-    a.bias[l] = bias[l];
-    a.out[l] = H ? (bf16*)H[l] : nullptr;
-    a.mask[l] = mask ? (u64*)mask[l] : nullptr;
-    nh += a.out[l] != nullptr;
-    nm += a.mask[l] != nullptr;
-  }
+  if (int rc = rr_f16s_args("rn_g_chain_fwd_rr_f16s", a, Whi, Wlo, dither, bias, H, mask, &nh, &nm)) return rc;
   const bool h012 = nh == 3 && !a.out[RR_L - 1] && nm == RR_L;
   RN_CHECK_ARG(nh == 0 || nh == RR_L || h012, "rn_g_chain_fwd_rr_f16s: H must hold none, all, or (with masks) all but the last activation");
   RN_CHECK_ARG(nm == 0 || (nm == RR_L && nh >= 3), "rn_g_chain_fwd_rr_f16s: masks come as a full set together with the stored activations");
@@ -1444,8 +1489,8 @@ extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* cons
   // e4m3 copies of H_0..2 (h_dtype = RN_FP8; a stored H_3 stays bf16): the two training output sets at K0 = 192
   if (h8) {
     RN_CHECK_ARG(K0 == 192 && ((h012 && xg_part) || h0123m), "rn_g_chain_fwd_rr_f16s: e4m3 copies need K0 == 192 and a training output set");
-    if (h0123m) g_chain_rr_f16s_kernel<12, true, true, true, false, false, 0, true, true><<<grid, RR_NT, 0, s>>>(Pp, ldp, a, xg_part, ntiles);
-    else g_chain_rr_f16s_kernel<12, true, false, true, true, false, 0, true, true><<<grid, RR_NT, 0, s>>>(Pp, ldp, a, xg_part, ntiles);
+    if (h0123m) g_chain_rr_f16s_kernel<12, true, true, true, false, false, 0, true><<<grid, RR_NT, 0, s>>>(Pp, ldp, a, xg_part, ntiles);
+    else g_chain_rr_f16s_kernel<12, true, false, true, true, false, 0, true><<<grid, RR_NT, 0, s>>>(Pp, ldp, a, xg_part, ntiles);
     RN_LAUNCH_CHECK("rn_g_chain_fwd_rr_f16s(e4m3 copies)");
     return 0;
   }
@@ -1468,7 +1513,7 @@ extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* cons
 }
 
 // f16s arithmetic on the factored first layer (see g_chain_rr_kernel, ALG0): Xp16 = fp16 object rows (B*n, 64).
-extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, const void* const* Whi, const void* const* Wlo,
+extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, const void* const* Whi, const void* const* Wlo, int dither,
                                            const float* const* bias, void* const* H, int h_dtype, void* const* mask, float* xg_part,
                                            const float* Vq, int inject_layer, int M, int L, int G, void* stream) {
   RN_CHECK_ARG(Xp16 && Vc && Whi && Wlo && bias && M > 0 && xg_part, "rn_g_chain_fwd_rr_f16s_alg0: bad pointer/size");
@@ -1480,42 +1525,28 @@ extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, in
                "rn_g_chain_fwd_rr_f16s_alg0: needs n %% %d == 0 and M a multiple of n*n and of %d (n=%d M=%d)", RR_WR, RR_TM, n, M);
   RN_CHECK_ARG(((uintptr_t)Xp16 | (uintptr_t)Vc) % 16 == 0, "rn_g_chain_fwd_rr_f16s_alg0: tables must be 16-byte aligned");
   RRArgsF a;
-  memset(&a, 0, sizeof(a));
-  a.prio = rr_prio();
   int nh = 0, nm = 0;
-  for (int l = 0; l < RR_L; ++l) {
-    RN_CHECK_ARG(Whi[l] && Wlo[l] && bias[l], "rn_g_chain_fwd_rr_f16s_alg0: layer %d weight/bias is NULL", l);
-    RN_CHECK_ARG(((uintptr_t)Whi[l] | (uintptr_t)Wlo[l] | (uintptr_t)bias[l] | (uintptr_t)(H ? H[l] : nullptr) | (uintptr_t)(mask ? mask[l] : nullptr)) % 16 == 0,
-                 "rn_g_chain_fwd_rr_f16s_alg0: layer %d pointers must be 16-byte aligned", l);
-    a.Whi[l] = (const f16*)Whi[l];
-    a.Wlo[l] = (const f16*)Wlo[l];
-    a.bias[l] = bias[l];
-    a.out[l] = H ? (bf16*)H[l] : nullptr;
-    a.mask[l] = mask ? (u64*)mask[l] : nullptr;
-    nh += a.out[l] != nullptr;
-    nm += a.mask[l] != nullptr;
-  }
+  if (int rc = rr_f16s_args("rn_g_chain_fwd_rr_f16s_alg0", a, Whi, Wlo, dither, bias, H, mask, &nh, &nm)) return rc;
   const bool h012 = nh == 3 && !a.out[RR_L - 1] && nm == RR_L;
   RN_CHECK_ARG((nh == 0 && nm == 0) || h012, "rn_g_chain_fwd_rr_f16s_alg0: H / masks: none (inference) or H_0..2 + all four masks (training)");
   const int ntiles = M / RR_TM;
   const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
   hipStream_t s = (hipStream_t)stream;
   const int rpb = n * n;
+  const f16* Xp = (const f16*)Xp16;
   if (inject_layer == 2) {
-    if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true, 2><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
-    else if (h8) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 2, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
-    else g_chain_rr_f16s_kernel<4, true, false, true, true, true, 2><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
+    if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true, 2><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
+    else if (h8) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 2, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
+    else g_chain_rr_f16s_kernel<4, true, false, true, true, true, 2><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
   } else {
-    const char* l3 = getenv("RN_F16S_LO3");                            // diagnostics: "1" keeps the second pass on the last layer
-    if (l3 && l3[0] == '1') {
-      RN_CHECK_ARG(!(nh && h8), "rn_g_chain_fwd_rr_f16s_alg0: RN_F16S_LO3=1 (diagnostics) keeps bf16 copies only");
-      if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
-      else g_chain_rr_f16s_kernel<4, true, false, true, true, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
-    } else {
-      if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true, 0, false><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
-      else if (h8) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, false, true><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
-      else g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, false><<<grid, RR_NT, 0, s>>>((const f16*)Xp16, 64, a, xg_part, ntiles, Vc, n);
-    }
+    if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n);
+#ifdef RN_DIAG
+#define RN_ABL(v) else if (h8 && g_diag_abl == v) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, true, v><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n);
+    RN_ABL(1) RN_ABL(2) RN_ABL(4) RN_ABL(6) RN_ABL(8) RN_ABL(16) RN_ABL(24) RN_ABL(64)
+#undef RN_ABL
+#endif
+    else if (h8) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n);
+    else g_chain_rr_f16s_kernel<4, true, false, true, true, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n);
   }
   RN_LAUNCH_CHECK("rn_g_chain_fwd_rr_f16s_alg0");
   return 0;

@@ -117,12 +117,16 @@ class PackedWeights:
                 H.pack_matrix(wc, kt, 1, N, kt, wp, code, plan.kpad[l], N)
                 self.fwd.append(wp)
             if rr and split:
-                wh = torch.empty(256 * 256, dtype=torch.float16, device=dev)
-                wl = torch.empty(256 * 256, dtype=torch.float16, device=dev)
-                frag_jobs.append((wc, kt, 1, N, kimg, wh, 4 | int(l == 0)))
-                frag_jobs.append((wc, kt, 1, N, kimg, wl, 8 | int(l == 0)))
+                # f16s on the register-resident chains: layer 0 = hi + lo images (two passes), layers >= 1 = F16S_DITHER
+                # tile-dithered hi images (one pass; include/rn_hip.h, rn_g_chain_fwd_rr_f16s)
+                V = 1 if l == 0 else H.F16S_DITHER
+                wh = torch.empty(V, 256 * 256, dtype=torch.float16, device=dev)
+                frag_jobs.append((wc, kt, 1, N, kimg, wh, 4 | int(l == 0) | ((V << 8) if V > 1 else 0)))
                 self.frag_hi.append(wh)
-                self.frag_lo.append(wl)
+                if l == 0:
+                    wl = torch.empty(256 * 256, dtype=torch.float16, device=dev)
+                    frag_jobs.append((wc, kt, 1, N, kimg, wl, 8 | 1))
+                    self.frag_lo.append(wl)
             elif rr:
                 wf = torch.empty(256 * 256, dtype=dt, device=dev)
                 frag_jobs.append((wc, kt, 1, N, kimg, wf, l == 0))
@@ -288,7 +292,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
                 Hs = [torch.empty(M, G, dtype=_h_copy_dtype(plan, dt, M), device=dev) for l in range(L - 1)] + [None]
                 masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
             part = torch.empty(M // R, G, dtype=torch.float32, device=dev)
-            H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, wfrag[0], wfrag[1], g_b, Hs, masks, part, M, G, Vq=Vq, inject=inj_l)
+            H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, wfrag[0], wfrag[1][0], g_b, Hs, masks, part, M, G, Vq=Vq, inject=inj_l)
             xg = _pair_sum_of(part, B, (n * n) // R, G, lazy_xg)
             if Hs is None:
                 return [None] * L, None, xg
@@ -313,7 +317,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
                 Hs = [torch.empty(M, G, dtype=hdt, device=dev) for l in range(L - 1)] + [None if whole else torch.empty(M, G, dtype=dt, device=dev)]
                 masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
             part = torch.empty(M // R, G, dtype=torch.float32, device=dev) if whole else None
-            H.g_chain_fwd_rr_f16s(P16, ld0, wfrag[0], wfrag[1], g_b, Hs, masks, ld0, part, M, G)
+            H.g_chain_fwd_rr_f16s(P16, ld0, wfrag[0], wfrag[1][0], g_b, Hs, masks, ld0, part, M, G)
             xg = torch.empty(B, G, dtype=torch.float32, device=dev)
             if whole:
                 H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // R, G)

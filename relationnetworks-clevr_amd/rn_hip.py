@@ -35,10 +35,10 @@ SIGNATURES = {
     "rn_g_chain_rr_tile": (_I, []),
     "rn_g_chain_rr_mask_bytes": (_Z, [_I]),
     "rn_g_chain_fwd_rr": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
-    "rn_g_chain_fwd_rr_f16s": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
+    "rn_g_chain_fwd_rr_f16s": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_alg0": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _I, _P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
-    "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_f_phi_fwd_from_partials": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr_reduce": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_chain_reduce_part_bytes": (_Z, [_I, _I]),
@@ -322,29 +322,35 @@ def g_chain_fwd_rr_alg0(Xp, Vc, n, Wfs, biases, Hs, masks, xg_part, M, G, Vq=Non
 
 
 @_timed("g_fwd")
-def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlos, biases, Hs, masks, xg_part, M, G, Vq=None, inject=0):
-    """f16s forward chain with the factored first layer (fp16 object rows, no pair matrix)."""
+def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlo0, biases, Hs, masks, xg_part, M, G, Vq=None, inject=0):
+    """f16s forward chain with the factored first layer (fp16 object rows, no pair matrix).  Whis[0] / Wlo0: the hi / lo images of
+    layer 0; Whis[1..3]: (dither, 65536) fp16 tile-dithered hi images each."""
     L = len(Whis)
+    dither = Whis[1].numel() // 65536
     hp = (C.c_void_p * L)(*[w.data_ptr() for w in Whis])
-    lp = (C.c_void_p * L)(*[w.data_ptr() for w in Wlos])
+    lp = (C.c_void_p * L)(*([Wlo0.data_ptr()] + [None] * (L - 1)))
     bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
     op = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
-    _check(load().rn_g_chain_fwd_rr_f16s_alg0(Xp16.data_ptr(), Vc.data_ptr(), n, hp, lp, bp, op, _h_code(Hs), mp, xg_part.data_ptr(), _ptr(Vq),
+    _check(load().rn_g_chain_fwd_rr_f16s_alg0(Xp16.data_ptr(), Vc.data_ptr(), n, hp, lp, dither, bp, op, _h_code(Hs), mp, xg_part.data_ptr(), _ptr(Vq),
                                               inject, M, L, G, _stream()), "rn_g_chain_fwd_rr_f16s_alg0")
 
 
 @_timed("g_fwd")
-def g_chain_fwd_rr_f16s(P16, ldp, Whis, Wlos, biases, Hs, masks, K0, xg_part, M, G):
-    """f16s forward in the register-resident mapping (fp16 pair matrix, fragment-major hi / lo fp16 weight images)."""
+def g_chain_fwd_rr_f16s(P16, ldp, Whis, Wlo0, biases, Hs, masks, K0, xg_part, M, G):
+    """f16s forward in the register-resident mapping (fp16 pair matrix; weight images as for g_chain_fwd_rr_f16s_alg0)."""
     L = len(Whis)
+    dither = Whis[1].numel() // 65536
     hp = (C.c_void_p * L)(*[w.data_ptr() for w in Whis])
-    lp = (C.c_void_p * L)(*[w.data_ptr() for w in Wlos])
+    lp = (C.c_void_p * L)(*([Wlo0.data_ptr()] + [None] * (L - 1)))
     bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
     op = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
-    _check(load().rn_g_chain_fwd_rr_f16s(P16.data_ptr(), ldp, hp, lp, bp, op, _h_code(Hs[:L - 1] if Hs is not None else None), mp, K0, _ptr(xg_part), M, L, G,
+    _check(load().rn_g_chain_fwd_rr_f16s(P16.data_ptr(), ldp, hp, lp, dither, bp, op, _h_code(Hs[:L - 1] if Hs is not None else None), mp, K0, _ptr(xg_part), M, L, G,
                                          _stream()), "rn_g_chain_fwd_rr_f16s")
+
+
+F16S_DITHER = 4      # tile-dithered hi images per g layer >= 1 (include/rn_hip.h, rn_g_chain_fwd_rr_f16s)
 
 
 def g_chain_rr_mask_bytes(M) -> int:
