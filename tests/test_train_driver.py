@@ -98,24 +98,39 @@ def test_log_lines_parse_with_plot_regexes(T):
     assert m and float(m.group(1)) == 1.5 and "(0%)" not in lines[1] and "[20/40 (50%)]" in lines[1]
 
 
+# (mode, losses rtol, gradient-norm rtol, final-parameter max-norm tol): bounds set from measurement on MI355X, see the docstring
+TRAJ_MODES = {"fp32": ("fp32", "1", 1e-5, 1e-5, 5e-4),             # measured 1.2e-6 / 1.6e-6 / 8.5e-5
+              "headline": ("auto", "1", 5e-4, 2e-3, 1e-2),          # what bench.py times: f16s forward, bf16 backward, e4m3 activation copies;
+              "headline-16bit-copies": ("auto", "0", 5e-4, 2e-3, 1e-2)}      # measured 1.1e-4 / 3.3e-4 / 3.2e-3 (16-bit copies: 8e-5 / 4.6e-4 / 3.2e-3)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", list(TRAJ_MODES))
 @pytest.mark.parametrize("fused_opt", [False, True])
-def test_training_trajectory_matches_reference(T, fused_opt):
+def test_training_trajectory_matches_reference(T, fused_opt, mode, monkeypatch):
     """fused_opt: clip + Adam through rn_clip_adam_step (the trainer's default) instead of torch's clip_grad_norm_ /
     optim.Adam.
     G-traj: 4 reference training steps (Adam 1e-4 / wd 1e-4 / clip 50, train-mode BN, dropout 0) recorded on
-    the CPU reference; the MI355X trainer in fp32 precision must reproduce the losses to 1e-3 and the
-    pre-clip gradient norms to 1e-2 (the first step exactly tests forward + all gradients)."""
+    the CPU reference (/root/reference/train.py:36-48 semantics); the MI355X trainer must reproduce the losses to 1e-3, the
+    pre-clip gradient norms to 1e-2 and the parameters after the four steps to 2e-2 (max-norm) -- in fp32 precision AND in the
+    arithmetic the headline number is timed in (precision "auto" = f16s forward on tile-dithered one-pass weights, bf16
+    backward, e4m3 copies of H_0..2 for the weight gradients; RN_H8=0: 16-bit copies).  The first step tests forward + all
+    gradients from identical parameters, steps 2..4 that the deviations do not compound.  Measured worst deviations are
+    printed (losses / norms / final parameters)."""
     import relationnetworks_clevr_amd as pkg
     from relationnetworks_clevr_amd import dp
+    precision, h8, l_tol, n_tol, p_tol = TRAJ_MODES[mode]
+    monkeypatch.setenv("RN_H8", h8)
     g = gold.load("G-traj")
     meta = g["meta"]
-    hyp = dict(formula.HYP[meta["cfg"]], dropout=0.0, precision="fp32")
+    hyp = dict(formula.HYP[meta["cfg"]], dropout=0.0, precision=precision)
 
     class A:
         qdict_size, adict_size = formula.QDICT, formula.ADICT
 
     m = pkg.RN(A, hyp)
+    if precision == "auto":
+        assert m.rl.resolved_precision(meta["b"], 64, 26) == "f16s"
     shapes = {k: tuple(v) for k, v in json.loads(str(g["state_names"])).items()}
     m.load_state_dict({k: torch.from_numpy(v) for k, v in formula.formula_fill_state(shapes, meta["seed"]).items()}, strict=False)
     m.cuda().train()
@@ -136,12 +151,12 @@ def test_training_trajectory_matches_reference(T, fused_opt):
             norms.append(float(tr.bucket.clip_grad_norm_(50.0)))
             opt.step()
         losses.append(float(loss.detach()))
-    print("losses", losses, "ref", g["losses"].tolist(), "norms", norms, g["grad_norms"].tolist())
-    assert np.allclose(losses, g["losses"], rtol=1e-3)
-    assert np.allclose(norms, g["grad_norms"], rtol=1e-2)
-    for k in g:
-        if k.startswith("final/"):
-            assert gold.rel_err(m.state_dict()[k[6:]].cpu().numpy(), g[k]) <= 2e-2, k
+    e_l = float(np.max(np.abs(np.array(losses) / g["losses"] - 1.0)))
+    e_n = float(np.max(np.abs(np.array(norms) / g["grad_norms"] - 1.0)))
+    e_p = max(gold.rel_err(m.state_dict()[k[6:]].cpu().numpy(), g[k]) for k in g if k.startswith("final/"))
+    print("trajectory[%s, fused_opt=%s]: losses %s (ref %s) worst rel %.2e; grad norms worst rel %.2e; final parameters worst %.2e"
+          % (mode, fused_opt, losses, g["losses"].tolist(), e_l, e_n, e_p))
+    assert e_l <= l_tol and e_n <= n_tol and e_p <= p_tol, (e_l, e_n, e_p)
 
 
 @pytest.mark.gpu
