@@ -230,17 +230,19 @@ int rn_rows_to_blocked(const void* src, void* dst, int dtype, int M, int back, v
  * multiplied with A[j] on the fp8 matrix pipe (exact products), and each question's sums are scaled by its row of dxg
  * (M / rows_per_question, 256) fp32 -- un-rounded, i.e. closer to the fp32 reference than a stored bf16 dZ_3 -- when the
  * question ends; rows_per_question % 64 == 0 then (otherwise it only steers the row splits; 0 = unknown).  M % 64 == 0.
- * Z = rn_wgrad_blocked_splits(M, rows_per_question) row splits (0: shape not covered), chosen so that no split straddles two
- * questions whenever B * d <= 64 for a divisor d of the 64-row steps per question (or 64 < B <= 256).
- * ws: rn_wgrad_blocked_ws_bytes(M, rows_per_question, njobs) bytes.  Afterwards ws holds, at
- * rn_wgrad_blocked_db_partials_offset(M, rows_per_question, njobs, j), (Z, 4, 256) fp32: four partial column sums of dZ[j] over
- * the 64-row steps [z*S/Z, (z+1)*S/Z) (S = M / 64) of split z -- per-question sums of dZ for free when no split straddles two
- * questions.  Deterministic (fixed-order reduction).  dZ / dz_dtype / A / dW / db: HOST arrays. */
-int rn_wgrad_blocked_splits(int M, int rows_per_question);
-size_t rn_wgrad_blocked_ws_bytes(int M, int rows_per_question, int njobs);
-size_t rn_wgrad_blocked_db_partials_offset(int M, int rows_per_question, int njobs, int job);
+ * Z = rn_wgrad_blocked_splits(M, rows_per_question, njobs, aligned) row splits per job (0: shape not covered): about 64 / njobs,
+ * so that the njobs x Z x 4 workgroups of a launch fill the chip once and all jobs stream at the same time; with aligned != 0
+ * a count that never lets a split straddle two questions (Z = B * d for a divisor d of the 64-row steps per question, or B
+ * itself) when one exists within 256.
+ * ws: rn_wgrad_blocked_ws_bytes(M, rows_per_question, njobs, aligned) bytes.  Afterwards ws holds, at
+ * rn_wgrad_blocked_db_partials_offset(M, rows_per_question, njobs, aligned, j), (Z, 4, 256) fp32: four partial column sums of
+ * dZ[j] over the 64-row steps [z*S/Z, (z+1)*S/Z) (S = M / 64) of split z -- per-question sums of dZ for free when the splits
+ * are question-aligned.  Deterministic (fixed-order reduction).  dZ / dz_dtype / A / dW / db: HOST arrays. */
+int rn_wgrad_blocked_splits(int M, int rows_per_question, int njobs, int aligned);
+size_t rn_wgrad_blocked_ws_bytes(int M, int rows_per_question, int njobs, int aligned);
+size_t rn_wgrad_blocked_db_partials_offset(int M, int rows_per_question, int njobs, int aligned, int job);
 int rn_g_wgrad_blocked(const void* const* dZ, const int* dz_dtype, const void* const* A, int a_dtype, const float* dxg,
-                       int rows_per_question, float* const* dW, float* const* db, int njobs, void* ws, int M, void* stream);
+                       int rows_per_question, int aligned, float* const* dW, float* const* db, int njobs, void* ws, int M, void* stream);
 /* The ReLU gate of the last g layer as an e4m3 {0, 1} row-blocked image (M x 256 bytes, byte 0x38 = 1.0) from the layer-3 lane
  * masks of rn_g_chain_fwd_rr* (rn_g_chain_rr_mask_bytes(M) bytes): the dZ operand of a gate job.  M % 32 == 0. */
 int rn_relu_gate_image(const void* mask, void* img, int M, void* stream);

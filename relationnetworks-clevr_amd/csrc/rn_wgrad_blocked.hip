@@ -316,12 +316,12 @@ __device__ __forceinline__ void kb_run(unsigned char* lds, const KbJob& jb_, int
 template <bool A8, int ABL = 0>
 __global__ __launch_bounds__(KB_NT) void wgrad_blocked_kernel(KbArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[KB_LDS_MAX];
-  // XCD-aware decode: consecutive ids round-robin over the 8 XCDs; the NB blocks of one row range share an XCD
-  const int per_job = 8 * KB_NB * ((a.Z + 7) / 8);
-  const int job = blockIdx.x / per_job, id = blockIdx.x - job * per_job;
-  const int xcd = id & 7, slot = id >> 3;
-  const int blk = slot % KB_NB, z = (slot / KB_NB) * 8 + xcd;
-  if (z >= a.Z) return;
+  // XCD-aware decode: consecutive ids round-robin over the 8 XCDs; the NB blocks of one unit (a job's row range) share an XCD,
+  // and the njobs x Z units are dealt out over the XCDs evenly (unit u -> XCD u % 8; jobs interleaved)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int blk = slot % KB_NB, u = (slot / KB_NB) * 8 + xcd;
+  if (u >= a.njobs * a.Z) return;
+  const int job = u % a.njobs, z = u / a.njobs;
   const KbJob& jb = a.job[job];
   if constexpr (A8) {
     if (jb.gate) {
@@ -359,42 +359,48 @@ __global__ __launch_bounds__(256) void wgrad_blocked_reduce_kernel(KbArgs a, int
   }
 }
 
-// Row splits: about 64 (x 4 workgroups = one per CU); when the rows of a question are known, a count that never lets a split
-// straddle two questions (Z = B * d, d | steps per question), so that the db partials are per-question sums of dZ as well.
-int kb_splits(int M, int rows_per_question) {
+// Row splits per job: njobs x Z x 4 workgroups ~ one per CU, all jobs of a launch streaming at the same time -- about 64 / njobs
+// (three jobs: 21 splits each = 252 workgroups that run ONE ring prologue and write ONE 64-KB partial tile each instead of
+// three; 16 MB of partials per step instead of 50).  aligned != 0 (the question-injected layer's backward reads the db partials
+// as per-question sums of dZ): a count that never lets a split straddle two questions -- Z = B * d, d | steps per question, as
+// close to the target as such a count gets, or B itself -- when one exists within 256 splits.
+int kb_splits(int M, int rows_per_question, int njobs, int aligned) {
   const int S = M / 64;
-  if (S < 1) return 0;
-  const int Zd = S >= 64 ? 64 : S;
-  if (rows_per_question <= 0 || rows_per_question % 64 || M % rows_per_question) return Zd;
+  if (S < 1 || njobs < 1) return 0;
+  const int target = 64 / njobs > 0 ? 64 / njobs : 1;
+  const int Zd = S >= target ? target : S;
+  if (!aligned || rows_per_question <= 0 || rows_per_question % 64 || M % rows_per_question) return Zd;
   const int B = M / rows_per_question, spq = rows_per_question / 64;
   if (B > 256) return Zd;
-  if (B > 64) return B;
-  int best = 0;
-  for (int d = 1; d <= spq && B * d <= 64; ++d)
+  if (B >= target) return B;
+  int best = B;
+  for (int d = 1; d <= spq && B * d <= target; ++d)
     if (spq % d == 0) best = B * d;
-  return best >= 16 || best == S ? best : Zd;
+  return best;
 }
 }  // namespace
 
-extern "C" int rn_wgrad_blocked_splits(int M, int rows_per_question) { return (M > 0 && M % 64 == 0) ? kb_splits(M, rows_per_question) : 0; }
+extern "C" int rn_wgrad_blocked_splits(int M, int rows_per_question, int njobs, int aligned) {
+  return (M > 0 && M % 64 == 0 && njobs > 0 && njobs <= KB_MAXJOBS) ? kb_splits(M, rows_per_question, njobs, aligned) : 0;
+}
 
-extern "C" size_t rn_wgrad_blocked_ws_bytes(int M, int rows_per_question, int njobs) {
-  const int Z = rn_wgrad_blocked_splits(M, rows_per_question);
-  if (Z <= 0 || njobs <= 0 || njobs > KB_MAXJOBS) return 0;
+extern "C" size_t rn_wgrad_blocked_ws_bytes(int M, int rows_per_question, int njobs, int aligned) {
+  const int Z = rn_wgrad_blocked_splits(M, rows_per_question, njobs, aligned);
+  if (Z <= 0) return 0;
   return (size_t)njobs * ((size_t)Z * 256 * 256 + (size_t)Z * 4 * 256) * sizeof(float);
 }
 
-extern "C" size_t rn_wgrad_blocked_db_partials_offset(int M, int rows_per_question, int njobs, int job) {
-  const int Z = rn_wgrad_blocked_splits(M, rows_per_question);
-  if (Z <= 0 || job < 0 || job >= njobs || njobs > KB_MAXJOBS) return 0;
+extern "C" size_t rn_wgrad_blocked_db_partials_offset(int M, int rows_per_question, int njobs, int aligned, int job) {
+  const int Z = rn_wgrad_blocked_splits(M, rows_per_question, njobs, aligned);
+  if (Z <= 0 || job < 0 || job >= njobs) return 0;
   return ((size_t)njobs * Z * 256 * 256 + (size_t)job * Z * 4 * 256) * sizeof(float);
 }
 
 static int kb_launch(const void* const* dZ, const int* dz_dtype, const void* const* A, int a_dtype, const float* dxg, int rows_per_question,
-                     float* const* dW, float* const* db, int njobs, void* ws, int M, void* stream, int abl) {
+                     int aligned, float* const* dW, float* const* db, int njobs, void* ws, int M, void* stream, int abl) {
   RN_CHECK_ARG(dZ && dz_dtype && A && dW && db && ws && njobs > 0 && njobs <= KB_MAXJOBS, "rn_g_wgrad_blocked: bad pointer / job count (%d, max %d)", njobs, KB_MAXJOBS);
   RN_CHECK_ARG(a_dtype == RN_BF16 || a_dtype == RN_FP8, "rn_g_wgrad_blocked: A must be bf16 or e4m3 (a_dtype=%d)", a_dtype);
-  const int Z = rn_wgrad_blocked_splits(M, rows_per_question);
+  const int Z = rn_wgrad_blocked_splits(M, rows_per_question, njobs, aligned);
   RN_CHECK_ARG(Z > 0, "rn_g_wgrad_blocked: needs M %% 64 == 0 (M=%d)", M);
   KbArgs a;
   memset(&a, 0, sizeof(a));
@@ -424,7 +430,7 @@ static int kb_launch(const void* const* dZ, const int* dz_dtype, const void* con
     }
   }
   hipStream_t s = (hipStream_t)stream;
-  const int grid = njobs * 8 * KB_NB * cdiv(Z, 8);
+  const int grid = 8 * KB_NB * cdiv(njobs * Z, 8);
 #ifdef RN_DIAG
   switch (abl) {
 #define RN_ABL(v) case v: if (a_dtype == RN_FP8) wgrad_blocked_kernel<true, v><<<grid, KB_NT, 0, s>>>(a); else wgrad_blocked_kernel<false, v><<<grid, KB_NT, 0, s>>>(a); break;
@@ -446,13 +452,13 @@ static int kb_launch(const void* const* dZ, const int* dz_dtype, const void* con
 }
 
 extern "C" int rn_g_wgrad_blocked(const void* const* dZ, const int* dz_dtype, const void* const* A, int a_dtype, const float* dxg,
-                                  int rows_per_question, float* const* dW, float* const* db, int njobs, void* ws, int M, void* stream) {
-  return kb_launch(dZ, dz_dtype, A, a_dtype, dxg, rows_per_question, dW, db, njobs, ws, M, stream, 0);
+                                  int rows_per_question, int aligned, float* const* dW, float* const* db, int njobs, void* ws, int M, void* stream) {
+  return kb_launch(dZ, dz_dtype, A, a_dtype, dxg, rows_per_question, aligned, dW, db, njobs, ws, M, stream, 0);
 }
 #ifdef RN_DIAG
 extern "C" int rn_diag_wgrad_blocked(const void* const* dZ, const int* dz_dtype, const void* const* A, int a_dtype, const float* dxg,
-                                     int rows_per_question, float* const* dW, float* const* db, int njobs, void* ws, int M, void* stream, int abl) {
-  return kb_launch(dZ, dz_dtype, A, a_dtype, dxg, rows_per_question, dW, db, njobs, ws, M, stream, abl);
+                                     int rows_per_question, int aligned, float* const* dW, float* const* db, int njobs, void* ws, int M, void* stream, int abl) {
+  return kb_launch(dZ, dz_dtype, A, a_dtype, dxg, rows_per_question, aligned, dW, db, njobs, ws, M, stream, abl);
 }
 #endif
 

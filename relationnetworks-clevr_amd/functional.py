@@ -655,7 +655,7 @@ class RelationalFunction(torch.autograd.Function):
                     jobs.append((dz_l, a_all[l], tmp, gB[l]))
                 else:
                     jobs.append((dz_l, a_all[l], gW[l], gB[l]))
-            ws_, parts = H.g_wgrad_blocked(jobs, M, dxg=dxg, rows_per_question=n * n)
+            ws_, parts = H.g_wgrad_blocked(jobs, M, dxg=dxg, rows_per_question=n * n, aligned=bool(rq_splits))
             if tmp is not None:
                 l = plan.inject
                 N_, kt_, gp = plan.widths[l], plan.ktrue[l], plan.widths[l - 1]
@@ -683,7 +683,7 @@ class RelationalFunction(torch.autograd.Function):
         # straddles two questions (64 splits: B | 64), else from the pair-reduction kernel
         rq_splits, inj_out = 0, {}
         if inj and rr_bwd and os.environ.get("RN_NO_RQ_FROM_WGRAD", "0") != "1":
-            z_ = H.wgrad_blocked_splits(M, n * n)
+            z_ = H.wgrad_blocked_splits(M, n * n, L - 1, aligned=True)
             if z_ > 0 and z_ % B == 0 and (M // 64) % z_ == 0 and (n * n) % (M // z_) == 0:
                 rq_splits = z_
         # RN_WGRAD_LATE=1 / 2 starts the (HBM-bound) wgrad stream only after the pair reduction / after dx, dq: measured

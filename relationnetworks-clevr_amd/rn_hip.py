@@ -54,11 +54,11 @@ SIGNATURES = {
     "rn_wgrad_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_g_linear_bwd_wgrad": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_rows_to_blocked": (_I, [_P, _P, _I, _I, _I, _P]),
-    "rn_wgrad_blocked_splits": (_I, [_I, _I]),
-    "rn_wgrad_blocked_ws_bytes": (_Z, [_I, _I, _I]),
-    "rn_wgrad_blocked_db_partials_offset": (_Z, [_I, _I, _I, _I]),
+    "rn_wgrad_blocked_splits": (_I, [_I, _I, _I, _I]),
+    "rn_wgrad_blocked_ws_bytes": (_Z, [_I, _I, _I, _I]),
+    "rn_wgrad_blocked_db_partials_offset": (_Z, [_I, _I, _I, _I, _I]),
     "rn_blocked_question_sums": (_I, [_P, _P, _I, _I, _P]),
-    "rn_g_wgrad_blocked": (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P]),
+    "rn_g_wgrad_blocked": (_I, [_P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _I, _P]),
     "rn_relu_gate_image": (_I, [_P, _P, _I, _P]),
     "rn_pair_reduce_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_reduce_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -449,9 +449,9 @@ def g_linear_bwd_wgrad(dZ, lddz, A, lda, dW, db, code, M, N, K, Ktrue):
                                      ws.data_ptr(), code, M, N, K, Ktrue, _stream()), "rn_g_linear_bwd_wgrad")
 
 
-def wgrad_blocked_splits(M, rows_per_question=0):
-    """Row splits of rn_g_wgrad_blocked for M pair rows (0: not covered)."""
-    return load().rn_wgrad_blocked_splits(M, rows_per_question)
+def wgrad_blocked_splits(M, rows_per_question=0, njobs=1, aligned=False):
+    """Row splits per job of an rn_g_wgrad_blocked launch of `njobs` jobs on M pair rows (0: not covered)."""
+    return load().rn_wgrad_blocked_splits(M, rows_per_question, njobs, int(aligned))
 
 
 @_timed("pair_reduce")
@@ -477,13 +477,14 @@ def relu_gate_image(mask, M):
 
 
 @_timed("g_wgrad")
-def g_wgrad_blocked(jobs, M, dxg=None, rows_per_question=0, abl=0):
+def g_wgrad_blocked(jobs, M, dxg=None, rows_per_question=0, aligned=False, abl=0):
     """Weight gradients of the 256-wide g layers on the chains' row-blocked images, one launch for all `jobs`:
     jobs = [(dZ, A, dW, db), ...]; a job whose dZ is an e4m3 image is a gate job (the last layer: gate image x dxg per question).
+    aligned: question-aligned row splits (the db partials are then per-question sums of dZ).
     -> (ws, [db partials (Z, 4, 256) per job]): the workspace must stay alive while the partials are in use."""
     lib = load()
     nj = len(jobs)
-    nb = lib.rn_wgrad_blocked_ws_bytes(M, rows_per_question, nj)
+    nb = lib.rn_wgrad_blocked_ws_bytes(M, rows_per_question, nj, int(aligned))
     if nb == 0:
         raise RuntimeError("rn_g_wgrad_blocked: unsupported shape M=%d, %d jobs" % (M, nj))
     a8 = jobs[0][1].dtype in FP8_DTYPES
@@ -493,17 +494,17 @@ def g_wgrad_blocked(jobs, M, dxg=None, rows_per_question=0, abl=0):
     ap = (C.c_void_p * nj)(*[j[1].data_ptr() for j in jobs])
     wp = (C.c_void_p * nj)(*[j[2].data_ptr() for j in jobs])
     bp = (C.c_void_p * nj)(*[j[3].data_ptr() for j in jobs])
-    args = (zp, zt, ap, RN_FP8 if a8 else RN_BF16, _ptr(dxg), rows_per_question, wp, bp, nj, ws.data_ptr(), M, _stream())
+    args = (zp, zt, ap, RN_FP8 if a8 else RN_BF16, _ptr(dxg), rows_per_question, int(aligned), wp, bp, nj, ws.data_ptr(), M, _stream())
     if abl:                                                   # RN_DIAG builds only (tools/): timing ablations, wrong results
         fn = lib.rn_diag_wgrad_blocked
         fn.restype, fn.argtypes = _I, SIGNATURES["rn_g_wgrad_blocked"][1] + [_I]
         _check(fn(*args, abl), "rn_diag_wgrad_blocked")
     else:
         _check(lib.rn_g_wgrad_blocked(*args), "rn_g_wgrad_blocked")
-    Z = lib.rn_wgrad_blocked_splits(M, rows_per_question)
+    Z = lib.rn_wgrad_blocked_splits(M, rows_per_question, nj, int(aligned))
     parts = []
     for j in range(nj):
-        off = lib.rn_wgrad_blocked_db_partials_offset(M, rows_per_question, nj, j) // 4
+        off = lib.rn_wgrad_blocked_db_partials_offset(M, rows_per_question, nj, int(aligned), j) // 4
         parts.append(ws.view(torch.float32)[off: off + Z * 4 * 256].view(Z, 4, 256))
     return ws, parts
 

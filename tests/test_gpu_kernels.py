@@ -706,23 +706,26 @@ def test_wgrad_blocked_three_jobs(H, B, n, a8):
     if a8:
         dZb[2] = H.relu_gate_image(mask, M)
     Hb = [H.rows_to_blocked(h) for h in Hc]
-    def run(sel):
+    def run(sel, aligned=True):
         outs = [(torch.full((G, G), float("nan"), device="cuda"), torch.full((G,), float("nan"), device="cuda")) for _ in sel]
-        ws, parts = H.g_wgrad_blocked([(dZb[j], Hb[j], o[0], o[1]) for j, o in zip(sel, outs)], M, dxg=dxg, rows_per_question=n * n)
+        ws, parts = H.g_wgrad_blocked([(dZb[j], Hb[j], o[0], o[1]) for j, o in zip(sel, outs)], M, dxg=dxg, rows_per_question=n * n, aligned=aligned)
         torch.cuda.synchronize()
         return outs, [p.clone() for p in parts]
     all3, parts3 = run([0, 1, 2])
     again, _ = run([0, 1, 2])
     dz3 = dxg.double().repeat_interleave(n * n, 0) * gate_image_ref(mask, M)
+    Z = H.wgrad_blocked_splits(M, n * n, 3, aligned=True)
+    free3, _ = run([0, 1, 2], aligned=False)                   # ~64 / 3 splits per job, not question-aligned: same sums, other order
     for j in range(3):
-        single, _ = run([j])
-        assert torch.equal(all3[j][0], single[0][0]) and torch.equal(all3[j][1], single[0][1]), j
         assert torch.equal(all3[j][0], again[j][0]) and torch.equal(all3[j][1], again[j][1]), j
+        assert rel(free3[j][0].cpu().numpy(), all3[j][0].cpu().numpy()) <= 2e-5 and rel(free3[j][1].cpu().numpy(), all3[j][1].cpu().numpy()) <= 2e-5, j
+        if H.wgrad_blocked_splits(M, n * n, 1, aligned=True) == Z:       # (same splits alone and in the launch of three: bitwise)
+            single, _ = run([j])
+            assert torch.equal(all3[j][0], single[0][0]) and torch.equal(all3[j][1], single[0][1]), j
         dz = dz3 if (a8 and j == 2) else dZ[j].double()
         eW = rel(all3[j][0].cpu().numpy(), (dz.t() @ Hc[j].double()).cpu().numpy())
         eb = rel(all3[j][1].cpu().numpy(), dz.sum(0).cpu().numpy())
         assert eW <= 2e-5 and eb <= 2e-5, (j, eW, eb)
-    Z = H.wgrad_blocked_splits(M, n * n)
     if Z % B == 0 and (M // 64) % Z == 0:
         rq = parts3[0].view(B, (Z // B) * 4, G).sum(1)
         assert rel(rq.cpu().numpy(), dZ[0].double().view(B, n * n, G).sum(1).cpu().numpy()) <= 2e-5

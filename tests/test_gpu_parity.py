@@ -224,7 +224,9 @@ def test_in_chain_pair_reduction_end_to_end(pkg, tag, monkeypatch):
 def test_injected_layer_question_sums_from_the_wgrad_partials(pkg, monkeypatch):
     """ir-*: the per-question sums of the injected layer's gradient (Rq -> dq and the question columns of dW_2) come from the
     streaming wgrad kernel's per-split column sums instead of a pair-reduction pass over dZ_2 (RN_NO_RQ_FROM_WGRAD=1): the same
-    bf16 values added in fp32 in another order -- everything agrees to fp32 rounding, the rest bitwise."""
+    bf16 values added in fp32 in another order -- everything agrees to fp32 rounding; what the blocked weight-gradient launch does
+    not produce is bitwise the same (its row splits are question-aligned only when Rq is taken from them: other summation order
+    for dW / db of layers 1..3)."""
     g = gold.load("G-ir64")
     monkeypatch.setenv("RN_NO_RQ_FROM_WGRAD", "1")
     lp0, loss0, dx0, dq0, gr0 = run_rl(pkg, g, "f16s")
@@ -233,9 +235,10 @@ def test_injected_layer_question_sums_from_the_wgrad_partials(pkg, monkeypatch):
     assert np.array_equal(lp0, lp1) and np.array_equal(dx0, dx1)
     assert 0 < l2rel(dq1, dq0) <= 1e-5
     for k in gr0:
-        if k == "g_layers.2.weight":
-            assert np.array_equal(gr0[k][:, :256], gr1[k][:, :256])
-            assert 0 < l2rel(gr1[k][:, 256:], gr0[k][:, 256:]) <= 1e-5
+        if k.startswith("g_layers.") and not k.startswith("g_layers.0."):
+            assert l2rel(gr1[k], gr0[k]) <= 1e-5, k
+            if k == "g_layers.2.weight":
+                assert 0 < l2rel(gr1[k][:, 256:], gr0[k][:, 256:]) <= 1e-5
         else:
             assert np.array_equal(gr0[k], gr1[k]), k
 
