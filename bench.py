@@ -328,12 +328,28 @@ def main():
     # ---- timed region: W warm-up steps, then exactly K steps, barrier + synchronize on both sides
     H.TIMER.enabled = False
     dt, loss = timed_steps(lambda: trainer.step(img, qst, lab), args.steps, args.warmup, sync)
+    comm = None
+    if world > 1:
+        # attribution (outside the timed region): K more steps with event brackets around the gradient all-reduce and the fused
+        # 1/world + clip + Adam -- the only parts of a step that exist because of the other ranks
+        trainer.timing = []
+        for _ in range(args.steps):
+            trainer.step(img, qst, lab)
+        torch.cuda.synchronize()
+        ar = sorted(e[0].elapsed_time(e[1]) for e in trainer.timing)
+        op = sorted(e[1].elapsed_time(e[2]) for e in trainer.timing)
+        trainer.timing = None
+        comm = {"allreduce_us_per_step": 1e3 * ar[len(ar) // 2], "optimizer_us_per_step": 1e3 * op[len(op) // 2],
+                "allreduce_bytes": 4 * trainer.bucket.numel}
+        for k_ in ("allreduce_us_per_step", "optimizer_us_per_step"):      # the slowest rank's
+            comm[k_] = max_over_ranks(comm[k_], world, dev)
     ksum_step = ksum = None
     if not args.no_kernel_timing:
         # HIP events cannot bracket kernels inside a graph replay: the same K steps are repeated eagerly (same kernels, same
         # shapes, same streams) with event brackets on the launch stream -- once as the step runs them (wgrads on the side
         # stream beside the pair reduction: `in_step`), once with that overlap off so that every kernel's duration is its own
         trainer.use_graph = False
+        overlap_default = pkg.options.OPT.wgrad_overlap
         # Eager launches are host-bound (~110 launches per step): with an idle GPU a bracket would also measure the host's
         # launch latency.  A one-thread spin kernel (torch.cuda._sleep) in front of every step keeps the GPU ~3 ms behind the
         # host, so the whole step is queued before it starts and a bracket spans GPU time only.
@@ -342,7 +358,7 @@ def main():
         spin = int(1000000 * 3.0 / max(e0.elapsed_time(e1), 1e-3))
         for tag in ("in_step", "alone"):
             if tag == "alone":
-                os.environ["RN_NO_WGRAD_OVERLAP"] = "1"
+                pkg.options.OPT.wgrad_overlap = False
             trainer.step(img, qst, lab)
             H.TIMER.enabled = True
             H.TIMER.reset()
@@ -354,7 +370,7 @@ def main():
                 ksum_step = H.TIMER.summary()
             else:
                 ksum = H.TIMER.summary()
-                os.environ.pop("RN_NO_WGRAD_OVERLAP", None)
+                pkg.options.OPT.wgrad_overlap = overlap_default
         trainer.use_graph = use_graph
     dt = max_over_ranks(dt, world, dev)
     if not torch.isfinite(loss).item():
@@ -373,12 +389,15 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "precision_requested": args.precision, "precision_resolved": prec,
                        "wgrad_activation_copies": ("e4m3 (H_0..2 kept for dW_1..3 only; RN_H8=0: 16-bit)"
-                                                   if prec in ("bf16", "f16s") and os.environ.get("RN_H8", "1") != "0" else "as the mode's storage type"),
+                                                   if prec in ("bf16", "f16s") and pkg.options.OPT.h8 else "as the mode's storage type"),
+                       "options_non_default": pkg.options.OPT.non_default(),
                        "launch": ("eager" if not use_graph else
                                   "one hipGraph replay per step: fwd + bwd + clip + Adam" if getattr(trainer, "_opt_in_graph", False) else
                                   "hipGraph replay of fwd+bwd, eager all-reduce/clip/Adam")},
             "loss": float(loss.detach()),
         }
+        if comm:
+            out.update(comm)
         if world == 1 and not args.no_parity:
             out["parity"] = parity_check(pkg, args.config, prec)
         if ksum:

@@ -151,17 +151,6 @@ int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, con
  * value dividing M). */
 int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M,
                       int rows_per_question, int L, int G, void* stream);
-/* ... with the pair reduction of the FIRST layer's gradient done on chip (n == 64 objects, rows_per_question = n*n): dZ[3] is
- * never formed in memory (pass NULL; dZ[0] NULL too: the gate job of rn_g_wgrad_blocked replaces it).  Per 256-row tile (4 i x 64 j)
- * the kernel leaves rj_part (rn_chain_reduce_part_bytes(M, 0) bytes: the fp32 sum over the tile's 4 i) and per 32-row block
- * ri_part (rn_chain_reduce_part_bytes(M, 1): column sums of its two 16-row halves); rn_pair_reduce_from_chain adds them into
- *   Rj[b,j,:] = sum_i dZ_0[(b,i,j),:]   Ri[b,i,:] = sum_j dZ_0[(b,i,j),:]   Rq[b,:] = sum_ij      (fp32; (B*n, 256), (B, 256))
- * -- what rn_pair_reduce_bwd computes from a stored dZ_0, here from the un-rounded fp32 values.  Deterministic. */
-size_t rn_chain_reduce_part_bytes(int M, int which);
-int rn_g_chain_bwd_rr_reduce(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, float* rj_part,
-                             float* ri_part, int n, int M, int L, int G, void* stream);
-int rn_pair_reduce_from_chain(const float* rj_part, const float* ri_part, float* Rj, float* Ri, float* Rq, int B, int n, int G,
-                              void* stream);
 /* MFMA-fragment-major weight image for rn_g_chain_fwd_rr: dst (65536 bf16) gets, for output block ob,
  * K16 step ks, lane, element e:  src[32 ob + lane % 32][kidx] (0 beyond R rows / C columns) with
  *   natural != 0:  kidx = 16 ks + 8 (lane / 32) + e

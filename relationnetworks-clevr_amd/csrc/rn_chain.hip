@@ -28,8 +28,6 @@
 // The end-of-slab barrier waits with a COUNTED vmcnt (only the slab's own loads; younger tile stores
 // and the next tile's source prefetch stay in flight) and a raw s_barrier.
 // The next tile's source rows (P / H_L) are prefetched into registers during the last slab.
-#include <stdlib.h>
-
 #include "rn_common.h"
 
 namespace {
@@ -420,7 +418,7 @@ static int num_cus() {
   return n;
 }
 static bool env_on(const char* name, bool dflt) {
-  const char* e = getenv(name);
+  const char* e = rn_diag_env(name);
   if (!e || !e[0]) return dflt;
   return e[0] != '0';
 }
@@ -430,7 +428,7 @@ static void chain_launch(int grid, hipStream_t s, const void* P, int ldp, const 
                          int ntiles) {
   const bool gl = env_on("RN_CHAIN_GLDS", true);            // RN_CHAIN_GLDS=0: register-staged weight slabs
   const bool pf = env_on("RN_CHAIN_PREFETCH", true);        // RN_CHAIN_PREFETCH=0: no next-tile source prefetch
-  const char* re = getenv("RN_CHAIN_RDEPTH");               // fragment read-ahead in K16 steps: 1 (default), 2 or 4
+  const char* re = rn_diag_env("RN_CHAIN_RDEPTH");               // fragment read-ahead in K16 steps: 1 (default), 2 or 4
   const int rd = re ? atoi(re) : 1;                          // measured: 1 -> 272 us, 2 -> 287 us, 4 -> 340 us (lock-step phases)
 #define RN_GO(G, PFV, R) g_chain_kernel<MODE, PREC_BF16, G, PFV, R><<<grid, CT_NT, 0, s>>>(P, ldp, a, L, xg_part, ntiles, g_trace)
   if (!gl) RN_GO(false, true, 1);

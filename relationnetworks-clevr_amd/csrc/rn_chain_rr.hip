@@ -22,8 +22,6 @@
 //   pair sum:  the LAST layer runs with the operands un-swapped, D[row][feature]: a lane then owns one feature
 //              of 16 rows and the pair sum is an in-lane fp32 add of the un-rounded activations; one partial
 //              row per wave (32 pair rows) goes to xg_part.
-#include <stdlib.h>
-
 #include "rn_common.h"
 
 namespace {
@@ -69,8 +67,6 @@ struct RRBwdArgs {                                      // the per-layer buffers
   const float* dxg;                                     // (B, 256) fp32
   int rows_per_b;
   int prio;
-  float* rj_part;                                       // RED: per tile, sum over the tile's 4 i of dZ_0 -- [tile][ob 8][jg 4][64 rows j][8 features] fp32
-  float* ri_part;                                       // RED: per wave and 16-row half, column sums of dZ_0 -- [32-row block][half 2][256] fp32
 };
 typedef __attribute__((ext_vector_type(16))) unsigned u32x16;
 // 16 lane masks (32 dwords) -> SGPRs.  Inline asm: a compiler-visible scalar load would make every LDS wait a
@@ -1025,18 +1021,13 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
 // ================================================================================================== backward
 // dZ[0] = dxg[b] * (H_3 > 0);  dZ[s+1] = (dZ[s] @ W_{3-s}) * (H_{2-s} > 0), s = 0..2 -- the ReLU gates come from the
 // forward kernel's lane masks (32 bytes per pair row and layer instead of a 512-byte activation row).
-// SKIP0: dZ[0] (the last layer's gradient) is not copied to HBM -- rn_g_linear_bwd_wgrad_gated rebuilds it from the
-// masks and dxg, the only consumer besides this kernel's own first step.
-// RED (64 objects: a tile is 4 i x 64 j, a wave one (i, half of the j)): the LAST gradient, dZ of layer 0, is not written
-// either.  Its only readers are the pair reductions Rj = sum_i, Ri = sum_j, Rq = sum_ij (model.py:116-127 backward), so each
-// 32-feature block goes, gated but un-rounded fp32, into LDS (the 32 KB in front of the weight ring: bias / Vc tables this
-// kernel does not use + the staging the earlier steps are done with by then), and two stages later
-//   * every wave adds one quarter of the block (8 features) over the tile's four i: 16 KB per tile and block leave as
-//     Rj partials instead of 16 KB of bf16 rows -- but 1/16 of them per (question, j) remain to be added, not 64;
-//   * every lane adds 16 rows of one feature of its own wave's block: the Ri partials (two halves x two waves per (b, i)).
-// rn_pair_reduce_from_chain finishes both (72 MB read instead of the 134 MB dZ_0 pass, which also is not written).
-// One more barrier per stage of the last step (behind the reads, in front of the next block's LDS writes).
-template <int ABL, bool SKIP0 = false, bool RED = false>
+// SKIP0: dZ[0] (the last layer's gradient) is not copied to HBM -- the gate job of rn_g_wgrad_blocked works from the masks and
+// dxg instead, its only consumer besides this kernel's own first step.
+// ABL (RN_DIAG builds only): timing ablations with wrong results.
+// (Round 2 also had the pair reduction of the LAST gradient, dZ of layer 0, inside this kernel -- every block through LDS in
+// fp32, added over the tile's four i and each wave's 32 j: 268 MB less HBM traffic, but the exchange made the last step
+// LDS-bound (+24 us here for -40 us in rn_pair_reduce_bwd) and the step gained 1 %: removed in round 3.)
+template <int ABL, bool SKIP0 = false>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int ntiles) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
@@ -1095,39 +1086,6 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
       if (ABL & 64) *reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2) = co[q];
       else __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2));
     };
-    // ---- RED: the last step's blocks through LDS (16-byte chunk c of row r sits at chunk position c ^ (r % 8): conflict-free
-    // for the row-per-lane b128 writes and for both read patterns)
-    unsigned char* const red = lds;                                   // [wave 8][row 32][32 features] fp32
-    const int i_l = w >> 1, jh = w & 1;
-    auto red_write = [&](int j, const float (&x)[4]) {
-      const f32x4 v = {x[0], x[1], x[2], x[3]};
-      *reinterpret_cast<f32x4*>(red + w * 4096 + n * 128 + (((2 * j + h) ^ (n & 7)) * 16)) = v;
-    };
-    auto red_read = [&](f32x4 (&rj)[4], float (&rv)[16]) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)                                      // features 8 i_l + 4 h + {0..3} of row n, waves (q, jh)
-        rj[q] = *reinterpret_cast<const f32x4*>(red + (2 * q + jh) * 4096 + n * 128 + (((2 * i_l + h) ^ (n & 7)) * 16));
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {                                   // feature n of rows 16 h + r, this wave's block
-        const int R = 16 * h + r;
-        rv[r] = *reinterpret_cast<const float*>(red + w * 4096 + R * 128 + (((n >> 2) ^ (R & 7)) * 16) + (n & 3) * 4);
-      }
-    };
-    const unsigned rj_lane = (unsigned)(((jh * 32 + n) * 8 + h * 4) * 4);
-    auto red_store_rj = [&](int cob, const f32x4 (&rj)[4]) {
-      const f32x4 sj = ((rj[0] + rj[1]) + rj[2]) + rj[3];
-      gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.rj_part + ((((long)tile * 8 + cob) * 4 + i_l) * 512));
-      asm volatile("" : "+s"(base));
-      __builtin_nontemporal_store(sj, reinterpret_cast<__attribute__((address_space(1))) f32x4*>(base + rj_lane));
-    };
-    auto red_store_ri = [&](int cob, const float (&rv)[16]) {
-      float si = rv[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) si += rv[r];
-      gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.ri_part + ((wt * 2) * RR_G + 32 * cob));
-      asm volatile("" : "+s"(base));
-      __builtin_nontemporal_store(si, reinterpret_cast<__attribute__((address_space(1))) float*>(base + (unsigned)((h * RR_G + n) * 4)));
-    };
     // ---- prologue: dZ[0] in operand layout (natural feature order) + its copy to HBM
     if (ABL & 1) {
 #pragma unroll
@@ -1168,8 +1126,6 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
       constexpr int ps = ob ? s : s - 1, pob = ob ? ob - 1 : 7;       // block whose epilogue runs here
       constexpr int cs = (sidx - 2) >> 3, cob = (sidx - 2) & 7;       // block copied out here
       constexpr bool has_co = sidx >= 2;
-      constexpr bool red_epi = RED && has_prev && ps == NS - 1;       // the previous block is one of the last step: -> LDS, fp32
-      constexpr bool red_co = RED && has_co && cs == NS - 1;          // ... and the one before it is reduced here instead of copied out
       constexpr int didx = sidx + RR_LA;
       constexpr int dl = (didx >> 3) % NS, dob = didx & 7;
       constexpr int nob = (sidx + 1) & 7;
@@ -1179,8 +1135,6 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
       u32x16(&gp)[2] = (sidx & 1) ? gA : gB;
       if (has_prev && !(ABL & 2)) mask_wait(gp[0], gp[1]);
       if (!(ABL & 2)) mask_load(a.mask + (NS - 1 - s) * a.mask_stride + (wt * 8 + ob) * 16, gn[0], gn[1]);
-      // RED: the previous stage's LDS writes (a last-step block) are read by OTHER waves right behind this barrier
-      if constexpr (red_co) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (ABL & 16) {                                                 // timing only: 16 more operations may stay in flight (a race)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BwdVm<SKIP0>::younger(sidx) + 16 < 63 ? BwdVm<SKIP0>::younger(sidx) + 16 : 63) : "memory");
         __builtin_amdgcn_s_barrier();
@@ -1189,10 +1143,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
         __builtin_amdgcn_s_barrier();
       }
       asm volatile("" ::: "memory");
-      f32x4 rj[4];
-      float rv[16];
-      if constexpr (red_co) red_read(rj, rv);
-      else if (has_co) co_read(cs + 1);
+      if (has_co) co_read(cs + 1);
       __builtin_amdgcn_sched_barrier(0);
       Frag* dst = nullptr;
       if (has_prev && ps < NS - 1) dst = ob ? out : in;
@@ -1214,23 +1165,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
           else ring[ks % RR_RD] = k.rd_frag(nob, f - 16);
         }
         if ((c & 1) && (c >> 1) < RR_DPW) k.dma_piece(a.W + dl * a.w_stride, dob, dob, c >> 1);
-        if constexpr (red_epi) {
-          // the reductions of the block before the previous one in gaps 3 and 4, then every wave's reads of it are complete
-          // (barrier) before the previous block overwrites it: gate in gap 6 + 2 j, LDS write in gap 7 + 2 j
-          if (c == 5) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-          }
-          if (c >= 6 && c < 14) {
-            const int j = (c - 6) >> 1;
-            if (((c - 6) & 1) == 0) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) x[j][r] = ((ABL & 2) || gate_bit(gp[0], gp[1], 4 * j + r)) ? acc[pob & 1][4 * j + r] : 0.f;
-            } else {
-              red_write(j, x[j]);
-            }
-          }
-        } else if (has_prev && c >= 2 && c < 14) {                    // epilogue of the previous block, 3 gaps per group
+        if (has_prev && c >= 2 && c < 14) {                           // epilogue of the previous block, 3 gaps per group
           const int j = (c - 2) / 3, ph = (c - 2) % 3;
           if (ph == 0) {
 #pragma unroll
@@ -1247,10 +1182,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
             }
           }
         }
-        if constexpr (red_co) {
-          if (c == 3) red_store_rj(cob, rj);
-          if (c == 4) red_store_ri(cob, rv);
-        } else if (has_co && (c == 4 || c == 8)) {
+        if (has_co && (c == 4 || c == 8)) {
           co_store(cs + 1, cob, (c >> 2) - 1);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1260,32 +1192,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
     RN_LAYER(1, actB, actA);
     RN_LAYER(2, actA, actB);
     // ---- tail: blocks (2, 6) and (2, 7)
-    if constexpr (RED) {
-      f32x4 rj[4];
-      float rv[16];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                   // block (2, 6) is in LDS, every wave's part of it
-      red_read(rj, rv);
-      red_store_rj(6, rj);
-      red_store_ri(6, rv);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                   // ... and has been read
-      u32x16(&gp)[2] = ((NS * 8 - 1) & 1) ? gB : gA;
-      if (!(ABL & 2)) mask_wait(gp[0], gp[1]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float x[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = ((ABL & 2) || gate_bit(gp[0], gp[1], 4 * j + r)) ? acc[1][4 * j + r] : 0.f;
-        red_write(j, x);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      red_read(rj, rv);
-      red_store_rj(7, rj);
-      red_store_ri(7, rv);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the next tile's staging writes overlap this area)
-    } else {
+    {
       co_read(NS);
 #pragma unroll
       for (int q = 0; q < 2; ++q) co_store(NS, 6, q);
@@ -1316,7 +1223,7 @@ static int g_diag_abl = 0;
 extern "C" int rn_diag_set_abl(int v) { g_diag_abl = v; return 0; }
 #endif
 static int rr_prio() {
-  const char* e = getenv("RN_RR_PRIO");
+  const char* e = rn_diag_env("RN_RR_PRIO");               // (RN_DIAG builds: static s_setprio for the second-dispatched waves, measured +-0.3 %)
   return e ? (e[0] != '0') : RR_PRIO_DEFAULT;
 }
 
@@ -1552,40 +1459,18 @@ extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, in
   return 0;
 }
 
-static int rr_bwd_launch(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, float* rj_part, float* ri_part,
-                         int M, int rows_per_question, int L, int G, void* stream);
-
 extern "C" int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M,
                                  int rows_per_question, int L, int G, void* stream) {
-  return rr_bwd_launch(dxg, mask, Wtf, dZ, nullptr, nullptr, M, rows_per_question, L, G, stream);
-}
-
-extern "C" size_t rn_chain_reduce_part_bytes(int M, int which) {
-  if (M <= 0 || M % RR_TM) return 0;
-  return which == 0 ? (size_t)(M / RR_TM) * 64 * RR_G * sizeof(float) : (size_t)(M / RR_WR) * 2 * RR_G * sizeof(float);
-}
-
-extern "C" int rn_g_chain_bwd_rr_reduce(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, float* rj_part,
-                                        float* ri_part, int n, int M, int L, int G, void* stream) {
-  RN_CHECK_ARG(rj_part && ri_part && ((uintptr_t)rj_part | (uintptr_t)ri_part) % 16 == 0, "rn_g_chain_bwd_rr_reduce: rj_part / ri_part must be 16-byte aligned buffers");
-  RN_CHECK_ARG(n == 64, "rn_g_chain_bwd_rr_reduce: the in-chain pair reduction covers n == 64 objects (a 256-row tile = 4 i x 64 j); got n=%d", n);
-  RN_CHECK_ARG(dZ && dZ[0] == nullptr && dZ[RR_L - 1] == nullptr, "rn_g_chain_bwd_rr_reduce: dZ[0] (rebuilt by the gated wgrad) and dZ[3] (reduced in the chain) must be NULL");
-  return rr_bwd_launch(dxg, mask, Wtf, dZ, rj_part, ri_part, M, n * n, L, G, stream);
-}
-
-static int rr_bwd_launch(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, float* rj_part, float* ri_part,
-                         int M, int rows_per_question, int L, int G, void* stream) {
   RN_CHECK_ARG(dxg && mask && Wtf && dZ && M > 0, "rn_g_chain_bwd_rr: bad pointer/size");
-  const bool red = rj_part != nullptr;
   RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_bwd_rr: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
   RN_CHECK_ARG(M % RR_TM == 0 && rows_per_question > 0 && M % rows_per_question == 0,
                "rn_g_chain_bwd_rr: M=%d must be a multiple of %d and of rows per question=%d", M, RR_TM, rows_per_question);
   RRBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.prio = rr_prio();
-  const bool skip0 = dZ[0] == nullptr;                     // the last layer's gradient is not stored (rn_g_linear_bwd_wgrad_gated rebuilds it)
+  const bool skip0 = dZ[0] == nullptr;                     // the last layer's gradient is not stored (the gate job of rn_g_wgrad_blocked replaces it)
   for (int l = 0; l < RR_L; ++l) {
-    RN_CHECK_ARG(mask[l] && (dZ[l] || (l == 0 && skip0) || (l == RR_L - 1 && red)) && (l == RR_L - 1 || Wtf[l]), "rn_g_chain_bwd_rr: entry %d has a NULL pointer", l);
+    RN_CHECK_ARG(mask[l] && (dZ[l] || (l == 0 && skip0)) && (l == RR_L - 1 || Wtf[l]), "rn_g_chain_bwd_rr: entry %d has a NULL pointer", l);
     RN_CHECK_ARG(((uintptr_t)mask[l] | (uintptr_t)dZ[l] | (uintptr_t)(l < RR_L - 1 ? Wtf[l] : nullptr)) % 16 == 0,
                  "rn_g_chain_bwd_rr: entry %d pointers must be 16-byte aligned", l);
   }
@@ -1597,7 +1482,7 @@ static int rr_bwd_launch(const float* dxg, const void* const* mask, const void* 
   a.mask_stride = (const u64*)mask[1] - (const u64*)mask[0];
   a.w_stride = (const bf16*)Wtf[1] - (const bf16*)Wtf[0];
   for (int l = 0; l < RR_L; ++l) {
-    RN_CHECK_ARG((const u64*)mask[l] == a.mask + l * a.mask_stride && ((l == 0 && skip0) || (l == RR_L - 1 && red) || (bf16*)dZ[l] == a.dZ + l * a.dz_stride) &&
+    RN_CHECK_ARG((const u64*)mask[l] == a.mask + l * a.mask_stride && ((l == 0 && skip0) || (bf16*)dZ[l] == a.dZ + l * a.dz_stride) &&
                      (l == RR_L - 1 || (const bf16*)Wtf[l] == a.W + l * a.w_stride),
                  "rn_g_chain_bwd_rr: mask / dZ / Wtf buffers must be equally spaced (slices of one allocation each)");
   }
@@ -1606,32 +1491,21 @@ static int rr_bwd_launch(const float* dxg, const void* const* mask, const void* 
   a.rows_per_b = rows_per_question;
   const int ntiles = M / RR_TM;
   const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
-  const char* ae = getenv("RN_RR_ABL");                    // diagnostics: timing-only ablations (results are wrong)
-  if (red) {
-    a.rj_part = rj_part;
-    a.ri_part = ri_part;
-    g_chain_rr_bwd_kernel<0, true, true><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles);
-    RN_LAUNCH_CHECK("rn_g_chain_bwd_rr_reduce");
-    return 0;
-  }
   if (skip0) {
     g_chain_rr_bwd_kernel<0, true><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles);
     RN_LAUNCH_CHECK("rn_g_chain_bwd_rr");
     return 0;
   }
-  switch (ae ? atoi(ae) : 0) {
-    case 1: g_chain_rr_bwd_kernel<1><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
-    case 2: g_chain_rr_bwd_kernel<2><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
-    case 3: g_chain_rr_bwd_kernel<3><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
-    case 4: g_chain_rr_bwd_kernel<4><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
-    case 7: g_chain_rr_bwd_kernel<7><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
-    case 15: g_chain_rr_bwd_kernel<15><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
-    case 16: g_chain_rr_bwd_kernel<16><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
-    case 17: g_chain_rr_bwd_kernel<17><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
-    case 32: g_chain_rr_bwd_kernel<32><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
-    case 64: g_chain_rr_bwd_kernel<64><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
+#ifdef RN_DIAG
+  switch (g_diag_abl) {                                    // timing-only ablations of the stored-dZ[0] variant (results are wrong)
+#define RN_ABL(v) case v: g_chain_rr_bwd_kernel<v><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
+    RN_ABL(1) RN_ABL(2) RN_ABL(3) RN_ABL(4) RN_ABL(7) RN_ABL(15) RN_ABL(16) RN_ABL(17) RN_ABL(32) RN_ABL(64)
+#undef RN_ABL
     default: g_chain_rr_bwd_kernel<0><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles); break;
   }
+#else
+  g_chain_rr_bwd_kernel<0><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles);
+#endif
   RN_LAUNCH_CHECK("rn_g_chain_bwd_rr");
   return 0;
 }

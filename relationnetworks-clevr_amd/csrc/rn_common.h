@@ -52,6 +52,15 @@ void rn_set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Diagnostic knobs (kernel-variant selection for A/B timing, timing ablations) exist in RN_DIAG builds only
+// (`RN_DIAG=1 python relationnetworks-clevr_amd/_build.py`): the product library never reads the process environment.
+#ifdef RN_DIAG
+#include <stdlib.h>
+static inline const char* rn_diag_env(const char* name) { return getenv(name); }
+#else
+static inline const char* rn_diag_env(const char*) { return nullptr; }
+#endif
+
 // ---- element traits ----------------------------------------------------------
 template <typename T> struct Elem;
 template <> struct Elem<bf16> {

@@ -8,8 +8,6 @@
 // All stores are 16-byte, fully coalesced; no MFMA here (K1 is HBM-write bound).
 #include <stdarg.h>
 
-#include <stdlib.h>
-
 #include "rn_common.h"
 
 // ---------------------------------------------------------------- error state
@@ -106,7 +104,7 @@ extern "C" int rn_pair_build_fwd(const float* x, long sxb, long sxn, long sxk, c
   RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32 || dtype == RN_F16, "rn_pair_build_fwd: bad dtype %d", dtype);
   int IB = (int)((long)B * n / 2048);
   IB = IB < 1 ? 1 : (IB > 8 ? 8 : IB);
-  if (const char* e = getenv("RN_K1_IB")) IB = atoi(e) > 0 ? atoi(e) : IB;        // diagnostics
+  if (const char* e = rn_diag_env("RN_K1_IB")) IB = atoi(e) > 0 ? atoi(e) : IB;        // diagnostics
   dim3 grid(cdiv(n, IB), B);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == RN_BF16 || dtype == RN_F16) {
@@ -507,71 +505,6 @@ __global__ __launch_bounds__(256) void pair_reduce_finish_kernel(const f32x4* __
   if (il == 0 && c < G4 && Rq) Rq[(long)b * G4 + c] = ((q + red[0][threadIdx.x]) + red[1][threadIdx.x]) + red[2][threadIdx.x];
 }
 
-// The finish of the in-chain pair reduction (rn_g_chain_bwd_rr_reduce, n == 64): the chain left, per 256-row tile, the sum of
-// dZ_0 over the tile's 4 i (rj_part: [tile][feature block 8][feature group 4][row j 64][8 features]) and per 32-row block and
-// 16-row half its column sums (ri_part: [block][half 2][256]).  Block = (question b, 32-feature block): first the 16 tiles of
-// the question are added into Rj (fixed order), then the 4 partials of every (b, i) into Ri and the 64 Ri rows into Rq
-// (fixed order, the 8 i-lanes meet in LDS) -- deterministic.  16 independent 32-byte loads per thread in flight.
-__global__ __launch_bounds__(256) void pair_reduce_from_chain_kernel(const f32x4* __restrict__ rj_part, const float* __restrict__ ri_part,
-                                                                     float* __restrict__ Rj, float* __restrict__ Ri, float* __restrict__ Rq) {
-  constexpr int N = 64, G = 256, TPB = 16;                            // objects, g width, tiles per question
-  __shared__ float red[7][32];
-  const int ob = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
-  {
-    const int jg = t >> 6, row = t & 63;
-    f32x4 v[TPB][2];
-#pragma unroll
-    for (int tt = 0; tt < TPB; ++tt) {
-      const f32x4* src = rj_part + (((((long)b * TPB + tt) * 8 + ob) * 4 + jg) * 64 + row) * 2;
-      v[tt][0] = src[0];
-      v[tt][1] = src[1];
-    }
-    f32x4 s0 = v[0][0], s1 = v[0][1];
-#pragma unroll
-    for (int tt = 1; tt < TPB; ++tt) {
-      s0 += v[tt][0];
-      s1 += v[tt][1];
-    }
-    f32x4* dst = reinterpret_cast<f32x4*>(Rj + ((long)b * N + row) * G + 32 * ob + 8 * jg);
-    dst[0] = s0;
-    dst[1] = s1;
-  }
-  {
-    const int f = t & 31, ig = t >> 5;
-    float p[8][4];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = ig + 8 * u;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) p[u][q] = ri_part[((((long)b * N + i) * 2 + (q >> 1)) * 2 + (q & 1)) * G + 32 * ob + f];
-    }
-    float qs = 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float r = ((p[u][0] + p[u][1]) + p[u][2]) + p[u][3];
-      Ri[((long)b * N + ig + 8 * u) * G + 32 * ob + f] = r;
-      qs = u ? qs + r : r;
-    }
-    if (ig > 0) red[ig - 1][f] = qs;
-    __syncthreads();
-    if (ig == 0) {
-      float tot = qs;
-#pragma unroll
-      for (int g = 0; g < 7; ++g) tot += red[g][f];
-      Rq[(long)b * G + 32 * ob + f] = tot;
-    }
-  }
-}
-
-extern "C" int rn_pair_reduce_from_chain(const float* rj_part, const float* ri_part, float* Rj, float* Ri, float* Rq, int B, int n, int G,
-                                         void* stream) {
-  RN_CHECK_ARG(rj_part && ri_part && Rj && Ri && Rq && B > 0, "rn_pair_reduce_from_chain: bad pointer/size");
-  RN_CHECK_ARG(n == 64 && G == 256, "rn_pair_reduce_from_chain: n == 64, G == 256 only (n=%d G=%d)", n, G);
-  RN_CHECK_ARG(((uintptr_t)rj_part | (uintptr_t)ri_part | (uintptr_t)Rj | (uintptr_t)Ri | (uintptr_t)Rq) % 16 == 0, "rn_pair_reduce_from_chain: pointers must be 16-byte aligned");
-  pair_reduce_from_chain_kernel<<<dim3(8, B), 256, 0, (hipStream_t)stream>>>((const f32x4*)rj_part, ri_part, Rj, Ri, Rq);
-  RN_LAUNCH_CHECK("rn_pair_reduce_from_chain");
-  return 0;
-}
 
 extern "C" size_t rn_pair_reduce_ws_bytes(int B, int n, int G) {
   return (size_t)cdiv(n, 16) * B * n * G * sizeof(float);            // Ri partials, one slab per block of 16 j

@@ -9,11 +9,10 @@ PyTorch only allocates buffers and supplies the stream; all arithmetic runs in
 librn_hip.so.  There is no CPU / eager fallback."""
 from __future__ import annotations
 
-import os
-
 import torch
 
 from . import rn_hip as H
+from .options import OPT
 
 PRECISIONS = ("bf16", "f16s", "fp32")
 
@@ -85,7 +84,7 @@ class PackedWeights:
         encoder's side stream, whose fork and join around the conv stack exist anyway (a fork / join of its own costs
         more than the 11 us it hides: measured).  The next get() with the same arguments returns the images without
         launching anything; the caller's join orders it after this stream."""
-        if self._last is None or os.environ.get("RN_NO_PACK_AHEAD", "0") == "1":
+        if self._last is None or not OPT.pack_ahead:
             return
         plan, g_w, code, split, bwd_images, rr_only, f_w, alg0_k, inj = self._last
         if not torch.is_grad_enabled():
@@ -188,7 +187,7 @@ class RRMasks:
 def rr_chain_ok(plan: LayerPlan, code):
     """The register-resident forward chain (rn_chain_rr.hip): bf16, exactly four 256-wide g layers, question
     injected at layer 0 with a padded layer-0 reduction length of 192 or 256 (the headline shape family)."""
-    if os.environ.get("RN_NO_RR_CHAIN", "0") == "1":
+    if not OPT.rr_chain:
         return False
     return (code == H.RN_BF16 and plan.L == 4 and all(w == 256 for w in plan.widths) and plan.kpad[0] in (192, 256)
             and all(kp == 256 for kp in plan.kpad[1:]))
@@ -198,7 +197,7 @@ def fused_chain_ok(plan: LayerPlan, code, B, n):
     """The fused LDS-resident chain (rn_chain.hip) covers the headline shape family: bf16 storage,
     all g widths 256, question injected at layer 0 (so every later layer has K == 256), and whole
     128-row tiles per question.  Everything else runs the per-layer kernels."""
-    if os.environ.get("RN_NO_FUSED_CHAIN", "0") == "1":
+    if not OPT.fused_chain:
         return False
     return (code == H.RN_BF16 and all(w == 256 for w in plan.widths) and plan.kpad[0] <= 256
             and all(kp == 256 for kp in plan.kpad[1:]) and (B * n * n) % H.g_chain_tile() == 0 and plan.L <= 8)
@@ -209,7 +208,7 @@ def inj_chain_ok(plan: LayerPlan, code, n, k, M):
     ir-fp): the factored first layer without a question term + the per-question bias row W_2[:, 256:] q[b] + b_2 at layer 2
     (rn_g_chain_fwd_rr*_alg0 with inject_layer = 2).  Four 256-wide layers, whole waves per (question, i), whole 256-row
     tiles per question."""
-    if os.environ.get("RN_NO_RR_CHAIN", "0") == "1" or os.environ.get("RN_NO_RR_MASKS", "0") == "1" or os.environ.get("RN_NO_INJ_CHAIN", "0") == "1":
+    if not OPT.rr_chain or not OPT.rr_masks or not OPT.inj_chain:
         return False
     return (code == H.RN_BF16 and plan.L == 4 and all(w == 256 for w in plan.widths) and plan.inject == 2 and k <= 32
             and plan.ktrue[2] == 256 + plan.Q and n % 32 == 0 and (n * n) % H.g_chain_rr_tile() == 0 and M % H.g_chain_rr_tile() == 0)
@@ -224,22 +223,22 @@ def _h_copy_dtype(plan, dt, M):
     """Storage type of the H_0..2 copies the register-resident chains keep for the weight gradient (row-blocked images,
     rn_g_wgrad_blocked is their only reader): OCP e4m3 bytes -- half the bytes written by the forward chain and read back --
     or the chain's 16-bit type with RN_H8=0 (A/B measurements, error comparisons)."""
-    if os.environ.get("RN_H8", "1") != "0" and dt == torch.bfloat16 and all(w == 256 for w in plan.widths):
+    if OPT.h8 and dt == torch.bfloat16 and all(w == 256 for w in plan.widths):
         return torch.float8_e4m3fn
     return dt
 
 
 def alg0_wgrad_ok(plan, k):
     """Layer-0 weight gradient from the pair reductions (rn_wgrad0_from_reductions) instead of a pass over dZ_0 and P."""
-    return plan.inject == 0 and k <= 32 and os.environ.get("RN_NO_ALGEBRAIC_WGRAD0", "0") != "1"
+    return plan.inject == 0 and k <= 32 and OPT.algebraic_wgrad0
 
 
 def alg0_forward_ok(plan, code, n, k, M):
     """The factored first layer (rn_g_chain_fwd_rr_alg0): bf16 register-resident chains, question injected at layer 0,
     whole waves per (question, i) and the algebraic layer-0 weight gradient in the backward pass (nothing reads P)."""
     return (rr_chain_ok(plan, code) and plan.inject == 0 and k <= 32 and n % 32 == 0 and M % H.g_chain_rr_tile() == 0
-            and os.environ.get("RN_NO_RR_MASKS", "0") != "1" and os.environ.get("RN_NO_ALGEBRAIC_WGRAD0", "0") != "1"
-            and os.environ.get("RN_NO_ALGEBRAIC_FWD0", "0") != "1")
+            and OPT.rr_masks and OPT.algebraic_wgrad0
+            and OPT.algebraic_fwd0)
 
 
 def _tables(x, q, plan, g_b, w0T, inj_w, xdt, B, n, k, Q, G, coord=None):
@@ -304,7 +303,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
             P = torch.empty(M, ld0, dtype=dt, device=dev)
             H.pair_build_fwd(x, q, P, code, B, n, k, Q, ld0)
         if (wfrag is not None and len(wfrag) == 2 and len(wfrag[0]) == L and rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0
-                and ((n * n) % 32 == 0 or keep_inputs) and os.environ.get("RN_NO_RR_MASKS", "0") != "1"):
+                and ((n * n) % 32 == 0 or keep_inputs) and OPT.rr_masks):
             # register-resident mapping: fp16 operand registers, hi + lo weight fragments; bf16 copies + lane masks for the
             # (shared, bf16) backward chain.  Waves that straddle two questions (n*n % 32 != 0, the 14x14 grid): the pair sum
             # comes from the stored H_3 instead of the in-lane partials (training only: inference has nowhere to store it)
@@ -370,7 +369,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
             Hs = None
             if keep_inputs:
                 Hs = [torch.empty(M, G, dtype=dt, device=dev) for l in range(L)]
-                if os.environ.get("RN_NO_RR_MASKS", "0") != "1":
+                if OPT.rr_masks:
                     masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
                     if whole:
                         Hs[-1] = None                       # (waves straddling questions: the pair sum needs the stored H_3)
@@ -433,7 +432,7 @@ class PairSumPartials:
 
 
 def _pair_sum_of(part, B, parts, G, lazy):
-    if lazy and os.environ.get("RN_NO_FUSED_PAIR_SUM", "0") != "1":
+    if lazy and OPT.fused_pair_sum:
         return PairSumPartials(part, B, parts, G)
     xg = torch.empty(B, G, dtype=torch.float32, device=part.device)
     H.pair_sum_fwd(part, G, xg, H.RN_F32, B, parts, G)
@@ -496,7 +495,7 @@ class RelationalFunction(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         # exactly g_chain_forward's condition for the register-resident branches (they consume only the fragment-major
         # images): whole waves per question, or -- waves straddling questions -- a stored H_3 (training only)
-        rr_only = (rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0 and os.environ.get("RN_NO_RR_MASKS", "0") != "1"
+        rr_only = (rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0 and OPT.rr_masks
                    and ((n * n) % 32 == 0 or need_grad))
         alg_fwd = rr_only and alg0_forward_ok(plan, code, n, k, M)
         inj_fwd = inj_chain_ok(plan, code, n, k, M)        # question injected at layer 2: same chains, per-question bias row
@@ -578,7 +577,7 @@ class RelationalFunction(torch.autograd.Function):
         # ---- g_theta backward
         dt = H.torch_dtype(code)
         inputs, wbwd, g_w = ctx.inputs, ctx.wbwd, ctx.g_w
-        fused_bwd = fused_chain_ok(plan, code, B, n) and L >= 2 and os.environ.get("RN_NO_FUSED_BWD", "0") != "1"
+        fused_bwd = fused_chain_ok(plan, code, B, n) and L >= 2 and OPT.fused_bwd
         rr_bwd = isinstance(ctx.HL, RRMasks)       # the register-resident chains: H_0..2 / dZ of layers 1..3 are row-blocked images
         if rr_bwd:
             # register-resident backward chain on the forward kernel's gates (one launch, no activation is re-read)
@@ -587,27 +586,13 @@ class RelationalFunction(torch.autograd.Function):
             # itself, the layer's wgrad, rebuilds it from the masks (rn_g_wgrad_blocked) -- 134 MB less written
             # by the chain and 134 MB less read by the wgrad at the headline shape
             gated_mask = None
-            red_parts = None
             # (needs the e4m3 H_2 image: the gate job runs on the fp8 matrix pipe; with 16-bit copies dZ_3 is stored)
-            if ((n * n) % 64 == 0 and inputs[L - 1].dtype in H.FP8_DTYPES and os.environ.get("RN_NO_GATED_WGRAD", "0") != "1"):
+            if ((n * n) % 64 == 0 and inputs[L - 1].dtype in H.FP8_DTYPES and OPT.gated_wgrad):
                 gated_mask = ctx.HL.masks[L - 1]
-                # RN_CHAIN_REDUCE=1 (opt-in): ... and neither is the FIRST layer's gradient where its only readers are the pair
-                # reductions (layer-0 weight gradient from the reductions, 64 objects): the chain adds each 256-row tile's four i
-                # and every wave's 32 j on chip and leaves 72 MB of fp32 partials instead of the 134 MB bf16 matrix
-                # (rn_g_chain_bwd_rr_reduce).  196 MB less HBM traffic per step, but measured neutral on the step (the chain's
-                # last step turns LDS-bound: +24 us alone, the reduction -21 us; 61.2-61.8 k q/s either way) -- DESIGN.md 6.1
-                if (n == 64 and L == 4 and (alg0_wgrad_ok(plan, k) or (bool(ctx.inj_path) and k <= 32))
-                        and os.environ.get("RN_CHAIN_REDUCE", "0") == "1"):
-                    red_parts = (torch.empty(H.chain_reduce_part_bytes(M, 0) // 4, **f32), torch.empty(H.chain_reduce_part_bytes(M, 1) // 4, **f32))
-                    dZs = [None] + list(torch.empty(L - 2, M, G, dtype=dt, device=dev)) + [None]
-                else:
-                    dZs = [None] + list(torch.empty(L - 1, M, G, dtype=dt, device=dev))
+                dZs = [None] + list(torch.empty(L - 1, M, G, dtype=dt, device=dev))
             else:
                 dZs = list(torch.empty(L, M, G, dtype=dt, device=dev))             # dZs[s] belongs to layer L-1-s
-            if red_parts is not None:
-                H.g_chain_bwd_rr_reduce(dxg, ctx.HL.masks, ctx.fragT, dZs, red_parts[0], red_parts[1], n, M, G)
-            else:
-                H.g_chain_bwd_rr(dxg, ctx.HL.masks, ctx.fragT, dZs, M, n * n, G)
+            H.g_chain_bwd_rr(dxg, ctx.HL.masks, ctx.fragT, dZs, M, n * n, G)
             dZ_of = {L - 1 - s: dZs[s] for s in range(L)}
         elif fused_bwd:
             # one launch: dZ_L = dxg * (H_L > 0), then dZ_{l-1} = (dZ_l @ W_l) * (H_{l-1} > 0) for every layer
@@ -620,7 +605,6 @@ class RelationalFunction(torch.autograd.Function):
             H.pair_sum_bwd(dxg, ctx.HL, G, dZ, G, code, B, n * n, G)
         if not isinstance(ctx.HL, RRMasks):
             gated_mask = None
-            red_parts = None
         ctx.HL = None
         gW, gB = [None] * L, [None] * L
         dq = None
@@ -672,7 +656,7 @@ class RelationalFunction(torch.autograd.Function):
         # backward that autograd runs next (small kernels that leave the chip mostly empty).  The main stream
         # re-joins at the end of the backward pass (engine callback).  Only when every parameter's .grad is
         # None (assign, not accumulate: autograd then launches no kernel on these tensors before the join).
-        overlap = (fused_bwd and os.environ.get("RN_NO_WGRAD_OVERLAP", "0") != "1"
+        overlap = (fused_bwd and OPT.wgrad_overlap
                    and all(_assign_only(p) for p in ctx.param_refs))
         # Layer 0 reads the pair matrix P = [x_j | x_i | q]: its weight gradient dZ_0^T P factors through the pair
         # reductions the input gradient needs anyway -- dW_0 = [Rj^T X | Ri^T X | Rq^T Q], db_0 = sum_b Rq -- three tiny
@@ -682,14 +666,14 @@ class RelationalFunction(torch.autograd.Function):
         # question injected at layer > 0: its per-question sums Rq from the wgrad kernel's per-split column sums when no split
         # straddles two questions (64 splits: B | 64), else from the pair-reduction kernel
         rq_splits, inj_out = 0, {}
-        if inj and rr_bwd and os.environ.get("RN_NO_RQ_FROM_WGRAD", "0") != "1":
+        if inj and rr_bwd and OPT.rq_from_wgrad:
             z_ = H.wgrad_blocked_splits(M, n * n, L - 1, aligned=True)
             if z_ > 0 and z_ % B == 0 and (M // 64) % z_ == 0 and (n * n) % (M // z_) == 0:
                 rq_splits = z_
         # RN_WGRAD_LATE=1 / 2 starts the (HBM-bound) wgrad stream only after the pair reduction / after dx, dq: measured
         # slower (1.102 / 1.137 vs 1.092 ms; all wgrads serially at the very end of the backward pass: 1.165) -- the window after the backward chain runs at the HBM roofline (~4 TB/s over
         # wgrad + pair reduction, tools/step_timeline.py) wherever the wgrads are put, and later they slow the conv backward
-        wgrad_late = int(os.environ.get("RN_WGRAD_LATE", "0")) if (alg0 and not inj) else 0
+        wgrad_late = OPT.wgrad_late if (alg0 and not inj) else 0
         if overlap:
             main, side = torch.cuda.current_stream(), _side_stream(dev)
             keep = [list(dZs), list(inputs), gated_mask, dxg]      # keep operands alive until the join
@@ -729,17 +713,14 @@ class RelationalFunction(torch.autograd.Function):
                 _wgrad(l, dZ, A_l)
             wl = g_w[l] if g_w[l].is_contiguous() else g_w[l].contiguous()
             fused_tail = (l == 0 and (plan.inject == 0 or inj) and k <= 32
-                          and os.environ.get("RN_NO_FUSED_PAIR_TAIL", "0") != "1")
+                          and OPT.fused_pair_tail)
             if l == plan.inject and l > 0 and rq_splits:
                 pass                                               # Rq, dq and the question columns of dW: done with the layer's wgrad
             elif l == plan.inject:
                 Rq = torch.empty(B, N, **f32)
                 if l == 0:
                     Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32)
-                    if red_parts is not None:
-                        H.pair_reduce_from_chain(red_parts[0], red_parts[1], Rj, Ri, Rq, B, n, N)
-                    else:
-                        H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N)
+                    H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N)
                 elif rr_bwd:
                     H.blocked_question_sums(dZ, Rq, M, n * n)      # (this layer's dZ is a row-blocked image)
                 else:
@@ -760,10 +741,7 @@ class RelationalFunction(torch.autograd.Function):
             elif l == 0:
                 Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32)
                 Rq = torch.empty(B, N, **f32) if alg0 else None                   # (all-pairs sums: the layer's bias gradient)
-                if red_parts is not None:
-                    H.pair_reduce_from_chain(red_parts[0], red_parts[1], Rj, Ri, Rq, B, n, N)
-                else:
-                    H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N)
+                H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N)
             if l == 0 and overlap and wgrad_late == 1:
                 _launch_wgrads()
             if l == 0 and alg0:
@@ -826,12 +804,14 @@ def relational_forward(x, q, mask, plan, packed, precision, g_w, g_b, f_w, f_b, 
 
 def grid_path_ok(plan: LayerPlan, precision, B, n, k):
     """Shapes / modes whose kernels take the conv grid + the coordinate table directly (the factored-first-layer paths)."""
-    if precision not in ("bf16", "f16s") or os.environ.get("RN_NO_GRID_FAST", "0") == "1":
+    if precision not in ("bf16", "f16s") or not OPT.grid_fast:
         return False
     code, M = H.RN_BF16, B * n * n
+    if not OPT.fused_pair_tail:                   # (the un-fused tail writes dx as (B, n, k): not the grid view's shape)
+        return False
     if inj_chain_ok(plan, code, n, k, M):
         return True
-    return (alg0_forward_ok(plan, code, n, k, M) and alg0_wgrad_ok(plan, k) and os.environ.get("RN_NO_FUSED_PAIR_TAIL", "0") != "1")
+    return alg0_forward_ok(plan, code, n, k, M) and alg0_wgrad_ok(plan, k)
 
 
 _ZEROS = {}
@@ -847,7 +827,7 @@ def _zeros_like_cached(n, ref):
 
 
 def _direct_conv_ok(inp, conv_w, stride, padding):
-    return (os.environ.get("RN_NO_DIRECT_CONV", "0") != "1" and inp.dtype == torch.float32 and tuple(conv_w.shape[2:]) == (3, 3)
+    return (OPT.direct_conv and inp.dtype == torch.float32 and tuple(conv_w.shape[2:]) == (3, 3)
             and tuple(stride) == (2, 2) and tuple(padding) == (1, 1) and conv_w.shape[0] == 24 and conv_w.shape[1] in (3, 24)
             and inp.shape[2] % 2 == 0 and inp.shape[3] % 2 == 0)
 
@@ -914,14 +894,14 @@ class ConvBNReLUFunction(torch.autograd.Function):
         dgamma = torch.empty_like(g); dbeta = torch.empty_like(bt)
         H.bn_relu_bwd(dy, x, dx, g, bt, mean, invstd, dgamma, dbeta)
         conv_bwd = lambda mask: torch.ops.aten.convolution_backward(dx, inp, conv_w, None, stride, padding, (1, 1), False, (0, 0), 1, mask)
-        if ctx.needs_input_grad[0] and os.environ.get("RN_NO_WGRAD_OVERLAP", "0") != "1" and _assign_only(ctx.w_ref):
+        if ctx.needs_input_grad[0] and OPT.wgrad_overlap and _assign_only(ctx.w_ref):
             # only the input gradient is on the dependency chain of the backward pass: the weight gradient (MIOpen's
             # wrw kernel plus its layout transposes, ~half of the conv backward) goes to the side stream and overlaps the
             # next layers' backward; the main stream re-joins at the end of the backward pass
             main, side = torch.cuda.current_stream(), _side_stream(dx.device, 1)     # (stream 0 carries the g_theta wgrads)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                if ctx.direct and os.environ.get("RN_NO_DIRECT_CONV_WGRAD", "0") != "1":
+                if ctx.direct and OPT.direct_conv_wgrad:
                     dw = torch.empty_like(conv_w)
                     H.conv3x3s2_bwd_weight(inp, dx, dw)                # fp32 matrix pipe, no layout transposes
                 else:
@@ -940,7 +920,7 @@ class ConvBNReLUFunction(torch.autograd.Function):
                 H.conv3x3s2_bwd_data(dx, conv_w.detach().contiguous(), din)
             else:
                 din = conv_bwd([True, False, False])[0]
-        elif ctx.direct and not ctx.needs_input_grad[0] and os.environ.get("RN_NO_DIRECT_CONV_WGRAD", "0") != "1":
+        elif ctx.direct and not ctx.needs_input_grad[0] and OPT.direct_conv_wgrad:
             din = None                                                 # first layer (the image needs no gradient): the END of
             dw = torch.empty_like(conv_w)                              # the backward pass, nothing left to overlap with
             H.conv3x3s2_bwd_weight(inp, dx, dw)
@@ -1017,6 +997,6 @@ class NllMeanFunction(torch.autograd.Function):
 
 def nll_loss_mean(logp, label):
     """Drop-in for F.nll_loss(logp, label) (mean) on GPU tensors; falls back to torch elsewhere."""
-    if logp.is_cuda and logp.dim() == 2 and os.environ.get("RN_NO_FUSED_NLL", "0") != "1":
+    if logp.is_cuda and logp.dim() == 2 and OPT.fused_nll:
         return NllMeanFunction.apply(logp, label)
     return torch.nn.functional.nll_loss(logp, label)

@@ -28,6 +28,7 @@ import torch.nn.functional as F
 try:                                    # imported as part of the package ...
     from . import functional as RF
     from . import rn_hip as H
+    from .options import OPT
 except ImportError:                     # ... or flat, exactly like the reference: `from model import RN`
     import importlib.util
     import sys
@@ -39,6 +40,7 @@ except ImportError:                     # ... or flat, exactly like the referenc
     sys.modules.setdefault("relationnetworks_clevr_amd", _pkg)
     from relationnetworks_clevr_amd import functional as RF          # type: ignore
     from relationnetworks_clevr_amd import rn_hip as H               # type: ignore
+    from relationnetworks_clevr_amd.options import OPT               # type: ignore
 
 
 class ConvInputModel(nn.Module):
@@ -56,7 +58,7 @@ class ConvInputModel(nn.Module):
 
     def forward(self, img):
         x = img
-        fused = (img.is_cuda and img.dtype == torch.float32 and os.environ.get("RN_NO_FUSED_BN", "0") != "1"
+        fused = (img.is_cuda and img.dtype == torch.float32 and OPT.fused_bn
                  and not (torch.is_grad_enabled() and not self.training))
         for i in range(1, 5):
             conv, bn = self._modules["conv%d" % i], self._modules["batchNorm%d" % i]
@@ -82,7 +84,7 @@ class QuestionEmbedModel(nn.Module):
 
     def forward(self, question):
         l = self.lstm
-        if (question.is_cuda and os.environ.get("RN_NO_FUSED_LSTM", "0") != "1" and l.num_layers == 1 and not l.bidirectional
+        if (question.is_cuda and OPT.fused_lstm and l.num_layers == 1 and not l.bidirectional
                 and l.batch_first and l.bias and getattr(l, "proj_size", 0) == 0 and l.input_size == 32 and l.hidden_size == 128
                 and self.wembedding.padding_idx is None and self.wembedding.max_norm is None and l.weight_ih_l0.dtype == torch.float32):
             # embedding + the whole recurrence in one launch per direction (rn_lstm.hip)
@@ -132,9 +134,9 @@ class RelationalLayer(RelationalLayerBase):
         self.g_layers = nn.ModuleList(layers)
         self.extraction = extraction
         # MI355X execution options
-        # "auto" -> "f16s" where the fused chain applies (log-probs within ~2e-4 of the fp32 reference), else
-        # "bf16" (~1e-2); "fp32" = exact-fp32 MFMA everywhere (~5e-7).  See DESIGN.md section 2.
-        self.precision = hyp.get("precision", os.environ.get("RN_PRECISION", "auto"))
+        # "auto" -> "f16s" where a kernel for it covers the shape (log-probs within ~2e-4 of the fp32 reference), else "fp32"
+        # (exact-fp32 MFMA, ~5e-7): whatever "auto" picks meets the 1e-3 bar.  "bf16" (~1e-2) only on request.  DESIGN.md section 2.
+        self.precision = hyp.get("precision", OPT.precision)
         self.forced_dropout_mask = None                  # tests: explicit (B, f_fc2) mask incl. 1/(1-p)
         self._packed = RF.PackedWeights()
         self._plan_cache = {}
@@ -197,10 +199,11 @@ class RelationalLayer(RelationalLayerBase):
 
     def resolved_precision(self, b, d, k):
         """The arithmetic mode a forward pass on (b, d, k) objects runs in: `self.precision`, with "auto" resolved to
-        "f16s" (meets the 1e-3 log-prob bar) wherever a kernel for it exists for this shape, else "bf16"."""
+        "f16s" wherever a kernel for it exists for this shape, else "fp32" (512-wide g layers, ragged pair counts: the
+        per-layer fp32-MFMA kernels) -- both meet the 1e-3 log-prob bar; "auto" never lands on single-pass bf16."""
         if self.precision != "auto":
             return self.precision
-        return "f16s" if RF.f16s_ok(self._plan(k), b, d) else "bf16"
+        return "f16s" if RF.f16s_ok(self._plan(k), b, d) else "fp32"
 
     @torch.no_grad()
     def extract_features(self, x, qst, layer_idx):
@@ -212,7 +215,7 @@ class RelationalLayer(RelationalLayerBase):
         plan = self._plan(k)
         if not 0 <= layer_idx < plan.L:
             raise ValueError("layer_idx must be in [0, %d)" % plan.L)
-        code = H.dtype_code("fp32" if self.precision == "fp32" else "bf16")
+        code = H.dtype_code("bf16" if self.precision == "bf16" else "fp32")     # (the per-layer kernels; parity-clean unless bf16 is asked for)
         H._dev(x, "x")
         wfwd, _ = self._packed.get(plan, [l.weight for l in self.g_layers], code, bwd_images=False)
         gb = [l.bias.detach().contiguous() for l in self.g_layers]
@@ -230,9 +233,9 @@ class RelationalLayer(RelationalLayerBase):
         (B*n*n, in) (extract.py:43,64-68).  When hooks (or extraction=True) are present the
         chain runs layer by layer on the same HIP kernels and each hooked layer's materialised
         input / output is handed to its hooks as fp32 tensors; inference only."""
-        if self.precision == "f16s":
-            raise RuntimeError('forward hooks / extraction need the per-layer kernels: use precision "bf16" or "fp32"')
-        code = H.dtype_code("bf16" if self.precision == "auto" else self.precision)
+        # (the per-layer kernels exist in bf16 and fp32: "auto" / "f16s" take the parity-clean one -- the hooks then see the
+        # reference's fp32 activations to ~1e-6)
+        code = H.dtype_code("bf16" if self.precision == "bf16" else "fp32")
         H._dev(x, "x")
         x = x.float()
         q = qst.float().contiguous()
@@ -270,7 +273,7 @@ class RN(nn.Module):
         self._coord_cache = {}                 # (b, d, device) -> (b, 2, d*d); entries are never evicted (see _coords)
         self._coord_tables = {}                # (d, device) -> (2, d*d): the batch-independent table the kernels read
         self._side_stream = None
-        self.overlap_streams = os.environ.get("RN_OVERLAP_STREAMS", "1") != "0"
+        self.overlap_streams = OPT.overlap_streams
         self.on_gpu = False
         self.conv = ConvInputModel()
         self.state_desc = hyp["state_description"]

@@ -40,9 +40,6 @@ SIGNATURES = {
     "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _I, _P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_f_phi_fwd_from_partials": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "rn_g_chain_bwd_rr_reduce": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "rn_chain_reduce_part_bytes": (_Z, [_I, _I]),
-    "rn_pair_reduce_from_chain": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pack_matrix_frag": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
     "rn_pack_matrix_frag_many": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
@@ -365,27 +362,6 @@ def g_chain_bwd_rr(dxg, masks, Wtfs, dZs, M, rows_per_question, G):
     wp = (C.c_void_p * (L - 1))(*[w.data_ptr() for w in Wtfs])
     zp = (C.c_void_p * L)(*[(z.data_ptr() if z is not None else None) for z in dZs])     # dZs[0] None: not stored
     _check(load().rn_g_chain_bwd_rr(dxg.data_ptr(), mp, wp, zp, M, rows_per_question, L, G, _stream()), "rn_g_chain_bwd_rr")
-
-
-def chain_reduce_part_bytes(M, which):
-    return load().rn_chain_reduce_part_bytes(M, which)
-
-
-@_timed("g_dgrad")
-def g_chain_bwd_rr_reduce(dxg, masks, Wtfs, dZs, rj_part, ri_part, n, M, G):
-    """Backward chain with the pair reduction of the first layer's gradient on chip (n == 64): dZs = [None, dZ_2, dZ_1, None]."""
-    L = len(dZs)
-    mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks])
-    wp = (C.c_void_p * (L - 1))(*[w.data_ptr() for w in Wtfs])
-    zp = (C.c_void_p * L)(*[(z.data_ptr() if z is not None else None) for z in dZs])
-    _check(load().rn_g_chain_bwd_rr_reduce(dxg.data_ptr(), mp, wp, zp, rj_part.data_ptr(), ri_part.data_ptr(), n, M, L, G, _stream()),
-           "rn_g_chain_bwd_rr_reduce")
-
-
-@_timed("pair_reduce")
-def pair_reduce_from_chain(rj_part, ri_part, Rj, Ri, Rq, B, n, G):
-    _check(load().rn_pair_reduce_from_chain(rj_part.data_ptr(), ri_part.data_ptr(), Rj.data_ptr(), Ri.data_ptr(), Rq.data_ptr(), B, n, G, _stream()),
-           "rn_pair_reduce_from_chain")
 
 
 def pack_matrix_split(src, sr, sc, R, Cc, hi, lo, ld, Rpad):

@@ -98,11 +98,16 @@ def _data(cfg, B):
     return x.cuda(), q.cuda(), y.cuda()
 
 
-def _worker(rank, world, port, cfg, steps, out_path):
+def _worker(rank, world, port, cfg, steps, out_path, backend="gloo"):
     from relationnetworks_clevr_amd import dp
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":                               # RCCL: one device per rank
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:                                               # both ranks on device 0, gloo carries the bucket
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     model = _model(cfg, seed=3 + rank)                  # different init per rank: the broadcast must fix it
     opt = _adam(model)
     tr = dp.DataParallelTrainer(model, opt, clip_norm=CLIP, use_graph=True)
@@ -122,15 +127,14 @@ def _worker(rank, world, port, cfg, steps, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cfg", ["original-sd", "original-fp"])
-def test_two_ranks_on_one_gpu_equal_one_rank_on_the_whole_batch(tmp_path, cfg):
+def _check_two_ranks_against_one(tmp_path, cfg, backend):
     from relationnetworks_clevr_amd import dp
     steps = 3
     out = str(tmp_path / "dp.pt")
     try:
-        mp.spawn(_worker, args=(2, _free_port(), cfg, steps, out), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), cfg, steps, out, backend), nprocs=2, join=True)
     except Exception as e:                                 # gloo built without device-tensor support: nothing to test here
-        if "gloo" in str(e).lower() and ("cuda" in str(e).lower() or "device" in str(e).lower()):
+        if backend == "gloo" and "gloo" in str(e).lower() and ("cuda" in str(e).lower() or "device" in str(e).lower()):
             pytest.skip("gloo cannot carry GPU tensors in this build: %s" % str(e)[:200])
         raise
     got = torch.load(out)
@@ -158,6 +162,19 @@ def test_two_ranks_on_one_gpu_equal_one_rank_on_the_whole_batch(tmp_path, cfg):
     assert not bad, "relative update error (err, |ref update|, |2-rank update|): %r" % (sorted(errs.items(), key=lambda kv: -kv[1][0])[:8],)
 
 
+@pytest.mark.parametrize("cfg", ["original-sd", "original-fp"])
+def test_two_ranks_on_one_gpu_equal_one_rank_on_the_whole_batch(tmp_path, cfg):
+    _check_two_ranks_against_one(tmp_path, cfg, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the RCCL (backend nccl) all-reduce over xGMI")
+@pytest.mark.parametrize("cfg", ["original-fp"])
+def test_two_ranks_over_rccl_equal_one_rank_on_the_whole_batch(tmp_path, cfg):
+    """The same assertion with one rank per DEVICE and backend "nccl" (= RCCL on ROCm) -- the configuration the reference's
+    DataParallel wrap stands for (train.py:256-258) and the driver's SCALE run uses.  Runs wherever two GPUs are visible."""
+    _check_two_ranks_against_one(tmp_path, cfg, "nccl")
+
+
 def test_bench_two_ranks_on_one_gpu():
     """The REAL N > 1 path of bench.py -- graph-replayed train step per rank, gradient all-reduce, fused 1/world + clip + Adam,
     barrier-bracketed timed region, MAX over ranks, kernel-timing passes on every rank, one JSON line from rank 0 -- launched
@@ -180,3 +197,5 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2" and d["dtype"] == "f16s"
     assert abs(d["value"] - 2 * 64 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
     assert np.isfinite(d["loss"]) and "roofline" in d and "cpu_baseline" not in d and "parity" not in d
+    # a multi-rank line says where a step's time outside forward + backward goes (attribution of a scaling miss)
+    assert d["allreduce_us_per_step"] > 0 and d["optimizer_us_per_step"] > 0 and d["allreduce_bytes"] == 4 * 484580

@@ -736,46 +736,6 @@ def test_wgrad_blocked_three_jobs(H, B, n, a8):
     assert rel(Rq.cpu().numpy(), dZ[1].double().view(B, n * n, G).sum(1).cpu().numpy()) <= 2e-5
 
 
-@pytest.mark.parametrize("B", [17, 3])
-def test_chain_bwd_in_chain_pair_reduction(H, B):
-    """rn_g_chain_bwd_rr_reduce + rn_pair_reduce_from_chain (64 objects): dZ of layers 2 and 1 bitwise those of the plain chain,
-    and Rj / Ri / Rq = the pair reductions of the first layer's gradient -- which is never stored -- against float64 sums of the
-    plain chain's bf16 matrix: the in-chain sums add the UN-rounded fp32 values, so they differ from it by the bf16 rounding of
-    the summands only (<= 2^-9 of the largest summand per term, far less in the sum).  17 questions: 272 tiles > 256 CUs."""
-    n, L, G = 64, 4, 256
-    M = B * n * n
-    g = torch.Generator(device="cuda").manual_seed(21)
-    masks = list(torch.randint(0, 256, (L, H.g_chain_rr_mask_bytes(M)), dtype=torch.uint8, device="cuda", generator=g))
-    dxg = (torch.rand(B, G, device="cuda", generator=g) - 0.5)
-    Wt = list(torch.empty(L - 1, 65536, dtype=torch.bfloat16, device="cuda"))
-    for st in range(L - 1):
-        W = dev(bf16_round(formula.hash_uniform((G, G), 630 + st, -0.15, 0.15)))
-        H.pack_matrix_frag(W, 1, G, G, G, Wt[st], st == 0)
-    full = [None] + list(torch.zeros(L - 1, M, G, dtype=torch.bfloat16, device="cuda"))
-    H.g_chain_bwd_rr(dxg, masks, Wt, full, M, n * n, G)
-    part = [None] + list(torch.zeros(L - 2, M, G, dtype=torch.bfloat16, device="cuda")) + [None]
-    rj_part = torch.full((H.chain_reduce_part_bytes(M, 0) // 4,), float("nan"), device="cuda")
-    ri_part = torch.full((H.chain_reduce_part_bytes(M, 1) // 4,), float("nan"), device="cuda")
-    H.g_chain_bwd_rr_reduce(dxg, masks, Wt, part, rj_part, ri_part, n, M, G)
-    Rj = torch.full((B * n, G), float("nan"), device="cuda"); Ri = torch.full((B * n, G), float("nan"), device="cuda")
-    Rq = torch.full((B, G), float("nan"), device="cuda")
-    H.pair_reduce_from_chain(rj_part, ri_part, Rj, Ri, Rq, B, n, G)
-    torch.cuda.synchronize()
-    assert torch.equal(full[1], part[1]) and torch.equal(full[2], part[2])
-    assert not torch.isnan(rj_part).any() and not torch.isnan(ri_part).any()
-    dz0 = full[3].double().view(B, n, n, G)                             # (b, i, j, f)
-    ref_j, ref_i, ref_q = dz0.sum(1).reshape(B * n, G), dz0.sum(2).reshape(B * n, G), dz0.sum((1, 2))
-    for name, got, ref in (("Rj", Rj, ref_j), ("Ri", Ri, ref_i), ("Rq", Rq, ref_q)):
-        e = float((got.double() - ref).abs().max() / ref.abs().max())
-        print(name, e)
-        assert e <= 1e-3, (name, e)
-    # deterministic
-    rj2 = torch.empty_like(rj_part); ri2 = torch.empty_like(ri_part)
-    H.g_chain_bwd_rr_reduce(dxg, masks, Wt, part, rj2, ri2, n, M, G)
-    torch.cuda.synchronize()
-    assert torch.equal(rj_part, rj2) and torch.equal(ri_part, ri2)
-
-
 def test_wgrad_fp8_operand(H):
     """The activation operand as an e4m3 image (a_dtype = RN_FP8): every e4m3 value is a bf16 value and both images put a pair
     row into the same MFMA k slot, so the kernel must give -- bitwise -- what it gives on the same values stored as bf16."""
@@ -1055,11 +1015,8 @@ def test_conv_bn_relu_block(N, hw):
     b.load_state_dict(a.state_dict())
     img = torch.rand(N, 3, hw, hw, device="cuda")
     tgt = torch.randn(N, 24, hw // 16, hw // 16, device="cuda")
-    os.environ["RN_NO_FUSED_BN"] = "1"
-    try:
+    with pkg.options.override(fused_bn=False):
         ya = a(img)
-    finally:
-        os.environ.pop("RN_NO_FUSED_BN")
     yb = b(img)
     assert rel(yb.detach().cpu().numpy(), ya.detach().cpu().numpy()) <= F32_TOL
     (ya * tgt).sum().backward()
@@ -1077,11 +1034,8 @@ def test_conv_bn_relu_block(N, hw):
     # evaluation mode: running statistics
     a.eval(); b.eval()
     with torch.no_grad():
-        os.environ["RN_NO_FUSED_BN"] = "1"
-        try:
+        with pkg.options.override(fused_bn=False):
             ea = a(img)
-        finally:
-            os.environ.pop("RN_NO_FUSED_BN")
         eb = b(img)
     assert rel(eb.cpu().numpy(), ea.cpu().numpy()) <= F32_TOL
 
@@ -1098,11 +1052,8 @@ def test_question_lstm(B, T):
     b.load_state_dict(a.state_dict())
     q = torch.from_numpy(formula.hash_ints((B, T), 900, 0, formula.QDICT + 1)).cuda()
     tgt = torch.randn(B, 128, device="cuda")
-    os.environ["RN_NO_FUSED_LSTM"] = "1"
-    try:
+    with pkg.options.override(fused_lstm=False):
         ha = a(q)
-    finally:
-        os.environ.pop("RN_NO_FUSED_LSTM")
     hb = b(q)
     assert rel(hb.detach().cpu().numpy(), ha.detach().cpu().numpy()) <= F32_TOL
     (ha * tgt).sum().backward()

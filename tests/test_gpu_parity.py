@@ -138,17 +138,20 @@ def test_relational_layer_f16s_parity(pkg, tag):
     assert e_dx <= 2e-2 and e_dq <= 2e-2 and e_b <= 1.2e-2, (e_dx, e_dq, e_b)
 
 
-@pytest.mark.parametrize("tag", ["G-fp64", "G-fp-small", "G-drop", "G-ir64", "G-ir-small"])
+@pytest.mark.parametrize("tag", ["G-fp64", "G-fp-small", "G-drop", "G-ir64", "G-ir-small", "G-sd4", "G-irsd4", "G-fp196"])
 def test_headline_mode_is_the_module_default_and_meets_the_bar(pkg, tag):
-    """precision="auto" -- what a user who touches nothing gets, and what bench.py reports as `value` -- resolves to
-    the parity-clean mode on the headline shape family: log-probs within 2e-4 of the reference (bar: 1e-3), same answers."""
+    """precision="auto" -- what a user who touches nothing gets, and what bench.py reports as `value` -- is parity-clean on EVERY
+    fixture: "f16s" on the headline shape family (four 256-wide g layers, whole tiles), "fp32" where no f16s kernel covers the shape
+    (the 512-wide *-sd models of config.json, the ragged B = 2 pair count of the 14 x 14 grid) -- never single-pass bf16.
+    Log-probs within 2e-4 of the reference (bar: 1e-3), same answers."""
     g = gold.load(tag)
     hyp = formula.HYP[g["meta"]["cfg"]]
     rl = pkg.RelationalLayer(hyp["rl_in_size"], formula.ADICT, hyp["lstm_hidden"], dict(hyp))
-    assert rl.precision == "auto" and rl.resolved_precision(g["meta"]["b"], g["meta"]["n"], hyp["rl_in_size"] // 2) == "f16s"
+    resolved = rl.resolved_precision(g["meta"]["b"], g["meta"]["n"], hyp["rl_in_size"] // 2)
+    assert rl.precision == "auto" and resolved == ("fp32" if tag in ("G-sd4", "G-irsd4", "G-fp196") else "f16s")
     lp, loss, dx, dq, grads = run_rl(pkg, g, "auto")
     e_lp = gold.rel_err(lp, g["log_probs"])
-    report(tag, precision="auto", log_probs=e_lp)
+    report(tag, precision="auto", resolved=resolved, log_probs=e_lp)
     assert e_lp <= 2e-4 and (lp.argmax(1) == g["log_probs"].argmax(1)).all()
 
 
@@ -162,9 +165,9 @@ def test_e4m3_activation_copies_touch_only_the_g_weight_gradients(pkg, tag, prec
     every touched tensor against the fp32 reference (sampled entries + norm for the full-size fixtures) is measured and reported,
     and must stay inside the mode's own band."""
     g = gold.load(tag)
-    monkeypatch.setenv("RN_H8", "0")
+    monkeypatch.setattr(pkg.options.OPT, "h8", False)
     lp0, loss0, dx0, dq0, gr0 = run_rl(pkg, g, precision)
-    monkeypatch.setenv("RN_H8", "1")
+    monkeypatch.setattr(pkg.options.OPT, "h8", True)
     lp1, loss1, dx1, dq1, gr1 = run_rl(pkg, g, precision)
     assert np.array_equal(lp0, lp1) and np.array_equal(dx0, dx1) and np.array_equal(dq0, dq1)
     touched = {"g_layers.%d.weight" % l for l in (1, 2, 3)} | {"g_layers.3.bias"}
@@ -190,37 +193,6 @@ def test_e4m3_activation_copies_touch_only_the_g_weight_gradients(pkg, tag, prec
            ref_err_e4m3={k: v[2] for k, v in rep.items()})
 
 
-@pytest.mark.parametrize("tag", ["G-fp64", "G-ir64"])
-def test_in_chain_pair_reduction_end_to_end(pkg, tag, monkeypatch):
-    """RN_CHAIN_REDUCE=1: the first layer's gradient matrix is never stored, the backward chain reduces it over the pair axes on
-    chip (rn_g_chain_bwd_rr_reduce).  Log-probs and the gradients of layers 1..3 / f_phi bitwise those of the default path; dx,
-    dq, dW_0, db_0 (all from the reductions) within the mode's band of the reference and within 2e-3 of the default path (the
-    in-chain sums add un-rounded fp32 values instead of the stored bf16 ones)."""
-    g = gold.load(tag)
-    monkeypatch.setenv("RN_CHAIN_REDUCE", "0")
-    lp0, loss0, dx0, dq0, gr0 = run_rl(pkg, g, "f16s")
-    monkeypatch.setenv("RN_CHAIN_REDUCE", "1")
-    lp1, loss1, dx1, dq1, gr1 = run_rl(pkg, g, "f16s")
-    assert np.array_equal(lp0, lp1)
-    from_red = {"g_layers.0.weight", "g_layers.0.bias"}
-    for k in gr0:
-        if k in from_red:
-            assert 0 < l2rel(gr1[k], gr0[k]) <= 2e-3, k
-        else:
-            assert np.array_equal(gr0[k], gr1[k]), k
-    assert 0 < l2rel(dx1, dx0) <= 2e-3
-    if tag == "G-fp64":                                      # (ir: dq comes from the injected layer's reduction, untouched)
-        assert 0 < l2rel(dq1, dq0) <= 2e-3
-    e_dx, e_dq = l2rel(dx1, g["dx"]), l2rel(dq1, g["dq"])
-    e_b = max(l2rel(gr1[k[5:]], g[k]) for k in g if k.startswith("grad/"))
-    report(tag, precision="f16s", chain_reduce=1, dx_l2=e_dx, dq_l2=e_dq, params_l2=e_b, dx_default=l2rel(dx0, g["dx"]))
-    # gradients: the backward pass of a ReLU network depends on the forward pass through the GATES only; one-pass fp16 weights
-    # (2^-12 relative per row -- the dithering averages over tiles, not inside a row) flip the gate of ~1e-3 of the units, those
-    # whose pre-activation is rounding noise.  Measured dx / dq 1.4e-2 / 1.2e-2 on G-fp64 (two passes on every layer: 4.7e-3 /
-    # 2.9e-3; the bf16 mode: up to 1.2e-1, BF16_GRAD_L2) -- noise, not bias: test_training_trajectory pins the consequence.
-    assert e_dx <= 2e-2 and e_dq <= 2e-2 and e_b <= 1.2e-2, (e_dx, e_dq, e_b)
-
-
 def test_injected_layer_question_sums_from_the_wgrad_partials(pkg, monkeypatch):
     """ir-*: the per-question sums of the injected layer's gradient (Rq -> dq and the question columns of dW_2) come from the
     streaming wgrad kernel's per-split column sums instead of a pair-reduction pass over dZ_2 (RN_NO_RQ_FROM_WGRAD=1): the same
@@ -228,9 +200,9 @@ def test_injected_layer_question_sums_from_the_wgrad_partials(pkg, monkeypatch):
     not produce is bitwise the same (its row splits are question-aligned only when Rq is taken from them: other summation order
     for dW / db of layers 1..3)."""
     g = gold.load("G-ir64")
-    monkeypatch.setenv("RN_NO_RQ_FROM_WGRAD", "1")
+    monkeypatch.setattr(pkg.options.OPT, "rq_from_wgrad", False)
     lp0, loss0, dx0, dq0, gr0 = run_rl(pkg, g, "f16s")
-    monkeypatch.setenv("RN_NO_RQ_FROM_WGRAD", "0")
+    monkeypatch.setattr(pkg.options.OPT, "rq_from_wgrad", True)
     lp1, loss1, dx1, dq1, gr1 = run_rl(pkg, g, "f16s")
     assert np.array_equal(lp0, lp1) and np.array_equal(dx0, dx1)
     assert 0 < l2rel(dq1, dq0) <= 1e-5
@@ -306,11 +278,13 @@ def test_released_checkpoints_load_and_match(pkg, tag, precision, tol):
         assert agree == 1.0
 
 
-def test_extraction_hooks(pkg):
-    """extract.py:49-74: hook on the INPUT of g_layers[2] of an ir-fp model built with extraction=True."""
+@pytest.mark.parametrize("precision", ["fp32", "auto", "f16s"])
+def test_extraction_hooks(pkg, precision):
+    """extract.py:49-74: hook on the INPUT of g_layers[2] of an ir-fp model built with extraction=True.  Under the default mode
+    ("auto") and under "f16s" the hooked chain runs the parity-clean per-layer kernels: the same fp32-accurate features."""
     g = gold.load("G-extract")
     meta = g["meta"]
-    hyp = dict(formula.HYP[meta["cfg"]], precision="fp32")
+    hyp = dict(formula.HYP[meta["cfg"]], precision=precision)
     b, n, k, Q = meta["b"], 64, hyp["rl_in_size"] // 2, hyp["lstm_hidden"]
     rl = pkg.RelationalLayer(hyp["rl_in_size"], formula.ADICT, Q, hyp, extraction=True)
     rl.load_state_dict({k_: torch.from_numpy(v) for k_, v in formula.formula_rl_state(hyp, meta["seed"]).items()})
@@ -328,7 +302,7 @@ def test_extraction_hooks(pkg):
     assert gold.rel_err(got["max"], g["max"]) <= 1e-4 and gold.rel_err(got["avg"], g["avg"]) <= 1e-4
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 2e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("auto", 1e-4), ("f16s", 1e-4), ("bf16", 2e-2)])
 def test_extraction_native_op(pkg, precision, tol):
     """the same features from the native op (RelationalLayer.extract_features -> rn_pair_features), no hook,
     nothing materialised in fp32.  bf16 tolerance: the activations themselves carry bf16 rounding (2^-8 relative per element)."""
@@ -496,8 +470,7 @@ def test_fused_coordinate_tagging_equals_the_concatenated_path(pkg, cfg, precisi
     lab = torch.from_numpy(formula.hash_ints((8,), 323, 0, formula.ADICT)).cuda()
 
     def run(fast):
-        os.environ["RN_NO_GRID_FAST"] = "0" if fast else "1"
-        try:
+        with pkg.options.override(grid_fast=fast):
             torch.manual_seed(9)
             m = pkg.RN(Args, dict(formula.HYP[cfg], precision=precision, dropout=0.0)).cuda()
             m.train()
@@ -506,8 +479,6 @@ def test_fused_coordinate_tagging_equals_the_concatenated_path(pkg, cfg, precisi
             loss.backward()
             torch.cuda.synchronize()
             return lp.detach().clone(), float(loss.detach()), {n_: p_.grad.clone() for n_, p_ in m.named_parameters()}
-        finally:
-            os.environ.pop("RN_NO_GRID_FAST", None)
 
     lp_a, loss_a, g_a = run(True)
     lp_b, loss_b, g_b = run(False)

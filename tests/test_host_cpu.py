@@ -56,6 +56,36 @@ def test_library_exports_every_declared_symbol(pkg):
     assert loaded.rn_wgrad_blocked_ws_bytes(64 * 4096, 4096, 3, 0) == 3 * (21 * 65536 + 21 * 4 * 256) * 4
 
 
+def test_library_and_hot_path_never_read_the_environment(pkg):
+    """dispatch must not depend on the process environment at call time.  The product librn_hip.so does not even
+    import getenv (kernel-variant knobs and timing ablations exist in RN_DIAG builds only, behind rn_diag_env); the Python side
+    reads the RN_* variables ONCE, at import, into options.OPT."""
+    import subprocess
+    und = subprocess.run(["nm", "-D", "--undefined-only", pkg.rn_hip.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in und
+    csrc = os.path.join(ROOT, "relationnetworks-clevr_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        src = open(os.path.join(csrc, f)).read()
+        if f == "rn_common.h":
+            assert src.count("getenv(") == 1 and "#ifdef RN_DIAG" in src            # the one call, inside the diagnostics helper
+        else:
+            assert "getenv(" not in src, f
+    pk = os.path.join(ROOT, "relationnetworks-clevr_amd")
+    for f in sorted(os.listdir(pk)):
+        if f.endswith(".py") and f not in ("options.py", "_build.py", "train.py"):   # (train.py: torchrun's RANK / WORLD_SIZE in main())
+            assert "environ" not in open(os.path.join(pk, f)).read(), f
+    O = pkg.options
+    assert O.OPT.h8 is True and O.OPT.precision == "auto" and O.OPT.non_default() == {}
+    o2 = O.Options({"RN_H8": "0", "RN_NO_RR_CHAIN": "1", "RN_WGRAD_LATE": "2", "RN_PRECISION": "fp32", "RN_NO_FUSED_BN": "0"})
+    assert (o2.h8, o2.rr_chain, o2.wgrad_late, o2.precision, o2.fused_bn) == (False, False, 2, "fp32", True)
+    with O.override(h8=False):
+        assert O.OPT.h8 is False
+    assert O.OPT.h8 is True
+    with pytest.raises(AttributeError):
+        with O.override(no_such_option=1):
+            pass
+
+
 def test_argument_validation_without_gpu(pkg):
     lib = pkg.rn_hip.load()
     rc = lib.rn_pair_build_fwd(None, 0, 0, 0, None, 0, None, 0, 1, 1, 1, 0, 64, None)

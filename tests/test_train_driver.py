@@ -120,7 +120,7 @@ def test_training_trajectory_matches_reference(T, fused_opt, mode, monkeypatch):
     import relationnetworks_clevr_amd as pkg
     from relationnetworks_clevr_amd import dp
     precision, h8, l_tol, n_tol, p_tol = TRAJ_MODES[mode]
-    monkeypatch.setenv("RN_H8", h8)
+    monkeypatch.setattr(pkg.options.OPT, "h8", h8 == "1")
     g = gold.load("G-traj")
     meta = g["meta"]
     hyp = dict(formula.HYP[meta["cfg"]], dropout=0.0, precision=precision)
@@ -388,7 +388,7 @@ def test_in_graph_clip_adam_follows_the_eager_optimiser_and_an_lr_schedule(T, mo
     img, q, y = T.load_tensor_data(batch, "cuda")
 
     def run(in_graph):
-        monkeypatch.setenv("RN_NO_GRAPH_ADAM", "0" if in_graph else "1")
+        monkeypatch.setattr(pkg.options.OPT, "graph_adam", in_graph)
         torch.manual_seed(0)
         m = pkg.RN(A, dict(formula.HYP["original-fp"], dropout=0.0)).cuda()
         opt = torch.optim.Adam(m.parameters(), lr=3e-4, weight_decay=1e-4)
