@@ -182,6 +182,11 @@ size_t rn_pair_sum_ws_bytes(int B, int npairs, int G);
 int rn_pair_sum_fwd(const void* HL, int ldh, float* xg, void* ws, int dtype, int B, int npairs, int G,
                     void* stream);
 
+/* ... of the two-rows-per-tile partials of rn_g_chain_fwd_rr_f16s_alg0 with a padded j axis: part (M / 256 * 2, 256) fp32, row
+ * 2 t + s = the sum over the rows of tile t that belong to question floor(256 t / rows_per_question) + s;
+ * xg[b, :] = the sum of its tiles' rows, in tile order.  M % rows_per_question == 0, M % 256 == 0. */
+int rn_pair_sum_tiles(const float* part, float* xg, int M, int rows_per_question, int G, void* stream);
+
 /* Backward of K3 fused with the last layer's ReLU gate:
  * dZ[b*npairs+p, c] = dxg[b, c] * (HL[b*npairs+p, c] > 0). */
 int rn_pair_sum_bwd(const float* dxg, const void* HL, int ldh, void* dZ, int lddz, int dtype, int B,
@@ -243,9 +248,11 @@ int rn_blocked_question_sums(const void* img, float* Rq, int M, int rows_per_que
  * of a g layer's pre-activation over the pair axes instead of materialising dP:
  *   Rj[b,j,:] = sum_i dZ[(b,i,j),:]   Ri[b,i,:] = sum_j dZ[(b,i,j),:]   Rq[b,:] = sum_ij dZ[(b,i,j),:]
  * Any of Rj / Ri / Rq may be NULL.  Outputs fp32; Rj, Ri: (B,n,G); Rq: (B,G). */
+/* njp >= n: pair rows per (question, i) group -- n for the plain n*n pair matrix, 32 ceil(n / 32) for the padded pair space of
+ * rn_g_chain_fwd_rr_f16s_alg0 (row (b, i, j) at (b*n + i) * njp + j; the rows j >= n are not read). */
 size_t rn_pair_reduce_ws_bytes(int B, int n, int G);
 int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri, float* Rq, void* ws, int dtype, int B,
-                       int n, int G, void* stream);
+                       int n, int njp, int G, void* stream);
 
 /* Input gradients of the pair expansion from the reductions, one launch (question injected at layer 0; W0 (N, 2k+Q) fp32):
  *   dx[b, j, c] = (Rj W0[:, 0:k] + Ri W0[:, k:2k])[b*n + j, c] for c < kout, written at element strides (sdb, sdn, sdk) -- e.g.
@@ -418,7 +425,14 @@ int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* co
  * Wf[2] / Whi[2], Wlo[2] hold W_2[:, 0:256] only, bias[2] is ignored.  Needs n*n % 256 == 0. */
 /* h_dtype: the type of the stored H_0..2 rows -- RN_BF16 (M x 256 bf16) or RN_FP8 (M x 256 e4m3 bytes, value = byte value), both as
  * ROW-BLOCKED images (the only reader is rn_g_wgrad_blocked).  Ignored when H is NULL. */
-int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, const void* const* Whi, const void* const* Wlo, int dither,
+/* njp: pair rows per (question, i) group.  njp == n: the pair rows are the n*n pairs of model.py:117-127 (n % 32 == 0).
+ * njp = 32 ceil(n / 32) > n (n % 4 == 0; e.g. the 14 x 14 grid, n = 196 -> 224): the j axis is PADDED -- pair row m = (b, i, j)
+ * with j = m mod njp, M = B * n * njp; rows with j >= n are invalid (they multiply the all-zero object row Xp16[B * n], which the
+ * caller provides; their mask bits are cleared in every layer and they are left out of the pair sums), H / mask cover the M
+ * padded rows, and xg_part holds TWO partial rows per 256-row tile, (M / 256 * 2, 256) -- reduce with rn_pair_sum_tiles.  The
+ * backward side (rn_g_chain_bwd_rr with rows_per_question = n * njp, rn_g_wgrad_blocked, rn_pair_reduce_bwd with njp) then sees
+ * zero gradients for the invalid rows without knowing about the padding.  Question at layer 0 only. */
+int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, int njp, const void* const* Whi, const void* const* Wlo, int dither,
                                 const float* const* bias, void* const* H, int h_dtype, void* const* mask, float* xg_part,
                                 const float* Vq, int inject_layer, int M, int L, int G, void* stream);
 int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, const void* const* Wf, const float* const* bias, void* const* H,

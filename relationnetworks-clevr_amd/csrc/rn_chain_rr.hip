@@ -712,11 +712,20 @@ struct F16Vm {
 // ABL (RN_DIAG builds only: timing ablations, WRONG results) -- 1: no bias rows (the block's first MFMA starts from zero), 2: no
 // barriers, 4: no waits for the weight stream, 8: no copy-out (no staging reads, no H stores), 16: no mask stores, 32: no epilogue
 // at all, 64: no weight requests
-template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false, int ABL = 0>
+// RAG (ALG0, question at layer 0) -- object counts that are no multiple of 32 (the 14 x 14 grid: n = 196): the j axis of every
+// (question, i) group is PADDED to njp = 32 ceil(n / 32) pair rows, so that a wave still lies inside one group (one Vc bias
+// row) and the factored first layer applies -- no 443-MB pair matrix, K = 64 instead of 192 on layer 0, no stored H_3.  Row m of
+// the padded pair space = (b, i, j) with j = m mod njp; rows with j >= n read an all-zero object row (index n_zero of Xp) and
+// are INVALID: their ReLU lane-mask bits are cleared in every layer (the backward chain, the gate job and the pair reductions
+// then see zero gradients for them without knowing about the padding) and they are left out of the pair sum.  A 256-row tile
+// may straddle two questions at a wave boundary: it leaves TWO partial rows (rn_pair_sum_tiles adds them up per question).
+template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false, int ABL = 0, bool RAG = false>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __restrict__ P, int ldp, RRArgsF a,
                                                                 float* __restrict__ xg_part, int ntiles,
                                                                 const float* __restrict__ Vc = nullptr, int n_obj = 0,
-                                                                const float* __restrict__ Vq = nullptr, int rows_per_b = 1) {
+                                                                const float* __restrict__ Vq = nullptr, int rows_per_b = 1,
+                                                                int njp = 0, int n_zero = 0) {
+  static_assert(!RAG || (ALG0 && INJ == 0 && XG), "padded j axis: the factored first layer with the question at layer 0");
   static_assert(INJ >= 0 && INJ < RR_L - 1, "the injected layer is one of the swapped-operand layers");
   static_assert(!H8 || STORE, "e4m3 copies of H_0..2 (a stored H_3 stays bf16: the pair sum reads it)");
   typedef F16Vm<NK0, STORE, ST3, XG, ALG0, INJ, H8> Vm;
@@ -747,8 +756,19 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
     return (long)b * n_obj + (r - i * n_obj);
   };
   auto vc_row = [&](long m0w_) -> long {
+    if constexpr (RAG) return m0w_ / njp;                             // (b, i) group of the wave: b * n + i
     const int nn = n_obj * n_obj, b = (int)(m0w_ / nn), r = (int)(m0w_ - (long)b * nn);
     return (long)b * n_obj + r / n_obj;
+  };
+  // RAG: this lane's object row of Xp for the wave that starts at padded pair row m0w_ (j = jw + n; beyond the n objects: the zero row)
+  auto rag_load = [&](long m0w_, int ks) -> Frag {
+    const int bi = (int)(m0w_ / njp), jw = (int)(m0w_ - (long)bi * njp), j = jw + n;
+    const int row = j < n_obj ? (bi / n_obj) * n_obj + j : n_zero;
+    return *reinterpret_cast<const Frag*>(reinterpret_cast<const unsigned char*>(P) + ((long)row * ldp + 8 * h) * 2 + 32 * ks);
+  };
+  auto in_frag = [&](long m0w_, int ks) -> Frag {
+    if constexpr (RAG) return rag_load(m0w_, ks);
+    else return load_row_frag(op_row(m0w_), ks);
   };
   float* const vc_s = reinterpret_cast<float*>(lds + RR_OFF_VC) + w * RR_G;
   auto vc_load = [&](long m0w_) -> f32x4 { return *reinterpret_cast<const f32x4*>(Vc + vc_row(m0w_) * RR_G + lane * 4); };
@@ -774,7 +794,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
 #pragma unroll
     for (int i = 0; i < Vm::dpw(0); ++i) dma_piece(0, s, s, i, tile);
 #pragma unroll
-  for (int ks = 0; ks < NK0; ++ks) actA[ks] = load_row_frag(op_row((long)tile * RR_TM + RR_WR * w), ks);
+  for (int ks = 0; ks < NK0; ++ks) actA[ks] = in_frag((long)tile * RR_TM + RR_WR * w, ks);
   if constexpr (ALG0) *reinterpret_cast<f32x4*>(vc_s + lane * 4) = vc_load((long)tile * RR_TM + RR_WR * w);
   if (t < RR_G) {
 #pragma unroll
@@ -797,6 +817,20 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
     float xs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) xs[i] = 0.f;
+    // RAG: valid rows of this wave = the first nv (a multiple of 4; 32 for all but a group's last wave).  Lane masks: swapped
+    // layers 0..2 have lane = row (both lane halves), the last layer accumulator group j' of lane half hh = rows 8 j' + 4 hh + r
+    u64 vm012 = ~0ull, vm3[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    float keep3[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (RAG) {
+      const int jw = (int)(m0w % njp), nv = (n_obj - jw) < RR_WR ? (n_obj - jw) : RR_WR;
+      const u64 lo = nv >= 32 ? 0xffffffffull : ((1ull << nv) - 1ull);
+      vm012 = lo | (lo << 32);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        vm3[jj] = (8 * jj < nv ? 0x00000000ffffffffull : 0ull) | (8 * jj + 4 < nv ? 0xffffffff00000000ull : 0ull);
+        keep3[jj] = (8 * jj + 4 * h < nv) ? 1.f : 0.f;
+      }
+    }
 
     auto bias_read = [&](int l, int ob) {
 #pragma unroll
@@ -808,8 +842,11 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
       }
     };
     auto mask_out = [&](int pl, int pob, int j, float x0, float x1, float x2, float x3) {
-      if constexpr (MASK && !(ABL & 16)) mask_store4(a.mask[pl] + (wt * 8 + pob) * 16 + 4 * j, __ballot(x0 > 0.f), __ballot(x1 > 0.f),
-                                                     __ballot(x2 > 0.f), __ballot(x3 > 0.f));
+      if constexpr (MASK && !(ABL & 16)) {
+        const u64 vm = !RAG ? ~0ull : (pl == RR_L - 1 ? vm3[j] : vm012);
+        mask_store4(a.mask[pl] + (wt * 8 + pob) * 16 + 4 * j, __ballot(x0 > 0.f) & vm, __ballot(x1 > 0.f) & vm, __ballot(x2 > 0.f) & vm,
+                    __ballot(x3 > 0.f) & vm);
+      }
     };
     // phases of group j: 0 masks, 1 fp16 operand of the next layer, 2 bf16 copy for HBM, 3 staging write
     auto epi_group = [&](int pl, int pob, int j, int ph, Frag* dst, u32x2 (&pk)[4]) {
@@ -866,7 +903,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
         for (int r = 0; r < 4; ++r) v[j][r] = fmaxf(acc[pob & 1][4 * j + r] + b3, 0.f);
       }
       if (ph == 1) {
-        if constexpr (XG) xs[pob] += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        if constexpr (XG && RAG) xs[pob] += keep3[j] * ((v[j][0] + v[j][1]) + (v[j][2] + v[j][3]));
+        else if constexpr (XG) xs[pob] += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
         mask_out(RR_L - 1, pob, j, v[j][0], v[j][1], v[j][2], v[j][3]);
       }
       if (ph == 2) {
@@ -947,7 +985,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
           if (has_co && c == CO2) co_store(cl, cob, 1);
           if (l == RR_L - 1 && (c & 1) == 0 && (c >> 1) < Vm::PF_PER) {
             const int i = ob * Vm::PF_PER + (c >> 1);
-            if (i < NK0) out[i] = load_row_frag(op_row(m0n), i);
+            if (i < NK0) out[i] = in_frag(m0n, i);
           }
           if (ALG0 && sidx == Vm::VC_STAGE && c == 1) vcreg = vc_load(m0n);
           if (INJ > 0 && sidx == Vm::VQ_STAGE && c == 1) vqreg = vq_load(tnext);
@@ -992,7 +1030,23 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (h == 0) {
+        if constexpr (RAG) {
+          // the tile's waves belong to at most two questions (a question = n_obj groups of njp / 32 waves): one partial row each
+          if (h == 0) {
+            const long rpq = (long)n_obj * njp;
+            const long q0 = ((long)tile * RR_TM) / rpq;
+            const int bw = (int)((((q0 + 1) * rpq - (long)tile * RR_TM) + RR_WR - 1) / RR_WR);      // waves of the first question (>= 1)
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < RR_NW; ++q) {
+              const float x = xs_s[q * RR_G + 32 * w + n];
+              if (q < bw) v0 += x;
+              else v1 += x;
+            }
+            xg_part[((long)tile * 2) * RR_G + 32 * w + n] = v0;
+            xg_part[((long)tile * 2 + 1) * RR_G + 32 * w + n] = v1;
+          }
+        } else if (h == 0) {
           float v = xs_s[32 * w + n];
 #pragma unroll
           for (int q = 1; q < RR_NW; ++q) v += xs_s[q * RR_G + 32 * w + n];
@@ -1420,7 +1474,7 @@ extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* cons
 }
 
 // f16s arithmetic on the factored first layer (see g_chain_rr_kernel, ALG0): Xp16 = fp16 object rows (B*n, 64).
-extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, const void* const* Whi, const void* const* Wlo, int dither,
+extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, int njp, const void* const* Whi, const void* const* Wlo, int dither,
                                            const float* const* bias, void* const* H, int h_dtype, void* const* mask, float* xg_part,
                                            const float* Vq, int inject_layer, int M, int L, int G, void* stream) {
   RN_CHECK_ARG(Xp16 && Vc && Whi && Wlo && bias && M > 0 && xg_part, "rn_g_chain_fwd_rr_f16s_alg0: bad pointer/size");
@@ -1428,8 +1482,11 @@ extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, in
   const bool h8 = H && h_dtype == RN_FP8;
   if (int rc = rr_check_inject("rn_g_chain_fwd_rr_f16s_alg0", Vq, inject_layer, n)) return rc;
   RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_fwd_rr_f16s_alg0: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
-  RN_CHECK_ARG(n > 0 && n % RR_WR == 0 && M % ((long)n * n) == 0 && M % RR_TM == 0,
-               "rn_g_chain_fwd_rr_f16s_alg0: needs n %% %d == 0 and M a multiple of n*n and of %d (n=%d M=%d)", RR_WR, RR_TM, n, M);
+  const bool rag = njp != n;                                          // padded j axis (see g_chain_rr_f16s_kernel, RAG)
+  RN_CHECK_ARG(n > 0 && njp >= n && njp - n < RR_WR && njp % RR_WR == 0 && (!rag || n % 4 == 0) && M % ((long)n * njp) == 0 && M % RR_TM == 0,
+               "rn_g_chain_fwd_rr_f16s_alg0: needs njp = 32 ceil(n / 32) (n %% 4 == 0 when padded) and M a multiple of n*njp and of %d (n=%d njp=%d M=%d)",
+               RR_TM, n, njp, M);
+  RN_CHECK_ARG(!rag || inject_layer == 0, "rn_g_chain_fwd_rr_f16s_alg0: a padded j axis goes with the question at layer 0");
   RN_CHECK_ARG(((uintptr_t)Xp16 | (uintptr_t)Vc) % 16 == 0, "rn_g_chain_fwd_rr_f16s_alg0: tables must be 16-byte aligned");
   RRArgsF a;
   int nh = 0, nm = 0;
@@ -1441,7 +1498,12 @@ extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, in
   hipStream_t s = (hipStream_t)stream;
   const int rpb = n * n;
   const f16* Xp = (const f16*)Xp16;
-  if (inject_layer == 2) {
+  if (rag) {
+    const int nz = (M / (n * njp)) * n;                               // the all-zero object row behind the B * n real ones
+    if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true, 0, false, 0, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, nullptr, 1, njp, nz);
+    else if (h8) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, true, 0, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, nullptr, 1, njp, nz);
+    else g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, false, 0, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, nullptr, 1, njp, nz);
+  } else if (inject_layer == 2) {
     if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true, 2><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
     else if (h8) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 2, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
     else g_chain_rr_f16s_kernel<4, true, false, true, true, true, 2><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);

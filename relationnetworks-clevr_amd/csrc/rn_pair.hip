@@ -346,6 +346,28 @@ extern "C" int rn_pair_sum_bwd(const float* dxg, const void* HL, int ldh, void* 
   return 0;
 }
 
+// ---- x_g from the two-rows-per-tile partials of the padded-j forward chain (rn_g_chain_fwd_rr_f16s_alg0, njp > n)
+__global__ __launch_bounds__(256) void pair_sum_tiles_kernel(const float* __restrict__ part, float* __restrict__ xg, long rpq, int G) {
+  const int b = blockIdx.x;
+  const long t0 = (long)b * rpq / 256, t1 = ((long)(b + 1) * rpq - 1) / 256;          // tiles that hold rows of question b
+  for (int f = threadIdx.x; f < G; f += 256) {
+    float acc = 0.f;
+    for (long t = t0; t <= t1; ++t) {
+      const long q0 = t * 256 / rpq;                                                    // first question of the tile: its row 0
+      acc += part[(2 * t + (q0 == b ? 0 : 1)) * G + f];
+    }
+    xg[(long)b * G + f] = acc;
+  }
+}
+
+extern "C" int rn_pair_sum_tiles(const float* part, float* xg, int M, int rows_per_question, int G, void* stream) {
+  RN_CHECK_ARG(part && xg && M > 0 && rows_per_question >= 256 && M % rows_per_question == 0 && M % 256 == 0 && G > 0,
+               "rn_pair_sum_tiles: needs M %% 256 == 0 and rows_per_question >= 256 dividing M (M=%d, rows_per_question=%d)", M, rows_per_question);
+  pair_sum_tiles_kernel<<<M / rows_per_question, 256, 0, (hipStream_t)stream>>>(part, xg, rows_per_question, G);
+  RN_LAUNCH_CHECK("rn_pair_sum_tiles");
+  return 0;
+}
+
 // ---------------------------------------- backward of the pair expansion (reductions)
 // Rj[b,j,:] = sum_i dZ[(b,i,j),:]   Ri[b,i,:] = sum_j dZ[(b,i,j),:]   Rq[b,:] = sum_i Ri[b,i,:]
 // ONE pass over dZ (HBM-bound: it is read exactly once).  Workgroup = (block of 16 j, question b); thread =
@@ -363,7 +385,7 @@ template <> struct Piece4<float> { typedef f32x4 Raw; static __device__ __forcei
 
 template <typename T, bool WANT_RJ>
 __global__ __launch_bounds__(256) void pair_reduce_kernel(const T* __restrict__ dZ, int ld, float* __restrict__ Rj,
-                                                          float* __restrict__ ri_part, int n, int G, long part_stride) {
+                                                          float* __restrict__ ri_part, int n, int njp, int G, long part_stride) {
   constexpr int CH = 4;                                               // columns per thread: 64 Rj accumulators, 16 small loads in flight
   constexpr int JB = 16;
   typedef typename Piece4<T>::Raw Raw;
@@ -387,7 +409,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const T* __restrict__ 
     constexpr int PD = 3;                                           // i's in flight per thread; <= 256 registers so that the workgroup fits NEXT TO a wgrad workgroup
     Raw v[PD][JB];
     auto issue = [&](Raw (&dst)[JB], int i) {
-      const T* base = dZ + (((long)b * n + i) * n + j0) * ld + c * CH;
+      const T* base = dZ + (((long)b * n + i) * njp + j0) * ld + c * CH;      // (njp pair rows per (b, i) group; the first n are read)
 #pragma unroll
       for (int j = 0; j < JB; ++j) dst[j] = *reinterpret_cast<const Raw*>(base + (long)(j < nj ? j : nj - 1) * ld);
     };
@@ -511,8 +533,8 @@ extern "C" size_t rn_pair_reduce_ws_bytes(int B, int n, int G) {
 }
 
 extern "C" int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri, float* Rq, void* ws, int dtype, int B,
-                                  int n, int G, void* stream) {
-  RN_CHECK_ARG(dZ && B > 0 && n > 0 && ws, "rn_pair_reduce_bwd: bad pointer/size");
+                                  int n, int njp, int G, void* stream) {
+  RN_CHECK_ARG(dZ && B > 0 && n > 0 && njp >= n && ws, "rn_pair_reduce_bwd: bad pointer/size (njp=%d must be >= n=%d)", njp, n);
   RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "rn_pair_reduce_bwd: bad dtype %d", dtype);
   const int CH = 4;
   RN_CHECK_ARG(G % CH == 0 && G / CH <= 256 && 256 % (G / CH) == 0 && lddz % (dtype == RN_BF16 ? 8 : 4) == 0, "rn_pair_reduce_bwd: G=%d unsupported", G);
@@ -527,7 +549,7 @@ extern "C" int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri
 #define RN_PR(T, RJ)                                                                                                   \
   do {                                                                                                                 \
     if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void*)pair_reduce_kernel<T, RJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-    pair_reduce_kernel<T, RJ><<<grid, 256, shm, s>>>((const T*)dZ, lddz, Rj, part, n, G, part_stride);                 \
+    pair_reduce_kernel<T, RJ><<<grid, 256, shm, s>>>((const T*)dZ, lddz, Rj, part, n, njp, G, part_stride);            \
   } while (0)
   if (dtype == RN_BF16) { if (Rj) RN_PR(bf16, true); else RN_PR(bf16, false); }
   else { if (Rj) RN_PR(float, true); else RN_PR(float, false); }

@@ -214,9 +214,19 @@ def inj_chain_ok(plan: LayerPlan, code, n, k, M):
             and plan.ktrue[2] == 256 + plan.Q and n % 32 == 0 and (n * n) % H.g_chain_rr_tile() == 0 and M % H.g_chain_rr_tile() == 0)
 
 
+def padded_j(n):
+    """Pair rows per (question, i) group on the factored-first-layer paths: n itself when a wave's 32 rows fit (n % 32 == 0), else
+    the next multiple of 32 -- the f16s chain then runs on a PADDED j axis (include/rn_hip.h, rn_g_chain_fwd_rr_f16s_alg0; the
+    14 x 14 grid: 196 -> 224) -- or None when that kernel does not cover n either (n % 4 != 0)."""
+    if n % 32 == 0:
+        return n
+    return _ru(n, 32) if n % 4 == 0 else None
+
+
 def f16s_ok(plan: LayerPlan, B, n):
-    """Shapes the "f16s" arithmetic (fp16 activations x split fp16 weights) has a kernel for."""
-    return fused_chain_ok(plan, H.RN_BF16, B, n) or inj_chain_ok(plan, H.RN_BF16, n, plan.k, B * n * n)
+    """Shapes the "f16s" arithmetic (fp16 activations x split / tile-dithered fp16 weights) has a kernel for."""
+    return (fused_chain_ok(plan, H.RN_BF16, B, n) or inj_chain_ok(plan, H.RN_BF16, n, plan.k, B * n * n)
+            or alg0_forward_ok(plan, H.RN_BF16, n, plan.k, B * n * n, f16s=True))
 
 
 def _h_copy_dtype(plan, dt, M):
@@ -233,10 +243,14 @@ def alg0_wgrad_ok(plan, k):
     return plan.inject == 0 and k <= 32 and OPT.algebraic_wgrad0
 
 
-def alg0_forward_ok(plan, code, n, k, M):
+def alg0_forward_ok(plan, code, n, k, M, f16s=False):
     """The factored first layer (rn_g_chain_fwd_rr_alg0): bf16 register-resident chains, question injected at layer 0,
-    whole waves per (question, i) and the algebraic layer-0 weight gradient in the backward pass (nothing reads P)."""
-    return (rr_chain_ok(plan, code) and plan.inject == 0 and k <= 32 and n % 32 == 0 and M % H.g_chain_rr_tile() == 0
+    whole waves per (question, i) -- f16s: on a padded j axis where n % 32 != 0 -- and the algebraic layer-0 weight gradient in
+    the backward pass (nothing reads P).  M = B * n * n."""
+    njp = padded_j(n)
+    if njp is None or (njp != n and not f16s):
+        return False
+    return (rr_chain_ok(plan, code) and plan.inject == 0 and k <= 32 and (M // n * njp) % H.g_chain_rr_tile() == 0
             and OPT.rr_masks and OPT.algebraic_wgrad0
             and OPT.algebraic_fwd0)
 
@@ -245,7 +259,8 @@ def _tables(x, q, plan, g_b, w0T, inj_w, xdt, B, n, k, Q, G, coord=None):
     """Tables of the factored first layer (+ the question rows of an injected later layer): -> (Xp, Vc, Vq | None, inject).
     coord (2, n): x is the conv grid itself (kf = k - 2 columns), the coordinate tags are read from the table in the kernel."""
     dev = x.device
-    Xp = torch.empty(B * n, 64, dtype=xdt, device=dev)
+    Xp = torch.empty(B * n + 1, 64, dtype=xdt, device=dev)       # (+ the all-zero object row the padded-j chain reads for j >= n)
+    Xp[B * n].zero_()
     Vc = torch.empty(B * n, G, dtype=torch.float32, device=dev)
     if inj_w is None:
         H.pair_tables(x, q, w0T, g_b[0], Xp, Vc, B, n, k, Q, G, coord=coord)
@@ -277,7 +292,7 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
     if split is not None:
         # "f16s": fp16 pair matrix + split fp16 weights through the fused chain; the bf16 pair matrix is only
         # needed by the backward pass (layer-0 wgrad)
-        if layer_hook is not None or not (fused_chain_ok(plan, code, B, n) or inj_w is not None):
+        if layer_hook is not None or not (fused_chain_ok(plan, code, B, n) or inj_w is not None or w0T is not None):
             raise RuntimeError('precision "f16s" needs a fused chain (bf16-class storage, all g widths 256, question injected at '
                                'layer 0 with B*n*n a multiple of 128 -- or at layer 2 with n*n a multiple of 256 --, no forward '
                                'hooks); use "bf16" or "fp32" here')
@@ -286,13 +301,21 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
             # factored first layer in the f16s arithmetic: fp16 object rows + fp32 bias rows, no pair matrix
             R = H.g_chain_rr_tile()                    # (one pair-sum partial row per 256-row tile on these paths)
             Xp, Vc, Vq, inj_l = _tables(x, q, plan, g_b, w0T, inj_w, torch.float16, B, n, k, Q, G, coord)
+            njp = n if inj_w is not None else padded_j(n)          # pair rows per (question, i) group: padded where n % 32 != 0
+            Mp = B * n * njp
             masks = Hs = None
             if keep_inputs:
-                Hs = [torch.empty(M, G, dtype=_h_copy_dtype(plan, dt, M), device=dev) for l in range(L - 1)] + [None]
-                masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device=dev))
-            part = torch.empty(M // R, G, dtype=torch.float32, device=dev)
-            H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, wfrag[0], wfrag[1][0], g_b, Hs, masks, part, M, G, Vq=Vq, inject=inj_l)
-            xg = _pair_sum_of(part, B, (n * n) // R, G, lazy_xg)
+                Hs = [torch.empty(Mp, G, dtype=_h_copy_dtype(plan, dt, Mp), device=dev) for l in range(L - 1)] + [None]
+                masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(Mp), dtype=torch.uint8, device=dev))
+            if njp != n:
+                part = torch.empty(Mp // R * 2, G, dtype=torch.float32, device=dev)      # two partial rows per tile (it may straddle questions)
+                H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, wfrag[0], wfrag[1][0], g_b, Hs, masks, part, Mp, G, njp=njp)
+                xg = torch.empty(B, G, dtype=torch.float32, device=dev)
+                H.pair_sum_tiles(part, xg, Mp, n * njp, G)
+            else:
+                part = torch.empty(M // R, G, dtype=torch.float32, device=dev)
+                H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, wfrag[0], wfrag[1][0], g_b, Hs, masks, part, M, G, Vq=Vq, inject=inj_l)
+                xg = _pair_sum_of(part, B, (n * n) // R, G, lazy_xg)
             if Hs is None:
                 return [None] * L, None, xg
             return [None] + Hs[:-1], RRMasks(masks), xg
@@ -497,7 +520,9 @@ class RelationalFunction(torch.autograd.Function):
         # images): whole waves per question, or -- waves straddling questions -- a stored H_3 (training only)
         rr_only = (rr_chain_ok(plan, code) and M % H.g_chain_rr_tile() == 0 and OPT.rr_masks
                    and ((n * n) % 32 == 0 or need_grad))
-        alg_fwd = rr_only and alg0_forward_ok(plan, code, n, k, M)
+        alg_fwd = alg0_forward_ok(plan, code, n, k, M, f16s=f16s)
+        njp = padded_j(n) if (alg_fwd and plan.inject == 0) else n           # (padded j axis: n % 32 != 0, f16s)
+        rr_only = rr_only or alg_fwd
         inj_fwd = inj_chain_ok(plan, code, n, k, M)        # question injected at layer 2: same chains, per-question bias row
         if inj_fwd:
             rr_only = alg_fwd = True
@@ -534,6 +559,7 @@ class RelationalFunction(torch.autograd.Function):
         ctx.label = label
         if need_grad:
             ctx.plan, ctx.code, ctx.dims = plan, code, (B, n, k, Q, M, G, F1, F2, A)
+            ctx.njp = njp if isinstance(HL, RRMasks) else n
             ctx.inj_path = inj_fwd
             ctx.coord = coord
             ctx.inputs, ctx.HL, ctx.wbwd = inputs, HL, wbwd
@@ -579,6 +605,8 @@ class RelationalFunction(torch.autograd.Function):
         inputs, wbwd, g_w = ctx.inputs, ctx.wbwd, ctx.g_w
         fused_bwd = fused_chain_ok(plan, code, B, n) and L >= 2 and OPT.fused_bwd
         rr_bwd = isinstance(ctx.HL, RRMasks)       # the register-resident chains: H_0..2 / dZ of layers 1..3 are row-blocked images
+        njp = ctx.njp                              # pair rows per (question, i) group: > n on the padded j axis (rr chains only)
+        Mc = B * n * njp                           # ... and the pair rows the chains / weight gradients work on
         if rr_bwd:
             # register-resident backward chain on the forward kernel's gates (one launch, no activation is re-read)
             fused_bwd = True
@@ -587,12 +615,12 @@ class RelationalFunction(torch.autograd.Function):
             # by the chain and 134 MB less read by the wgrad at the headline shape
             gated_mask = None
             # (needs the e4m3 H_2 image: the gate job runs on the fp8 matrix pipe; with 16-bit copies dZ_3 is stored)
-            if ((n * n) % 64 == 0 and inputs[L - 1].dtype in H.FP8_DTYPES and OPT.gated_wgrad):
+            if ((n * njp) % 64 == 0 and inputs[L - 1].dtype in H.FP8_DTYPES and OPT.gated_wgrad):
                 gated_mask = ctx.HL.masks[L - 1]
-                dZs = [None] + list(torch.empty(L - 1, M, G, dtype=dt, device=dev))
+                dZs = [None] + list(torch.empty(L - 1, Mc, G, dtype=dt, device=dev))
             else:
-                dZs = list(torch.empty(L, M, G, dtype=dt, device=dev))             # dZs[s] belongs to layer L-1-s
-            H.g_chain_bwd_rr(dxg, ctx.HL.masks, ctx.fragT, dZs, M, n * n, G)
+                dZs = list(torch.empty(L, Mc, G, dtype=dt, device=dev))            # dZs[s] belongs to layer L-1-s
+            H.g_chain_bwd_rr(dxg, ctx.HL.masks, ctx.fragT, dZs, Mc, n * njp, G)
             dZ_of = {L - 1 - s: dZs[s] for s in range(L)}
         elif fused_bwd:
             # one launch: dZ_L = dxg * (H_L > 0), then dZ_{l-1} = (dZ_l @ W_l) * (H_{l-1} > 0) for every layer
@@ -633,13 +661,13 @@ class RelationalFunction(torch.autograd.Function):
                 gW[l] = torch.empty(N_, kt_, **f32)
                 gB[l] = torch.empty(N_, **f32)
                 # the last layer without a stored gradient: its gate as an e4m3 {0, 1} image, scaled by dxg per question in the kernel
-                dz_l = dz_all[l] if dz_all[l] is not None else H.relu_gate_image(gated_mask, M)
+                dz_l = dz_all[l] if dz_all[l] is not None else H.relu_gate_image(gated_mask, Mc)
                 if inj and l == plan.inject:
                     tmp = torch.empty(N_, plan.widths[l - 1], **f32)
                     jobs.append((dz_l, a_all[l], tmp, gB[l]))
                 else:
                     jobs.append((dz_l, a_all[l], gW[l], gB[l]))
-            ws_, parts = H.g_wgrad_blocked(jobs, M, dxg=dxg, rows_per_question=n * n, aligned=bool(rq_splits))
+            ws_, parts = H.g_wgrad_blocked(jobs, Mc, dxg=dxg, rows_per_question=n * njp, aligned=bool(rq_splits))
             if tmp is not None:
                 l = plan.inject
                 N_, kt_, gp = plan.widths[l], plan.ktrue[l], plan.widths[l - 1]
@@ -720,7 +748,7 @@ class RelationalFunction(torch.autograd.Function):
                 Rq = torch.empty(B, N, **f32)
                 if l == 0:
                     Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32)
-                    H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N)
+                    H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N, njp=njp)
                 elif rr_bwd:
                     H.blocked_question_sums(dZ, Rq, M, n * n)      # (this layer's dZ is a row-blocked image)
                 else:
@@ -741,7 +769,7 @@ class RelationalFunction(torch.autograd.Function):
             elif l == 0:
                 Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32)
                 Rq = torch.empty(B, N, **f32) if alg0 else None                   # (all-pairs sums: the layer's bias gradient)
-                H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N)
+                H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N, njp=njp)
             if l == 0 and overlap and wgrad_late == 1:
                 _launch_wgrads()
             if l == 0 and alg0:
@@ -811,7 +839,7 @@ def grid_path_ok(plan: LayerPlan, precision, B, n, k):
         return False
     if inj_chain_ok(plan, code, n, k, M):
         return True
-    return alg0_forward_ok(plan, code, n, k, M) and alg0_wgrad_ok(plan, k)
+    return alg0_forward_ok(plan, code, n, k, M, f16s=precision == "f16s") and alg0_wgrad_ok(plan, k)
 
 
 _ZEROS = {}

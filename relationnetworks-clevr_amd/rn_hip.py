@@ -38,7 +38,8 @@ SIGNATURES = {
     "rn_g_chain_fwd_rr_f16s": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_alg0": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _I, _P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
-    "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_pair_sum_tiles": (_I, [_P, _P, _I, _I, _I, _P]),
     "rn_f_phi_fwd_from_partials": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pack_matrix_frag": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
@@ -58,7 +59,7 @@ SIGNATURES = {
     "rn_g_wgrad_blocked": (_I, [_P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _I, _P]),
     "rn_relu_gate_image": (_I, [_P, _P, _I, _P]),
     "rn_pair_reduce_ws_bytes": (_Z, [_I, _I, _I]),
-    "rn_pair_reduce_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_pair_reduce_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_pair_dx_dq": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _I, _I, _I, _I, _I, _P]),
     "rn_wgrad0_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_wgrad0_from_reductions": (_I, [_P, _P, _P, _P, _L, _L, _L, _P, _I, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -319,9 +320,10 @@ def g_chain_fwd_rr_alg0(Xp, Vc, n, Wfs, biases, Hs, masks, xg_part, M, G, Vq=Non
 
 
 @_timed("g_fwd")
-def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlo0, biases, Hs, masks, xg_part, M, G, Vq=None, inject=0):
+def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlo0, biases, Hs, masks, xg_part, M, G, Vq=None, inject=0, njp=None):
     """f16s forward chain with the factored first layer (fp16 object rows, no pair matrix).  Whis[0] / Wlo0: the hi / lo images of
-    layer 0; Whis[1..3]: (dither, 65536) fp16 tile-dithered hi images each."""
+    layer 0; Whis[1..3]: (dither, 65536) fp16 tile-dithered hi images each.  njp > n: padded j axis (M = B * n * njp, Xp16 with a
+    trailing zero row, two partial rows per tile in xg_part)."""
     L = len(Whis)
     dither = Whis[1].numel() // 65536
     hp = (C.c_void_p * L)(*[w.data_ptr() for w in Whis])
@@ -329,7 +331,7 @@ def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlo0, biases, Hs, masks, xg_part
     bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
     op = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
-    _check(load().rn_g_chain_fwd_rr_f16s_alg0(Xp16.data_ptr(), Vc.data_ptr(), n, hp, lp, dither, bp, op, _h_code(Hs), mp, xg_part.data_ptr(), _ptr(Vq),
+    _check(load().rn_g_chain_fwd_rr_f16s_alg0(Xp16.data_ptr(), Vc.data_ptr(), n, njp or n, hp, lp, dither, bp, op, _h_code(Hs), mp, xg_part.data_ptr(), _ptr(Vq),
                                               inject, M, L, G, _stream()), "rn_g_chain_fwd_rr_f16s_alg0")
 
 
@@ -486,11 +488,16 @@ def g_wgrad_blocked(jobs, M, dxg=None, rows_per_question=0, aligned=False, abl=0
 
 
 @_timed("pair_reduce")
-def pair_reduce_bwd(dZ, lddz, Rj, Ri, Rq, code, B, n, G):
+def pair_reduce_bwd(dZ, lddz, Rj, Ri, Rq, code, B, n, G, njp=None):
     lib = load()
     ws = torch.empty(max(lib.rn_pair_reduce_ws_bytes(B, n, G), 16), dtype=torch.uint8, device=dZ.device)
-    _check(lib.rn_pair_reduce_bwd(dZ.data_ptr(), lddz, _ptr(Rj), _ptr(Ri), _ptr(Rq), ws.data_ptr(), code, B, n, G, _stream()),
+    _check(lib.rn_pair_reduce_bwd(dZ.data_ptr(), lddz, _ptr(Rj), _ptr(Ri), _ptr(Rq), ws.data_ptr(), code, B, n, njp or n, G, _stream()),
            "rn_pair_reduce_bwd")
+
+
+@_timed("pair_sum")
+def pair_sum_tiles(part, xg, M, rows_per_question, G):
+    _check(load().rn_pair_sum_tiles(part.data_ptr(), xg.data_ptr(), M, rows_per_question, G, _stream()), "rn_pair_sum_tiles")
 
 
 @_timed("pair_reduce")

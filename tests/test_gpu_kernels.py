@@ -552,6 +552,61 @@ def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
             assert bool((d <= HsA[l].float().abs() * 2.0 ** -4 + 2.0 ** -10).all()), l
 
 
+@pytest.mark.parametrize("B,n", [(16, 196), (4, 40)])
+def test_g_chain_fwd_rr_f16s_alg0_padded(H, B, n):
+    """Object counts that are no multiple of 32 (the 14 x 14 grid): the factored first layer on a PADDED j axis (njp = 32 ceil(n /
+    32) pair rows per (question, i) group).  On the n valid rows of every group the stored copies, the masks and the pair sums must
+    be those of the f16s chain on the explicitly built pair matrix (same arithmetic up to the exact fp32 bracket of layer 0 and
+    the tile a row lands in -- the dithered weight image -- i.e. the mode's accuracy class); the invalid rows must have all-zero
+    masks in every layer; rn_pair_sum_tiles must add the two-rows-per-tile partials up per question."""
+    L, G, k, Q = 4, 256, 26, 128
+    njp = (n + 31) // 32 * 32
+    M, Mp, kt, K0 = B * n * n, B * n * njp, 2 * 26 + 128, 192
+    x = formula.hash_uniform((B, n, k), 400, -1, 1).astype(np.float32)
+    q = formula.hash_uniform((B, Q), 401, -1, 1).astype(np.float32)
+    Ws = [formula.hash_uniform((G, kt if l == 0 else G), 410 + l, -0.15, 0.15).astype(np.float32) for l in range(L)]
+    bs = [formula.hash_uniform((G,), 420 + l, -0.3, 0.3).astype(np.float32) for l in range(L)]
+    wd = [dev(w) for w in Ws]
+    w0T = torch.empty(kt, G, device="cuda")
+    hiA, loA, jobsA = f16s_images(H, wd, kt, k)
+    hiP, loP, jobsP = f16s_images(H, wd, kt, kt)
+    H.pack_matrix_frag_many(jobsA + jobsP + [(wd[0], kt, 1, G, kt, w0T, 2)])
+    Xp = torch.zeros(B * n + 1, 64, dtype=torch.float16, device="cuda"); Vc = torch.empty(B * n, G, device="cuda")
+    H.pair_tables(dev(x), dev(q), w0T, dev(bs[0]), Xp, Vc, B, n, k, Q, G)
+    assert not Xp[B * n].any()
+    P16 = torch.zeros(M, K0, dtype=torch.float16, device="cuda")
+    H.pair_build_fwd(dev(x), dev(q), P16, H.RN_F16, B, n, k, Q, K0)
+    bd = [dev(b) for b in bs]
+    HsA = [torch.full((Mp, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3)] + [None]
+    mA = list(torch.full((L, H.g_chain_rr_mask_bytes(Mp)), 0xff, dtype=torch.uint8, device="cuda"))
+    pA = torch.full((Mp // 256 * 2, G), float("nan"), device="cuda")
+    H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, HsA, mA, pA, Mp, G, njp=njp)
+    xgA = torch.full((B, G), float("nan"), device="cuda")
+    H.pair_sum_tiles(pA, xgA, Mp, n * njp, G)
+    HsP = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(4)]
+    mP = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
+    H.g_chain_fwd_rr_f16s(P16, K0, hiP, loP, bd, HsP, mP, K0, None, M, G)
+    torch.cuda.synchronize()
+    HsA, HsP = unblock_h(HsA), unblock_h(HsP)
+    valid = lambda t: t.view(B * n, njp, -1)[:, :n].reshape(M, -1)
+    # inference variant (no stores): the same pair sums, bitwise
+    pI = torch.full_like(pA, float("nan"))
+    H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, None, None, pI, Mp, G, njp=njp)
+    torch.cuda.synchronize()
+    assert torch.equal(pI, pA)
+    xgP = HsP[3].double().view(B, n * n, G).sum(1)
+    assert rel(xgA.cpu().numpy(), xgP.cpu().numpy()) <= 3e-3
+    for l in range(3):
+        a, b = valid(HsA[l]).float().cpu().numpy(), HsP[l].float().cpu().numpy()
+        assert np.abs(a - b).max() <= 4 * BF16_ULP * np.abs(b).max(), l
+    for l in range(L):
+        gA = torch.from_numpy(rr_mask_decode(mA[l], Mp, l))
+        gP = torch.from_numpy(rr_mask_decode(mP[l], M, l))
+        assert (valid(gA) != gP).float().mean().item() <= 5e-3, l
+        inval = gA.view(B * n, njp, G)[:, n:]
+        assert not inval.any(), l                              # padded rows: gates cleared in every layer
+
+
 @pytest.mark.parametrize("mode,M", [("train", 256 * 290), ("infer", 256 * 5)])
 def test_g_chain_fwd_rr_f16s(H, mode, M):
     """f16s on the register-resident chain: against a float64 emulation that rounds the operand to fp16 after every
@@ -953,6 +1008,15 @@ def test_pair_reduce_bwd(H, code, B, n, G):
     Rq2 = torch.empty_like(Rq)
     H.pair_reduce_bwd(dev(dZ).to(tdt(code)), G, None, None, Rq2, code, B, n, G)
     assert torch.equal(Rq, Rq2)
+    # the padded pair space of the factored-first-layer chain (njp = 32 ceil(n / 32) rows per (b, i) group): the rows j >= n are
+    # not read (NaN here) and the sums are bitwise those of the dense matrix
+    njp = (n + 31) // 32 * 32
+    if njp != n:
+        pad = np.full((B, n, njp, G), np.nan, np.float32)
+        pad[:, :, :n] = dZ.reshape(B, n, n, G)
+        Rj3 = torch.empty_like(Rj); Ri3 = torch.empty_like(Ri); Rq3 = torch.empty_like(Rq)
+        H.pair_reduce_bwd(dev(pad.reshape(-1, G)).to(tdt(code)), G, Rj3, Ri3, Rq3, code, B, n, G, njp=njp)
+        assert torch.equal(Rj3, Rj) and torch.equal(Ri3, Ri) and torch.equal(Rq3, Rq)
 
 
 # ----------------------------------------------------------------------------- K4 small fp32
