@@ -46,7 +46,8 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"bf16": 2500.0, "f16s": 2500.0, "fp32": 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 DTYPE_DETAIL = {"bf16": "bf16 x bf16 MFMA, fp32 accumulate", "fp32": "fp32 MFMA (exact fmaf chains)",
-                "f16s": "fp16 activations x fp16 hi+lo split weights (2 MFMA passes per product), fp32 accumulate; backward bf16"}
+                "f16s": "fp16 activations x fp16 weights, fp32 accumulate: layer 0 hi + lo split weights (2 MFMA passes), layers 1-3 one pass on "
+                        "tile-dithered weight images (4 roundings, tile t uses image t mod 4); backward bf16, e4m3 copies of H_0..2 for the weight gradients"}
 
 
 class A:
@@ -141,6 +142,12 @@ def parity_check(pkg, cfg, prec):
                        "log_prob_rel_err": e, "argmax_agree": float((lpn.argmax(1) == g["log_probs"].argmax(1)).mean()),
                        "dx_l2_rel": l2rel(xt.grad.cpu().numpy(), g["dx"]), "dq_l2_rel": l2rel(qt.grad.cpu().numpy(), g["dq"]),
                        "bias_grads_l2_rel_max": max(l2rel(grads[k_[5:]], g[k_]) for k_ in g if k_.startswith("grad/"))}
+        # the weight gradients (what the e4m3 activation copies touch): 64 sampled entries + the norm of every tensor the fixture
+        # pins (gold.check_grads: max-norm relative error, worst of sample / norm)
+        per = {}
+        gold.check_grads(g, grads, float("inf"), per)
+        out[tag_rl]["g_weight_grads_rel_err"] = {k_: per[k_] for k_ in sorted(per) if k_.startswith("g_layers") and k_.endswith("weight")}
+        out[tag_rl]["activation_copies"] = "e4m3" if (prec in ("bf16", "f16s") and pkg.options.OPT.h8) else "16-bit / fp32"
     if tag_ck:
         g = gold.load(tag_ck)
         m = quiet_rn(pkg, dict(formula.HYP[g["meta"]["cfg"]], precision=prec))
@@ -414,14 +421,16 @@ def main():
             kern = {kk: {"algorithmic_flops": fl[kk], "ms": per[kk], "achieved_tflops": fl[kk] / (per[kk] * 1e-3) / 1e12,
                          "frac": fl[kk] / (per[kk] * 1e-3) / 1e12 / peak, "ms_serial": per_step.get(kk)} for kk in per}
             inj_l = hyp["question_injection_position"]
-            alg0 = (prec in ("bf16", "f16s") and hyp["g_layers"] == [256] * 4 and n % 32 == 0 and M % 256 == 0 and k <= 32
+            njp = n if n % 32 == 0 else ((n + 31) // 32 * 32 if (prec == "f16s" and n % 4 == 0 and inj_l == 0) else 0)   # padded j axis
+            alg0 = (prec in ("bf16", "f16s") and hyp["g_layers"] == [256] * 4 and njp > 0 and (B * n * njp) % 256 == 0 and k <= 32
                     and (inj_l == 0 or (inj_l == 2 and (n * n) % 256 == 0)))
             # executed flops: the factored first layer runs K = 64 on chip and the question (wherever it is injected) enters as
             # a bias row, so every layer is a K = 64 / 256 product; the split-weight mode runs every product twice (hi + lo).
             # The algorithmic count stays the reference formulation's (model.py:130-152).
-            executed = 2.0 * M * 256 * (64 + 3 * 256) if alg0 else float(fwd)
-            if prec == "f16s" and alg0 and inj_l == 0:
-                executed = 2.0 * M * 256 * (2 * 64 + 2 * 256 + 2 * 256 + 256)      # (the last layer runs on the hi halves only)
+            Mx = B * n * njp if alg0 else M                           # (executed rows: the padded pair space where n % 32 != 0)
+            executed = 2.0 * Mx * 256 * (64 + 3 * 256) if alg0 else float(fwd)
+            if prec == "f16s" and alg0:
+                executed = 2.0 * Mx * 256 * (2 * 64 + 3 * 256)        # two passes on layer 0, one on the tile-dithered images of layers 1..3
             elif prec == "f16s":
                 executed *= 2.0
             kname = {"bf16": "g_chain_rr_kernel", "f16s": "g_chain_rr_f16s_kernel"}.get(prec) if alg0 else None
@@ -471,6 +480,14 @@ def main():
                 if "unsupported" not in r and not args.no_parity:
                     r["parity"] = parity_check(pkg, args.config, p2)
                 others[p2] = r
+            if prec in ("bf16", "f16s") and pkg.options.OPT.h8:
+                # the benched mode with 16-bit instead of e4m3 copies of H_0..2 (and a stored last-layer gradient): what the e4m3
+                # copies buy, and what they cost in weight-gradient error (parity block of both)
+                with pkg.options.override(h8=False):
+                    r = mode_rate(pkg, dp, base_hyp, prec, dev, img, qst, lab, B)
+                    if not args.no_parity:
+                        r["parity"] = parity_check(pkg, args.config, prec)
+                others[prec + ", 16-bit activation copies"] = r
             out["other_modes"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, B, args.hw)
