@@ -188,19 +188,28 @@ def hbm_traffic_from_profiles(kernel_pat):
 
 
 def time_launch(fn, n=20):
-    """median duration (ms) of ONE launch, event bracket per launch on the current stream."""
+    """Duration (ms) of ONE launch from HIP events on the current stream: median bracket around TWO back-to-back launches
+    minus median bracket around ONE.  A bracket around a single launch also holds the event packets' own ~5 us (and, with
+    an empty queue, the host's launch latency) -- a quarter of a 20 us kernel; the difference holds one launch and agrees
+    with rocprofv3's kernel durations (profiles/README.md).  A ~100 us spin kernel is queued first so that everything
+    bracketed is already in the queue when the device reaches it."""
     for _ in range(3):
         fn()
-    ts = []
-    for _ in range(n):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        fn()
-        e1.record()
-        torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    ts.sort()
-    return ts[len(ts) // 2]
+
+    def bracket(reps):
+        ts = []
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(200000)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        return ts[len(ts) // 2]
+    return bracket(2) - bracket(1)
 
 
 def pair_build_k1(H, B, n, k, Q, dev):

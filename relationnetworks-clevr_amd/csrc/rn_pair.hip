@@ -27,69 +27,116 @@ extern "C" int rn_abi_version(void) { return RN_ABI_VERSION; }
 // k columns change with j.  LDS holds:  pre[n][PW] (first PW = roundup(k,CH) columns of every
 // j-row) and suf[ld] (the j-independent remainder: x_i | q | 0).  The copy loop then streams
 // 16-byte chunks LDS -> HBM, consecutive lanes -> consecutive 16 B.
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void pair_build_kernel(const float* __restrict__ x, long sxb, long sxn, long sxk,
                                                          const float* __restrict__ q, long sqb, T* __restrict__ P,
                                                          int n, int k, int Q, int ld, int IB) {
   constexpr int CH = Elem<T>::kPer16B;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int PW = (k + CH - 1) / CH * CH;
-  T* pre = reinterpret_cast<T*>(smem_raw);          // [n][PW]
-  T* suf = pre + (size_t)n * PW;                    // [ld]
+  T* pre = reinterpret_cast<T*>(smem_raw);          // [n][PW]   (columns k..PW-1 are never written: masked out below)
+  T* suf = pre + (size_t)n * PW;                    // [IB][ld]  (columns 0..k-1 likewise)
   const int b = blockIdx.y;
   const int t = threadIdx.x;
+  const int i0 = blockIdx.x * IB;
+  const int ni = min(IB, n - i0);
   const float* xb = x + (long)b * sxb;
   const int cpr = ld / CH;                          // 16-byte chunks per row
-  // j-dependent head: pre[j][e] = x[b,j,e]  (e < k)
-  for (int idx = t; idx < n * k; idx += 256) {
-    const int j = idx % n, e = idx / n;
-    pre[j * PW + e] = Elem<T>::from_f32(xb[(long)j * sxn + (long)e * sxk]);
+  // One staging phase for the whole block -- the j-dependent head pre[j][e] = x[b,j,e] (e < k) and the j-independent
+  // remainder (x_i | q | 0) of every i this block writes -- then ONE barrier; the copy loops below never wait again.
+  // Every global load of the phase is issued before the first LDS write waits on one: one memory latency, not two.
+  // Straight-line: unconditional loads from clamped addresses (a branch per load would put a full wait after each one),
+  // (row, column) of the walk advanced incrementally instead of divided out per element.
+  const int ns = ni * (ld - k), sw = ld - k;
+  const bool efast = sxk <= sxn;      // consecutive lanes walk the contiguous axis of x (object-major input: k; the conv view: n)
+  const int inner = efast ? k : n, outer = efast ? n : k;
+  const long s_in = efast ? sxk : sxn, s_out = efast ? sxn : sxk;
+  constexpr int US = 6, UP = 8;
+  float rs[US], rp[UP];
+  int sa = t / sw, sr = t - sa * sw;                 // suffix element t + 256 u  ->  (i - i0, column - k)
+  const int sqa = 256 / sw, sqr = 256 - sqa * sw;
+  int sa_[US], sr_[US];
+#pragma unroll
+  for (int u = 0; u < US; ++u) {
+    sa_[u] = sa; sr_[u] = sr;
+    const int c = k + sr, ii = min(sa, ni - 1);
+    const float* src = c < 2 * k ? xb + (long)(i0 + ii) * sxn + (long)(c - k) * sxk
+                                 : (c < 2 * k + Q ? q + (long)b * sqb + (c - 2 * k) : xb);
+    rs[u] = *src;
+    if (c >= 2 * k + Q) rs[u] = 0.f;
+    sr += sqr; sa += sqa;
+    if (sr >= sw) { sr -= sw; ++sa; }
   }
-  for (int ii = 0; ii < IB; ++ii) {
-    const int i = blockIdx.x * IB + ii;
-    if (i >= n) break;                               // uniform per block
-    __syncthreads();                                 // previous copy loop done with suf / pre tail
-    for (int c = k + t; c < ld; c += 256) {
-      float v = 0.f;
-      if (c < 2 * k) v = xb[(long)i * sxn + (long)(c - k) * sxk];
-      else if (c < 2 * k + Q) v = q[(long)b * sqb + (c - 2 * k)];
-      suf[c] = Elem<T>::from_f32(v);
+  int pa = t / inner, pr = t - pa * inner;           // head element t + 256 u  ->  (outer, inner) index of x[b]
+  const int pqa = 256 / inner, pqr = 256 - pqa * inner;
+  for (int base = 0; base < n * k; base += 256 * UP) {
+    int pa_[UP], pr_[UP];
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+      pa_[u] = pa; pr_[u] = pr;
+      rp[u] = xb[(long)min(pa, outer - 1) * s_out + (long)pr * s_in];
+      pr += pqr; pa += pqa;
+      if (pr >= inner) { pr -= inner; ++pa; }
     }
-    __syncthreads();
-    // tail of the head chunk(s): columns k..PW-1 come from suf (they depend on i, not j)
-    if (PW > k) {
-      const int tw = PW - k;
-      for (int idx = t; idx < n * tw; idx += 256) {
-        const int j = idx / tw, e = k + idx % tw;
-        pre[j * PW + e] = suf[e];
-      }
-      __syncthreads();
+    if (base == 0) {
+#pragma unroll
+      for (int u = 0; u < US; ++u)
+        if (sa_[u] < ni) suf[sa_[u] * ld + k + sr_[u]] = Elem<T>::from_f32(rs[u]);
     }
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
-    u32x4_* dst = reinterpret_cast<u32x4_*>(P + ((long)(b * n + i) * n) * ld);
-    const int hc = PW / CH;                          // head chunks per row
-    // A thread keeps ONE chunk column c for the whole (b, i) span: the j-independent chunks (c >= hc: x_i | q | 0, all but
-    // the first few of a row) are then a register constant -- no LDS read, no index arithmetic per store -- and only the
-    // head chunks are read from LDS per row.  rpp rows per pass, consecutive lanes -> consecutive 16 B of consecutive rows
-    // (one contiguous rpp * ld * sizeof(T) byte burst per pass).  Non-temporal: the matrix is written once and read by
-    // another kernel; in L2 it would only evict what that kernel needs.
-    const int rpp = 256 / cpr;                       // rows per pass (threads beyond rpp * cpr idle in the copy)
-    if (rpp > 0) {
-      const int jr = t / cpr, c = t - jr * cpr;
-      if (jr < rpp) {
-        const bool head = c < hc;
-        const u32x4_ sv = *reinterpret_cast<const u32x4_*>(suf + c * CH);
-        for (int j = jr; j < n; j += rpp) {
-          const u32x4_ v = head ? *reinterpret_cast<const u32x4_*>(pre + j * PW + c * CH) : sv;
-          __builtin_nontemporal_store(v, dst + (long)j * cpr + c);
-        }
+#pragma unroll
+    for (int u = 0; u < UP; ++u)
+      if (pa_[u] < outer) pre[(efast ? pa_[u] : pr_[u]) * PW + (efast ? pr_[u] : pa_[u])] = Elem<T>::from_f32(rp[u]);
+  }
+  for (int idx = t + 256 * US; idx < ns; idx += 256) {      // (more than 6 * 256 suffix elements: very wide rows)
+    const int ii = idx / sw, c = k + idx % sw;
+    float v = 0.f;
+    if (c < 2 * k) v = xb[(long)(i0 + ii) * sxn + (long)(c - k) * sxk];
+    else if (c < 2 * k + Q) v = q[(long)b * sqb + (c - 2 * k)];
+    suf[ii * ld + c] = Elem<T>::from_f32(v);
+  }
+  __syncthreads();
+  const int hc = PW / CH;                            // head chunks per row
+  // A thread keeps ONE chunk column c for a whole (b, i) span: the j-independent chunks (c >= hc: x_i | q | 0, all but
+  // the first few of a row) are then a register constant -- no LDS read, no index arithmetic per store -- and only the
+  // head chunks are read from LDS per row (the chunk that straddles column k is merged in registers: lanes of x_j under
+  // the mask, x_i above it).  rpp rows per pass, consecutive lanes -> consecutive 16 B of consecutive rows (one contiguous
+  // rpp * ld * sizeof(T) byte burst per pass).
+  const int rpp = 256 / cpr;                         // rows per pass (threads beyond rpp * cpr idle in the copy)
+  if (rpp > 0) {
+    const int jr = t / cpr, c = t - jr * cpr;
+    if (jr >= rpp) return;
+    const bool head = c < hc;
+    u32x4_ m = {0u, 0u, 0u, 0u};                     // bytes of this chunk that come from x_j
+    if (head) {
+      unsigned char* mb = reinterpret_cast<unsigned char*>(&m);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mb[e] = (c * CH + e / (int)sizeof(T) < k) ? 0xff : 0;
+    }
+    const T* prow = pre + c * CH;
+    for (int ii = 0; ii < ni; ++ii) {
+      u32x4_* dst = reinterpret_cast<u32x4_*>(P + ((long)(b * n + i0 + ii) * n) * ld) + c;
+      const u32x4_ sv = *reinterpret_cast<const u32x4_*>(suf + ii * ld + c * CH) & ~m;
+      for (int j = jr; j < n; j += rpp) {
+        u32x4_ v = sv;
+        if (head) v |= *reinterpret_cast<const u32x4_*>(prow + j * PW) & m;
+        if (NT) __builtin_nontemporal_store(v, dst + (long)j * cpr); else dst[(long)j * cpr] = v;
       }
-    } else {                                         // rows wider than 256 chunks: the generic walk
-      const int total = n * cpr;
+    }
+  } else {                                           // rows wider than 256 chunks: the generic walk
+    const int total = n * cpr;
+    for (int ii = 0; ii < ni; ++ii) {
+      u32x4_* dst = reinterpret_cast<u32x4_*>(P + ((long)(b * n + i0 + ii) * n) * ld);
       for (int g = t; g < total; g += 256) {
         const int j = g / cpr, c = g - j * cpr;
-        const T* src = (c < hc) ? (pre + j * PW + c * CH) : (suf + c * CH);
-        dst[g] = *reinterpret_cast<const u32x4_*>(src);
+        u32x4_ v = *reinterpret_cast<const u32x4_*>(suf + ii * ld + c * CH);
+        if (c < hc) {
+          u32x4_ m;
+          unsigned char* mb = reinterpret_cast<unsigned char*>(&m);
+          for (int e = 0; e < 16; ++e) mb[e] = (c * CH + e / (int)sizeof(T) < k) ? 0xff : 0;
+          v = (*reinterpret_cast<const u32x4_*>(pre + j * PW + c * CH) & m) | (v & ~m);
+        }
+        dst[g] = v;
       }
     }
   }
@@ -102,27 +149,32 @@ extern "C" int rn_pair_build_fwd(const float* x, long sxb, long sxn, long sxk, c
   RN_CHECK_ARG(ld % 64 == 0 && ld >= 2 * k + Q, "rn_pair_build_fwd: ld=%d must be a multiple of 64 and >= 2k+Q=%d", ld,
                2 * k + Q);
   RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32 || dtype == RN_F16, "rn_pair_build_fwd: bad dtype %d", dtype);
-  int IB = (int)((long)B * n / 2048);
-  IB = IB < 1 ? 1 : (IB > 8 ? 8 : IB);
-  if (const char* e = rn_diag_env("RN_K1_IB")) IB = atoi(e) > 0 ? atoi(e) : IB;        // diagnostics
+  // rows of one i per workgroup: ~56 KB of stores behind each staging phase (measured optimum 2 at the headline shape: 18.7 us
+  // vs 20.2 / 19.1 for 1 / 4), but no fewer than ~1000 workgroups
+  const long span = (long)n * ld * (dtype == RN_F32 ? 4 : 2);
+  int IB = (int)((57344 + span / 2) / span);
+  IB = IB < 2 ? 2 : (IB > 8 ? 8 : IB);
+  const int cap = (int)((long)B * n / 1024);
+  if (IB > cap) IB = cap < 1 ? 1 : cap;
+  bool nt = true;
+#ifdef RN_DIAG
+  if (const char* e = rn_diag_env("RN_K1_IB")) IB = atoi(e) > 0 ? atoi(e) : IB;
+  if (const char* e = rn_diag_env("RN_K1_NT")) nt = atoi(e) != 0;
+#endif
   dim3 grid(cdiv(n, IB), B);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == RN_BF16 || dtype == RN_F16) {
-    size_t lds = ((size_t)n * ((k + 7) / 8 * 8) + ld) * sizeof(bf16);
-    RN_CHECK_ARG(lds <= RN_LDS_MAX, "rn_pair_build_fwd: n*k too large for LDS staging (%zu B > %d B)", lds, RN_LDS_MAX);
-    if (dtype == RN_BF16) {
-      if (lds > 64 * 1024) RN_LDS_OPT_IN(pair_build_kernel<bf16>, "rn_pair_build_fwd");
-      pair_build_kernel<bf16><<<grid, 256, lds, s>>>(x, sxb, sxn, sxk, q, sqb, (bf16*)P, n, k, Q, ld, IB);
-    } else {
-      if (lds > 64 * 1024) RN_LDS_OPT_IN(pair_build_kernel<f16>, "rn_pair_build_fwd");
-      pair_build_kernel<f16><<<grid, 256, lds, s>>>(x, sxb, sxn, sxk, q, sqb, (f16*)P, n, k, Q, ld, IB);
-    }
-  } else {
-    size_t lds = ((size_t)n * ((k + 3) / 4 * 4) + ld) * sizeof(float);
-    RN_CHECK_ARG(lds <= RN_LDS_MAX, "rn_pair_build_fwd: n*k too large for LDS staging (%zu B > %d B)", lds, RN_LDS_MAX);
-    if (lds > 64 * 1024) RN_LDS_OPT_IN(pair_build_kernel<float>, "rn_pair_build_fwd");
-    pair_build_kernel<float><<<grid, 256, lds, s>>>(x, sxb, sxn, sxk, q, sqb, (float*)P, n, k, Q, ld, IB);
-  }
+  const int esz = dtype == RN_F32 ? 4 : 2, ch = 16 / esz;
+  const size_t lds = ((size_t)n * ((k + ch - 1) / ch * ch) + (size_t)IB * ld) * esz;
+  RN_CHECK_ARG(lds <= RN_LDS_MAX, "rn_pair_build_fwd: n*k too large for LDS staging (%zu B > %d B)", lds, RN_LDS_MAX);
+#define RN_K1_LAUNCH(T, NT)                                                                      \
+  do {                                                                                           \
+    if (lds > 64 * 1024) RN_LDS_OPT_IN((pair_build_kernel<T, NT>), "rn_pair_build_fwd");         \
+    pair_build_kernel<T, NT><<<grid, 256, lds, s>>>(x, sxb, sxn, sxk, q, sqb, (T*)P, n, k, Q, ld, IB); \
+  } while (0)
+  if (dtype == RN_BF16) { if (nt) RN_K1_LAUNCH(bf16, true); else RN_K1_LAUNCH(bf16, false); }
+  else if (dtype == RN_F16) { if (nt) RN_K1_LAUNCH(f16, true); else RN_K1_LAUNCH(f16, false); }
+  else { if (nt) RN_K1_LAUNCH(float, true); else RN_K1_LAUNCH(float, false); }
+#undef RN_K1_LAUNCH
   RN_LAUNCH_CHECK("rn_pair_build_fwd");
   return 0;
 }

@@ -8,7 +8,7 @@ for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES" 
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR" "SQ_INSTS_MFMA SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_INSTS_SENDMSG" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pc_$i -o p -- python $R/tools/run_kernels_once.py chainbwd $MODE > $OUT/log_$i.txt 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pc_$i -o p -- python $R/tools/run_kernels_once.py $MODE > $OUT/log_$i.txt 2>&1
   f=$(find /tmp/pc_$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python $R/tools/pmc_table.py $f >> $OUT/pmc.txt || echo "set $i failed: $set" >> $OUT/pmc.txt
 done

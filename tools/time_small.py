@@ -25,6 +25,10 @@ Rj = torch.empty(B * n, G, device=dev); Ri = torch.empty(B * n, G, device=dev); 
 dx = torch.empty(B, n, k, device=dev); dq = torch.empty(B, Q, device=dev); dW0 = torch.empty(G, kt, device=dev); db0 = torch.empty(G, device=dev)
 gW = torch.empty(G, G, device=dev); gB = torch.empty(G, device=dev)
 masks = torch.randint(0, 255, (H.g_chain_rr_mask_bytes(M),), dtype=torch.uint8, device=dev)
+gate = H.relu_gate_image(masks, M); dZb = [H.rows_to_blocked(dZ) for _ in range(2)]; H8 = [H.rows_to_blocked(Hh) for _ in range(3)]
+gWs = [torch.empty(G, G, device=dev) for _ in range(3)]; gBs = [torch.empty(G, device=dev) for _ in range(3)]
+jobs = [(dZb[0], H8[0], gWs[0], gBs[0]), (dZb[1], H8[1], gWs[1], gBs[1]), (gate, H8[2], gWs[2], gBs[2])]
+part32 = torch.randn(M // 32 * (1 if n % 32 == 0 else 2), G, device=dev)
 rows = [
     ("pair_tables", lambda: H.pair_tables(x, q, w0T, b0, Xp, Vc, B, n, k, Q, G)),
     ("pair_sum_fwd (segsum of the chain partials)", lambda: H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // 256, G)),
@@ -33,8 +37,9 @@ rows = [
     ("pair_reduce_bwd (+finish)", lambda: H.pair_reduce_bwd(dZ, G, Rj, Ri, Rq, H.RN_BF16, B, n, G)),
     ("pair_dx_dq", lambda: H.pair_dx_dq(Rj, Ri, Rq, W0, dx, dq, B, n, k, Q, G)),
     ("wgrad0_from_reductions (part + finish)", lambda: H.wgrad0_from_reductions(Rj, Ri, Rq, x, q, dW0, db0)),
-    ("g_linear_bwd_wgrad K=256 (stream + reduce)", lambda: H.g_linear_bwd_wgrad(dZ, G, Hh, G, gW, gB, H.RN_BF16, M, G, G, G)),
-    ("g_linear_bwd_wgrad_gated (stream + reduce)", lambda: H.g_linear_bwd_wgrad_gated(masks, dxg, n * n, Hh, G, gW, gB, M, G, G)),
+    ("relu_gate_image (masks -> e4m3 {0,1} image)", lambda: H.relu_gate_image(masks, M)),
+    ("g_wgrad_blocked, step's three jobs (2 stored + gate)", lambda: H.g_wgrad_blocked(jobs, M, dxg=dxg, rows_per_question=n * n)),
+    ("pair_sum_tiles", lambda: H.pair_sum_tiles(part32, xg, M, n * n, G)),
 ]
 only = sys.argv[1] if len(sys.argv) > 1 else None
 for name, fn in rows:
