@@ -329,6 +329,13 @@ __global__ __launch_bounds__(TR ? FP_KS * 256 : 256) void f_phi_fwd_kernel(
       if (r0 + r < B) {
         const float* src = xg_part + (long)(r0 + r) * parts * G + k;
         int p = 0;
+        for (; p + 32 <= parts; p += 32) {             // 32 loads in flight: a batch is one round trip to L2 / HBM
+          float u[32];
+#pragma unroll
+          for (int i = 0; i < 32; ++i) u[i] = src[(long)(p + i) * G];
+#pragma unroll
+          for (int i = 0; i < 32; ++i) v += u[i];
+        }
         for (; p + 8 <= parts; p += 8) {
           float u[8];
 #pragma unroll

@@ -26,5 +26,7 @@ ls -la $OUT
 python bench.py --config ir-fp --no-cpu-baseline > $OUT/bench_ir_fp.json 2>> $OUT/bench.err
 python bench.py --hw 224 --batch 32 --steps 10 --no-cpu-baseline > $OUT/bench_stress_b32_n196.json 2>> $OUT/bench.err
 python tools/time_small.py > $OUT/small_kernels_alone.txt 2>/dev/null
+python tools/time_wgrad.py > $OUT/wgrad_alone.txt 2>/dev/null
+python tools/time_fwd_f16s.py > $OUT/fwd_chain_alone.txt 2>/dev/null
 python tools/time_k1.py > $OUT/k1_alone.txt 2>/dev/null
 ls -la $OUT
