@@ -623,6 +623,15 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const RnAdamChunk* __res
                                                         float bc2_sqrt, float* __restrict__ norm_out, const float* __restrict__ hyper = nullptr,
                                                         const int* __restrict__ step_dev = nullptr) {
   __shared__ float coef_s, hs[8];
+  __shared__ double nred[4];
+  // the norm: every block adds the npartial (<= 256) partials in the same fixed tree (-> the same value everywhere) -- one
+  // load per thread and a shuffle tree instead of one thread walking the list (which was three quarters of this kernel)
+  {
+    double x = (int)threadIdx.x < npartial ? partial[threadIdx.x] : 0.0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+    if ((threadIdx.x & 63) == 0) nred[threadIdx.x >> 6] = x;
+  }
   if (hyper) {
     // hyper-parameters and the update count from device memory: the launch can sit in a captured graph and still follow an LR
     // schedule.  hyper = {grad_scale, max_norm, lr, beta1, beta2, eps, weight_decay}; bias corrections as on the host (double)
@@ -636,9 +645,9 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const RnAdamChunk* __res
     gscale = hs[0]; max_norm = hs[1]; lr = hs[2]; beta1 = hs[3]; beta2 = hs[4]; eps = hs[5]; wd = hs[6]; bc1 = hs[7]; bc2_sqrt = coef_s;
     __syncthreads();
   }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < npartial; ++i) s += partial[i];
+    const double s = (nred[0] + nred[1]) + (nred[2] + nred[3]);
     const float total = gscale * (float)sqrt(s);           // norm of the SCALED gradient (gscale = 1 / world after a sum all-reduce)
     float c = 1.f;
     if (max_norm > 0.f) {
