@@ -28,8 +28,16 @@ def _stale(target, deps):
     return t == 0.0 or any(_mtime(d) > t for d in deps)
 
 
+def _flags_changed() -> bool:
+    """The objects on disk were compiled with other flags (a diagnostics build left behind, or the other way round)."""
+    try:
+        return open(os.path.join(OBJ, "flags.txt")).read() != " ".join(FLAGS)
+    except OSError:
+        return True
+
+
 def needs_build() -> bool:
-    return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+    return _flags_changed() or _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
 
 
 def _hipcc():
@@ -42,6 +50,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
+    force = force or _flags_changed()
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o"))
@@ -57,6 +66,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         list(ex.map(run, jobs))
     run([hipcc] + FLAGS + ["-shared", "-o", LIB + ".tmp"] + [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES])
     os.replace(LIB + ".tmp", LIB)
+    with open(os.path.join(OBJ, "flags.txt"), "w") as f:
+        f.write(" ".join(FLAGS))
     return LIB
 
 
