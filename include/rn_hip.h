@@ -432,8 +432,11 @@ int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* co
  * padded rows, and xg_part holds TWO partial rows per 256-row tile, (M / 256 * 2, 256) -- reduce with rn_pair_sum_tiles.  The
  * backward side (rn_g_chain_bwd_rr with rows_per_question = n * njp, rn_g_wgrad_blocked, rn_pair_reduce_bwd with njp) then sees
  * zero gradients for the invalid rows without knowing about the padding.  Question at layer 0 only. */
+/* gate_image (may be NULL; with the e4m3 training output set): M x 256 bytes -- the last layer's ReLU gate as an e4m3 {0, 1} row-blocked
+ * image (1.0 = 0x38), exactly what rn_relu_gate_image builds from mask[3]: the `dZ` operand of the last layer's gate job in
+ * rn_g_wgrad_blocked, written from the forward kernel's epilogue instead of by a launch of its own in the backward pass. */
 int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, int njp, const void* const* Whi, const void* const* Wlo, int dither,
-                                const float* const* bias, void* const* H, int h_dtype, void* const* mask, float* xg_part,
+                                const float* const* bias, void* const* H, int h_dtype, void* const* mask, void* gate_image, float* xg_part,
                                 const float* Vq, int inject_layer, int M, int L, int G, void* stream);
 int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, const void* const* Wf, const float* const* bias, void* const* H,
                            int h_dtype, void* const* mask, float* xg_part, const float* Vq, int inject_layer, int M, int L, int G,

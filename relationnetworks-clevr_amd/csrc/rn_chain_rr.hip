@@ -657,6 +657,7 @@ struct RRArgsF {
   bf16* out[RR_L];
   u64* mask[RR_L];
   int prio;
+  unsigned char* gate;                                  // GATE: e4m3 {0, 1} row-blocked image of the last layer's ReLU gate
 };
 __device__ __forceinline__ unsigned relu_pack_f16(float a, float b) {     // saturate instead of overflowing fp16 to inf
   const f32x2 f = {fminf(a, 65504.f), fminf(b, 65504.f)};
@@ -665,7 +666,7 @@ __device__ __forceinline__ unsigned relu_pack_f16(float a, float b) {     // sat
   x = __builtin_elementwise_max(x, z);
   return __builtin_bit_cast(unsigned, x);
 }
-template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false>
+template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false, bool GATE = false>
 struct F16Vm {
   static constexpr int PF_PER = (NK0 + 7) / 8;
   static constexpr int VC_STAGE = (RR_L - 1) * 8 + 4;                // ALG0: the stage that requests the next tile's bias row
@@ -684,9 +685,10 @@ struct F16Vm {
       for (int c = 0; c < PF_PER; ++c) k += ((sidx & 7) * PF_PER + c < NK0) ? 1 : 0;
     if (ALG0 && sidx == VC_STAGE) k += 1;
     if (INJ > 0 && sidx == VQ_STAGE) k += 1;
+    if (GATE && (sidx >> 3) == RR_L - 1 && (sidx & 7) >= 1) k += 1;   // the gate cells of the last layer's block (sidx & 7) - 1
     return k;
   }
-  static constexpr int tail() { return (STORE && ST3 ? 4 : 0) + (XG ? (ALG0 ? 1 : 8) : 0); }
+  static constexpr int tail() { return (STORE && ST3 ? 4 : 0) + (XG ? (ALG0 ? 1 : 8) : 0) + (GATE ? 1 : 0); }
   // weights of stage s+1 were requested in stage s+1-F_LA: younger are the stages s-(F_LA-2) .. s-1
   static constexpr int younger(int sidx, bool first) {
     int k = 0;
@@ -719,7 +721,14 @@ struct F16Vm {
 // are INVALID: their ReLU lane-mask bits are cleared in every layer (the backward chain, the gate job and the pair reductions
 // then see zero gradients for them without knowing about the padding) and they are left out of the pair sum.  A 256-row tile
 // may straddle two questions at a wave boundary: it leaves TWO partial rows (rn_pair_sum_tiles adds them up per question).
-template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false, int ABL = 0, bool RAG = false>
+// GATE: the last layer's ReLU gate also leaves as an e4m3 {0, 1} byte image (1.0 = 0x38) in the row-blocked layout of the H copies
+// (byte (m, f) at ((m / 16) 256 + f) 16 + m % 16) -- the operand the gate job of rn_g_wgrad_blocked multiplies with the H_2 image;
+// built here it costs one 16-byte store per lane and block in the MFMA shadow instead of a kernel of its own (8 MB of masks ->
+// 67 MB) at the head of the HBM-bound window behind the backward chain.  In the un-swapped last layer a lane owns feature n of
+// rows 8 j + 4 h + r: per 16-row group two of the cell's four dwords, the other two sit in the partner lane (n, 1 - h) --
+// two v_permlane32_swap hand lane half 0 the whole cell of rows 0..15 and half 1 that of rows 16..31.
+template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false, int ABL = 0, bool RAG = false,
+          bool GATE = false>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __restrict__ P, int ldp, RRArgsF a,
                                                                 float* __restrict__ xg_part, int ntiles,
                                                                 const float* __restrict__ Vc = nullptr, int n_obj = 0,
@@ -728,7 +737,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
   static_assert(!RAG || (ALG0 && INJ == 0 && XG), "padded j axis: the factored first layer with the question at layer 0");
   static_assert(INJ >= 0 && INJ < RR_L - 1, "the injected layer is one of the swapped-operand layers");
   static_assert(!H8 || STORE, "e4m3 copies of H_0..2 (a stored H_3 stays bf16: the pair sum reads it)");
-  typedef F16Vm<NK0, STORE, ST3, XG, ALG0, INJ, H8> Vm;
+  static_assert(!GATE || (H8 && MASK && !ST3), "the gate image belongs to the training output set with e4m3 copies");
+  typedef F16Vm<NK0, STORE, ST3, XG, ALG0, INJ, H8, GATE> Vm;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
   k.init(lds);
@@ -897,10 +907,30 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
       __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2));
     };
     float b3 = 0.f;
+    unsigned gd[4];                                                    // GATE: the lane's four gate bytes of accumulator group j
+    const unsigned gate_lane = (unsigned)((h * RR_G + n) * 16);
+    auto gate_store = [&](int pob) {
+      if constexpr (GATE) {
+        // gd[0], gd[1]: dwords h, 2 + h of the cell (rows 0..15, feature n); gd[2], gd[3]: of the cell of rows 16..31
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(gd[0], gd[2], false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(gd[1], gd[3], false, false);
+        const u32x4 cell = {s0[0], s0[1], s1[0], s1[1]};
+        gbl_u8* base = (gbl_u8*)(a.gate + m0w * RR_G);
+        asm volatile("" : "+s"(base));
+        __builtin_nontemporal_store(cell, reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + gate_lane + 512 * pob));
+      }
+    };
     auto epi3_group = [&](int pob, int j, int ph, f32x4 (&v)[4]) {
       if (ph == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[j][r] = fmaxf(acc[pob & 1][4 * j + r] + b3, 0.f);
+      }
+      if (ph == 3) {
+        if constexpr (GATE) {
+          unsigned g = (v[j][0] > 0.f ? 0x38u : 0u) | (v[j][1] > 0.f ? 0x3800u : 0u) | (v[j][2] > 0.f ? 0x380000u : 0u) | (v[j][3] > 0.f ? 0x38000000u : 0u);
+          if constexpr (RAG) g = keep3[j] != 0.f ? g : 0u;              // (padded rows: gate 0, like their mask bits)
+          gd[j] = g;
+        }
       }
       if (ph == 1) {
         if constexpr (XG && RAG) xs[pob] += keep3[j] * ((v[j][0] + v[j][1]) + (v[j][2] + v[j][3]));
@@ -972,7 +1002,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
           if (has_prev && !(ABL & 32)) {
             const int j = c / CPG, ph = c % CPG;
             if (pl == RR_L - 1) {
-              if (ph < 3) epi3_group(pob, j, ph, v);
+              if (ph < 4) epi3_group(pob, j, ph, v);
+              if (j == 3 && ph == 3) gate_store(pob);
             } else if (CPG >= 4) {
               if (ph < 4) epi_group(pl, pob, j, ph, dst, pk);
             } else {                                                  // NK = 4: two gaps per group, two phases per gap
@@ -1011,7 +1042,9 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
         epi3_group(7, j, 0, v);
         epi3_group(7, j, 1, v);
         epi3_group(7, j, 2, v);
+        epi3_group(7, j, 3, v);
       }
+      gate_store(7);
       if constexpr (STORE && ST3) {
         co_read(RR_L - 1);
 #pragma unroll
@@ -1475,8 +1508,8 @@ extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* cons
 
 // f16s arithmetic on the factored first layer (see g_chain_rr_kernel, ALG0): Xp16 = fp16 object rows (B*n, 64).
 extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, int njp, const void* const* Whi, const void* const* Wlo, int dither,
-                                           const float* const* bias, void* const* H, int h_dtype, void* const* mask, float* xg_part,
-                                           const float* Vq, int inject_layer, int M, int L, int G, void* stream) {
+                                           const float* const* bias, void* const* H, int h_dtype, void* const* mask, void* gate_image,
+                                           float* xg_part, const float* Vq, int inject_layer, int M, int L, int G, void* stream) {
   RN_CHECK_ARG(Xp16 && Vc && Whi && Wlo && bias && M > 0 && xg_part, "rn_g_chain_fwd_rr_f16s_alg0: bad pointer/size");
   RN_CHECK_ARG(!H || h_dtype == RN_BF16 || h_dtype == RN_FP8, "rn_g_chain_fwd_rr_f16s_alg0: h_dtype must be RN_BF16 or RN_FP8 (got %d)", h_dtype);
   const bool h8 = H && h_dtype == RN_FP8;
@@ -1493,6 +1526,9 @@ extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, in
   if (int rc = rr_f16s_args("rn_g_chain_fwd_rr_f16s_alg0", a, Whi, Wlo, dither, bias, H, mask, &nh, &nm)) return rc;
   const bool h012 = nh == 3 && !a.out[RR_L - 1] && nm == RR_L;
   RN_CHECK_ARG((nh == 0 && nm == 0) || h012, "rn_g_chain_fwd_rr_f16s_alg0: H / masks: none (inference) or H_0..2 + all four masks (training)");
+  RN_CHECK_ARG(!gate_image || (h8 && h012 && (uintptr_t)gate_image % 16 == 0), "rn_g_chain_fwd_rr_f16s_alg0: the gate image goes with the e4m3 training output set");
+  a.gate = (unsigned char*)gate_image;
+  const bool gate = gate_image != nullptr;
   const int ntiles = M / RR_TM;
   const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
   hipStream_t s = (hipStream_t)stream;
@@ -1501,10 +1537,12 @@ extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, in
   if (rag) {
     const int nz = (M / (n * njp)) * n;                               // the all-zero object row behind the B * n real ones
     if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true, 0, false, 0, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, nullptr, 1, njp, nz);
+    else if (h8 && gate) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, true, 0, true, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, nullptr, 1, njp, nz);
     else if (h8) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, true, 0, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, nullptr, 1, njp, nz);
     else g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, false, 0, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, nullptr, 1, njp, nz);
   } else if (inject_layer == 2) {
     if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true, 2><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
+    else if (h8 && gate) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 2, true, 0, false, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
     else if (h8) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 2, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
     else g_chain_rr_f16s_kernel<4, true, false, true, true, true, 2><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
   } else {
@@ -1514,6 +1552,7 @@ extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, in
     RN_ABL(1) RN_ABL(2) RN_ABL(4) RN_ABL(6) RN_ABL(8) RN_ABL(16) RN_ABL(24) RN_ABL(64)
 #undef RN_ABL
 #endif
+    else if (h8 && gate) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, true, 0, false, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n);
     else if (h8) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n);
     else g_chain_rr_f16s_kernel<4, true, false, true, true, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n);
   }

@@ -367,7 +367,13 @@ __global__ __launch_bounds__(256) void wgrad_blocked_reduce_kernel(KbArgs a, int
 int kb_splits(int M, int rows_per_question, int njobs, int aligned) {
   const int S = M / 64;
   if (S < 1 || njobs < 1) return 0;
-  const int target = 64 / njobs > 0 ? 64 / njobs : 1;
+  // 48 row splits over all jobs = 192 workgroups: three quarters of the chip.  The launch runs on a side stream beside the
+  // latency-bound kernels that close the backward pass (pair reduction, dx / dq, the conv stack's backward); with a workgroup
+  // on every CU (64 splits) those kernels wait for CU slots and stretch 3-5x -- measured on the whole step, same box: 64 ->
+  // 0.983 ms, 54 -> 0.955, 48 -> 0.931, 42 -> 0.944, 36 -> 0.976 (the kernel alone is fastest at 64).
+  int total = 48;
+  if (const char* e = rn_diag_env("RN_KB_TOTAL")) total = atoi(e) > 0 ? atoi(e) : total;      // (diagnostics builds)
+  const int target = total / njobs > 0 ? total / njobs : 1;
   const int Zd = S >= target ? target : S;
   if (!aligned || rows_per_question <= 0 || rows_per_question % 64 || M % rows_per_question) return Zd;
   const int B = M / rows_per_question, spq = rows_per_question / 64;

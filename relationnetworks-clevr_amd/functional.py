@@ -180,8 +180,9 @@ class RRMasks:
     """ReLU lane masks of the register-resident forward chain: what the backward pass keeps INSTEAD of the last
     activation (rn_g_chain_fwd_rr / rn_g_chain_bwd_rr)."""
 
-    def __init__(self, masks):
+    def __init__(self, masks, gate=None):
         self.masks = masks
+        self.gate = gate          # the last layer's gate as an e4m3 {0, 1} row-blocked image, when the forward chain wrote it
 
 
 def rr_chain_ok(plan: LayerPlan, code):
@@ -303,22 +304,25 @@ def g_chain_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, la
             Xp, Vc, Vq, inj_l = _tables(x, q, plan, g_b, w0T, inj_w, torch.float16, B, n, k, Q, G, coord)
             njp = n if inj_w is not None else padded_j(n)          # pair rows per (question, i) group: padded where n % 32 != 0
             Mp = B * n * njp
-            masks = Hs = None
+            masks = Hs = gate = None
             if keep_inputs:
                 Hs = [torch.empty(Mp, G, dtype=_h_copy_dtype(plan, dt, Mp), device=dev) for l in range(L - 1)] + [None]
                 masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(Mp), dtype=torch.uint8, device=dev))
+                if Hs[0].dtype in H.FP8_DTYPES and (n * njp) % 64 == 0 and OPT.gated_wgrad and OPT.gate_fwd:
+                    # the operand of the last layer's weight-gradient gate job, written from the forward kernel's epilogue
+                    gate = torch.empty(Mp, G, dtype=Hs[0].dtype, device=dev)
             if njp != n:
                 part = torch.empty(Mp // R * 2, G, dtype=torch.float32, device=dev)      # two partial rows per tile (it may straddle questions)
-                H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, wfrag[0], wfrag[1][0], g_b, Hs, masks, part, Mp, G, njp=njp)
+                H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, wfrag[0], wfrag[1][0], g_b, Hs, masks, part, Mp, G, njp=njp, gate=gate)
                 xg = torch.empty(B, G, dtype=torch.float32, device=dev)
                 H.pair_sum_tiles(part, xg, Mp, n * njp, G)
             else:
                 part = torch.empty(M // R, G, dtype=torch.float32, device=dev)
-                H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, wfrag[0], wfrag[1][0], g_b, Hs, masks, part, M, G, Vq=Vq, inject=inj_l)
+                H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, wfrag[0], wfrag[1][0], g_b, Hs, masks, part, M, G, Vq=Vq, inject=inj_l, gate=gate)
                 xg = _pair_sum_of(part, B, (n * n) // R, G, lazy_xg)
             if Hs is None:
                 return [None] * L, None, xg
-            return [None] + Hs[:-1], RRMasks(masks), xg
+            return [None] + Hs[:-1], RRMasks(masks, gate), xg
         P16 = torch.empty(M, ld0, dtype=torch.float16, device=dev)
         H.pair_build_fwd(x, q, P16, H.RN_F16, B, n, k, Q, ld0)
         P = None
@@ -607,16 +611,18 @@ class RelationalFunction(torch.autograd.Function):
         rr_bwd = isinstance(ctx.HL, RRMasks)       # the register-resident chains: H_0..2 / dZ of layers 1..3 are row-blocked images
         njp = ctx.njp                              # pair rows per (question, i) group: > n on the padded j axis (rr chains only)
         Mc = B * n * njp                           # ... and the pair rows the chains / weight gradients work on
+        gate_img = None
         if rr_bwd:
             # register-resident backward chain on the forward kernel's gates (one launch, no activation is re-read)
             fused_bwd = True
             # the last layer's gradient dZ_{L-1} = gate x dxg[question] is never stored: its only reader besides the chain
             # itself, the layer's wgrad, rebuilds it from the masks (rn_g_wgrad_blocked) -- 134 MB less written
             # by the chain and 134 MB less read by the wgrad at the headline shape
-            gated_mask = None
+            gated_mask = gate_img = None
             # (needs the e4m3 H_2 image: the gate job runs on the fp8 matrix pipe; with 16-bit copies dZ_3 is stored)
             if ((n * njp) % 64 == 0 and inputs[L - 1].dtype in H.FP8_DTYPES and OPT.gated_wgrad):
                 gated_mask = ctx.HL.masks[L - 1]
+                gate_img = ctx.HL.gate                     # (the f16s forward chain has already written the gate's image)
                 dZs = [None] + list(torch.empty(L - 1, Mc, G, dtype=dt, device=dev))
             else:
                 dZs = list(torch.empty(L, Mc, G, dtype=dt, device=dev))            # dZs[s] belongs to layer L-1-s
@@ -661,7 +667,7 @@ class RelationalFunction(torch.autograd.Function):
                 gW[l] = torch.empty(N_, kt_, **f32)
                 gB[l] = torch.empty(N_, **f32)
                 # the last layer without a stored gradient: its gate as an e4m3 {0, 1} image, scaled by dxg per question in the kernel
-                dz_l = dz_all[l] if dz_all[l] is not None else H.relu_gate_image(gated_mask, Mc)
+                dz_l = dz_all[l] if dz_all[l] is not None else (gate_img if gate_img is not None else H.relu_gate_image(gated_mask, Mc))
                 if inj and l == plan.inject:
                     tmp = torch.empty(N_, plan.widths[l - 1], **f32)
                     jobs.append((dz_l, a_all[l], tmp, gB[l]))
@@ -704,7 +710,7 @@ class RelationalFunction(torch.autograd.Function):
         wgrad_late = OPT.wgrad_late if (alg0 and not inj) else 0
         if overlap:
             main, side = torch.cuda.current_stream(), _side_stream(dev)
-            keep = [list(dZs), list(inputs), gated_mask, dxg]      # keep operands alive until the join
+            keep = [list(dZs), list(inputs), gated_mask, gate_img, dxg]      # keep operands alive until the join
             dz_all = dict(dZ_of)
 
             def _launch_wgrads():

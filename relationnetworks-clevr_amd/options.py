@@ -21,6 +21,7 @@ _SPEC = {
     "algebraic_fwd0":    ("RN_NO_ALGEBRAIC_FWD0", True, "first layer factored through the pair structure (tables instead of the pair matrix)"),
     "algebraic_wgrad0":  ("RN_NO_ALGEBRAIC_WGRAD0", True, "layer-0 weight gradient from the pair reductions"),
     "gated_wgrad":       ("RN_NO_GATED_WGRAD", True, "last layer's gradient never stored (gate job of rn_g_wgrad_blocked)"),
+    "gate_fwd":          ("RN_NO_GATE_FWD", True, "... and its gate image written by the f16s forward chain (else by rn_relu_gate_image in the backward pass)"),
     "rq_from_wgrad":     ("RN_NO_RQ_FROM_WGRAD", True, "injected layer's per-question sums from the weight-gradient kernel's db partials"),
     "fused_pair_tail":   ("RN_NO_FUSED_PAIR_TAIL", True, "dx and dq in one launch (rn_pair_dx_dq), straight into the conv grid's layout"),
     "fused_pair_sum":    ("RN_NO_FUSED_PAIR_SUM", True, "pair-sum partials added inside the f_phi launch"),

@@ -38,7 +38,7 @@ SIGNATURES = {
     "rn_g_chain_fwd_rr_f16s": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_alg0": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _I, _P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
-    "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_sum_tiles": (_I, [_P, _P, _I, _I, _I, _P]),
     "rn_f_phi_fwd_from_partials": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -320,10 +320,11 @@ def g_chain_fwd_rr_alg0(Xp, Vc, n, Wfs, biases, Hs, masks, xg_part, M, G, Vq=Non
 
 
 @_timed("g_fwd")
-def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlo0, biases, Hs, masks, xg_part, M, G, Vq=None, inject=0, njp=None):
+def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlo0, biases, Hs, masks, xg_part, M, G, Vq=None, inject=0, njp=None, gate=None):
     """f16s forward chain with the factored first layer (fp16 object rows, no pair matrix).  Whis[0] / Wlo0: the hi / lo images of
     layer 0; Whis[1..3]: (dither, 65536) fp16 tile-dithered hi images each.  njp > n: padded j axis (M = B * n * njp, Xp16 with a
-    trailing zero row, two partial rows per tile in xg_part)."""
+    trailing zero row, two partial rows per tile in xg_part).  gate: (M * 256) e4m3 bytes receiving the last layer's gate image
+    (what relu_gate_image builds from masks[3]); with e4m3 Hs only."""
     L = len(Whis)
     dither = Whis[1].numel() // 65536
     hp = (C.c_void_p * L)(*[w.data_ptr() for w in Whis])
@@ -331,8 +332,8 @@ def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlo0, biases, Hs, masks, xg_part
     bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
     op = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
-    _check(load().rn_g_chain_fwd_rr_f16s_alg0(Xp16.data_ptr(), Vc.data_ptr(), n, njp or n, hp, lp, dither, bp, op, _h_code(Hs), mp, xg_part.data_ptr(), _ptr(Vq),
-                                              inject, M, L, G, _stream()), "rn_g_chain_fwd_rr_f16s_alg0")
+    _check(load().rn_g_chain_fwd_rr_f16s_alg0(Xp16.data_ptr(), Vc.data_ptr(), n, njp or n, hp, lp, dither, bp, op, _h_code(Hs), mp, _ptr(gate),
+                                              xg_part.data_ptr(), _ptr(Vq), inject, M, L, G, _stream()), "rn_g_chain_fwd_rr_f16s_alg0")
 
 
 @_timed("g_fwd")

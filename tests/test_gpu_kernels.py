@@ -550,6 +550,20 @@ def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
             assert same >= 0.97, (l, same)
             d = (Hs8[l].float() - HsA[l].float()).abs()
             assert bool((d <= HsA[l].float().abs() * 2.0 ** -4 + 2.0 ** -10).all()), l
+        # ... and with the last layer's gate image written from the epilogue: everything else bitwise as before, the image
+        # bitwise what rn_relu_gate_image builds from the layer's lane masks
+        Hg = [torch.full((M, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [None]
+        mg = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
+        pg = torch.full((M // 256, G), float("nan"), dtype=torch.float32, device="cuda")
+        gate = torch.full((M, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn)
+        H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, Hg, mg, pg, M, G, gate=gate)
+        torch.cuda.synchronize()
+        assert torch.equal(pg, p8)
+        for l in range(L):
+            assert torch.equal(mg[l], m8[l]), l
+        for l in range(3):
+            assert torch.equal(unblock(Hg[l]).view(torch.uint8), Hs8[l].view(torch.uint8)), l
+        assert torch.equal(gate.view(torch.uint8), H.relu_gate_image(m8[3], M).view(torch.uint8))
 
 
 @pytest.mark.parametrize("B,n", [(16, 196), (4, 40)])
@@ -605,6 +619,19 @@ def test_g_chain_fwd_rr_f16s_alg0_padded(H, B, n):
         assert (valid(gA) != gP).float().mean().item() <= 5e-3, l
         inval = gA.view(B * n, njp, G)[:, n:]
         assert not inval.any(), l                              # padded rows: gates cleared in every layer
+    # e4m3 copies + the last layer's gate image from the epilogue: the image is bitwise rn_relu_gate_image of the layer's masks
+    # (zero on the padded rows), the masks and pair sums those of the run above
+    H8 = [torch.full((Mp, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [None]
+    m8 = list(torch.zeros(L, H.g_chain_rr_mask_bytes(Mp), dtype=torch.uint8, device="cuda"))
+    p8 = torch.full_like(pA, float("nan"))
+    gate = torch.full((Mp, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn)
+    H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, H8, m8, p8, Mp, G, njp=njp, gate=gate)
+    torch.cuda.synchronize()
+    assert torch.equal(p8, pA)
+    for l in range(L):
+        assert torch.equal(m8[l], mA[l]), l
+    assert torch.equal(gate.view(torch.uint8), H.relu_gate_image(m8[3], Mp).view(torch.uint8))
+    assert not unblock(gate).view(torch.uint8).view(B * n, njp, G)[:, n:].any()
 
 
 @pytest.mark.parametrize("mode,M", [("train", 256 * 290), ("infer", 256 * 5)])
