@@ -28,4 +28,4 @@ def pretty(k):
         if ch == ">": depth -= 1
         if ch == "(" and depth == 0: break
         out += ch
-    return out[-72:]
+    return out[-96:]

@@ -10,7 +10,7 @@ from kname import pretty
 for k, d in acc.items():
     m = {c: sum(v) / len(v) for c, v in d.items()}
     name = pretty(k)
-    line = "%-72s" % name
+    line = "%-96s" % name
     wc = m.get("SQ_WAVE_CYCLES", 0)
     for c in sorted(m):
         line += " %s=%.3g" % (c.replace("SQ_", ""), m[c])
