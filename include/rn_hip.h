@@ -398,8 +398,10 @@ int rn_bn_relu_fwd(const float* x, float* y, const float* gamma, const float* be
                    float eps, float momentum, int N, int C, int HW, void* stream);
 int rn_bn_relu_apply(const float* x, float* y, const float* gamma, const float* beta, const float* mean, const float* invstd,
                      int N, int C, int HW, void* stream);
+/* zero_out (may be NULL): C floats set to 0 by the same launch -- the conv-bias gradient (identically zero, see above) as a tensor of
+ * its own without a fill launch (a shared zero vector handed to autograd for several leaves is cloned: a memcpy node per layer). */
 int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const float* gamma, const float* beta, const float* mean,
-                   const float* invstd, float* dgamma, float* dbeta, void* ws, int N, int C, int HW, void* stream);
+                   const float* invstd, float* dgamma, float* dbeta, float* zero_out, void* ws, int N, int C, int HW, void* stream);
 
 /* The first g layer factored through the pair structure (question injected at layer 0; model.py:130-139 builds the pair
  * matrix [x_j | x_i | q] and multiplies it by W0): W0 [x_j | x_i | q] + b0 = W0a x_j + (W0b x_i + W0c q + b0).

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(CN_T) void cn_bwd_apply_kernel(const f32x4* __restr
                                                             double count, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int C, int hw4, long n4) {
+                                                            float* __restrict__ dbeta, float* __restrict__ zero_out, int C, int hw4, long n4) {
   const int c = blockIdx.y;
   double s1 = 0.0, s2 = 0.0;
   for (int s = 0; s < S; ++s) {
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(CN_T) void cn_bwd_apply_kernel(const f32x4* __restr
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     dgamma[c] = dga;
     dbeta[c] = (float)s1;
+    if (zero_out) zero_out[c] = 0.f;
   }
   const float sc = ga * is, sh = beta[c] - m * sc;
   const float k0 = (float)(s1 / count), k1 = (float)((double)dga * is / count);
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(CF_T) void cn_bwd_fused_kernel(const f32x4* __restr
                                                             f32x4* __restrict__ dx, double count, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int C, int hw4, long n4) {
+                                                            float* __restrict__ dbeta, float* __restrict__ zero_out, int C, int hw4, long n4) {
   __shared__ double red[2 * CF_T / 64];
   const int c = blockIdx.x, t = threadIdx.x;
   const float m = mean[c], is = invstd[c], ga = gamma[c];
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(CF_T) void cn_bwd_fused_kernel(const f32x4* __restr
   if (t == 0) {
     dgamma[c] = dga;
     dbeta[c] = (float)s[0];
+    if (zero_out) zero_out[c] = 0.f;
   }
   const float k0 = (float)(s[0] / count), k1 = (float)((double)dga * is / count);
 #pragma unroll(KEEP ? NV : 2)
@@ -394,7 +396,7 @@ extern "C" int rn_bn_relu_apply(const float* x, float* y, const float* gamma, co
 }
 
 extern "C" int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const float* gamma, const float* beta, const float* mean,
-                              const float* invstd, float* dgamma, float* dbeta, void* ws, int N, int C, int HW, void* stream) {
+                              const float* invstd, float* dgamma, float* dbeta, float* zero_out, void* ws, int N, int C, int HW, void* stream) {
   if (int rc = cn_check("rn_bn_relu_bwd", dy, x, N, C, HW)) return rc;
   RN_CHECK_ARG(dx && gamma && beta && mean && invstd && dgamma && dbeta && ws && (uintptr_t)dx % 16 == 0, "rn_bn_relu_bwd: NULL / misaligned argument");
   const long n4 = (long)N * HW / 4;
@@ -402,8 +404,8 @@ extern "C" int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const 
   hipStream_t s = (hipStream_t)stream;
   if (n4 <= 4 * CF_T) {
     const double cnt = (double)N * HW;
-    if (n4 <= CF_T) cn_bwd_fused_kernel<1, true><<<C, CF_T, 0, s>>>((const f32x4*)dy, (const f32x4*)x, (f32x4*)dx, cnt, mean, invstd, gamma, beta, dgamma, dbeta, C, hw4, n4);
-    else cn_bwd_fused_kernel<4, true><<<C, CF_T, 0, s>>>((const f32x4*)dy, (const f32x4*)x, (f32x4*)dx, cnt, mean, invstd, gamma, beta, dgamma, dbeta, C, hw4, n4);
+    if (n4 <= CF_T) cn_bwd_fused_kernel<1, true><<<C, CF_T, 0, s>>>((const f32x4*)dy, (const f32x4*)x, (f32x4*)dx, cnt, mean, invstd, gamma, beta, dgamma, dbeta, zero_out, C, hw4, n4);
+    else cn_bwd_fused_kernel<4, true><<<C, CF_T, 0, s>>>((const f32x4*)dy, (const f32x4*)x, (f32x4*)dx, cnt, mean, invstd, gamma, beta, dgamma, dbeta, zero_out, C, hw4, n4);
     RN_LAUNCH_CHECK("rn_bn_relu_bwd(fused)");
     return 0;
   }
@@ -411,7 +413,7 @@ extern "C" int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const 
   int gx = (int)((n4 + CN_T * 4 - 1) / (CN_T * 4));
   if (gx < 1) gx = 1;
   cn_bwd_apply_kernel<<<dim3(gx, C), CN_T, 0, s>>>((const f32x4*)dy, (const f32x4*)x, (f32x4*)dx, (const double*)ws, S, (double)N * HW,
-                                                   mean, invstd, gamma, beta, dgamma, dbeta, C, hw4, n4);
+                                                   mean, invstd, gamma, beta, dgamma, dbeta, zero_out, C, hw4, n4);
   RN_LAUNCH_CHECK("rn_bn_relu_bwd");
   return 0;
 }

@@ -261,7 +261,8 @@ def _tables(x, q, plan, g_b, w0T, inj_w, xdt, B, n, k, Q, G, coord=None):
     coord (2, n): x is the conv grid itself (kf = k - 2 columns), the coordinate tags are read from the table in the kernel."""
     dev = x.device
     Xp = torch.empty(B * n + 1, 64, dtype=xdt, device=dev)       # (+ the all-zero object row the padded-j chain reads for j >= n)
-    Xp[B * n].zero_()
+    if n % 32:                                                   # (only the padded-j chain reads the row: no fill launch otherwise)
+        Xp[B * n].zero_()
     Vc = torch.empty(B * n, G, dtype=torch.float32, device=dev)
     if inj_w is None:
         H.pair_tables(x, q, w0T, g_b[0], Xp, Vc, B, n, k, Q, G, coord=coord)
@@ -926,7 +927,10 @@ class ConvBNReLUFunction(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dgamma = torch.empty_like(g); dbeta = torch.empty_like(bt)
-        H.bn_relu_bwd(dy, x, dx, g, bt, mean, invstd, dgamma, dbeta)
+        # the conv-bias gradient (identically zero) is a tensor of its own, zeroed by the same launch: a shared zero vector would be
+        # CLONED by autograd for every leaf it is handed to -- one memcpy node per layer on the critical path of the captured step
+        db = torch.empty_like(bt) if ctx.has_bias else None
+        H.bn_relu_bwd(dy, x, dx, g, bt, mean, invstd, dgamma, dbeta, zero_out=db)
         conv_bwd = lambda mask: torch.ops.aten.convolution_backward(dx, inp, conv_w, None, stride, padding, (1, 1), False, (0, 0), 1, mask)
         if ctx.needs_input_grad[0] and OPT.wgrad_overlap and _assign_only(ctx.w_ref):
             # only the input gradient is on the dependency chain of the backward pass: the weight gradient (MIOpen's
@@ -960,7 +964,6 @@ class ConvBNReLUFunction(torch.autograd.Function):
             H.conv3x3s2_bwd_weight(inp, dx, dw)
         else:
             din, dw, _ = conv_bwd([ctx.needs_input_grad[0], True, False])
-        db = _zeros_like_cached(conv_w.shape[0], conv_w) if ctx.has_bias else None
         return din, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 

@@ -91,7 +91,7 @@ SIGNATURES = {
     "rn_bn_relu_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_bn_relu_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _I, _I, _P]),
     "rn_bn_relu_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "rn_bn_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "rn_bn_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
 }
 # diagnostics (include/rn_hip_debug.h): tests / tools only, not part of the product ABI
 DEBUG_SIGNATURES = {
@@ -562,12 +562,14 @@ def bn_relu_apply(x, y, gamma, beta, mean, invstd):
 
 
 @_timed("bn_relu")
-def bn_relu_bwd(dy, x, dx, gamma, beta, mean, invstd, dgamma, dbeta):
+def bn_relu_bwd(dy, x, dx, gamma, beta, mean, invstd, dgamma, dbeta, zero_out=None):
+    """zero_out: C floats the same launch sets to zero (the conv-bias gradient)."""
     N, Cc, Hh, Ww = x.shape
     lib = load()
     ws = torch.empty(max(lib.rn_bn_relu_ws_bytes(N, Cc, Hh * Ww), 16), dtype=torch.uint8, device=x.device)
     _check(lib.rn_bn_relu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
-                              invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), N, Cc, Hh * Ww, _stream()), "rn_bn_relu_bwd")
+                              invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(zero_out), ws.data_ptr(), N, Cc, Hh * Ww, _stream()),
+           "rn_bn_relu_bwd")
 
 
 # ------------------------------------------------------------------ fused f_phi
