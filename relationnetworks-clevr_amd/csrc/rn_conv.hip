@@ -273,6 +273,87 @@ __global__ __launch_bounds__(CV_T) void conv3x3s2_bwd_data_ks_kernel(const float
   }
 }
 
+// ---- the large layers on the fp32 matrix pipe.  The convolution as a (24 x 9 CIN) x (9 CIN x pixels) product with
+// v_mfma_f32_32x32x2_f32 (a k-ordered fp32 FMA chain per output, like the scalar loop): A = the weights (rows = output channels,
+// padded to 32), B = the input taps of 32 consecutive output pixels of one row, D[co][pixel] -- a lane then owns ONE pixel and the
+// stores of a channel are 128 contiguous bytes.  The reduction index is ordered (channel pair, tap) with the two k-values of an
+// instruction = channels c and c + CP / 2 at the same tap: the per-lane LDS address of the tap is then a constant offset from a
+// lane base (one ds_read_b32 with an immediate offset per MFMA), and a lane's weights (9 CP / 2 floats) stay in registers for
+// the life of the workgroup.  Unit = (image, 4 output rows, 32-pixel segment): the 9 input rows x 65 columns of all channels
+// are staged in LDS (zero padded), wave w computes output row w.  CP = channels padded to even (24 -> 24, 3 -> 4).
+template <int CIN, int CP>
+__global__ __launch_bounds__(256) void conv3x3s2_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                                 int N, int H, int W, int units, int segs) {
+  constexpr int NK = 9 * CP / 2, CS = 66, HALF = CP / 2;
+  extern __shared__ __attribute__((aligned(16))) float cm_smem[];     // [CP][9][CS]
+  const int OH = H >> 1, OW = W >> 1;
+  const int t = threadIdx.x, l = t & 63, wv = t >> 6, p = l & 31, h = l >> 5;
+  // this lane's weights: row co = p, k-values (channel cp + HALF h, tap)
+  float wr[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    const int cp = kk / 9, tap = kk - 9 * cp, ci = cp + HALF * h;
+    const bool ok = p < 24 && ci < CIN;
+    const float u = w[((long)(ok ? p : 0) * CIN + (ok ? ci : 0)) * 9 + tap];
+    wr[kk] = ok ? u : 0.f;
+  }
+  const int lane_base = (HALF * h * 9 + 2 * wv) * CS + 2 * p;
+  const int rpi = (OH + 3) / 4;                                       // row blocks per image
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int seg = u % segs, rb = (u / segs) % rpi, n = u / (segs * rpi);
+    const int oy0 = 4 * rb, ox0 = 32 * seg;
+    const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;                   // staged (row 0, column 0)
+    __syncthreads();                                                  // the previous unit's reads are done
+    // staging: wave wv takes rows wv, wv + 4, ..; lanes walk the columns; EVERY load of the unit is issued before the first LDS
+    // write waits on one (unconditional loads from clamped addresses: one memory round trip per unit, not one per batch)
+    constexpr int NR = (CP * 9 + 3) / 4;                                // rows per wave
+    constexpr int NB = NR > 32 ? 4 : 1, RB = (NR + NB - 1) / NB;        // (24 channels: four batches of 14 loads -- the lane's 108 weights live in registers too)
+#pragma unroll 1
+    for (int b = 0; b < NB; ++b) {
+      float v[RB];
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const int row = wv + 4 * (b * RB + q), ci = row / 9, iy = iy0 + (row - ci * 9), ix = ix0 + l;
+        const bool ok = b * RB + q < NR && row < CP * 9 && ci < CIN && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const int off = ok ? ((n * CIN + ci) * H + iy) * W + ix : 0;     // (32-bit element offsets: N Cin H W < 2^31, checked on the host)
+        const float u = x[off];
+        v[q] = ok ? u : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const int row = wv + 4 * (b * RB + q);
+        if (b * RB + q < NR && row < CP * 9) cm_smem[row * CS + l] = v[q];
+      }
+    }
+    float e = 0.f;                                                      // column 64 of row t
+    {
+      const int row = t < CP * 9 ? t : 0, ci = row / 9, iy = iy0 + (row - ci * 9), ix = ix0 + 64;
+      const bool ok = t < CP * 9 && ci < CIN && iy >= 0 && iy < H && ix < W;
+      const float u = x[ok ? ((n * CIN + ci) * H + iy) * W + ix : 0];
+      e = ok ? u : 0.f;
+    }
+    if (t < CP * 9) cm_smem[t * CS + 64] = e;
+    __syncthreads();
+    typedef __attribute__((ext_vector_type(16))) float f32x16_;
+    f32x16_ acc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+    const float* xb = cm_smem + lane_base;
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      const int cp = kk / 9, tap = kk - 9 * cp, ky = tap / 3, kx = tap - 3 * ky;
+      acc[kk & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[kk], xb[(cp * 9 + ky) * CS + kx], acc[kk & 1], 0, 0, 0);
+    }
+    const int oy = oy0 + wv, ox = ox0 + p;
+    if (oy < OH && ox < OW) {
+      // D row co = 8 (i / 4) + 4 h + i % 4 (i < 12: the 24 real channels), D column = this lane's pixel
+      float* yo = y + (((long)n * 24) * OH + oy) * OW + ox;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) yo[(long)(8 * (i >> 2) + 4 * h + (i & 3)) * OH * OW] = acc[0][i] + acc[1][i];
+    }
+  }
+}
+
 static int cv_check(const char* who, const void* a, const void* b, const void* c, int N, int Cin, int Cout, int H, int W) {
   RN_CHECK_ARG(a && b && c && N > 0 && H > 0 && W > 0, "%s: bad pointer/size", who);
   RN_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && Cout == 24 && (Cin == 3 || Cin == 24),
@@ -286,6 +367,19 @@ extern "C" int rn_conv3x3s2_fwd(const float* x, const float* w, float* y, int N,
   const long px = (long)N * (H / 2) * (W / 2);
   const int gx = (int)((px + CV_T - 1) / CV_T);
   // big layers: 24 channels per thread (fewest input reads); small ones: 8 per thread, 3x the waves
+  // (the 3-channel layer stays on the scalar kernel: K = 27 is too short for the staging to pay -- 15.6 us against 13.1)
+  bool mfma = Cin == 24 && px >= 32768 && W >= 64 && (long)N * Cin * H * W < (1L << 31);
+  if (const char* e = rn_diag_env("RN_CONV_MFMA")) mfma = mfma && atoi(e) != 0;      // (diagnostics builds: A/B against the scalar kernels)
+  if (mfma) {
+    // the large layers: fp32 matrix pipe (units of 4 output rows x 32 pixels; all channels of the 9 input rows in LDS)
+    const int segs = (W / 2 + 31) / 32, units = N * ((H / 2 + 3) / 4) * segs;
+    const size_t shm = (size_t)24 * 9 * 66 * sizeof(float);
+    const int grid = units < 1024 ? units : 1024;
+    (void)hipFuncSetAttribute((const void*)conv3x3s2_fwd_mfma_kernel<24, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    conv3x3s2_fwd_mfma_kernel<24, 24><<<grid, 256, shm, (hipStream_t)stream>>>(x, w, y, N, H, W, units, segs);
+    RN_LAUNCH_CHECK("rn_conv3x3s2_fwd(mfma)");
+    return 0;
+  }
   if (Cin == 3) conv3x3s2_fwd_kernel<3, 24, 24><<<dim3(gx, 1), CV_T, 0, (hipStream_t)stream>>>(x, w, y, N, H, W);
   else if (px >= 200000) conv3x3s2_fwd_kernel<24, 24, 24><<<dim3(gx, 1), CV_T, 0, (hipStream_t)stream>>>(x, w, y, N, H, W);
   else if (px >= CV_KS_MAX) conv3x3s2_fwd_kernel<24, 24, 8><<<dim3(gx, 3), CV_T, 0, (hipStream_t)stream>>>(x, w, y, N, H, W);
@@ -299,6 +393,8 @@ extern "C" int rn_conv3x3s2_bwd_data(const float* dy, const float* w, float* dx,
   RN_CHECK_ARG(Cin == 24 && (uintptr_t)dx % 8 == 0, "rn_conv3x3s2_bwd_data: built for 24 input channels");
   const long px = (long)N * (H / 2) * (W / 2);
   const int gx = (int)((px + CV_T - 1) / CV_T);
+  // (the same product on the fp32 matrix pipe as the forward's large-layer kernel was built too -- four accumulator tiles, one per
+  // pixel parity: 21.2 us against 24.0 on the 32 x 32 -> 64 x 64 layer, nothing on the 14 x 14 grid's layers: not kept)
   if (px >= CV_KS_MAX) conv3x3s2_bwd_data_kernel<24, 24, 8><<<dim3(gx, 3), CV_T, 0, (hipStream_t)stream>>>(dy, w, dx, N, H, W);
   else conv3x3s2_bwd_data_ks_kernel<24, 24, 8><<<dim3((int)((px + 63) / 64), 3), CV_T, 0, (hipStream_t)stream>>>(dy, w, dx, N, H, W);
   RN_LAUNCH_CHECK("rn_conv3x3s2_bwd_data");
