@@ -9,6 +9,7 @@ PyTorch only allocates buffers and supplies the stream; all arithmetic runs in
 librn_hip.so.  There is no CPU / eager fallback."""
 from __future__ import annotations
 
+import os
 import torch
 
 from . import rn_hip as H
@@ -729,6 +730,8 @@ class RelationalFunction(torch.autograd.Function):
                                 continue                           # layer 0: from the pair reductions, below
                             _wgrad(l, dz_all[l], inputs_all[l])
             inputs_all = list(inputs)
+            # (capturing this fork BEHIND the main stream's next launch -- same dependencies, the trick that removed the launch gaps of
+            # the conv-stack backward -- made the step 17 % slower here: the replayed graph's queue mapping is not ours to steer)
             if not wgrad_late:
                 _launch_wgrads()
 
@@ -936,8 +939,19 @@ class ConvBNReLUFunction(torch.autograd.Function):
             # only the input gradient is on the dependency chain of the backward pass: the weight gradient (MIOpen's
             # wrw kernel plus its layout transposes, ~half of the conv backward) goes to the side stream and overlaps the
             # next layers' backward; the main stream re-joins at the end of the backward pass
-            main, side = torch.cuda.current_stream(), _side_stream(dx.device, 1)     # (stream 0 carries the g_theta wgrads)
-            side.wait_stream(main)
+            # Captured order and stream matter here (tools/step_timeline.py, same box): the input gradient is launched FIRST and the
+            # weight gradient forks off the event recorded before it -- with the fork in front, every bwd_data launch of the
+            # captured step started 10-18 us late -- and the weight gradients share the g_theta weight-gradient stream instead of a
+            # stream of their own: the ROCm graph executor maps the capture's streams onto 4 hardware queues, and a fourth side
+            # stream ended up behind another one's kernels (the LSTM backward then started 100 us late).  Together -2.5 % on the step.
+            main, side = torch.cuda.current_stream(), _side_stream(dx.device, 0)
+            ev = main.record_event()
+            if ctx.direct and inp.shape[1] == 24:
+                din = torch.empty_like(inp)
+                H.conv3x3s2_bwd_data(dx, conv_w.detach().contiguous(), din)
+            else:
+                din = conv_bwd([True, False, False])[0]
+            side.wait_event(ev)
             with torch.cuda.stream(side):
                 if ctx.direct and OPT.direct_conv_wgrad:
                     dw = torch.empty_like(conv_w)
@@ -953,11 +967,6 @@ class ConvBNReLUFunction(torch.autograd.Function):
                 torch.cuda.current_stream().wait_stream(side)
                 keep.clear()
             torch.autograd.Variable._execution_engine.queue_callback(_join)
-            if ctx.direct and inp.shape[1] == 24:
-                din = torch.empty_like(inp)
-                H.conv3x3s2_bwd_data(dx, conv_w.detach().contiguous(), din)
-            else:
-                din = conv_bwd([True, False, False])[0]
         elif ctx.direct and not ctx.needs_input_grad[0] and OPT.direct_conv_wgrad:
             din = None                                                 # first layer (the image needs no gradient): the END of
             dw = torch.empty_like(conv_w)                              # the backward pass, nothing left to overlap with
