@@ -48,8 +48,10 @@ class FlatGradBucket:
             total += p.numel()
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.numel = total
+        self.offsets = offs
         self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, offs)]
         self._zeros = {}
+        RF.register_grad_slots(self.params, self.flat, offs)     # backward kernels may then write gradients in place (gather mode)
         self.attach_()
 
     def attach_(self):
@@ -62,16 +64,31 @@ class FlatGradBucket:
             p.grad = None
 
     def gather_(self):
-        """Pack the freshly produced gradients into the flat buffer (one cat kernel) and re-attach."""
-        parts = []
-        for p in self.params:
+        """Make the flat buffer hold this backward pass's gradients and re-attach the views.  Gradients the backward kernels
+        wrote straight into their slots (functional.grad_out) are already in place; if every one is, nothing is launched;
+        if none is, ONE concatenation kernel packs them; a few strays are copied one by one."""
+        base, stray = self.flat.data_ptr(), []
+        for p, o in zip(self.params, self.offsets):
             g = p.grad
-            if g is None:                                   # parameter unused in this graph (e.g. conv for *-sd)
-                g = self._zeros.get(p.numel())
+            if g is not None and g.is_contiguous() and g.data_ptr() == base + 4 * o:
+                continue
+            stray.append((p, o, g))
+        if len(stray) == len(self.params):
+            parts = []
+            for p, o, g in stray:
+                if g is None:                               # parameter unused in this graph (e.g. conv for *-sd)
+                    g = self._zeros.get(p.numel())
+                    if g is None:
+                        g = self._zeros[p.numel()] = torch.zeros(p.numel(), dtype=torch.float32, device=self.flat.device)
+                parts.append(g.reshape(-1))
+            torch.cat(parts, out=self.flat)
+        else:
+            for p, o, g in stray:
+                slot = self.flat[o:o + p.numel()]
                 if g is None:
-                    g = self._zeros[p.numel()] = torch.zeros(p.numel(), dtype=torch.float32, device=self.flat.device)
-            parts.append(g.reshape(-1))
-        torch.cat(parts, out=self.flat)
+                    slot.zero_()
+                else:
+                    slot.copy_(g.reshape(-1))
         self.attach_()
 
     def zero_(self):

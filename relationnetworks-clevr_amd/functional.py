@@ -177,6 +177,34 @@ def _side_stream(dev, which=0):
     return s
 
 
+# ---- gradients straight into a FlatGradBucket (dp.py) ---------------------------------------------------------------
+# A bucket registers (parameter -> slot of its flat buffer).  A backward function that is about to allocate the gradient of a
+# registered parameter takes a FRESH VIEW of the slot instead and lets its kernels write there: autograd then assigns that
+# view as .grad (no copy: a fresh view is uniquely owned), and the bucket's gather step finds the gradient already in place --
+# no concatenation kernel between the end of the backward pass and the optimiser.  Only when autograd will ASSIGN
+# (_assign_only: .grad is None, no hooks): accumulating `grad += view-of-the-same-memory` would double the new gradient.
+_GRAD_SLOTS = {}
+
+
+def register_grad_slots(params, flat, offsets):
+    import weakref
+    for p_, o in zip(params, offsets):
+        _GRAD_SLOTS[id(p_)] = (weakref.ref(p_), weakref.ref(flat), o)
+
+
+def grad_out(param, shape=None):
+    """The tensor a backward function writes `param`'s gradient into (see above); shape: the gradient's shape when the caller
+    needs another one than the parameter's (then no slot is used unless the element count matches a contiguous view)."""
+    shape = tuple(param.shape) if shape is None else tuple(shape)
+    slot = _GRAD_SLOTS.get(id(param)) if OPT.grads_in_bucket else None
+    if slot is not None:
+        pref, fref, off = slot
+        flat = fref()
+        if pref() is param and flat is not None and flat.device == param.device and shape == tuple(param.shape) and _assign_only(param):
+            return flat[off:off + param.numel()].view(shape)
+    return torch.empty(shape, dtype=torch.float32, device=param.device)
+
+
 class RRMasks:
     """ReLU lane masks of the register-resident forward chain: what the backward pass keeps INSTEAD of the last
     activation (rn_g_chain_fwd_rr / rn_g_chain_bwd_rr)."""
@@ -572,6 +600,7 @@ class RelationalFunction(torch.autograd.Function):
             ctx.fragT = list(packed.fragT)
             ctx.g_w = [w.detach() for w in g_w]
             ctx.param_refs = list(g_w) + list(g_b)
+            ctx.f_param_refs = list(f_w) + list(f_b)
             ctx.fw = fw
             ctx.mask = mask
             ctx.save_for_backward(x, q, xg, f1, f2, out)
@@ -598,9 +627,10 @@ class RelationalFunction(torch.autograd.Function):
             gloss = gloss.float().contiguous()
         fw = ctx.fw
         # ---- f_phi backward (fp32): two launches (dz chain incl. log_softmax; all weight / bias gradients)
-        dW3 = torch.empty(A, F2, **f32); db3 = torch.empty(A, **f32)
-        dW2 = torch.empty(F2, F1, **f32); db2 = torch.empty(F2, **f32)
-        dW1 = torch.empty(F1, G, **f32); db1 = torch.empty(F1, **f32)
+        fp = ctx.f_param_refs                                # (f_fc1..3 weights, then biases)
+        dW3 = grad_out(fp[2], (A, F2)); db3 = grad_out(fp[5], (A,))
+        dW2 = grad_out(fp[1], (F2, F1)); db2 = grad_out(fp[4], (F2,))
+        dW1 = grad_out(fp[0], (F1, G)); db1 = grad_out(fp[3], (F1,))
         dxg = torch.empty(B, G, **f32)
         if gout is None:
             H.f_phi_bwd_nll(gloss, label, out, f2, f1, xg, fw, ctx.mask, (dW1, dW2, dW3), (db1, db2, db3), dxg)
@@ -650,8 +680,8 @@ class RelationalFunction(torch.autograd.Function):
 
         def _wgrad(l, dz, a_l):                                        # row-major operands: the general kernel
             N_, kt_, kp_ = plan.widths[l], plan.ktrue[l], plan.kpad[l]
-            gW[l] = torch.empty(N_, kt_, **f32)
-            gB[l] = torch.empty(N_, **f32)
+            gW[l] = grad_out(ctx.param_refs[l], (N_, kt_))
+            gB[l] = grad_out(ctx.param_refs[L + l], (N_,))
             H.g_linear_bwd_wgrad(dz, N_, a_l, kp_, gW[l], gB[l], code, M, N_, kp_, kt_)
 
         def _wgrads_blocked(dz_all, a_all):
@@ -666,8 +696,8 @@ class RelationalFunction(torch.autograd.Function):
             jobs, tmp = [], None
             for l in order:
                 N_, kt_ = plan.widths[l], plan.ktrue[l]
-                gW[l] = torch.empty(N_, kt_, **f32)
-                gB[l] = torch.empty(N_, **f32)
+                gW[l] = grad_out(ctx.param_refs[l], (N_, kt_))
+                gB[l] = grad_out(ctx.param_refs[L + l], (N_,))
                 # the last layer without a stored gradient: its gate as an e4m3 {0, 1} image, scaled by dxg per question in the kernel
                 dz_l = dz_all[l] if dz_all[l] is not None else (gate_img if gate_img is not None else H.relu_gate_image(gated_mask, Mc))
                 if inj and l == plan.inject:
@@ -784,8 +814,8 @@ class RelationalFunction(torch.autograd.Function):
                 _launch_wgrads()
             if l == 0 and alg0:
                 def _wgrad0():
-                    gW[0] = torch.empty(N, kt, **f32)
-                    gB[0] = torch.empty(N, **f32)
+                    gW[0] = grad_out(ctx.param_refs[0], (N, kt))
+                    gB[0] = grad_out(ctx.param_refs[L], (N,))
                     H.wgrad0_from_reductions(Rj, Ri, Rq, x, q if plan.inject == 0 else None, gW[0], gB[0], coord=ctx.coord)
                 # (measured: on the conv weight-gradient stream instead -3.5 %, on the main stream behind dx / dq -1 %)
                 if overlap:                                        # off the critical path: onto the wgrad stream
@@ -919,6 +949,7 @@ class ConvBNReLUFunction(torch.autograd.Function):
             ctx.conv_args = (stride, padding)
             ctx.has_bias = conv_b is not None
             ctx.w_ref = conv_w                   # the leaf itself: backward looks at .grad / hooks (see _assign_only)
+            ctx.leaf_refs = (conv_b, gamma, beta)
         return y
 
     @staticmethod
@@ -929,10 +960,11 @@ class ConvBNReLUFunction(torch.autograd.Function):
         stride, padding = ctx.conv_args
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dgamma = torch.empty_like(g); dbeta = torch.empty_like(bt)
+        b_ref, gamma_ref, beta_ref = ctx.leaf_refs
+        dgamma = grad_out(gamma_ref); dbeta = grad_out(beta_ref)
         # the conv-bias gradient (identically zero) is a tensor of its own, zeroed by the same launch: a shared zero vector would be
         # CLONED by autograd for every leaf it is handed to -- one memcpy node per layer on the critical path of the captured step
-        db = torch.empty_like(bt) if ctx.has_bias else None
+        db = grad_out(b_ref) if ctx.has_bias else None
         H.bn_relu_bwd(dy, x, dx, g, bt, mean, invstd, dgamma, dbeta, zero_out=db)
         conv_bwd = lambda mask: torch.ops.aten.convolution_backward(dx, inp, conv_w, None, stride, padding, (1, 1), False, (0, 0), 1, mask)
         if ctx.needs_input_grad[0] and OPT.wgrad_overlap and _assign_only(ctx.w_ref):
@@ -954,7 +986,7 @@ class ConvBNReLUFunction(torch.autograd.Function):
             side.wait_event(ev)
             with torch.cuda.stream(side):
                 if ctx.direct and OPT.direct_conv_wgrad:
-                    dw = torch.empty_like(conv_w)
+                    dw = grad_out(ctx.w_ref)
                     H.conv3x3s2_bwd_weight(inp, dx, dw)                # fp32 matrix pipe, no layout transposes
                 else:
                     dw = conv_bwd([False, True, False])[1]
@@ -969,7 +1001,7 @@ class ConvBNReLUFunction(torch.autograd.Function):
             torch.autograd.Variable._execution_engine.queue_callback(_join)
         elif ctx.direct and not ctx.needs_input_grad[0] and OPT.direct_conv_wgrad:
             din = None                                                 # first layer (the image needs no gradient): the END of
-            dw = torch.empty_like(conv_w)                              # the backward pass, nothing left to overlap with
+            dw = grad_out(ctx.w_ref)                                   # the backward pass, nothing left to overlap with
             H.conv3x3s2_bwd_weight(inp, dx, dw)
         else:
             din, dw, _ = conv_bwd([ctx.needs_input_grad[0], True, False])
@@ -996,6 +1028,7 @@ class QuestionLSTMFunction(torch.autograd.Function):
             H.lstm_fwd(idx, *ws, xs, gates, cs, hs)
             ctx.save_for_backward(idx, xs, gates, cs, hs, ws[1], ws[2])
             ctx.vocab = emb.shape[0]
+            ctx.leaf_refs = (emb, W_ih, W_hh, b_ih, b_hh)
             return hs[T].clone()
         hn = torch.empty(B, Hh, **f32)
         H.lstm_fwd(idx, *ws, None, None, None, hn)
@@ -1008,15 +1041,18 @@ class QuestionLSTMFunction(torch.autograd.Function):
         dgates = torch.empty_like(gates)
         H.lstm_bwd(dhn.float().contiguous(), gates, cs, W_hh, dgates)
         dg = dgates.view(T * B, G4)
-        dW_hh = dg.t().mm(hs[:T].reshape(T * B, -1))
-        dW_ih = dg.t().mm(xs.view(T * B, -1))
-        db = dg.sum(0)
+        emb_r, wih_r, whh_r, bih_r, bhh_r = ctx.leaf_refs
+        dW_hh = torch.mm(dg.t(), hs[:T].reshape(T * B, -1), out=grad_out(whh_r))
+        dW_ih = torch.mm(dg.t(), xs.view(T * B, -1), out=grad_out(wih_r))
+        db = torch.sum(dg, 0, out=grad_out(bih_r))
+        db2 = grad_out(bhh_r)                   # (the same values; a tensor of its own: autograd would clone a shared one)
+        db2.copy_(db)
         demb = None
         if ctx.needs_input_grad[1]:
             dx = dg.mm(W_ih)
-            demb = torch.empty(ctx.vocab, xs.shape[2], dtype=torch.float32, device=dg.device)
+            demb = grad_out(emb_r, (ctx.vocab, xs.shape[2]))
             H.embedding_bwd(idx, dx, demb)
-        return None, demb, dW_ih, dW_hh, db, db
+        return None, demb, dW_ih, dW_hh, db, db2
 
 
 class NllMeanFunction(torch.autograd.Function):

@@ -36,6 +36,7 @@ _SPEC = {
     "overlap_streams":   ("RN_OVERLAP_STREAMS", True, "question encoder beside the conv stack (second stream)"),
     "fused_nll":         ("RN_NO_FUSED_NLL", True, "own NLL kernels"),
     "fused_loss":        ("RN_NO_FUSED_LOSS", True, "loss inside the f_phi launch (trainer)"),
+    "grads_in_bucket":   ("RN_NO_GRADS_IN_BUCKET", True, "backward kernels write parameter gradients straight into a registered FlatGradBucket (trainer)"),
     "fused_adam":        ("RN_NO_FUSED_ADAM", True, "fused clip + Adam on the flat bucket (trainer)"),
     "graph_adam":        ("RN_NO_GRAPH_ADAM", True, "... inside the captured step on one GPU"),
 }
