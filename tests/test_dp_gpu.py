@@ -29,6 +29,49 @@ def _free_port():
     return p
 
 
+def test_backward_writes_gradients_into_the_bucket_only_when_autograd_assigns():
+    """functional.grad_out: with a FlatGradBucket registered and .grad = None (the trainer's gather mode) every parameter
+    gradient of the whole model is produced in its slot of the flat buffer -- gather_() launches nothing -- and equals, bitwise,
+    what the fresh-tensor path gives; with .grad attached (accumulate mode) the slots are left alone and two backward passes
+    add up."""
+    import contextlib, io
+    import relationnetworks_clevr_amd as pkg
+    from relationnetworks_clevr_amd import dp
+    from bench import make_batch
+    import json
+    hyp = json.load(open(os.path.join(os.path.dirname(pkg.rn_hip.__file__), "config.json")))["hyperparams"]["original-fp"]
+    torch.manual_seed(3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = pkg.RN(A, dict(hyp, dropout=0.0))
+    model.cuda().train()
+    img, qst, lab = make_batch(8, torch.device("cuda"), 128)
+    bucket = dp.FlatGradBucket(model.parameters())
+
+    def backward():
+        torch.nn.functional.nll_loss(model(img, qst), lab).backward()
+
+    bucket.detach_()
+    backward()
+    base = bucket.flat.data_ptr()
+    for p_, o in zip(bucket.params, bucket.offsets):
+        assert p_.grad is not None and p_.grad.data_ptr() == base + 4 * o, "a gradient was not produced in its slot"
+    bucket.gather_()
+    in_place = bucket.flat.clone()
+    with pkg.options.override(grads_in_bucket=False):
+        bucket.detach_()
+        backward()
+        assert all(p_.grad.data_ptr() != base + 4 * o for p_, o in zip(bucket.params, bucket.offsets))
+        bucket.gather_()
+    assert torch.equal(bucket.flat, in_place)
+    # accumulate mode: .grad stays attached to the bucket, autograd adds into it -- the functions must NOT write there themselves
+    bucket.zero_()
+    backward()
+    backward()
+    torch.cuda.synchronize()
+    err = (bucket.flat - 2 * in_place).abs().max() / in_place.abs().max()
+    assert float(err) <= 1e-5, float(err)
+
+
 def test_fused_clip_adam_grad_scale_equals_single_rank_and_torch():
     import relationnetworks_clevr_amd as pkg
     from relationnetworks_clevr_amd import dp
