@@ -319,7 +319,7 @@ class RN(nn.Module):
             self.coord_tensor = keep
         return ct
 
-    def _text_on_side_stream(self, qst_idxs):
+    def _text_on_side_stream(self, qst_idxs, after=None):
         """The LSTM is a serial chain of ~20 tiny kernels that leaves the chip empty; fork it onto a
         second HIP stream so it (and, through autograd's stream bookkeeping, its backward) overlaps
         the conv stack.  Joined before the relational layer; capturable in a hipGraph."""
@@ -327,7 +327,10 @@ class RN(nn.Module):
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=qst_idxs.device)
         side = self._side_stream
-        side.wait_stream(cur)
+        if after is not None:
+            side.wait_event(after)
+        else:
+            side.wait_stream(cur)
         with torch.cuda.stream(side):
             self.rl._packed.repack_ahead()                      # this step's weight images: off the critical path, same fork/join
             self.rl.draw_dropout_ahead(qst_idxs.shape[0], qst_idxs.device)
@@ -341,12 +344,18 @@ class RN(nn.Module):
     def forward(self, img, qst_idxs, label=None):
         side = None
         coord = None
+        fork_ev = None
         if self.overlap_streams and qst_idxs.is_cuda and not self.state_desc:
-            qst, side = self._text_on_side_stream(qst_idxs)
+            # the question encoder forks off HERE (it depends on nothing of this pass) but is launched -- captured -- behind the conv
+            # stack: with the fork in front, the replayed graph's first conv kernels started late (-1.8 % on the step, same box;
+            # DESIGN.md, "capture order")
+            fork_ev = torch.cuda.current_stream().record_event()
         if self.state_desc:
             x = img                                             # (B, 12, 7) state descriptions
         else:
             x = self.conv(img)                                  # (B, 24, d, d)
+            if fork_ev is not None:
+                qst, side = self._text_on_side_stream(qst_idxs, after=fork_ev)
             b, k, d, _ = x.size()
             coord = None
             if self.rl.grid_fast_path(b, d * d, k + 2):
