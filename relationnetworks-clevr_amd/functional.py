@@ -882,18 +882,6 @@ def grid_path_ok(plan: LayerPlan, precision, B, n, k):
     return alg0_forward_ok(plan, code, n, k, M, f16s=precision == "f16s") and alg0_wgrad_ok(plan, k)
 
 
-_ZEROS = {}
-
-
-def _zeros_like_cached(n, ref):
-    """A shared read-only zero vector (the conv-bias gradient): no fill kernel per step."""
-    key = (n, ref.dtype, ref.device)
-    z = _ZEROS.get(key)
-    if z is None:
-        z = _ZEROS[key] = torch.zeros(n, dtype=ref.dtype, device=ref.device)
-    return z
-
-
 def _direct_conv_ok(inp, conv_w, stride, padding):
     return (OPT.direct_conv and inp.dtype == torch.float32 and tuple(conv_w.shape[2:]) == (3, 3)
             and tuple(stride) == (2, 2) and tuple(padding) == (1, 1) and conv_w.shape[0] == 24 and conv_w.shape[1] in (3, 24)
