@@ -314,6 +314,17 @@ int rn_f_phi_fwd_from_partials(const float* xg_part, int parts_per_row, float* x
                                const float* b2, const float* W3, const float* b3, const float* mask, const long long* label, float* f1,
                                float* f2, float* out, float* loss, void* sync_ws, int transposed, int B, int G, int F1, int F2, int A,
                                void* stream);
+/* The training step's f_phi in ONE launch up to dxg: rn_f_phi_fwd_from_partials (transposed forward weights W1T..W3T, loss folded
+ * in) followed, in the same kernel and for the same rows, by the backward dz chain for d loss = 1 -- the log-prob gradient of a
+ * mean NLL is -1/B at the label whatever happens in between.  W1..W3: the natural (out, in) weights; bwd_ws:
+ * rn_f_phi_bwd_ws_bytes(B, F1, F2, A) bytes, receives the dz rows; dxg (B, G) out.  rn_f_phi_bwd_grads then turns bwd_ws into
+ * the six parameter gradients (exactly the second launch of rn_f_phi_bwd_nll).  A loss gradient other than 1: rn_f_phi_bwd_nll. */
+int rn_f_phi_fwd_bwd_from_partials(const float* xg_part, int parts_per_row, float* xg, const float* W1T, const float* b1, const float* W2T,
+                                   const float* b2, const float* W3T, const float* b3, const float* W1, const float* W2, const float* W3,
+                                   const float* mask, const long long* label, float* f1, float* f2, float* out, float* loss, void* sync_ws,
+                                   void* bwd_ws, float* dxg, int B, int G, int F1, int F2, int A, void* stream);
+int rn_f_phi_bwd_grads(const void* bwd_ws, const float* xg, const float* f1, const float* f2, float* dW1, float* db1, float* dW2,
+                       float* db2, float* dW3, float* db3, int B, int G, int F1, int F2, int A, void* stream);
 size_t rn_f_phi_bwd_ws_bytes(int B, int F1, int F2, int A);
 int rn_f_phi_bwd(const float* gout, const float* out, const float* f2, const float* f1, const float* xg, const float* W1,
                  const float* W2, const float* W3, const float* mask, float* dW1, float* db1, float* dW2, float* db2,

@@ -308,6 +308,15 @@ __device__ __forceinline__ void fp_layer_pass(const float* __restrict__ W, const
 }
 }  // namespace
 
+// The backward dz chain of the SAME rows in the same launch (training step with the loss folded in: the log-prob gradient is
+// -1/B at the label whatever the rest of the step does, so nothing has to be waited for): W1..3 natural (out, in) weights (NULL:
+// no tail), dz3 / dz2 / dz1 (B x A / F2 / F1) and dxg (B x G) outputs -- for d loss = 1; rn_f_phi_bwd_grads finishes the job.
+struct FpBwdTail {
+  const float *W1, *W2, *W3;
+  float *dz3, *dz2, *dz1, *dxg;
+  __host__ __device__ FpBwdTail() : W1(nullptr), W2(nullptr), W3(nullptr), dz3(nullptr), dz2(nullptr), dz1(nullptr), dxg(nullptr) {}
+};
+
 // TR: W_l are given TRANSPOSED, (in, out) row-major -- the thread-per-output-feature walk is then coalesced
 template <bool TR>
 __global__ __launch_bounds__(TR ? FP_KS * 256 : 256) void f_phi_fwd_kernel(
@@ -315,7 +324,8 @@ __global__ __launch_bounds__(TR ? FP_KS * 256 : 256) void f_phi_fwd_kernel(
     const float* __restrict__ b2, const float* __restrict__ W3, const float* __restrict__ b3, const float* __restrict__ mask,
     float* __restrict__ f1, float* __restrict__ f2, float* __restrict__ out, int B, int G, int F1, int F2, int A,
     const long long* __restrict__ label = nullptr, float* __restrict__ loss = nullptr, float* loss_part = nullptr,
-    unsigned* done_count = nullptr, const float* __restrict__ xg_part = nullptr, int parts = 0, float* __restrict__ xg_out = nullptr) {
+    unsigned* done_count = nullptr, const float* __restrict__ xg_part = nullptr, int parts = 0, float* __restrict__ xg_out = nullptr,
+    FpBwdTail bt = FpBwdTail()) {
   __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW], red[FP_KQ * FP_RB * 256];
   __shared__ float lrow[FP_RB];
   const int t = threadIdx.x, r0 = blockIdx.x * FP_RB;
@@ -397,6 +407,53 @@ __global__ __launch_bounds__(TR ? FP_KS * 256 : 256) void f_phi_fwd_kernel(
         *loss = tot / (float)B;
         *done_count = 0u;
       }
+    }
+  }
+  if constexpr (TR) {
+    if (bt.W1 && label) {
+      // ---- backward dz chain of this block's rows (what f_phi_bwd_dz_kernel does from global memory in a launch of its own)
+      __syncthreads();                                   // (sa: layer 3's input has been read; sb: the logits have been read)
+      if (t < FP_RB) {
+        const int b = r0 + t;
+        const float gl = -1.f / (float)B;
+        const int lb = b < B ? fp_label(label[b], A) : -1;
+        const float* z = sb + t * FP_MAXW;
+        float mx = z[0];
+        for (int a = 1; a < A; ++a) mx = fmaxf(mx, z[a]);
+        float ssum = 0.f;
+        for (int a = 0; a < A; ++a) ssum += expf(z[a] - mx);
+        const float ls = mx + logf(ssum);
+        for (int a = 0; a < A; ++a) {
+          // exp of the STORED log-prob (z - ls rounded to fp32), exactly as the stand-alone kernel computes it
+          const float v = b < B ? ((a == lb ? gl : 0.f) - expf(z[a] - ls) * gl) : 0.f;
+          sa[t * FP_MAXW + a] = v;
+          if (b < B) bt.dz3[(long)b * A + a] = v;
+        }
+      }
+      __syncthreads();
+      fp_layer_pass<true>(bt.W3, nullptr, sa, A, F2, red, [&](int r, int j, float z) {
+        float v = 0.f;
+        if (r0 + r < B) {
+          const long o = (long)(r0 + r) * F2 + j;
+          v = (f2[o] > 0.f) ? z * (mask ? mask[o] : 1.f) : 0.f;
+          bt.dz2[o] = v;
+        }
+        sb[r * FP_MAXW + j] = v;
+      });
+      __syncthreads();
+      fp_layer_pass<true>(bt.W2, nullptr, sb, F2, F1, red, [&](int r, int j, float z) {
+        float v = 0.f;
+        if (r0 + r < B) {
+          const long o = (long)(r0 + r) * F1 + j;
+          v = (f1[o] > 0.f) ? z : 0.f;
+          bt.dz1[o] = v;
+        }
+        sa[r * FP_MAXW + j] = v;
+      });
+      __syncthreads();
+      fp_layer_pass<true>(bt.W1, nullptr, sa, F1, G, red, [&](int r, int j, float z) {
+        if (r0 + r < B) bt.dxg[(long)(r0 + r) * G + j] = z;
+      });
     }
   }
 }
@@ -551,6 +608,46 @@ extern "C" int rn_f_phi_fwd_from_partials(const float* xg_part, int parts_per_ro
   if (transposed) f_phi_fwd_kernel<true><<<cdiv(B, FP_RB), FP_KS * 256, 0, (hipStream_t)stream>>>(nullptr, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A, label, loss, part, cnt, xg_part, parts_per_row, xg);
   else f_phi_fwd_kernel<false><<<cdiv(B, FP_RB), 256, 0, (hipStream_t)stream>>>(nullptr, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A, label, loss, part, cnt, xg_part, parts_per_row, xg);
   RN_LAUNCH_CHECK("rn_f_phi_fwd_from_partials");
+  return 0;
+}
+
+// rn_f_phi_fwd_from_partials (transposed weights, loss folded in) + the backward dz chain for d loss = 1 in the SAME launch:
+// W1..3 = the natural (out, in) weights, bwd_ws = rn_f_phi_bwd_ws_bytes(...) bytes (receives the dz rows), dxg (B, G) out.
+// rn_f_phi_bwd_grads then produces the six parameter gradients from bwd_ws; a loss gradient other than 1 takes rn_f_phi_bwd_nll.
+extern "C" int rn_f_phi_fwd_bwd_from_partials(const float* xg_part, int parts_per_row, float* xg, const float* W1T, const float* b1,
+                                              const float* W2T, const float* b2, const float* W3T, const float* b3, const float* W1,
+                                              const float* W2, const float* W3, const float* mask, const long long* label, float* f1,
+                                              float* f2, float* out, float* loss, void* sync_ws, void* bwd_ws, float* dxg, int B, int G,
+                                              int F1, int F2, int A, void* stream) {
+  RN_CHECK_ARG(xg_part && parts_per_row > 0 && xg && W1T && b1 && W2T && b2 && W3T && b3 && W1 && W2 && W3 && label && f1 && f2 && out && loss &&
+                   sync_ws && bwd_ws && dxg,
+               "rn_f_phi_fwd_bwd_from_partials: NULL pointer / bad count");
+  if (int rc = fp_check("rn_f_phi_fwd_bwd_from_partials", B, G, F1, F2, A)) return rc;
+  RN_CHECK_ARG(((uintptr_t)W1T | (uintptr_t)W2T | (uintptr_t)W3T | (uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)W3) % 16 == 0,
+               "rn_f_phi_fwd_bwd_from_partials: weights must be 16-byte aligned");
+  unsigned* cnt = (unsigned*)sync_ws;
+  float* part = (float*)sync_ws + 4;
+  FpBwdTail bt;
+  bt.W1 = W1; bt.W2 = W2; bt.W3 = W3;
+  bt.dz1 = (float*)bwd_ws;
+  bt.dz2 = bt.dz1 + (size_t)B * F1;
+  bt.dz3 = bt.dz2 + (size_t)B * F2;
+  bt.dxg = dxg;
+  f_phi_fwd_kernel<true><<<cdiv(B, FP_RB), FP_KS * 256, 0, (hipStream_t)stream>>>(nullptr, W1T, b1, W2T, b2, W3T, b3, mask, f1, f2, out, B, G, F1, F2, A,
+                                                                                  label, loss, part, cnt, xg_part, parts_per_row, xg, bt);
+  RN_LAUNCH_CHECK("rn_f_phi_fwd_bwd_from_partials");
+  return 0;
+}
+
+extern "C" int rn_f_phi_bwd_grads(const void* bwd_ws, const float* xg, const float* f1, const float* f2, float* dW1, float* db1, float* dW2,
+                                  float* db2, float* dW3, float* db3, int B, int G, int F1, int F2, int A, void* stream) {
+  RN_CHECK_ARG(bwd_ws && xg && f1 && f2 && dW1 && db1 && dW2 && db2 && dW3 && db3, "rn_f_phi_bwd_grads: NULL pointer");
+  if (int rc = fp_check("rn_f_phi_bwd_grads", B, G, F1, F2, A)) return rc;
+  const float* dz1 = (const float*)bwd_ws;
+  const float* dz2 = dz1 + (size_t)B * F1;
+  const float* dz3 = dz2 + (size_t)B * F2;
+  f_phi_bwd_grads_kernel<<<F1 + F2 + A, 256, 0, (hipStream_t)stream>>>(dz1, dz2, dz3, xg, f1, f2, dW1, db1, dW2, db2, dW3, db3, B, G, F1, F2, A);
+  RN_LAUNCH_CHECK("rn_f_phi_bwd_grads");
   return 0;
 }
 

@@ -239,7 +239,6 @@ class DataParallelTrainer:
         self.use_graph = use_graph
         self._graph = None
         self._static = None
-        self._ones = {}
         self.timing = None                                 # a list: step() appends (start, after all-reduce, after optimiser) events
         self._fused_opt = FusedClipAdam(self.bucket, optimizer) if FusedClipAdam.supports(self.bucket, optimizer) else None
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -257,10 +256,7 @@ class DataParallelTrainer:
             loss = RF.nll_loss_mean(out, label)            # F.nll_loss (mean), one launch each way on the GPU
         # the loss gradient is a cached one (loss.backward() alone launches a fill kernel for it: one more node on the
         # critical path of the captured step, between the f_phi launches)
-        one = self._ones.get((loss.device, loss.dtype))
-        if one is None:
-            one = self._ones[(loss.device, loss.dtype)] = torch.ones((), dtype=loss.dtype, device=loss.device)
-        loss.backward(one)
+        loss.backward(RF.unit_loss_grad(loss.device, loss.dtype) if loss.is_cuda else torch.ones_like(loss))
         self.bucket.gather_()
         return loss
 

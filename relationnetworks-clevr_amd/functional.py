@@ -205,6 +205,26 @@ def grad_out(param, shape=None):
     return torch.empty(shape, dtype=torch.float32, device=param.device)
 
 
+# ---- the trainer's loss gradient ------------------------------------------------------------------------------------
+# loss.backward() hands the first backward function a gradient of 1.  The trainer passes THIS cached tensor (no fill launch),
+# and a function that finds it knows the value without reading device memory: the f_phi forward launch may then have run the
+# backward dz chain already (rn_f_phi_fwd_bwd_from_partials).  Any other tensor takes the general path.
+_UNIT_LOSS_GRAD = {}
+
+
+def unit_loss_grad(device, dtype=torch.float32):
+    key = (torch.device(device), dtype)
+    t = _UNIT_LOSS_GRAD.get(key)
+    if t is None:
+        t = _UNIT_LOSS_GRAD[key] = torch.ones((), dtype=dtype, device=device)
+    return t
+
+
+def is_unit_loss_grad(g):
+    t = _UNIT_LOSS_GRAD.get((g.device, g.dtype)) if g is not None else None
+    return t is not None and g.data_ptr() == t.data_ptr() and g.numel() == 1
+
+
 class RRMasks:
     """ReLU lane masks of the register-resident forward chain: what the backward pass keeps INSTEAD of the last
     activation (rn_g_chain_fwd_rr / rn_g_chain_bwd_rr)."""
@@ -496,7 +516,7 @@ def _pair_sum_of(part, B, parts, G, lazy):
     return xg
 
 
-def f_phi_forward(xg, fw, fb, mask, wT=None, label=None):
+def f_phi_forward(xg, fw, fb, mask, wT=None, label=None, pre_bwd=False):
     """f_phi + log_softmax (model.py:155-162): fc1 -> relu -> fc2 -> dropout mask -> relu -> fc3 -> log_softmax,
     fp32.  Returns (f1, f2, log_probs), with `label` (int64 (B,)) also the mean NLL as a fourth element (same launch).
     xg: the (B, G) pair sums, or PairSumPartials (their summation then rides in the same launch; .xg holds them afterwards)."""
@@ -509,6 +529,12 @@ def f_phi_forward(xg, fw, fb, mask, wT=None, label=None):
     f1 = torch.empty(B, F1, dtype=torch.float32, device=dev)
     f2 = torch.empty(B, F2, dtype=torch.float32, device=dev)
     out = torch.empty(B, A, dtype=torch.float32, device=dev)
+    if lazy is not None and pre_bwd and label is not None and wT is not None:
+        # the training step: the backward dz chain (for d loss = 1) rides in the same launch -> (.., loss, (dz workspace, dxg))
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dxg = torch.empty(B, G, dtype=torch.float32, device=dev)
+        ws = H.f_phi_fwd_bwd_from_partials(lazy.part, lazy.parts, xg, wT, fb, fw, mask, label, f1, f2, out, loss, dxg)
+        return f1, f2, out, loss, (ws, dxg)
     if lazy is not None:
         loss = torch.empty((), dtype=torch.float32, device=dev) if label is not None else None
         H.f_phi_fwd_from_partials(lazy.part, lazy.parts, xg, wT if wT is not None else fw, fb, mask, label, f1, f2, out, loss,
@@ -583,9 +609,14 @@ class RelationalFunction(torch.autograd.Function):
         if mask is not None:
             mask = mask.float().contiguous()
         loss = None
+        ctx.fphi_pre = None
         if label is not None:
             label = label.long().contiguous()
-            f1, f2, out, loss = f_phi_forward(xg, fw, fb, mask, wT=packed.fT, label=label)
+            r = f_phi_forward(xg, fw, fb, mask, wT=packed.fT, label=label,
+                              pre_bwd=need_grad and OPT.fphi_fused_bwd and isinstance(xg, PairSumPartials))
+            f1, f2, out, loss = r[:4]
+            if len(r) == 5:
+                ctx.fphi_pre = r[4]
         else:
             f1, f2, out = f_phi_forward(xg, fw, fb, mask, wT=packed.fT)
         if isinstance(xg, PairSumPartials):
@@ -631,10 +662,15 @@ class RelationalFunction(torch.autograd.Function):
         dW3 = grad_out(fp[2], (A, F2)); db3 = grad_out(fp[5], (A,))
         dW2 = grad_out(fp[1], (F2, F1)); db2 = grad_out(fp[4], (F2,))
         dW1 = grad_out(fp[0], (F1, G)); db1 = grad_out(fp[3], (F1,))
-        dxg = torch.empty(B, G, **f32)
-        if gout is None:
+        if gout is None and ctx.fphi_pre is not None and is_unit_loss_grad(gloss):
+            # the forward launch already ran the dz chain for d loss = 1: the parameter gradients are all that is left
+            ws_, dxg = ctx.fphi_pre
+            H.f_phi_bwd_grads(ws_, xg, f1, f2, (dW1, dW2, dW3), (db1, db2, db3))
+        elif gout is None:
+            dxg = torch.empty(B, G, **f32)
             H.f_phi_bwd_nll(gloss, label, out, f2, f1, xg, fw, ctx.mask, (dW1, dW2, dW3), (db1, db2, db3), dxg)
         else:
+            dxg = torch.empty(B, G, **f32)
             H.f_phi_bwd(gout, out, f2, f1, xg, fw, ctx.mask, (dW1, dW2, dW3), (db1, db2, db3), dxg)
         # ---- g_theta backward
         dt = H.torch_dtype(code)

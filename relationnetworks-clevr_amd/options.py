@@ -35,6 +35,7 @@ _SPEC = {
     "fused_lstm":        ("RN_NO_FUSED_LSTM", True, "one-launch embedding + LSTM"),
     "overlap_streams":   ("RN_OVERLAP_STREAMS", True, "question encoder beside the conv stack (second stream)"),
     "fused_nll":         ("RN_NO_FUSED_NLL", True, "own NLL kernels"),
+    "fphi_fused_bwd":    ("RN_NO_FPHI_FUSED_BWD", True, "trainer: f_phi's backward dz chain in the forward launch (the loss gradient is the cached 1)"),
     "fused_loss":        ("RN_NO_FUSED_LOSS", True, "loss inside the f_phi launch (trainer)"),
     "grads_in_bucket":   ("RN_NO_GRADS_IN_BUCKET", True, "backward kernels write parameter gradients straight into a registered FlatGradBucket (trainer)"),
     "fused_adam":        ("RN_NO_FUSED_ADAM", True, "fused clip + Adam on the flat bucket (trainer)"),

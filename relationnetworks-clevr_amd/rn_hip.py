@@ -73,6 +73,8 @@ SIGNATURES = {
     "rn_f_phi_bwd_ws_bytes": (_Z, [_I, _I, _I, _I]),
     "rn_f_phi_nll_ws_bytes": (_Z, [_I]),
     "rn_f_phi_fwd_nll": (_I, [_P] * 14 + [_I] * 6 + [_P]),
+    "rn_f_phi_fwd_bwd_from_partials": (_I, [_P, _I] + [_P] * 19 + [_I] * 5 + [_P]),
+    "rn_f_phi_bwd_grads": (_I, [_P] * 10 + [_I] * 5 + [_P]),
     "rn_f_phi_bwd_nll": (_I, [_P] * 18 + [_I] * 5 + [_P]),
     "rn_f_phi_bwd": (_I, [_P] * 17 + [_I] * 5 + [_P]),
     "rn_lstm_fwd": (_I, [_P] * 10 + [_I] * 5 + [_P]),
@@ -616,6 +618,31 @@ def f_phi_fwd_from_partials(xg_part, parts_per_row, xg, fw, fb, mask, label, f1,
                                              fb[1].data_ptr(), fw[2].data_ptr(), fb[2].data_ptr(), _ptr(mask), _ptr(label), f1.data_ptr(),
                                              f2.data_ptr(), out.data_ptr(), _ptr(loss), ws, int(transposed), B, G, F1, F2, A, _stream()),
            "rn_f_phi_fwd_from_partials")
+
+
+@_timed("f_phi")
+def f_phi_fwd_bwd_from_partials(xg_part, parts_per_row, xg, fwT, fb, fw, mask, label, f1, f2, out, loss, dxg):
+    """The training step's f_phi up to dxg in one launch (fwT: transposed forward weights, fw: the natural ones; d loss = 1).
+    -> the dz workspace f_phi_bwd_grads finishes from."""
+    B, G = xg.shape
+    F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
+    lib = load()
+    ws = torch.empty(max(lib.rn_f_phi_bwd_ws_bytes(B, F1, F2, A), 16), dtype=torch.uint8, device=xg.device)
+    _check(lib.rn_f_phi_fwd_bwd_from_partials(xg_part.data_ptr(), parts_per_row, xg.data_ptr(), fwT[0].data_ptr(), fb[0].data_ptr(),
+                                              fwT[1].data_ptr(), fb[1].data_ptr(), fwT[2].data_ptr(), fb[2].data_ptr(), fw[0].data_ptr(),
+                                              fw[1].data_ptr(), fw[2].data_ptr(), _ptr(mask), label.data_ptr(), f1.data_ptr(), f2.data_ptr(),
+                                              out.data_ptr(), loss.data_ptr(), _nll_sync_ws(B, xg.device).data_ptr(), ws.data_ptr(),
+                                              dxg.data_ptr(), B, G, F1, F2, A, _stream()), "rn_f_phi_fwd_bwd_from_partials")
+    return ws
+
+
+@_timed("f_phi")
+def f_phi_bwd_grads(ws, xg, f1, f2, dW, db):
+    B, G = xg.shape
+    F1, F2, A = dW[0].shape[0], dW[1].shape[0], dW[2].shape[0]
+    _check(load().rn_f_phi_bwd_grads(ws.data_ptr(), xg.data_ptr(), f1.data_ptr(), f2.data_ptr(), dW[0].data_ptr(), db[0].data_ptr(),
+                                     dW[1].data_ptr(), db[1].data_ptr(), dW[2].data_ptr(), db[2].data_ptr(), B, G, F1, F2, A, _stream()),
+           "rn_f_phi_bwd_grads")
 
 
 @_timed("f_phi")

@@ -1337,3 +1337,17 @@ def test_f_phi_from_partials(H, B, parts, nll, tr):
     H.f_phi_fwd_from_partials(part, parts, xg2, w, fb, mask, label, mk(B, F1), mk(B, F2), mk(B, A), mk() if nll else None, transposed=tr)
     torch.cuda.synchronize()
     assert torch.equal(xg, xg2)
+    if nll and tr:
+        # the training step's variant: forward + the backward dz chain for d loss = 1 in ONE launch, the parameter gradients from
+        # its workspace -- bitwise the forward above and rn_f_phi_bwd_nll with a loss gradient of 1
+        xg3, f1c, f2c, outc, lossc, dxg = mk(B, G), mk(B, F1), mk(B, F2), mk(B, A), mk(), mk(B, G)
+        ws = H.f_phi_fwd_bwd_from_partials(part, parts, xg3, w, fb, fw, mask, label, f1c, f2c, outc, lossc, dxg)
+        dWa = [mk(*x.shape) for x in fw]; dba = [mk(x.shape[0]) for x in fw]
+        H.f_phi_bwd_grads(ws, xg3, f1c, f2c, dWa, dba)
+        dWb = [mk(*x.shape) for x in fw]; dbb = [mk(x.shape[0]) for x in fw]; dxgb = mk(B, G)
+        H.f_phi_bwd_nll(torch.ones((), device="cuda"), label, out, f2, f1, xg, fw, mask, dWb, dbb, dxgb)
+        torch.cuda.synchronize()
+        assert torch.equal(xg3, xg) and torch.equal(f1c, f1) and torch.equal(f2c, f2) and torch.equal(outc, out) and torch.equal(lossc, loss)
+        assert torch.equal(dxg, dxgb)
+        for a, b in zip(dWa + dba, dWb + dbb):
+            assert torch.equal(a, b)
