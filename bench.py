@@ -383,9 +383,9 @@ def main():
                 trainer.step(img, qst, lab)
             H.TIMER.enabled = False
             if tag == "in_step":
-                ksum_step = H.TIMER.summary()
+                ksum_step = H.TIMER.summary(steps=args.steps)
             else:
-                ksum = H.TIMER.summary()
+                ksum = H.TIMER.summary(steps=args.steps)
                 pkg.options.OPT.wgrad_overlap = overlap_default
         trainer.use_graph = use_graph
     dt = max_over_ranks(dt, world, dev)

@@ -198,11 +198,22 @@ class KernelTimer:
         ts = sorted(a.elapsed_time(b) for a, b in pairs)
         return ts[len(ts) // 2]
 
-    def summary(self):
-        """{name: (brackets, total ms)} with the empty-bracket overhead removed from every bracket."""
+    def summary(self, steps=None):
+        """{name: (brackets, total ms)} with the empty-bracket overhead removed from every bracket.  steps: the brackets cover
+        that many identical steps -- the total is then steps x the MEDIAN per-step sum (one slow step, e.g. a clock dip
+        right after the timed region, does not move it)."""
         torch.cuda.synchronize()
         ov = self.bracket_overhead_ms()
-        return {k: (len(v), sum(max(a.elapsed_time(b) - ov, 0.0) for a, b in v)) for k, v in self.pairs.items()}
+        out = {}
+        for k, v in self.pairs.items():
+            d = [max(a.elapsed_time(b) - ov, 0.0) for a, b in v]
+            if steps and len(d) % steps == 0 and len(d) >= steps:
+                per = len(d) // steps
+                tot = sorted(sum(d[i * per:(i + 1) * per]) for i in range(steps))
+                out[k] = (len(d), steps * tot[len(tot) // 2])
+            else:
+                out[k] = (len(d), sum(d))
+        return out
 
 
 TIMER = KernelTimer()
