@@ -43,6 +43,22 @@ __device__ __forceinline__ void cn_block_reduce(double (&v)[NV], double* red) { 
   for (int i = 0; i < NV; ++i) v[i] = red[i] + red[NV + i] + red[2 * NV + i] + red[3 * NV + i];
   __syncthreads();
 }
+// The S (<= 32) slice partials of a channel, added in slice order: lane l loads partial l (one round trip for all of them -- the
+// plain loop is S dependent scalar loads, ~10 us in front of every workgroup of the apply kernels, which is most of what those
+// kernels took), then the values are read back lane by lane: the same sums, in the same order, as the loop gave.
+__device__ __forceinline__ void cn_slice_sums(const double* __restrict__ part, int c, int S, double& s0, double& s1) {
+  const int l = threadIdx.x & 63;
+  const double a = l < S ? part[((long)c * S + l) * 2] : 0.0, b = l < S ? part[((long)c * S + l) * 2 + 1] : 0.0;
+  const u32x2 ab = __builtin_bit_cast(u32x2, a), bb = __builtin_bit_cast(u32x2, b);
+  s0 = 0.0;
+  s1 = 0.0;
+  for (int i = 0; i < S; ++i) {                          // (i is wave-uniform: v_readlane)
+    const u32x2 x = {(unsigned)__builtin_amdgcn_readlane((int)ab[0], i), (unsigned)__builtin_amdgcn_readlane((int)ab[1], i)};
+    const u32x2 y = {(unsigned)__builtin_amdgcn_readlane((int)bb[0], i), (unsigned)__builtin_amdgcn_readlane((int)bb[1], i)};
+    s0 += __builtin_bit_cast(double, x);
+    s1 += __builtin_bit_cast(double, y);
+  }
+}
 }  // namespace
 
 // part[(c * S + s) * 2 + {0, 1}] = sum, sum of squares over slice s of channel c
@@ -80,11 +96,8 @@ __global__ __launch_bounds__(CN_T) void cn_apply_kernel(const f32x4* __restrict_
   const int c = blockIdx.y;
   float m, is;
   if constexpr (FROM_PART) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int s = 0; s < S; ++s) {
-      s0 += part[((long)c * S + s) * 2];
-      s1 += part[((long)c * S + s) * 2 + 1];
-    }
+    double s0, s1;
+    cn_slice_sums(part, c, S, s0, s1);
     const double md = s0 / count;
     double var = s1 / count - md * md;
     if (var < 0.0) var = 0.0;
@@ -152,11 +165,8 @@ __global__ __launch_bounds__(CN_T) void cn_bwd_apply_kernel(const f32x4* __restr
                                                             const float* __restrict__ beta, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ zero_out, int C, int hw4, long n4) {
   const int c = blockIdx.y;
-  double s1 = 0.0, s2 = 0.0;
-  for (int s = 0; s < S; ++s) {
-    s1 += part[((long)c * S + s) * 2];
-    s2 += part[((long)c * S + s) * 2 + 1];
-  }
+  double s1, s2;
+  cn_slice_sums(part, c, S, s1, s2);
   const float m = mean[c], is = invstd[c], ga = gamma[c];
   const float dga = (float)((double)is * (s2 - (double)m * s1));
   if (blockIdx.x == 0 && threadIdx.x == 0) {

@@ -396,14 +396,26 @@ __global__ __launch_bounds__(TR ? FP_KS * 256 : 256) void f_phi_fwd_kernel(
   // mean NLL of the batch (train.py:41) in the same launch: block partials in a fixed order, combined by whichever
   // block finishes last (also in a fixed order: deterministic); the counter re-arms itself for the next launch
   if (label) {
+    __shared__ int last_s;
     __syncthreads();
     if (t == 0) {
       loss_part[blockIdx.x] = ((lrow[0] + lrow[1]) + lrow[2]) + lrow[3];
       __threadfence();
-      if (atomicAdd(done_count, 1u) == gridDim.x - 1) {
-        __threadfence();
-        float tot = 0.f;
-        for (unsigned i = 0; i < gridDim.x; ++i) tot += reinterpret_cast<volatile float*>(loss_part)[i];
+      last_s = atomicAdd(done_count, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last_s && t < 64) {
+      // the last block adds the block partials in block order; up to 64 of them are fetched by one wave at once (one round trip
+      // instead of a chain of them on the tail of the launch) and read back lane by lane: the same sum as the plain loop
+      __threadfence();
+      float tot = 0.f;
+      for (unsigned i0 = 0; i0 < gridDim.x; i0 += 64) {
+        const unsigned i = i0 + t;
+        const float v = i < gridDim.x ? reinterpret_cast<volatile float*>(loss_part)[i] : 0.f;
+        const unsigned cnt = gridDim.x - i0 < 64u ? gridDim.x - i0 : 64u;
+        for (unsigned j = 0; j < cnt; ++j) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)j));
+      }
+      if (t == 0) {
         *loss = tot / (float)B;
         *done_count = 0u;
       }
