@@ -354,6 +354,76 @@ __global__ __launch_bounds__(256) void conv3x3s2_fwd_mfma_kernel(const float* __
   }
 }
 
+// ... the same kernel for 64-column inputs (the headline's second layer) with the input rows moved HBM -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: a wave instruction moves four 256-byte rows, no registers, so all 54 requests of a unit are in flight
+// at once -- the register-staged version needs four round trips because a lane's 108 weights live in registers too).  Rows are
+// packed at 64 floats: the tap left of column 0 (lane p = 0, kx = 0) is masked to zero instead of being stored, and the rows above
+// the image (first row block) are zeroed by the wave that requested them.
+__global__ __launch_bounds__(256) void conv3x3s2_fwd_mfma_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                                     int N, int H, int units) {
+  constexpr int CIN = 24, NK = 9 * 12, HALF = 12, W = 64, OW = 32, NROW = CIN * 9, NINST = NROW / 4, PAD = 4;
+  typedef __attribute__((address_space(3))) unsigned char lds_u8_;
+  extern __shared__ __attribute__((aligned(16))) float cd_smem[];     // [PAD floats][216 rows][64]
+  const int OH = H >> 1;
+  const int t = threadIdx.x, l = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), p = l & 31, h = l >> 5;
+  float wr[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    const int cp = kk / 9, tap = kk - 9 * cp, ci = cp + HALF * h;
+    const float u = w[((long)(p < 24 ? p : 0) * CIN + ci) * 9 + tap];
+    wr[kk] = p < 24 ? u : 0.f;
+  }
+  const int lane_base = PAD + (HALF * h * 9 + 2 * wv) * W + 2 * p - 1;
+  const unsigned lds0 = (unsigned)(size_t)(lds_u8_*)cd_smem + PAD * 4;
+  const int rpi = OH / 4;
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int rb = u % rpi, n = u / rpi;
+    const int oy0 = 4 * rb, iy0 = 2 * oy0 - 1;
+    __syncthreads();                                                  // the previous unit's reads are done
+    const float* xn = x + (long)n * CIN * H * W;
+    asm volatile("" : "+s"(xn));
+#pragma unroll
+    for (int q = 0; q < (NINST + 3) / 4; ++q) {
+      const int inst = wv + 4 * q;
+      if (inst < NINST) {
+        const int R = 4 * inst + (l >> 4), ci = R / 9, iy = iy0 + (R - ci * 9);
+        const unsigned voff = (unsigned)((((ci * H + (iy < 0 ? 0 : iy)) * W) << 2) + ((l & 15) << 4));
+        const unsigned dst = lds0 + inst * 1024;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(xn), "s"(dst)
+                     : "memory");
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (rb == 0) {                                                    // rows above the image: zero (requested from row 0 above)
+#pragma unroll
+      for (int q = 0; q < (NINST + 3) / 4; ++q) {
+        const int inst = wv + 4 * q, R = 4 * inst + (l >> 4);
+        if (inst < NINST && R % 9 == 0) *reinterpret_cast<f32x4*>(cd_smem + PAD + R * W + (l & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    __syncthreads();
+    typedef __attribute__((ext_vector_type(16))) float f32x16_;
+    f32x16_ acc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+    const float* xb = cd_smem + lane_base;
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      const int cp = kk / 9, tap = kk - 9 * cp, ky = tap / 3, kx = tap - 3 * ky;
+      float v = xb[(cp * 9 + ky) * W + kx];
+      if (kx == 0) v = p == 0 ? 0.f : v;                              // the column left of the image
+      acc[kk & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[kk], v, acc[kk & 1], 0, 0, 0);
+    }
+    const int oy = oy0 + wv;
+    float* yo = y + (((long)n * 24) * OH + oy) * OW + p;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) yo[(long)(8 * (i >> 2) + 4 * h + (i & 3)) * OH * OW] = acc[0][i] + acc[1][i];
+  }
+}
+
 static int cv_check(const char* who, const void* a, const void* b, const void* c, int N, int Cin, int Cout, int H, int W) {
   RN_CHECK_ARG(a && b && c && N > 0 && H > 0 && W > 0, "%s: bad pointer/size", who);
   RN_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && Cout == 24 && (Cin == 3 || Cin == 24),
@@ -373,10 +443,18 @@ extern "C" int rn_conv3x3s2_fwd(const float* x, const float* w, float* y, int N,
   if (mfma) {
     // the large layers: fp32 matrix pipe (units of 4 output rows x 32 pixels; all channels of the 9 input rows in LDS)
     const int segs = (W / 2 + 31) / 32, units = N * ((H / 2 + 3) / 4) * segs;
-    const size_t shm = (size_t)24 * 9 * 66 * sizeof(float);
     const int grid = units < 1024 ? units : 1024;
-    (void)hipFuncSetAttribute((const void*)conv3x3s2_fwd_mfma_kernel<24, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    conv3x3s2_fwd_mfma_kernel<24, 24><<<grid, 256, shm, (hipStream_t)stream>>>(x, w, y, N, H, W, units, segs);
+    bool dma = W == 64 && (H / 2) % 4 == 0 && (uintptr_t)x % 16 == 0;
+    if (const char* e = rn_diag_env("RN_CONV_DMA")) dma = dma && atoi(e) != 0;
+    if (dma) {
+      const size_t shm = ((size_t)24 * 9 * 64 + 4) * sizeof(float);
+      (void)hipFuncSetAttribute((const void*)conv3x3s2_fwd_mfma_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      conv3x3s2_fwd_mfma_dma_kernel<<<grid, 256, shm, (hipStream_t)stream>>>(x, w, y, N, H, units);
+    } else {
+      const size_t shm = (size_t)24 * 9 * 66 * sizeof(float);
+      (void)hipFuncSetAttribute((const void*)conv3x3s2_fwd_mfma_kernel<24, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      conv3x3s2_fwd_mfma_kernel<24, 24><<<grid, 256, shm, (hipStream_t)stream>>>(x, w, y, N, H, W, units, segs);
+    }
     RN_LAUNCH_CHECK("rn_conv3x3s2_fwd(mfma)");
     return 0;
   }
