@@ -414,6 +414,15 @@ int rn_bn_relu_apply(const float* x, float* y, const float* gamma, const float* 
 int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const float* gamma, const float* beta, const float* mean,
                    const float* invstd, float* dgamma, float* dbeta, float* zero_out, void* ws, int N, int C, int HW, void* stream);
 
+/* rn_bn_relu_bwd of a block whose input needs no gradient (the first block: the image) together with the weight gradient of its
+ * convolution (autograd of model.py:22-35 for that block): pass 1 as above; the weight-gradient kernel then forms the conv output
+ * gradient from dy and the conv output xc (N, 24, H/2, W/2) while staging, so it is never written.  inp: the block's input
+ * (N, Cin, H, W); dw (24, Cin, 3, 3); ws_bn / ws_conv: rn_bn_relu_ws_bytes(N, 24, H/2 * W/2) / rn_conv3x3s2_bwd_weight_ws_bytes bytes.
+ * Results equal rn_bn_relu_bwd + rn_conv3x3s2_bwd_weight. */
+int rn_bn_relu_bwd_conv_wgrad(const float* dy, const float* xc, const float* inp, const float* gamma, const float* beta,
+                              const float* mean, const float* invstd, float* dgamma, float* dbeta, float* zero_out, float* dw,
+                              void* ws_bn, void* ws_conv, int N, int Cin, int H, int W, void* stream);
+
 /* The first g layer factored through the pair structure (question injected at layer 0; model.py:130-139 builds the pair
  * matrix [x_j | x_i | q] and multiplies it by W0): W0 [x_j | x_i | q] + b0 = W0a x_j + (W0b x_i + W0c q + b0).
  *   rn_pair_tables: Xp (B*n, 64) bf16 = x[b, j, 0:k] zero padded;  Vc (B*n, N) fp32 = b0 + W0b x[b, i] + W0c q[b]

@@ -61,6 +61,10 @@ static inline const char* rn_diag_env(const char* name) { return getenv(name); }
 static inline const char* rn_diag_env(const char*) { return nullptr; }
 #endif
 
+// rn_convnorm.hip: pass 1 of the batch-norm backward (slice sums into ws), launched by rn_conv.hip's fused entry
+int rn_cn_launch_bwd_sums(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                          void* ws, int N, int C, int HW, void* stream, int* S);
+
 // ---- element traits ----------------------------------------------------------
 template <typename T> struct Elem;
 template <> struct Elem<bf16> {

@@ -354,17 +354,19 @@ __global__ __launch_bounds__(256) void conv3x3s2_fwd_mfma_kernel(const float* __
   }
 }
 
-// ... the same kernel for 64-column inputs (the headline's second layer) with the input rows moved HBM -> LDS by LDS-DMA
-// (global_load_lds_dwordx4: a wave instruction moves four 256-byte rows, no registers, so all 54 requests of a unit are in flight
-// at once -- the register-staged version needs four round trips because a lane's 108 weights live in registers too).  Rows are
-// packed at 64 floats: the tap left of column 0 (lane p = 0, kx = 0) is masked to zero instead of being stored, and the rows above
-// the image (first row block) are zeroed by the wave that requested them.
+// ... the same product for 64 / 32 / 16-column inputs (layers 2..4 at the headline shape) with the input rows moved HBM -> LDS by
+// LDS-DMA (global_load_lds_dwordx4: a wave instruction moves 1 KB = 4 / 8 / 16 rows, no registers, so all requests of a unit are
+// in flight at once -- the register-staged version needs four round trips because a lane's 108 weights live in registers too).
+// A wave's 32 pixels are RW = 32 / OW consecutive output rows (contiguous in y); a unit is 4 RW output rows of an image (the
+// whole image when it has fewer).  Rows are packed at W floats: the taps left of column 0 and above row 0 are masked to zero
+// instead of being stored.
+template <int W>
 __global__ __launch_bounds__(256) void conv3x3s2_fwd_mfma_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
-                                                                     int N, int H, int units) {
-  constexpr int CIN = 24, NK = 9 * 12, HALF = 12, W = 64, OW = 32, NROW = CIN * 9, NINST = NROW / 4, PAD = 4;
+                                                                     int N, int H, int units, int RU) {
+  constexpr int CIN = 24, NK = 9 * 12, HALF = 12, OW = W / 2, RW = 32 / OW, LPR = W / 4, RPI = 64 / LPR, PAD = 4;
   typedef __attribute__((address_space(3))) unsigned char lds_u8_;
-  extern __shared__ __attribute__((aligned(16))) float cd_smem[];     // [PAD floats][216 rows][64]
-  const int OH = H >> 1;
+  extern __shared__ __attribute__((aligned(16))) float cd_smem[];     // [PAD floats][24][RT rows][W]
+  const int OH = H >> 1, RT = 2 * RU + 1, NROW = CIN * RT, NINST = (NROW + RPI - 1) / RPI;   // RU: output rows per unit (<= 4 RW)
   const int t = threadIdx.x, l = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), p = l & 31, h = l >> 5;
   float wr[NK];
 #pragma unroll
@@ -373,54 +375,50 @@ __global__ __launch_bounds__(256) void conv3x3s2_fwd_mfma_dma_kernel(const float
     const float u = w[((long)(p < 24 ? p : 0) * CIN + ci) * 9 + tap];
     wr[kk] = p < 24 ? u : 0.f;
   }
-  const int lane_base = PAD + (HALF * h * 9 + 2 * wv) * W + 2 * p - 1;
+  const int prow = p / OW, pcol = p - prow * OW;                      // this lane's pixel inside the wave's tile
   const unsigned lds0 = (unsigned)(size_t)(lds_u8_*)cd_smem + PAD * 4;
-  const int rpi = OH / 4;
+  const int rpi = OH / RU;
+  const bool active = wv * RW < RU;
   for (int u = blockIdx.x; u < units; u += gridDim.x) {
     const int rb = u % rpi, n = u / rpi;
-    const int oy0 = 4 * rb, iy0 = 2 * oy0 - 1;
+    const int oy0 = RU * rb, iy0 = 2 * oy0 - 1;
     __syncthreads();                                                  // the previous unit's reads are done
     const float* xn = x + (long)n * CIN * H * W;
     asm volatile("" : "+s"(xn));
-#pragma unroll
-    for (int q = 0; q < (NINST + 3) / 4; ++q) {
-      const int inst = wv + 4 * q;
-      if (inst < NINST) {
-        const int R = 4 * inst + (l >> 4), ci = R / 9, iy = iy0 + (R - ci * 9);
-        const unsigned voff = (unsigned)((((ci * H + (iy < 0 ? 0 : iy)) * W) << 2) + ((l & 15) << 4));
-        const unsigned dst = lds0 + inst * 1024;
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(voff), "s"(xn), "s"(dst)
-                     : "memory");
-      }
+    for (int inst = wv; inst < NINST; inst += 4) {
+      int R = RPI * inst + l / LPR;
+      R = R < NROW ? R : NROW - 1;                                    // (the last instruction's tail re-requests the last row)
+      const int ci = R / RT, iy = iy0 + (R - ci * RT);
+      const unsigned voff = (unsigned)((((ci * H + (iy < 0 ? 0 : (iy < H ? iy : H - 1))) * W) << 2) + ((l % LPR) << 4));
+      const unsigned dst = lds0 + inst * 1024;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(voff), "s"(xn), "s"(dst)
+                   : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (rb == 0) {                                                    // rows above the image: zero (requested from row 0 above)
-#pragma unroll
-      for (int q = 0; q < (NINST + 3) / 4; ++q) {
-        const int inst = wv + 4 * q, R = 4 * inst + (l >> 4);
-        if (inst < NINST && R % 9 == 0) *reinterpret_cast<f32x4*>(cd_smem + PAD + R * W + (l & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
     __syncthreads();
-    typedef __attribute__((ext_vector_type(16))) float f32x16_;
-    f32x16_ acc[2];
+    if (active) {
+      typedef __attribute__((ext_vector_type(16))) float f32x16_;
+      f32x16_ acc[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
-    const float* xb = cd_smem + lane_base;
+      for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+      const int orow = wv * RW + prow;                                // output row inside the unit
+      const float* xb = cd_smem + PAD + (HALF * h * RT + 2 * orow) * W + 2 * pcol - 1;
+      const bool left = pcol == 0, top = oy0 + orow == 0;
 #pragma unroll
-    for (int kk = 0; kk < NK; ++kk) {
-      const int cp = kk / 9, tap = kk - 9 * cp, ky = tap / 3, kx = tap - 3 * ky;
-      float v = xb[(cp * 9 + ky) * W + kx];
-      if (kx == 0) v = p == 0 ? 0.f : v;                              // the column left of the image
-      acc[kk & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[kk], v, acc[kk & 1], 0, 0, 0);
+      for (int kk = 0; kk < NK; ++kk) {
+        const int cp = kk / 9, tap = kk - 9 * cp, ky = tap / 3, kx = tap - 3 * ky;
+        float v = xb[(cp * RT + ky) * W + kx];
+        if (kx == 0) v = left ? 0.f : v;                              // the column left of the image
+        if (ky == 0) v = top ? 0.f : v;                               // the row above it
+        acc[kk & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[kk], v, acc[kk & 1], 0, 0, 0);
+      }
+      float* yo = y + (((long)n * 24) * OH + oy0 + wv * RW) * OW + p;   // (the wave's RW rows are contiguous)
+#pragma unroll
+      for (int i = 0; i < 12; ++i) yo[(long)(8 * (i >> 2) + 4 * h + (i & 3)) * OH * OW] = acc[0][i] + acc[1][i];
     }
-    const int oy = oy0 + wv;
-    float* yo = y + (((long)n * 24) * OH + oy) * OW + p;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) yo[(long)(8 * (i >> 2) + 4 * h + (i & 3)) * OH * OW] = acc[0][i] + acc[1][i];
   }
 }
 
@@ -527,6 +525,25 @@ extern "C" int rn_conv3x3s2_fwd(const float* x, const float* w, float* y, int N,
   const long px = (long)N * (H / 2) * (W / 2);
   const int gx = (int)((px + CV_T - 1) / CV_T);
   // big layers: 24 channels per thread (fewest input reads); small ones: 8 per thread, 3x the waves
+  // the small 24 -> 24 layers (32- and 16-column inputs): the LDS-DMA matrix-pipe kernel with 2 / 4 output rows per wave
+  {
+    bool small = Cin == 24 && (W == 32 || W == 16) && H == W && N >= 16 && (uintptr_t)x % 16 == 0;
+    if (const char* e = rn_diag_env("RN_CONV_DMA_SMALL")) small = small && atoi(e) != 0;
+    if (small) {
+      const int OHs = H / 2, RU = W == 32 ? 8 : 8;                     // output rows per unit (W = 16: the whole 8-row image, two waves)
+      const int units_s = N * (OHs / RU);
+      const int rows_per_inst = 256 / W, nrow = 24 * (2 * RU + 1);     // (whole 1 KB instructions: the last one's tail needs room)
+      const size_t shm = ((size_t)((nrow + rows_per_inst - 1) / rows_per_inst) * rows_per_inst * W + 4) * sizeof(float);
+      if (W == 32) {
+        (void)hipFuncSetAttribute((const void*)conv3x3s2_fwd_mfma_dma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        conv3x3s2_fwd_mfma_dma_kernel<32><<<units_s, 256, shm, (hipStream_t)stream>>>(x, w, y, N, H, units_s, RU);
+      } else {
+        conv3x3s2_fwd_mfma_dma_kernel<16><<<units_s, 256, shm, (hipStream_t)stream>>>(x, w, y, N, H, units_s, RU);
+      }
+      RN_LAUNCH_CHECK("rn_conv3x3s2_fwd(mfma, small)");
+      return 0;
+    }
+  }
   // (the 3-channel layer stays on the scalar kernel: K = 27 is too short for the staging to pay -- 15.6 us against 13.1)
   bool mfma = Cin == 24 && px >= 32768 && W >= 64 && (long)N * Cin * H * W < (1L << 31);
   if (const char* e = rn_diag_env("RN_CONV_MFMA")) mfma = mfma && atoi(e) != 0;      // (diagnostics builds: A/B against the scalar kernels)
@@ -538,8 +555,8 @@ extern "C" int rn_conv3x3s2_fwd(const float* x, const float* w, float* y, int N,
     if (const char* e = rn_diag_env("RN_CONV_DMA")) dma = dma && atoi(e) != 0;
     if (dma) {
       const size_t shm = ((size_t)24 * 9 * 64 + 4) * sizeof(float);
-      (void)hipFuncSetAttribute((const void*)conv3x3s2_fwd_mfma_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-      conv3x3s2_fwd_mfma_dma_kernel<<<grid, 256, shm, (hipStream_t)stream>>>(x, w, y, N, H, units);
+      (void)hipFuncSetAttribute((const void*)conv3x3s2_fwd_mfma_dma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      conv3x3s2_fwd_mfma_dma_kernel<64><<<grid, 256, shm, (hipStream_t)stream>>>(x, w, y, N, H, units, 4);
     } else {
       const size_t shm = (size_t)24 * 9 * 66 * sizeof(float);
       (void)hipFuncSetAttribute((const void*)conv3x3s2_fwd_mfma_kernel<24, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -590,12 +607,24 @@ extern "C" int rn_conv3x3s2_bwd_data(const float* dy, const float* w, float* dx,
 //   CIN = 3 : 4 waves, wave = one output row of the single tile; the four partial sums meet in LDS at the end.
 // Blocks are persistent over units; one partial per block goes to the workspace and conv_wgrad_reduce_kernel sums the
 // partials in a fixed order.
+// BN (with BN = true): dy is the gradient of relu(batch_norm(conv)) and the kernel forms the convolution's output gradient from it
+// and the conv output while staging, dconv = gamma invstd (dz - S1/n - (xc - mean) invstd dgamma / n) with dz = dy where the block's
+// output was > 0 -- cn_bwd_apply_kernel's expressions (rn_convnorm.hip), so the first block's dconv (25 MB written and read back
+// at the very end of the backward pass) never goes to memory.  S1, S2 come from that file's pass 1, summed here in its slice order.
 namespace {
 typedef __attribute__((ext_vector_type(16))) float cv_f32x16;
+struct CwBn {
+  const float* xc;                                      // the convolution's output (N, 24, Ho, Wo)
+  const double* part;                                   // [24][S][2] slice sums of pass 1
+  int S;
+  double count;
+  const float *mean, *invstd, *gamma, *beta;
+  float *dgamma, *dbeta, *zero_out;
+};
 }
-template <int CIN>
+template <int CIN, bool BN>
 __global__ __launch_bounds__(CIN == 3 ? 256 : 448) void conv3x3s2_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                               float* __restrict__ part, int H, int W, int units, int cpi) {
+                                                                               float* __restrict__ part, int H, int W, int units, int cpi, CwBn bn) {
   constexpr int NC = CIN * 9, NW = CIN == 3 ? 4 : 7;
   constexpr bool NSPLIT = CIN != 3;                     // waves split the (ci, ky, kx) tiles, not the rows
   extern __shared__ __attribute__((aligned(16))) float cw_smem[];
@@ -607,6 +636,32 @@ __global__ __launch_bounds__(CIN == 3 ? 256 : 448) void conv3x3s2_wgrad_kernel(c
   const int boff = col < NC ? (col / 9) * 9 * CS + ((col % 9) / 3) * CS + col % 3 + 2 * half : 0;
   const int aoff = ncol * DS + half;
   for (int i = t; i < CIN * 9 * CS + 32 * DS; i += NW * 64) cw_smem[i] = 0.f;      // pads (and channels 24..31 of dy) stay zero
+  __shared__ float coef[24][5];                         // sc, sh, mean, S1/n, invstd dgamma / n
+  if constexpr (BN) {
+    __shared__ double sums[24][32][2];
+    for (int i = t; i < 24 * bn.S * 2; i += NW * 64) sums[i / (2 * bn.S)][(i / 2) % bn.S][i & 1] = bn.part[i];   // one round trip
+    __syncthreads();
+    if (t < 24) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int i = 0; i < bn.S; ++i) {
+        s1 += sums[t][i][0];
+        s2 += sums[t][i][1];
+      }
+      const float m = bn.mean[t], is = bn.invstd[t], ga = bn.gamma[t];
+      const float dga = (float)((double)is * (s2 - (double)m * s1));
+      const float sc = ga * is;
+      coef[t][0] = sc;
+      coef[t][1] = bn.beta[t] - m * sc;
+      coef[t][2] = m;
+      coef[t][3] = (float)(s1 / bn.count);
+      coef[t][4] = (float)((double)dga * is / bn.count);
+      if (blockIdx.x == 0) {
+        bn.dgamma[t] = dga;
+        bn.dbeta[t] = (float)s1;
+        if (bn.zero_out) bn.zero_out[t] = 0.f;
+      }
+    }
+  }
   cv_f32x16 acc[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
@@ -629,16 +684,28 @@ __global__ __launch_bounds__(CIN == 3 ? 256 : 448) void conv3x3s2_wgrad_kernel(c
       }
     for (int row0 = w; row0 < 24 * 4; row0 += 8 * NW)
       for (int c = l; c < Wo; c += 64) {
-        float v[8];
+        float v[8], xv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int row = row0 + q * NW, co = row >> 2, rr = row & 3;
-          v[q] = (row < 24 * 4 && oy0 + rr < Ho) ? dy[(((long)n * 24 + co) * Ho + oy0 + rr) * Wo + c] : 0.f;
+          const bool ok = row < 24 * 4 && oy0 + rr < Ho;
+          const long a = (((long)n * 24 + co) * Ho + oy0 + rr) * Wo + c;
+          v[q] = ok ? dy[a] : 0.f;
+          if constexpr (BN) xv[q] = ok ? bn.xc[a] : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int row = row0 + q * NW;
-          if (row < 24 * 4) dys[(row >> 2) * DS + (row & 3) * Wo + c] = v[q];
+          if (row < 24 * 4) {
+            float o = v[q];
+            if constexpr (BN) {
+              const float* cf = coef[row >> 2];
+              const float dz = (xv[q] * cf[0] + cf[1] > 0.f) ? v[q] : 0.f;
+              o = cf[0] * (dz - cf[3] - (xv[q] - cf[2]) * cf[4]);
+              o = oy0 + (row & 3) < Ho ? o : 0.f;
+            }
+            dys[(row >> 2) * DS + (row & 3) * Wo + c] = o;
+          }
         }
       }
     __syncthreads();
@@ -680,6 +747,135 @@ __global__ __launch_bounds__(CIN == 3 ? 256 : 448) void conv3x3s2_wgrad_kernel(c
   }
 }
 
+// The first layer at the headline shape (3 x 128 x 128 images) with every row of a unit moved HBM -> LDS by LDS-DMA: the
+// register-staged kernel above spends its time in 4-5 dependent load round trips per unit (19 us for 38 MB); here all ~40-60
+// 1 KB requests of a unit are in flight at once.  x rows are packed at 128 floats, two per request, each request 2 floats
+// further on (bank spread for the tap gather); the tap left of column 0 and the row above row 0 are masked.  A channel's 4 dy
+// rows are contiguous in memory = one request, at 257-float pitch.  BN: the conv output comes in the same way and one pass
+// over LDS turns dy into dconv in place.
+template <bool BN>
+__global__ __launch_bounds__(256) void conv3x3s2_wgrad1_dma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   float* __restrict__ part, int H, int units, int cpi, CwBn bn) {
+  constexpr int CIN = 3, NC = 27, W = 128, Wo = 64, PAD = 4, XP = 258, NXI = 14, DS = 257;
+  constexpr int XS = PAD + NXI * XP, DYS = 32 * DS;     // floats: [x rows][dy: 32 channels][conv output: 24 channels]
+  typedef __attribute__((address_space(3))) unsigned char lds_u8_;
+  extern __shared__ __attribute__((aligned(16))) float cw_smem[];
+  float* xs = cw_smem;
+  float* dys = cw_smem + XS;
+  float* xcs = dys + DYS;
+  __shared__ float coef[24][5];                         // sc, sh, mean, S1/n, invstd dgamma / n
+  const int Ho = H / 2;
+  const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), ncol = l & 31, half = l >> 5;
+  const int colc = ncol < NC ? ncol : 0, ci = colc / 9, ky = (colc % 9) / 3, kx = colc % 3;
+  const int xr = ci * 9 + 2 * w + ky;                   // this lane's tap row for the wave's output row
+  const int boff = PAD + (xr >> 1) * XP + (xr & 1) * W + kx - 1 + 2 * half;
+  const int aoff = ncol * DS + half + w * Wo;
+  const bool dead = ncol >= NC, edge = half == 0 && kx == 0;
+  for (int i = t; i < 8 * DS; i += 256) dys[24 * DS + i] = 0.f;       // channels 24..31 of the A operand
+  if constexpr (BN) {
+    double* sums = (double*)xcs;                        // [24][S][2], before the first unit uses the region
+    for (int i = t; i < 24 * bn.S * 2; i += 256) sums[i] = bn.part[i];
+    __syncthreads();
+    if (t < 24) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int i = 0; i < bn.S; ++i) {
+        s1 += sums[(t * bn.S + i) * 2];
+        s2 += sums[(t * bn.S + i) * 2 + 1];
+      }
+      const float m = bn.mean[t], is = bn.invstd[t], ga = bn.gamma[t];
+      const float dga = (float)((double)is * (s2 - (double)m * s1));
+      const float sc = ga * is;
+      coef[t][0] = sc;
+      coef[t][1] = bn.beta[t] - m * sc;
+      coef[t][2] = m;
+      coef[t][3] = (float)(s1 / bn.count);
+      coef[t][4] = (float)((double)dga * is / bn.count);
+      if (blockIdx.x == 0) {
+        bn.dgamma[t] = dga;
+        bn.dbeta[t] = (float)s1;
+        if (bn.zero_out) bn.zero_out[t] = 0.f;
+      }
+    }
+  }
+  const unsigned lds_x = (unsigned)(size_t)(lds_u8_*)xs + PAD * 4, lds_dy = (unsigned)(size_t)(lds_u8_*)dys, lds_xc = (unsigned)(size_t)(lds_u8_*)xcs;
+  cv_f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int n = __builtin_amdgcn_readfirstlane(u / cpi), oy0 = __builtin_amdgcn_readfirstlane(4 * (u - n * cpi));
+    __syncthreads();                                    // the previous unit's reads (or the prologue) are done
+    {
+      const float* xn = x + (long)n * CIN * H * W;
+      asm volatile("" : "+s"(xn));
+      for (int inst = w; inst < NXI; inst += 4) {
+        int r = 2 * inst + (l >> 5);
+        r = r < 27 ? r : 26;
+        const int c = r / 9, iy = 2 * oy0 - 1 + (r - 9 * c);
+        const unsigned voff = (unsigned)((((c * H + (iy < 0 ? 0 : iy)) * W) << 2) + ((l & 31) << 4));
+        const unsigned dst = lds_x + inst * (XP * 4);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(xn), "s"(dst) : "memory");
+      }
+      const long doff = ((long)n * 24 * Ho + oy0) * Wo;
+      const float* dn = dy + doff;
+      asm volatile("" : "+s"(dn));
+      const unsigned lane_off = (unsigned)(l << 4);
+      for (int co = w; co < 24; co += 4) {
+        const unsigned voff = (unsigned)((co * Ho * Wo) << 2) + lane_off;
+        const unsigned dst = lds_dy + co * (DS * 4);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dn), "s"(dst) : "memory");
+      }
+      if constexpr (BN) {
+        const float* cn = bn.xc + doff;
+        asm volatile("" : "+s"(cn));
+        for (int co = w; co < 24; co += 4) {
+          const unsigned voff = (unsigned)((co * Ho * Wo) << 2) + lane_off;
+          const unsigned dst = lds_xc + co * (DS * 4);
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(voff), "s"(cn), "s"(dst) : "memory");
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (BN) {
+#pragma unroll 8
+      for (int co = 0; co < 24; ++co) {
+        const float g = dys[co * DS + t], v = xcs[co * DS + t];
+        const float* cf = coef[co];
+        const float dz = (v * cf[0] + cf[1] > 0.f) ? g : 0.f;
+        dys[co * DS + t] = cf[0] * (dz - cf[3] - (v - cf[2]) * cf[4]);
+      }
+      __syncthreads();
+    }
+    const bool zall = dead || (ky == 0 && oy0 == 0 && w == 0);        // (the row above the image)
+#pragma unroll 4
+    for (int ox0 = 0; ox0 < Wo; ox0 += 4) {
+      float b0 = xs[boff + 2 * ox0], b1 = xs[boff + 2 * ox0 + 4];
+      if (ox0 == 0) b0 = edge ? 0.f : b0;                            // (the column left of the image)
+      b0 = zall ? 0.f : b0;
+      b1 = zall ? 0.f : b1;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dys[aoff + ox0], b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dys[aoff + ox0 + 2], b1, acc[1], 0, 0, 0);
+    }
+  }
+  // D row co = 8 (i / 4) + 4 half + i % 4 (i < 12 for the 24 real channels), D column = this lane's (ci, ky, kx)
+  float* dst = part + (long)blockIdx.x * 24 * NC;
+  __syncthreads();
+  float* red = cw_smem;                                 // [4 waves][12][64]
+#pragma unroll
+  for (int i = 0; i < 12; ++i) red[(w * 12 + i) * 64 + l] = acc[0][i] + acc[1][i];
+  __syncthreads();
+  for (int idx = t; idx < 12 * 64; idx += 256) {
+    const int i = idx >> 6, ln = idx & 63, c = ln & 31, co = 8 * (i >> 2) + 4 * (ln >> 5) + (i & 3);
+    if (c < NC) dst[co * NC + c] = ((red[idx] + red[12 * 64 + idx]) + red[2 * 12 * 64 + idx]) + red[3 * 12 * 64 + idx];
+  }
+}
+
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nout, int nparts) {
   __shared__ float red[3][64];
   const int o = blockIdx.x * 64 + (threadIdx.x & 63), s = threadIdx.x >> 6;
@@ -712,24 +908,49 @@ extern "C" size_t rn_conv3x3s2_bwd_weight_ws_bytes(int N, int Cin, int H, int W)
   return (size_t)cw_plan(N, Cin, H, W).grid * 24 * Cin * 9 * sizeof(float);
 }
 
-extern "C" int rn_conv3x3s2_bwd_weight(const float* x, const float* dy, float* dw, void* ws, int N, int Cin, int Cout, int H, int W,
-                                       void* stream) {
-  if (int rc = cv_check("rn_conv3x3s2_bwd_weight", x, dy, dw, N, Cin, Cout, H, W)) return rc;
-  RN_CHECK_ARG(ws, "rn_conv3x3s2_bwd_weight: NULL workspace");
+namespace {
+template <bool BN>
+static int cw_launch(const char* who, const float* x, const float* dy, float* dw, void* ws, int N, int Cin, int H, int W, const CwBn& bn, hipStream_t s) {
   const CwPlan p = cw_plan(N, Cin, H, W);
-  RN_CHECK_ARG(p.shm <= 160 * 1024, "rn_conv3x3s2_bwd_weight: W=%d needs %zu bytes of LDS", W, p.shm);
-  hipStream_t s = (hipStream_t)stream;
+  RN_CHECK_ARG(p.shm <= 150 * 1024, "%s: W=%d needs %zu bytes of LDS", who, W, p.shm);
   float* part = (float*)ws;
-  if (Cin == 3) {
-    if (p.shm > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv3x3s2_wgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.shm);
-    conv3x3s2_wgrad_kernel<3><<<p.grid, 256, p.shm, s>>>(x, dy, part, H, W, p.units, p.cpi);
+  bool dma = Cin == 3 && W == 128 && H % 8 == 0 && ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)bn.xc) % 16 == 0;
+  if (const char* e = rn_diag_env("RN_WGRAD1_DMA")) dma = dma && atoi(e) != 0;
+  if (dma) {
+    const size_t shm = (size_t)(4 + 14 * 258 + 32 * 257 + (BN ? 24 * 257 : 0)) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)conv3x3s2_wgrad1_dma_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    conv3x3s2_wgrad1_dma_kernel<BN><<<p.grid, 256, shm, s>>>(x, dy, part, H, p.units, p.cpi, bn);
+  } else if (Cin == 3) {
+    if (p.shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv3x3s2_wgrad_kernel<3, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.shm);
+    conv3x3s2_wgrad_kernel<3, BN><<<p.grid, 256, p.shm, s>>>(x, dy, part, H, W, p.units, p.cpi, bn);
   } else {
-    if (p.shm > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv3x3s2_wgrad_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.shm);
-    conv3x3s2_wgrad_kernel<24><<<p.grid, 448, p.shm, s>>>(x, dy, part, H, W, p.units, p.cpi);
+    if (p.shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv3x3s2_wgrad_kernel<24, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.shm);
+    conv3x3s2_wgrad_kernel<24, BN><<<p.grid, 448, p.shm, s>>>(x, dy, part, H, W, p.units, p.cpi, bn);
   }
-  RN_LAUNCH_CHECK("rn_conv3x3s2_bwd_weight");
+  RN_LAUNCH_CHECK(who);
   const int nout = 24 * Cin * 9;
   conv_wgrad_reduce_kernel<<<(nout + 63) / 64, 256, 0, s>>>(part, dw, nout, p.grid);
   RN_LAUNCH_CHECK("rn_conv3x3s2_bwd_weight(reduce)");
   return 0;
+}
+}  // namespace
+
+extern "C" int rn_conv3x3s2_bwd_weight(const float* x, const float* dy, float* dw, void* ws, int N, int Cin, int Cout, int H, int W,
+                                       void* stream) {
+  if (int rc = cv_check("rn_conv3x3s2_bwd_weight", x, dy, dw, N, Cin, Cout, H, W)) return rc;
+  RN_CHECK_ARG(ws, "rn_conv3x3s2_bwd_weight: NULL workspace");
+  return cw_launch<false>("rn_conv3x3s2_bwd_weight", x, dy, dw, ws, N, Cin, H, W, CwBn{}, (hipStream_t)stream);
+}
+
+extern "C" int rn_bn_relu_bwd_conv_wgrad(const float* dy, const float* xc, const float* inp, const float* gamma, const float* beta,
+                                         const float* mean, const float* invstd, float* dgamma, float* dbeta, float* zero_out, float* dw,
+                                         void* ws_bn, void* ws_conv, int N, int Cin, int H, int W, void* stream) {
+  if (int rc = cv_check("rn_bn_relu_bwd_conv_wgrad", inp, dy, dw, N, Cin, 24, H, W)) return rc;
+  RN_CHECK_ARG(xc && gamma && beta && mean && invstd && dgamma && dbeta && ws_bn && ws_conv, "rn_bn_relu_bwd_conv_wgrad: NULL argument");
+  CwBn bn;
+  bn.xc = xc; bn.part = (const double*)ws_bn; bn.count = (double)N * (H / 2) * (W / 2);
+  bn.mean = mean; bn.invstd = invstd; bn.gamma = gamma; bn.beta = beta;
+  bn.dgamma = dgamma; bn.dbeta = dbeta; bn.zero_out = zero_out;
+  if (int rc = rn_cn_launch_bwd_sums(dy, xc, mean, invstd, gamma, beta, ws_bn, N, 24, (H / 2) * (W / 2), stream, &bn.S)) return rc;
+  return cw_launch<true>("rn_bn_relu_bwd_conv_wgrad", inp, dy, dw, ws_conv, N, Cin, H, W, bn, (hipStream_t)stream);
 }

@@ -405,6 +405,17 @@ extern "C" int rn_bn_relu_apply(const float* x, float* y, const float* gamma, co
   return 0;
 }
 
+// pass 1 of the backward for rn_conv.hip's fused weight-gradient kernel (which is pass 2 there); *S = slices per channel in ws
+int rn_cn_launch_bwd_sums(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                          void* ws, int N, int C, int HW, void* stream, int* S) {
+  if (int rc = cn_check("rn_bn_relu_bwd_conv_wgrad", dy, x, N, C, HW)) return rc;
+  const long n4 = (long)N * HW / 4;
+  *S = cn_slices(n4);
+  cn_bwd_sums_kernel<<<dim3(*S, C), CN_T, 0, (hipStream_t)stream>>>((const f32x4*)dy, (const f32x4*)x, mean, invstd, gamma, beta, (double*)ws, C, HW / 4, n4, *S);
+  RN_LAUNCH_CHECK("rn_bn_relu_bwd_conv_wgrad(sums)");
+  return 0;
+}
+
 extern "C" int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const float* gamma, const float* beta, const float* mean,
                               const float* invstd, float* dgamma, float* dbeta, float* zero_out, void* ws, int N, int C, int HW, void* stream) {
   if (int rc = cn_check("rn_bn_relu_bwd", dy, x, N, C, HW)) return rc;

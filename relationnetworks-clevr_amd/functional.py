@@ -983,9 +983,16 @@ class ConvBNReLUFunction(torch.autograd.Function):
         inp, conv_w, x, g, bt, mean, invstd = ctx.saved_tensors
         stride, padding = ctx.conv_args
         dy = dy.contiguous()
-        dx = torch.empty_like(x)
         b_ref, gamma_ref, beta_ref = ctx.leaf_refs
         dgamma = grad_out(gamma_ref); dbeta = grad_out(beta_ref)
+        if ctx.direct and not ctx.needs_input_grad[0] and OPT.direct_conv_wgrad and OPT.bn_wgrad_fused:
+            # first block (the image needs no gradient) = the END of the backward pass: the conv output gradient is formed inside
+            # the weight-gradient kernel and never written
+            db = grad_out(b_ref) if ctx.has_bias else None
+            dw = grad_out(ctx.w_ref)
+            H.bn_relu_bwd_conv_wgrad(dy, x, inp, g, bt, mean, invstd, dgamma, dbeta, dw, zero_out=db)
+            return None, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
+        dx = torch.empty_like(x)
         # the conv-bias gradient (identically zero) is a tensor of its own, zeroed by the same launch: a shared zero vector would be
         # CLONED by autograd for every leaf it is handed to -- one memcpy node per layer on the critical path of the captured step
         db = grad_out(b_ref) if ctx.has_bias else None

@@ -94,6 +94,7 @@ SIGNATURES = {
     "rn_bn_relu_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _I, _I, _P]),
     "rn_bn_relu_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rn_bn_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "rn_bn_relu_bwd_conv_wgrad": (_I, [_P] * 13 + [_I, _I, _I, _I, _P]),
 }
 # diagnostics (include/rn_hip_debug.h): tests / tools only, not part of the product ABI
 DEBUG_SIGNATURES = {
@@ -583,6 +584,19 @@ def bn_relu_bwd(dy, x, dx, gamma, beta, mean, invstd, dgamma, dbeta, zero_out=No
     _check(lib.rn_bn_relu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
                               invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(zero_out), ws.data_ptr(), N, Cc, Hh * Ww, _stream()),
            "rn_bn_relu_bwd")
+
+
+@_timed("conv")
+def bn_relu_bwd_conv_wgrad(dy, xc, inp, gamma, beta, mean, invstd, dgamma, dbeta, dw, zero_out=None):
+    """Batch-norm + ReLU backward of a block whose input needs no gradient, fused with its convolution's weight gradient
+    (the conv output gradient stays in the kernel).  xc: the conv output; inp: the block's input."""
+    N, Cin, Hh, Ww = inp.shape
+    lib = load()
+    ws_bn = torch.empty(max(lib.rn_bn_relu_ws_bytes(N, 24, (Hh // 2) * (Ww // 2)), 16), dtype=torch.uint8, device=inp.device)
+    ws_cv = torch.empty(max(lib.rn_conv3x3s2_bwd_weight_ws_bytes(N, Cin, Hh, Ww), 16), dtype=torch.uint8, device=inp.device)
+    _check(lib.rn_bn_relu_bwd_conv_wgrad(dy.data_ptr(), xc.data_ptr(), inp.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                                         invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(zero_out), dw.data_ptr(),
+                                         ws_bn.data_ptr(), ws_cv.data_ptr(), N, Cin, Hh, Ww, _stream()), "rn_bn_relu_bwd_conv_wgrad")
 
 
 # ------------------------------------------------------------------ fused f_phi

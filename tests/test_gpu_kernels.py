@@ -1156,7 +1156,7 @@ def test_question_lstm(B, T):
 
 
 # ----------------------------------------------------------------------------- conv stack: direct 3x3 / stride-2 convolutions
-@pytest.mark.parametrize("N,Cin,Hh,Ww", [(64, 3, 128, 128), (64, 24, 64, 64), (5, 24, 32, 32), (3, 24, 16, 16), (2, 3, 12, 20), (2, 24, 6, 4)])
+@pytest.mark.parametrize("N,Cin,Hh,Ww", [(64, 3, 128, 128), (64, 24, 64, 64), (5, 24, 32, 32), (3, 24, 16, 16), (2, 3, 12, 20), (2, 24, 6, 4), (3, 3, 64, 128), (2, 3, 132, 128)])
 def test_conv3x3s2_bwd_weight(H, N, Cin, Hh, Ww):
     """The MFMA weight gradient of the conv stack against the library's (fp32, summation order differs)."""
     x = dev(formula.hash_uniform((N, Cin, Hh, Ww), 70, -1, 1))
@@ -1169,7 +1169,7 @@ def test_conv3x3s2_bwd_weight(H, N, Cin, Hh, Ww):
     assert rel(dw.cpu().numpy(), ref.cpu().numpy()) <= 2e-6
 
 
-@pytest.mark.parametrize("N,Cin,hw", [(64, 3, 128), (64, 24, 64), (3, 24, 16), (2, 3, 34), (32, 24, 72), (33, 24, 66), (32, 24, 112)])
+@pytest.mark.parametrize("N,Cin,hw", [(64, 3, 128), (64, 24, 64), (3, 24, 16), (2, 3, 34), (32, 24, 72), (33, 24, 66), (32, 24, 112), (64, 24, 32), (64, 24, 16), (17, 24, 32), (16, 24, 16)])
 def test_conv3x3s2_direct(H, N, Cin, hw):
     """rn_conv.hip against torch's conv2d (MIOpen) and its input gradient: fp32, summation order only."""
     x = dev(formula.hash_uniform((N, Cin, hw, hw), 950, -1, 1))
@@ -1185,6 +1185,30 @@ def test_conv3x3s2_direct(H, N, Cin, hw):
         xr = x.clone().requires_grad_(True)
         torch.nn.functional.conv2d(xr, w, None, stride=2, padding=1).backward(dy)
         assert rel(dx.cpu().numpy(), xr.grad.cpu().numpy()) <= F32_TOL
+
+
+@pytest.mark.parametrize("N,Cin,hw", [(64, 3, 128), (3, 3, 36), (5, 24, 32), (2, 3, 136), (3, 3, 128)])
+def test_bn_relu_bwd_conv_wgrad(H, N, Cin, hw):
+    """The first block's fused backward (batch-norm pass 2 inside the weight-gradient kernel) against the two separate entries:
+    the same expressions on the same slice sums (small layers: the one-launch batch-norm kernel sums in another order), dw to fp32
+    rounding (summation order of the products).  128-column images take the LDS-DMA kernel."""
+    inp = dev(formula.hash_uniform((N, Cin, hw, hw), 960, -1, 1))
+    xc = dev(formula.hash_uniform((N, 24, hw // 2, hw // 2), 961, -2, 2))
+    dy = dev(formula.hash_uniform((N, 24, hw // 2, hw // 2), 962, -1, 1))
+    gamma = dev(formula.hash_uniform((24,), 963, 0.5, 1.5)); beta = dev(formula.hash_uniform((24,), 964, -0.5, 0.5))
+    mean = xc.mean((0, 2, 3)).contiguous(); invstd = torch.rsqrt(xc.var((0, 2, 3), unbiased=False) + 1e-5).contiguous()
+    nan = lambda *sh: torch.full(sh, float("nan"), device="cuda")
+    dx = nan(*xc.shape); dg0, db0, z0, dw0 = nan(24), nan(24), nan(24), nan(24, Cin, 3, 3)
+    H.bn_relu_bwd(dy, xc, dx, gamma, beta, mean, invstd, dg0, db0, zero_out=z0)
+    H.conv3x3s2_bwd_weight(inp, dx, dw0)
+    dg1, db1, z1, dw1 = nan(24), nan(24), nan(24), nan(24, Cin, 3, 3)
+    H.bn_relu_bwd_conv_wgrad(dy, xc, inp, gamma, beta, mean, invstd, dg1, db1, dw1, zero_out=z1)
+    torch.cuda.synchronize()
+    assert torch.equal(z1, torch.zeros_like(z1))
+    if N * (hw // 2) ** 2 > 16384 * 4:
+        assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert rel(dg1.cpu().numpy(), dg0.cpu().numpy()) <= 2e-6 and rel(db1.cpu().numpy(), db0.cpu().numpy()) <= 2e-6
+    assert rel(dw1.cpu().numpy(), dw0.cpu().numpy()) <= 2e-6
 
 
 def test_f_phi_nll_fused(H):
