@@ -364,6 +364,11 @@ int rn_clip_adam_step(const void* chunks, int nchunks, float* g, float* m, float
 int rn_clip_adam_step_dev(const void* chunks, int nchunks, float* g, float* m, float* v, long n, void* ws, const float* hyper,
                           int* step_dev, float* norm_out, void* stream);
 
+/* The batch hand-off in front of a captured step (train.py:36-40: img / qst / label of the next batch): up to 4 device-to-device
+ * copies as ONE launch (three library copies are three launches, ~12 us in front of every replay at the headline shape).
+ * dst[i], src[i]: 16-byte aligned, bytes[i] any size (a multiple of 16 bytes goes through 16-byte accesses, the rest bytewise). */
+int rn_copy_many(void* const* dst, const void* const* src, const size_t* bytes, int n, void* stream);
+
 /* Question encoder (reference model.py:39-58): embedding lookup + 1-layer LSTM (E = 32 -> H = 128, gate order
  * i, f, g, o, zero initial state) as ONE launch per direction (rn_lstm.hip), fp32.
  *   fwd: idx (B, T) int64 tokens (clamped to [0, V)); emb (V, E); W_ih (4H, E), W_hh (4H, H), b_ih, b_hh (4H).

@@ -870,3 +870,54 @@ extern "C" int rn_debug_stamp(unsigned long long* slot, void* stream) {
   RN_LAUNCH_CHECK("rn_debug_stamp");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ batch hand-off
+namespace {
+struct CopyMany {
+  unsigned char* dst[4];
+  const unsigned char* src[4];
+  size_t bytes[4];
+  int blk0[5];                                            // first workgroup of segment i (blk0[n] = grid)
+  int n;
+};
+constexpr int CM_PER_BLOCK = 256 * 4 * 16;               // bytes per workgroup: 4 x 16 bytes per thread, all loads before the stores
+}
+__global__ __launch_bounds__(256) void copy_many_kernel(CopyMany c) {
+  int i = 0;
+  while (i + 1 < c.n && (int)blockIdx.x >= c.blk0[i + 1]) ++i;
+  const size_t off = (size_t)((int)blockIdx.x - c.blk0[i]) * CM_PER_BLOCK, n = c.bytes[i], n16 = n & ~(size_t)15;
+  const unsigned char* s = c.src[i];
+  unsigned char* d = c.dst[i];
+  u32x4 v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const size_t a = off + ((size_t)q * 256 + threadIdx.x) * 16;
+    if (a < n16) v[q] = *reinterpret_cast<const u32x4*>(s + a);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const size_t a = off + ((size_t)q * 256 + threadIdx.x) * 16;
+    if (a < n16) *reinterpret_cast<u32x4*>(d + a) = v[q];
+  }
+  if (off + CM_PER_BLOCK >= n && n16 + threadIdx.x < n && off <= n16) d[n16 + threadIdx.x] = s[n16 + threadIdx.x];   // (< 16 bytes)
+}
+
+extern "C" int rn_copy_many(void* const* dst, const void* const* src, const size_t* bytes, int n, void* stream) {
+  RN_CHECK_ARG(dst && src && bytes && n > 0 && n <= 4, "rn_copy_many: bad argument (n=%d, 1..4)", n);
+  CopyMany c;
+  memset(&c, 0, sizeof(c));
+  c.n = n;
+  int grid = 0;
+  for (int i = 0; i < n; ++i) {
+    RN_CHECK_ARG(dst[i] && src[i] && ((uintptr_t)dst[i] | (uintptr_t)src[i]) % 16 == 0 && bytes[i] > 0, "rn_copy_many: segment %d: NULL / misaligned / empty", i);
+    c.dst[i] = (unsigned char*)dst[i];
+    c.src[i] = (const unsigned char*)src[i];
+    c.bytes[i] = bytes[i];
+    c.blk0[i] = grid;
+    grid += (int)((bytes[i] + CM_PER_BLOCK - 1) / CM_PER_BLOCK);
+  }
+  c.blk0[n] = grid;
+  copy_many_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(c);
+  RN_LAUNCH_CHECK("rn_copy_many");
+  return 0;
+}

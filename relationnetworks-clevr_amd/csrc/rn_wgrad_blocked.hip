@@ -80,7 +80,7 @@ template <bool Z8, bool A8> struct KbFrag {
 };
 
 // ABL (RN_DIAG builds only, tools/): timing ablations with WRONG results -- 1: the stream alone (no fragment reads, no MFMAs),
-// 2: compute alone (no requests), 4: no barriers, 64: no conversions
+// 2: compute alone (no requests), 4: no barriers, 8 / 16: no A / dZ fragment reads, 64: no conversions
 template <bool Z8, bool A8, int ABL = 0>
 __device__ __forceinline__ void kb_run(unsigned char* lds, const KbJob& jb_, int S, int Z, int z, int nh, int kb) {
   typedef KbGeo<Z8, A8> G;
@@ -119,6 +119,8 @@ __device__ __forceinline__ void kb_run(unsigned char* lds, const KbJob& jb_, int
   const unsigned zoff = (unsigned)(((Z8 ? h : 2 * h) * 128 + wn * 64 + n) * 16);
   const unsigned aoff = (unsigned)(G::ZB + ((A8 ? h : 2 * h) * 128 + wk * 64 + n) * 16);
   auto read_piece = [&](const unsigned char* st, int R, KbFrag<Z8, A8>& f, int q) {
+    if ((ABL & 8) && q == 2) return;                      // (ablation: no A fragment reads)
+    if ((ABL & 16) && q < 2) return;                      // (ablation: no dZ fragment reads)
     if (q < 2) {                                          // the dZ fragments of both n blocks: MFMA a (q = 0), MFMA b (q = 1)
       if constexpr (Z8) {
         if (q == 0) {
@@ -440,7 +442,7 @@ static int kb_launch(const void* const* dZ, const int* dz_dtype, const void* con
 #ifdef RN_DIAG
   switch (abl) {
 #define RN_ABL(v) case v: if (a_dtype == RN_FP8) wgrad_blocked_kernel<true, v><<<grid, KB_NT, 0, s>>>(a); else wgrad_blocked_kernel<false, v><<<grid, KB_NT, 0, s>>>(a); break;
-    RN_ABL(1) RN_ABL(2) RN_ABL(3) RN_ABL(4) RN_ABL(6) RN_ABL(66)
+    RN_ABL(1) RN_ABL(2) RN_ABL(3) RN_ABL(4) RN_ABL(6) RN_ABL(66) RN_ABL(8) RN_ABL(24) RN_ABL(10) RN_ABL(26)
 #undef RN_ABL
     default:
 #else

@@ -280,8 +280,13 @@ class DataParallelTrainer:
         if self.use_graph:
             if self._graph is None:
                 self._capture(img, qst, label)
-            for dst, src in zip(self._static, (img, qst, label)):
-                if dst.data_ptr() != src.data_ptr():
+            todo = [(dst, src) for dst, src in zip(self._static, (img, qst, label)) if dst.data_ptr() != src.data_ptr()]
+            if todo and OPT.batch_copy_fused and all(s_.is_cuda and s_.is_contiguous() and s_.dtype == d.dtype and s_.shape == d.shape
+                                                     and s_.data_ptr() % 16 == 0 for d, s_ in todo):
+                from . import rn_hip as _H
+                _H.copy_many(todo)                          # one launch for the whole batch hand-off
+            else:
+                for dst, src in todo:
                     dst.copy_(src, non_blocking=True)
             if self._opt_in_graph:
                 self._fused_opt.sync_hyper(self.clip_norm, 1.0)

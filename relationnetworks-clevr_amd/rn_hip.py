@@ -85,6 +85,7 @@ SIGNATURES = {
     "rn_clip_adam_chunk": (_I, []),
     "rn_clip_adam_ws_bytes": (_Z, []),
     "rn_clip_adam_step_dev": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P]),
+    "rn_copy_many": (_I, [_P, _P, _P, _I, _P]),
     "rn_clip_adam_step": (_I, [_P, _I, _P, _P, _P, _L, _P] + [C.c_float] * 7 + [_I, _P, _P]),
     "rn_conv3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_conv3x3s2_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -771,3 +772,16 @@ def nll_mean_fwd(logp, label, loss):
 
 def nll_mean_bwd(label, gloss, gout):
     _check(load().rn_nll_mean_bwd(label.data_ptr(), gloss.data_ptr(), gout.data_ptr(), gout.shape[0], gout.shape[1], _stream()), "rn_nll_mean_bwd")
+
+
+def copy_many(pairs):
+    """[(dst, src), ...] (<= 4 pairs of contiguous device tensors of equal byte size): ONE launch instead of one library copy each --
+    the batch hand-off in front of a captured step."""
+    n = len(pairs)
+    for d, s_ in pairs:
+        if not (d.is_contiguous() and s_.is_contiguous() and d.dtype == s_.dtype and d.numel() == s_.numel() and d.is_cuda and s_.is_cuda):
+            raise ValueError("copy_many: tensors must be contiguous device tensors of the same type and size")
+    dst = (C.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
+    src = (C.c_void_p * n)(*[s_.data_ptr() for _, s_ in pairs])
+    nb = (C.c_size_t * n)(*[d.numel() * d.element_size() for d, _ in pairs])
+    _check(load().rn_copy_many(dst, src, nb, n, _stream()), "rn_copy_many")

@@ -1375,3 +1375,19 @@ def test_f_phi_from_partials(H, B, parts, nll, tr):
         assert torch.equal(dxg, dxgb)
         for a, b in zip(dWa + dba, dWb + dbb):
             assert torch.equal(a, b)
+
+
+def test_copy_many(H):
+    """The batch hand-off: up to four copies in one launch, sizes with and without a 16-byte tail; bytes outside stay untouched."""
+    srcs = [torch.randn(64, 3, 128, 128, device="cuda"), torch.randint(0, 80, (64, 43), device="cuda"), torch.randint(0, 28, (64,), device="cuda"),
+            torch.randint(0, 255, (16 * 1024 + 7,), dtype=torch.uint8, device="cuda")]
+    pads = [torch.full((s.numel() * s.element_size() + 64,), 0xA5, dtype=torch.uint8, device="cuda") for s in srcs]
+    dsts = [p[16:16 + s.numel() * s.element_size()].view(s.dtype).view(s.shape) for p, s in zip(pads, srcs)]
+    H.copy_many(list(zip(dsts, srcs)))
+    torch.cuda.synchronize()
+    for d, s, p in zip(dsts, srcs, pads):
+        assert torch.equal(d, s)
+        assert bool((p[:16] == 0xA5).all()) and bool((p[16 + s.numel() * s.element_size():] == 0xA5).all())
+    H.copy_many([(dsts[2], srcs[2])])
+    with pytest.raises(ValueError):
+        H.copy_many([(dsts[0], srcs[1])])

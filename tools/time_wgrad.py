@@ -48,7 +48,8 @@ for name, A, z3 in (("e4m3 A", A8, gate), ("bf16 A", A16, dZ[2])):
 us = timeit(lambda: H.g_linear_bwd_wgrad(dZ[0], G, A16[0], G, dW[0], db[0], 0, M, G, G, G))
 print("general row-major kernel: %7.1f us" % us)
 if os.environ.get("RN_DIAG", "0") == "1":
-    for abl, what in ((1, "stream only"), (2, "compute only"), (3, "loop + barriers only"), (66, "compute only, no conversions")):
-        for name, jobs in (("stored, e4m3", [(dZ[0], A8[0], dW[0], db[0])]), ("gate job", [(gate, A8[2], dW[2], db[2])])):
+    for abl, what in ((1, "stream only"), (2, "compute only"), (3, "loop + barriers only"), (66, "compute only, no conversions"), (8, "no A frag reads"), (24, "no frag reads at all"), (10, "compute only, no A frag reads"), (26, "compute only, no frag reads")):
+        for name, jobs in (("stored, e4m3", [(dZ[0], A8[0], dW[0], db[0])]), ("gate job", [(gate, A8[2], dW[2], db[2])]),
+                           ("three jobs", [(dZ[0], A8[0], dW[0], db[0]), (dZ[1], A8[1], dW[1], db[1]), (gate, A8[2], dW[2], db[2])])):
             us = timeit(lambda: H.g_wgrad_blocked(jobs, M, abl=abl, **kw))
             print("ABL %3d (%s) %s: %7.1f us" % (abl, what, name, us))
