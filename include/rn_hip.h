@@ -384,6 +384,10 @@ int rn_lstm_fwd(const long long* idx, const float* emb, const float* W_ih, const
 int rn_lstm_bwd(const float* dhn, const float* gates, const float* cs, const float* W_hh, float* dgates, int B, int T, int H,
                 void* stream);
 int rn_embedding_bwd(const long long* idx, const float* dx, float* demb, int B, int T, int V, int E, void* stream);
+/* rn_embedding_bwd and the two bias gradients in one launch: db_ih = db_hh (may be NULL) = column sums of dgates (T*B, 4H), fixed
+ * order.  demb == NULL (the embedding needs no gradient): the bias gradients alone. */
+int rn_lstm_bwd_tail(const long long* idx, const float* dx, float* demb, const float* dgates, float* db_ih, float* db_hh, int B, int T,
+                     int V, int E, int H, void* stream);
 
 /* The 3x3 / stride-2 / pad-1 convolutions of ConvInputModel (reference model.py:13-20) as direct fp32 kernels (rn_conv.hip):
  * x (N, Cin, H, W), w (Cout, Cin, 3, 3) -- nn.Conv2d layout --, y (N, Cout, H/2, W/2), all contiguous; no bias (the fused

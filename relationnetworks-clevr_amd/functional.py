@@ -1073,16 +1073,25 @@ class QuestionLSTMFunction(torch.autograd.Function):
         H.lstm_bwd(dhn.float().contiguous(), gates, cs, W_hh, dgates)
         dg = dgates.view(T * B, G4)
         emb_r, wih_r, whh_r, bih_r, bhh_r = ctx.leaf_refs
+        # the embedding gradient FIRST (it hangs on a product of its own), with the two bias gradients in its launch (db_hh = db_ih:
+        # a tensor of its own, autograd would clone a shared one); the two weight-gradient products close the chain -- this side
+        # stream is as long as the conv stack's backward beside it, every launch on it counts
+        db = grad_out(bih_r); db2 = grad_out(bhh_r)
+        demb = dx = None
+        if OPT.lstm_tail_fused:
+            if ctx.needs_input_grad[1]:
+                dx = dg.mm(W_ih)
+                demb = grad_out(emb_r, (ctx.vocab, xs.shape[2]))
+            H.lstm_bwd_tail(idx, dx, demb, dgates, db, db2)
         dW_hh = torch.mm(dg.t(), hs[:T].reshape(T * B, -1), out=grad_out(whh_r))
         dW_ih = torch.mm(dg.t(), xs.view(T * B, -1), out=grad_out(wih_r))
-        db = torch.sum(dg, 0, out=grad_out(bih_r))
-        db2 = grad_out(bhh_r)                   # (the same values; a tensor of its own: autograd would clone a shared one)
-        db2.copy_(db)
-        demb = None
-        if ctx.needs_input_grad[1]:
-            dx = dg.mm(W_ih)
-            demb = grad_out(emb_r, (ctx.vocab, xs.shape[2]))
-            H.embedding_bwd(idx, dx, demb)
+        if not OPT.lstm_tail_fused:
+            torch.sum(dg, 0, out=db)
+            db2.copy_(db)
+            if ctx.needs_input_grad[1]:
+                dx = dg.mm(W_ih)
+                demb = grad_out(emb_r, (ctx.vocab, xs.shape[2]))
+                H.embedding_bwd(idx, dx, demb)
         return None, demb, dW_ih, dW_hh, db, db2
 
 

@@ -31,6 +31,7 @@ _SPEC = {
     "wgrad_late":        ("RN_WGRAD_LATE", 0, "1 / 2: start the weight-gradient stream after the pair reduction / after dx, dq (measured slower)"),
     "direct_conv":       ("RN_NO_DIRECT_CONV", True, "own 3x3 / stride-2 convolution kernels (else MIOpen)"),
     "direct_conv_wgrad": ("RN_NO_DIRECT_CONV_WGRAD", True, "... and their weight gradient"),
+    "lstm_tail_fused": ("RN_NO_FUSED_LSTM_TAIL", True, "question encoder backward: embedding gradient first, bias gradients in its launch"),
     "batch_copy_fused": ("RN_NO_BATCH_COPY_FUSED", True, "captured step: the batch's three hand-off copies as one launch"),
     "bn_wgrad_fused": ("RN_NO_BN_WGRAD_FUSED", True, "first conv block: batch-norm backward pass 2 inside the weight-gradient kernel"),
     "fused_bn":          ("RN_NO_FUSED_BN", True, "fused conv-bias + BatchNorm + ReLU kernels"),

@@ -84,6 +84,7 @@ SIGNATURES = {
     "rn_nll_mean_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "rn_clip_adam_chunk": (_I, []),
     "rn_clip_adam_ws_bytes": (_Z, []),
+    "rn_lstm_bwd_tail": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_clip_adam_step_dev": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P]),
     "rn_copy_many": (_I, [_P, _P, _P, _I, _P]),
     "rn_clip_adam_step": (_I, [_P, _I, _P, _P, _P, _L, _P] + [C.c_float] * 7 + [_I, _P, _P]),
@@ -728,6 +729,15 @@ def embedding_bwd(idx, dx, demb):
     B, T = idx.shape
     _check(load().rn_embedding_bwd(idx.data_ptr(), dx.data_ptr(), demb.data_ptr(), B, T, demb.shape[0], demb.shape[1], _stream()),
            "rn_embedding_bwd")
+
+
+@_timed("lstm")
+def lstm_bwd_tail(idx, dx, demb, dgates, db_ih, db_hh=None):
+    """Embedding gradient (demb may be None) and the bias gradients (column sums of dgates (T, B, 4H)) in one launch."""
+    B, T = idx.shape
+    _check(load().rn_lstm_bwd_tail(idx.data_ptr(), _ptr(dx), _ptr(demb), dgates.data_ptr(), db_ih.data_ptr(), _ptr(db_hh), B, T,
+                                   demb.shape[0] if demb is not None else 0, demb.shape[1] if demb is not None else 32,
+                                   dgates.shape[-1] // 4, _stream()), "rn_lstm_bwd_tail")
 
 
 # ------------------------------------------------------------------ R-CBIR pair features (extract.py)

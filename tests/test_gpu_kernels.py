@@ -1391,3 +1391,22 @@ def test_copy_many(H):
     H.copy_many([(dsts[2], srcs[2])])
     with pytest.raises(ValueError):
         H.copy_many([(dsts[0], srcs[1])])
+
+
+@pytest.mark.parametrize("B,T,V", [(64, 43, 82), (5, 7, 11), (200, 43, 82)])
+def test_lstm_bwd_tail(H, B, T, V):
+    """Embedding gradient + bias gradients in one launch: the embedding part bitwise the stand-alone entry (same order), the
+    column sums against torch (fp64)."""
+    idx = torch.tensor(formula.hash_uniform((B, T), 970, 0, V).astype(np.int64).clip(0, V - 1), device="cuda")
+    dx = dev(formula.hash_uniform((T * B, 32), 971, -1, 1))
+    dg = dev(formula.hash_uniform((T, B, 512), 972, -1, 1))
+    d0 = torch.full((V, 32), float("nan"), device="cuda"); d1 = torch.full_like(d0, float("nan"))
+    b1 = torch.full((512,), float("nan"), device="cuda"); b2 = torch.full_like(b1, float("nan")); b3 = torch.full_like(b1, float("nan"))
+    H.embedding_bwd(idx, dx, d0)
+    H.lstm_bwd_tail(idx, dx, d1, dg, b1, b2)
+    H.lstm_bwd_tail(idx, None, None, dg, b3)
+    torch.cuda.synchronize()
+    assert torch.equal(d0, d1) and torch.equal(b1, b2) and torch.equal(b1, b3)
+    ref = torch.zeros(V, 32, dtype=torch.float64, device="cuda").index_add_(0, idx.t().reshape(-1), dx.double())
+    assert rel(d1.cpu().numpy(), ref.cpu().numpy()) <= F32_TOL
+    assert rel(b1.cpu().numpy(), dg.double().sum((0, 1)).cpu().numpy()) <= F32_TOL
