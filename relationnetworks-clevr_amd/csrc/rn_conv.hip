@@ -876,6 +876,84 @@ __global__ __launch_bounds__(256) void conv3x3s2_wgrad1_dma_kernel(const float* 
   }
 }
 
+// ... and the 24 -> 24 layers (64- / 32- / 16-column inputs) the same way: 256 / W x rows and 128 / W channels of dy rows per 1-KB
+// request, 7 waves = the 7 column tiles of (ci, ky, kx) as in the register-staged kernel.  (The 64-column layer's weight gradient
+// is the last thing on the side stream of the backward pass: 31 us there, staged through registers.)
+template <int W>
+__global__ __launch_bounds__(448) void conv3x3s2_wgrad24_dma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                    float* __restrict__ part, int H, int units, int cpi) {
+  constexpr int CIN = 24, NC = 216, Wo = W / 2, PAD = 4, RPI = 256 / W, CPI = 128 / W, XP = 258, DP = 257;
+  constexpr int NXI = (NC + RPI - 1) / RPI, NDI = 24 / CPI, XS = PAD + NXI * XP;
+  typedef __attribute__((address_space(3))) unsigned char lds_u8_;
+  extern __shared__ __attribute__((aligned(16))) float cw_smem[];
+  float* xs = cw_smem;
+  float* dys = cw_smem + XS;                            // [32 / CPI requests][DP]: channels 24..31 stay zero
+  const int Ho = H / 2;
+  const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), ncol = l & 31, half = l >> 5;
+  const int col = 32 * w + ncol, colc = col < NC ? col : 0, ci = colc / 9, ky = (colc % 9) / 3, kx = colc % 3;
+  int boff[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = ci * 9 + 2 * rr + ky;
+    boff[rr] = PAD + (r / RPI) * XP + (r % RPI) * W + kx - 1 + 2 * half;
+  }
+  const int aoff = (ncol / CPI) * DP + (ncol % CPI) * (4 * Wo) + half;
+  const bool dead = col >= NC, edge = half == 0 && kx == 0;
+  for (int i = t; i < (32 / CPI - NDI) * DP; i += 448) dys[NDI * DP + i] = 0.f;
+  const unsigned lds_x = (unsigned)(size_t)(lds_u8_*)xs + PAD * 4, lds_dy = (unsigned)(size_t)(lds_u8_*)dys;
+  cv_f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int n = __builtin_amdgcn_readfirstlane(u / cpi), oy0 = __builtin_amdgcn_readfirstlane(4 * (u - n * cpi));
+    __syncthreads();                                    // the previous unit's reads (or the zero fill) are done
+    {
+      const float* xn = x + (long)n * CIN * H * W;
+      asm volatile("" : "+s"(xn));
+      for (int inst = w; inst < NXI; inst += 7) {
+        int r = RPI * inst + l / (W / 4);
+        r = r < NC ? r : NC - 1;
+        const int c = r / 9, iy = 2 * oy0 - 1 + (r - 9 * c);
+        const unsigned voff = (unsigned)((((c * H + (iy < 0 ? 0 : iy)) * W) << 2) + ((l % (W / 4)) << 4));
+        const unsigned dst = lds_x + inst * (XP * 4);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(xn), "s"(dst) : "memory");
+      }
+      const float* dn = dy + ((long)n * 24 * Ho + oy0) * Wo;
+      asm volatile("" : "+s"(dn));
+      for (int inst = w; inst < NDI; inst += 7) {
+        const int c = CPI * inst + l / (W / 2);
+        const unsigned voff = (unsigned)((c * Ho * Wo) << 2) + (unsigned)((l % (W / 2)) << 4);
+        const unsigned dst = lds_dy + inst * (DP * 4);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dn), "s"(dst) : "memory");
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const bool zall = dead || (ky == 0 && oy0 == 0 && rr == 0);      // (the row above the image)
+#pragma unroll 4
+      for (int ox0 = 0; ox0 < Wo; ox0 += 4) {
+        float b0 = xs[boff[rr] + 2 * ox0], b1 = xs[boff[rr] + 2 * ox0 + 4];
+        if (ox0 == 0) b0 = edge ? 0.f : b0;                            // (the column left of the image)
+        b0 = zall ? 0.f : b0;
+        b1 = zall ? 0.f : b1;
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dys[aoff + rr * Wo + ox0], b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dys[aoff + rr * Wo + ox0 + 2], b1, acc[1], 0, 0, 0);
+      }
+    }
+  }
+  float* dst = part + (long)blockIdx.x * 24 * NC;
+  if (col < NC) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dst[(8 * (i >> 2) + 4 * half + (i & 3)) * NC + col] = acc[0][i] + acc[1][i];
+  }
+}
+
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nout, int nparts) {
   __shared__ float red[3][64];
   const int o = blockIdx.x * 64 + (threadIdx.x & 63), s = threadIdx.x >> 6;
@@ -909,6 +987,10 @@ extern "C" size_t rn_conv3x3s2_bwd_weight_ws_bytes(int N, int Cin, int H, int W)
 }
 
 namespace {
+static bool cw_dma24_on() {
+  if (const char* e = rn_diag_env("RN_WGRAD24_DMA")) return atoi(e) != 0;
+  return true;
+}
 template <bool BN>
 static int cw_launch(const char* who, const float* x, const float* dy, float* dw, void* ws, int N, int Cin, int H, int W, const CwBn& bn, hipStream_t s) {
   const CwPlan p = cw_plan(N, Cin, H, W);
@@ -920,6 +1002,16 @@ static int cw_launch(const char* who, const float* x, const float* dy, float* dw
     const size_t shm = (size_t)(4 + 14 * 258 + 32 * 257 + (BN ? 24 * 257 : 0)) * sizeof(float);
     (void)hipFuncSetAttribute((const void*)conv3x3s2_wgrad1_dma_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     conv3x3s2_wgrad1_dma_kernel<BN><<<p.grid, 256, shm, s>>>(x, dy, part, H, p.units, p.cpi, bn);
+  } else if (!BN && Cin == 24 && H == W && (W == 64 || W == 32 || W == 16) && ((uintptr_t)x | (uintptr_t)dy) % 16 == 0 && cw_dma24_on()) {
+    const int rpi = 256 / W, cpi_d = 128 / W;
+    const size_t shm = (size_t)(4 + ((216 + rpi - 1) / rpi) * 258 + (32 / cpi_d) * 257) * sizeof(float);
+#define RN_CW24(W_)                                                                                                                          \
+  {                                                                                                                                          \
+    (void)hipFuncSetAttribute((const void*)conv3x3s2_wgrad24_dma_kernel<W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);          \
+    conv3x3s2_wgrad24_dma_kernel<W_><<<p.grid, 448, shm, s>>>(x, dy, part, H, p.units, p.cpi);                                               \
+  }
+    if (W == 64) RN_CW24(64) else if (W == 32) RN_CW24(32) else RN_CW24(16)
+#undef RN_CW24
   } else if (Cin == 3) {
     if (p.shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv3x3s2_wgrad_kernel<3, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.shm);
     conv3x3s2_wgrad_kernel<3, BN><<<p.grid, 256, p.shm, s>>>(x, dy, part, H, W, p.units, p.cpi, bn);
