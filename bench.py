@@ -367,11 +367,12 @@ def main():
         trainer.use_graph = False
         overlap_default = pkg.options.OPT.wgrad_overlap
         # Eager launches are host-bound (~110 launches per step): with an idle GPU a bracket would also measure the host's
-        # launch latency.  A one-thread spin kernel (torch.cuda._sleep) in front of every step keeps the GPU ~3 ms behind the
-        # host, so the whole step is queued before it starts and a bracket spans GPU time only.
+        # launch latency.  A one-thread spin kernel (torch.cuda._sleep) in front of every step keeps the GPU ~10 ms behind the
+        # host (a slow host needs > 3 ms for the ~110 launches and their event packets: brackets read 10 % long on such a box),
+        # so the whole step is queued before it starts and a bracket spans GPU time only.
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); torch.cuda._sleep(1000000); e1.record(); torch.cuda.synchronize()
-        spin = int(1000000 * 3.0 / max(e0.elapsed_time(e1), 1e-3))
+        spin = int(1000000 * 10.0 / max(e0.elapsed_time(e1), 1e-3))
         for tag in ("in_step", "alone"):
             if tag == "alone":
                 pkg.options.OPT.wgrad_overlap = False
