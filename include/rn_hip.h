@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RN_ABI_VERSION 2   /* bumped whenever a signature or a buffer layout of this header changes */
+#define RN_ABI_VERSION 3   /* bumped whenever a signature or a buffer layout of this header changes */
 
 enum { RN_BF16 = 0, RN_F32 = 1, RN_F16 = 2, RN_FP8 = 3 };   /* RN_F16: pair matrix / split weights of the f16s forward only;
                                                              * RN_FP8: OCP e4m3 copies of the stored activations (h_dtype / a_dtype) */
