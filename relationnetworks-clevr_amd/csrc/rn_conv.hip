@@ -954,17 +954,23 @@ __global__ __launch_bounds__(448) void conv3x3s2_wgrad24_dma_kernel(const float*
   }
 }
 
+// (the layer-1 reduction is the last kernel before the optimiser: 32 outputs x 8 slices per block, 16 loads in flight per thread --
+// 4 dependent round trips over 512 partials instead of 16)
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nout, int nparts) {
-  __shared__ float red[3][64];
-  const int o = blockIdx.x * 64 + (threadIdx.x & 63), s = threadIdx.x >> 6;
+  __shared__ float red[7][32];
+  const int o = blockIdx.x * 32 + (threadIdx.x & 31), s = threadIdx.x >> 5;
   float a = 0.f;
   if (o < nout) {
-#pragma unroll 8
-    for (int b = s; b < nparts; b += 4) a += part[(long)b * nout + o];
+#pragma unroll 16
+    for (int b = s; b < nparts; b += 8) a += part[(long)b * nout + o];
   }
-  if (s) red[s - 1][threadIdx.x & 63] = a;
+  if (s) red[s - 1][threadIdx.x & 31] = a;
   __syncthreads();
-  if (s == 0 && o < nout) dw[o] = ((a + red[0][threadIdx.x]) + red[1][threadIdx.x]) + red[2][threadIdx.x];
+  if (s == 0 && o < nout) {
+#pragma unroll
+    for (int q = 0; q < 7; ++q) a += red[q][threadIdx.x];
+    dw[o] = a;
+  }
 }
 
 namespace {
@@ -1021,7 +1027,7 @@ static int cw_launch(const char* who, const float* x, const float* dy, float* dw
   }
   RN_LAUNCH_CHECK(who);
   const int nout = 24 * Cin * 9;
-  conv_wgrad_reduce_kernel<<<(nout + 63) / 64, 256, 0, s>>>(part, dw, nout, p.grid);
+  conv_wgrad_reduce_kernel<<<(nout + 31) / 32, 256, 0, s>>>(part, dw, nout, p.grid);
   RN_LAUNCH_CHECK("rn_conv3x3s2_bwd_weight(reduce)");
   return 0;
 }
