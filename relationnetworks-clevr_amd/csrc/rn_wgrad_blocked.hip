@@ -35,6 +35,10 @@
 // layers of a step) run as ONE launch + ONE reduction launch.
 #include "rn_common.h"
 
+#ifndef KB_RING24
+#define KB_RING24 6       // ring stages of a 24-KB step (bf16 dZ + e4m3 A) ...
+#define KB_RING16 8       // ... and of a 16-KB one (gate job)
+#endif
 namespace {
 constexpr int KB_NT = 256, KB_NB = 4, KB_MAXJOBS = 4;
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
@@ -59,12 +63,15 @@ template <bool Z8, bool A8> struct KbGeo {
   static constexpr int ZB = 64 * 128 * (Z8 ? 1 : 2);      // dZ tile of a 64-row step
   static constexpr int AB = 64 * 128 * (A8 ? 1 : 2);      // A tile
   static constexpr int STG = ZB + AB;
-  static constexpr int NSTG = STG <= 16384 ? 8 : (STG <= 24576 ? 6 : 4);
+  static constexpr int NSTG = STG <= 16384 ? KB_RING16 : (STG <= 24576 ? KB_RING24 : 4);
   static constexpr int LA = NSTG - 1;                     // stage s + LA is requested in step s
   static constexpr int PZ = ZB / 1024 / 4, PA = AB / 1024 / 4;   // 1-KB LDS-DMA pieces per wave and step
   static constexpr int LDS = NSTG * STG;
 };
-constexpr int KB_LDS_MAX = 6 * 24576;
+// the ring of a launch: e4m3 activation images (stored jobs: 24-KB steps, gate jobs: 16-KB steps) or bf16 ones (32-KB steps)
+template <bool A8> constexpr int kb_lds_bytes() {
+  return A8 ? (KbGeo<false, true>::LDS > KbGeo<true, true>::LDS ? KbGeo<false, true>::LDS : KbGeo<true, true>::LDS) : KbGeo<false, false>::LDS;
+}
 
 __device__ __forceinline__ void kb_dma(const unsigned char* uniform_src, unsigned lane_off, unsigned lds_dst) {
   unsigned keep;
@@ -317,7 +324,7 @@ __device__ __forceinline__ void kb_run(unsigned char* lds, const KbJob& jb_, int
 
 template <bool A8, int ABL = 0>
 __global__ __launch_bounds__(KB_NT) void wgrad_blocked_kernel(KbArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[KB_LDS_MAX];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kb_lds_bytes<A8>()];
   // XCD-aware decode: consecutive ids round-robin over the 8 XCDs; the NB blocks of one unit (a job's row range) share an XCD,
   // and the njobs x Z units are dealt out over the XCDs evenly (unit u -> XCD u % 8; jobs interleaved)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
