@@ -429,12 +429,17 @@ __global__ __launch_bounds__(256) void conv3x3s2_fwd_mfma_dma_kernel(const float
 // wave.  Unit = (image, 4 rows a): the 5 x 32 dy values of all 24 channels arrive by LDS-DMA (a wave instruction moves eight
 // 128-byte rows); the column right of the image (lane b = 31, db = 1) is masked, the row below it zeroed by the requesting wave.
 // A lane writes its 2 x 2 input block as two 8-byte stores per channel (256 contiguous bytes per half-wave).
+// OW = dy columns (32 / 16 / 8: layers 2..4 at the headline shape): a wave's 32 lanes are RW = 32 / OW consecutive rows a; a unit is
+// RU rows of an image (4 RW, or the whole image when it has fewer: then only RU / RW waves compute).  RU + 1 dy rows per channel are
+// staged, packed at OW floats; the column right of the image and the row below it are masked in registers.
+template <int OW>
 __global__ __launch_bounds__(256) void conv3x3s2_bwd_data_mfma_dma_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                                          float* __restrict__ dx, int N, int OH, int units) {
-  constexpr int C = 24, HALF = 12, NK = 9 * HALF, OW = 32, W = 64, NROW = C * 5, NINST = NROW / 8;
+                                                                          float* __restrict__ dx, int N, int OH, int units, int RU) {
+  constexpr int C = 24, HALF = 12, NK = 9 * HALF, W = 2 * OW, RW = 32 / OW, LPR = OW / 4, RPI = 64 / LPR;
   typedef __attribute__((address_space(3))) unsigned char lds_u8_;
-  __shared__ __attribute__((aligned(16))) float ds[NROW * OW + 4];     // [co][5 rows][32] (+ one readable element behind the last row)
-  const int H = 2 * OH;
+  extern __shared__ __attribute__((aligned(16))) float bd_smem[];     // [co][RU + 1 rows][OW] (+ the last request's tail)
+  float* ds = bd_smem;
+  const int H = 2 * OH, RT = RU + 1, NROW = C * RT, NINST = (NROW + RPI - 1) / RPI;
   const int t = threadIdx.x, l = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), p = l & 31, h = l >> 5;
   float wr[NK];                                                       // w[co = cp + 12 h][ci = p][tap], index cp * 9 + tap
 #pragma unroll
@@ -443,71 +448,68 @@ __global__ __launch_bounds__(256) void conv3x3s2_bwd_data_mfma_dma_kernel(const 
     const float u = w[((long)(cp + HALF * h) * C + (p < C ? p : 0)) * 9 + tap];
     wr[kk] = p < C ? u : 0.f;
   }
-  const int lane_base = (HALF * h * 5 + wv) * OW + p;
+  const int pr = p / OW, pb = p - pr * OW;                            // this lane's pixel inside the wave's tile
+  const int arow = wv * RW + pr;                                      // its row a inside the unit
+  const int lane_base = (HALF * h * RT + arow) * OW + pb;
   const unsigned lds0 = (unsigned)(size_t)(lds_u8_*)ds;
-  const int rpi = OH / 4;
+  const int rpi = OH / RU;
+  const bool active = wv * RW < RU;
   typedef __attribute__((ext_vector_type(16))) float f32x16_;
   for (int u = blockIdx.x; u < units; u += gridDim.x) {
-    const int rb = u % rpi, n = u / rpi, a0 = 4 * rb;
+    const int rb = u % rpi, n = u / rpi, a0 = RU * rb;
     __syncthreads();
     const float* dn = dy + (long)n * C * OH * OW;
     asm volatile("" : "+s"(dn));
-#pragma unroll
-    for (int q = 0; q < (NINST + 3) / 4; ++q) {
-      const int inst = wv + 4 * q;
-      if (inst < NINST) {
-        const int R = 8 * inst + (l >> 3), co = R / 5, a = a0 + (R - co * 5);
-        const unsigned voff = (unsigned)((((co * OH + (a < OH ? a : OH - 1)) * OW) << 2) + ((l & 7) << 4));
-        const unsigned dst = lds0 + inst * 1024;
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(voff), "s"(dn), "s"(dst)
-                     : "memory");
-      }
+    for (int inst = wv; inst < NINST; inst += 4) {
+      int R = RPI * inst + l / LPR;
+      R = R < NROW ? R : NROW - 1;
+      const int co = R / RT, a = a0 + (R - co * RT);
+      const unsigned voff = (unsigned)((((co * OH + (a < OH ? a : OH - 1)) * OW) << 2) + ((l % LPR) << 4));
+      const unsigned dst = lds0 + inst * 1024;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(voff), "s"(dn), "s"(dst)
+                   : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (a0 + 4 >= OH) {                                               // the row below the image: zero (requested from the last row above)
-#pragma unroll
-      for (int q = 0; q < (NINST + 3) / 4; ++q) {
-        const int inst = wv + 4 * q, R = 8 * inst + (l >> 3);
-        if (inst < NINST && a0 + R % 5 >= OH) *reinterpret_cast<f32x4*>(ds + R * OW + (l & 7) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
     __syncthreads();
-    f32x16_ ee, eo, oe, oo;
+    if (active) {
+      f32x16_ ee, eo, oe, oo;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ee[i] = eo[i] = oe[i] = oo[i] = 0.f;
-    const float* db_ = ds + lane_base;
-    const bool edge = p == OW - 1;                                    // b + 1 is outside the image
+      for (int i = 0; i < 16; ++i) ee[i] = eo[i] = oe[i] = oo[i] = 0.f;
+      const float* db_ = ds + lane_base;
+      const int a = a0 + arow;
+      const bool edge = pb == OW - 1, bot = a + 1 >= OH;               // b + 1 / a + 1 outside the image
 #pragma unroll
-    for (int cp = 0; cp < HALF; ++cp) {
-      const float d00 = db_[(cp * 5) * OW], d10 = db_[(cp * 5 + 1) * OW];
-      float d01 = db_[(cp * 5) * OW + 1], d11 = db_[(cp * 5 + 1) * OW + 1];
-      d01 = edge ? 0.f : d01;
-      d11 = edge ? 0.f : d11;
-      const float* wc = wr + cp * 9;
-      ee = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[4], d00, ee, 0, 0, 0);
-      eo = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[3], d01, eo, 0, 0, 0);
-      oe = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[1], d10, oe, 0, 0, 0);
-      oo = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[0], d11, oo, 0, 0, 0);
-      eo = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[5], d00, eo, 0, 0, 0);
-      oe = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[7], d00, oe, 0, 0, 0);
-      oo = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[2], d10, oo, 0, 0, 0);
-      oo = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[6], d01, oo, 0, 0, 0);
-      oo = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[8], d00, oo, 0, 0, 0);
-    }
-    const int a = a0 + wv;
-    float* xo = dx + (((long)n * C) * H + 2 * a) * W + 2 * p;
+      for (int cp = 0; cp < HALF; ++cp) {
+        const float d00 = db_[(cp * RT) * OW];
+        float d10 = db_[(cp * RT + 1) * OW], d01 = db_[(cp * RT) * OW + 1], d11 = db_[(cp * RT + 1) * OW + 1];
+        d01 = edge ? 0.f : d01;
+        d10 = bot ? 0.f : d10;
+        d11 = (edge || bot) ? 0.f : d11;
+        const float* wc = wr + cp * 9;
+        ee = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[4], d00, ee, 0, 0, 0);
+        eo = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[3], d01, eo, 0, 0, 0);
+        oe = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[1], d10, oe, 0, 0, 0);
+        oo = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[0], d11, oo, 0, 0, 0);
+        eo = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[5], d00, eo, 0, 0, 0);
+        oe = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[7], d00, oe, 0, 0, 0);
+        oo = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[2], d10, oo, 0, 0, 0);
+        oo = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[6], d01, oo, 0, 0, 0);
+        oo = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[8], d00, oo, 0, 0, 0);
+      }
+      float* xo = dx + (((long)n * C) * H + 2 * a) * W + 2 * pb;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      float* xc = xo + (long)(8 * (i >> 2) + 4 * h + (i & 3)) * H * W;
-      // (the four values go through VGPRs explicitly: hipcc 7.2 otherwise forms the 8-byte store pairs inside the accumulator
-      // registers and stores element 0's pair for a whole group of four rows)
-      float v0 = ee[i], v1 = eo[i], v2 = oe[i], v3 = oo[i];
-      asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
-      *reinterpret_cast<u32x2*>(xc) = u32x2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)};
-      *reinterpret_cast<u32x2*>(xc + W) = u32x2{__builtin_bit_cast(unsigned, v2), __builtin_bit_cast(unsigned, v3)};
+      for (int i = 0; i < 12; ++i) {
+        float* xc = xo + (long)(8 * (i >> 2) + 4 * h + (i & 3)) * H * W;
+        // (the four values go through VGPRs explicitly: hipcc 7.2 otherwise forms the 8-byte store pairs inside the accumulator
+        // registers and stores element 0's pair for a whole group of four rows)
+        float v0 = ee[i], v1 = eo[i], v2 = oe[i], v3 = oo[i];
+        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+        *reinterpret_cast<u32x2*>(xc) = u32x2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)};
+        *reinterpret_cast<u32x2*>(xc + W) = u32x2{__builtin_bit_cast(unsigned, v2), __builtin_bit_cast(unsigned, v3)};
+      }
     }
   }
 }
@@ -582,9 +584,18 @@ extern "C" int rn_conv3x3s2_bwd_data(const float* dy, const float* w, float* dx,
   // scalar kernel and nothing on the 14 x 14 grid's layers: only this shape is taken)
   bool mfma = W == 64 && (H / 2) % 4 == 0 && px >= 32768 && (uintptr_t)dy % 16 == 0;
   if (const char* e = rn_diag_env("RN_CONV_DMA")) mfma = mfma && atoi(e) != 0;
-  if (mfma) {
-    const int units = N * (H / 2 / 4);
-    conv3x3s2_bwd_data_mfma_dma_kernel<<<units < 1024 ? units : 1024, 256, 0, (hipStream_t)stream>>>(dy, w, dx, N, H / 2, units);
+  // ... and the 16 x 16 / 8 x 8 gradients, 2 / 4 rows per wave: 8.4 / 7.3 us alone against the scalar kernels' 8.0 / 5.3, but +0.9 % on the
+  // step -- 128 / 64 workgroups leave the chip to the streams beside the conv backward (the same trade as the forward's last layer)
+  bool small = (W == 32 || W == 16) && H == W && N >= 16 && (uintptr_t)dy % 16 == 0;
+  if (const char* e = rn_diag_env("RN_BD_DMA_SMALL")) small = small && atoi(e) != 0;
+  if (mfma || small) {
+    const int OH = H / 2, OW = W / 2, RU = OH < 4 * (32 / OW) ? OH : 4 * (32 / OW);
+    const int units = N * (OH / RU), rpi = 256 / OW, nrow = 24 * (RU + 1);
+    const size_t shm = ((size_t)((nrow + rpi - 1) / rpi) * rpi * OW + 4) * sizeof(float);
+    const int grid = units < 1024 ? units : 1024;
+    if (OW == 32) conv3x3s2_bwd_data_mfma_dma_kernel<32><<<grid, 256, shm, (hipStream_t)stream>>>(dy, w, dx, N, OH, units, RU);
+    else if (OW == 16) conv3x3s2_bwd_data_mfma_dma_kernel<16><<<grid, 256, shm, (hipStream_t)stream>>>(dy, w, dx, N, OH, units, RU);
+    else conv3x3s2_bwd_data_mfma_dma_kernel<8><<<grid, 256, shm, (hipStream_t)stream>>>(dy, w, dx, N, OH, units, RU);
     RN_LAUNCH_CHECK("rn_conv3x3s2_bwd_data(mfma)");
     return 0;
   }
