@@ -1169,7 +1169,7 @@ def test_conv3x3s2_bwd_weight(H, N, Cin, Hh, Ww):
     assert rel(dw.cpu().numpy(), ref.cpu().numpy()) <= 2e-6
 
 
-@pytest.mark.parametrize("N,Cin,hw", [(64, 3, 128), (64, 24, 64), (3, 24, 16), (2, 3, 34), (32, 24, 72), (33, 24, 66), (32, 24, 112), (64, 24, 32), (64, 24, 16), (17, 24, 32), (16, 24, 16)])
+@pytest.mark.parametrize("N,Cin,hw", [(64, 3, 128), (64, 24, 64), (3, 24, 16), (2, 3, 34), (32, 24, 72), (33, 24, 66), (32, 24, 112), (64, 24, 32), (64, 24, 16), (17, 24, 32), (16, 24, 16), (17, 3, 128)])
 def test_conv3x3s2_direct(H, N, Cin, hw):
     """rn_conv.hip against torch's conv2d (MIOpen) and its input gradient: fp32, summation order only."""
     x = dev(formula.hash_uniform((N, Cin, hw, hw), 950, -1, 1))
