@@ -228,7 +228,7 @@ def pair_build_k1(H, B, n, k, Q, dev):
 
 
 def mode_rate(pkg, dp, hyp, prec, dev, img, qst, lab, B, steps=10):
-    """One more arithmetic mode: the same graph-replayed train step, timed over `steps` steps (host clock, synchronised)."""
+    """One more arithmetic mode: the same graph-replayed train step, timed over groups of `steps` steps (host clock, synchronised)."""
     torch.manual_seed(42)
     model = quiet_rn(pkg, dict(hyp, precision=prec))
     model.cuda(dev)
@@ -240,12 +240,15 @@ def mode_rate(pkg, dp, hyp, prec, dev, img, qst, lab, B, steps=10):
             tr.step(img, qst, lab)
     except RuntimeError as e:
         return {"unsupported": str(e)[:120]}
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        tr.step(img, qst, lab)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(3):                                   # three groups of `steps`, the median one (a one-off host stall in a 10-step
+        torch.cuda.synchronize()                         # window once read 10x slow)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step(img, qst, lab)
+        torch.cuda.synchronize()
+        dts.append(time.perf_counter() - t0)
+    dt = sorted(dts)[1]
     return {"value": B * steps / dt, "unit": "questions/s", "ms_per_step": 1e3 * dt / steps}
 
 
