@@ -943,6 +943,18 @@ __global__ __launch_bounds__(256) void pair_tables_kernel(const float* __restric
   __shared__ float xs[16][32];
   __shared__ float qs[1024];
   const int t = threadIdx.x, b = blockIdx.y, i0 = blockIdx.x * 16;
+  // headline shape (one feature per thread, Q = 128): the thread's 26 + 128 weights are requested BEFORE the object rows and the
+  // question are staged -- they depend on nothing staged, and behind the barrier they were a second round trip
+  const bool pre = N <= 256 && Q == 128;
+  float pwi[32], pwv[128], pb0 = 0.f;
+  if (pre) {
+    const int f = t < N ? t : 0;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) pwi[c] = c < k ? W0T[(long)(k + c) * N + f] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 128; ++u) pwv[u] = W0T[(long)(2 * k + u) * N + f];
+    pb0 = b0[f];
+  }
   for (int c = t; c < 16 * 32; c += 256) {
     const int r = c >> 5, cc = c & 31;
     float v = 0.f;
@@ -958,6 +970,22 @@ __global__ __launch_bounds__(256) void pair_tables_kernel(const float* __restric
 #pragma unroll
       for (int e = 0; e < 4; ++e) dst[e] = (TX)(c4 + e < 32 ? xs[r][c4 + e] : 0.f);
     }
+  }
+  if (pre) {
+    if (t < N) {
+      float cq = pb0;
+#pragma unroll
+      for (int u = 0; u < 128; ++u) cq = fmaf(pwv[u], qs[u], cq);
+#pragma unroll 4
+      for (int r = 0; r < 16; ++r) {
+        if (i0 + r >= n) break;
+        float v = cq;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) v = fmaf(pwi[c], xs[r][c], v);
+        Vc[((long)b * n + i0 + r) * N + t] = v;
+      }
+    }
+    return;
   }
   for (int f = t; f < N; f += 256) {
     // This kernel is a chain of L2 round trips on the critical path in front of the forward chain: the x_i weights and the first
