@@ -351,17 +351,32 @@ def main():
     if world > 1:
         # attribution (outside the timed region): K more steps with event brackets around the gradient all-reduce and the fused
         # 1/world + clip + Adam -- the only parts of a step that exist because of the other ranks
-        trainer.timing = []
-        for _ in range(args.steps):
-            trainer.step(img, qst, lab)
-        torch.cuda.synchronize()
-        ar = sorted(e[0].elapsed_time(e[1]) for e in trainer.timing)
-        op = sorted(e[1].elapsed_time(e[2]) for e in trainer.timing)
-        trainer.timing = None
-        comm = {"allreduce_us_per_step": 1e3 * ar[len(ar) // 2], "optimizer_us_per_step": 1e3 * op[len(op) // 2],
-                "allreduce_bytes": 4 * trainer.bucket.numel}
-        for k_ in ("allreduce_us_per_step", "optimizer_us_per_step"):      # the slowest rank's
-            comm[k_] = max_over_ranks(comm[k_], world, dev)
+        if getattr(trainer, "_opt_in_graph", False):
+            # the exchange is a node of the replayed graph (events cannot bracket it there): the same all-reduce on a scratch
+            # bucket of the same size, eagerly, back to back with a barrier in front -- its stand-alone cost
+            scratch = torch.zeros_like(trainer.bucket.flat)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+            dist.all_reduce(scratch)
+            sync()
+            for e0_, e1_ in ev:
+                e0_.record(); dist.all_reduce(scratch); e1_.record()
+            torch.cuda.synchronize()
+            ar = sorted(e0_.elapsed_time(e1_) for e0_, e1_ in ev)
+            comm = {"allreduce_us_per_step": 1e3 * ar[len(ar) // 2], "optimizer_us_per_step": None, "allreduce_bytes": 4 * trainer.bucket.numel,
+                    "exchange": "inside the replayed step graph (all-reduce + 1/world + clip + Adam); the figure is the same collective launched alone"}
+            comm["allreduce_us_per_step"] = max_over_ranks(comm["allreduce_us_per_step"], world, dev)
+        else:
+            trainer.timing = []
+            for _ in range(args.steps):
+                trainer.step(img, qst, lab)
+            torch.cuda.synchronize()
+            ar = sorted(e[0].elapsed_time(e[1]) for e in trainer.timing)
+            op = sorted(e[1].elapsed_time(e[2]) for e in trainer.timing)
+            trainer.timing = None
+            comm = {"allreduce_us_per_step": 1e3 * ar[len(ar) // 2], "optimizer_us_per_step": 1e3 * op[len(op) // 2],
+                    "allreduce_bytes": 4 * trainer.bucket.numel, "exchange": "eager, behind the replayed fwd + bwd graph"}
+            for k_ in ("allreduce_us_per_step", "optimizer_us_per_step"):      # the slowest rank's
+                comm[k_] = max_over_ranks(comm[k_], world, dev)
     ksum_step = ksum = None
     if not args.no_kernel_timing:
         # HIP events cannot bracket kernels inside a graph replay: the same K steps are repeated eagerly (same kernels, same
@@ -412,6 +427,7 @@ def main():
                                                    if prec in ("bf16", "f16s") and pkg.options.OPT.h8 else "as the mode's storage type"),
                        "options_non_default": pkg.options.OPT.non_default(),
                        "launch": ("eager" if not use_graph else
+                                  "one hipGraph replay per step: fwd + bwd + all-reduce + clip + Adam" if (getattr(trainer, "_opt_in_graph", False) and world > 1) else
                                   "one hipGraph replay per step: fwd + bwd + clip + Adam" if getattr(trainer, "_opt_in_graph", False) else
                                   "hipGraph replay of fwd+bwd, eager all-reduce/clip/Adam")},
             "loss": float(loss.detach()),

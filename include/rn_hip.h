@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RN_ABI_VERSION 3   /* bumped whenever a signature or a buffer layout of this header changes */
+#define RN_ABI_VERSION 4   /* bumped whenever a signature or a buffer layout of this header changes */
 
 enum { RN_BF16 = 0, RN_F32 = 1, RN_F16 = 2, RN_FP8 = 3 };   /* RN_F16: pair matrix / split weights of the f16s forward only;
                                                              * RN_FP8: OCP e4m3 copies of the stored activations (h_dtype / a_dtype) */
@@ -151,6 +151,22 @@ int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, con
  * value dividing M). */
 int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M,
                       int rows_per_question, int L, int G, void* stream);
+/* The same chain with the pair-axis reductions of the expansion backward (model.py:117-127) formed ON CHIP: the gradient of layer
+ * 0's pre-activation (dZ[3] above: 134 MB at B = 64, n = 64) is neither written nor read back -- its only readers are
+ *   Rj[b,j,:] = sum_i dZ_0[(b,i,j),:]   and   Ri[b,i,:] = sum_j dZ_0[(b,i,j),:]
+ * and the kernel leaves fp32 PARTIALS of both, summed from the un-rounded accumulators in a fixed order (bitwise reproducible):
+ *   rj_part (M / 256 / tiles_per_unit, 32, 256): unit u = ((b * n/32 + jg) * nu + v), nu = (n / 8) / tiles_per_unit, holds the sum
+ *            over the i of its tiles_per_unit tiles (8 consecutive i each) for the 32 objects j of block jg;
+ *   ri_part (M / 16, 256): rows ((b*n + i) * n/32 + jg) * 2 + {0, 1} = the sums over the two 16-object halves of block jg.
+ * rn_pair_reduce_parts adds them up to Rj, Ri (B*n, 256) and Rq (B, 256) -- what rn_pair_reduce_bwd produces from a stored dZ_0.
+ * Needs n % 32 == 0 (no padded j axis), the masks of a forward call with the same M, dZ[0] == NULL (the gate job of
+ * rn_g_wgrad_blocked stands in for it) and dZ[1], dZ[2] as above; dZ[3] is ignored.  tiles_per_unit: any divisor of n / 8 --
+ * rn_g_chain_bwd_rr_red_tpu(M, n) returns the largest power of two that still gives every CU a unit (0: shape not supported). */
+int rn_g_chain_bwd_rr_red_tpu(int M, int n);
+int rn_g_chain_bwd_rr_red(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M, int n, int L, int G,
+                          float* rj_part, float* ri_part, int tiles_per_unit, void* stream);
+int rn_pair_reduce_parts(const float* rj_part, const float* ri_part, float* Rj, float* Ri, float* Rq, int B, int n, int G, int nu,
+                         void* stream);
 /* MFMA-fragment-major weight image for rn_g_chain_fwd_rr: dst (65536 bf16) gets, for output block ob,
  * K16 step ks, lane, element e:  src[32 ob + lane % 32][kidx] (0 beyond R rows / C columns) with
  *   natural != 0:  kidx = 16 ks + 8 (lane / 32) + e

@@ -108,11 +108,11 @@ struct RRCore {
   // from then on turns EVERY vmcnt / lgkmcnt wait into a full drain (0) while one is pending.  An asm statement
   // is invisible to its bookkeeping; its own counted waits only get a little stricter.  M0 is the compiler's:
   // saved and restored.
-  __device__ __forceinline__ void dma_piece(const bf16* Wl, int ob2, int slot, int i) const {
+  __device__ __forceinline__ void dma_piece(const bf16* Wl, int ob2, int slot, int i, int ring_off = RR_OFF_RING) const {
     unsigned z = 0;
     asm volatile("" : "+s"(z));                        // opaque 0: the base is computed AT the use (SALU), not hoisted and spilled
     const unsigned char* ub = reinterpret_cast<const unsigned char*>(Wl) + (z + ob2 * RR_STAGE + (RR_DPW * w + i) * 1024);
-    const unsigned dst = (unsigned)(size_t)(lds_u8*)lds + (z + RR_OFF_RING + slot * RR_STAGE + (RR_DPW * w + i) * 1024);
+    const unsigned dst = (unsigned)(size_t)(lds_u8*)lds + (z + ring_off + slot * RR_STAGE + (RR_DPW * w + i) * 1024);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
@@ -132,8 +132,8 @@ struct RRCore {
                  : "memory");
   }
   __device__ __forceinline__ Frag rd_at(int abs) const { return *reinterpret_cast<lds_frag*>(rbase[abs >> 16] + (abs & 0xffff)); }
-  __device__ __forceinline__ Frag rd_frag(int slot, int ks) const {
-    const int abs = RR_OFF_RING + slot * RR_STAGE + ks * 1024, r = abs >> 16;
+  __device__ __forceinline__ Frag rd_frag(int slot, int ks, int ring_off = RR_OFF_RING) const {
+    const int abs = ring_off + slot * RR_STAGE + ks * 1024, r = abs >> 16;
     return *reinterpret_cast<lds_frag*>(rbase[r] + (abs & 0xffff));
   }
 };
@@ -314,12 +314,19 @@ struct FwdVm {
     return k < 63 ? k : 63;
   }
 };
-template <bool SKIP0>
+template <bool SKIP0, bool RED = false>
 struct BwdVm {
-  static constexpr int ops(int sidx) { return RR_DPW + (sidx >= 2 ? 2 : 0); }
+  // RED (pair reductions inside the kernel): a 6-slot ring -- the two slots it gives up are one exchange buffer
+  static constexpr int NSLOT = RED ? 6 : RR_NSLOT, LA = NSLOT - 1, YS = LA - 2;   // YS: whole stages younger than the awaited weights
+  static constexpr int ops(int sidx) {
+    int k = RR_DPW + ((sidx >= 2 && (!RED || sidx < 18)) ? 2 : 0);    // weight requests + the two copy-out stores (RED: dZ of layer 0 is not stored)
+    if (RED && sidx >= 12 && sidx < 20) k += 1;                       // the gate dword of layer-0 block sidx - 12
+    if (RED && sidx >= 17) k += 1;                                    // the Ri partial of block sidx - 17
+    return k;
+  }
   static constexpr int younger(int sidx) {                            // the tile prologue (56 operations; 40 without the dZ[0] copy) is younger too
-    int k = sidx < 5 ? (SKIP0 ? 32 : 40) : 0;
-    for (int t = sidx - 5 > 0 ? sidx - 5 : 0; t < sidx; ++t) k += ops(t);
+    int k = sidx < YS ? (SKIP0 ? 32 : 40) : 0;
+    for (int t = sidx - YS > 0 ? sidx - YS : 0; t < sidx; ++t) k += ops(t);
     return k < 63 ? k : 63;
   }
 };
@@ -1111,43 +1118,93 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
 // SKIP0: dZ[0] (the last layer's gradient) is not copied to HBM -- the gate job of rn_g_wgrad_blocked works from the masks and
 // dxg instead, its only consumer besides this kernel's own first step.
 // ABL (RN_DIAG builds only): timing ablations with wrong results.
+// RED: the gradient of layer 0's pre-activation never leaves the chip -- its only readers are the pair-axis reductions of the
+//   expansion backward (Rj = sum over i, Ri = sum over j), and those are formed here, in fp32, from the un-rounded accumulators:
+//   * a tile is 8 waves = 8 consecutive i of ONE (question, block of 32 j): wave-tile (b, i, jg) = forward wave (b*n + i) * (n/32) + jg;
+//   * the last dgrad step runs with the MFMA operands UN-swapped (D[row][feature], like the forward's last layer): a lane then owns
+//     one feature of 16 rows (= 16 j), so Ri is an in-lane sum (two partial rows per wave-tile -- one per lane half -- go to ri_part);
+//   * the ReLU gate of layer 0 is stored as lane masks of the SWAPPED layout (lane = row): for the un-swapped layout the dword
+//     that holds a feature's 32 row bits is fetched per lane (a coalesced 128-byte read per wave and block, issued two dgrad
+//     steps ahead) and tested bit by bit -- two VALU operations per value instead of one v_cndmask on an SGPR mask;
+//   * Rj needs the sum over the tile's 8 waves: every wave writes its gated fp32 block into a double-buffered LDS exchange area,
+//     and after the next stage's barrier wave w adds up the eighth it OWNS (accumulator group w / 2, register pair w % 2) over
+//     the 8 waves in wave order -- two accumulators per block, carried in registers over the tiles_per_unit consecutive tiles of
+//     a unit (same question and j block, consecutive i) and written once per unit to rj_part.  Every sum has a fixed order:
+//     results are bitwise reproducible.
+//   LDS: the weight ring shrinks to 6 slots (5 stages ahead: 5 us of cover for an L2 fetch) and moves up by two; exchange buffer 0
+//   takes the two slots' place, buffer 1 the bias / staging area, which the copy-outs of layers 2 and 1 have left two barriers before its
+//   first use (and which the next tile touches two barriers after its last).
 // (Round 2 also had the pair reduction of the LAST gradient, dZ of layer 0, inside this kernel -- every block through LDS in
-// fp32, added over the tile's four i and each wave's 32 j: 268 MB less HBM traffic, but the exchange made the last step
-// LDS-bound (+24 us here for -40 us in rn_pair_reduce_bwd) and the step gained 1 %: removed in round 3.)
-template <int ABL, bool SKIP0 = false>
-__global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int ntiles) {
+// fp32 in the swapped layout, added over the tile's four i and each wave's 32 j: the exchange made the last step LDS-bound
+// (+24 us here for -40 us in rn_pair_reduce_bwd) and the step gained 1 %: removed in round 3.)
+namespace {
+constexpr int RR_XBUF_BYTES = RR_NW * 4 * 2 * 512;                    // [wave][accumulator group][register pair][lane] x 8 bytes = 32 KB
+constexpr int RR_OFF_XB1 = 0, RR_OFF_XB0 = RR_OFF_RING, RR_OFF_RING_RED = RR_OFF_XB0 + RR_XBUF_BYTES;   // (both buffers below 64 KB: one address register + immediates)
+static_assert(RR_OFF_XB1 + RR_XBUF_BYTES <= RR_OFF_RING && RR_OFF_RING_RED + 6 * RR_STAGE <= RR_LDS, "exchange buffers + 6-slot ring");
+struct RRRedArgs {
+  float* rj_part;                                                     // (units, 32, 256) fp32
+  float* ri_part;                                                     // (M / 16, 256) fp32: row ((b*n + i) * (n/32) + jg) * 2 + lane half
+  int n_obj, tiles_per_unit;
+};
+}  // namespace
+template <int ABL, bool SKIP0 = false, bool RED = false>
+__global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int ntiles, RRRedArgs ra = RRRedArgs{nullptr, nullptr, 0, 1}) {
+  static_assert(!RED || (SKIP0 && ABL == 0), "in-kernel pair reductions: the product variant without a stored dZ[0]");
+  typedef BwdVm<SKIP0, RED> Vm;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
   k.init(lds);
   const int lane = k.lane, w = k.w, n = k.n, h = k.h;
   unsigned char* const stg = lds + RR_OFF_STG + w * RR_STG;
   constexpr int NS = RR_L - 1;                                        // dgrad steps
+  constexpr int NSL = Vm::NSLOT, LA = Vm::LA, RING = RED ? RR_OFF_RING_RED : RR_OFF_RING;
 
   Frag actA[16], actB[16], ring[RR_RD];
   f32x16 acc[2];
   u32x4 co[2];
   u32x16 gA[2], gB[2];                                               // two sets of 16 lane masks (SGPRs)
+  // RED state: the lane's gate dwords of layer 0 (one per block), this wave's share of the Rj sums, the exchange reads in flight
+  unsigned gdw[8];
+  float racc[8][2];
+  f32x2 xv[4];
+  float rs = 0.f;
 
-  int tile = blockIdx.x;
-  if (tile >= ntiles) return;
+  const int nunits = RED ? ntiles / ra.tiles_per_unit : ntiles;       // (non-RED: a unit is a tile)
+  int unit = blockIdx.x;
+  if (unit >= nunits) return;
   // Two waves share each SIMD; the hardware arbitrates their issue slots by priority, then age, and the second-dispatched
   // half loses every stage head.  One static s_setprio for that half evens the pair out (MI355X_MICROARCH.md, "Two waves
   // per SIMD", item 4).  RN_RR_PRIO=0 turns it off.
   if (a.prio && k.w >= RR_NW / 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-  for (int s = 0; s < RR_LA; ++s)
+  for (int s = 0; s < LA; ++s)
 #pragma unroll
-    for (int i = 0; i < RR_DPW; ++i) k.dma_piece(a.W, s, s, i);
+    for (int i = 0; i < RR_DPW; ++i) k.dma_piece(a.W, s, s, i, RING);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < RR_RD; ++r) ring[r] = k.rd_frag(0, r);
+  for (int r = 0; r < RR_RD; ++r) ring[r] = k.rd_frag(0, r, RING);
   // dword of a block's (un-swapped, last-layer) mask image that holds row n: mask i = 4 (n / 8) + n % 4, half (n / 4) % 2
   const int rowsel = 2 * (4 * (n >> 3) + (n & 3)) + ((n >> 2) & 1);
+  // RED: the same dword index, read the other way -- in a SWAPPED layer's mask image it holds the 32 row bits of feature n
+  const int jgs = RED ? ra.n_obj / RR_WR : 1, tpbj = RED ? ra.n_obj / RR_NW : 1;
+  unsigned char* const xwb = lds + (w * 8) * 512 + lane * 8;          // this wave's slice of an exchange buffer
+  const unsigned char* const xrb = lds + w * 512 + lane * 8;          // ... and the piece it owns of every wave's slice
 
-  for (; tile < ntiles; tile += gridDim.x) {
-    const long m0w = (long)tile * RR_TM + RR_WR * w;
-    const long wt = (long)tile * RR_NW + w;
+  for (; unit < nunits; unit += gridDim.x) {
+   if constexpr (RED) {
+#pragma unroll
+     for (int ob = 0; ob < 8; ++ob) racc[ob][0] = racc[ob][1] = 0.f;
+   }
+   for (int tu = 0; tu < (RED ? ra.tiles_per_unit : 1); ++tu) {
+    const int tile = RED ? unit * ra.tiles_per_unit + tu : unit;
+    // wave-tile of this wave = index of the forward wave whose 32 pair rows it takes over
+    long wt = (long)tile * RR_NW + w;
+    if constexpr (RED) {
+      const int bj = tile / tpbj, ig = tile - bj * tpbj, bq = bj / jgs, jg = bj - bq * jgs;
+      wt = ((long)bq * ra.n_obj + ig * RR_NW + w) * jgs + jg;
+    }
+    const long m0w = wt * RR_WR;
     const long b = (m0w + n) / a.rows_per_b;                          // question of THIS lane's pair row (a wave may straddle two)
     // zi < NS: dZ of layers 3..1 -- read only by the weight gradient: row-blocked image (transposing read-back); zi == NS: dZ of
     // layer 0, read by the pair reduction: row-major
@@ -1172,6 +1229,39 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
       // weight images that every workgroup re-reads for every tile (measured: 222 -> 150 us)
       if (ABL & 64) *reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2) = co[q];
       else __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2));
+    };
+    // ---- RED: epilogue of block pob of the LAST step (accumulator D[row 8 j + 4 h + r][feature 32 pob + n]), group j, phase ph
+    unsigned rb = 0;
+    float gx[4];
+    auto red_epi = [&](int pob, int j, int ph) {
+      const f32x16& c = acc[pob & 1];
+      if (ph == 0) {
+        if (j == 0) rb = gdw[pob] >> (4 * h);                         // bit 8 j + r = gate of row 8 j + 4 h + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // (the element is copied out first: __builtin_bit_cast straight on `c[i]` reads element 0 with hipcc 7.2; and the
+          //  0 / -1 word is made opaque, else the pair v_bfe_i32 + v_and becomes v_and + v_cmp + s_nop + v_cndmask)
+          const float v = c[4 * j + r];
+          unsigned t = (unsigned)__builtin_amdgcn_sbfe((int)rb, 8 * j + r, 1);
+          asm("" : "+v"(t));
+          gx[r] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & t);
+        }
+      } else if (ph == 1) {
+        const float s4 = (gx[0] + gx[1]) + (gx[2] + gx[3]);
+        rs = j == 0 ? s4 : rs + s4;
+      } else {
+        unsigned char* xw = xwb + ((pob & 1) ? RR_OFF_XB1 : RR_OFF_XB0);
+        *reinterpret_cast<f32x2*>(xw + (2 * j) * 512) = f32x2{gx[0], gx[1]};
+        *reinterpret_cast<f32x2*>(xw + (2 * j + 1) * 512) = f32x2{gx[2], gx[3]};
+        if (j == 3) {
+          // Ri partials of this wave-tile: the two lane halves hold rows 8 j + 4 h + {0..3} of the same feature and leave one
+          // partial row EACH (a full-wave 256-byte store; v_permlane32_swap on two copies of one value is mis-compiled by hipcc 7.2)
+          ra.ri_part[(wt * 2 + h) * RR_G + 32 * pob + n] = rs;
+        }
+      }
+    };
+    auto x_read = [&](int blk, int src) {
+      xv[src & 3] = *reinterpret_cast<const f32x2*>(xrb + ((blk & 1) ? RR_OFF_XB1 : RR_OFF_XB0) + src * (8 * 512));
     };
     // ---- prologue: dZ[0] in operand layout (natural feature order) + its copy to HBM
     if (ABL & 1) {
@@ -1212,25 +1302,35 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
       constexpr bool has_prev = sidx > 0;
       constexpr int ps = ob ? s : s - 1, pob = ob ? ob - 1 : 7;       // block whose epilogue runs here
       constexpr int cs = (sidx - 2) >> 3, cob = (sidx - 2) & 7;       // block copied out here
-      constexpr bool has_co = sidx >= 2;
-      constexpr int didx = sidx + RR_LA;
+      constexpr bool has_co = sidx >= 2 && !(RED && cs == NS - 1);    // (RED: the last step's blocks leave through the exchange)
+      constexpr bool has_x = RED && sidx >= 2 && cs == NS - 1;        // the exchange of block cob is complete behind this stage's barrier
+      constexpr int didx = sidx + LA;
       constexpr int dl = (didx >> 3) % NS, dob = didx & 7;
-      constexpr int nob = (sidx + 1) & 7;
+      constexpr int slot = sidx % NSL, nslot = (sidx + 1) % NSL, dslot = didx % NSL;
+      constexpr bool un_swapped = RED && s == NS - 1;
+      constexpr bool gate_this = !(RED && s == NS - 1), gate_prev = has_prev && !(RED && ps == NS - 1);   // gates that come as SGPR lane masks
       // gate of THIS block (layer 2 - s): requested now, used by the epilogue that runs in the next stage; the
       // gate of the previous block, requested one stage ago, must have arrived
       u32x16(&gn)[2] = (sidx & 1) ? gB : gA;
       u32x16(&gp)[2] = (sidx & 1) ? gA : gB;
-      if (has_prev && !(ABL & 2)) mask_wait(gp[0], gp[1]);
-      if (!(ABL & 2)) mask_load(a.mask + (NS - 1 - s) * a.mask_stride + (wt * 8 + ob) * 16, gn[0], gn[1]);
+      if (gate_prev && !(ABL & 2)) mask_wait(gp[0], gp[1]);
+      if (gate_this && !(ABL & 2)) mask_load(a.mask + (NS - 1 - s) * a.mask_stride + (wt * 8 + ob) * 16, gn[0], gn[1]);
+      // (the exchange buffers are read by OTHER waves behind this barrier: the writes must have left the LDS queue)
+      if constexpr (has_x) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (ABL & 16) {                                                 // timing only: 16 more operations may stay in flight (a race)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BwdVm<SKIP0>::younger(sidx) + 16 < 63 ? BwdVm<SKIP0>::younger(sidx) + 16 : 63) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Vm::younger(sidx) + 16 < 63 ? Vm::younger(sidx) + 16 : 63) : "memory");
         __builtin_amdgcn_s_barrier();
       } else if (!(ABL & 8)) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BwdVm<SKIP0>::younger(sidx)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Vm::younger(sidx)) : "memory");
         __builtin_amdgcn_s_barrier();
       }
       asm volatile("" ::: "memory");
       if (has_co) co_read(cs + 1);
+      if constexpr (has_x) {
+#pragma unroll
+        for (int src = 0; src < 4; ++src) x_read(cob, src);
+      }
+      if constexpr (RED && sidx >= 12 && sidx < 20) gdw[sidx - 12] = reinterpret_cast<const unsigned*>(a.mask)[(wt * 8 + sidx - 12) * 32 + rowsel];
       __builtin_amdgcn_sched_barrier(0);
       Frag* dst = nullptr;
       if (has_prev && ps < NS - 1) dst = ob ? out : in;
@@ -1239,7 +1339,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         const int c = ks;
-        const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[ks % RR_RD]), fb = __builtin_bit_cast(bf16x8, in[ks]);
+        const bf16x8 fw = __builtin_bit_cast(bf16x8, ring[ks % RR_RD]), fx = __builtin_bit_cast(bf16x8, in[ks]);
+        const bf16x8 fa = un_swapped ? fx : fw, fb = un_swapped ? fw : fx;
         if (ks == 0) {
           const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           acc[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, z, 0, 0, 0);
@@ -1248,13 +1349,15 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
         }
         {
           const int f = ks + RR_RD;
-          if (f < 16) ring[ks % RR_RD] = k.rd_frag(ob, f);
-          else ring[ks % RR_RD] = k.rd_frag(nob, f - 16);
+          if (f < 16) ring[ks % RR_RD] = k.rd_frag(slot, f, RING);
+          else ring[ks % RR_RD] = k.rd_frag(nslot, f - 16, RING);
         }
-        if ((c & 1) && (c >> 1) < RR_DPW) k.dma_piece(a.W + dl * a.w_stride, dob, dob, c >> 1);
+        if ((c & 1) && (c >> 1) < RR_DPW) k.dma_piece(a.W + dl * a.w_stride, dob, dslot, c >> 1, RING);
         if (has_prev && c >= 2 && c < 14) {                           // epilogue of the previous block, 3 gaps per group
           const int j = (c - 2) / 3, ph = (c - 2) % 3;
-          if (ph == 0) {
+          if constexpr (RED && ps == NS - 1) {
+            red_epi(pob, j, ph);
+          } else if (ph == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[j][r] = ((ABL & 2) || gate_bit(gp[0], gp[1], 4 * j + r)) ? acc[pob & 1][4 * j + r] : 0.f;
           } else if (ph == 1) {
@@ -1272,14 +1375,46 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
         if (has_co && (c == 4 || c == 8)) {
           co_store(cs + 1, cob, (c >> 2) - 1);
         }
+        if constexpr (has_x) {                                        // this wave's share of the Rj sums, the 8 waves in wave order
+          if (c >= 4 && c < 12) {
+            racc[cob][0] += xv[(c - 4) & 3][0];
+            racc[cob][1] += xv[(c - 4) & 3][1];
+            if (c < 8) x_read(cob, c);                                // (sources 4..7 take the registers of 0..3 as those are added)
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
     RN_LAYER(0, actA, actB);
     RN_LAYER(1, actB, actA);
     RN_LAYER(2, actA, actB);
+    if constexpr (RED) {
+      // ---- tail: block (2, 7)'s epilogue; then the exchanges of blocks (2, 6) [written during the last stage] and (2, 7).
+      // Buffer 1 still holds block 5, read at the top of the last stage: nobody may overwrite it before everybody is here.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) red_epi(7, j, ph);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int blk = 6; blk < 8; ++blk)
+#pragma unroll
+        for (int s4 = 0; s4 < RR_NW; s4 += 4) {
+#pragma unroll
+          for (int src = s4; src < s4 + 4; ++src) x_read(blk, src);
+#pragma unroll
+          for (int src = s4; src < s4 + 4; ++src) {
+            racc[blk][0] += xv[src & 3][0];
+            racc[blk][1] += xv[src & 3][1];
+          }
+        }
+    } else {
     // ---- tail: blocks (2, 6) and (2, 7)
-    {
       co_read(NS);
 #pragma unroll
       for (int q = 0; q < 2; ++q) co_store(NS, 6, q);
@@ -1300,6 +1435,16 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
 #pragma unroll
       for (int q = 0; q < 2; ++q) co_store(NS, 7, q);
     }
+   }
+   if constexpr (RED) {
+     // the unit's Rj partial: this wave owns accumulator group w / 2, register pair w % 2 -> rows 8 (w / 2) + 4 h + 2 (w % 2) + e
+     float* dst = ra.rj_part + ((long)unit * RR_WR + 8 * (w >> 1) + 4 * h + 2 * (w & 1)) * RR_G + n;
+#pragma unroll
+     for (int ob = 0; ob < 8; ++ob) {
+       dst[32 * ob] = racc[ob][0];
+       dst[RR_G + 32 * ob] = racc[ob][1];
+     }
+   }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1608,5 +1753,51 @@ extern "C" int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, cons
   g_chain_rr_bwd_kernel<0><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles);
 #endif
   RN_LAUNCH_CHECK("rn_g_chain_bwd_rr");
+  return 0;
+}
+
+// The backward chain with the pair-axis reductions of layer 0's gradient formed on chip (g_chain_rr_bwd_kernel, RED).
+extern "C" int rn_g_chain_bwd_rr_red_tpu(int M, int n) {
+  if (M <= 0 || n <= 0 || n % RR_WR != 0 || n % RR_NW != 0 || M % ((long)n * n) != 0 || M % RR_TM != 0) return 0;
+  const int ntiles = M / RR_TM, tpbj = n / RR_NW;                     // tiles per (question, block of 32 j)
+  int tpu = 1;
+  while (tpu * 2 <= tpbj && tpbj % (tpu * 2) == 0 && ntiles / (tpu * 2) >= rr_num_cus()) tpu *= 2;
+  return tpu;
+}
+
+extern "C" int rn_g_chain_bwd_rr_red(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M, int n,
+                                     int L, int G, float* rj_part, float* ri_part, int tiles_per_unit, void* stream) {
+  RN_CHECK_ARG(dxg && mask && Wtf && dZ && rj_part && ri_part && M > 0, "rn_g_chain_bwd_rr_red: bad pointer/size");
+  RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_bwd_rr_red: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
+  RN_CHECK_ARG(rn_g_chain_bwd_rr_red_tpu(M, n) > 0, "rn_g_chain_bwd_rr_red: needs n %% 32 == 0 and M a multiple of n*n (M=%d n=%d)", M, n);
+  const int ntiles = M / RR_TM, tpbj = n / RR_NW;
+  RN_CHECK_ARG(tiles_per_unit > 0 && tpbj % tiles_per_unit == 0, "rn_g_chain_bwd_rr_red: tiles_per_unit=%d must divide n / 8 = %d", tiles_per_unit, tpbj);
+  RRBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.prio = rr_prio();
+  RN_CHECK_ARG(dZ[0] == nullptr && dZ[1] && dZ[2], "rn_g_chain_bwd_rr_red: dZ[0] must be NULL (gate job), dZ[1], dZ[2] the stored images; dZ[3] is not written");
+  for (int l = 0; l < RR_L; ++l) {
+    RN_CHECK_ARG(mask[l] && (l == RR_L - 1 || Wtf[l]), "rn_g_chain_bwd_rr_red: entry %d has a NULL pointer", l);
+    RN_CHECK_ARG(((uintptr_t)mask[l] | (uintptr_t)(l == 1 || l == 2 ? dZ[l] : nullptr) | (uintptr_t)(l < RR_L - 1 ? Wtf[l] : nullptr)) % 16 == 0,
+                 "rn_g_chain_bwd_rr_red: entry %d pointers must be 16-byte aligned", l);
+  }
+  a.mask = (const u64*)mask[0];
+  a.dz_stride = (bf16*)dZ[2] - (bf16*)dZ[1];
+  a.dZ = (bf16*)dZ[1] - a.dz_stride;
+  a.W = (const bf16*)Wtf[0];
+  a.mask_stride = (const u64*)mask[1] - (const u64*)mask[0];
+  a.w_stride = (const bf16*)Wtf[1] - (const bf16*)Wtf[0];
+  for (int l = 0; l < RR_L; ++l) {
+    RN_CHECK_ARG((const u64*)mask[l] == a.mask + l * a.mask_stride && (l == RR_L - 1 || (const bf16*)Wtf[l] == a.W + l * a.w_stride),
+                 "rn_g_chain_bwd_rr_red: mask / Wtf buffers must be equally spaced (slices of one allocation each)");
+  }
+  RN_CHECK_ARG(((uintptr_t)dxg | (uintptr_t)rj_part | (uintptr_t)ri_part) % 16 == 0, "rn_g_chain_bwd_rr_red: dxg / partials must be 16-byte aligned");
+  a.dxg = dxg;
+  a.rows_per_b = n * n;
+  RRRedArgs ra{rj_part, ri_part, n, tiles_per_unit};
+  const int nunits = ntiles / tiles_per_unit;
+  const int grid = nunits < rr_num_cus() ? nunits : rr_num_cus();
+  g_chain_rr_bwd_kernel<0, true, true><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles, ra);
+  RN_LAUNCH_CHECK("rn_g_chain_bwd_rr_red");
   return 0;
 }

@@ -380,7 +380,10 @@ int kb_splits(int M, int rows_per_question, int njobs, int aligned) {
   // latency-bound kernels that close the backward pass (pair reduction, dx / dq, the conv stack's backward); with a workgroup
   // on every CU (64 splits) those kernels wait for CU slots and stretch 3-5x -- measured on the whole step, same box: 64 ->
   // 0.983 ms, 54 -> 0.955, 48 -> 0.931, 42 -> 0.944, 36 -> 0.976 (the kernel alone is fastest at 64).
-  int total = 48;
+#ifndef RN_KB_TOTAL
+#define RN_KB_TOTAL 48
+#endif
+  int total = RN_KB_TOTAL;
   if (const char* e = rn_diag_env("RN_KB_TOTAL")) total = atoi(e) > 0 ? atoi(e) : total;      // (diagnostics builds)
   const int target = total / njobs > 0 ? total / njobs : 1;
   const int Zd = S >= target ? target : S;

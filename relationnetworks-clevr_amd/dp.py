@@ -44,13 +44,15 @@ class FlatGradBucket:
         for p in self.params:
             if p.dtype != torch.float32:
                 raise TypeError("FlatGradBucket expects fp32 master parameters")
-            offs.append(total)
+            total = (total + 3) // 4 * 4                  # every slot starts on 16 bytes: backward kernels write dW / db straight
+            offs.append(total)                            # into the views with vector stores (the pad floats stay zero)
             total += p.numel()
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.numel = total
         self.offsets = offs
         self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, offs)]
         self._zeros = {}
+        self._known_zero = set()                          # slots of parameters without a gradient that are already zero
         RF.register_grad_slots(self.params, self.flat, offs)     # backward kernels may then write gradients in place (gather mode)
         self.attach_()
 
@@ -81,19 +83,29 @@ class FlatGradBucket:
                     if g is None:
                         g = self._zeros[p.numel()] = torch.zeros(p.numel(), dtype=torch.float32, device=self.flat.device)
                 parts.append(g.reshape(-1))
-            torch.cat(parts, out=self.flat)
+            if self.numel == sum(p.numel() for p in self.params):
+                torch.cat(parts, out=self.flat)
+            else:                                           # (padded slots: no single concatenation)
+                for (p, o, _g), part in zip(stray, parts):
+                    self.flat[o:o + p.numel()].copy_(part)
+            self._known_zero.clear()
         else:
+            # nothing but this method writes the slot of a parameter that has no gradient (the optimiser reads it): zeroed
+            # once, it stays zero -- no fill launch per unused parameter and step (the 16 conv / BN tensors of the *-sd models)
             for p, o, g in stray:
-                slot = self.flat[o:o + p.numel()]
                 if g is None:
-                    slot.zero_()
+                    if o not in self._known_zero:
+                        self.flat[o:o + p.numel()].zero_()
+                        self._known_zero.add(o)
                 else:
-                    slot.copy_(g.reshape(-1))
+                    self._known_zero.discard(o)
+                    self.flat[o:o + p.numel()].copy_(g.reshape(-1))
         self.attach_()
 
     def zero_(self):
         """Accumulate mode: replaces optimizer.zero_grad(): one memset, the .grad views stay attached."""
         self.flat.zero_()
+        self._known_zero.clear()
 
     def check_attached(self):
         for p in self.params:
@@ -139,19 +151,17 @@ class FusedClipAdam:
 
     def __init__(self, bucket: "FlatGradBucket", optimizer):
         import numpy as np
-        from . import rn_hip as H
+        H = RF.H                                           # (the binding `functional` imported: works under the flat import too)
         self.H, self.bucket, self.opt = H, bucket, optimizer
         dev = bucket.flat.device
         ch = H.load().rn_clip_adam_chunk()
         rec = []
-        off = 0
-        for p in bucket.params:
+        for p, off in zip(bucket.params, bucket.offsets):
             n, done = p.numel(), 0
             while done < n:
                 c = min(ch, n - done)
                 rec.append((p.data_ptr() + 4 * done, off + done, c, 0))
                 done += c
-            off += n
         arr = np.array(rec, dtype=np.dtype([("p", "<u8"), ("o", "<i8"), ("c", "<i4"), ("z", "<i4")]))
         self.chunks = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
         self.nchunks = len(rec)
@@ -242,10 +252,14 @@ class DataParallelTrainer:
         self.timing = None                                 # a list: step() appends (start, after all-reduce, after optimiser) events
         self._fused_opt = FusedClipAdam(self.bucket, optimizer) if FusedClipAdam.supports(self.bucket, optimizer) else None
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        # one GPU: nothing sits between backward and the optimiser, so clip + Adam join the captured step (no eager -> graph
-        # boundary: ~25 us of idle chip per step); with more ranks the all-reduce stays eager and the optimiser follows it
-        self._opt_in_graph = (use_graph and self._fused_opt is not None and world == 1
-                              and OPT.graph_adam)
+        self.world = world
+        # The whole step is ONE graph whenever it can be: with one GPU nothing sits between backward and the optimiser, so clip +
+        # Adam join the captured step (no graph -> eager boundary: ~25 us of idle chip per step); with more ranks the gradient
+        # all-reduce is captured too when the backend's collectives are stream-ordered (RCCL: `nccl`), so that the N > 1 step
+        # has the shape of the N = 1 step -- fwd + bwd + all-reduce + (1/world, clip, Adam) in one replay.  Any other backend
+        # (gloo moves the bucket through the host) keeps the all-reduce and the optimiser eager behind the replayed fwd + bwd.
+        coll_in_graph = world == 1 or (OPT.graph_allreduce and dist.get_backend(group) == "nccl")
+        self._opt_in_graph = (use_graph and self._fused_opt is not None and coll_in_graph and OPT.graph_adam)
 
     def _fwd_bwd(self, img, qst, label):
         self.bucket.detach_()
@@ -267,14 +281,31 @@ class DataParallelTrainer:
         with torch.cuda.stream(side):                   # warm-up outside capture (MIOpen find, allocator, packs)
             for _ in range(2):
                 self._fwd_bwd(*self._static)
+            if self._opt_in_graph and self.world > 1:   # ... and the communicator's first collective (lazy initialisation)
+                dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.group)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self._opt_in_graph and self.world > 1:
+            try:
+                self._graph = self._capture_graph(True)
+                return
+            except Exception as e:                      # a backend / runtime that cannot capture its collective: eager exchange
+                import warnings
+                warnings.warn("the gradient all-reduce could not be captured into the step graph (%s: %s); it stays eager"
+                              % (type(e).__name__, str(e)[:200]))
+                self._opt_in_graph = False
+                torch.cuda.synchronize()
+        self._graph = self._capture_graph(self._opt_in_graph)
+
+    def _capture_graph(self, with_opt):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self._loss = self._fwd_bwd(*self._static)
-            if self._opt_in_graph:
-                self._fused_opt.step_dev()
-        self._graph = graph
+            if with_opt:
+                if self.world > 1:
+                    dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.group)
+                self._fused_opt.step_dev()              # (the 1/world factor is the hyper block's grad_scale)
+        return graph
 
     def step(self, img, qst, label):
         if self.use_graph:
@@ -283,13 +314,15 @@ class DataParallelTrainer:
             todo = [(dst, src) for dst, src in zip(self._static, (img, qst, label)) if dst.data_ptr() != src.data_ptr()]
             if todo and OPT.batch_copy_fused and all(s_.is_cuda and s_.is_contiguous() and s_.dtype == d.dtype and s_.shape == d.shape
                                                      and s_.data_ptr() % 16 == 0 for d, s_ in todo):
-                from . import rn_hip as _H
-                _H.copy_many(todo)                          # one launch for the whole batch hand-off
+                RF.H.copy_many(todo)                        # one launch for the whole batch hand-off
             else:
                 for dst, src in todo:
                     dst.copy_(src, non_blocking=True)
+            # BEFORE the replay, in every mode: the captured kernels have the parameters' addresses baked in
+            if self._fused_opt is not None:
+                self._fused_opt._check_storage()
             if self._opt_in_graph:
-                self._fused_opt.sync_hyper(self.clip_norm, 1.0)
+                self._fused_opt.sync_hyper(self.clip_norm, 1.0 / self.world)
             self._graph.replay()
             self.bucket.attach_()
             loss = self._loss

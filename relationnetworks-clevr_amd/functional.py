@@ -688,13 +688,24 @@ class RelationalFunction(torch.autograd.Function):
             # by the chain and 134 MB less read by the wgrad at the headline shape
             gated_mask = gate_img = None
             # (needs the e4m3 H_2 image: the gate job runs on the fp8 matrix pipe; with 16-bit copies dZ_3 is stored)
+            red_parts = None
             if ((n * njp) % 64 == 0 and inputs[L - 1].dtype in H.FP8_DTYPES and OPT.gated_wgrad):
                 gated_mask = ctx.HL.masks[L - 1]
                 gate_img = ctx.HL.gate                     # (the f16s forward chain has already written the gate's image)
-                dZs = [None] + list(torch.empty(L - 1, Mc, G, dtype=dt, device=dev))
+                # layer 0's gradient is read by the pair-axis reductions only: they are formed inside the chain and dZ_0
+                # (134 MB written + read back at the headline shape) never exists -- rn_g_chain_bwd_rr_red
+                tpu = H.g_chain_bwd_rr_red_tpu(Mc, n) if (OPT.chain_reduce and njp == n and L == 4 and k <= 32
+                                                          and (alg0_wgrad_ok(plan, k) or bool(ctx.inj_path))) else 0
+                if tpu > 0:
+                    dZs = [None] + list(torch.empty(L - 2, Mc, G, dtype=dt, device=dev)) + [None]
+                    red_parts = (torch.empty(Mc // 256 // tpu, 32, G, **f32), torch.empty(Mc // 16, G, **f32), (n // 8) // tpu)
+                    H.g_chain_bwd_rr_red(dxg, ctx.HL.masks, ctx.fragT, dZs, Mc, n, G, red_parts[0], red_parts[1], tpu)
+                else:
+                    dZs = [None] + list(torch.empty(L - 1, Mc, G, dtype=dt, device=dev))
             else:
                 dZs = list(torch.empty(L, Mc, G, dtype=dt, device=dev))            # dZs[s] belongs to layer L-1-s
-            H.g_chain_bwd_rr(dxg, ctx.HL.masks, ctx.fragT, dZs, Mc, n * njp, G)
+            if red_parts is None:
+                H.g_chain_bwd_rr(dxg, ctx.HL.masks, ctx.fragT, dZs, Mc, n * njp, G)
             dZ_of = {L - 1 - s: dZs[s] for s in range(L)}
         elif fused_bwd:
             # one launch: dZ_L = dxg * (H_L > 0), then dZ_{l-1} = (dZ_l @ W_l) * (H_{l-1} > 0) for every layer
@@ -713,6 +724,12 @@ class RelationalFunction(torch.autograd.Function):
         dx = None
         inj = bool(ctx.inj_path)        # the chains ran with the question injected at layer plan.inject > 0 as a bias row
 
+
+        def _pair_reduce(dz0, Rj, Ri, Rq, N_):
+            if rr_bwd and red_parts is not None:                       # the chain has already reduced: add its partials up
+                H.pair_reduce_parts(red_parts[0], red_parts[1], Rj, Ri, Rq, B, n, N_, red_parts[2])
+            else:
+                H.pair_reduce_bwd(dz0, N_, Rj, Ri, Rq, code, B, n, N_, njp=njp)
 
         def _wgrad(l, dz, a_l):                                        # row-major operands: the general kernel
             N_, kt_, kp_ = plan.widths[l], plan.ktrue[l], plan.kpad[l]
@@ -824,7 +841,7 @@ class RelationalFunction(torch.autograd.Function):
                 Rq = torch.empty(B, N, **f32)
                 if l == 0:
                     Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32)
-                    H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N, njp=njp)
+                    _pair_reduce(dZ, Rj, Ri, Rq, N)
                 elif rr_bwd:
                     H.blocked_question_sums(dZ, Rq, M, n * n)      # (this layer's dZ is a row-blocked image)
                 else:
@@ -845,7 +862,7 @@ class RelationalFunction(torch.autograd.Function):
             elif l == 0:
                 Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32)
                 Rq = torch.empty(B, N, **f32) if alg0 else None                   # (all-pairs sums: the layer's bias gradient)
-                H.pair_reduce_bwd(dZ, N, Rj, Ri, Rq, code, B, n, N, njp=njp)
+                _pair_reduce(dZ, Rj, Ri, Rq, N)
             if l == 0 and overlap and wgrad_late == 1:
                 _launch_wgrads()
             if l == 0 and alg0:
@@ -854,10 +871,15 @@ class RelationalFunction(torch.autograd.Function):
                     gB[0] = grad_out(ctx.param_refs[L], (N,))
                     H.wgrad0_from_reductions(Rj, Ri, Rq, x, q if plan.inject == 0 else None, gW[0], gB[0], coord=ctx.coord)
                 # (measured: on the conv weight-gradient stream instead -3.5 %, on the main stream behind dx / dq -1 %)
-                if overlap:                                        # off the critical path: onto the wgrad stream
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
+                if overlap and OPT.wgrad0_stream == 1:
+                    pass                                           # (main stream, behind dx / dq: below)
+                elif overlap:                                      # off the critical path: onto the wgrad stream (or one of its own)
+                    s0 = side if OPT.wgrad0_stream == 0 else _side_stream(dev, 2)
+                    s0.wait_stream(main)
+                    with torch.cuda.stream(s0):
                         _wgrad0()
+                    if s0 is not side:
+                        side.wait_stream(s0)                       # (the join at the end of the backward pass waits for `side`)
                     # x and q too: they are alive only through this node's saved tensors, which autograd releases as soon as
                     # backward() returns -- the caching allocator would hand their blocks to the conv / LSTM backward that the
                     # main stream runs next while this side-stream kernel still reads them (seen as a wrong dW_0 on a busy GPU)
@@ -886,6 +908,8 @@ class RelationalFunction(torch.autograd.Function):
                 dZp = torch.empty(M, gp, dtype=dt, device=dev)
                 H.g_linear_bwd_dgrad(dZ, N, wbwd[l], N, A_l, kp, dZp, gp, code, M, N, gp)
                 dZ = dZp
+            if l == 0 and alg0 and overlap and OPT.wgrad0_stream == 1:
+                _wgrad0()                                          # main stream, behind dx / dq
             inputs[l] = None
         ctx.inputs = None
         if rq_splits:

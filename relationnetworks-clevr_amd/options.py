@@ -21,6 +21,7 @@ _SPEC = {
     "algebraic_fwd0":    ("RN_NO_ALGEBRAIC_FWD0", True, "first layer factored through the pair structure (tables instead of the pair matrix)"),
     "algebraic_wgrad0":  ("RN_NO_ALGEBRAIC_WGRAD0", True, "layer-0 weight gradient from the pair reductions"),
     "gated_wgrad":       ("RN_NO_GATED_WGRAD", True, "last layer's gradient never stored (gate job of rn_g_wgrad_blocked)"),
+    "chain_reduce":      ("RN_NO_CHAIN_REDUCE", True, "pair-axis reductions of layer 0's gradient inside the backward chain (dZ_0 never stored; n % 32 == 0)"),
     "gate_fwd":          ("RN_NO_GATE_FWD", True, "... and its gate image written by the f16s forward chain (else by rn_relu_gate_image in the backward pass)"),
     "rq_from_wgrad":     ("RN_NO_RQ_FROM_WGRAD", True, "injected layer's per-question sums from the weight-gradient kernel's db partials"),
     "fused_pair_tail":   ("RN_NO_FUSED_PAIR_TAIL", True, "dx and dq in one launch (rn_pair_dx_dq), straight into the conv grid's layout"),
@@ -28,6 +29,7 @@ _SPEC = {
     "grid_fast":         ("RN_NO_GRID_FAST", True, "kernels take the conv grid + coordinate table (no concatenated object tensor)"),
     "pack_ahead":        ("RN_NO_PACK_AHEAD", True, "weight images packed on the question encoder's side stream"),
     "wgrad_overlap":     ("RN_NO_WGRAD_OVERLAP", True, "weight gradients on a side stream"),
+    "wgrad0_stream":     ("RN_WGRAD0_STREAM", 2, "layer-0 weight gradient (from the pair reductions): 0 on the weight-gradient stream, 1 on the main stream behind dx / dq, 2 on a stream of its own (measured, one box: 85.6 / 87.0 / 87.9 k q/s)"),
     "wgrad_late":        ("RN_WGRAD_LATE", 0, "1 / 2: start the weight-gradient stream after the pair reduction / after dx, dq (measured slower)"),
     "direct_conv":       ("RN_NO_DIRECT_CONV", True, "own 3x3 / stride-2 convolution kernels (else MIOpen)"),
     "direct_conv_wgrad": ("RN_NO_DIRECT_CONV_WGRAD", True, "... and their weight gradient"),
@@ -42,6 +44,7 @@ _SPEC = {
     "fused_loss":        ("RN_NO_FUSED_LOSS", True, "loss inside the f_phi launch (trainer)"),
     "grads_in_bucket":   ("RN_NO_GRADS_IN_BUCKET", True, "backward kernels write parameter gradients straight into a registered FlatGradBucket (trainer)"),
     "fused_adam":        ("RN_NO_FUSED_ADAM", True, "fused clip + Adam on the flat bucket (trainer)"),
+    "graph_allreduce":   ("RN_NO_GRAPH_ALLREDUCE", True, "N > 1 over RCCL: the gradient all-reduce inside the captured step too (else eager, with the optimiser behind it)"),
     "graph_adam":        ("RN_NO_GRAPH_ADAM", True, "... inside the captured step on one GPU"),
 }
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librn_hip.so")
 RN_BF16, RN_F32, RN_F16, RN_FP8 = 0, 1, 2, 3
 RN_RELU, RN_ACCUMULATE = 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -42,6 +42,9 @@ SIGNATURES = {
     "rn_pair_sum_tiles": (_I, [_P, _P, _I, _I, _I, _P]),
     "rn_f_phi_fwd_from_partials": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_g_chain_bwd_rr_red_tpu": (_I, [_I, _I]),
+    "rn_g_chain_bwd_rr_red": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "rn_pair_reduce_parts": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pack_matrix_frag": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
     "rn_pack_matrix_frag_many": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "rn_g_chain_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -381,6 +384,29 @@ def g_chain_bwd_rr(dxg, masks, Wtfs, dZs, M, rows_per_question, G):
     wp = (C.c_void_p * (L - 1))(*[w.data_ptr() for w in Wtfs])
     zp = (C.c_void_p * L)(*[(z.data_ptr() if z is not None else None) for z in dZs])     # dZs[0] None: not stored
     _check(load().rn_g_chain_bwd_rr(dxg.data_ptr(), mp, wp, zp, M, rows_per_question, L, G, _stream()), "rn_g_chain_bwd_rr")
+
+
+def g_chain_bwd_rr_red_tpu(M, n):
+    """Tiles per unit of the reducing backward chain for this shape (0: not supported -- store dZ_0 and use pair_reduce_bwd)."""
+    return int(load().rn_g_chain_bwd_rr_red_tpu(M, n))
+
+
+@_timed("g_dgrad")
+def g_chain_bwd_rr_red(dxg, masks, Wtfs, dZs, M, n, G, rj_part, ri_part, tpu):
+    """Register-resident backward chain with the pair-axis reductions of layer 0's gradient formed on chip: dZs[0] None (gate job),
+    dZs[1..2] row-blocked images, dZs[3] not written; partial sums to rj_part / ri_part (pair_reduce_parts adds them up)."""
+    L = len(dZs)
+    mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks])
+    wp = (C.c_void_p * (L - 1))(*[w.data_ptr() for w in Wtfs])
+    zp = (C.c_void_p * L)(*[(z.data_ptr() if z is not None else None) for z in dZs])
+    _check(load().rn_g_chain_bwd_rr_red(dxg.data_ptr(), mp, wp, zp, M, n, L, G, rj_part.data_ptr(), ri_part.data_ptr(), tpu, _stream()),
+           "rn_g_chain_bwd_rr_red")
+
+
+@_timed("pair_reduce")
+def pair_reduce_parts(rj_part, ri_part, Rj, Ri, Rq, B, n, G, nu):
+    _check(load().rn_pair_reduce_parts(rj_part.data_ptr(), ri_part.data_ptr(), Rj.data_ptr(), Ri.data_ptr(), _ptr(Rq), B, n, G, nu, _stream()),
+           "rn_pair_reduce_parts")
 
 
 def pack_matrix_split(src, sr, sc, R, Cc, hi, lo, ld, Rpad):

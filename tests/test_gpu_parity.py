@@ -165,6 +165,8 @@ def test_e4m3_activation_copies_touch_only_the_g_weight_gradients(pkg, tag, prec
     every touched tensor against the fp32 reference (sampled entries + norm for the full-size fixtures) is measured and reported,
     and must stay inside the mode's own band."""
     g = gold.load(tag)
+    # (both legs with a stored dZ_0: the chain that reduces it on chip needs the e4m3 set -- its own test is the next one)
+    monkeypatch.setattr(pkg.options.OPT, "chain_reduce", False)
     monkeypatch.setattr(pkg.options.OPT, "h8", False)
     lp0, loss0, dx0, dq0, gr0 = run_rl(pkg, g, precision)
     monkeypatch.setattr(pkg.options.OPT, "h8", True)
@@ -191,6 +193,32 @@ def test_e4m3_activation_copies_touch_only_the_g_weight_gradients(pkg, tag, prec
             assert np.array_equal(gr0[k], gr1[k]), k
     report(tag, precision=precision, e4m3_vs_16bit={k: v[0] for k, v in rep.items()}, ref_err_16bit={k: v[1] for k, v in rep.items()},
            ref_err_e4m3={k: v[2] for k, v in rep.items()})
+
+
+@pytest.mark.parametrize("tag", ["G-fp64", "G-ir64", "G-fp-small"])
+def test_pair_reductions_inside_the_backward_chain(pkg, tag, monkeypatch):
+    """rn_g_chain_bwd_rr_red (the module default where n % 32 == 0): layer 0's gradient never leaves the chip, its pair-axis sums are
+    formed in fp32 from the un-rounded accumulators.  Against the stored-dZ_0 path (bf16 rows + rn_pair_reduce_bwd,
+    RN_NO_CHAIN_REDUCE=1): the forward and everything that does not read those sums -- log-probs, dW / db of layers 1..3, f_phi --
+    is bitwise the same; dx, dq (question at layer 0), dW_0, db_0 move by the bf16 rounding that is gone (<= 5e-3 relative L2) and
+    do not get worse against the reference (model.py:117-127 backward)."""
+    g = gold.load(tag)
+    monkeypatch.setattr(pkg.options.OPT, "chain_reduce", False)
+    lp0, loss0, dx0, dq0, gr0 = run_rl(pkg, g, "f16s")
+    monkeypatch.setattr(pkg.options.OPT, "chain_reduce", True)
+    lp1, loss1, dx1, dq1, gr1 = run_rl(pkg, g, "f16s")
+    assert np.array_equal(lp0, lp1)
+    inj0 = formula.HYP[g["meta"]["cfg"]]["question_injection_position"] == 0
+    assert 0 < l2rel(dx1, dx0) <= 5e-3
+    assert (0 < l2rel(dq1, dq0) <= 5e-3) if inj0 else np.array_equal(dq0, dq1)
+    for k in gr0:
+        if k.startswith("g_layers.0."):
+            assert 0 < l2rel(gr1[k], gr0[k]) <= 5e-3, k
+        else:
+            assert np.array_equal(gr0[k], gr1[k]), k
+    e0, e1 = l2rel(dx0, g["dx"]), l2rel(dx1, g["dx"])
+    report(tag, precision="f16s", chain_reduce_dx_l2=(e0, e1), chain_reduce_dq_l2=(l2rel(dq0, g["dq"]), l2rel(dq1, g["dq"])))
+    assert e1 <= 1.05 * e0 + 1e-4
 
 
 def test_injected_layer_question_sums_from_the_wgrad_partials(pkg, monkeypatch):
