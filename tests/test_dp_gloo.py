@@ -87,7 +87,9 @@ def test_flat_bucket_semantics():
     from relationnetworks_clevr_amd import dp
     m = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
     b = dp.FlatGradBucket(m.parameters())
-    assert b.numel == 5 * 3 + 3 + 3 * 2 + 2 == b.flat.numel()
+    # every slot starts on 16 bytes (backward kernels write dW / db into the views with vector stores): 15 | 3 | 6 | 2 -> 16 + 4 + 8 + 2
+    assert b.offsets == [0, 16, 20, 28] and b.numel == 30 == b.flat.numel()
+    assert all(v.data_ptr() % 16 == 0 for v in b.views)
     x = torch.randn(7, 5)
     m(x).sum().backward()
     g1 = [p.grad.clone() for p in m.parameters()]

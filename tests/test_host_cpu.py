@@ -179,3 +179,26 @@ def test_product_never_imports_the_oracle():
                 code = re.sub(r'"""[\s\S]*?"""', "", src)
                 code = "\n".join(l for l in code.splitlines() if not l.strip().startswith(("#", "//", "*", "/*")))
                 assert "/root/reference" not in code, f
+
+
+def test_flat_import_like_the_reference_has_no_relative_imports_behind_it():
+    """train.py run like the reference's (the package directory itself on sys.path: `import model`, `import dp`, train.py:25) must
+    not meet a relative import later, inside a function -- ADVICE r3: DataParallelTrainer.step() did `from . import rn_hip`, which
+    raises 'attempted relative import with no known parent package' on the first captured step.  (a) no function body of dp.py /
+    train.py holds a relative import; (b) the flat imports work in a fresh interpreter and share ONE binding module with
+    `functional` (dp reaches the library through RF.H)."""
+    import ast
+    import subprocess
+    import sys
+    pkgdir = os.path.join(ROOT, "relationnetworks-clevr_amd")
+    for name in ("dp.py", "train.py"):
+        tree = ast.parse(open(os.path.join(pkgdir, name)).read())
+        for fn in ast.walk(tree):
+            if isinstance(fn, (ast.FunctionDef, ast.AsyncFunctionDef)):
+                for node in ast.walk(fn):
+                    assert not (isinstance(node, ast.ImportFrom) and node.level > 0), "%s: relative import inside %s()" % (name, fn.name)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import dp, train; "
+            "assert dp.RF.H is sys.modules['relationnetworks_clevr_amd.rn_hip'] or dp.RF.H.__name__.endswith('rn_hip'); print('flat ok')"
+            % (ROOT, pkgdir))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=pkgdir)
+    assert r.returncode == 0 and "flat ok" in r.stdout, r.stderr[-2000:]
