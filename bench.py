@@ -22,6 +22,8 @@ that is "f16s", the mode that meets the 1e-3 log-prob bar).  What the line carri
                    `traffic_source`) or null.  `kernels` / `all_g_theta`: every g_theta kernel as the step runs it
                    (wgrads on a side stream beside the pair reduction); `ms_serial` / `all_g_theta_serial`: the same
                    with that overlap off.
+  sustained        the same graph replayed for --sustain seconds (default 3) right after the K timed steps: rate, ms/step and the
+                   rocm-smi clocks / power sampled meanwhile -- K = 20 steps are 15 ms, too short for the chip's sustained clocks.
   pair_build_k1    rn_pair_build_fwd launched on its own at the benched shape: 94.83 MB / duration vs 8 TB/s
                    (north_star's "HBM GB/s on the pair-build kernel"; the headline path itself builds two small
                    tables instead, reported as `pair_tables`).
@@ -106,7 +108,7 @@ def cpu_baseline(cfg, B, hw, warm=3, steps=5):
                       % (steps, ts[0], ts[-1], B, cfg, warm, model)}
 
 
-def parity_check(pkg, cfg, prec):
+def parity_check(pkg, cfg, prec, hw=128):
     """The checker leg: the benched arithmetic mode against the reference's golden vectors (tests/golden/*.npz, recorded
     from /root/reference/model.py by tests/golden/make_golden.py), measured NOW on this GPU.  Inputs are the fixtures'
     closed-form ones (oracle/formula.py: test-data generator, used here as the checker's input only)."""
@@ -120,7 +122,11 @@ def parity_check(pkg, cfg, prec):
         return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
     out = {"mode": prec, "tolerance": 1e-3, "metric": "max|got - ref| / max|ref| on log-probs (fp32 reference, identical inputs)"}
-    tag_rl = "G-fp64" if cfg == "original-fp" else ("G-ir64" if cfg == "ir-fp" else None)
+    # the relational-layer fixture of the BENCHED shape: the 14 x 14 grid (--hw 224) has its own, recorded at its real size
+    if hw == 224:
+        tag_rl = "G-fp196-b32" if cfg == "original-fp" else None
+    else:
+        tag_rl = "G-fp64" if cfg == "original-fp" else ("G-ir64" if cfg == "ir-fp" else None)
     tag_ck = "pretrained_original_fp" if cfg == "original-fp" else ("pretrained_ir_fp" if cfg == "ir-fp" else None)
     worst = 0.0
     if tag_rl:
@@ -140,7 +146,9 @@ def parity_check(pkg, cfg, prec):
         worst = max(worst, e)
         out[tag_rl] = {"what": "relational layer, B=%d n=%d, formula weights, fwd+bwd" % (g["meta"]["b"], g["meta"]["n"]),
                        "log_prob_rel_err": e, "argmax_agree": float((lpn.argmax(1) == g["log_probs"].argmax(1)).mean()),
-                       "dx_l2_rel": l2rel(xt.grad.cpu().numpy(), g["dx"]), "dq_l2_rel": l2rel(qt.grad.cpu().numpy(), g["dq"]),
+                       "dx_l2_rel": (l2rel(xt.grad.cpu().numpy(), g["dx"]) if "dx" in g else
+                                     abs(float(np.linalg.norm(xt.grad.double().cpu().numpy())) - float(g["dx_norm"])) / float(g["dx_norm"])),
+                       "dq_l2_rel": l2rel(qt.grad.cpu().numpy(), g["dq"]),
                        "bias_grads_l2_rel_max": max(l2rel(grads[k_[5:]], g[k_]) for k_ in g if k_.startswith("grad/"))}
         # the weight gradients (what the e4m3 activation copies touch): 64 sampled entries + the norm of every tensor the fixture
         # pins (gold.check_grads: max-norm relative error, worst of sample / norm)
@@ -252,6 +260,57 @@ def mode_rate(pkg, dp, hyp, prec, dev, img, qst, lab, B, steps=10):
     return {"value": B * steps / dt, "unit": "questions/s", "ms_per_step": 1e3 * dt / steps}
 
 
+class ClockSampler:
+    """rocm-smi's sclk / mclk / power of device 0, sampled every ~0.25 s by a thread while the sustained run is going."""
+
+    def __init__(self, period=0.25):
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self._thr = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                r = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5)
+                d = json.loads(r.stdout)
+                c = next(iter(d.values()))
+                row = {}
+                for k_, v in c.items():
+                    m = re.search(r"\((\d+)Mhz\)", str(v))
+                    if "sclk" in k_ and m:
+                        row["sclk_mhz"] = int(m.group(1))
+                    elif "mclk" in k_ and m:
+                        row["mclk_mhz"] = int(m.group(1))
+                    elif "Power" in k_:
+                        try:
+                            row["power_w"] = float(v)
+                        except (TypeError, ValueError):
+                            pass
+                if row:
+                    self.samples.append((time.perf_counter(), row))
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def start(self):
+        self._thr.start()
+
+    def stop(self):
+        self._stop.set()
+        self._thr.join(timeout=10)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        out = {"samples": len(self.samples)}
+        for key in ("sclk_mhz", "mclk_mhz", "power_w"):
+            vals = [r[key] for _t, r in self.samples if key in r]
+            if vals:
+                out[key] = {"min": min(vals), "max": max(vals), "mean": sum(vals) / len(vals), "last": vals[-1]}
+        return out
+
+
 def timed_steps(step, steps, warmup, sync):
     """W untimed warm-up steps, then EXACTLY K steps bracketed by sync() on both sides -> (seconds, last step's result).
     Shared by the real run and the launch-plumbing dry run."""
@@ -291,6 +350,8 @@ def main():
     ap.add_argument("--no-other-modes", action="store_true", help="skip the extra timing of the other arithmetic modes")
     ap.add_argument("--no-parity", action="store_true", help="skip the live parity check against the golden fixtures")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--sustain", type=float, default=3.0,
+                    help="seconds of back-to-back steps AFTER the timed K steps, same graph: reported as `sustained` (0: skip)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -347,6 +408,21 @@ def main():
     # ---- timed region: W warm-up steps, then exactly K steps, barrier + synchronize on both sides
     H.TIMER.enabled = False
     dt, loss = timed_steps(lambda: trainer.step(img, qst, lab), args.steps, args.warmup, sync)
+    sustained = None
+    if args.sustain > 0:
+        # The contract's K = 20 steps last ~15 ms -- too short for the chip to reach its sustained clocks under matrix load.
+        # The same replay for `--sustain` seconds (step count fixed beforehand from the timed region's rate, so that every
+        # rank runs the same number), bracketed like the timed region; rocm-smi clocks sampled by a thread meanwhile (rank 0).
+        n_sus = max(int(args.sustain / max(dt / args.steps, 1e-6)), args.steps)
+        clocks = ClockSampler() if rank == 0 else None
+        if clocks:
+            clocks.start()
+        dt_s, _ = timed_steps(lambda: trainer.step(img, qst, lab), n_sus, 0, sync)
+        if clocks:
+            clocks.stop()
+        dt_s = max_over_ranks(dt_s, world, dev)
+        sustained = {"value": world * B * n_sus / dt_s, "unit": "questions/s", "ms_per_step": 1e3 * dt_s / n_sus, "steps": n_sus,
+                     "seconds": dt_s, "clocks": clocks.summary() if clocks else None}
     comm = None
     if world > 1:
         # attribution (outside the timed region): K more steps with event brackets around the gradient all-reduce and the fused
@@ -432,10 +508,13 @@ def main():
                                   "hipGraph replay of fwd+bwd, eager all-reduce/clip/Adam")},
             "loss": float(loss.detach()),
         }
+        if sustained:
+            sustained["vs_value"] = sustained["value"] / out["value"]
+            out["sustained"] = sustained
         if comm:
             out.update(comm)
         if world == 1 and not args.no_parity:
-            out["parity"] = parity_check(pkg, args.config, prec)
+            out["parity"] = parity_check(pkg, args.config, prec, args.hw)
         if ksum:
             names = ("g_fwd", "g_dgrad", "g_wgrad")
             # primary: the brackets of the step as it runs (`in_step`: the launch durations over the timed region's own launch
@@ -507,7 +586,7 @@ def main():
                     continue
                 r = mode_rate(pkg, dp, base_hyp, p2, dev, img, qst, lab, B)
                 if "unsupported" not in r and not args.no_parity:
-                    r["parity"] = parity_check(pkg, args.config, p2)
+                    r["parity"] = parity_check(pkg, args.config, p2, args.hw)
                 others[p2] = r
             if prec in ("bf16", "f16s") and pkg.options.OPT.h8:
                 # the benched mode with 16-bit instead of e4m3 copies of H_0..2 (and a stored last-layer gradient): what the e4m3
@@ -515,7 +594,7 @@ def main():
                 with pkg.options.override(h8=False):
                     r = mode_rate(pkg, dp, base_hyp, prec, dev, img, qst, lab, B)
                     if not args.no_parity:
-                        r["parity"] = parity_check(pkg, args.config, prec)
+                        r["parity"] = parity_check(pkg, args.config, prec, args.hw)
                 others[prec + ", 16-bit activation copies"] = r
             out["other_modes"] = others
         if world == 1 and not args.no_cpu_baseline:

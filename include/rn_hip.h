@@ -312,6 +312,19 @@ int rn_colsum_f32(const float* src, long ld, float* out, int R, int C, void* str
  * L2-normalise every pair row (F.normalize semantics, eps 1e-12), then maxf / avgf (B, F) fp32 = maximum / mean over the
  * npairs rows of each question.  One pass over A.  F % 64 == 0, F <= 512; ws: rn_pair_features_ws_bytes(B, npairs, F). */
 size_t rn_pair_features_ws_bytes(int B, int npairs, int F);
+/* The same features WITHOUT the matrix (SURVEY.md 8f row N3 as specified): the input of g layer `nlayers` is formed tile by tile
+ * on chip -- a workgroup builds 64 pair rows [x_j | x_i] (model.py:117-127) in LDS, runs g layers 0 .. nlayers-1 on them in fp32
+ * (v_mfma_f32_32x32x2_f32) with the activation tile resident in LDS, L2-normalises the rows of the result over its first F columns
+ * and leaves one (max, sum) pair per tile in ws; a finish launch reduces per question.  Neither (B n^2, in) nor any activation
+ * is written to memory.  nlayers = 0: the features are the pair rows themselves (F <= 2k).
+ *   x: objects (B, n, k) fp32, element strides; Wt[l]: (K_l, 256) fp32 TRANSPOSED weights of layer l -- Wt[l][c][f] = W_l[f][c]
+ *   for the first K_0 = 2k (l = 0) / K_l = 256 (l > 0) input columns, i.e. without the question columns; bias[l]: (256) fp32, or
+ *   with bias_per_question[l] != 0 a (B, 256) table W_l[:, K_l:] q_b + b_l -- how the question enters at its injection layer
+ *   (model.py:131-142).  g width 256, nlayers <= 4, 2k <= 256.  maxf, avgf: (B, F) fp32; ws: rn_extract_ws_bytes(B, n, F). */
+size_t rn_extract_ws_bytes(int B, int n, int F);
+int rn_extract_features(const float* x, long sxb, long sxn, long sxk, const float* const* Wt, const float* const* bias,
+                        const int* bias_per_question, int nlayers, int F, float* maxf, float* avgf, void* ws, int B, int n, int k,
+                        void* stream);
 int rn_pair_features(const void* A, int lda, int F, float* maxf, float* avgf, void* ws, int dtype, int B, int npairs, void* stream);
 
 /* f_phi + log_softmax (model.py:155-162) in one launch, its backward in two (rn_small.hip; fp32 FMA):

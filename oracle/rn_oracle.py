@@ -130,6 +130,21 @@ def rl_forward_np(x, q, params, inject: int, dropout_mask=None, keep=True):
     return out, cache
 
 
+def pair_features_np(x, q, params, inject: int, layer_idx: int):
+    """extract.py:49-74 (hook on the INPUT of g_layers[layer_idx], extract.py:43,101): strip the question columns of an injection
+    layer (:66-67), F.normalize(p=2, dim=2, eps=1e-12) per pair row (:68), max / mean over each question's n^2 pairs (:69-70).
+    -> (maxf, avgf), each (B, F)."""
+    b, n, k = x.shape
+    _, cache = rl_forward_np(x, q, params, inject)
+    z = cache["acts"][layer_idx]
+    if layer_idx == inject:
+        z = z[:, : z.shape[1] - q.shape[1]]
+    z = z.reshape(b, n * n, -1)
+    nrm = np.maximum(np.sqrt((z.astype(np.float64) ** 2).sum(2, keepdims=True)), 1e-12)
+    u = (z / nrm).astype(F32)
+    return u.max(1), u.mean(1, dtype=np.float64).astype(F32)
+
+
 def rl_backward_np(x, q, params, cache, grad_out):
     """Gradients of RelationalLayer.forward w.r.t. x, q and every rl parameter,
     given d(loss)/d(log_probs) (B, A).  Mirrors what autograd derives for

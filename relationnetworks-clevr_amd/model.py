@@ -207,24 +207,43 @@ class RelationalLayer(RelationalLayerBase):
 
     @torch.no_grad()
     def extract_features(self, x, qst, layer_idx):
-        """R-CBIR features of extract.py:49-74 without a hook: the input of g layer `layer_idx` is L2-normalised per
-        pair and reduced to (max, mean) over each question's pairs on the GPU (rn_pair_features; the question columns of
-        an injection layer are excluded, extract.py:66-67).  Returns two (B, F) fp32 tensors.  The g chain stops at that
-        layer; nothing is materialised in fp32 (the hook-compatible path stays available)."""
+        """R-CBIR features of extract.py:49-74 without a hook and without the matrix the hook reads: the input of g layer
+        `layer_idx` -- (B n^2, in) in the reference: 402 MB for the injected layer of the IR models at B = 64 -- is formed tile by
+        tile on chip (rn_extract_features: pair rows in LDS, g layers 0 .. layer_idx-1 in fp32 on the matrix pipe with the tile
+        resident), L2-normalised per pair and reduced to (max, mean) over each question's pairs; the question columns of an
+        injection layer are excluded (extract.py:66-67).  Returns two (B, F) fp32 tensors, F = 2k for layer 0, else the g width.
+        SURVEY.md 8f row N3.  The 512-wide *-sd models take the per-layer kernels + rn_pair_features (a materialised fp32 input:
+        M = B * 144 rows only); registering a forward hook keeps working for every model (_forward_hook_compat)."""
         b, d, k = x.size()
         plan = self._plan(k)
         if not 0 <= layer_idx < plan.L:
             raise ValueError("layer_idx must be in [0, %d)" % plan.L)
-        code = H.dtype_code("bf16" if self.precision == "bf16" else "fp32")     # (the per-layer kernels; parity-clean unless bf16 is asked for)
         H._dev(x, "x")
+        Q = qst.shape[1]
+        if all(w_ == 256 for w_ in plan.widths[:layer_idx]) and 2 * k <= 256 and layer_idx <= 4:
+            xs, q = x.float(), qst.float().contiguous()
+            Wts, biases, per_q = [], [], []
+            for l in range(layer_idx):
+                W, bias = self.g_layers[l].weight.detach(), self.g_layers[l].bias.detach()
+                kin = 2 * k if l == 0 else plan.widths[l - 1]
+                Wts.append(W[:, :kin].t().contiguous())
+                if l == plan.inject:                           # [.. | q] @ W^T + b = .. @ W[:, :kin]^T + (q @ W[:, kin:]^T + b): a per-question bias row
+                    biases.append(torch.addmm(bias, q, W[:, kin:].t()).contiguous())
+                    per_q.append(True)
+                else:
+                    biases.append(bias.contiguous())
+                    per_q.append(False)
+            F_ = 2 * k if layer_idx == 0 else plan.widths[layer_idx - 1]
+            return H.extract_features(xs, Wts, biases, per_q, F_)
+        code = H.dtype_code("bf16" if self.precision == "bf16" else "fp32")     # (the per-layer kernels; parity-clean unless bf16 is asked for)
         wfwd, _ = self._packed.get(plan, [l.weight for l in self.g_layers], code, bwd_images=False)
         gb = [l.bias.detach().contiguous() for l in self.g_layers]
         inputs, _, _ = RF.g_chain_forward(x.float(), qst.float().contiguous(), plan, gb, wfwd, code, keep_inputs=True,
                                           stop_at=layer_idx)
         A = inputs[layer_idx]
-        F_ = plan.ktrue[layer_idx] - (qst.shape[1] if layer_idx == plan.inject else 0)
+        F_ = plan.ktrue[layer_idx] - (Q if layer_idx == plan.inject else 0)
         if F_ % 64:
-            raise RuntimeError("feature width %d of layer %d is not a multiple of 64 (layer 0 of the *-fp configs: use the hook path)" % (F_, layer_idx))
+            raise RuntimeError("feature width %d of layer %d is not a multiple of 64 (use the hook path)" % (F_, layer_idx))
         return H.pair_features(A, A.shape[1], F_, code, b, d * d)
 
     @torch.no_grad()

@@ -72,6 +72,8 @@ SIGNATURES = {
     "rn_colsum_f32": (_I, [_P, _L, _P, _I, _I, _P]),
     "rn_pair_features_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_features": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "rn_extract_ws_bytes": (_Z, [_I, _I, _I]),
+    "rn_extract_features": (_I, [_P, _L, _L, _L, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "rn_f_phi_fwd": (_I, [_P] * 11 + [_I] * 6 + [_P]),
     "rn_f_phi_bwd_ws_bytes": (_Z, [_I, _I, _I, _I]),
     "rn_f_phi_nll_ws_bytes": (_Z, [_I]),
@@ -775,6 +777,24 @@ def pair_features(A, lda, F, code, B, npairs):
     ws = torch.empty(max(lib.rn_pair_features_ws_bytes(B, npairs, F), 16), dtype=torch.uint8, device=A.device)
     _check(lib.rn_pair_features(A.data_ptr(), lda, F, maxf.data_ptr(), avgf.data_ptr(), ws.data_ptr(), code, B, npairs, _stream()),
            "rn_pair_features")
+    return maxf, avgf
+
+
+def extract_features(x, Wts, biases, per_q, F):
+    """(maxf, avgf), each (B, F) fp32, of the input of g layer len(Wts) -- formed on chip from the objects x (B, n, k), never
+    materialised (rn_extract_features).  Wts[l]: (K_l, 256) fp32 transposed weights; biases[l]: (256,) or, with per_q[l], (B, 256)."""
+    lib = load()
+    B, n, k = x.shape
+    L = len(Wts)
+    maxf = torch.empty(B, F, dtype=torch.float32, device=x.device)
+    avgf = torch.empty(B, F, dtype=torch.float32, device=x.device)
+    ws = torch.empty(max(lib.rn_extract_ws_bytes(B, n, F), 16), dtype=torch.uint8, device=x.device)
+    wp = (C.c_void_p * max(L, 1))(*[w.data_ptr() for w in Wts])
+    bp = (C.c_void_p * max(L, 1))(*[b_.data_ptr() for b_ in biases])
+    pq = (C.c_int * max(L, 1))(*[int(bool(v)) for v in per_q])
+    sx = x.stride()
+    _check(lib.rn_extract_features(x.data_ptr(), sx[0], sx[1], sx[2], wp, bp, pq, L, F, maxf.data_ptr(), avgf.data_ptr(), ws.data_ptr(),
+                                   B, n, k, _stream()), "rn_extract_features")
     return maxf, avgf
 
 

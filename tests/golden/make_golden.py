@@ -155,9 +155,10 @@ def record_e2e(tag, cfg, b, seed, img_hw=128, T=20):
     print(tag, lp.shape, conv.shape)
 
 
-def record_extract(tag, cfg, b, seed, layer_idx=2):
+def record_extract(tag, cfg, b, seed, layer_idx=2, q_seed=None):
     """extract.py:49-74 semantics: hook the *input* of g_layers[k], strip the
-    trailing question columns, L2-normalise per pair, max / mean over pairs."""
+    trailing question columns, L2-normalise per pair, max / mean over pairs.
+    q_seed: a non-zero question embedding (pins how the question enters the layers in front of the hook)."""
     hyp = REF_HYP[cfg]
     rl = refmodel.RelationalLayer(hyp["rl_in_size"], formula.ADICT, hyp["lstm_hidden"], hyp, extraction=True)
     sd = formula.formula_rl_state(hyp, seed)
@@ -166,6 +167,8 @@ def record_extract(tag, cfg, b, seed, layer_idx=2):
     n, k, Q = 64, hyp["rl_in_size"] // 2, hyp["lstm_hidden"]
     x = torch.from_numpy(formula.formula_objects(b, n, k, seed + 1))
     q = torch.zeros(b, Q)                       # extract.py:103 feeds an all-zero question
+    if q_seed is not None:
+        q = torch.from_numpy(formula.hash_uniform((b, Q), q_seed, -1.0, 1.0))
     got = {}
     def hook(_m, i, o):
         feats = i[0].detach().view(b, n * n, -1)
@@ -178,7 +181,7 @@ def record_extract(tag, cfg, b, seed, layer_idx=2):
     with torch.no_grad():
         assert rl(x, q) is None                 # model.py:147-148
     np.savez_compressed(os.path.join(HERE, tag + ".npz"), max=got["max"], avg=got["avg"],
-                        meta=np.array(json.dumps(dict(cfg=cfg, b=b, seed=seed, layer_idx=layer_idx))))
+                        meta=np.array(json.dumps(dict(cfg=cfg, b=b, seed=seed, layer_idx=layer_idx, q_seed=q_seed))))
     print(tag, got["max"].shape)
 
 
@@ -239,6 +242,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "traj":
         record_train_traj("G-traj", "original-fp", 8, 4, seed=91)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "extract":
+        for cfg_ in ("original-fp", "ir-fp"):
+            for li in range(4):
+                record_extract("G-extract-%s-%d" % (cfg_, li), cfg_, 3, seed=82 + li, layer_idx=li, q_seed=90 + li)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "stress":
         # BASELINE.json configs[4] at its real size (B=32, 14x14 grid: M = 1,229,312 pair rows; ~12 GB, ~1 min on 8 cores)
         record_rl("G-fp196-b32", "original-fp", 32, 196, seed=52, light=True)
@@ -255,5 +263,8 @@ if __name__ == "__main__":
     record_e2e("G-e2e", "original-fp", 4, seed=71)
     record_e2e("G-e2e-ir", "ir-fp", 4, seed=72)
     record_extract("G-extract", "ir-fp", 4, seed=81)
+    for cfg_ in ("original-fp", "ir-fp"):       # every hook position of both 256-wide models, with a real question (N3)
+        for li in range(4):
+            record_extract("G-extract-%s-%d" % (cfg_, li), cfg_, 3, seed=82 + li, layer_idx=li, q_seed=90 + li)
     record_pretrained()
     record_train_traj("G-traj", "original-fp", 8, 4, seed=91)

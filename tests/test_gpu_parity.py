@@ -347,6 +347,70 @@ def test_extraction_native_op(pkg, precision, tol):
     assert gold.rel_err(mx.cpu().numpy(), g["max"]) <= tol and gold.rel_err(av.cpu().numpy(), g["avg"]) <= tol
 
 
+@pytest.mark.parametrize("precision", ["auto", "bf16"])
+@pytest.mark.parametrize("cfg", ["original-fp", "ir-fp"])
+@pytest.mark.parametrize("layer_idx", [0, 1, 2, 3])
+def test_extraction_fused_op_every_hook_position(pkg, cfg, layer_idx, precision):
+    """SURVEY 8f row N3 as specified: RelationalLayer.extract_features -> rn_extract_features forms the input of g layer
+    `layer_idx` on chip (pair rows in LDS, layers 0 .. layer_idx-1 in fp32 on the matrix pipe) -- no (B n^2, in) matrix, no stored
+    activation -- for EVERY hook position of both 256-wide models, layer 0 included (F = 52: the normalised [x_j | x_i] rows), with
+    a non-zero question (it enters as a per-question bias row at its injection layer).  Against the reference's own hook recipe
+    (extract.py:49-74) to fp32 accuracy, whatever `precision` the module trains in (the op is fp32 by design); the hook-compatible
+    path must give the same features."""
+    g = gold.load("G-extract-%s-%d" % (cfg, layer_idx))
+    meta = g["meta"]
+    hyp = dict(formula.HYP[cfg], precision=precision)
+    b, n, k, Q = meta["b"], 64, hyp["rl_in_size"] // 2, hyp["lstm_hidden"]
+    rl = pkg.RelationalLayer(hyp["rl_in_size"], formula.ADICT, Q, hyp, extraction=True)
+    rl.load_state_dict({k_: torch.from_numpy(v) for k_, v in formula.formula_rl_state(hyp, meta["seed"]).items()})
+    rl.cuda().eval()
+    x = torch.from_numpy(formula.formula_objects(b, n, k, meta["seed"] + 1)).cuda()
+    q = torch.from_numpy(formula.hash_uniform((b, Q), meta["q_seed"], -1.0, 1.0)).cuda()
+    calls = []
+    orig = pkg.rn_hip.extract_features
+    try:
+        pkg.rn_hip.extract_features = lambda *a, **kw: (calls.append(1), orig(*a, **kw))[1]
+        mx, av = rl.extract_features(x, q, layer_idx)
+    finally:
+        pkg.rn_hip.extract_features = orig
+    assert calls, "the fused op was not taken"
+    assert mx.shape == g["max"].shape == (b, 52 if layer_idx == 0 else 256)
+    assert gold.rel_err(mx.cpu().numpy(), g["max"]) <= 2e-5 and gold.rel_err(av.cpu().numpy(), g["avg"]) <= 2e-5
+    if precision == "auto":
+        got = {}
+
+        def hook(_m, i, _o):
+            feats = i[0].view(b, n * n, -1)
+            if layer_idx == hyp["question_injection_position"]:
+                feats = feats[:, :, :-Q]
+            feats = feats / feats.norm(2, 2, keepdim=True).clamp_min(1e-12)
+            got["max"], got["avg"] = feats.max(1)[0].cpu().numpy(), feats.mean(1).cpu().numpy()
+
+        hnd = rl.g_layers[layer_idx].register_forward_hook(hook)
+        assert rl(x, q) is None
+        hnd.remove()
+        assert gold.rel_err(got["max"], g["max"]) <= 1e-4 and gold.rel_err(got["avg"], g["avg"]) <= 1e-4
+
+
+def test_extraction_fused_op_ragged_object_count(pkg):
+    """n = 9 objects (a 3 x 3 grid) and n = 100: tiles with fewer than 64 valid rows / two tiles per (b, i) with a ragged second
+    one; against the oracle's restatement of the hook recipe."""
+    from oracle import rn_oracle as O
+    hyp = dict(formula.HYP["ir-fp"])
+    k, Q = hyp["rl_in_size"] // 2, hyp["lstm_hidden"]
+    sd = formula.formula_rl_state(hyp, 5)
+    params = formula.params_from_state(sd, 4)
+    rl = pkg.RelationalLayer(hyp["rl_in_size"], formula.ADICT, Q, hyp, extraction=True)
+    rl.load_state_dict({k_: torch.from_numpy(v) for k_, v in sd.items()})
+    rl.cuda().eval()
+    for n, li in ((9, 2), (100, 1), (100, 0)):
+        x = formula.formula_objects(2, n, k, 6 + n)
+        q = formula.hash_uniform((2, Q), 7, -1.0, 1.0)
+        mx_ref, av_ref = O.pair_features_np(x, q, params, hyp["question_injection_position"], li)
+        mx, av = rl.extract_features(torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda(), li)
+        assert gold.rel_err(mx.cpu().numpy(), mx_ref) <= 2e-5 and gold.rel_err(av.cpu().numpy(), av_ref) <= 2e-5, (n, li)
+
+
 def test_changing_batch_size_and_eval_train(pkg):
     """quirk C1 fixed: a different batch size after the first forward must work."""
     hyp = dict(formula.HYP["original-fp"])

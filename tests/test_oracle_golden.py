@@ -80,3 +80,20 @@ def test_full_model_restatement(tag):
     with torch.no_grad():
         lp = m(img, qst)
     assert gold.rel_err(lp.numpy(), g["log_probs"]) <= TOL
+
+
+@pytest.mark.parametrize("cfg", ["original-fp", "ir-fp"])
+@pytest.mark.parametrize("layer_idx", [0, 1, 2, 3])
+def test_extraction_restatement(cfg, layer_idx):
+    """oracle.pair_features_np against the features the REFERENCE's hook recipe (extract.py:49-74) produced for every hook
+    position of both 256-wide models, with a non-zero question (tests/golden/make_golden.py: record_extract)."""
+    g = gold.load("G-extract-%s-%d" % (cfg, layer_idx))
+    meta = g["meta"]
+    hyp = formula.HYP[cfg]
+    b, n, k, Q = meta["b"], 64, hyp["rl_in_size"] // 2, hyp["lstm_hidden"]
+    params = formula.params_from_state(formula.formula_rl_state(hyp, meta["seed"]), 4)
+    x = formula.formula_objects(b, n, k, meta["seed"] + 1)
+    q = formula.hash_uniform((b, Q), meta["q_seed"], -1.0, 1.0)
+    mx, av = O.pair_features_np(x, q, params, hyp["question_injection_position"], layer_idx)
+    assert mx.shape == g["max"].shape
+    assert gold.rel_err(mx, g["max"]) <= TOL and gold.rel_err(av, g["avg"]) <= TOL
