@@ -24,6 +24,8 @@ that is "f16s", the mode that meets the 1e-3 log-prob bar).  What the line carri
                    with that overlap off.
   sustained        the same graph replayed for --sustain seconds (default 3) right after the K timed steps: rate, ms/step and the
                    rocm-smi clocks / power sampled meanwhile -- K = 20 steps are 15 ms, too short for the chip's sustained clocks.
+  convergence      (--convergence STEPS) fp32 and the benched mode trained on a learnable synthetic task with the same seeds:
+                   loss curves, held-out accuracy, and the e4m3 copy guard's log.
   pair_build_k1    rn_pair_build_fwd launched on its own at the benched shape: 94.83 MB / duration vs 8 TB/s
                    (north_star's "HBM GB/s on the pair-build kernel"; the headline path itself builds two small
                    tables instead, reported as `pair_tables`).
@@ -350,6 +352,9 @@ def main():
     ap.add_argument("--no-other-modes", action="store_true", help="skip the extra timing of the other arithmetic modes")
     ap.add_argument("--no-parity", action="store_true", help="skip the live parity check against the golden fixtures")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--convergence", type=int, default=0, metavar="STEPS",
+                    help="also train STEPS steps on the learnable synthetic task in fp32 and in the benched mode (same seeds) and report "
+                         "both loss curves + held-out accuracy as `convergence` (train.convergence_run; ~15 s per mode at 300 steps)")
     ap.add_argument("--sustain", type=float, default=3.0,
                     help="seconds of back-to-back steps AFTER the timed K steps, same graph: reported as `sustained` (0: skip)")
     args = ap.parse_args()
@@ -508,6 +513,11 @@ def main():
                                   "hipGraph replay of fwd+bwd, eager all-reduce/clip/Adam")},
             "loss": float(loss.detach()),
         }
+        if args.convergence > 0 and world == 1:
+            from relationnetworks_clevr_amd import train as T
+            out["convergence"] = {"task": "train.SyntheticRelationalTask (colour / quadrant of one square; 25-step mean losses), B=64, Adam lr 1e-3, clip 50",
+                                  "fp32": T.convergence_run("fp32", steps=args.convergence, model_name=args.config),
+                                  prec: T.convergence_run(args.precision, steps=args.convergence, model_name=args.config)}
         if sustained:
             sustained["vs_value"] = sustained["value"] / out["value"]
             out["sustained"] = sustained

@@ -256,6 +256,12 @@ int rn_g_wgrad_blocked(const void* const* dZ, const int* dz_dtype, const void* c
 /* The ReLU gate of the last g layer as an e4m3 {0, 1} row-blocked image (M x 256 bytes, byte 0x38 = 1.0) from the layer-3 lane
  * masks of rn_g_chain_fwd_rr* (rn_g_chain_rr_mask_bytes(M) bytes): the dZ operand of a gate job.  M % 32 == 0. */
 int rn_relu_gate_image(const void* mask, void* img, int M, void* stream);
+/* Health of an e4m3 activation copy H_l, l = 0..2 (h_dtype = RN_FP8; fixed scale 1: values below 2^-10 flush to zero, values
+ * above 448 are clamped): mask = the layer's lane masks of the SAME forward call (which elements were positive before rounding),
+ * img = its row-blocked e4m3 image.  out4 (4 x uint64, ZEROED by the caller, accumulated with integer atomics): positive elements,
+ * positive elements whose byte is 0 (flushed), bytes at the clamp 0x7e, largest byte.  The caller decides what to do about a
+ * flushed fraction that is too large (dp.DataParallelTrainer switches to 16-bit copies). */
+int rn_fp8_copy_health(const void* mask, const void* img, unsigned long long* out4, int M, void* stream);
 /* Rq[b, f] (B, 256) fp32 = sum over the rows of question b of a 16-bit row-blocked image -- the per-question sums of dZ when
  * the splits above straddle questions.  rows_per_question % 8 == 0. */
 int rn_blocked_question_sums(const void* img, float* Rq, int M, int rows_per_question, void* stream);

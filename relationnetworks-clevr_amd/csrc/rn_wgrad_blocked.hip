@@ -516,6 +516,55 @@ extern "C" int rn_relu_gate_image(const void* mask, void* img, int M, void* stre
   return 0;
 }
 
+// Health of an e4m3 activation copy (rn_fp8_copy_health): how much of a layer's post-ReLU activation does NOT survive as an e4m3
+// byte.  The copies use a fixed scale of 1 (rn_common.h): values below 2^-10 flush to zero, values above 448 are clamped.  The
+// forward chain's lane masks say which elements were positive BEFORE rounding (swapped layers 0..2: word 4 j + r of a block, lane
+// n + 32 h -> row n, feature 8 j + 4 h + r), so a set gate bit over a zero byte is a flushed element.  A workgroup = one 32-row
+// block, a thread = one feature; integer counters (order-independent), accumulated with atomics:
+//   out[0] = positive elements (gate bits), out[1] = ... whose byte is 0, out[2] = bytes at the clamp (0x7e = 448), out[3] = largest byte.
+__global__ __launch_bounds__(256) void fp8_copy_health_kernel(const unsigned* __restrict__ mask, const unsigned char* __restrict__ img,
+                                                              unsigned long long* __restrict__ out) {
+  __shared__ unsigned red[4][4];
+  const long wt = blockIdx.x;
+  const int f = threadIdx.x, fb = f & 31;
+  const unsigned rowbits = mask[(wt * 8 + (f >> 5)) * 32 + 2 * (4 * (fb >> 3) + (fb & 3)) + ((fb >> 2) & 1)];   // bit n = row n of feature f
+  unsigned pos = 0, flushed = 0, sat = 0, mx = 0;
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const u32x4 cell = *reinterpret_cast<const u32x4*>(img + ((2 * wt + hf) * 256 + f) * 16);     // rows 16 hf .. + 15 of feature f
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned byte = (cell[r >> 2] >> (8 * (r & 3))) & 0xffu, bit = (rowbits >> (16 * hf + r)) & 1u;
+      pos += bit;
+      flushed += bit & (byte == 0u ? 1u : 0u);
+      sat += byte == 0x7eu ? 1u : 0u;
+      mx = byte > mx ? byte : mx;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    pos += __shfl_xor(pos, o); flushed += __shfl_xor(flushed, o); sat += __shfl_xor(sat, o);
+    const unsigned m2 = __shfl_xor(mx, o); mx = m2 > mx ? m2 : mx;
+  }
+  if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; red[0][w] = pos; red[1][w] = flushed; red[2][w] = sat; red[3][w] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(out + 0, (unsigned long long)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+    atomicAdd(out + 1, (unsigned long long)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
+    atomicAdd(out + 2, (unsigned long long)(red[2][0] + red[2][1] + red[2][2] + red[2][3]));
+    unsigned m4 = red[3][0]; for (int w = 1; w < 4; ++w) m4 = red[3][w] > m4 ? red[3][w] : m4;
+    atomicMax(out + 3, (unsigned long long)m4);
+  }
+}
+
+extern "C" int rn_fp8_copy_health(const void* mask, const void* img, unsigned long long* out4, int M, void* stream) {
+  RN_CHECK_ARG(mask && img && out4 && M > 0 && M % 32 == 0 && ((uintptr_t)mask | (uintptr_t)img) % 16 == 0 && (uintptr_t)out4 % 8 == 0,
+               "rn_fp8_copy_health: needs 16-byte aligned buffers and M %% 32 == 0 (M=%d)", M);
+  fp8_copy_health_kernel<<<M / 32, 256, 0, (hipStream_t)stream>>>((const unsigned*)mask, (const unsigned char*)img, out4);
+  RN_LAUNCH_CHECK("rn_fp8_copy_health");
+  return 0;
+}
+
 // Row-blocked image of a row-major (M, 256) matrix (tests / tools; the chains write the images themselves).
 //   src_dtype RN_BF16: 16-bit elements, 8-row blocks;  RN_FP8: bytes, 16-row blocks.  M % 16 == 0.
 __global__ __launch_bounds__(256) void to_blocked_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, long M, int es, int back) {

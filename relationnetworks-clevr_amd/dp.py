@@ -242,8 +242,13 @@ class DataParallelTrainer:
     collective, the clip and the optimizer stay eager (a handful of launches, and identical for any
     world size).  Inputs are copied into static buffers, so shapes must not change between steps."""
 
-    def __init__(self, model, optimizer, clip_norm: float | None = 50.0, group=None, use_graph: bool = False):
+    def __init__(self, model, optimizer, clip_norm: float | None = 50.0, group=None, use_graph: bool = False,
+                 copy_guard_every: int = 512, copy_guard_max_flushed: float = 0.05, copy_guard_max_clamped: float = 1e-3):
         self.model, self.opt, self.clip_norm, self.group = model, optimizer, clip_norm, group
+        # guard of the e4m3 activation copies (check_activation_copies): at step 1 and then every `copy_guard_every` steps; 0 = never
+        self.copy_guard_every, self.copy_guard_max_flushed, self.copy_guard_max_clamped = copy_guard_every, copy_guard_max_flushed, copy_guard_max_clamped
+        self.copy_guard_log = []
+        self._nstep = 0
         broadcast_module_state(model, 0, group)
         self.bucket = FlatGradBucket(model.parameters())
         self.use_graph = use_graph
@@ -260,6 +265,57 @@ class DataParallelTrainer:
         # (gloo moves the bucket through the host) keeps the all-reduce and the optimiser eager behind the replayed fwd + bwd.
         coll_in_graph = world == 1 or (OPT.graph_allreduce and dist.get_backend(group) == "nccl")
         self._opt_in_graph = (use_graph and self._fused_opt is not None and coll_in_graph and OPT.graph_adam)
+
+    def check_activation_copies(self, img, qst, label):
+        """The e4m3 copies of H_0..2 (kept for the weight gradients of g layers 1..3) use a FIXED scale of 1: a post-ReLU value
+        below 2^-10 becomes 0, one above 448 is clamped.  Fine for the released checkpoints (activations peak at 11) and for
+        default-initialised models -- but nothing in the step itself would notice a model that drifts out of that range.  This
+        runs ONE extra training forward on the given batch (eager, outside the step graph; BatchNorm buffers and the RNG state
+        are put back) with a probe that counts, per copy, the positive activations that were flushed to zero and the bytes at the
+        clamp (rn_fp8_copy_health), and switches the module to 16-bit copies (options.h8 = False, the step graph is re-captured)
+        when more than `copy_guard_max_flushed` of the positive activations of a layer are flushed or more than
+        `copy_guard_max_clamped` of its elements are clamped.  With several ranks the decision is the OR over ranks.
+        -> {"layers": {l: {"positive", "flushed", "clamped", "max_value"}}, "switched": bool} or None (no e4m3 copies in use)."""
+        if not (OPT.h8 and img.is_cuda):
+            return None
+        bufs = [(b_, b_.clone()) for b_ in self.model.buffers()]
+        rng = torch.cuda.get_rng_state(img.device)
+        RF.COPY_HEALTH_PROBE = probe = []
+        try:
+            with torch.enable_grad():
+                if hasattr(self.model, "forward_loss") and OPT.fused_loss:
+                    self.model.forward_loss(img, qst, label)
+                else:
+                    self.model(img, qst)
+        finally:
+            RF.COPY_HEALTH_PROBE = None
+            with torch.no_grad():
+                for b_, old in bufs:
+                    b_.copy_(old)
+            torch.cuda.set_rng_state(rng, img.device)
+        if not probe:
+            return None
+        rep, bad = {}, False
+        for l, t in probe:
+            pos, flushed, clamped, maxb = [int(v) for v in t.cpu().tolist()]
+            tot = max(pos, 1)
+            # e4m3 byte -> value (positive): exponent bits 6..3 (bias 7), mantissa bits 2..0
+            e, m = (maxb >> 3) & 15, maxb & 7
+            maxv = (m / 8.0) * 2.0 ** -6 if e == 0 else (1.0 + m / 8.0) * 2.0 ** (e - 7)
+            rep[l] = {"positive": pos, "flushed": flushed / tot, "clamped": clamped / tot, "max_value": maxv}
+            bad = bad or flushed / tot > self.copy_guard_max_flushed or clamped / tot > self.copy_guard_max_clamped
+        if self.world > 1:
+            flag = torch.tensor([1.0 if bad else 0.0], device=img.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            bad = bool(flag.item() > 0)
+        out = {"step": self._nstep, "layers": rep, "switched": bad}
+        self.copy_guard_log.append(out)
+        if bad:
+            import warnings
+            warnings.warn("e4m3 activation copies lose too much (%s): switching to 16-bit copies" % rep)
+            OPT.h8 = False
+            self._graph = None                                 # (the captured step has the e4m3 kernels baked in)
+        return out
 
     def _fwd_bwd(self, img, qst, label):
         self.bucket.detach_()
@@ -308,6 +364,9 @@ class DataParallelTrainer:
         return graph
 
     def step(self, img, qst, label):
+        self._nstep += 1
+        if self.copy_guard_every and (self._nstep == 1 or self._nstep % self.copy_guard_every == 0):
+            self.check_activation_copies(img, qst, label)
         if self.use_graph:
             if self._graph is None:
                 self._capture(img, qst, label)

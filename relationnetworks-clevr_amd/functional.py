@@ -225,6 +225,11 @@ def is_unit_loss_grad(g):
     return t is not None and g.data_ptr() == t.data_ptr() and g.numel() == 1
 
 
+# Set to a list by dp.DataParallelTrainer.check_activation_copies(): the next training forward appends (layer, counters) of every
+# e4m3 activation copy it writes (rn_fp8_copy_health).  None: no probe, nothing is launched.
+COPY_HEALTH_PROBE = None
+
+
 class RRMasks:
     """ReLU lane masks of the register-resident forward chain: what the backward pass keeps INSTEAD of the last
     activation (rn_g_chain_fwd_rr / rn_g_chain_bwd_rr)."""
@@ -600,6 +605,10 @@ class RelationalFunction(torch.autograd.Function):
                                          wfrag=(packed.frag_hi, packed.frag_lo) if f16s else packed.frag,
                                          w0T=packed.w0T if alg_fwd else None, inj_w=inj_w, coord=coord, lazy_xg=True)
         G = plan.widths[-1]
+        if COPY_HEALTH_PROBE is not None and need_grad and isinstance(HL, RRMasks):
+            for l in range(1, L):                              # inputs[l] = the copy of H_{l-1}
+                if inputs[l] is not None and inputs[l].dtype in H.FP8_DTYPES:
+                    COPY_HEALTH_PROBE.append((l - 1, H.fp8_copy_health(HL.masks[l - 1], inputs[l], inputs[l].numel() // G)))
         if xg is None:
             xg = torch.empty(B, G, dtype=torch.float32, device=dev)
             H.pair_sum_fwd(HL, G, xg, code, B, n * n, G)

@@ -61,6 +61,7 @@ SIGNATURES = {
     "rn_blocked_question_sums": (_I, [_P, _P, _I, _I, _P]),
     "rn_g_wgrad_blocked": (_I, [_P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _I, _P]),
     "rn_relu_gate_image": (_I, [_P, _P, _I, _P]),
+    "rn_fp8_copy_health": (_I, [_P, _P, _P, _I, _P]),
     "rn_pair_reduce_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_reduce_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_pair_dx_dq": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _I, _I, _I, _I, _I, _P]),
@@ -778,6 +779,14 @@ def pair_features(A, lda, F, code, B, npairs):
     _check(lib.rn_pair_features(A.data_ptr(), lda, F, maxf.data_ptr(), avgf.data_ptr(), ws.data_ptr(), code, B, npairs, _stream()),
            "rn_pair_features")
     return maxf, avgf
+
+
+def fp8_copy_health(mask, img, M):
+    """-> int64 tensor (4,) on the device: positive elements, flushed (positive but byte 0), clamped (byte 0x7e), largest byte of
+    the e4m3 copy `img` of a swapped layer (0..2) whose lane masks are `mask` (rn_fp8_copy_health)."""
+    out = torch.zeros(4, dtype=torch.int64, device=img.device)
+    _check(load().rn_fp8_copy_health(mask.data_ptr(), img.data_ptr(), out.data_ptr(), M, _stream()), "rn_fp8_copy_health")
+    return out
 
 
 def extract_features(x, Wts, biases, per_q, F):

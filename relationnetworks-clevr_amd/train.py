@@ -76,6 +76,78 @@ class SyntheticClevr:
             yield {"image": img, "question": qst, "answer": torch.randint(1, self.ad + 1, (B, 1), generator=g)}
 
 
+class SyntheticRelationalTask(SyntheticClevr):
+    """A LEARNABLE stand-in for CLEVR (no dataset in this environment): the answer is a function of the image AND the question,
+    so a training run has something to converge to -- what the convergence checks of the arithmetic modes train on
+    (tests/test_convergence.py, bench.py --convergence).  Image: uniform noise in [0, 0.3) with ONE 40 x 40 square of one of
+    three colours (a single channel at 0.9) centred in one of the four quadrants.  Question: 20 tokens, all 3 except the LAST
+    one, which asks 1 = "which colour?" or 2 = "which quadrant?" (after the reference's question reversal, utils.py:138-141, that
+    token comes first -- so the batches put it first and load_tensor_data flips it to the end).  Answer (1-based like the
+    reference's, utils.py:149): colour -> 1..3, quadrant -> 4..7.  Same collate format as SyntheticClevr."""
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed)
+        hw = self.hw
+        side, q2 = (5 * hw) // 16, hw // 2
+        for _ in range(len(self)):
+            B = self.bs
+            img = torch.rand(B, 3, hw, hw, generator=g) * 0.3
+            colour = torch.randint(0, 3, (B,), generator=g)
+            quad = torch.randint(0, 4, (B,), generator=g)
+            kind = torch.randint(1, 3, (B,), generator=g)
+            for s_ in range(B):
+                cy, cx = q2 // 2 + (int(quad[s_]) // 2) * q2, q2 // 2 + (int(quad[s_]) % 2) * q2
+                img[s_, int(colour[s_]), cy - side // 2:cy + side // 2, cx - side // 2:cx + side // 2] = 0.9
+            qst = torch.full((B, self.max_len), 3, dtype=torch.int64)
+            qst[:, 0] = kind
+            ans = torch.where(kind == 1, colour + 1, quad + 4).reshape(B, 1)
+            yield {"image": img, "question": qst, "answer": ans}
+
+
+def convergence_run(precision, steps=400, batch=64, lr=1e-3, seed=0, device="cuda", h8=None, eval_batches=4, log_every=25,
+                    model_name="original-fp", use_graph=True):
+    """Train `model_name` for `steps` Adam steps (clip 50, weight decay 1e-4: train.py:45-46,330) on SyntheticRelationalTask in the
+    arithmetic mode `precision`, same seeds whatever the mode -> {"loss": [mean loss per `log_every` steps], "final_loss",
+    "accuracy" (held-out batches, eval mode), "copy_guard": the trainer's e4m3 guard log}.  The run the convergence test and
+    bench.py --convergence compare across modes."""
+    import contextlib
+    try:
+        from . import options as _opt
+    except ImportError:
+        import options as _opt                                   # type: ignore
+    hyp = dict(json.load(open(os.path.join(_HERE, "config.json")))["hyperparams"][model_name], precision=precision)
+
+    class _A:
+        qdict_size, adict_size = 82, 28
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(open(os.devnull, "w")):
+        model = RN(_A, hyp)
+    model.cuda(torch.device(device)) if str(device).startswith("cuda") else None
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=1e-4)
+    ctx = _opt.override(h8=h8) if h8 is not None else contextlib.nullcontext()
+    with ctx:
+        tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0, use_graph=use_graph)
+        data = SyntheticRelationalTask((steps + eval_batches) * batch, batch, seed=seed + 1)
+        it = iter(data)
+        curve, acc_l = [], []
+        for st in range(steps):
+            img, qst, lab = load_tensor_data(next(it), device)
+            acc_l.append(tr.step(img, qst, lab).detach().clone())
+            if (st + 1) % log_every == 0:
+                curve.append(float(torch.stack(acc_l).mean()))
+                acc_l = []
+        model.eval()
+        hit = tot = 0
+        with torch.no_grad():
+            for _ in range(eval_batches):
+                img, qst, lab = load_tensor_data(next(it), device)
+                hit += int((model(img, qst).argmax(1) == lab).sum())
+                tot += lab.numel()
+    return {"precision": precision, "h8": _opt.OPT.h8 if h8 is None else h8, "steps": steps, "batch": batch, "lr": lr, "loss": curve,
+            "final_loss": curve[-1], "accuracy": hit / tot, "copy_guard": tr.copy_guard_log}
+
+
 # -------------------------------------------------------------------------------------- schedule
 def lr_for_epoch(epoch, base_lr=5e-6, lr_max=5e-4, lr_gamma=2.0, lr_step=20):
     """Learning rate in effect DURING `epoch` (1-based) of a run started at epoch 1, reproducing the
