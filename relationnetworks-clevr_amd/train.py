@@ -111,10 +111,8 @@ def convergence_run(precision, steps=400, batch=64, lr=1e-3, seed=0, device="cud
     "accuracy" (held-out batches, eval mode), "copy_guard": the trainer's e4m3 guard log}.  The run the convergence test and
     bench.py --convergence compare across modes."""
     import contextlib
-    try:
-        from . import options as _opt
-    except ImportError:
-        import options as _opt                                   # type: ignore
+    import sys
+    _opt = sys.modules[type(dp.OPT).__module__]                  # the options module dp imported (package or flat import alike)
     hyp = dict(json.load(open(os.path.join(_HERE, "config.json")))["hyperparams"][model_name], precision=precision)
 
     class _A:
