@@ -495,6 +495,59 @@ def test_g_chain_fwd_rr_alg0(H, mode, B, n):
     assert rel(part.cpu().numpy(), ref.reshape(M // 256, 256, G).sum(1)) <= tol
 
 
+
+def f16s_alg0_emulation(x, q, Ws, bs, n, njp):
+    """float64 emulation of the FACTORED f16s chain's arithmetic (rn_g_chain_fwd_rr_f16s_alg0; model.py:108-152) on the padded pair
+    space: layer 0 = fp16(x_j) @ (hi + lo of W0[:, :k])^T + [W0[:, k:2k] x_i + W0[:, 2k:] q + b0] (the bracket exact), layers 1..3 =
+    the fp16-rounded previous activation @ the tile's dithered hi image; -> (list of pre-activations z_l (Mp, G), valid-row mask
+    (Mp,), the EXACT fp32-model activations of the last layer (Mp, G))."""
+    B, _, k = x.shape
+    G, L = Ws[0].shape[0], len(Ws)
+    f16r = lambda a: np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+    Mp = B * n * njp
+    b_of, i_of, j_of = np.divmod(np.arange(Mp) // njp, n)[0], (np.arange(Mp) // njp) % n, np.arange(Mp) % njp
+    valid = j_of < n
+    jj = np.where(valid, j_of, 0)
+    xj = np.where(valid[:, None], x[b_of, jj], 0.0)
+    W0 = Ws[0].astype(np.float64)
+    wh = f16r(Ws[0][:, :k]); wl = f16r(Ws[0][:, :k] - wh)
+    brack = x[b_of, i_of].astype(np.float64) @ W0[:, k:2 * k].T + q[b_of].astype(np.float64) @ W0[:, 2 * k:].T + bs[0]
+    zs = [f16r(xj).astype(np.float64) @ (wh.astype(np.float64) + wl.astype(np.float64)).T + brack]
+    exact = np.maximum(xj.astype(np.float64) @ W0[:, :k].T + brack, 0)
+    timg = (np.arange(Mp) // 256) % F16S_V
+    prev = f16r(np.maximum(zs[0], 0)).astype(np.float64)
+    for l in range(1, L):
+        z = np.empty((Mp, G))
+        for d, im in enumerate(dither_images(Ws[l])):
+            z[timg == d] = prev[timg == d] @ im.astype(np.float64).T + bs[l]
+        zs.append(z)
+        exact = np.maximum(exact @ Ws[l].astype(np.float64).T + bs[l], 0)
+        prev = f16r(np.maximum(z, 0)).astype(np.float64)
+    return zs, valid, exact
+
+
+def check_against_f16s_emulation(zs, valid, exact, Hs, masks, part, M_tiles_rows, n_parts_per_tile=1, grp_tol=3e-4):
+    """The kernel's stored bf16 copies (row-major, already un-blocked), lane masks and per-tile pair-sum partials against the
+    emulation: copies to 1 bf16 ulp, masks = the gates of the kernel's own pre-activations up to rounding-noise elements, pair
+    sums to 1e-3, and to 3e-4 of the EXACT chain over groups of V tiles (one of each dithered image)."""
+    L = len(zs)
+    Mp, G = zs[0].shape
+    for l in range(L):
+        ref = np.maximum(zs[l], 0) * valid[:, None]
+        if Hs is not None and l < 3:
+            got = Hs[l].float().cpu().numpy() * valid[:, None]
+            assert rel(got, bf16_round(ref)) <= BF16_ULP, l
+        if masks is not None:
+            bad = rr_mask_decode(masks[l], Mp, l) != ((zs[l] > 0) & valid[:, None])
+            assert np.abs(zs[l][bad]).max(initial=0.0) <= 2e-3 * np.abs(zs[l]).max() and bad.mean() <= 2e-3, (l, bad.sum())
+    last = np.maximum(zs[-1], 0) * valid[:, None]
+    got = part.cpu().numpy().reshape(Mp // 256, n_parts_per_tile, G).sum(1)
+    assert rel(got, last.reshape(Mp // 256, 256, G).sum(1)) <= 1e-3
+    nt = (Mp // 256) // F16S_V * F16S_V
+    e_grp = rel(got[:nt].reshape(nt // F16S_V, F16S_V, G).sum(1), (exact * valid[:, None])[:nt * 256].reshape(nt // F16S_V, 256 * F16S_V, G).sum(1))
+    assert e_grp <= grp_tol, e_grp
+
+
 @pytest.mark.parametrize("mode,B,n", [("train", 19, 64), ("infer", 2, 32)])
 def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
     """f16s arithmetic on the factored first layer: must agree with rn_g_chain_fwd_rr_f16s on the explicitly built fp16 pair
@@ -526,6 +579,10 @@ def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
     H.g_chain_fwd_rr_f16s(P16, K0, hiP, loP, bd, HsP, mP, K0, pP, M, G)
     torch.cuda.synchronize()
     HsA, HsP = unblock_h(HsA), unblock_h(HsP)
+    # the direct oracle leg: the factored kernel against the float64 emulation of ITS arithmetic and against
+    # the exact chain -- not only against the sibling kernel on the pair matrix (below)
+    zs, valid, exact = f16s_alg0_emulation(x, q, Ws, bs, n, n)
+    check_against_f16s_emulation(zs, valid, exact, HsA, mA, pA, M)
     assert rel(pA.cpu().numpy(), pP.view(M // 256, 8, G).sum(1).cpu().numpy()) <= 2e-3
     if train:
         for l in range(3):
@@ -602,6 +659,10 @@ def test_g_chain_fwd_rr_f16s_alg0_padded(H, B, n):
     H.g_chain_fwd_rr_f16s(P16, K0, hiP, loP, bd, HsP, mP, K0, None, M, G)
     torch.cuda.synchronize()
     HsA, HsP = unblock_h(HsA), unblock_h(HsP)
+    # the direct oracle leg on the PADDED pair space (njp = 224 for the 14 x 14 grid): float64 emulation of the kernel's arithmetic
+    zs, vrow, exact = f16s_alg0_emulation(x, q, Ws, bs, n, njp)
+    # (groups of V tiles hold different numbers of valid rows here: the image offsets cancel less evenly than on whole tiles)
+    check_against_f16s_emulation(zs, vrow, exact, HsA, mA, pA, Mp, n_parts_per_tile=2, grp_tol=1e-3)
     valid = lambda t: t.view(B * n, njp, -1)[:, :n].reshape(M, -1)
     # inference variant (no stores): the same pair sums, bitwise
     pI = torch.full_like(pA, float("nan"))
