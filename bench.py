@@ -418,7 +418,7 @@ def main():
         # The contract's K = 20 steps last ~15 ms -- too short for the chip to reach its sustained clocks under matrix load.
         # The same replay for `--sustain` seconds (step count fixed beforehand from the timed region's rate, so that every
         # rank runs the same number), bracketed like the timed region; rocm-smi clocks sampled by a thread meanwhile (rank 0).
-        n_sus = max(int(args.sustain / max(dt / args.steps, 1e-6)), args.steps)
+        n_sus = max(int(args.sustain / max(max_over_ranks(dt, world, dev) / args.steps, 1e-6)), args.steps)   # (the SAME count on every rank)
         clocks = ClockSampler() if rank == 0 else None
         if clocks:
             clocks.start()
@@ -539,19 +539,17 @@ def main():
             kern = {kk: {"algorithmic_flops": fl[kk], "ms": per[kk], "achieved_tflops": fl[kk] / (per[kk] * 1e-3) / 1e12,
                          "frac": fl[kk] / (per[kk] * 1e-3) / 1e12 / peak, "ms_serial": per_step.get(kk)} for kk in per}
             inj_l = hyp["question_injection_position"]
-            njp = n if n % 32 == 0 else ((n + 31) // 32 * 32 if (prec == "f16s" and n % 4 == 0 and inj_l == 0) else 0)   # padded j axis
-            alg0 = (prec in ("bf16", "f16s") and hyp["g_layers"] == [256] * 4 and njp > 0 and (B * n * njp) % 256 == 0 and k <= 32
-                    and (inj_l == 0 or (inj_l == 2 and (n * n) % 256 == 0)))
-            # executed flops: the factored first layer runs K = 64 on chip and the question (wherever it is injected) enters as
-            # a bias row, so every layer is a K = 64 / 256 product; the split-weight mode runs every product twice (hi + lo).
+            # ONE shape predicate, the module's own (functional.chain_ok): the register-resident chains run iff the mode is "f16s"
+            RFm = pkg.functional
+            plan = model.rl._plan(k)
+            alg0 = prec == "f16s" and RFm.chain_ok(plan, B, n)
+            njp = (n if inj_l else RFm.padded_j(n)) if alg0 else n
+            # executed flops: the factored first layer runs K = 64 on chip (two passes: hi + lo weights) and the question, wherever
+            # it is injected, enters as a bias row, so layers 1..3 are K = 256 products (one pass on tile-dithered images).
             # The algorithmic count stays the reference formulation's (model.py:130-152).
             Mx = B * n * njp if alg0 else M                           # (executed rows: the padded pair space where n % 32 != 0)
-            executed = 2.0 * Mx * 256 * (64 + 3 * 256) if alg0 else float(fwd)
-            if prec == "f16s" and alg0:
-                executed = 2.0 * Mx * 256 * (2 * 64 + 3 * 256)        # two passes on layer 0, one on the tile-dithered images of layers 1..3
-            elif prec == "f16s":
-                executed *= 2.0
-            kname = {"bf16": "g_chain_rr_kernel", "f16s": "g_chain_rr_f16s_kernel"}.get(prec) if alg0 else None
+            executed = 2.0 * Mx * 256 * (2 * 64 + 3 * 256) if alg0 else float(fwd)
+            kname = "g_chain_rr_f16s_kernel" if alg0 else None
             traffic, tsrc = (None, None)
             if kname and B == 64 and n == 64 and inj_l == 0:        # (the profiled shape: original-fp, B=64, 8x8)
                 traffic, tsrc = hbm_traffic_from_profiles(re.escape(kname) + "<4, true")       # the training variant
@@ -591,7 +589,7 @@ def main():
                 out["pair_build_k1"] = pair_build_k1(H, B, n, k, hyp["lstm_hidden"] if hyp["question_injection_position"] == 0 else 0, dev)
         if world == 1 and not args.no_other_modes:
             others = {}
-            for p2 in ("bf16", "f16s", "fp32"):
+            for p2 in ("f16s", "fp32", "bf16"):                         # ("bf16": the per-layer kernels -- slower AND less accurate than the default)
                 if p2 == prec:
                     continue
                 r = mode_rate(pkg, dp, base_hyp, p2, dev, img, qst, lab, B)

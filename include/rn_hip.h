@@ -20,8 +20,8 @@
  * Storage dtypes of the pair / activation / packed-weight buffers:
  *   RN_BF16 : bf16 storage, bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate.
  *   RN_F32  : fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32) -- exact-fp32 parity mode.
- *   RN_F16  : accepted by rn_pair_build_fwd / rn_pack_matrix(_split) only: operands of the "f16s"
- *             forward chain (fp16 activations x fp16 hi+lo split weights, rn_g_chain_fwd_f16s).
+ *   RN_F16  : accepted by rn_pair_build_fwd / rn_pack_matrix only (an fp16 pair matrix: tools, K1 measurements).
+ *   RN_FP8  : OCP e4m3 bytes -- the activation copies the forward chain keeps for the weight gradients (h_dtype / a_dtype).
  * Row index of every "pair" matrix: r = (b*n + i)*n + j   (model.py:127).
  */
 #ifndef RN_HIP_H
@@ -44,6 +44,25 @@ enum { RN_RELU = 1, RN_ACCUMULATE = 2 };
 int rn_abi_version(void);
 const char* rn_last_error(void);
 
+/* Bytes of caller-provided scratch (`ws`, `sync_ws`, mask buffers) an entry point needs for a shape -- ONE getter for all of them:
+ * op names the entry point, a..d are its shape arguments in the order given here (unused ones 0). */
+enum {
+  RN_WS_RR_MASK = 0,          /* (M)                                  one lane-mask buffer of the register-resident chains       */
+  RN_WS_PAIR_SUM = 1,         /* (B, npairs, G)                       rn_pair_sum_fwd                                             */
+  RN_WS_WGRAD = 2,            /* (M, N, K)                            rn_g_linear_bwd_wgrad                                       */
+  RN_WS_WGRAD_BLOCKED = 3,    /* (M, rows_per_question, njobs, aligned) rn_g_wgrad_blocked                                        */
+  RN_WS_PAIR_REDUCE = 4,      /* (B, n, G)                            rn_pair_reduce_bwd                                          */
+  RN_WS_WGRAD0 = 5,           /* (B, n, N)                            rn_wgrad0_from_reductions                                   */
+  RN_WS_PAIR_FEATURES = 6,    /* (B, npairs, F)                       rn_pair_features                                            */
+  RN_WS_EXTRACT = 7,          /* (B, n, F)                            rn_extract_features                                         */
+  RN_WS_F_PHI_BWD = 8,        /* (B, F1, F2, A)                       rn_f_phi_bwd*, rn_f_phi_fwd_bwd_from_partials               */
+  RN_WS_F_PHI_NLL = 9,        /* (B)                                  sync_ws of the f_phi launches that carry the loss           */
+  RN_WS_CLIP_ADAM = 10,       /* ()                                   rn_clip_adam_step*                                          */
+  RN_WS_CONV_BWD_WEIGHT = 11, /* (N, Cin, H, W)                       rn_conv3x3s2_bwd_weight, rn_bn_relu_bwd_conv_wgrad          */
+  RN_WS_BN_RELU = 12          /* (N, C, HW)                           rn_bn_relu_fwd / _bwd                                       */
+};
+size_t rn_workspace_bytes(int op, int a, int b, int c, int d);
+
 /* K1 -- fused pair-expand + coord-tag carry + question broadcast.
  * Replaces model.py:112-127 (+ :135-140 when the question is injected at g layer 0).
  *   P[r, 0:k]      = x[b, j, :]      P[r, k:2k] = x[b, i, :]
@@ -65,11 +84,6 @@ int rn_qst_broadcast(const float* q, long sqb, void* A, int dtype, int B, int n,
 int rn_pack_matrix(const float* src, long sr, long sc, int R, int C, void* dst, int dtype, int ld, int Rpad,
                    void* stream);
 
-/* fp16 hi/lo split of a fp32 matrix: hi = fp16(src), lo = fp16(src - hi) (both zero padded like
- * rn_pack_matrix) -- weight operands of rn_g_chain_fwd_f16s. */
-int rn_pack_matrix_split(const float* src, long sr, long sc, int R, int C, void* hi, void* lo, int ld, int Rpad,
-                         void* stream);
-
 /* K2 -- one g_theta layer:  H = relu(A @ W^T + bias)      (model.py:141-145)
  * A: (M, lda) dtype, reduction length K (K % 64 == 0, columns >= true K are zero),
  * Wp: (N, ldw) packed dtype (rn_pack_matrix), bias: fp32 (N), H: (M, ldh) dtype.
@@ -77,75 +91,23 @@ int rn_pack_matrix_split(const float* src, long sr, long sc, int R, int C, void*
 int rn_g_linear_fwd(const void* A, int lda, const void* Wp, int ldw, const float* bias, void* H, int ldh,
                     int dtype, int M, int N, int K, void* stream);
 
-/* Fused K2 chain + K3 partials (bf16 storage; the un-fused entry points above stay the general
- * path).  Runs all L g layers (model.py:130-145) for every T-row tile of P with the 256-wide
- * activation tile resident in LDS; each activation is written once to H[l] (M, 256) -- or not at
- * all when H or H[l] is NULL (inference) -- and never read back.  xg_part (M/T, 256) fp32 receives
- * the per-tile column sums of the last activation (model.py:151-152) -- pass NULL when n*n is not a
- * multiple of T (tiles straddle questions; use rn_pair_sum_fwd on H[L-1] instead); reduce them per question
- * with rn_pair_sum_fwd(xg_part, ..., RN_F32, B, n*n/T, 256).
- * Wp[l]: packed (256, K[l]) weights with ld == K[l]; K[0] % 64 == 0, K[0] <= 256, K[l>0] == 256;
- * Wp / bias / H / K are HOST arrays of L entries.  G == 256; M must be a multiple of the tile
- * height T = rn_g_chain_tile() (128) and xg_part, when given, has M/T rows. */
-int rn_g_chain_tile(void);
-int rn_g_chain_fwd(const void* P, int ldp, const void* const* Wp, const float* const* bias, void* const* H,
-                   const int* K, float* xg_part, int dtype, int M, int L, int G, void* stream);
-
-/* "f16s" forward chain: same tiling as rn_g_chain_fwd, but the LDS-resident activation tile and P are
- * fp16 and every product runs twice on v_mfma_f32_32x32x16_f16 against the hi and lo halves of the
- * split weights (fp32 accumulate).  Weight rounding -- the systematic error that keeps single-pass
- * bf16 at 1e-2 -- drops out: log-probs land within ~2e-4 of the fp32 reference (bar: 1e-3).
- * P: (M, ldp) fp16; Whi/Wlo[l]: (256, K[l]) fp16 (rn_pack_matrix_split); H[l]: (M, 256) **bf16** copies of
- * the activations for the (bf16) backward, may be NULL.  Other arguments as rn_g_chain_fwd. */
-int rn_g_chain_fwd_f16s(const void* P, int ldp, const void* const* Whi, const void* const* Wlo,
-                        const float* const* bias, void* const* H, const int* K, float* xg_part, int M, int L,
-                        int G, void* stream);
-
-/* Register-resident chains (rn_chain_rr.hip): the headline shape family -- L == 4, G == 256, question
- * injected at layer 0 with a padded layer-0 reduction length K0 of 192 or 256, M % 256 == 0.  Same
- * arithmetic as rn_g_chain_fwd / rn_g_chain_bwd (bf16 operands, fp32 accumulate), different mapping:
- * 8 waves x 32 pair rows per workgroup, the activation stays in MFMA operand registers from layer to
- * layer, LDS carries only the weight stream.
- *
- * Forward.  Wf[l]: fragment-major bf16 images (128 KB each) written by rn_pack_matrix_frag -- layer 0
- * packed `natural` (its operand is read from the P rows), layers 1..3 permuted (their operand is the
- * previous layer's MFMA output).
- * H: NULL / four NULLs (inference; xg_part required), all four (M, 256) bf16 activations, or -- with
- *    mask -- H[0..2] only (H[3] NULL): nobody needs the last activation once its pair sum and its ReLU
- *    mask are produced on chip.  H[0..2] are written as ROW-BLOCKED images (see rn_g_wgrad_blocked, their only
- *    reader); a stored H[3] (read by rn_pair_sum_fwd) is row-major.
- * mask: NULL, or four buffers of rn_g_chain_rr_mask_bytes(M) = 32 M bytes: the ReLU gate (pre-activation
- *    > 0) of every element of layer l as 64-bit LANE masks in the kernel's own accumulator layout
- *    (opaque; the consumer is rn_g_chain_bwd_rr).  Requires H[0..2].
- * xg_part: (M/32, 256) fp32 sums of the UN-rounded last activation over each wave's 32 pair rows, or NULL;
- *    requires n*n % 32 == 0 -- reduce with rn_pair_sum_fwd(xg_part, 256, xg, ws, RN_F32, B, n*n/32, 256). */
+/* Register-resident chains (rn_chain_rr.hip): the headline shape family -- L == 4, G == 256, at most 32 features per object,
+ * question injected at layer 0 or 2.  8 waves x 32 pair rows per workgroup; the activation stays in MFMA operand registers from
+ * layer to layer, LDS carries only the weight stream.  The forward chain is rn_g_chain_fwd_rr_f16s_alg0 (declared with the tables
+ * of the factored first layer, below); what it leaves for the backward pass:
+ *   H[0..2]: copies of the activations as ROW-BLOCKED images (see rn_g_wgrad_blocked, their only reader), e4m3 or bf16;
+ *   mask:    four buffers of rn_workspace_bytes(RN_WS_RR_MASK, M) = 32 M bytes: the ReLU gate (pre-activation > 0) of every
+ *            element of layer l as 64-bit LANE masks in the kernel's own accumulator layout (opaque; the consumers are
+ *            rn_g_chain_bwd_rr* and rn_fp8_copy_health);
+ *   xg_part: fp32 sums of the UN-rounded last activation, one row per 256-row tile.
+ * rn_g_chain_rr_tile() = 256: the tile height (M and, with the question at layer 2, n*n must be multiples of it). */
 int rn_g_chain_rr_tile(void);
-size_t rn_g_chain_rr_mask_bytes(int M);
-int rn_g_chain_fwd_rr(const void* P, int ldp, const void* const* Wf, const float* const* bias, void* const* H,
-                      void* const* mask, int K0, float* xg_part, int M, int L, int G, void* stream);
-
-/* f16s forward in the register-resident mapping (the parity-grade fast mode): P16 (M, ldp) fp16, fp16 operand registers
- * (activations saturate at 65504), fp32 accumulate.
- *   layer 0:     two MFMA passes, against Whi[0] = fp16(W_0) and Wlo[0] = fp16(W_0 - hi) (fragment-major images,
- *                rn_pack_matrix_frag_many modes 4 | 1 and 8 | 1);
- *   layers 1..3: ONE pass on TILE-DITHERED hi images: Whi[l] holds `dither` (1, 2, 4, 8; the module uses 4) images, 65536 fp16
- *                apart, image d = fp16(W + ((d + 1/2) / dither - 1/2) ulp_fp16(W)) (mode 4 | dither << 8), and 256-row tile t
- *                multiplies image t mod dither: the weight rounding error no longer has the same sign for all pairs of a
- *                question and averages out in the pair sum (model.py:151-152) like the activation rounding does.  Wlo[1..3]
- *                are not read (may be NULL).  Error against the fp32 reference on the released checkpoints: 1.7e-4 / 1.9e-4
- *                (original-fp / ir-fp; one plain pass: 2.6e-3; the bar is 1e-3).
- * H (bf16 copies) / mask / xg_part as rn_g_chain_fwd_rr; supported output sets: inference (no H), training (H[0..2] + masks +
- * xg_part), all four H without masks. */
-/* h_dtype = RN_FP8 (K0 == 192, the two training output sets): H[0..2] receive e4m3 bytes (as rn_g_chain_fwd_rr_f16s_alg0), a stored
- * H[3] stays bf16 (rn_pair_sum_fwd reads it). */
-int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, const void* const* Wlo, int dither, const float* const* bias,
-                           void* const* H, int h_dtype, void* const* mask, int K0, float* xg_part, int M, int L, int G, void* stream);
 
 /* Backward (pair-sum broadcast + ReLU gates + the three dgrad steps):
  *   dZ[0]   = dxg[b] * gate_3                         b = question of the pair row
  *   dZ[s+1] = (dZ[s] @ W_{3-s}) * gate_{2-s}          s = 0, 1, 2
  * gate_l = mask[l] of the forward call.  Wtf[s]: fragment-major image of W_{3-s}^T, i.e.
- * rn_pack_matrix_frag(W, 1, in_features, 256, 256, dst, natural = (s == 0)).  All four dZ (M, 256) bf16 are
+ * an entry (W, sr = 1, sc = in_features, 256, 256, dst, natural = (s == 0)) of rn_pack_matrix_frag_many.  All four dZ (M, 256) bf16 are
  * written: dZ[0..2] (layers 3..1, read only by rn_g_wgrad_blocked) as ROW-BLOCKED 16-bit images, dZ[3] (layer 0, read by the
  * pair reduction) row-major.  dZ[0] may be NULL (rn_g_wgrad_blocked's gate job works from the masks instead).  rows_per_question = n*n (any
  * value dividing M). */
@@ -167,34 +129,22 @@ int rn_g_chain_bwd_rr_red(const float* dxg, const void* const* mask, const void*
                           float* rj_part, float* ri_part, int tiles_per_unit, void* stream);
 int rn_pair_reduce_parts(const float* rj_part, const float* ri_part, float* Rj, float* Ri, float* Rq, int B, int n, int G, int nu,
                          void* stream);
-/* MFMA-fragment-major weight image for rn_g_chain_fwd_rr: dst (65536 bf16) gets, for output block ob,
- * K16 step ks, lane, element e:  src[32 ob + lane % 32][kidx] (0 beyond R rows / C columns) with
- *   natural != 0:  kidx = 16 ks + 8 (lane / 32) + e
- *   natural == 0:  kidx = 32 (ks / 2) + 4 (lane / 32) + 8 (2 (ks % 2) + e / 4) + e % 4
- * src: fp32, element (r, c) at src[r * sr + c * sc] (model.py:96-99 nn.Linear weight: sr = in, sc = 1). */
-int rn_pack_matrix_frag(const float* src, long sr, long sc, int R, int C, void* dst, int natural, void* stream);
-
-/* `count` (<= 16) rn_pack_matrix_frag calls in one launch; all arguments are HOST arrays of `count` entries.
- * natural[i] == 2 selects a plain fp32 TRANSPOSE instead: dst (C, R) fp32 row-major = src^T (the f_phi weights);
- * natural[i] == 4 | n / 8 | n (n = 0, 1) write the fp16 hi = fp16(w) / lo = fp16(w - hi) image in K order n;
- * natural[i] == 4 | n | V << 8 (V = 2, 4, 8) writes V tile-dithered hi images, 65536 fp16 apart (see rn_g_chain_fwd_rr_f16s). */
+/* MFMA-fragment-major weight images for the register-resident chains, `count` (<= 16) of them in ONE launch; all arguments are
+ * HOST arrays of `count` entries.  Image i: dst (65536 elements) gets, for output block ob, K16 step ks, lane, element e:
+ * src[32 ob + lane % 32][kidx] (0 beyond R rows / C columns) with
+ *   natural & 1:    kidx = 16 ks + 8 (lane / 32) + e                            (the operand is read from memory rows)
+ *   else:           kidx = 32 (ks / 2) + 4 (lane / 32) + 8 (2 (ks % 2) + e / 4) + e % 4   (the operand is the previous MFMA's output)
+ * src: fp32, element (r, c) at src[r * sr + c * sc] (model.py:96-99 nn.Linear weight: sr = in, sc = 1).  Element type by natural[i]:
+ *   0 / 1:            bf16 (the backward chain's W^T images);
+ *   2:                a plain fp32 TRANSPOSE instead: dst (C, R) fp32 row-major = src^T (the f_phi weights, W_0^T of the tables);
+ *   4 | n, 8 | n:     the fp16 hi = fp16(w) / lo = fp16(w - hi) image in K order n (layer 0 of the f16s forward chain);
+ *   4 | n | V << 8:   V (2, 4, 8) TILE-DITHERED hi images, 65536 fp16 apart: image d = fp16(w + ((d + 1/2) / V - 1/2) ulp_fp16(w))
+ *                     (layers 1..3 of the f16s forward chain, see rn_g_chain_fwd_rr_f16s_alg0). */
 int rn_pack_matrix_frag_many(const float* const* src, const long* sr, const long* sc, const int* R, const int* C,
                              void* const* dst, const int* natural, int count, void* stream);
 
-/* Fused backward chain (bf16 storage): pair-sum broadcast + last ReLU gate + all L-1 dgrad steps
- *  for every 128-row tile, tile resident in LDS:
- *   dZ[0]   = dxg[b] * (HL > 0)                                   (gradient of layer L-1's pre-activation)
- *   dZ[s+1] = (dZ[s] @ W_{L-1-s}[:, :256]) * (Hgate[s] > 0)        s = 0 .. L-2
- * Wt[s]: transposed packed weight of layer L-1-s, (256 in, 256 out) row-major (rn_pack_matrix);
- * Hgate[s]: the INPUT activation of layer L-1-s (= output of layer L-2-s), (M, 256).
- * All dZ (M, 256) are written (wgrad consumes them).  Wt / Hgate / dZ are HOST arrays.
- * Requires G == 256, L >= 2, M % 128 == 0 (a 128-row tile may straddle two questions). */
-int rn_g_chain_bwd(const void* HL, const float* dxg, const void* const* Wt, const void* const* Hgate,
-                   void* const* dZ, int dtype, int M, int rows_per_question, int L, int G, void* stream);
-
 /* K3 -- sum over the n*n pairs of every question: xg[b,:] = sum_p HL[b*npairs+p, :]
- * (model.py:151-152).  ws: >= rn_pair_sum_ws_bytes(...) bytes of scratch. */
-size_t rn_pair_sum_ws_bytes(int B, int npairs, int G);
+ * (model.py:151-152).  ws: >= rn_workspace_bytes(RN_WS_PAIR_SUM, B, npairs, G) bytes of scratch. */
 int rn_pair_sum_fwd(const void* HL, int ldh, float* xg, void* ws, int dtype, int B, int npairs, int G,
                     void* stream);
 
@@ -219,24 +169,21 @@ int rn_g_linear_bwd_dgrad(const void* dZ, int lddz, const void* Wt, int ldwt, co
  * dZ: (M, lddz) width N (N % 256 == 0); A: (M, lda) with K padded columns (K % 32 == 0), both ROW-MAJOR of `dtype`;
  * dW: fp32 (N, Ktrue) contiguous (nn.Linear layout); db: fp32 (N).
  * Deterministic: split over M into per-block partials in ws, then an ordered reduction. */
-size_t rn_wgrad_ws_bytes(int M, int N, int K);
 int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, int lda, float* dW, float* db, void* ws,
                           int dtype, int M, int N, int K, int Ktrue, void* stream);
 
-/* ROW-BLOCKED operand images.  The register-resident chains (rn_g_chain_fwd_rr*, rn_g_chain_bwd_rr) store what ONLY the weight
+/* ROW-BLOCKED operand images.  The register-resident chains (rn_g_chain_fwd_rr_f16s_alg0, rn_g_chain_bwd_rr*) store what ONLY the weight
  * gradient reads -- the activation copies H[0..2] and the gradients dZ[0..2] (layers 3..1) -- in the layout that product wants,
  * 16 bytes = consecutive pair rows of ONE feature (= one lane's MFMA operand when the contraction runs over the rows):
  *   16-bit image (bf16) of an (M, 256) matrix:  element (m, f) at ((m / 8) * 256 + f) * 8 + m % 8
  *   e4m3 image (H copies with h_dtype = RN_FP8): byte    (m, f) at ((m / 16) * 256 + f) * 16 + m % 16
- * Same byte counts as the row-major matrices.  rn_rows_to_blocked converts a row-major (M, 256) matrix (back != 0: the other
- * way) -- for tests and tools; M % 16 == 0, dtype RN_BF16 or RN_FP8. */
-int rn_rows_to_blocked(const void* src, void* dst, int dtype, int M, int back, void* stream);
+ * Same byte counts as the row-major matrices.  (rn_rows_to_blocked of include/rn_hip_debug.h converts either way: tests, tools.) */
 
 /* Weight gradients of up to 4 256-wide g layers in ONE launch (+ one reduction launch) on row-blocked images:
  *   job j:  dW[j] (256, 256) = dZ[j]^T A[j],  db[j] (256) = column sums of dZ[j]          (model.py:141-145 autograd)
  * dZ[j]: 16-bit image (dz_dtype[j] = RN_BF16); A[j]: image of the layer's input, a_dtype = RN_BF16 or RN_FP8 (all jobs alike).
  * dz_dtype[j] = RN_FP8 (needs a_dtype = RN_FP8): a GATE job -- the LAST layer, whose gradient is never stored:
- * dZ_3[(b, pair), f] = gate[(b, pair), f] * dxg[b][f].  dZ[j] is then the e4m3 {0, 1} image of the gate (rn_relu_gate_image),
+ * dZ_3[(b, pair), f] = gate[(b, pair), f] * dxg[b][f].  dZ[j] is then the e4m3 {0, 1} image of the gate (the forward chain's gate_image),
  * multiplied with A[j] on the fp8 matrix pipe (exact products), and each question's sums are scaled by its row of dxg
  * (M / rows_per_question, 256) fp32 -- un-rounded, i.e. closer to the fp32 reference than a stored bf16 dZ_3 -- when the
  * question ends; rows_per_question % 64 == 0 then (otherwise it only steers the row splits; 0 = unknown).  M % 64 == 0.
@@ -244,18 +191,16 @@ int rn_rows_to_blocked(const void* src, void* dst, int dtype, int M, int back, v
  * so that the njobs x Z x 4 workgroups of a launch fill the chip once and all jobs stream at the same time; with aligned != 0
  * a count that never lets a split straddle two questions (Z = B * d for a divisor d of the 64-row steps per question, or B
  * itself) when one exists within 256.
- * ws: rn_wgrad_blocked_ws_bytes(M, rows_per_question, njobs, aligned) bytes.  Afterwards ws holds, at
+ * ws: rn_workspace_bytes(RN_WS_WGRAD_BLOCKED, M, rows_per_question, njobs, aligned) bytes.  Afterwards ws holds, at
  * rn_wgrad_blocked_db_partials_offset(M, rows_per_question, njobs, aligned, j), (Z, 4, 256) fp32: four partial column sums of
  * dZ[j] over the 64-row steps [z*S/Z, (z+1)*S/Z) (S = M / 64) of split z -- per-question sums of dZ for free when the splits
  * are question-aligned.  Deterministic (fixed-order reduction).  dZ / dz_dtype / A / dW / db: HOST arrays. */
 int rn_wgrad_blocked_splits(int M, int rows_per_question, int njobs, int aligned);
-size_t rn_wgrad_blocked_ws_bytes(int M, int rows_per_question, int njobs, int aligned);
 size_t rn_wgrad_blocked_db_partials_offset(int M, int rows_per_question, int njobs, int aligned, int job);
 int rn_g_wgrad_blocked(const void* const* dZ, const int* dz_dtype, const void* const* A, int a_dtype, const float* dxg,
                        int rows_per_question, int aligned, float* const* dW, float* const* db, int njobs, void* ws, int M, void* stream);
 /* The ReLU gate of the last g layer as an e4m3 {0, 1} row-blocked image (M x 256 bytes, byte 0x38 = 1.0) from the layer-3 lane
- * masks of rn_g_chain_fwd_rr* (rn_g_chain_rr_mask_bytes(M) bytes): the dZ operand of a gate job.  M % 32 == 0. */
-int rn_relu_gate_image(const void* mask, void* img, int M, void* stream);
+ * masks of rn_g_chain_fwd_rr* (rn_workspace_bytes(RN_WS_RR_MASK, M) bytes): the dZ operand of a gate job.  M % 32 == 0. */
 /* Health of an e4m3 activation copy H_l, l = 0..2 (h_dtype = RN_FP8; fixed scale 1: values below 2^-10 flush to zero, values
  * above 448 are clamped): mask = the layer's lane masks of the SAME forward call (which elements were positive before rounding),
  * img = its row-blocked e4m3 image.  out4 (4 x uint64, ZEROED by the caller, accumulated with integer atomics): positive elements,
@@ -272,7 +217,6 @@ int rn_blocked_question_sums(const void* img, float* Rq, int M, int rows_per_que
  * Any of Rj / Ri / Rq may be NULL.  Outputs fp32; Rj, Ri: (B,n,G); Rq: (B,G). */
 /* njp >= n: pair rows per (question, i) group -- n for the plain n*n pair matrix, 32 ceil(n / 32) for the padded pair space of
  * rn_g_chain_fwd_rr_f16s_alg0 (row (b, i, j) at (b*n + i) * njp + j; the rows j >= n are not read). */
-size_t rn_pair_reduce_ws_bytes(int B, int n, int G);
 int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri, float* Rq, void* ws, int dtype, int B,
                        int n, int njp, int G, void* stream);
 
@@ -287,11 +231,10 @@ int rn_pair_dx_dq(const float* Rj, const float* Ri, const float* Rq, const float
  *   dW0[:, 0:k] = Rj^T X,  dW0[:, k:2k] = Ri^T X,  dW0[:, 2k:2k+Q] = Rq^T q,  db0 = sum_b Rq[b]
  * with X = x viewed as (B*n, k) -- identical to dZ_0^T P (rounding aside: x enters in fp32 instead of P's storage
  * dtype) without reading dZ_0 or P.  Rj, Ri (B*n, N), Rq (B, N) fp32 from rn_pair_reduce_bwd; x (B, n, k) element
- * strides; q (B, Q) row stride sqb; dW0 (N, 2k+Q), db0 (N); k <= 32; ws: rn_wgrad0_ws_bytes(B, n, N) bytes.
+ * strides; q (B, Q) row stride sqb; dW0 (N, 2k+Q), db0 (N); k <= 32; ws: rn_workspace_bytes(RN_WS_WGRAD0, B, n, N) bytes.
  * Q == 0 (no question at layer 0): q may be NULL; Rq (all-pairs sums) still gives db0, NULL leaves db0 = 0.
  * coord != NULL: x supplies only the first kf columns of an object, the rest are the coordinate tags coord (k - kf, n), as in
  * rn_pair_tables. */
-size_t rn_wgrad0_ws_bytes(int B, int n, int N);
 int rn_wgrad0_from_reductions(const float* Rj, const float* Ri, const float* Rq, const float* x, long sxb, long sxn, long sxk,
                               const float* coord, int kf, const float* q, long sqb, float* dW0, float* db0, void* ws, int B, int n,
                               int k, int Q, int N, void* stream);
@@ -306,18 +249,10 @@ int rn_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, lo
                 int M, int N, int K, const float* bias, const float* mul, long ldmul, const float* gate,
                 long ldgate, int flags, void* stream);
 
-/* log_softmax over dim 1 (model.py:162) and its backward: dz = g - exp(out) * sum(g). */
-int rn_log_softmax_fwd(const float* z, float* out, int B, int A, void* stream);
-int rn_log_softmax_bwd(const float* out, const float* gout, float* dz, int B, int A, void* stream);
-
-/* column sums: out[c] = sum_r src[r*ld + c]  (bias gradients of f_phi). */
-int rn_colsum_f32(const float* src, long ld, float* out, int R, int C, void* stream);
-
 /* R-CBIR pair features (reference extract.py:60-71): for the INPUT of a g layer, A (B*npairs, lda)
  * in `dtype`, first F columns (the question columns of an injection layer excluded by the caller's F):
  * L2-normalise every pair row (F.normalize semantics, eps 1e-12), then maxf / avgf (B, F) fp32 = maximum / mean over the
- * npairs rows of each question.  One pass over A.  F % 64 == 0, F <= 512; ws: rn_pair_features_ws_bytes(B, npairs, F). */
-size_t rn_pair_features_ws_bytes(int B, int npairs, int F);
+ * npairs rows of each question.  One pass over A.  F % 64 == 0, F <= 512; ws: rn_workspace_bytes(RN_WS_PAIR_FEATURES, B, npairs, F). */
 /* The same features WITHOUT the matrix (SURVEY.md 8f row N3 as specified): the input of g layer `nlayers` is formed tile by tile
  * on chip -- a workgroup builds 64 pair rows [x_j | x_i] (model.py:117-127) in LDS, runs g layers 0 .. nlayers-1 on them in fp32
  * (v_mfma_f32_32x32x2_f32) with the activation tile resident in LDS, L2-normalises the rows of the result over its first F columns
@@ -326,8 +261,7 @@ size_t rn_pair_features_ws_bytes(int B, int npairs, int F);
  *   x: objects (B, n, k) fp32, element strides; Wt[l]: (K_l, 256) fp32 TRANSPOSED weights of layer l -- Wt[l][c][f] = W_l[f][c]
  *   for the first K_0 = 2k (l = 0) / K_l = 256 (l > 0) input columns, i.e. without the question columns; bias[l]: (256) fp32, or
  *   with bias_per_question[l] != 0 a (B, 256) table W_l[:, K_l:] q_b + b_l -- how the question enters at its injection layer
- *   (model.py:131-142).  g width 256, nlayers <= 4, 2k <= 256.  maxf, avgf: (B, F) fp32; ws: rn_extract_ws_bytes(B, n, F). */
-size_t rn_extract_ws_bytes(int B, int n, int F);
+ *   (model.py:131-142).  g width 256, nlayers <= 4, 2k <= 256.  maxf, avgf: (B, F) fp32; ws: rn_workspace_bytes(RN_WS_EXTRACT, B, n, F). */
 int rn_extract_features(const float* x, long sxb, long sxn, long sxk, const float* const* Wt, const float* const* bias,
                         const int* bias_per_question, int nlayers, int F, float* maxf, float* avgf, void* ws, int B, int n, int k,
                         void* stream);
@@ -337,7 +271,7 @@ int rn_pair_features(const void* A, int lda, int F, float* maxf, float* avgf, vo
  *   f1 = relu(xg W1^T + b1) (B, F1);  f2 = relu((f1 W2^T + b2) * mask) (B, F2);  out = log_softmax(f2 W3^T + b3) (B, A)
  * W_l: nn.Linear layout (out, in) row-major -- or, with transposed != 0 in the forward call, (in, out) copies (fp32 transpose
  * mode of rn_pack_matrix_frag_many: coalesced weight reads, 41 -> ~12 us); mask: (B, F2) dropout mask already scaled by 1/(1-p), or NULL.
- * Backward: gout = d loss / d out; writes dW_l, db_l and dxg (B, G); ws: rn_f_phi_bwd_ws_bytes(B, F1, F2, A) bytes.
+ * Backward: gout = d loss / d out; writes dW_l, db_l and dxg (B, G); ws: rn_workspace_bytes(RN_WS_F_PHI_BWD, B, F1, F2, A) bytes.
  * Widths are multiples of 4 (A excepted) and <= 1024, B <= 1024. */
 int rn_f_phi_fwd(const float* xg, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                  const float* b3, const float* mask, float* f1, float* f2, float* out, int transposed, int B, int G, int F1,
@@ -352,7 +286,7 @@ int rn_f_phi_fwd_from_partials(const float* xg_part, int parts_per_row, float* x
 /* The training step's f_phi in ONE launch up to dxg: rn_f_phi_fwd_from_partials (transposed forward weights W1T..W3T, loss folded
  * in) followed, in the same kernel and for the same rows, by the backward dz chain for d loss = 1 -- the log-prob gradient of a
  * mean NLL is -1/B at the label whatever happens in between.  W1..W3: the natural (out, in) weights; bwd_ws:
- * rn_f_phi_bwd_ws_bytes(B, F1, F2, A) bytes, receives the dz rows; dxg (B, G) out.  rn_f_phi_bwd_grads then turns bwd_ws into
+ * rn_workspace_bytes(RN_WS_F_PHI_BWD, B, F1, F2, A) bytes, receives the dz rows; dxg (B, G) out.  rn_f_phi_bwd_grads then turns bwd_ws into
  * the six parameter gradients (exactly the second launch of rn_f_phi_bwd_nll).  A loss gradient other than 1: rn_f_phi_bwd_nll. */
 int rn_f_phi_fwd_bwd_from_partials(const float* xg_part, int parts_per_row, float* xg, const float* W1T, const float* b1, const float* W2T,
                                    const float* b2, const float* W3T, const float* b3, const float* W1, const float* W2, const float* W3,
@@ -360,15 +294,13 @@ int rn_f_phi_fwd_bwd_from_partials(const float* xg_part, int parts_per_row, floa
                                    void* bwd_ws, float* dxg, int B, int G, int F1, int F2, int A, void* stream);
 int rn_f_phi_bwd_grads(const void* bwd_ws, const float* xg, const float* f1, const float* f2, float* dW1, float* db1, float* dW2,
                        float* db2, float* dW3, float* db3, int B, int G, int F1, int F2, int A, void* stream);
-size_t rn_f_phi_bwd_ws_bytes(int B, int F1, int F2, int A);
 int rn_f_phi_bwd(const float* gout, const float* out, const float* f2, const float* f1, const float* xg, const float* W1,
                  const float* W2, const float* W3, const float* mask, float* dW1, float* db1, float* dW2, float* db2,
                  float* dW3, float* db3, float* dxg, void* ws, int B, int G, int F1, int F2, int A, void* stream);
 /* The same with the mean negative log-likelihood of the batch (F.nll_loss(output, label), train.py:41) folded in:
  * the forward also writes loss[0] = -mean_b out[b][label[b]] (label: int64, 0 <= label < A), the backward takes
- * gloss = d L / d loss (one device float) instead of a log-prob gradient.  sync_ws: rn_f_phi_nll_ws_bytes(B) bytes that the
+ * gloss = d L / d loss (one device float) instead of a log-prob gradient.  sync_ws: rn_workspace_bytes(RN_WS_F_PHI_NLL, B) bytes that the
  * caller zeroes ONCE; afterwards it belongs to these calls (block partials + a self re-arming completion counter). */
-size_t rn_f_phi_nll_ws_bytes(int B);
 int rn_f_phi_fwd_nll(const float* xg, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                      const float* b3, const float* mask, const long long* label, float* f1, float* f2, float* out, float* loss,
                      void* sync_ws, int transposed, int B, int G, int F1, int F2, int A, void* stream);
@@ -388,9 +320,8 @@ int rn_nll_mean_bwd(const long long* label, const float* gloss, float* gout, int
  * DEVICE array of nchunks records {float* param; long flat_off; int count; int pad} (count <= rn_clip_adam_chunk(),
  * a chunk never crosses a parameter) mapping flat ranges to the parameter tensors; step: 1-based update count;
  * grad_scale multiplies the gradient first (1 / world after a SUM all-reduce; 1 otherwise);
- * ws: rn_clip_adam_ws_bytes() bytes; norm_out: optional device float receiving the (scaled) gradient norm. */
+ * ws: rn_workspace_bytes(RN_WS_CLIP_ADAM) bytes; norm_out: optional device float receiving the (scaled) gradient norm. */
 int rn_clip_adam_chunk(void);
-size_t rn_clip_adam_ws_bytes(void);
 int rn_clip_adam_step(const void* chunks, int nchunks, float* g, float* m, float* v, long n, void* ws, float grad_scale, float max_norm, float lr,
                       float beta1, float beta2, float eps, float weight_decay, int step, float* norm_out, void* stream);
 /* ... with the per-step scalars in device memory, so that the two launches can be part of a captured hipGraph: hyper = 7 floats
@@ -433,8 +364,7 @@ int rn_conv3x3s2_fwd(const float* x, const float* w, float* y, int N, int Cin, i
 int rn_conv3x3s2_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, void* stream);
 /* Weight gradient of the same convolution (autograd of model.py:13-20): dw (24, Cin, 3, 3) fp32 =
  * sum_{n,oy,ox} dy[n][co][oy][ox] * x[n][ci][2 oy + ky - 1][2 ox + kx - 1], on the fp32 matrix pipe; ws =
- * rn_conv3x3s2_bwd_weight_ws_bytes(N, Cin, H, W) bytes (per-block partials, summed in a fixed order). */
-size_t rn_conv3x3s2_bwd_weight_ws_bytes(int N, int Cin, int H, int W);
+ * rn_workspace_bytes(RN_WS_CONV_BWD_WEIGHT, N, Cin, H, W) bytes (per-block partials, summed in a fixed order). */
 int rn_conv3x3s2_bwd_weight(const float* x, const float* dy, float* dw, void* ws, int N, int Cin, int Cout, int H, int W, void* stream);
 
 /* BatchNorm2d + ReLU of the conv stack in front of the relation layer (reference model.py:22-35), fused into two
@@ -446,8 +376,7 @@ int rn_conv3x3s2_bwd_weight(const float* x, const float* dy, float* dw, void* ws
  *   apply (evaluation): the same map with caller-prepared mean (= running_mean - conv_bias) and invstd.
  *   bwd:  dz = dy * (y > 0) (mask recomputed from x), dgamma / dbeta (C) out,
  *         dx = gamma * invstd * (dz - mean_n(dz) - xhat * mean_n(dz * xhat)).
- * ws: rn_bn_relu_ws_bytes(N, C, HW) bytes. */
-size_t rn_bn_relu_ws_bytes(int N, int C, int HW);
+ * ws: rn_workspace_bytes(RN_WS_BN_RELU, N, C, HW) bytes. */
 int rn_bn_relu_fwd(const float* x, float* y, const float* gamma, const float* beta, const float* conv_bias,
                    float* running_mean, float* running_var, long long* num_batches, float* mean, float* invstd, void* ws,
                    float eps, float momentum, int N, int C, int HW, void* stream);
@@ -461,52 +390,55 @@ int rn_bn_relu_bwd(const float* dy, const float* x, float* dx, const float* gamm
 /* rn_bn_relu_bwd of a block whose input needs no gradient (the first block: the image) together with the weight gradient of its
  * convolution (autograd of model.py:22-35 for that block): pass 1 as above; the weight-gradient kernel then forms the conv output
  * gradient from dy and the conv output xc (N, 24, H/2, W/2) while staging, so it is never written.  inp: the block's input
- * (N, Cin, H, W); dw (24, Cin, 3, 3); ws_bn / ws_conv: rn_bn_relu_ws_bytes(N, 24, H/2 * W/2) / rn_conv3x3s2_bwd_weight_ws_bytes bytes.
+ * (N, Cin, H, W); dw (24, Cin, 3, 3); ws_bn / ws_conv: rn_workspace_bytes(RN_WS_BN_RELU, N, 24, H/2 * W/2) / rn_workspace_bytes(RN_WS_CONV_BWD_WEIGHT, ...) bytes.
  * Results equal rn_bn_relu_bwd + rn_conv3x3s2_bwd_weight. */
 int rn_bn_relu_bwd_conv_wgrad(const float* dy, const float* xc, const float* inp, const float* gamma, const float* beta,
                               const float* mean, const float* invstd, float* dgamma, float* dbeta, float* zero_out, float* dw,
                               void* ws_bn, void* ws_conv, int N, int Cin, int H, int W, void* stream);
 
-/* The first g layer factored through the pair structure (question injected at layer 0; model.py:130-139 builds the pair
- * matrix [x_j | x_i | q] and multiplies it by W0): W0 [x_j | x_i | q] + b0 = W0a x_j + (W0b x_i + W0c q + b0).
- *   rn_pair_tables: Xp (B*n, 64) bf16 = x[b, j, 0:k] zero padded;  Vc (B*n, N) fp32 = b0 + W0b x[b, i] + W0c q[b]
- *     (W0T = W0 transposed, (2k+Q, N) fp32; x (B, n, k) with element strides; k <= 32).
- *   rn_g_chain_fwd_rr_alg0: the register-resident forward chain on those tables -- layer 0 is a K = 64 product on the
- *     object rows with the Vc row of (question, i) as its bias; the pair matrix never exists.  Wf[0] is the fragment-major
- *     image of W0[:, 0:k] (natural layout), Wf[1..3] as for rn_g_chain_fwd_rr.  n % 32 == 0, M = B*n*n.  H / mask: both NULL
- *     (inference) or H_0..2 (H[3] NULL) + the four masks (training); xg_part (M/256, 256) fp32: ONE partial pair-sum row per
- *     256-row tile (the tile's eight waves add their rows on chip; a tile lies inside one question) -- reduce with
- *     rn_pair_sum_fwd(xg_part, 256, xg, ws, RN_F32, B, n*n/256, 256).  The same for rn_g_chain_fwd_rr_f16s_alg0. */
-/* Coordinate tagging fused (model.py:195-201, 208-218): with coord != NULL the object (b, p) is [x[b, p, 0:kf] | coord[0:k-kf, p]]
- * -- x is then the conv grid itself, viewed (B, n, kf) at element strides, and coord the (k - kf, n) fp32 table of
- * RN.build_coord_tensor (channel 0 = x = lin[p % d], channel 1 = y = lin[p / d]); no concatenated tensor exists.
- * coord == NULL: x carries all k columns (kf ignored).  Q == 0: no question term (q may be NULL). */
+/* THE FORWARD CHAIN (headline path; model.py:108-152): tables of the factored first layer + one launch for the four g layers and
+ * the pair sum.  The pair matrix [x_j | x_i | q] of model.py:117-127 never exists:
+ *   W0 [x_j | x_i | q] + b0 = W0a x_j + (W0b x_i + W0c q + b0)
+ * rn_pair_tables: Xp (B*n [+ 1], 64) = x[b, j, 0:k] zero padded, in xp_dtype (RN_F16 for the chain);  Vc (B*n, N) fp32 = b0 +
+ *   W0b x[b, i] + W0c q[b]   (W0T = W0 transposed, (2k+Q, N) fp32; x (B, n, k) with element strides; k <= 32; Q = 0: no question
+ *   term).  coord != NULL: x supplies only the first kf columns of an object (the conv grid), the rest are the coordinate tags
+ *   coord (k - kf, n) of model.py:195-201 -- the concatenated object tensor never exists either.
+ * rn_g_chain_fwd_rr_f16s_alg0: the register-resident chain on those tables, "f16s" arithmetic -- fp16 operand registers (activations
+ *   saturate at 65504), fp32 accumulate:
+ *   layer 0:     a K = 64 product on the object rows with the Vc row of (question, i) as its bias; two MFMA passes, against Whi[0] =
+ *                fp16(W0[:, 0:k]) and Wlo[0] = fp16(W0[:, 0:k] - hi) (rn_pack_matrix_frag_many modes 4 | 1 and 8 | 1);
+ *   layers 1..3: ONE pass on TILE-DITHERED hi images: Whi[l] holds `dither` (1, 2, 4, 8; the module uses 4) images, 65536 fp16 apart,
+ *                image d = fp16(W + ((d + 1/2) / dither - 1/2) ulp_fp16(W)) (mode 4 | dither << 8), and 256-row tile t multiplies
+ *                image t mod dither: the weight rounding error no longer has the same sign for all pairs of a question and averages
+ *                out in the pair sum (model.py:151-152) like the activation rounding does.  Wlo[1..3] are not read (may be NULL).
+ *                Error against the fp32 reference on the released checkpoints: 1.7e-4 / 1.9e-4 (original-fp / ir-fp; one plain
+ *                pass: 2.6e-3; the bar is 1e-3).
+ *   inject_layer = 0: the question is part of the tables (Q > 0 in rn_pair_tables).  inject_layer = 2 (the "IR" variants,
+ *     model.py:131-142; tables built with Q = 0): layer 2's input is [H_1 | q[b]], i.e. W_2 [H_1 | q] + b_2 = W_2[:, 0:256] H_1 + Vq[b]
+ *     with Vq (B, 256) fp32 = W_2[:, 256:] q[b] + b_2 prepared by the caller (one small rn_gemm_f32); Whi[2] holds W_2[:, 0:256]
+ *     only, bias[2] is ignored.  Needs n divisible by 32 and n*n by 256.
+ *   H / mask: both NULL (inference) or H[0..2] (H[3] NULL) + the four masks (training).  h_dtype: the type of the stored H_0..2 rows
+ *     -- RN_BF16 (M x 256 bf16) or RN_FP8 (M x 256 e4m3 bytes, value = byte value), both as ROW-BLOCKED images (the only reader is
+ *     rn_g_wgrad_blocked).  Ignored when H is NULL.
+ *   xg_part (M/256, 256) fp32: ONE partial pair-sum row per 256-row tile (the tile's eight waves add their rows on chip) -- reduce
+ *     with rn_pair_sum_fwd(xg_part, 256, xg, ws, RN_F32, B, n*n/256, 256) or let rn_f_phi_fwd_from_partials add them up.
+ *   njp: pair rows per (question, i) group.  njp == n: the pair rows are the n*n pairs of model.py:117-127 (n a multiple of 32).
+ *     njp = 32 ceil(n / 32) > n (n a multiple of 4; e.g. the 14 x 14 grid, n = 196 -> 224): the j axis is PADDED -- pair row m =
+ *     (b, i, j) with j = m mod njp, M = B * n * njp; rows with j >= n are invalid (they multiply the all-zero object row
+ *     Xp16[B * n], which the caller provides; their mask bits are cleared in every layer and they are left out of the pair sums),
+ *     H / mask cover the M padded rows, and xg_part holds TWO partial rows per 256-row tile, (M / 256 * 2, 256) -- reduce with
+ *     rn_pair_sum_tiles.  The backward side (rn_g_chain_bwd_rr with rows_per_question = n * njp, rn_g_wgrad_blocked,
+ *     rn_pair_reduce_bwd with njp) then sees zero gradients for the invalid rows without knowing about the padding.  Question at
+ *     layer 0 only.
+ *   gate_image (may be NULL; with the e4m3 training output set): M x 256 bytes -- the last layer's ReLU gate as an e4m3 {0, 1}
+ *     row-blocked image (1.0 = 0x38), exactly what rn_relu_gate_image (include/rn_hip_debug.h) builds from mask[3]: the `dZ` operand
+ *     of the last layer's gate job in rn_g_wgrad_blocked, written from the forward kernel's epilogue. */
 int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* coord, int kf, const float* q, long ldq,
                    const float* W0T, const float* b0, void* Xp, int xp_dtype /* RN_BF16 | RN_F16 */, float* Vc, int B, int n, int k,
                    int Q, int N, void* stream);
-/* ... and in the f16s arithmetic (fp16 object rows; Whi / Wlo as for rn_g_chain_fwd_rr_f16s, layer 0 = W0[:, 0:k] natural) */
-/* inject_layer = 0: the question is part of the tables (Q > 0 in rn_pair_tables).  inject_layer = 2 (the "IR" variants,
- * model.py:131-142; tables built with Q = 0): layer 2's input is [H_1 | q[b]], i.e. W_2 [H_1 | q] + b_2 =
- * W_2[:, 0:256] H_1 + Vq[b] with Vq (B, 256) fp32 = W_2[:, 256:] q[b] + b_2 prepared by the caller (one small rn_gemm_f32);
- * Wf[2] / Whi[2], Wlo[2] hold W_2[:, 0:256] only, bias[2] is ignored.  Needs n*n % 256 == 0. */
-/* h_dtype: the type of the stored H_0..2 rows -- RN_BF16 (M x 256 bf16) or RN_FP8 (M x 256 e4m3 bytes, value = byte value), both as
- * ROW-BLOCKED images (the only reader is rn_g_wgrad_blocked).  Ignored when H is NULL. */
-/* njp: pair rows per (question, i) group.  njp == n: the pair rows are the n*n pairs of model.py:117-127 (n % 32 == 0).
- * njp = 32 ceil(n / 32) > n (n % 4 == 0; e.g. the 14 x 14 grid, n = 196 -> 224): the j axis is PADDED -- pair row m = (b, i, j)
- * with j = m mod njp, M = B * n * njp; rows with j >= n are invalid (they multiply the all-zero object row Xp16[B * n], which the
- * caller provides; their mask bits are cleared in every layer and they are left out of the pair sums), H / mask cover the M
- * padded rows, and xg_part holds TWO partial rows per 256-row tile, (M / 256 * 2, 256) -- reduce with rn_pair_sum_tiles.  The
- * backward side (rn_g_chain_bwd_rr with rows_per_question = n * njp, rn_g_wgrad_blocked, rn_pair_reduce_bwd with njp) then sees
- * zero gradients for the invalid rows without knowing about the padding.  Question at layer 0 only. */
-/* gate_image (may be NULL; with the e4m3 training output set): M x 256 bytes -- the last layer's ReLU gate as an e4m3 {0, 1} row-blocked
- * image (1.0 = 0x38), exactly what rn_relu_gate_image builds from mask[3]: the `dZ` operand of the last layer's gate job in
- * rn_g_wgrad_blocked, written from the forward kernel's epilogue instead of by a launch of its own in the backward pass. */
 int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, int njp, const void* const* Whi, const void* const* Wlo, int dither,
                                 const float* const* bias, void* const* H, int h_dtype, void* const* mask, void* gate_image, float* xg_part,
                                 const float* Vq, int inject_layer, int M, int L, int G, void* stream);
-int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, const void* const* Wf, const float* const* bias, void* const* H,
-                           int h_dtype, void* const* mask, float* xg_part, const float* Vq, int inject_layer, int M, int L, int G,
-                           void* stream);
 
 #ifdef __cplusplus
 }

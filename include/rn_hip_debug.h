@@ -21,6 +21,14 @@ int rn_probe_fp8_cvt(const float* in, float scale, void* out8_bf16, void* out8_f
  * Captured between the kernels of the step's hipGraph it yields a concurrent multi-stream timeline (tools/step_timeline.py). */
 int rn_debug_stamp(unsigned long long* slot, void* stream);
 
+/* Row-major (M, 256) matrix <-> row-blocked image (include/rn_hip.h, "ROW-BLOCKED operand images"; back != 0: the other way).
+ * The chains write the images themselves; tests and tools convert with this.  M % 16 == 0, dtype RN_BF16 or RN_FP8. */
+int rn_rows_to_blocked(const void* src, void* dst, int dtype, int M, int back, void* stream);
+
+/* e4m3 {0, 1} row-blocked image (1.0 = 0x38) of the last layer's lane masks -- what the f16s forward chain writes from its epilogue
+ * (gate_image); the tests build the reference image with this.  M % 32 == 0. */
+int rn_relu_gate_image(const void* mask, void* img, int M, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

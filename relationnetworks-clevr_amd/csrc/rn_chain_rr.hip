@@ -1,27 +1,23 @@
-// Register-resident fused g_theta chain (model.py:130-152): the headline-shape kernel.
+// Register-resident fused g_theta chains (model.py:130-152 and their backward): the headline-shape kernels.
 //
-// A workgroup is 4 waves, ONE per SIMD, each with the whole 512-register file.  A wave owns 64 pair
-// rows for ALL four layers: with swapped MFMA operands (weights = A, activations = B) the 32x32 output
-// block D[feature][row] leaves a lane holding features {8j + 4h + r} of row n -- after bias + ReLU +
-// bf16 packing those registers ARE the B operand of the next layer's MFMA, provided the next layer's
-// weights are packed with the matching K permutation (rn_pack_matrix_frag).  The activation therefore
-// never goes through LDS between layers; LDS traffic is the weight stream only (one 1-KB A fragment
-// feeds 2 MFMAs = 16 B/clk/wave, a quarter of the LDS read rate) plus the staging of the rows that are
-// copied to HBM for the backward pass.
+// A workgroup is 8 waves, two per SIMD, each wave with 256 registers and 32 pair rows for ALL four layers (tile = 256 rows,
+// persistent workgroups).  With swapped MFMA operands (weights = A, activations = B) the 32x32 output block D[feature][row]
+// leaves a lane holding features {8j + 4h + r} of row n -- after bias + ReLU + 16-bit packing those registers ARE the B operand
+// of the next layer's MFMA, provided the next layer's weights are packed with the matching K permutation
+// (rn_pack_matrix_frag_many).  The activation therefore never goes through LDS between layers; LDS carries the weight stream
+// (fragment-major 16-KB blocks, L2 -> LDS by LDS-DMA into a ring, one counted s_waitcnt vmcnt + s_barrier per stage) and the
+// staging of what is copied to HBM for the backward pass.
 //
-//   per wave:  act[2][16 k-steps][2 row blocks] x 4 VGPR (ping-pong, 256 regs)  +  2 x 2 accumulators (64)
-//              + 8-deep A-fragment ring (32)
-//   per stage: one 32-feature output block `ob` of one layer = 16 KB of weights = 16 fragments x 2 MFMAs.
-//              The epilogue of block ob-1 (bias, ReLU, pack, stage, copy-out) is interleaved with the MFMAs
-//              of block ob, at most ~5 single-issue instructions per MFMA gap (MI355X_MICROARCH.md).
-//   weights:   fragment-major images stream L2 -> LDS by LDS-DMA into an 8-slot ring, 7 stages ahead; one
-//              counted s_waitcnt vmcnt + s_barrier per stage (vmcnt retires in order and counts the stores).
-//              8 blocks per layer == 8 slots, so every LDS address is a compile-time constant.
-//   stores:    H_l rows are staged per block as [64 rows][64 B] and written with 16-byte row-contiguous
-//              stores (a lane-per-row store would touch 32 cache lines per instruction).
-//   pair sum:  the LAST layer runs with the operands un-swapped, D[row][feature]: a lane then owns one feature
-//              of 16 rows and the pair sum is an in-lane fp32 add of the un-rounded activations; one partial
-//              row per wave (32 pair rows) goes to xg_part.
+//   per wave:  act[2][16 k-steps] x 4 VGPR (ping-pong, 128 regs) + 2 accumulators (32) + a fragment read-ahead ring
+//   per stage: one 32-feature output block `ob` of one layer = 16 fragments x 1 MFMA (32 rows).  The epilogue of block ob-1
+//              (bias, ReLU, pack, masks, staging, copy-out) is sliced over the MFMA gaps of block ob (sched_barrier per gap).
+//   stores:    H_l copies leave as ROW-BLOCKED images (the layout of their only reader, rn_wgrad_blocked.hip), e4m3 or 16-bit.
+//   pair sum:  the LAST layer runs with the operands un-swapped, D[row][feature]: a lane then owns one feature of 16 rows and the
+//              pair sum is an in-lane fp32 add of the un-rounded activations; one partial row per tile goes to xg_part.
+//
+// Kernels here: g_chain_rr_f16s_kernel (forward, the "f16s" arithmetic on the FACTORED first layer -- the only forward chain;
+// the round-1..3 bf16 and pair-matrix variants were removed in round 4, the per-layer kernels of rn_gemm.hip cover what they
+// covered) and g_chain_rr_bwd_kernel (backward, bf16, from the forward's lane masks; RED: with the pair-axis reductions on chip).
 #include "rn_common.h"
 
 namespace {
@@ -52,13 +48,6 @@ typedef unsigned long long u64;
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef __attribute__((address_space(3))) const Frag lds_frag;
 
-struct RRArgs {
-  const bf16* W[RR_L];                                  // fragment-major (rn_pack_matrix_frag), 128 KB each
-  const float* bias[RR_L];
-  bf16* out[RR_L];                                      // H_l (M, 256) or null
-  u64* mask[RR_L];                                      // ReLU lane masks of layer l (M * 32 bytes) or null
-  int prio;                                             // 1: the second-dispatched half of the waves raises its issue priority
-};
 struct RRBwdArgs {                                      // the per-layer buffers are equally spaced (checked on the host):
   const bf16* W;                                        // step s: fragment-major W_{3-s}^T at W + s * w_stride
   const u64* mask;                                      // lane masks of layer l (forward kernel) at mask + l * mask_stride
@@ -214,23 +203,6 @@ __device__ __forceinline__ unsigned co_off_blk8(int lane, int cob, int t) {
 // dst[((ob * 16 + ks) * 64 + lane) * 8 + e] = src[32 ob + lane % 32][kidx], 0 beyond (R, C)
 //   natural  : kidx = 16 ks + 8 h + e                         (operand read straight from memory rows)
 //   permuted : kidx = 32 (ks / 2) + 4 h + 8 (2 (ks % 2) + e / 4) + e % 4   (operand = previous MFMA output)
-__global__ __launch_bounds__(256) void pack_frag_kernel(const float* __restrict__ src, long sr, long sc, int R, int C,
-                                                        bf16* __restrict__ dst, int natural) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  const int e = g & 7, lane = (g >> 3) & 63, ks = (g >> 9) & 15, ob = g >> 13;
-  const int h = lane >> 5, m = 32 * ob + (lane & 31);
-  const int kidx = natural ? 16 * ks + 8 * h + e : 32 * (ks >> 1) + 4 * h + 8 * (2 * (ks & 1) + (e >> 2)) + (e & 3);
-  const float v = (m < R && kidx < C) ? src[(long)m * sr + (long)kidx * sc] : 0.f;
-  dst[g] = (bf16)v;
-}
-
-extern "C" int rn_pack_matrix_frag(const float* src, long sr, long sc, int R, int C, void* dst, int natural, void* stream) {
-  RN_CHECK_ARG(src && dst && R > 0 && R <= RR_G && C > 0 && C <= RR_G, "rn_pack_matrix_frag: needs 0 < R, C <= 256 (R=%d C=%d)", R, C);
-  pack_frag_kernel<<<RR_G * RR_G / 256, 256, 0, (hipStream_t)stream>>>(src, sr, sc, R, C, (bf16*)dst, natural);
-  RN_LAUNCH_CHECK("rn_pack_matrix_frag");
-  return 0;
-}
-
 // all fragment-major images of a step in ONE launch (7 per training step: 4 forward + 3 transposed)
 namespace {
 constexpr int RR_MAXPACK = 16;
@@ -291,29 +263,6 @@ extern "C" int rn_pack_matrix_frag_many(const float* const* src, const long* sr,
 // stay in flight: the requests of the five stages in between plus whatever else those stages issue (stores,
 // next-tile row loads).  The models below give a LOWER bound of that number per site -- waiting for more than
 // necessary is always safe, waiting for less is a race.
-template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false>
-struct FwdVm {
-  static constexpr int PF_PER = (NK0 + 7) / 8;                       // next-tile row loads per stage of the last layer
-  static constexpr int VC_STAGE = (RR_L - 1) * 8 + 4;                // ALG0: the stage that requests the next tile's bias row
-  static constexpr int VQ_STAGE = (RR_L - 1) * 8 + 2;                // INJ: ... and the next tile's question row of layer INJ
-  static constexpr int ops(int sidx) {                                // VMEM operations a stage issues (per wave)
-    int k = RR_DPW;
-    if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += (H8 && ((sidx - 2) >> 3) < RR_L - 1) ? (((sidx - 2) & 1) ? 2 : 0) : 2;   // e4m3 copies leave two blocks at a time
-    if ((sidx >> 3) == RR_L - 1)
-      for (int c = 0; c < PF_PER; ++c) k += ((sidx & 7) * PF_PER + c < NK0) ? 1 : 0;
-    if (ALG0 && sidx == VC_STAGE) k += 1;
-    if (INJ > 0 && sidx == VQ_STAGE) k += 1;
-    return k;
-  }
-  static constexpr int tail() { return (STORE && ST3 ? 4 : 0) + (XG ? (ALG0 ? 1 : 8) : 0); }
-  static constexpr int younger(int sidx, bool first) {
-    int k = 0;
-    for (int t = sidx - 5; t < sidx; ++t) k += t >= 0 ? ops(t) : (first ? 0 : ops(t + 8 * RR_L));
-    if (sidx < 5 && !first) k += tail();
-    if (first && sidx <= 5) k += RR_DPW * (5 - sidx) + NK0 + (ALG0 ? 1 : 0);   // the prologue's later requests and the first pair rows
-    return k < 63 ? k : 63;
-  }
-};
 template <bool SKIP0, bool RED = false>
 struct BwdVm {
   // RED (pair reductions inside the kernel): a 6-slot ring -- the two slots it gives up are one exchange buffer
@@ -331,327 +280,15 @@ struct BwdVm {
   }
 };
 
-// =================================================================================================== forward
-// ALG0 -- the first layer factored through the pair structure (question injected at layer 0, n % 32 == 0):
-//   W0 [x_j | x_i | q] + b0 = W0a x_j + (W0b x_i + W0c q + b0): the bracket is constant over a wave's 32 pair rows (same
-//   question, same i) and comes in as the layer's BIAS row -- Vc[b*n + i][256], fp32, from rn_pair_tables; only the
-//   x_j part is left as an MFMA, K = 64 (P = the packed object rows Xp[b*n + j][64], a 0.5 MB table that lives in L2)
-//   instead of K = 192 on a 138 MB pair matrix that then never exists.
-// INJ > 0 -- the question injected at layer INJ (the reference's "IR" variants, model.py:131-142): the layer's input is
-//   [H_{INJ-1} | q[b]], so W_INJ [H | q] + b = W_INJ[:, 0:256] H + (W_INJ[:, 256:] q[b] + b): the bracket is a per-QUESTION
-//   constant -- Vq[b][256], fp32, one small product on the host side -- and takes the place of the layer's bias row in LDS
-//   for the tile (a 256-row tile lies inside one question: n*n % 256 == 0).  The row of the next tile is fetched during the
-//   last layer and written at the tile's tail, when no wave reads the old one any more.
-// H8 -- the H_l copies for the weight gradient leave as OCP e4m3 bytes (rn_common.h): the packed bf16 pairs of a group are
-//   converted once more (clamp + two v_cvt_scalef32_pk_fp8_bf16) and TWO blocks share a staging row (64 B) and leave together
-//   after the odd one, in the same two 16-byte stores per lane as a bf16 block -- a row must receive 64 contiguous bytes per
-//   store instruction: 32-byte pieces (one block at a time) ran the kernel at half its speed (270 us instead of 126).
-//   Half the bytes written here and read back by the weight-gradient kernel.
-template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false>
-__global__ __launch_bounds__(RR_NT) void g_chain_rr_kernel(const bf16* __restrict__ P, int ldp, RRArgs a,
-                                                           float* __restrict__ xg_part, int ntiles,
-                                                           const float* __restrict__ Vc = nullptr, int n_obj = 0,
-                                                           const float* __restrict__ Vq = nullptr, int rows_per_b = 1) {
-  static_assert(NK0 % 4 == 0 && NK0 >= 4 && NK0 <= 16, "layer-0 reduction length");
-  static_assert(INJ >= 0 && INJ < RR_L - 1, "the injected layer is one of the swapped-operand layers");
-  static_assert(!H8 || STORE, "e4m3 copies of H_0..2 (a stored H_3 stays bf16: the pair sum reads it)");
-  typedef FwdVm<NK0, STORE, ST3, XG, ALG0, INJ, H8> Vm;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
-  RRCore k;
-  k.init(lds);
-  const int t = threadIdx.x, lane = k.lane, w = k.w, n = k.n, h = k.h;
-  unsigned char* const stg = lds + RR_OFF_STG + w * RR_STG;
-  float* const bias_s = reinterpret_cast<float*>(lds + RR_OFF_BIAS);
-
-  const unsigned prow_off = (unsigned)(n * ldp + 8 * h) * 2u;         // this lane's byte offset inside a wave's 32 pair rows
-  auto load_row_frag = [&](long m0w, int ks) -> Frag {                // layer-0 operand straight from the pair rows
-    gbl_cu8* base = (gbl_cu8*)reinterpret_cast<const unsigned char*>(P + m0w * ldp);
-    asm volatile("" : "+s"(base));
-    return *reinterpret_cast<__attribute__((address_space(1))) const Frag*>(base + prow_off + 32 * ks);
-  };
-
-  // ALG0: pair row m = (b, i, j) -> object row b*n + j of Xp (a wave's 32 rows share b and i) and bias row b*n + i of Vc
-  auto op_row = [&](long m0w_) -> long {
-    if constexpr (!ALG0) return m0w_;
-    const int nn = n_obj * n_obj, b = (int)(m0w_ / nn), r = (int)(m0w_ - (long)b * nn), i = r / n_obj;
-    return (long)b * n_obj + (r - i * n_obj);
-  };
-  auto vc_row = [&](long m0w_) -> long {
-    const int nn = n_obj * n_obj, b = (int)(m0w_ / nn), r = (int)(m0w_ - (long)b * nn);
-    return (long)b * n_obj + r / n_obj;
-  };
-  float* const vc_s = reinterpret_cast<float*>(lds + RR_OFF_VC) + w * RR_G;
-  auto vc_load = [&](long m0w_) -> f32x4 { return *reinterpret_cast<const f32x4*>(Vc + vc_row(m0w_) * RR_G + lane * 4); };
-  f32x4 vcreg = {0.f, 0.f, 0.f, 0.f};
-  f32x4 vqreg = {0.f, 0.f, 0.f, 0.f};
-  auto vq_load = [&](int tile_) -> f32x4 {
-    return *reinterpret_cast<const f32x4*>(Vq + (long)(((long)tile_ * RR_TM) / rows_per_b) * RR_G + lane * 4);
-  };
-
-  Frag actA[16], actB[16], ring[RR_RD];
-  f32x16 acc[2];
-  u32x4 co[2];
-  f32x16 cinit;                                                       // bias of the current block, laid out like the accumulator
-
-  int tile = blockIdx.x;
-  if (tile >= ntiles) return;
-  // Two waves share each SIMD; the hardware arbitrates their issue slots by priority, then age, and the second-dispatched
-  // half loses every stage head.  One static s_setprio for that half evens the pair out (MI355X_MICROARCH.md, "Two waves
-  // per SIMD", item 4).  RN_RR_PRIO=0 turns it off.
-  if (a.prio && k.w >= RR_NW / 2) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-  for (int s = 0; s < RR_LA; ++s)
-#pragma unroll
-    for (int i = 0; i < RR_DPW; ++i) k.dma_piece(a.W[0], s, s, i);
-#pragma unroll
-  for (int ks = 0; ks < NK0; ++ks) actA[ks] = load_row_frag(op_row((long)tile * RR_TM + RR_WR * w), ks);
-  if constexpr (ALG0) *reinterpret_cast<f32x4*>(vc_s + lane * 4) = vc_load((long)tile * RR_TM + RR_WR * w);
-  if (t < RR_G) {
-#pragma unroll
-    for (int l = 0; l < RR_L; ++l)
-      bias_s[l * RR_G + t] = (INJ > 0 && l == INJ) ? Vq[(long)(((long)tile * RR_TM) / rows_per_b) * RR_G + t] : a.bias[l][t];
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < RR_RD; ++r) ring[r] = k.rd_frag(0, r);
-  bool first = true;
-
-  for (; tile < ntiles; tile += gridDim.x) {
-    const long m0w = (long)tile * RR_TM + RR_WR * w;                 // this wave's first pair row
-    const long wt = (long)tile * RR_NW + w;                           // ... = its 32-row block number
-    const int tnext = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
-    const long m0n = (long)tnext * RR_TM + RR_WR * w;
-    float xs[8];                                                      // pair-sum partials: feature 32 ob + lane % 32, this lane's 16 rows
-#pragma unroll
-    for (int i = 0; i < 8; ++i) xs[i] = 0.f;
-
-    // ---- epilogue pieces ---------------------------------------------------------------------------------
-    auto bias_read = [&](int l, int ob) {                             // -> C operand of the block's first MFMA
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float* src = (ALG0 && l == 0) ? vc_s : bias_s + l * RR_G;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(src + 32 * ob + 8 * j + 4 * h);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cinit[4 * j + r] = b[r];
-      }
-    };
-    auto mask_out = [&](int pl, int pob, int j, float x0, float x1, float x2, float x3) {
-      if constexpr (MASK) mask_store4(a.mask[pl] + (wt * 8 + pob) * 16 + 4 * j, __ballot(x0 > 0.f), __ballot(x1 > 0.f),
-                                      __ballot(x2 > 0.f), __ballot(x3 > 0.f));
-    };
-    // layers 0..2, group j of output block (pl, pob): features 32 pob + 8 j + 4 h + {0..3} of row n (the bias came
-    // in through the accumulator)
-    auto epi_group = [&](int pl, int pob, int j, int phase_lo, int phase_hi, Frag* dst, u32x2 (&pk)[4]) {
-      const f32x16& c = acc[pob & 1];
-      if (phase_lo <= 0 && 0 <= phase_hi) mask_out(pl, pob, j, c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]);
-      if (phase_lo <= 1 && 1 <= phase_hi) {
-        pk[j][0] = relu_pack_bf16(c[4 * j + 0], c[4 * j + 1]);
-        pk[j][1] = relu_pack_bf16(c[4 * j + 2], c[4 * j + 3]);
-      }
-      if (phase_lo <= 2 && 2 <= phase_hi) {
-        if constexpr (H8) *reinterpret_cast<unsigned*>(stg + n * RR_SRS8 + 32 * (pob & 1) + 8 * j + 4 * h) = rn_fp8x4_from_bf16(pk[j][0], pk[j][1]);
-        else if constexpr (STORE) *reinterpret_cast<u32x2*>(stg + n * RR_SRS + 16 * j + 8 * h) = pk[j];
-        if (dst) {
-          dst[2 * pob + (j >> 1)][(j & 1) * 2 + 0] = pk[j][0];
-          dst[2 * pob + (j >> 1)][(j & 1) * 2 + 1] = pk[j][1];
-        }
-      }
-    };
-    // cl < RR_L - 1: the row-blocked image for the weight gradient (transposing read-back); the last layer's rows (a stored
-    // H_3: the pair sum reads it) stay row-major
-    auto co_read = [&](int cl) {
-      if (cl < RR_L - 1) {
-        if constexpr (H8) co_read_blk8(stg, lane, co);
-        else co_read_blk16(stg, lane, co);
-        return;
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) co[q] = *reinterpret_cast<const u32x4*>(stg + (16 * q + (lane >> 2)) * RR_SRS + (lane & 3) * 16);
-    };
-    const unsigned orow_off = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
-    auto co_store = [&](int cl, int cob, int q) {
-      if (cl < RR_L - 1) {
-        // e4m3: blocks cob - 1, cob (one byte per element); 16-bit: block cob.  m0w * 256 elements = the wave's first row block
-        gbl_u8* baseb = (gbl_u8*)(reinterpret_cast<unsigned char*>(a.out[cl]) + m0w * RR_G * (H8 ? 1 : 2));
-        asm volatile("" : "+s"(baseb));
-        const unsigned off = H8 ? co_off_blk8(lane, cob, q) : co_off_blk16(lane, cob, q);
-        __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(baseb + off));
-        return;
-      }
-      gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.out[cl] + m0w * RR_G);
-      asm volatile("" : "+s"(base));
-      // non-temporal: read back only by the backward pass; in L2 it would evict the weight images
-      __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2));
-    };
-    // LAST layer: operands un-swapped (activations = A, weights = B), so D[row][feature] leaves a lane with ONE
-    // feature (32 pob + lane % 32) of 16 rows (8 (i / 4) + 4 h + i % 4): the pair sum (model.py:151-152) is an
-    // in-lane fp32 add of the un-rounded activations -- no cross-lane traffic, no LDS.
-    float b3 = 0.f;
-    auto epi3_group = [&](int pob, int j, int phase_lo, int phase_hi, f32x4 (&v)[4]) {
-      if (phase_lo <= 0 && 0 <= phase_hi) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[j][r] = fmaxf(acc[pob & 1][4 * j + r] + b3, 0.f);
-      }
-      if (phase_lo <= 1 && 1 <= phase_hi) {
-        if constexpr (XG) xs[pob] += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-        mask_out(RR_L - 1, pob, j, v[j][0], v[j][1], v[j][2], v[j][3]);
-      }
-      if (phase_lo <= 2 && 2 <= phase_hi) {
-        if constexpr (STORE && ST3) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(stg + (8 * j + 4 * h + r) * RR_SRS + n * 2) = (bf16)v[j][r];
-        }
-      }
-    };
-    // ---- one stage = one 32-feature output block of one layer ------------------------------------------------
-    auto stage = [&](auto lc, auto obc, Frag (&in)[16], Frag (&out)[16]) {
-      constexpr int l = decltype(lc)::value, ob = decltype(obc)::value;
-      constexpr int NK = (l == 0) ? NK0 : 16;
-      constexpr int CPG = NK / 4;                                     // MFMA gaps per epilogue group
-      constexpr int sidx = l * 8 + ob;
-      constexpr bool has_prev = sidx > 0;                             // (l, ob) == (0, 0): the tail of the last tile did it
-      constexpr int pl = ob ? l : l - 1, pob = ob ? ob - 1 : 7;
-      constexpr int cl = (sidx - 2) >> 3, cob = (sidx - 2) & 7;
-      constexpr bool has_co = STORE && sidx >= 2 && (cl < RR_L - 1 || ST3) && (!H8 || cl == RR_L - 1 || (cob & 1));
-      constexpr int didx = sidx + RR_LA;                              // stage whose weights are requested now
-      constexpr int dl = (didx >> 3) & 3, dob = didx & 7;
-      constexpr int nob = (sidx + 1) & 7;                             // next stage (the read-ahead crosses into it)
-      if (l < RR_L - 1) bias_read(l, ob);
-      if (has_prev && pl == RR_L - 1) b3 = bias_s[pl * RR_G + 32 * pob + n];
-      if (l == 0 && Vm::younger(sidx, true) != Vm::younger(sidx, false)) {
-        if (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Vm::younger(sidx, true)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Vm::younger(sidx, false)) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Vm::younger(sidx, false)) : "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (has_co) co_read(cl);
-      __builtin_amdgcn_sched_barrier(0);
-      Frag* dst = nullptr;
-      if (has_prev && pl < RR_L - 1) dst = ob ? out : in;
-      f32x4 v[4];
-      u32x2 pk[4];
-#pragma unroll
-      for (int ks = 0; ks < NK; ++ks) {
-        const int c = ks;
-        const bf16x8 fw = __builtin_bit_cast(bf16x8, ring[ks % RR_RD]), fx = __builtin_bit_cast(bf16x8, in[ks]);
-        const bf16x8 fa = (l == RR_L - 1) ? fx : fw, fb = (l == RR_L - 1) ? fw : fx;
-        if (ks == 0 && l < RR_L - 1) {
-          acc[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, cinit, 0, 0, 0);
-        } else if (ks == 0) {
-          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, z, 0, 0, 0);
-        } else {
-          acc[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[ob & 1], 0, 0, 0);
-        }
-        // ---- fillers of this MFMA gap
-        {                                                             // refill the ring slot just consumed, RR_RD fragments ahead
-          const int f = ks + RR_RD;
-          if (f < NK) ring[ks % RR_RD] = k.rd_frag(ob, f);
-          else ring[ks % RR_RD] = k.rd_frag(nob, f - NK);
-        }
-        if ((c & 1) && (c >> 1) < RR_DPW) k.dma_piece(a.W[dl], dob, dob, c >> 1);
-        if (has_prev && pl == RR_L - 1) {
-          const int j = c / CPG, ph = c % CPG;
-          if (ph < 3) epi3_group(pob, j, ph, ph, v);
-        } else if (has_prev) {
-          const int j = c / CPG, ph = c % CPG;
-          if (CPG >= 3) {
-            if (ph < 3) epi_group(pl, pob, j, ph, ph, dst, pk);
-          } else if (CPG == 2) {
-            if (ph == 0) epi_group(pl, pob, j, 0, 1, dst, pk);
-            else epi_group(pl, pob, j, 2, 2, dst, pk);
-          } else {
-            epi_group(pl, pob, j, 0, 2, dst, pk);
-          }
-        }
-        constexpr int CO1 = NK >= 12 ? 4 : NK / 4, CO2 = NK >= 12 ? 8 : NK - 1;   // the two copy-out stores of the stage
-        if (has_co && c == CO1) co_store(cl, cob, 0);
-        if (has_co && c == CO2) co_store(cl, cob, 1);
-        if (l == RR_L - 1 && (c & 1) == 0 && (c >> 1) < Vm::PF_PER) {   // next tile's pair rows -> the idle half of the ping-pong
-          const int i = ob * Vm::PF_PER + (c >> 1);
-          if (i < NK0) out[i] = load_row_frag(op_row(m0n), i);
-        }
-        if (ALG0 && sidx == Vm::VC_STAGE && c == 1) vcreg = vc_load(m0n);
-        if (INJ > 0 && sidx == Vm::VQ_STAGE && c == 1) vqreg = vq_load(tnext);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
 #define RN_LAYER(L_, IN_, OUT_)                                                                                      \
   stage(IC<L_>{}, IC<0>{}, IN_, OUT_); stage(IC<L_>{}, IC<1>{}, IN_, OUT_); stage(IC<L_>{}, IC<2>{}, IN_, OUT_);      \
   stage(IC<L_>{}, IC<3>{}, IN_, OUT_); stage(IC<L_>{}, IC<4>{}, IN_, OUT_); stage(IC<L_>{}, IC<5>{}, IN_, OUT_);      \
   stage(IC<L_>{}, IC<6>{}, IN_, OUT_); stage(IC<L_>{}, IC<7>{}, IN_, OUT_)
-    RN_LAYER(0, actA, actB);
-    RN_LAYER(1, actB, actA);
-    RN_LAYER(2, actA, actB);
-    RN_LAYER(3, actB, actA);
-    first = false;
-
-    // ---- tail: blocks (3, 6) and (3, 7) leave the chip
-    {
-      f32x4 v[4];
-      if constexpr (STORE && ST3) {
-        co_read(RR_L - 1);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) co_store(RR_L - 1, 6, q);
-      }
-      b3 = bias_s[(RR_L - 1) * RR_G + 32 * 7 + n];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) epi3_group(7, j, 0, 2, v);
-      if constexpr (STORE && ST3) {
-        co_read(RR_L - 1);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) co_store(RR_L - 1, 7, q);
-      }
-      if constexpr (XG && ALG0) {
-        // the factored-first-layer paths (a tile lies inside one question): the eight waves' partial rows meet in the staging
-        // area, idle since the last copy-out, and ONE row per tile leaves -- (M / 256, 256) instead of (M / 32, 256) for the
-        // reduction launch behind this kernel.  Wave w adds feature block w in wave order (deterministic).
-        float* const xs_s = reinterpret_cast<float*>(lds + RR_OFF_STG);
-#pragma unroll
-        for (int ob = 0; ob < 8; ++ob) {
-          const float tot = xs[ob] + __shfl_xor(xs[ob], 32);          // the two 16-row halves of this wave's 32 rows
-          if (h == 0) xs_s[w * RR_G + 32 * ob + n] = tot;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (h == 0) {
-          float v = xs_s[32 * w + n];
-#pragma unroll
-          for (int q = 1; q < RR_NW; ++q) v += xs_s[q * RR_G + 32 * w + n];
-          xg_part[(long)tile * RR_G + 32 * w + n] = v;
-        }
-      } else if constexpr (XG) {
-#pragma unroll
-        for (int ob = 0; ob < 8; ++ob) {
-          const float tot = xs[ob] + __shfl_xor(xs[ob], 32);          // the two 16-row halves of this wave's 32 rows
-          if (h == 0) xg_part[((long)tile * RR_NW + w) * RR_G + 32 * ob + n] = tot;
-        }
-      }
-      if constexpr (ALG0) *reinterpret_cast<f32x4*>(vc_s + lane * 4) = vcreg;   // wave-private row: LDS is in order per wave
-      if constexpr (INJ > 0) {
-        // shared row: every wave is past its last read of the old one (barrier of stage (INJ+1, 0)); the write must have
-        // landed before the other waves read it 8 * INJ + ... barriers from now -- this wave drains its LDS queue here
-        if (w == 0) {
-          *reinterpret_cast<f32x4*>(bias_s + INJ * RR_G + lane * 4) = vqreg;
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // trailing (unused) weight requests, scalar stores
-  if constexpr (MASK) asm volatile("s_dcache_wb" ::: "memory");
-}
 
 // ================================================================================================ forward, f16s
-// The parity-grade arithmetic of rn_g_chain_fwd_f16s in the register-resident mapping: fp16 activations in the operand
-// registers, every product twice -- against the hi and the lo half of the fp16-split weights (fp32 accumulate) -- so
-// the weight rounding error that keeps single-pass bf16 at ~1e-2 of the fp32 reference drops out.  Same structure as
-// g_chain_rr_kernel; a stage is hi | lo = 32 KB (4 ring slots, 3 stages ahead), the stored activation copies and the
-// masks are the bf16 kernel's (the backward pass is shared).
+// The parity-grade 16-bit arithmetic: fp16 activations in the operand registers (fp32 accumulate); layer 0 multiplies the hi AND
+// the lo half of its fp16-split weights, layers 1..3 one tile-dithered image each (below) -- the systematic weight rounding error
+// that keeps single-pass bf16 at ~1e-2 of the fp32 reference drops out.  A ring stage is hi | lo = 32 KB (4 slots, 3 stages ahead).
 namespace {
 constexpr int F_STAGE = 32 * 1024, F_NSLOT = 4, F_LA = 3, F_RDK = 2;
 static_assert(F_NSLOT * F_STAGE == RR_NSLOT * RR_STAGE, "same ring bytes");
@@ -707,7 +344,15 @@ struct F16Vm {
 };
 }  // namespace
 
-// ALG0: as in g_chain_rr_kernel -- P = the packed fp16 object rows (K = 64), layer-0 bias row = Vc[b*n + i].
+// ALG0 -- the first layer factored through the pair structure (the only instantiated form):
+//   W0 [x_j | x_i | q] + b0 = W0a x_j + (W0b x_i + W0c q + b0): the bracket is constant over a wave's 32 pair rows (same question,
+//   same i) and comes in as the layer's BIAS row -- Vc[b*n + i][256], fp32, from rn_pair_tables; only the x_j part is left as an
+//   MFMA, K = 64 (P = the packed fp16 object rows Xp[b*n + j][64], a 0.5 MB table that lives in L2) instead of K = 192 on a
+//   100 MB pair matrix that then never exists.
+// INJ > 0 -- the question injected at layer INJ (the reference's "IR" variants, model.py:131-142): the layer's input is
+//   [H_{INJ-1} | q[b]], so W_INJ [H | q] + b = W_INJ[:, 0:256] H + (W_INJ[:, 256:] q[b] + b): the bracket is a per-QUESTION constant
+//   -- Vq[b][256], fp32, one small product on the host side -- and takes the place of the layer's bias row in LDS for the tile (a
+//   256-row tile lies inside one question: n*n % 256 == 0).  The next tile's row is fetched during the last layer.
 // Passes.  Layer 0 runs hi + lo (its K = 64 / 192 product is a twelfth .. a quarter of a later layer's).  Layers 1..3 run ONE pass
 // on TILE-DITHERED hi images (rn_pack_matrix_frag_many): tile t multiplies image t mod V, V = 4 roundings of the weights whose
 // mean is within ulp / 8 of the fp32 weight.  What keeps single-pass 16-bit arithmetic at 3e-3 of the fp32 reference is not the
@@ -716,8 +361,9 @@ struct F16Vm {
 // arithmetic on the released checkpoints, 24 questions, tools/dbg/emulate_lo_sets.py; the bar is 1e-3): hi + lo on layers 0..2
 // (round 2) 1.1e-4 / on all four 5e-5 (ir-fp); one pass everywhere 2.6e-3 / 6.3e-4; THIS scheme 1.7e-4 (original-fp) / 1.9e-4
 // (ir-fp) -- with 448 instead of 704 / 832 MFMAs per wave and tile.
-// H8: as in g_chain_rr_kernel -- the e4m3 copy is converted from the fp16 operand pair the group has just built (clamp + two
-// v_cvt_scalef32_pk_fp8_f16 instead of the separate bf16 rounding).
+// H8 -- the H_l copies for the weight gradient leave as OCP e4m3 bytes (rn_common.h), converted from the fp16 operand pair the
+//   group has just built (clamp + two v_cvt_scalef32_pk_fp8_f16); TWO blocks share a staging row (64 B) and leave together after
+//   the odd one: a row must receive 64 contiguous bytes per store instruction (32-byte pieces ran the kernel at half speed).
 // ABL (RN_DIAG builds only: timing ablations, WRONG results) -- 1: no bias rows (the block's first MFMA starts from zero), 2: no
 // barriers, 4: no waits for the weight stream, 8: no copy-out (no staging reads, no H stores), 16: no mask stores, 32: no epilogue
 // at all, 64: no weight requests
@@ -1471,58 +1117,8 @@ static int rr_num_cus() {
 }
 
 extern "C" int rn_g_chain_rr_tile(void) { return RR_TM; }
-extern "C" size_t rn_g_chain_rr_mask_bytes(int M) { return M > 0 ? (size_t)M * 32 : 0; }
+size_t rnws_rr_mask(int M) { return M > 0 ? (size_t)M * 32 : 0; }
 
-template <int NK0>
-static void rr_fwd_launch(int grid, hipStream_t s, const bf16* P, int ldp, const RRArgs& a, float* xg, int ntiles, bool store,
-                          bool st3, bool mask) {
-#define RN_GO(ST, S3, MK, XG_) g_chain_rr_kernel<NK0, ST, S3, MK, XG_><<<grid, RR_NT, 0, s>>>(P, ldp, a, xg, ntiles)
-  if (!store) RN_GO(false, false, false, true);                        // inference: pair sums only
-  else if (mask && !st3 && xg) RN_GO(true, false, true, true);         // training: H_0..2 + masks + pair sums
-  else if (mask && xg) RN_GO(true, true, true, true);
-  else if (mask) RN_GO(true, true, true, false);
-  else if (xg) RN_GO(true, true, false, true);
-  else RN_GO(true, true, false, false);
-#undef RN_GO
-}
-
-extern "C" int rn_g_chain_fwd_rr(const void* P, int ldp, const void* const* Wf, const float* const* bias, void* const* H,
-                                 void* const* mask, int K0, float* xg_part, int M, int L, int G, void* stream) {
-  RN_CHECK_ARG(P && Wf && bias && M > 0, "rn_g_chain_fwd_rr: bad pointer/size");
-  RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_fwd_rr: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
-  RN_CHECK_ARG(M % RR_TM == 0, "rn_g_chain_fwd_rr: M=%d must be a multiple of %d", M, RR_TM);
-  RN_CHECK_ARG(K0 == 192 || K0 == 256, "rn_g_chain_fwd_rr: layer-0 reduction length %d unsupported (192 or 256)", K0);
-  RN_CHECK_ARG(ldp % 8 == 0 && ldp >= K0 && ((uintptr_t)P % 16 == 0), "rn_g_chain_fwd_rr: bad P layout");
-  RRArgs a;
-  memset(&a, 0, sizeof(a));
-  a.prio = rr_prio();
-  int nh = 0, nm = 0;
-  for (int l = 0; l < RR_L; ++l) {
-    RN_CHECK_ARG(Wf[l] && bias[l], "rn_g_chain_fwd_rr: layer %d weight/bias is NULL", l);
-    RN_CHECK_ARG(((uintptr_t)Wf[l] | (uintptr_t)bias[l] | (uintptr_t)(H ? H[l] : nullptr) | (uintptr_t)(mask ? mask[l] : nullptr)) % 16 == 0,
-                 "rn_g_chain_fwd_rr: layer %d pointers must be 16-byte aligned", l);
-    a.W[l] = (const bf16*)Wf[l];
-    a.bias[l] = bias[l];
-    a.out[l] = H ? (bf16*)H[l] : nullptr;
-    a.mask[l] = mask ? (u64*)mask[l] : nullptr;
-    nh += a.out[l] != nullptr;
-    nm += a.mask[l] != nullptr;
-  }
-  // H: none (inference), all four, or -- together with the masks -- layers 0..2 only (the last activation is
-  // then needed by nobody: its pair sum and its ReLU mask are produced on chip)
-  const bool h012 = nh == 3 && !a.out[RR_L - 1] && nm == RR_L;
-  RN_CHECK_ARG(nh == 0 || nh == RR_L || h012, "rn_g_chain_fwd_rr: H must hold none, all, or (with masks) all but the last activation");
-  RN_CHECK_ARG(nm == 0 || (nm == RR_L && nh >= 3), "rn_g_chain_fwd_rr: masks come as a full set together with the stored activations");
-  RN_CHECK_ARG(nh || xg_part, "rn_g_chain_fwd_rr: nothing to compute (no H, no xg_part)");
-  const int ntiles = M / RR_TM;
-  const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
-  if (K0 == 192) rr_fwd_launch<12>(grid, (hipStream_t)stream, (const bf16*)P, ldp, a, xg_part, ntiles, nh > 0, nh == RR_L, nm > 0);
-  else rr_fwd_launch<16>(grid, (hipStream_t)stream, (const bf16*)P, ldp, a, xg_part, ntiles, nh > 0, nh == RR_L, nm > 0);
-  RN_LAUNCH_CHECK("rn_g_chain_fwd_rr");
-  return 0;
-}
-
-// The forward chain with the first layer factored through the pair structure (see g_chain_rr_kernel, ALG0).
 static int rr_check_inject(const char* who, const float* Vq, int inj, int n) {
   RN_CHECK_ARG(inj == 0 || inj == 2, "%s: the question can be injected at layer 0 (tables) or 2 (got %d)", who, inj);
   RN_CHECK_ARG(inj == 0 || (Vq && ((uintptr_t)Vq % 16 == 0)), "%s: injection at layer %d needs the 16-byte aligned question rows Vq", who, inj);
@@ -1530,52 +1126,7 @@ static int rr_check_inject(const char* who, const float* Vq, int inj, int n) {
   return 0;
 }
 
-extern "C" int rn_g_chain_fwd_rr_alg0(const void* Xp, const float* Vc, int n, const void* const* Wf, const float* const* bias,
-                                      void* const* H, int h_dtype, void* const* mask, float* xg_part, const float* Vq, int inject_layer,
-                                      int M, int L, int G, void* stream) {
-  RN_CHECK_ARG(Xp && Vc && Wf && bias && M > 0 && xg_part, "rn_g_chain_fwd_rr_alg0: bad pointer/size");
-  RN_CHECK_ARG(!H || h_dtype == RN_BF16 || h_dtype == RN_FP8, "rn_g_chain_fwd_rr_alg0: h_dtype must be RN_BF16 or RN_FP8 (got %d)", h_dtype);
-  const bool h8 = H && h_dtype == RN_FP8;
-  if (int rc = rr_check_inject("rn_g_chain_fwd_rr_alg0", Vq, inject_layer, n)) return rc;
-  RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_fwd_rr_alg0: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
-  RN_CHECK_ARG(n > 0 && n % RR_WR == 0 && M % ((long)n * n) == 0 && M % RR_TM == 0,
-               "rn_g_chain_fwd_rr_alg0: needs n %% %d == 0 and M a multiple of n*n and of %d (n=%d M=%d)", RR_WR, RR_TM, n, M);
-  RN_CHECK_ARG(((uintptr_t)Xp | (uintptr_t)Vc) % 16 == 0, "rn_g_chain_fwd_rr_alg0: tables must be 16-byte aligned");
-  RRArgs a;
-  memset(&a, 0, sizeof(a));
-  a.prio = rr_prio();
-  int nh = 0, nm = 0;
-  for (int l = 0; l < RR_L; ++l) {
-    RN_CHECK_ARG(Wf[l] && bias[l], "rn_g_chain_fwd_rr_alg0: layer %d weight/bias is NULL", l);
-    RN_CHECK_ARG(((uintptr_t)Wf[l] | (uintptr_t)bias[l] | (uintptr_t)(H ? H[l] : nullptr) | (uintptr_t)(mask ? mask[l] : nullptr)) % 16 == 0,
-                 "rn_g_chain_fwd_rr_alg0: layer %d pointers must be 16-byte aligned", l);
-    a.W[l] = (const bf16*)Wf[l];
-    a.bias[l] = bias[l];
-    a.out[l] = H ? (bf16*)H[l] : nullptr;
-    a.mask[l] = mask ? (u64*)mask[l] : nullptr;
-    nh += a.out[l] != nullptr;
-    nm += a.mask[l] != nullptr;
-  }
-  const bool h012 = nh == 3 && !a.out[RR_L - 1] && nm == RR_L;
-  RN_CHECK_ARG((nh == 0 && nm == 0) || h012, "rn_g_chain_fwd_rr_alg0: H / masks: none (inference) or H_0..2 + all four masks (training)");
-  const int ntiles = M / RR_TM;
-  const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
-  hipStream_t s = (hipStream_t)stream;
-  const int rpb = n * n;
-  if (inject_layer == 2) {
-    if (nh == 0) g_chain_rr_kernel<4, false, false, false, true, true, 2><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
-    else if (h8) g_chain_rr_kernel<4, true, false, true, true, true, 2, true><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
-    else g_chain_rr_kernel<4, true, false, true, true, true, 2><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
-  } else {
-    if (nh == 0) g_chain_rr_kernel<4, false, false, false, true, true><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n);
-    else if (h8) g_chain_rr_kernel<4, true, false, true, true, true, 0, true><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n);
-    else g_chain_rr_kernel<4, true, false, true, true, true><<<grid, RR_NT, 0, s>>>((const bf16*)Xp, 64, a, xg_part, ntiles, Vc, n);
-  }
-  RN_LAUNCH_CHECK("rn_g_chain_fwd_rr_alg0");
-  return 0;
-}
-
-// Shared argument checks of the two f16s entry points: Whi[0] / Wlo[0] = the two fragment-major fp16 images of layer 0,
+// Argument checks of the f16s entry point: Whi[0] / Wlo[0] = the two fragment-major fp16 images of layer 0,
 // Whi[1..3] = `dither` tile-dithered hi images each (128 KB apart); Wlo[1..3] are not read.
 static int rr_f16s_args(const char* who, RRArgsF& a, const void* const* Whi, const void* const* Wlo, int dither, const float* const* bias,
                         void* const* H, void* const* mask, int* nh_, int* nm_) {
@@ -1601,57 +1152,7 @@ static int rr_f16s_args(const char* who, RRArgsF& a, const void* const* Whi, con
   return 0;
 }
 
-extern "C" int rn_g_chain_fwd_rr_f16s(const void* P16, int ldp, const void* const* Whi, const void* const* Wlo, int dither, const float* const* bias,
-                                      void* const* H, int h_dtype, void* const* mask, int K0, float* xg_part, int M, int L, int G,
-                                      void* stream) {
-  RN_CHECK_ARG(P16 && Whi && Wlo && bias && M > 0, "rn_g_chain_fwd_rr_f16s: bad pointer/size");
-  RN_CHECK_ARG(!H || h_dtype == RN_BF16 || h_dtype == RN_FP8, "rn_g_chain_fwd_rr_f16s: h_dtype must be RN_BF16 or RN_FP8 (got %d)", h_dtype);
-  const bool h8 = H && h_dtype == RN_FP8;
-  RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_fwd_rr_f16s: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
-  RN_CHECK_ARG(M % RR_TM == 0, "rn_g_chain_fwd_rr_f16s: M=%d must be a multiple of %d", M, RR_TM);
-  RN_CHECK_ARG(K0 == 192 || K0 == 256, "rn_g_chain_fwd_rr_f16s: layer-0 reduction length %d unsupported (192 or 256)", K0);
-  RN_CHECK_ARG(ldp % 8 == 0 && ldp >= K0 && ((uintptr_t)P16 % 16 == 0), "rn_g_chain_fwd_rr_f16s: bad P layout");
-  RRArgsF a;
-  int nh = 0, nm = 0;
-  if (int rc = rr_f16s_args("rn_g_chain_fwd_rr_f16s", a, Whi, Wlo, dither, bias, H, mask, &nh, &nm)) return rc;
-  const bool h012 = nh == 3 && !a.out[RR_L - 1] && nm == RR_L;
-  RN_CHECK_ARG(nh == 0 || nh == RR_L || h012, "rn_g_chain_fwd_rr_f16s: H must hold none, all, or (with masks) all but the last activation");
-  RN_CHECK_ARG(nm == 0 || (nm == RR_L && nh >= 3), "rn_g_chain_fwd_rr_f16s: masks come as a full set together with the stored activations");
-  RN_CHECK_ARG(nh || xg_part, "rn_g_chain_fwd_rr_f16s: nothing to compute (no H, no xg_part)");
-  const bool h0123m = nh == RR_L && nm == RR_L;                       // waves straddling questions: H_3 stored for the pair sum, masks for the backward chain
-  RN_CHECK_ARG(nh == 0 || h012 || (nh == RR_L && nm == 0) || (h0123m && !xg_part),
-               "rn_g_chain_fwd_rr_f16s: supported outputs: inference, training (H_0..2 + masks + xg_part), all four H, all four H + masks (no xg_part)");
-  const int ntiles = M / RR_TM;
-  const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
-  hipStream_t s = (hipStream_t)stream;
-  const f16* Pp = (const f16*)P16;
-  // e4m3 copies of H_0..2 (h_dtype = RN_FP8; a stored H_3 stays bf16): the two training output sets at K0 = 192
-  if (h8) {
-    RN_CHECK_ARG(K0 == 192 && ((h012 && xg_part) || h0123m), "rn_g_chain_fwd_rr_f16s: e4m3 copies need K0 == 192 and a training output set");
-    if (h0123m) g_chain_rr_f16s_kernel<12, true, true, true, false, false, 0, true><<<grid, RR_NT, 0, s>>>(Pp, ldp, a, xg_part, ntiles);
-    else g_chain_rr_f16s_kernel<12, true, false, true, true, false, 0, true><<<grid, RR_NT, 0, s>>>(Pp, ldp, a, xg_part, ntiles);
-    RN_LAUNCH_CHECK("rn_g_chain_fwd_rr_f16s(e4m3 copies)");
-    return 0;
-  }
-#define RN_GO(NK0_, ST, S3, MK, XG_) g_chain_rr_f16s_kernel<NK0_, ST, S3, MK, XG_><<<grid, RR_NT, 0, s>>>(Pp, ldp, a, xg_part, ntiles)
-#define RN_SEL(NK0_)                                                        \
-  do {                                                                      \
-    if (nh == 0) RN_GO(NK0_, false, false, false, true);                    \
-    else if (h012 && xg_part) RN_GO(NK0_, true, false, true, true);         \
-    else if (h012) { rn_set_error("rn_g_chain_fwd_rr_f16s: training output set needs xg_part"); return -1; } \
-    else if (h0123m) RN_GO(NK0_, true, true, true, false);                  \
-    else if (xg_part) RN_GO(NK0_, true, true, false, true);                 \
-    else RN_GO(NK0_, true, true, false, false);                             \
-  } while (0)
-  if (K0 == 192) RN_SEL(12);
-  else RN_SEL(16);
-#undef RN_SEL
-#undef RN_GO
-  RN_LAUNCH_CHECK("rn_g_chain_fwd_rr_f16s");
-  return 0;
-}
-
-// f16s arithmetic on the factored first layer (see g_chain_rr_kernel, ALG0): Xp16 = fp16 object rows (B*n, 64).
+// The forward chain (f16s arithmetic, factored first layer): Xp16 = fp16 object rows (B*n [+ 1], 64).
 extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, int njp, const void* const* Whi, const void* const* Wlo, int dither,
                                            const float* const* bias, void* const* H, int h_dtype, void* const* mask, void* gate_image,
                                            float* xg_part, const float* Vq, int inject_layer, int M, int L, int G, void* stream) {

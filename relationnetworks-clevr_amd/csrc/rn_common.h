@@ -61,6 +61,21 @@ static inline const char* rn_diag_env(const char* name) { return getenv(name); }
 static inline const char* rn_diag_env(const char*) { return nullptr; }
 #endif
 
+// workspace sizes of the entry points, one function per file that owns the layout; exported through rn_workspace_bytes (rn_pair.hip)
+size_t rnws_rr_mask(int M);
+size_t rnws_conv_bwd_weight(int N, int Cin, int H, int W);
+size_t rnws_bn_relu(int N, int C, int HW);
+size_t rnws_extract(int B, int n, int F);
+size_t rnws_pair_sum(int B, int npairs, int G);
+size_t rnws_pair_reduce(int B, int n, int G);
+size_t rnws_wgrad0(int B, int n, int N);
+size_t rnws_pair_features(int B, int npairs, int F);
+size_t rnws_f_phi_nll(int B);
+size_t rnws_f_phi_bwd(int B, int F1, int F2, int A);
+size_t rnws_clip_adam(void);
+size_t rnws_wgrad(int M, int N, int K);
+size_t rnws_wgrad_blocked(int M, int rows_per_question, int njobs, int aligned);
+
 // rn_convnorm.hip: pass 1 of the batch-norm backward (slice sums into ws), launched by rn_conv.hip's fused entry
 int rn_cn_launch_bwd_sums(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                           void* ws, int N, int C, int HW, void* stream, int* S);

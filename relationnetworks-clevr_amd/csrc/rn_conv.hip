@@ -998,7 +998,7 @@ static CwPlan cw_plan(int N, int Cin, int H, int W) {
 }
 }  // namespace
 
-extern "C" size_t rn_conv3x3s2_bwd_weight_ws_bytes(int N, int Cin, int H, int W) {
+size_t rnws_conv_bwd_weight(int N, int Cin, int H, int W) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0) return 0;
   return (size_t)cw_plan(N, Cin, H, W).grid * 24 * Cin * 9 * sizeof(float);
 }

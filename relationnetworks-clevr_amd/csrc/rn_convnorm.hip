@@ -359,7 +359,7 @@ static int cn_check(const char* who, const void* a, const void* b, int N, int C,
   return 0;
 }
 
-extern "C" size_t rn_bn_relu_ws_bytes(int N, int C, int HW) {
+size_t rnws_bn_relu(int N, int C, int HW) {
   if (N <= 0 || C <= 0 || HW <= 0) return 0;
   return (size_t)C * cn_slices((long)N * HW / 4) * 2 * sizeof(double);
 }

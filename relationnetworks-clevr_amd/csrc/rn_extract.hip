@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void extract_finish_kernel(const float* __rest
 }
 }  // namespace
 
-extern "C" size_t rn_extract_ws_bytes(int B, int n, int F) {
+size_t rnws_extract(int B, int n, int F) {
   return (B > 0 && n > 0 && F > 0) ? (size_t)2 * B * n * cdiv(n, XT) * F * sizeof(float) : 0;
 }
 

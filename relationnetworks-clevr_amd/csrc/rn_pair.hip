@@ -21,6 +21,26 @@ void rn_set_error(const char* fmt, ...) {
 extern "C" const char* rn_last_error(void) { return g_err; }
 extern "C" int rn_abi_version(void) { return RN_ABI_VERSION; }
 
+// ------------------------------------------------------------------ workspace sizes
+extern "C" size_t rn_workspace_bytes(int op, int a, int b, int c, int d) {
+  switch (op) {
+    case RN_WS_RR_MASK: return rnws_rr_mask(a);
+    case RN_WS_PAIR_SUM: return rnws_pair_sum(a, b, c);
+    case RN_WS_WGRAD: return rnws_wgrad(a, b, c);
+    case RN_WS_WGRAD_BLOCKED: return rnws_wgrad_blocked(a, b, c, d);
+    case RN_WS_PAIR_REDUCE: return rnws_pair_reduce(a, b, c);
+    case RN_WS_WGRAD0: return rnws_wgrad0(a, b, c);
+    case RN_WS_PAIR_FEATURES: return rnws_pair_features(a, b, c);
+    case RN_WS_EXTRACT: return rnws_extract(a, b, c);
+    case RN_WS_F_PHI_BWD: return rnws_f_phi_bwd(a, b, c, d);
+    case RN_WS_F_PHI_NLL: return rnws_f_phi_nll(a);
+    case RN_WS_CLIP_ADAM: return rnws_clip_adam();
+    case RN_WS_CONV_BWD_WEIGHT: return rnws_conv_bwd_weight(a, b, c, d);
+    case RN_WS_BN_RELU: return rnws_bn_relu(a, b, c);
+    default: rn_set_error("rn_workspace_bytes: unknown op %d", op); return 0;
+  }
+}
+
 // ------------------------------------------------------------------ K1 pair build
 // One workgroup = one question b and IB consecutive "i" objects.  For a fixed (b,i) the
 // n rows (b,i,0..n-1) are one contiguous n*ld*sizeof(T) byte span of P, and only the first
@@ -225,30 +245,6 @@ __global__ __launch_bounds__(256) void pack_matrix_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void pack_matrix_split_kernel(const float* __restrict__ src, long sr, long sc, int R,
-                                                                int C, f16* __restrict__ hi, f16* __restrict__ lo, int ld,
-                                                                int Rpad) {
-  const long total = (long)Rpad * ld;
-  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
-    const int r = (int)(g / ld), c = (int)(g - (long)r * ld);
-    const float v = (r < R && c < C) ? src[(long)r * sr + (long)c * sc] : 0.f;
-    const f16 h = (f16)v;
-    hi[g] = h;
-    lo[g] = (f16)(v - (float)h);
-  }
-}
-
-extern "C" int rn_pack_matrix_split(const float* src, long sr, long sc, int R, int C, void* hi, void* lo, int ld, int Rpad,
-                                    void* stream) {
-  RN_CHECK_ARG(src && hi && lo && R > 0 && C > 0 && ld >= C && Rpad >= R, "rn_pack_matrix_split: bad pointer/size");
-  const long total = (long)Rpad * ld;
-  int blocks = cdiv(total, 256);
-  if (blocks > 2048) blocks = 2048;
-  pack_matrix_split_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(src, sr, sc, R, C, (f16*)hi, (f16*)lo, ld, Rpad);
-  RN_LAUNCH_CHECK("rn_pack_matrix_split");
-  return 0;
-}
-
 extern "C" int rn_pack_matrix(const float* src, long sr, long sc, int R, int C, void* dst, int dtype, int ld, int Rpad,
                               void* stream) {
   RN_CHECK_ARG(src && dst && R > 0 && C > 0 && ld >= C && Rpad >= R, "rn_pack_matrix: bad pointer/size");
@@ -349,7 +345,7 @@ static int segsum_launch(const void* in, int ld, float* out, void* ws, int dtype
   return 0;
 }
 
-extern "C" size_t rn_pair_sum_ws_bytes(int B, int npairs, int G) {
+size_t rnws_pair_sum(int B, int npairs, int G) {
   return (size_t)B * cdiv(npairs, 256) * G * sizeof(float);
 }
 
@@ -580,7 +576,7 @@ __global__ __launch_bounds__(256) void pair_reduce_finish_kernel(const f32x4* __
 }
 
 
-extern "C" size_t rn_pair_reduce_ws_bytes(int B, int n, int G) {
+size_t rnws_pair_reduce(int B, int n, int G) {
   return (size_t)cdiv(n, 16) * B * n * G * sizeof(float);            // Ri partials, one slab per block of 16 j
 }
 
@@ -777,7 +773,7 @@ __global__ __launch_bounds__(256) void wgrad0_finish_kernel(const float* __restr
   }
 }
 
-extern "C" size_t rn_wgrad0_ws_bytes(int B, int n, int N) {
+size_t rnws_wgrad0(int B, int n, int N) {
   return (size_t)cdiv((long)B * n, W0_RS) * 2 * N * W0_CMAX * sizeof(float);
 }
 
@@ -852,7 +848,7 @@ static int pf_slices(int npairs) {
   int s = npairs / 64;
   return s < 1 ? 1 : (s > 64 ? 64 : s);
 }
-extern "C" size_t rn_pair_features_ws_bytes(int B, int npairs, int F) { return (size_t)2 * B * pf_slices(npairs) * F * sizeof(float); }
+size_t rnws_pair_features(int B, int npairs, int F) { return (size_t)2 * B * pf_slices(npairs) * F * sizeof(float); }
 
 extern "C" int rn_pair_features(const void* A, int lda, int F, float* maxf, float* avgf, void* ws, int dtype, int B, int npairs,
                                 void* stream) {

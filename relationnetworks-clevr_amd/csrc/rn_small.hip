@@ -81,69 +81,6 @@ extern "C" int rn_gemm_f32(const float* A, long sam, long sak, const float* B, l
   return 0;
 }
 
-// one wave per row
-__global__ __launch_bounds__(256) void log_softmax_fwd_kernel(const float* __restrict__ z, float* __restrict__ out,
-                                                              int Bn, int A) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= Bn) return;
-  const float* zr = z + (long)row * A;
-  float mx = -INFINITY;
-  for (int c = lane; c < A; c += 64) mx = fmaxf(mx, zr[c]);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  float sum = 0.f;
-  for (int c = lane; c < A; c += 64) sum += expf(zr[c] - mx);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-  const float lse = mx + logf(sum);
-  for (int c = lane; c < A; c += 64) out[(long)row * A + c] = zr[c] - lse;
-}
-
-__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __restrict__ out,
-                                                              const float* __restrict__ gout, float* __restrict__ dz,
-                                                              int Bn, int A) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= Bn) return;
-  float gs = 0.f;
-  for (int c = lane; c < A; c += 64) gs += gout[(long)row * A + c];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) gs += __shfl_xor(gs, o);
-  for (int c = lane; c < A; c += 64) {
-    const long i = (long)row * A + c;
-    dz[i] = gout[i] - expf(out[i]) * gs;
-  }
-}
-
-extern "C" int rn_log_softmax_fwd(const float* z, float* out, int B, int A, void* stream) {
-  RN_CHECK_ARG(z && out && B > 0 && A > 0, "rn_log_softmax_fwd: bad pointer/size");
-  log_softmax_fwd_kernel<<<cdiv(B, 4), 256, 0, (hipStream_t)stream>>>(z, out, B, A);
-  RN_LAUNCH_CHECK("rn_log_softmax_fwd");
-  return 0;
-}
-
-extern "C" int rn_log_softmax_bwd(const float* out, const float* gout, float* dz, int B, int A, void* stream) {
-  RN_CHECK_ARG(out && gout && dz && B > 0 && A > 0, "rn_log_softmax_bwd: bad pointer/size");
-  log_softmax_bwd_kernel<<<cdiv(B, 4), 256, 0, (hipStream_t)stream>>>(out, gout, dz, B, A);
-  RN_LAUNCH_CHECK("rn_log_softmax_bwd");
-  return 0;
-}
-
-__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ src, long ld, float* __restrict__ out,
-                                                         int R, int C) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int r = 0; r < R; ++r) s += src[(long)r * ld + c];
-  out[c] = s;
-}
-
-extern "C" int rn_colsum_f32(const float* src, long ld, float* out, int R, int C, void* stream) {
-  RN_CHECK_ARG(src && out && R > 0 && C > 0, "rn_colsum_f32: bad pointer/size");
-  colsum_f32_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(src, ld, out, R, C);
-  RN_LAUNCH_CHECK("rn_colsum_f32");
-  return 0;
-}
-
 // ------------------------------------------------------------------------------------------------ fused f_phi
 // f_phi (model.py:155-162) is three tiny matrix products on B rows (17 MFLOP at B = 64): its cost is the number
 // of dependent launches on the critical path between the forward and the backward chain, not arithmetic.  One
@@ -589,7 +526,7 @@ extern "C" int rn_f_phi_fwd(const float* xg, const float* W1, const float* b1, c
 
 // f_phi + log_softmax + mean NLL (train.py:40-41) in one launch.  sync_ws: rn_f_phi_nll_ws_bytes(B) bytes, ZEROED ONCE by the
 // caller and then owned by these calls (block partials + a completion counter that re-arms itself).
-extern "C" size_t rn_f_phi_nll_ws_bytes(int B) { return B > 0 ? ((size_t)cdiv(B, FP_RB) + 4) * sizeof(float) : 0; }
+size_t rnws_f_phi_nll(int B) { return B > 0 ? ((size_t)cdiv(B, FP_RB) + 4) * sizeof(float) : 0; }
 
 extern "C" int rn_f_phi_fwd_nll(const float* xg, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                                 const float* b3, const float* mask, const long long* label, float* f1, float* f2, float* out,
@@ -663,7 +600,7 @@ extern "C" int rn_f_phi_bwd_grads(const void* bwd_ws, const float* xg, const flo
   return 0;
 }
 
-extern "C" size_t rn_f_phi_bwd_ws_bytes(int B, int F1, int F2, int A) { return (size_t)B * (F1 + F2 + A) * sizeof(float); }
+size_t rnws_f_phi_bwd(int B, int F1, int F2, int A) { return (size_t)B * (F1 + F2 + A) * sizeof(float); }
 
 extern "C" int rn_f_phi_bwd(const float* gout, const float* out, const float* f2, const float* f1, const float* xg, const float* W1,
                             const float* W2, const float* W3, const float* mask, float* dW1, float* db1, float* dW2, float* db2,
@@ -785,7 +722,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const RnAdamChunk* __res
 }
 
 extern "C" int rn_clip_adam_chunk(void) { return OPT_CHUNK; }
-extern "C" size_t rn_clip_adam_ws_bytes(void) { return OPT_NB * sizeof(double); }
+size_t rnws_clip_adam(void) { return OPT_NB * sizeof(double); }
 
 extern "C" int rn_clip_adam_step(const void* chunks, int nchunks, float* g, float* m, float* v, long n, void* ws, float grad_scale,
                                  float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* norm_out,

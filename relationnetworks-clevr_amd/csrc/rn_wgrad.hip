@@ -221,7 +221,7 @@ static void wgrad_plan(int M, int N, int K, int* nkt, int* gy, int* Z, int* rps)
   *rps = r;
 }
 
-extern "C" size_t rn_wgrad_ws_bytes(int M, int N, int K) {
+size_t rnws_wgrad(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0 || N % 256 || K % 32) return 0;
   int nkt, gy, Z, rps;
   wgrad_plan(M, N, K, &nkt, &gy, &Z, &rps);

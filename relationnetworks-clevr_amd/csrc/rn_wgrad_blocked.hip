@@ -34,6 +34,7 @@
 // Same fp32 partial format and fixed-order reduction as the general kernel: bitwise deterministic.  Up to 4 jobs (the three
 // layers of a step) run as ONE launch + ONE reduction launch.
 #include "rn_common.h"
+#include "../../include/rn_hip_debug.h"
 
 #ifndef KB_RING24
 #define KB_RING24 6       // ring stages of a 24-KB step (bf16 dZ + e4m3 A) ...
@@ -402,7 +403,7 @@ extern "C" int rn_wgrad_blocked_splits(int M, int rows_per_question, int njobs, 
   return (M > 0 && M % 64 == 0 && njobs > 0 && njobs <= KB_MAXJOBS) ? kb_splits(M, rows_per_question, njobs, aligned) : 0;
 }
 
-extern "C" size_t rn_wgrad_blocked_ws_bytes(int M, int rows_per_question, int njobs, int aligned) {
+size_t rnws_wgrad_blocked(int M, int rows_per_question, int njobs, int aligned) {
   const int Z = rn_wgrad_blocked_splits(M, rows_per_question, njobs, aligned);
   if (Z <= 0) return 0;
   return (size_t)njobs * ((size_t)Z * 256 * 256 + (size_t)Z * 4 * 256) * sizeof(float);

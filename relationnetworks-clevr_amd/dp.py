@@ -168,7 +168,7 @@ class FusedClipAdam:
         self.ptrs = [p.data_ptr() for p in bucket.params]
         self.m = torch.zeros_like(bucket.flat)
         self.v = torch.zeros_like(bucket.flat)
-        self.ws = torch.empty(H.load().rn_clip_adam_ws_bytes(), dtype=torch.uint8, device=dev)
+        self.ws = torch.empty(H.workspace_bytes(H.WS_CLIP_ADAM), dtype=torch.uint8, device=dev)
         self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.t = 0
         # in-graph mode (one GPU): every per-step scalar lives in device memory -- hyper = {grad_scale, max_norm, lr, beta1, beta2,
@@ -371,7 +371,7 @@ class DataParallelTrainer:
             if self._graph is None:
                 self._capture(img, qst, label)
             todo = [(dst, src) for dst, src in zip(self._static, (img, qst, label)) if dst.data_ptr() != src.data_ptr()]
-            if todo and OPT.batch_copy_fused and all(s_.is_cuda and s_.is_contiguous() and s_.dtype == d.dtype and s_.shape == d.shape
+            if todo and all(s_.is_cuda and s_.is_contiguous() and s_.dtype == d.dtype and s_.shape == d.shape
                                                      and s_.data_ptr() % 16 == 0 for d, s_ in todo):
                 RF.H.copy_many(todo)                        # one launch for the whole batch hand-off
             else:

@@ -58,7 +58,7 @@ class ConvInputModel(nn.Module):
 
     def forward(self, img):
         x = img
-        fused = (img.is_cuda and img.dtype == torch.float32 and OPT.fused_bn
+        fused = (img.is_cuda and img.dtype == torch.float32
                  and not (torch.is_grad_enabled() and not self.training))
         for i in range(1, 5):
             conv, bn = self._modules["conv%d" % i], self._modules["batchNorm%d" % i]
@@ -84,7 +84,7 @@ class QuestionEmbedModel(nn.Module):
 
     def forward(self, question):
         l = self.lstm
-        if (question.is_cuda and OPT.fused_lstm and l.num_layers == 1 and not l.bidirectional
+        if (question.is_cuda and l.num_layers == 1 and not l.bidirectional
                 and l.batch_first and l.bias and getattr(l, "proj_size", 0) == 0 and l.input_size == 32 and l.hidden_size == 128
                 and self.wembedding.padding_idx is None and self.wembedding.max_norm is None and l.weight_ih_l0.dtype == torch.float32):
             # embedding + the whole recurrence in one launch per direction (rn_lstm.hip)
@@ -199,8 +199,9 @@ class RelationalLayer(RelationalLayerBase):
 
     def resolved_precision(self, b, d, k):
         """The arithmetic mode a forward pass on (b, d, k) objects runs in: `self.precision`, with "auto" resolved to
-        "f16s" wherever a kernel for it exists for this shape, else "fp32" (512-wide g layers, ragged pair counts: the
-        per-layer fp32-MFMA kernels) -- both meet the 1e-3 log-prob bar; "auto" never lands on single-pass bf16."""
+        "f16s" wherever the register-resident chains cover the shape (functional.chain_ok), else "fp32" (512-wide g layers, other
+        depths: the per-layer fp32-MFMA kernels) -- both meet the 1e-3 log-prob bar; "auto" never lands on single-pass bf16.
+        An explicit "f16s" on a shape the chains do not cover raises; "bf16" always means the per-layer bf16 kernels."""
         if self.precision != "auto":
             return self.precision
         return "f16s" if RF.f16s_ok(self._plan(k), b, d) else "fp32"
@@ -238,8 +239,7 @@ class RelationalLayer(RelationalLayerBase):
         code = H.dtype_code("bf16" if self.precision == "bf16" else "fp32")     # (the per-layer kernels; parity-clean unless bf16 is asked for)
         wfwd, _ = self._packed.get(plan, [l.weight for l in self.g_layers], code, bwd_images=False)
         gb = [l.bias.detach().contiguous() for l in self.g_layers]
-        inputs, _, _ = RF.g_chain_forward(x.float(), qst.float().contiguous(), plan, gb, wfwd, code, keep_inputs=True,
-                                          stop_at=layer_idx)
+        inputs, _ = RF.layers_forward(x.float(), qst.float().contiguous(), plan, gb, wfwd, code, keep_inputs=True, stop_at=layer_idx)
         A = inputs[layer_idx]
         F_ = plan.ktrue[layer_idx] - (Q if layer_idx == plan.inject else 0)
         if F_ % 64:
@@ -269,7 +269,7 @@ class RelationalLayer(RelationalLayerBase):
                 for hook in list(layer._forward_hooks.values()):
                     hook(layer, (inp,), outp)
 
-        _inputs, HL, _xg = RF.g_chain_forward(x, q, plan, gb, wfwd, code, keep_inputs=False, layer_hook=layer_hook)
+        _inputs, HL = RF.layers_forward(x, q, plan, gb, wfwd, code, keep_inputs=False, layer_hook=layer_hook)
         if self.extraction:
             return None                                        # reference model.py:147-148
         B = x.shape[0]

@@ -23,20 +23,13 @@ _lib = None
 _P, _I, _L, _Z = C.c_void_p, C.c_int, C.c_long, C.c_size_t
 SIGNATURES = {
     "rn_abi_version": (_I, []),
+    "rn_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "rn_last_error": (C.c_char_p, []),
     "rn_pair_build_fwd": (_I, [_P, _L, _L, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_qst_broadcast": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_pack_matrix": (_I, [_P, _L, _L, _I, _I, _P, _I, _I, _I, _P]),
-    "rn_pack_matrix_split": (_I, [_P, _L, _L, _I, _I, _P, _P, _I, _I, _P]),
-    "rn_g_chain_fwd_f16s": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rn_g_linear_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "rn_g_chain_tile": (_I, []),
-    "rn_g_chain_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_g_chain_rr_tile": (_I, []),
-    "rn_g_chain_rr_mask_bytes": (_Z, [_I]),
-    "rn_g_chain_fwd_rr": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
-    "rn_g_chain_fwd_rr_f16s": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
-    "rn_g_chain_fwd_rr_alg0": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _I, _P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_sum_tiles": (_I, [_P, _P, _I, _I, _I, _P]),
@@ -45,39 +38,23 @@ SIGNATURES = {
     "rn_g_chain_bwd_rr_red_tpu": (_I, [_I, _I]),
     "rn_g_chain_bwd_rr_red": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "rn_pair_reduce_parts": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "rn_pack_matrix_frag": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
     "rn_pack_matrix_frag_many": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "rn_g_chain_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "rn_pair_sum_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_sum_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_sum_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "rn_g_linear_bwd_dgrad": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
-    "rn_wgrad_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_g_linear_bwd_wgrad": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "rn_rows_to_blocked": (_I, [_P, _P, _I, _I, _I, _P]),
     "rn_wgrad_blocked_splits": (_I, [_I, _I, _I, _I]),
-    "rn_wgrad_blocked_ws_bytes": (_Z, [_I, _I, _I, _I]),
     "rn_wgrad_blocked_db_partials_offset": (_Z, [_I, _I, _I, _I, _I]),
     "rn_blocked_question_sums": (_I, [_P, _P, _I, _I, _P]),
     "rn_g_wgrad_blocked": (_I, [_P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _I, _P]),
-    "rn_relu_gate_image": (_I, [_P, _P, _I, _P]),
     "rn_fp8_copy_health": (_I, [_P, _P, _P, _I, _P]),
-    "rn_pair_reduce_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_reduce_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_pair_dx_dq": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _I, _I, _I, _I, _I, _P]),
-    "rn_wgrad0_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_wgrad0_from_reductions": (_I, [_P, _P, _P, _P, _L, _L, _L, _P, _I, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_gemm_f32": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _P, _L, _P, _L, _I, _P]),
-    "rn_log_softmax_fwd": (_I, [_P, _P, _I, _I, _P]),
-    "rn_log_softmax_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
-    "rn_colsum_f32": (_I, [_P, _L, _P, _I, _I, _P]),
-    "rn_pair_features_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_pair_features": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
-    "rn_extract_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_extract_features": (_I, [_P, _L, _L, _L, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "rn_f_phi_fwd": (_I, [_P] * 11 + [_I] * 6 + [_P]),
-    "rn_f_phi_bwd_ws_bytes": (_Z, [_I, _I, _I, _I]),
-    "rn_f_phi_nll_ws_bytes": (_Z, [_I]),
     "rn_f_phi_fwd_nll": (_I, [_P] * 14 + [_I] * 6 + [_P]),
     "rn_f_phi_fwd_bwd_from_partials": (_I, [_P, _I] + [_P] * 19 + [_I] * 5 + [_P]),
     "rn_f_phi_bwd_grads": (_I, [_P] * 10 + [_I] * 5 + [_P]),
@@ -89,16 +66,13 @@ SIGNATURES = {
     "rn_nll_mean_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "rn_nll_mean_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "rn_clip_adam_chunk": (_I, []),
-    "rn_clip_adam_ws_bytes": (_Z, []),
     "rn_lstm_bwd_tail": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_clip_adam_step_dev": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P]),
     "rn_copy_many": (_I, [_P, _P, _P, _I, _P]),
     "rn_clip_adam_step": (_I, [_P, _I, _P, _P, _P, _L, _P] + [C.c_float] * 7 + [_I, _P, _P]),
     "rn_conv3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_conv3x3s2_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "rn_conv3x3s2_bwd_weight_ws_bytes": (_Z, [_I, _I, _I, _I]),
     "rn_conv3x3s2_bwd_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "rn_bn_relu_ws_bytes": (_Z, [_I, _I, _I]),
     "rn_bn_relu_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _I, _I, _P]),
     "rn_bn_relu_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rn_bn_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -106,11 +80,34 @@ SIGNATURES = {
 }
 # diagnostics (include/rn_hip_debug.h): tests / tools only, not part of the product ABI
 DEBUG_SIGNATURES = {
+    "rn_relu_gate_image": (_I, [_P, _P, _I, _P]),
+    "rn_rows_to_blocked": (_I, [_P, _P, _I, _I, _I, _P]),
     "rn_debug_stamp": (_I, [_P, _P]),
     "rn_probe_tr16": (_I, [_P, _P, _P]),
     "rn_probe_tr8": (_I, [_P, _P, _P]),
     "rn_probe_fp8_cvt": (_I, [_P, C.c_float, _P, _P, _P, _I, _P]),
 }
+
+
+# rn_workspace_bytes ops (include/rn_hip.h: RN_WS_*)
+WS_RR_MASK = 0
+WS_PAIR_SUM = 1
+WS_WGRAD = 2
+WS_WGRAD_BLOCKED = 3
+WS_PAIR_REDUCE = 4
+WS_WGRAD0 = 5
+WS_PAIR_FEATURES = 6
+WS_EXTRACT = 7
+WS_F_PHI_BWD = 8
+WS_F_PHI_NLL = 9
+WS_CLIP_ADAM = 10
+WS_CONV_BWD_WEIGHT = 11
+WS_BN_RELU = 12
+
+
+def workspace_bytes(op, a=0, b=0, c=0, d=0) -> int:
+    """Bytes of scratch the entry point named by `op` needs for a shape (rn_workspace_bytes)."""
+    return int(load().rn_workspace_bytes(op, int(a), int(b), int(c), int(d)))
 
 
 def load(path: str | None = None):
@@ -272,28 +269,8 @@ def g_linear_fwd(A, lda, Wp, ldw, bias, H, ldh, code, M, N, K, h_offset_elems=0)
                                   ldh, code, M, N, K, _stream()), "rn_g_linear_fwd")
 
 
-def g_chain_tile() -> int:
-    return load().rn_g_chain_tile()
-
-
-@_timed("g_fwd")
-def g_chain_fwd(P, ldp, Wps, biases, Hs, Ks, xg_part, code, M, G):
-    """Fused forward chain; Hs entries may be None (activation not stored)."""
-    L = len(Wps)
-    wp = (C.c_void_p * L)(*[w.data_ptr() for w in Wps])
-    bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
-    hp = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs])
-    kk = (C.c_int * L)(*Ks)
-    _check(load().rn_g_chain_fwd(P.data_ptr(), ldp, wp, bp, hp, kk, _ptr(xg_part), code, M, L, G, _stream()), "rn_g_chain_fwd")
-
-
 def g_chain_rr_tile() -> int:
     return load().rn_g_chain_rr_tile()
-
-
-def pack_matrix_frag(src, sr, sc, R, Cc, dst, natural, src_offset=0):
-    _check(load().rn_pack_matrix_frag(src.data_ptr() + 4 * src_offset, sr, sc, R, Cc, dst.data_ptr(), int(natural), _stream()),
-           "rn_pack_matrix_frag")
 
 
 def pack_matrix_frag_many(jobs):
@@ -303,18 +280,6 @@ def pack_matrix_frag_many(jobs):
                                            (C.c_long * n)(*[j[2] for j in jobs]), (C.c_int * n)(*[j[3] for j in jobs]),
                                            (C.c_int * n)(*[j[4] for j in jobs]), (C.c_void_p * n)(*[j[5].data_ptr() for j in jobs]),
                                            (C.c_int * n)(*[int(j[6]) for j in jobs]), n, _stream()), "rn_pack_matrix_frag_many")
-
-
-@_timed("g_fwd")
-def g_chain_fwd_rr(P, ldp, Wfs, biases, Hs, masks, K0, xg_part, M, G):
-    """Register-resident forward chain.  Hs: None or 4 entries (the last may be None when masks are given);
-    masks: None or 4 uint8 buffers of g_chain_rr_mask_bytes(M)."""
-    L = len(Wfs)
-    wp = (C.c_void_p * L)(*[w.data_ptr() for w in Wfs])
-    bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
-    hp = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
-    mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
-    _check(load().rn_g_chain_fwd_rr(P.data_ptr(), ldp, wp, bp, hp, mp, K0, _ptr(xg_part), M, L, G, _stream()), "rn_g_chain_fwd_rr")
 
 
 @_timed("pair_build")
@@ -328,17 +293,7 @@ def pair_tables(x, q, W0T, b0, Xp, Vc, B, n, k, Q, N, coord=None):
                                  W0T.data_ptr(), b0.data_ptr(), Xp.data_ptr(), xdt, Vc.data_ptr(), B, n, k, Q, N, _stream()), "rn_pair_tables")
 
 
-@_timed("g_fwd")
-def g_chain_fwd_rr_alg0(Xp, Vc, n, Wfs, biases, Hs, masks, xg_part, M, G, Vq=None, inject=0):
-    """Register-resident forward chain with the first layer factored through the pair structure (no pair matrix).
-    inject = 2 + Vq (B, 256) fp32: the question enters layer 2 as a per-question bias row."""
-    L = len(Wfs)
-    wp = (C.c_void_p * L)(*[w.data_ptr() for w in Wfs])
-    bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
-    hp = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
-    mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
-    _check(load().rn_g_chain_fwd_rr_alg0(Xp.data_ptr(), Vc.data_ptr(), n, wp, bp, hp, _h_code(Hs), mp, xg_part.data_ptr(), _ptr(Vq), inject,
-                                         M, L, G, _stream()), "rn_g_chain_fwd_rr_alg0")
+F16S_DITHER = 4      # tile-dithered hi images per g layer >= 1 (include/rn_hip.h, rn_g_chain_fwd_rr_f16s_alg0)
 
 
 @_timed("g_fwd")
@@ -358,25 +313,8 @@ def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlo0, biases, Hs, masks, xg_part
                                               xg_part.data_ptr(), _ptr(Vq), inject, M, L, G, _stream()), "rn_g_chain_fwd_rr_f16s_alg0")
 
 
-@_timed("g_fwd")
-def g_chain_fwd_rr_f16s(P16, ldp, Whis, Wlo0, biases, Hs, masks, K0, xg_part, M, G):
-    """f16s forward in the register-resident mapping (fp16 pair matrix; weight images as for g_chain_fwd_rr_f16s_alg0)."""
-    L = len(Whis)
-    dither = Whis[1].numel() // 65536
-    hp = (C.c_void_p * L)(*[w.data_ptr() for w in Whis])
-    lp = (C.c_void_p * L)(*([Wlo0.data_ptr()] + [None] * (L - 1)))
-    bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
-    op = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
-    mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
-    _check(load().rn_g_chain_fwd_rr_f16s(P16.data_ptr(), ldp, hp, lp, dither, bp, op, _h_code(Hs[:L - 1] if Hs is not None else None), mp, K0, _ptr(xg_part), M, L, G,
-                                         _stream()), "rn_g_chain_fwd_rr_f16s")
-
-
-F16S_DITHER = 4      # tile-dithered hi images per g layer >= 1 (include/rn_hip.h, rn_g_chain_fwd_rr_f16s)
-
-
 def g_chain_rr_mask_bytes(M) -> int:
-    return load().rn_g_chain_rr_mask_bytes(M)
+    return workspace_bytes(WS_RR_MASK, M, 0, 0, 0)
 
 
 @_timed("g_dgrad")
@@ -412,39 +350,10 @@ def pair_reduce_parts(rj_part, ri_part, Rj, Ri, Rq, B, n, G, nu):
            "rn_pair_reduce_parts")
 
 
-def pack_matrix_split(src, sr, sc, R, Cc, hi, lo, ld, Rpad):
-    _check(load().rn_pack_matrix_split(src.data_ptr(), sr, sc, R, Cc, hi.data_ptr(), lo.data_ptr(), ld, Rpad, _stream()),
-           "rn_pack_matrix_split")
-
-
-@_timed("g_fwd")
-def g_chain_fwd_f16s(P, ldp, Whis, Wlos, biases, Hs, Ks, xg_part, M, G):
-    """f16s forward chain: P fp16, split fp16 weights, Hs = bf16 activation copies (entries may be None)."""
-    L = len(Whis)
-    hp = (C.c_void_p * L)(*[w.data_ptr() for w in Whis])
-    lp = (C.c_void_p * L)(*[w.data_ptr() for w in Wlos])
-    bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
-    op = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs])
-    kk = (C.c_int * L)(*Ks)
-    _check(load().rn_g_chain_fwd_f16s(P.data_ptr(), ldp, hp, lp, bp, op, kk, _ptr(xg_part), M, L, G, _stream()),
-           "rn_g_chain_fwd_f16s")
-
-
-@_timed("g_dgrad")
-def g_chain_bwd(HL, dxg, Wts, Hgates, dZs, code, M, rows_per_question, G):
-    """Fused backward chain: dZs[0] from (HL, dxg); dZs[s+1] through layer L-1-s gated by Hgates[s]."""
-    L = len(dZs)
-    wp = (C.c_void_p * (L - 1))(*[w.data_ptr() for w in Wts])
-    gp = (C.c_void_p * (L - 1))(*[h.data_ptr() for h in Hgates])
-    zp = (C.c_void_p * L)(*[z.data_ptr() for z in dZs])
-    _check(load().rn_g_chain_bwd(HL.data_ptr(), dxg.data_ptr(), wp, gp, zp, code, M, rows_per_question, L, G, _stream()),
-           "rn_g_chain_bwd")
-
-
 @_timed("pair_sum")
 def pair_sum_fwd(HL, ldh, xg, code, B, npairs, G):
     lib = load()
-    nb = lib.rn_pair_sum_ws_bytes(B, npairs, G)
+    nb = workspace_bytes(WS_PAIR_SUM, B, npairs, G, 0)
     ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=xg.device)
     _check(lib.rn_pair_sum_fwd(HL.data_ptr(), ldh, xg.data_ptr(), ws.data_ptr(), code, B, npairs, G, _stream()), "rn_pair_sum_fwd")
 
@@ -465,7 +374,7 @@ def g_linear_bwd_dgrad(dZ, lddz, Wt, ldwt, Hprev, ldhp, dZprev, lddzp, code, M, 
 def g_linear_bwd_wgrad(dZ, lddz, A, lda, dW, db, code, M, N, K, Ktrue):
     """General weight gradient on ROW-MAJOR operands (any N % 256 == 0, K % 32 == 0; bf16 or fp32)."""
     lib = load()
-    nb = lib.rn_wgrad_ws_bytes(M, N, K)
+    nb = workspace_bytes(WS_WGRAD, M, N, K, 0)
     if nb == 0:
         raise RuntimeError("rn_wgrad_ws_bytes: unsupported shape M=%d N=%d K=%d" % (M, N, K))
     ws = torch.empty(nb, dtype=torch.uint8, device=dW.device)
@@ -508,7 +417,7 @@ def g_wgrad_blocked(jobs, M, dxg=None, rows_per_question=0, aligned=False, abl=0
     -> (ws, [db partials (Z, 4, 256) per job]): the workspace must stay alive while the partials are in use."""
     lib = load()
     nj = len(jobs)
-    nb = lib.rn_wgrad_blocked_ws_bytes(M, rows_per_question, nj, int(aligned))
+    nb = workspace_bytes(WS_WGRAD_BLOCKED, M, rows_per_question, nj, int(aligned))
     if nb == 0:
         raise RuntimeError("rn_g_wgrad_blocked: unsupported shape M=%d, %d jobs" % (M, nj))
     a8 = jobs[0][1].dtype in FP8_DTYPES
@@ -536,7 +445,7 @@ def g_wgrad_blocked(jobs, M, dxg=None, rows_per_question=0, aligned=False, abl=0
 @_timed("pair_reduce")
 def pair_reduce_bwd(dZ, lddz, Rj, Ri, Rq, code, B, n, G, njp=None):
     lib = load()
-    ws = torch.empty(max(lib.rn_pair_reduce_ws_bytes(B, n, G), 16), dtype=torch.uint8, device=dZ.device)
+    ws = torch.empty(max(workspace_bytes(WS_PAIR_REDUCE, B, n, G, 0), 16), dtype=torch.uint8, device=dZ.device)
     _check(lib.rn_pair_reduce_bwd(dZ.data_ptr(), lddz, _ptr(Rj), _ptr(Ri), _ptr(Rq), ws.data_ptr(), code, B, n, njp or n, G, _stream()),
            "rn_pair_reduce_bwd")
 
@@ -561,7 +470,7 @@ def wgrad0_from_reductions(Rj, Ri, Rq, x, q, dW0, db0, coord=None):
     k = kf + (coord.shape[0] if coord is not None else 0)      # coord (k - kf, n): the coordinate tags are not part of x
     N, Q = Rj.shape[1], (q.shape[1] if q is not None else 0)      # q None: no question columns in layer 0 (Rq still gives db0)
     lib = load()
-    ws = torch.empty(max(lib.rn_wgrad0_ws_bytes(B, n, N), 16), dtype=torch.uint8, device=Rj.device)
+    ws = torch.empty(max(workspace_bytes(WS_WGRAD0, B, n, N, 0), 16), dtype=torch.uint8, device=Rj.device)
     sx = x.stride()
     _check(lib.rn_wgrad0_from_reductions(Rj.data_ptr(), Ri.data_ptr(), _ptr(Rq), x.data_ptr(), sx[0], sx[1], sx[2], _ptr(coord), kf, _ptr(q),
                                          q.stride(0) if q is not None else 0, dW0.data_ptr(), db0.data_ptr(), ws.data_ptr(), B, n, k, Q, N,
@@ -576,24 +485,12 @@ def gemm_f32(A, sam, sak, Bm, sbk, sbn, Cm, ldc, M, N, K, bias=None, mul=None, l
                               flags, _stream()), "rn_gemm_f32")
 
 
-def log_softmax_fwd(z, out, B, A):
-    _check(load().rn_log_softmax_fwd(z.data_ptr(), out.data_ptr(), B, A, _stream()), "rn_log_softmax_fwd")
-
-
-def log_softmax_bwd(out, gout, dz, B, A):
-    _check(load().rn_log_softmax_bwd(out.data_ptr(), gout.data_ptr(), dz.data_ptr(), B, A, _stream()), "rn_log_softmax_bwd")
-
-
-def colsum_f32(src, ld, out, R, Cc):
-    _check(load().rn_colsum_f32(src.data_ptr(), ld, out.data_ptr(), R, Cc, _stream()), "rn_colsum_f32")
-
-
 # ------------------------------------------------------------------ conv stack: BatchNorm2d + ReLU
 @_timed("bn_relu")
 def bn_relu_fwd(x, y, gamma, beta, conv_bias, running_mean, running_var, num_batches, mean, invstd, eps, momentum):
     N, Cc, Hh, Ww = x.shape
     lib = load()
-    ws = torch.empty(max(lib.rn_bn_relu_ws_bytes(N, Cc, Hh * Ww), 16), dtype=torch.uint8, device=x.device)
+    ws = torch.empty(max(workspace_bytes(WS_BN_RELU, N, Cc, Hh * Ww, 0), 16), dtype=torch.uint8, device=x.device)
     _check(lib.rn_bn_relu_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(conv_bias), _ptr(running_mean),
                               _ptr(running_var), _ptr(num_batches), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), eps, momentum,
                               N, Cc, Hh * Ww, _stream()), "rn_bn_relu_fwd")
@@ -611,7 +508,7 @@ def bn_relu_bwd(dy, x, dx, gamma, beta, mean, invstd, dgamma, dbeta, zero_out=No
     """zero_out: C floats the same launch sets to zero (the conv-bias gradient)."""
     N, Cc, Hh, Ww = x.shape
     lib = load()
-    ws = torch.empty(max(lib.rn_bn_relu_ws_bytes(N, Cc, Hh * Ww), 16), dtype=torch.uint8, device=x.device)
+    ws = torch.empty(max(workspace_bytes(WS_BN_RELU, N, Cc, Hh * Ww, 0), 16), dtype=torch.uint8, device=x.device)
     _check(lib.rn_bn_relu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
                               invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(zero_out), ws.data_ptr(), N, Cc, Hh * Ww, _stream()),
            "rn_bn_relu_bwd")
@@ -623,8 +520,8 @@ def bn_relu_bwd_conv_wgrad(dy, xc, inp, gamma, beta, mean, invstd, dgamma, dbeta
     (the conv output gradient stays in the kernel).  xc: the conv output; inp: the block's input."""
     N, Cin, Hh, Ww = inp.shape
     lib = load()
-    ws_bn = torch.empty(max(lib.rn_bn_relu_ws_bytes(N, 24, (Hh // 2) * (Ww // 2)), 16), dtype=torch.uint8, device=inp.device)
-    ws_cv = torch.empty(max(lib.rn_conv3x3s2_bwd_weight_ws_bytes(N, Cin, Hh, Ww), 16), dtype=torch.uint8, device=inp.device)
+    ws_bn = torch.empty(max(workspace_bytes(WS_BN_RELU, N, 24, (Hh // 2) * (Ww // 2), 0), 16), dtype=torch.uint8, device=inp.device)
+    ws_cv = torch.empty(max(workspace_bytes(WS_CONV_BWD_WEIGHT, N, Cin, Hh, Ww), 16), dtype=torch.uint8, device=inp.device)
     _check(lib.rn_bn_relu_bwd_conv_wgrad(dy.data_ptr(), xc.data_ptr(), inp.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
                                          invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(zero_out), dw.data_ptr(),
                                          ws_bn.data_ptr(), ws_cv.data_ptr(), N, Cin, Hh, Ww, _stream()), "rn_bn_relu_bwd_conv_wgrad")
@@ -649,7 +546,7 @@ def _nll_sync_ws(B, device):
     key = (device, B)
     ws = _NLL_WS.get(key)
     if ws is None:
-        ws = _NLL_WS[key] = torch.zeros(max(load().rn_f_phi_nll_ws_bytes(B), 16), dtype=torch.uint8, device=device)
+        ws = _NLL_WS[key] = torch.zeros(max(workspace_bytes(WS_F_PHI_NLL, B, 0, 0, 0), 16), dtype=torch.uint8, device=device)
     return ws
 
 
@@ -683,7 +580,7 @@ def f_phi_fwd_bwd_from_partials(xg_part, parts_per_row, xg, fwT, fb, fw, mask, l
     B, G = xg.shape
     F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
     lib = load()
-    ws = torch.empty(max(lib.rn_f_phi_bwd_ws_bytes(B, F1, F2, A), 16), dtype=torch.uint8, device=xg.device)
+    ws = torch.empty(max(workspace_bytes(WS_F_PHI_BWD, B, F1, F2, A), 16), dtype=torch.uint8, device=xg.device)
     _check(lib.rn_f_phi_fwd_bwd_from_partials(xg_part.data_ptr(), parts_per_row, xg.data_ptr(), fwT[0].data_ptr(), fb[0].data_ptr(),
                                               fwT[1].data_ptr(), fb[1].data_ptr(), fwT[2].data_ptr(), fb[2].data_ptr(), fw[0].data_ptr(),
                                               fw[1].data_ptr(), fw[2].data_ptr(), _ptr(mask), label.data_ptr(), f1.data_ptr(), f2.data_ptr(),
@@ -706,7 +603,7 @@ def f_phi_bwd_nll(gloss, label, out, f2, f1, xg, fw, mask, dW, db, dxg):
     B, G = xg.shape
     F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
     lib = load()
-    ws = torch.empty(max(lib.rn_f_phi_bwd_ws_bytes(B, F1, F2, A), 16), dtype=torch.uint8, device=xg.device)
+    ws = torch.empty(max(workspace_bytes(WS_F_PHI_BWD, B, F1, F2, A), 16), dtype=torch.uint8, device=xg.device)
     _check(lib.rn_f_phi_bwd_nll(gloss.data_ptr(), label.data_ptr(), out.data_ptr(), f2.data_ptr(), f1.data_ptr(), xg.data_ptr(),
                                 fw[0].data_ptr(), fw[1].data_ptr(), fw[2].data_ptr(), _ptr(mask), dW[0].data_ptr(), db[0].data_ptr(),
                                 dW[1].data_ptr(), db[1].data_ptr(), dW[2].data_ptr(), db[2].data_ptr(), dxg.data_ptr(), ws.data_ptr(),
@@ -718,7 +615,7 @@ def f_phi_bwd(gout, out, f2, f1, xg, fw, mask, dW, db, dxg):
     B, G = xg.shape
     F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
     lib = load()
-    ws = torch.empty(max(lib.rn_f_phi_bwd_ws_bytes(B, F1, F2, A), 16), dtype=torch.uint8, device=xg.device)
+    ws = torch.empty(max(workspace_bytes(WS_F_PHI_BWD, B, F1, F2, A), 16), dtype=torch.uint8, device=xg.device)
     _check(lib.rn_f_phi_bwd(gout.data_ptr(), out.data_ptr(), f2.data_ptr(), f1.data_ptr(), xg.data_ptr(), fw[0].data_ptr(), fw[1].data_ptr(),
                             fw[2].data_ptr(), _ptr(mask), dW[0].data_ptr(), db[0].data_ptr(), dW[1].data_ptr(), db[1].data_ptr(),
                             dW[2].data_ptr(), db[2].data_ptr(), dxg.data_ptr(), ws.data_ptr(), B, G, F1, F2, A, _stream()), "rn_f_phi_bwd")
@@ -775,7 +672,7 @@ def pair_features(A, lda, F, code, B, npairs):
     lib = load()
     maxf = torch.empty(B, F, dtype=torch.float32, device=A.device)
     avgf = torch.empty(B, F, dtype=torch.float32, device=A.device)
-    ws = torch.empty(max(lib.rn_pair_features_ws_bytes(B, npairs, F), 16), dtype=torch.uint8, device=A.device)
+    ws = torch.empty(max(workspace_bytes(WS_PAIR_FEATURES, B, npairs, F, 0), 16), dtype=torch.uint8, device=A.device)
     _check(lib.rn_pair_features(A.data_ptr(), lda, F, maxf.data_ptr(), avgf.data_ptr(), ws.data_ptr(), code, B, npairs, _stream()),
            "rn_pair_features")
     return maxf, avgf
@@ -797,7 +694,7 @@ def extract_features(x, Wts, biases, per_q, F):
     L = len(Wts)
     maxf = torch.empty(B, F, dtype=torch.float32, device=x.device)
     avgf = torch.empty(B, F, dtype=torch.float32, device=x.device)
-    ws = torch.empty(max(lib.rn_extract_ws_bytes(B, n, F), 16), dtype=torch.uint8, device=x.device)
+    ws = torch.empty(max(workspace_bytes(WS_EXTRACT, B, n, F, 0), 16), dtype=torch.uint8, device=x.device)
     wp = (C.c_void_p * max(L, 1))(*[w.data_ptr() for w in Wts])
     bp = (C.c_void_p * max(L, 1))(*[b_.data_ptr() for b_ in biases])
     pq = (C.c_int * max(L, 1))(*[int(bool(v)) for v in per_q])
@@ -825,7 +722,7 @@ def conv3x3s2_bwd_data(dy, w, dx):
 def conv3x3s2_bwd_weight(x, dy, dw):
     """dw (24, Cin, 3, 3) of the 3x3 / stride-2 / pad-1 convolution from x (N, Cin, H, W) and dy (N, 24, H/2, W/2)."""
     N, Cin, Hh, Ww = x.shape
-    ws = torch.empty(max(load().rn_conv3x3s2_bwd_weight_ws_bytes(N, Cin, Hh, Ww), 16), dtype=torch.uint8, device=x.device)
+    ws = torch.empty(max(workspace_bytes(WS_CONV_BWD_WEIGHT, N, Cin, Hh, Ww), 16), dtype=torch.uint8, device=x.device)
     _check(load().rn_conv3x3s2_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), N, Cin, dy.shape[1], Hh, Ww, _stream()),
            "rn_conv3x3s2_bwd_weight")
 

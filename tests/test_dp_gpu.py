@@ -230,8 +230,8 @@ def test_bench_two_ranks_on_one_gpu():
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     env = dict(os.environ, RN_BENCH_SAME_GPU="1", RN_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--sustain", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -240,5 +240,6 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2" and d["dtype"] == "f16s"
     assert abs(d["value"] - 2 * 64 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
     assert np.isfinite(d["loss"]) and "roofline" in d and "cpu_baseline" not in d and "parity" not in d
+    assert d["sustained"]["steps"] >= 5 and d["sustained"]["value"] > 0            # (the same step count on both ranks: no hang)
     # a multi-rank line says where a step's time outside forward + backward goes (attribution of a scaling miss)
     assert d["allreduce_us_per_step"] > 0 and d["optimizer_us_per_step"] > 0 and d["allreduce_bytes"] == 4 * 484580

@@ -297,38 +297,9 @@ def test_g_linear_bwd_dgrad(H, code, M, N, Kin):
     assert np.all(got[Hp <= 0] == 0)
 
 
-@pytest.mark.parametrize("K0,K0true,L,store", [(192, 180, 4, True), (64, 52, 2, True), (256, 256, 4, False)])
-def test_g_chain_fwd_fused(H, K0, K0true, L, store):
-    """Fused LDS-resident chain: every stored activation must equal one un-fused layer applied to the
-    kernel's OWN previous activation (<= 1 bf16 ulp), and the per-tile pair-sum partials must be
-    the column sums of the last activation."""
-    M, G = 1024 if L == 2 else 40960, 256          # 40960 rows = 320 tiles > 256 CUs: persistent loop exercised
-    P = np.zeros((M, K0), np.float32); P[:, :K0true] = formula.hash_uniform((M, K0true), 300, -1, 1)
-    P = bf16_round(P)
-    Ws, bs, Ks = [], [], []
-    for l in range(L):
-        kt, kp = (K0true, K0) if l == 0 else (G, G)
-        W = np.zeros((G, kp), np.float32); W[:, :kt] = formula.hash_uniform((G, kt), 310 + l, -0.15, 0.15)
-        Ws.append(bf16_round(W)); bs.append(formula.hash_uniform((G,), 320 + l, -0.3, 0.3)); Ks.append(kp)
-    Hs = [torch.empty(M, G, dtype=torch.bfloat16, device="cuda") if store else None for _ in range(L)]
-    T = H.g_chain_tile()
-    part = torch.empty(M // T, G, dtype=torch.float32, device="cuda")
-    H.g_chain_fwd(dev(P).bfloat16(), K0, [dev(w).bfloat16() for w in Ws], [dev(b) for b in bs], Hs, Ks, part, 0, M, G)
-    torch.cuda.synchronize()
-    if store:
-        prev = P
-        for l in range(L):
-            got = Hs[l].float().cpu().numpy()
-            ref = np.maximum(prev.astype(np.float64) @ Ws[l].astype(np.float64).T + bs[l], 0)
-            err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
-            assert err.max() <= BF16_ULP, (l, err.max())
-            prev = got
-        assert rel(part.cpu().numpy(), prev.reshape(M // T, T, G).sum(1, dtype=np.float64)) <= F32_TOL
-    else:   # nothing stored: the partials must match the un-fused chain's pair sum within bf16 chain noise
-        prev = P
-        for l in range(L):
-            prev = bf16_round(np.maximum(prev.astype(np.float64) @ Ws[l].astype(np.float64).T + bs[l], 0))
-        assert rel(part.cpu().numpy(), prev.reshape(M // T, T, G).sum(1, dtype=np.float64)) <= 2e-3
+def pack_frag(H, src, sr, sc, R, Cc, dst, natural):
+    """one fragment-major image (rn_pack_matrix_frag_many with a single job)"""
+    H.pack_matrix_frag_many([(src, sr, sc, R, Cc, dst, natural)])
 
 
 def frag_pack_ref(W, natural):
@@ -349,7 +320,7 @@ def frag_pack_ref(W, natural):
 def test_pack_matrix_frag(H, natural):
     W = bf16_round(formula.hash_uniform((256, 180 if natural else 256), 330, -1, 1))
     dst = torch.empty(65536, dtype=torch.bfloat16, device="cuda")
-    H.pack_matrix_frag(dev(W), W.shape[1], 1, 256, W.shape[1], dst, natural)
+    pack_frag(H, dev(W), W.shape[1], 1, 256, W.shape[1], dst, natural)
     assert np.array_equal(dst.float().cpu().numpy(), frag_pack_ref(W, natural))
 
 
@@ -368,132 +339,6 @@ def rr_mask_decode(buf, M, l):
     else:
         g[:, b_idx, :, a_idx] = np.moveaxis(bits, 1, -1)[:, i, lane].transpose(1, 2, 0, 3)
     return g.reshape(M, 256)
-
-
-def rr_setup(H, M, K0, K0true):
-    G, L = 256, 4
-    P = np.zeros((M, K0), np.float32); P[:, :K0true] = formula.hash_uniform((M, K0true), 300, -1, 1)
-    P = bf16_round(P)
-    Ws, bs, Wf = [], [], []
-    for l in range(L):
-        kt = K0true if l == 0 else G
-        W = bf16_round(formula.hash_uniform((G, kt), 310 + l, -0.15, 0.15))
-        Ws.append(W); bs.append(formula.hash_uniform((G,), 320 + l, -0.3, 0.3))
-        f = torch.empty(65536, dtype=torch.bfloat16, device="cuda")
-        H.pack_matrix_frag(dev(W), kt, 1, G, kt, f, l == 0)
-        Wf.append(f)
-    return P, Ws, bs, Wf
-
-
-@pytest.mark.parametrize("K0,K0true,mode,M", [(192, 180, "all", 256 * 300), (256, 256, "all+mask", 256 * 3),
-                                                (192, 180, "train", 256 * 290), (192, 180, "infer", 256 * 520)])
-def test_g_chain_fwd_rr(H, K0, K0true, mode, M):
-    """Register-resident chain: every stored activation must equal one un-fused layer applied to the kernel's
-    OWN previous activation (<= 1 bf16 ulp); the per-wave pair-sum partials are the column sums of the UN-rounded
-    last activation; the lane masks are the ReLU gates.  290 .. 520 tiles > 256 CUs: the persistent loop, its
-    seams and the dummy tail are exercised.  mode: which of (H_0..3, masks) the call asks for."""
-    L, G = 4, 256
-    P, Ws, bs, Wf = rr_setup(H, M, K0, K0true)
-    nan16 = lambda: torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda")
-    Hs = None if mode == "infer" else [nan16() for _ in range(3)] + [None if mode == "train" else nan16()]
-    masks = [torch.zeros(H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda") for _ in range(L)] if "mask" in mode or mode == "train" else None
-    part = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
-    H.g_chain_fwd_rr(dev(P).bfloat16(), K0, Wf, [dev(b) for b in bs], Hs, masks, K0, part, M, G)
-    torch.cuda.synchronize()
-    Hs = unblock_h(Hs)
-    prev = P[:, :K0true]
-    for l in range(L):
-        ref = np.maximum(prev.astype(np.float64) @ Ws[l].astype(np.float64).T + bs[l], 0)
-        if Hs is not None and Hs[l] is not None:
-            got = Hs[l].float().cpu().numpy()
-            err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
-            assert err.max() <= BF16_ULP, (l, err.max())
-            prev = got
-        else:
-            prev = bf16_round(ref)
-        if masks is not None:
-            gate = rr_mask_decode(masks[l], M, l)
-            # the kernel gates on its fp32 pre-activation: only elements whose reference value is rounding noise may differ
-            bad = gate != (ref > 0)
-            assert np.abs(ref[bad]).max(initial=0.0) <= 1e-4 * np.abs(ref).max(), (l, bad.sum())
-            assert bad.mean() <= 1e-4
-    # the pair sum adds the UN-rounded fp32 activations (not the stored bf16 copies)
-    tol = F32_TOL if (Hs is not None and Hs[2] is not None) else 2e-3
-    assert rel(part.cpu().numpy(), ref.reshape(M // 32, 32, G).sum(1)) <= tol
-
-
-@pytest.mark.parametrize("mode,B,n", [("train", 19, 64), ("infer", 3, 32), ("train", 2, 96), ("train8", 19, 64), ("train8", 2, 96)])
-def test_g_chain_fwd_rr_alg0(H, mode, B, n):
-    """The factored first layer: W0 [x_j | x_i | q] + b0 = W0a x_j + (W0b x_i + W0c q + b0).  rn_pair_tables must give the
-    packed object rows and the fp32 bias rows; the chain on them must reproduce layer 0 of the pair formula (x_j product
-    on bf16 operands, the bracket exact), then behave like rn_g_chain_fwd_rr: every stored activation one un-fused
-    layer of the kernel's own previous one, masks = gates, partials = column sums of the un-rounded last activation.
-    19 * 64 * 64 / 256 = 304 tiles > 256 CUs (persistent loop + prefetch seams); n = 96: three waves per (b, i)."""
-    L, G, k, Q = 4, 256, 26, 128
-    M, kt = B * n * n, 2 * 26 + 128
-    x = formula.hash_uniform((B, n, k), 400, -1, 1).astype(np.float32)
-    q = formula.hash_uniform((B, Q), 401, -1, 1).astype(np.float32)
-    Ws = [formula.hash_uniform((G, kt if l == 0 else G), 410 + l, -0.15, 0.15).astype(np.float32) for l in range(L)]
-    Ws = [Ws[0]] + [bf16_round(w) for w in Ws[1:]]
-    bs = [formula.hash_uniform((G,), 420 + l, -0.3, 0.3).astype(np.float32) for l in range(L)]
-    w0d = dev(Ws[0])
-    w0T = torch.empty(kt, G, device="cuda")
-    Wf = [torch.empty(65536, dtype=torch.bfloat16, device="cuda") for _ in range(L)]
-    jobs = [(w0d, kt, 1, G, k, Wf[0], 1), (w0d, kt, 1, G, kt, w0T, 2)]
-    jobs += [(dev(Ws[l]), G, 1, G, G, Wf[l], 0) for l in range(1, L)]
-    H.pack_matrix_frag_many(jobs)
-    Xp = torch.full((B * n, 64), float("nan"), dtype=torch.bfloat16, device="cuda")
-    Vc = torch.full((B * n, G), float("nan"), device="cuda")
-    H.pair_tables(dev(x), dev(q), w0T, dev(bs[0]), Xp, Vc, B, n, k, Q, G)
-    train = mode.startswith("train")
-    Hs = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3)] + [None] if train else None
-    masks = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda")) if train else None
-    part = torch.full((M // 256, G), float("nan"), dtype=torch.float32, device="cuda")
-    H.g_chain_fwd_rr_alg0(Xp, Vc, n, Wf, [dev(b) for b in bs], Hs, masks, part, M, G)
-    torch.cuda.synchronize()
-    Hs = unblock_h(Hs)
-    if mode == "train8":
-        # e4m3 copies (h_dtype = RN_FP8): same arithmetic, so masks and pair sums bitwise; the bytes = the e4m3 rounding of the bf16 copies
-        Hs8 = [torch.full((M, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [None]
-        masks8 = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
-        part8 = torch.full((M // 256, G), float("nan"), dtype=torch.float32, device="cuda")
-        H.g_chain_fwd_rr_alg0(Xp, Vc, n, Wf, [dev(b) for b in bs], Hs8, masks8, part8, M, G)
-        torch.cuda.synchronize()
-        Hs8 = unblock_h(Hs8)
-        assert torch.equal(part, part8)
-        for l in range(L):
-            assert torch.equal(masks[l], masks8[l]), l
-        for l in range(3):
-            assert torch.equal(Hs8[l].view(torch.uint8), Hs[l].float().to(torch.float8_e4m3fn).view(torch.uint8)), l
-    # tables
-    xp = Xp.float().cpu().numpy()
-    assert np.array_equal(xp[:, :k], bf16_round(x.reshape(B * n, k))) and not xp[:, k:].any()
-    W0 = Ws[0].astype(np.float64)
-    vc_ref = bs[0] + x.reshape(B * n, k).astype(np.float64) @ W0[:, k:2 * k].T + np.repeat(q.astype(np.float64) @ W0[:, 2 * k:].T, n, axis=0)
-    assert rel(Vc.cpu().numpy(), vc_ref) <= F32_TOL
-    # layer 0 of the pair formula: pair row (b, i, j) = W0a x_j (bf16 operands) + Vc[b, i]
-    uj = bf16_round(x.reshape(B * n, k)).astype(np.float64) @ bf16_round(Ws[0][:, :k]).astype(np.float64).T     # (B n, G)
-    pre = uj.reshape(B, 1, n, G) + vc_ref.reshape(B, n, 1, G)
-    ref = np.maximum(pre, 0).reshape(M, G)
-    prev = None
-    for l in range(L):
-        if l:
-            ref = np.maximum(prev.astype(np.float64) @ Ws[l].astype(np.float64).T + bs[l], 0)
-        if Hs is not None and Hs[l] is not None:
-            got = Hs[l].float().cpu().numpy()
-            err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
-            assert err.max() <= BF16_ULP, (l, err.max())
-            prev = got
-        else:
-            prev = bf16_round(ref)
-        if masks is not None:
-            gate = rr_mask_decode(masks[l], M, l)
-            bad = gate != (ref > 0)
-            assert np.abs(ref[bad]).max(initial=0.0) <= 1e-4 * np.abs(ref).max(), (l, bad.sum())
-            assert bad.mean() <= 1e-4
-    tol = F32_TOL if train else 2e-3
-    assert rel(part.cpu().numpy(), ref.reshape(M // 256, 256, G).sum(1)) <= tol
-
 
 
 def f16s_alg0_emulation(x, q, Ws, bs, n, njp):
@@ -550,9 +395,10 @@ def check_against_f16s_emulation(zs, valid, exact, Hs, masks, part, M_tiles_rows
 
 @pytest.mark.parametrize("mode,B,n", [("train", 19, 64), ("infer", 2, 32)])
 def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
-    """f16s arithmetic on the factored first layer: must agree with rn_g_chain_fwd_rr_f16s on the explicitly built fp16 pair
-    matrix to fp16-operand accuracy (layer 0 differs only in that the x_i / q / bias part is now exact fp32): pair sums to
-    2e-3, stored bf16 copies to 1 bf16 ulp of the largest value, masks on all but rounding-noise elements."""
+    """The forward chain (f16s arithmetic on the factored first layer, model.py:108-152) against the float64 emulation of ITS
+    arithmetic and against the exact chain: stored bf16 copies to 1 bf16 ulp of the largest value, masks = the gates of the kernel's
+    own pre-activations on all but rounding-noise elements, pair sums to 1e-3 (3e-4 of the exact chain over groups of V tiles);
+    then the e4m3 copies and the gate image against the 16-bit run."""
     L, G, k, Q = 4, 256, 26, 128
     M, kt, K0 = B * n * n, 2 * 26 + 128, 192
     x = formula.hash_uniform((B, n, k), 400, -1, 1).astype(np.float32)
@@ -562,34 +408,22 @@ def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
     wd = [dev(w) for w in Ws]
     w0T = torch.empty(kt, G, device="cuda")
     hiA, loA, jobsA = f16s_images(H, wd, kt, k)             # factored first layer: W0[:, 0:k]
-    hiP, loP, jobsP = f16s_images(H, wd, kt, kt)            # pair matrix: all of W0
-    H.pack_matrix_frag_many(jobsA + jobsP + [(wd[0], kt, 1, G, kt, w0T, 2)])
+    H.pack_matrix_frag_many(jobsA + [(wd[0], kt, 1, G, kt, w0T, 2)])
     Xp = torch.empty(B * n, 64, dtype=torch.float16, device="cuda"); Vc = torch.empty(B * n, G, device="cuda")
     H.pair_tables(dev(x), dev(q), w0T, dev(bs[0]), Xp, Vc, B, n, k, Q, G)
-    P16 = torch.zeros(M, K0, dtype=torch.float16, device="cuda")
-    H.pair_build_fwd(dev(x), dev(q), P16, H.RN_F16, B, n, k, Q, K0)
     train = mode == "train"
     def outs(rows):
         Hs = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3)] + [None] if train else None
         masks = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda")) if train else None
         return Hs, masks, torch.full((M // rows, G), float("nan"), dtype=torch.float32, device="cuda")
-    HsA, mA, pA = outs(256); HsP, mP, pP = outs(32)       # (one partial row per tile on the factored path, per wave on the other)
+    HsA, mA, pA = outs(256)                               # (one partial row per tile)
     bd = [dev(b) for b in bs]
     H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, HsA, mA, pA, M, G)
-    H.g_chain_fwd_rr_f16s(P16, K0, hiP, loP, bd, HsP, mP, K0, pP, M, G)
     torch.cuda.synchronize()
-    HsA, HsP = unblock_h(HsA), unblock_h(HsP)
-    # the direct oracle leg: the factored kernel against the float64 emulation of ITS arithmetic and against
-    # the exact chain -- not only against the sibling kernel on the pair matrix (below)
+    HsA = unblock_h(HsA)
     zs, valid, exact = f16s_alg0_emulation(x, q, Ws, bs, n, n)
     check_against_f16s_emulation(zs, valid, exact, HsA, mA, pA, M)
-    assert rel(pA.cpu().numpy(), pP.view(M // 256, 8, G).sum(1).cpu().numpy()) <= 2e-3
     if train:
-        for l in range(3):
-            a, b = HsA[l].float().cpu().numpy(), HsP[l].float().cpu().numpy()
-            assert np.abs(a - b).max() <= 2 * BF16_ULP * np.abs(b).max(), l
-        for l in range(L):
-            assert (mA[l] != mP[l]).float().mean().item() <= 2e-3, l
         # e4m3 copies: same arithmetic (masks, pair sums bitwise); the bytes are the e4m3 rounding of the fp16 operand, i.e. of
         # the value the bf16 copy rounds -- equal to the rounded bf16 copy except where the two 16-bit roundings straddle a tie
         Hs8 = [torch.full((M, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [None]
@@ -627,9 +461,9 @@ def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
 def test_g_chain_fwd_rr_f16s_alg0_padded(H, B, n):
     """Object counts that are no multiple of 32 (the 14 x 14 grid): the factored first layer on a PADDED j axis (njp = 32 ceil(n /
     32) pair rows per (question, i) group).  On the n valid rows of every group the stored copies, the masks and the pair sums must
-    be those of the f16s chain on the explicitly built pair matrix (same arithmetic up to the exact fp32 bracket of layer 0 and
-    the tile a row lands in -- the dithered weight image -- i.e. the mode's accuracy class); the invalid rows must have all-zero
-    masks in every layer; rn_pair_sum_tiles must add the two-rows-per-tile partials up per question."""
+    be those of the float64 emulation of the kernel's arithmetic on the padded pair space; the invalid rows must have all-zero
+    masks in every layer; rn_pair_sum_tiles must add the two-rows-per-tile partials up per question (checked against the exact
+    chain's per-question sums)."""
     L, G, k, Q = 4, 256, 26, 128
     njp = (n + 31) // 32 * 32
     M, Mp, kt, K0 = B * n * n, B * n * njp, 2 * 26 + 128, 192
@@ -640,13 +474,10 @@ def test_g_chain_fwd_rr_f16s_alg0_padded(H, B, n):
     wd = [dev(w) for w in Ws]
     w0T = torch.empty(kt, G, device="cuda")
     hiA, loA, jobsA = f16s_images(H, wd, kt, k)
-    hiP, loP, jobsP = f16s_images(H, wd, kt, kt)
-    H.pack_matrix_frag_many(jobsA + jobsP + [(wd[0], kt, 1, G, kt, w0T, 2)])
+    H.pack_matrix_frag_many(jobsA + [(wd[0], kt, 1, G, kt, w0T, 2)])
     Xp = torch.zeros(B * n + 1, 64, dtype=torch.float16, device="cuda"); Vc = torch.empty(B * n, G, device="cuda")
     H.pair_tables(dev(x), dev(q), w0T, dev(bs[0]), Xp, Vc, B, n, k, Q, G)
     assert not Xp[B * n].any()
-    P16 = torch.zeros(M, K0, dtype=torch.float16, device="cuda")
-    H.pair_build_fwd(dev(x), dev(q), P16, H.RN_F16, B, n, k, Q, K0)
     bd = [dev(b) for b in bs]
     HsA = [torch.full((Mp, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3)] + [None]
     mA = list(torch.full((L, H.g_chain_rr_mask_bytes(Mp)), 0xff, dtype=torch.uint8, device="cuda"))
@@ -654,11 +485,8 @@ def test_g_chain_fwd_rr_f16s_alg0_padded(H, B, n):
     H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, HsA, mA, pA, Mp, G, njp=njp)
     xgA = torch.full((B, G), float("nan"), device="cuda")
     H.pair_sum_tiles(pA, xgA, Mp, n * njp, G)
-    HsP = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(4)]
-    mP = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
-    H.g_chain_fwd_rr_f16s(P16, K0, hiP, loP, bd, HsP, mP, K0, None, M, G)
     torch.cuda.synchronize()
-    HsA, HsP = unblock_h(HsA), unblock_h(HsP)
+    HsA = unblock_h(HsA)
     # the direct oracle leg on the PADDED pair space (njp = 224 for the 14 x 14 grid): float64 emulation of the kernel's arithmetic
     zs, vrow, exact = f16s_alg0_emulation(x, q, Ws, bs, n, njp)
     # (groups of V tiles hold different numbers of valid rows here: the image offsets cancel less evenly than on whole tiles)
@@ -669,15 +497,10 @@ def test_g_chain_fwd_rr_f16s_alg0_padded(H, B, n):
     H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, None, None, pI, Mp, G, njp=njp)
     torch.cuda.synchronize()
     assert torch.equal(pI, pA)
-    xgP = HsP[3].double().view(B, n * n, G).sum(1)
-    assert rel(xgA.cpu().numpy(), xgP.cpu().numpy()) <= 3e-3
-    for l in range(3):
-        a, b = valid(HsA[l]).float().cpu().numpy(), HsP[l].float().cpu().numpy()
-        assert np.abs(a - b).max() <= 4 * BF16_ULP * np.abs(b).max(), l
+    xg_exact = (exact * vrow[:, None]).reshape(B, n * njp, G).sum(1)            # per question, over the valid rows: the whole pair sum
+    assert rel(xgA.cpu().numpy(), xg_exact) <= 1e-3
     for l in range(L):
         gA = torch.from_numpy(rr_mask_decode(mA[l], Mp, l))
-        gP = torch.from_numpy(rr_mask_decode(mP[l], M, l))
-        assert (valid(gA) != gP).float().mean().item() <= 5e-3, l
         inval = gA.view(B * n, njp, G)[:, n:]
         assert not inval.any(), l                              # padded rows: gates cleared in every layer
     # e4m3 copies + the last layer's gate image from the epilogue: the image is bitwise rn_relu_gate_image of the layer's masks
@@ -693,85 +516,6 @@ def test_g_chain_fwd_rr_f16s_alg0_padded(H, B, n):
         assert torch.equal(m8[l], mA[l]), l
     assert torch.equal(gate.view(torch.uint8), H.relu_gate_image(m8[3], Mp).view(torch.uint8))
     assert not unblock(gate).view(torch.uint8).view(B * n, njp, G)[:, n:].any()
-
-
-@pytest.mark.parametrize("mode,M", [("train", 256 * 290), ("infer", 256 * 5)])
-def test_g_chain_fwd_rr_f16s(H, mode, M):
-    """f16s on the register-resident chain: against a float64 emulation that rounds the operand to fp16 after every
-    layer (the kernel's operand registers), with hi + lo split weights on layer 0 and the tile's dithered hi image on layers
-    1..3; the stored bf16 copies agree in max-norm (1 bf16 ulp of the largest value), the pair sums to 1e-3, and the result is
-    within 3e-4 of the EXACT fp32 chain.  The masks must be the gates of the kernel's own pre-activations."""
-    L, G, K0, K0true = 4, 256, 192, 180
-    f16r = lambda a: np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
-    P = np.zeros((M, K0), np.float32); P[:, :K0true] = formula.hash_uniform((M, K0true), 300, -1, 1)
-    P = f16r(P)
-    Ws = [formula.hash_uniform((G, K0true if l == 0 else G), 310 + l, -0.15, 0.15).astype(np.float32) for l in range(L)]
-    bs = [formula.hash_uniform((G,), 320 + l, -0.3, 0.3) for l in range(L)]
-    his, los, jobs = f16s_images(H, [dev(w) for w in Ws], K0true, K0true)
-    H.pack_matrix_frag_many(jobs)
-    train = mode == "train"
-    Hs = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3)] + [None] if train else None
-    masks = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda")) if train else None
-    part = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
-    H.g_chain_fwd_rr_f16s(dev(P).half(), K0, his, los, [dev(b) for b in bs], Hs, masks, K0, part, M, G)
-    torch.cuda.synchronize()
-    Hs = unblock_h(Hs)
-    prev = P[:, :K0true].astype(np.float64)
-    exact = prev
-    timg = (np.arange(M) // 256) % F16S_V                      # the dithered image a pair row's tile multiplies
-    for l in range(L):
-        if l == 0:                                            # two passes: hi + lo
-            wh = f16r(Ws[l]); wl = f16r(Ws[l] - wh)
-            z = prev @ (wh.astype(np.float64) + wl.astype(np.float64)).T + bs[l]
-        else:                                                 # one pass on the tile's dithered hi image
-            z = np.empty((M, G))
-            for d, im in enumerate(dither_images(Ws[l])):
-                z[timg == d] = prev[timg == d] @ im.astype(np.float64).T + bs[l]
-        ref = np.maximum(z, 0)
-        exact = np.maximum(exact @ Ws[l].astype(np.float64).T + bs[l], 0)
-        if train and l < 3:
-            assert rel(Hs[l].float().cpu().numpy(), bf16_round(ref)) <= BF16_ULP, l
-        if train:
-            bad = rr_mask_decode(masks[l], M, l) != (z > 0)
-            assert np.abs(z[bad]).max(initial=0.0) <= 2e-3 * np.abs(z).max() and bad.mean() <= 2e-3, (l, bad.sum())
-        prev = f16r(ref).astype(np.float64)
-    assert rel(part.cpu().numpy(), ref.reshape(M // 32, 32, G).sum(1)) <= 1e-3
-    # against the EXACT fp32 chain: a single tile carries its image's rounding offset (up to 3/8 ulp on every weight, same sign:
-    # the error of plain one-pass fp16, a few 1e-3 here); over V consecutive tiles -- one of each image -- the offsets cancel
-    nt = (M // 256) // F16S_V * F16S_V
-    got = part.cpu().numpy()[:nt * 8].reshape(nt // F16S_V, 8 * F16S_V, G).sum(1)
-    e_grp = rel(got, exact[:nt * 256].reshape(nt // F16S_V, 256 * F16S_V, G).sum(1))
-    e_one = rel(part.cpu().numpy(), exact.reshape(M // 32, 32, G).sum(1))
-    print("f16s pair sums vs the exact chain: one wave's 32 rows %.2e, %d-tile groups %.2e" % (e_one, F16S_V, e_grp))
-    assert e_grp <= 3e-4 and e_one <= 1e-2
-    if train:
-        # e4m3 copies (h_dtype = RN_FP8) on the pair-matrix chain: same arithmetic (masks, pair sums bitwise), bytes = the e4m3
-        # rounding of the fp16 operand; with all four activations requested H_3 stays bf16 and bitwise the plain run's
-        Hs8 = [torch.full((M, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [None]
-        m8 = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
-        p8 = torch.full((M // 32, G), float("nan"), dtype=torch.float32, device="cuda")
-        H.g_chain_fwd_rr_f16s(dev(P).half(), K0, his, los, [dev(b) for b in bs], Hs8, m8, K0, p8, M, G)
-        torch.cuda.synchronize()
-        Hs8 = unblock_h(Hs8)
-        assert torch.equal(part, p8)
-        for l in range(L):
-            assert torch.equal(masks[l], m8[l]), l
-        for l in range(3):
-            same = (Hs8[l].view(torch.uint8) == Hs[l].float().to(torch.float8_e4m3fn).view(torch.uint8)).float().mean().item()
-            assert same >= 0.97, (l, same)
-            assert bool(((Hs8[l].float() - Hs[l].float()).abs() <= Hs[l].float().abs() * 2.0 ** -4 + 2.0 ** -10).all()), l
-        Hs4 = [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(4)]
-        m4 = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
-        H.g_chain_fwd_rr_f16s(dev(P).half(), K0, his, los, [dev(b) for b in bs], Hs4, m4, K0, None, M, G)
-        Hs48 = [torch.full((M, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [torch.full((M, G), float("nan"), dtype=torch.bfloat16, device="cuda")]
-        m48 = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
-        H.g_chain_fwd_rr_f16s(dev(P).half(), K0, his, los, [dev(b) for b in bs], Hs48, m48, K0, None, M, G)
-        torch.cuda.synchronize()
-        Hs48 = unblock_h(Hs48)
-        assert torch.equal(Hs4[3], Hs48[3])
-        for l in range(3):
-            assert torch.equal(Hs48[l].view(torch.uint8), Hs8[l].view(torch.uint8)), l
-            assert torch.equal(m4[l], m48[l])
 
 
 def gate_image_ref(mask, M):
@@ -805,7 +549,7 @@ def test_wgrad_gated_and_bwd_skip0(H, B, n):
     Wt = list(torch.empty(L - 1, 65536, dtype=torch.bfloat16, device="cuda"))
     for st in range(L - 1):
         W = dev(bf16_round(formula.hash_uniform((G, G), 330 + st, -0.15, 0.15)))
-        H.pack_matrix_frag(W, 1, G, G, G, Wt[st], st == 0)
+        pack_frag(H, W, 1, G, G, G, Wt[st], st == 0)
     full = list(torch.zeros(L, M, G, dtype=torch.bfloat16, device="cuda"))
     H.g_chain_bwd_rr(dxg, masks, Wt, full, M, n * n, G)
     part = [None] + list(torch.zeros(L - 1, M, G, dtype=torch.bfloat16, device="cuda"))
@@ -845,7 +589,7 @@ def test_g_chain_bwd_rr_red(H, B, n, tpu):
     Ws = []
     for st in range(L - 1):
         Ws.append(bf16_round(formula.hash_uniform((G, G), 340 + st, -0.15, 0.15)))
-        H.pack_matrix_frag(dev(Ws[-1]), 1, G, G, G, Wt[st], st == 0)
+        pack_frag(H, dev(Ws[-1]), 1, G, G, G, Wt[st], st == 0)
     old = [None] + list(torch.zeros(L - 1, M, G, dtype=torch.bfloat16, device="cuda"))
     H.g_chain_bwd_rr(dxg, masks, Wt, old, M, n * n, G)
     tpu = tpu or H.g_chain_bwd_rr_red_tpu(M, n)
@@ -954,19 +698,18 @@ def test_wgrad_fp8_operand(H):
 
 @pytest.mark.parametrize("B,npairs", [(2, 512), (24, 32 * 100), (16, 144)])
 def test_g_chain_bwd_rr(H, B, npairs):
-    """Register-resident backward chain on the masks of a real forward call: dZ[0] = bf16(dxg) where gate_3; every
-    further dZ equals one un-fused dgrad step on the kernel's OWN previous dZ (<= 1 bf16 ulp), zero where gated.
-    (16, 144): a wave's 32 rows straddle two questions."""
-    G, L, K0 = 256, 4, 192
+    """Register-resident backward chain on arbitrary (random) lane masks: dZ[0] = bf16(dxg) where gate_3; every further dZ equals
+    one un-fused dgrad step on the kernel's OWN previous dZ (<= 1 bf16 ulp), zero where gated.  (16, 144): a wave's 32 rows
+    straddle two questions."""
+    G, L = 256, 4
     M = B * npairs
-    P, Ws, bs, Wf = rr_setup(H, M, K0, 180)
-    Hs = [torch.empty(M, G, dtype=torch.bfloat16, device="cuda") for _ in range(L)]
-    masks = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))       # equally spaced
-    H.g_chain_fwd_rr(dev(P).bfloat16(), K0, Wf, [dev(b) for b in bs], Hs, masks, K0, None, M, G)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    masks = list(torch.randint(0, 256, (L, H.g_chain_rr_mask_bytes(M)), dtype=torch.uint8, device="cuda", generator=g))       # equally spaced
+    Ws = [bf16_round(formula.hash_uniform((G, G), 310 + l, -0.15, 0.15)) for l in range(L)]
     dxg = formula.hash_uniform((B, G), 410, -1, 1)
     Wtf = list(torch.empty(L - 1, 65536, dtype=torch.bfloat16, device="cuda"))
     for s, f in enumerate(Wtf):
-        H.pack_matrix_frag(dev(Ws[L - 1 - s]), 1, G, G, G, f, s == 0)       # element (in, out) = W[out][in]
+        pack_frag(H, dev(Ws[L - 1 - s]), 1, G, G, G, f, s == 0)       # element (in, out) = W[out][in]
     dZs = list(torch.full((L, M, G), float("nan"), dtype=torch.bfloat16, device="cuda"))
     H.g_chain_bwd_rr(dev(dxg), masks, Wtf, dZs, M, npairs, G)
     torch.cuda.synchronize()
@@ -980,74 +723,6 @@ def test_g_chain_bwd_rr(H, B, npairs):
         err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
         assert err.max() <= BF16_ULP, (s, err.max())
         assert np.all(got[~gates[L - 2 - s]] == 0)
-
-
-def test_g_chain_fwd_f16s(H):
-    """f16s chain (fp16 tile x fp16 hi+lo weights): against a float64 emulation that rounds the tile to fp16
-    after every layer and uses the same split weights.  Stored activations are bf16 copies of the fp16 tile."""
-    M, G, K0, K0true, L = 2048, 256, 192, 180, 4
-    def f16r(a):
-        return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
-    P = np.zeros((M, K0), np.float32); P[:, :K0true] = formula.hash_uniform((M, K0true), 500, -1, 1)
-    P = f16r(P)
-    Ws, bs, Ks, his, los = [], [], [], [], []
-    for l in range(L):
-        kt, kp = (K0true, K0) if l == 0 else (G, G)
-        W = np.zeros((G, kp), np.float32); W[:, :kt] = formula.hash_uniform((G, kt), 510 + l, -0.15, 0.15)
-        Ws.append(W); bs.append(formula.hash_uniform((G,), 520 + l, -0.3, 0.3)); Ks.append(kp)
-        hi = torch.empty(G, kp, dtype=torch.float16, device="cuda"); lo = torch.empty_like(hi)
-        H.pack_matrix_split(dev(W), kp, 1, G, kp, hi, lo, kp, G)
-        his.append(hi); los.append(lo)
-        wh = f16r(W)
-        assert np.array_equal(hi.float().cpu().numpy(), wh) and np.array_equal(lo.float().cpu().numpy(), f16r(W - wh))
-    Hs = [torch.empty(M, G, dtype=torch.bfloat16, device="cuda") for _ in range(L)]
-    part = torch.empty(M // 128, G, dtype=torch.float32, device="cuda")
-    H.g_chain_fwd_f16s(dev(P).half(), K0, his, los, [dev(b) for b in bs], Hs, Ks, part, M, G)
-    torch.cuda.synchronize()
-    prev = P.astype(np.float64)
-    for l in range(L):
-        wh = f16r(Ws[l]); wl = f16r(Ws[l] - wh)
-        z = prev @ (wh.astype(np.float64) + wl.astype(np.float64)).T + bs[l]
-        prev = f16r(np.maximum(z, 0)).astype(np.float64)
-        got = Hs[l].float().cpu().numpy()
-        ref = bf16_round(prev)
-        if l == 0:      # same operands: only accumulation order + the two roundings differ
-            err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
-            assert err.max() <= 2 * BF16_ULP, (l, err.max())
-        # deeper layers see each other's fp16 rounding decisions: compare in max-norm (1 bf16 ulp of the largest value)
-        assert rel(got, ref) <= BF16_ULP, (l, rel(got, ref))
-    assert rel(part.cpu().numpy(), prev.reshape(M // 128, 128, G).sum(1)) <= 1e-3
-    # and it is much closer to the exact fp32 chain than the bf16 chain can be
-    exact = P.astype(np.float64)
-    for l in range(L):
-        exact = np.maximum(exact @ Ws[l].astype(np.float64).T + bs[l], 0)
-    assert rel(part.cpu().numpy(), exact.reshape(M // 128, 128, G).sum(1)) <= 3e-4
-
-
-@pytest.mark.parametrize("B,npairs", [(2, 512), (8, 144), (300, 256)])
-def test_g_chain_bwd_fused(H, B, npairs):
-    """Fused backward chain: dZ[0] = dxg * (HL > 0) exactly; every further dZ must equal one un-fused
-    dgrad step applied to the kernel's OWN previous dZ (<= 1 bf16 ulp).  (8, 144): 128-row tiles
-    straddle questions; (300, 256): more tiles than CUs (persistent loop + next-tile prefetch)."""
-    G, L = 256, 4
-    M = B * npairs
-    Hs = [bf16_round(np.maximum(formula.hash_uniform((M, G), 400 + l, -1, 1), 0)) for l in range(L)]   # H_1..H_L
-    dxg = formula.hash_uniform((B, G), 410, -1, 1)
-    Ws = [bf16_round(formula.hash_uniform((G, G), 420 + l, -0.15, 0.15)) for l in range(L)]           # W_l (out, in)
-    dZs = [torch.empty(M, G, dtype=torch.bfloat16, device="cuda") for _ in range(L)]
-    Wts = [dev(np.ascontiguousarray(Ws[L - 1 - s].T)).bfloat16() for s in range(L - 1)]              # (in, out)
-    gates = [dev(Hs[L - 2 - s]).bfloat16() for s in range(L - 1)]                                    # input act of layer L-1-s
-    H.g_chain_bwd(dev(Hs[L - 1]).bfloat16(), dev(dxg), Wts, gates, dZs, 0, M, npairs, G)
-    torch.cuda.synchronize()
-    ref0 = bf16_round(np.repeat(dxg, npairs, axis=0) * (Hs[L - 1] > 0))
-    got = dZs[0].float().cpu().numpy()
-    assert np.array_equal(got, ref0)
-    for s in range(L - 1):
-        ref = (got.astype(np.float64) @ Ws[L - 1 - s].astype(np.float64)) * (Hs[L - 2 - s] > 0)
-        got = dZs[s + 1].float().cpu().numpy()
-        err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
-        assert err.max() <= BF16_ULP, (s, err.max())
-        assert np.all(got[Hs[L - 2 - s] <= 0] == 0)
 
 
 # ----------------------------------------------------------------------------- K3
@@ -1177,23 +852,6 @@ def test_gemm_f32_variants(H):
     assert rel(out.cpu().numpy(), g.astype(np.float64) @ w[:, 30:50]) <= F32_TOL
 
 
-def test_log_softmax_and_colsum(H):
-    B, A = 67, 28
-    z = formula.hash_uniform((B, A), 90, -30, 30)
-    out = torch.empty(B, A, dtype=torch.float32, device="cuda")
-    H.log_softmax_fwd(dev(z), out, B, A)
-    ref = O.log_softmax_np(z)
-    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-5
-    g = formula.hash_uniform((B, A), 91)
-    dz = torch.empty_like(out)
-    H.log_softmax_bwd(out, dev(g), dz, B, A)
-    refd = g - np.exp(ref.astype(np.float64)) * g.sum(1, keepdims=True)
-    assert rel(dz.cpu().numpy(), refd) <= F32_TOL
-    cs = torch.empty(A, dtype=torch.float32, device="cuda")
-    H.colsum_f32(dev(g), A, cs, B, A)
-    assert rel(cs.cpu().numpy(), g.sum(0, dtype=np.float64)) <= F32_TOL
-
-
 def test_argument_errors_are_loud(H):
     P = torch.empty(16, 100, dtype=torch.bfloat16, device="cuda")
     x = torch.zeros(1, 4, 3, device="cuda")
@@ -1217,8 +875,11 @@ def test_conv_bn_relu_block(N, hw):
     b.load_state_dict(a.state_dict())
     img = torch.rand(N, 3, hw, hw, device="cuda")
     tgt = torch.randn(N, 24, hw // 16, hw // 16, device="cuda")
-    with pkg.options.override(fused_bn=False):
-        ya = a(img)
+    def stock(m, x):                                          # the reference's op sequence (model.py:22-35) on m's own parameters
+        for i in range(1, 5):
+            x = torch.nn.functional.relu(m._modules["batchNorm%d" % i](m._modules["conv%d" % i](x)))
+        return x
+    ya = stock(a, img)
     yb = b(img)
     assert rel(yb.detach().cpu().numpy(), ya.detach().cpu().numpy()) <= F32_TOL
     (ya * tgt).sum().backward()
@@ -1236,8 +897,7 @@ def test_conv_bn_relu_block(N, hw):
     # evaluation mode: running statistics
     a.eval(); b.eval()
     with torch.no_grad():
-        with pkg.options.override(fused_bn=False):
-            ea = a(img)
+        ea = stock(a, img)
         eb = b(img)
     assert rel(eb.cpu().numpy(), ea.cpu().numpy()) <= F32_TOL
 
@@ -1254,8 +914,7 @@ def test_question_lstm(B, T):
     b.load_state_dict(a.state_dict())
     q = torch.from_numpy(formula.hash_ints((B, T), 900, 0, formula.QDICT + 1)).cuda()
     tgt = torch.randn(B, 128, device="cuda")
-    with pkg.options.override(fused_lstm=False):
-        ha = a(q)
+    ha = a.lstm(a.wembedding(q))[1][0][0]                     # the reference's op sequence (model.py:52-58) on a's own parameters
     hb = b(q)
     assert rel(hb.detach().cpu().numpy(), ha.detach().cpu().numpy()) <= F32_TOL
     (ha * tgt).sum().backward()
@@ -1397,7 +1056,7 @@ def test_f_phi_large_batch_and_label_clamp(H, B):
         assert rel(got.cpu().numpy(), want.cpu().numpy()) <= 2e-4
 
 
-@pytest.mark.parametrize("f16s", [False, True])
+@pytest.mark.parametrize("f16s", [True])
 def test_e4m3_copies_saturate_instead_of_turning_into_nan(H, f16s):
     """Activations beyond the e4m3 range (448) must be stored as 448 (byte 0x7e), never as the NaN byte the raw conversion
     produces: a layer-0 bias of +600 drives every H_0 value there; the wgrad that reads the copies then stays finite."""
@@ -1420,11 +1079,6 @@ def test_e4m3_copies_saturate_instead_of_turning_into_nan(H, f16s):
         H.pack_matrix_frag_many(jobs + [(wd[0], kt, 1, G, kt, w0T, 2)])
         H.pair_tables(dev(x), dev(q), w0T, bd[0], Xp, Vc, B, n, k, Q, G)
         H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hi, lo, bd, Hs8, masks, part, M, G)
-    else:
-        Wf = [torch.empty(65536, dtype=torch.bfloat16, device="cuda") for _ in range(L)]
-        H.pack_matrix_frag_many([(wd[0], kt, 1, G, k, Wf[0], 1), (wd[0], kt, 1, G, kt, w0T, 2)] + [(wd[l], G, 1, G, G, Wf[l], 0) for l in range(1, L)])
-        H.pair_tables(dev(x), dev(q), w0T, bd[0], Xp, Vc, B, n, k, Q, G)
-        H.g_chain_fwd_rr_alg0(Xp, Vc, n, Wf, bd, Hs8, masks, part, M, G)
     torch.cuda.synchronize()
     b0 = Hs8[0].view(torch.uint8)
     assert bool((b0 == 0x7e).all()), torch.unique(b0).tolist()[:8]

@@ -44,16 +44,25 @@ def test_library_exports_every_declared_symbol(pkg):
     hv = int(re.search(r"#define\s+RN_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "rn_hip.h")).read()).group(1))
     assert loaded.rn_abi_version() == hv == pkg.rn_hip.ABI_VERSION
     # pure host entry points (no device work) are callable without a GPU
-    assert loaded.rn_wgrad_ws_bytes(262144, 256, 256) == (256 * 256 * 256 + 256 * 256) * 4
-    assert loaded.rn_wgrad_ws_bytes(100, 100, 256) == 0
-    assert loaded.rn_pair_sum_ws_bytes(64, 4096, 256) == 64 * 16 * 256 * 4
+    Hm = pkg.rn_hip
+    ws = Hm.workspace_bytes
+    assert ws(Hm.WS_WGRAD, 262144, 256, 256) == (256 * 256 * 256 + 256 * 256) * 4
+    assert ws(Hm.WS_WGRAD, 100, 100, 256) == 0
+    assert ws(Hm.WS_PAIR_SUM, 64, 4096, 256) == 64 * 16 * 256 * 4
+    assert ws(Hm.WS_RR_MASK, 262144) == 32 * 262144 and ws(Hm.WS_EXTRACT, 64, 64, 256) == 2 * 64 * 64 * 256 * 4
+    assert ws(99) == 0 and b"unknown op" in loaded.rn_last_error()
+    # the Python constants are the header's enum
+    hdr = open(os.path.join(ROOT, "include", "rn_hip.h")).read()
+    for name, val in re.findall(r"(RN_WS_[A-Z0-9_]+) = (\d+)", hdr):
+        assert getattr(Hm, name[3:]) == int(val), name
+    assert len(declared) <= 60
     # row splits of the blocked weight gradient: njobs x Z x 4 workgroups ~ three quarters of the CUs; question-aligned on request
     sp = loaded.rn_wgrad_blocked_splits
     assert sp(64 * 4096, 4096, 1, 0) == 48 and sp(64 * 4096, 4096, 3, 0) == 16 and sp(2 * 1024, 1024, 1, 0) == 32 and sp(100, 0, 1, 0) == 0
     assert sp(64 * 4096, 4096, 1, 1) == 64 and sp(32 * 4096, 4096, 1, 1) == 32 and sp(3 * 4096, 4096, 1, 1) == 48 and sp(128 * 4096, 4096, 1, 1) == 128
     assert sp(17 * 4096, 4096, 1, 1) == 34 and sp(32 * 38416, 38416, 1, 1) == 48 and sp(64 * 4096, 4096, 3, 1) == 64 and sp(4 * 4096, 4096, 3, 1) == 16
     assert sp(64 * 4096, 4096, 5, 0) == 0
-    assert loaded.rn_wgrad_blocked_ws_bytes(64 * 4096, 4096, 3, 0) == 3 * (16 * 65536 + 16 * 4 * 256) * 4
+    assert ws(Hm.WS_WGRAD_BLOCKED, 64 * 4096, 4096, 3, 0) == 3 * (16 * 65536 + 16 * 4 * 256) * 4
 
 
 def test_library_and_hot_path_never_read_the_environment(pkg):
@@ -76,8 +85,9 @@ def test_library_and_hot_path_never_read_the_environment(pkg):
             assert "environ" not in open(os.path.join(pk, f)).read(), f
     O = pkg.options
     assert O.OPT.h8 is True and O.OPT.precision == "auto" and O.OPT.non_default() == {}
-    o2 = O.Options({"RN_H8": "0", "RN_NO_RR_CHAIN": "1", "RN_WGRAD_LATE": "2", "RN_PRECISION": "fp32", "RN_NO_FUSED_BN": "0"})
-    assert (o2.h8, o2.rr_chain, o2.wgrad_late, o2.precision, o2.fused_bn) == (False, False, 2, "fp32", True)
+    o2 = O.Options({"RN_H8": "0", "RN_NO_CHAIN_REDUCE": "1", "RN_PRECISION": "fp32", "RN_NO_FUSED_ADAM": "0", "RN_OVERLAP_STREAMS": "0"})
+    assert (o2.h8, o2.chain_reduce, o2.precision, o2.fused_adam, o2.overlap_streams) == (False, False, "fp32", True, False)
+    assert len(O._SPEC) <= 15
     with O.override(h8=False):
         assert O.OPT.h8 is False
     assert O.OPT.h8 is True
