@@ -164,6 +164,7 @@ typedef __attribute__((ext_vector_type(2))) int rr_i32x2;
 typedef __attribute__((address_space(3))) rr_i32x2* lds_tr8;
 // 16-bit block staged as [32 rows][RR_SRS], 32 features = 64 B per row: -> co[t] = rows 8 rb .. 8 rb + 7 (rb = 2 t + lane / 32) of
 // feature 16 ((lane / 16) % 2) + lane % 16
+template <int SRS = RR_SRS>
 __device__ __forceinline__ void co_read_blk16(const unsigned char* stg, int lane, u32x4 (&co)[2]) {
   const int g = lane >> 4, li = lane & 15;
 #pragma unroll
@@ -171,7 +172,7 @@ __device__ __forceinline__ void co_read_blk16(const unsigned char* stg, int lane
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int row = 8 * (2 * t + (g >> 1)) + 4 * u + (li >> 2);
-      const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr16)(stg + row * RR_SRS + 32 * (g & 1) + 8 * (li & 3)));
+      const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr16)(stg + row * SRS + 32 * (g & 1) + 8 * (li & 3)));
       const u32x2 rr = __builtin_bit_cast(u32x2, r);
       co[t][2 * u] = rr[0];
       co[t][2 * u + 1] = rr[1];
@@ -804,6 +805,13 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
   unsigned char* const stg = lds + RR_OFF_STG + w * RR_STG;
   constexpr int NS = RR_L - 1;                                        // dgrad steps
   constexpr int NSL = Vm::NSLOT, LA = Vm::LA, RING = RED ? RR_OFF_RING_RED : RR_OFF_RING;
+  // staging row stride of the 16-bit blocks (64 B of features + padding).  80 B keeps the row-major 16-byte reads of a stored dZ_0
+  // aligned; without them (RED) 72 B is the better padding: the 8-byte epilogue writes of 16 lanes and the transposing reads of a
+  // lane group then fall on distinct banks (stride 18 dwords: 0, 18, 4, 22, ... mod 32)
+#ifndef RN_RED_SRS
+#define RN_RED_SRS 72
+#endif
+  constexpr int SRS = RED ? RN_RED_SRS : RR_SRS;
 
   Frag actA[16], actB[16], ring[RR_RD];
   f32x16 acc[2];
@@ -856,11 +864,11 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
     // layer 0, read by the pair reduction: row-major
     auto co_read = [&](int zi) {
       if (zi < NS) {
-        co_read_blk16(stg, lane, co);
+        co_read_blk16<SRS>(stg, lane, co);
         return;
       }
 #pragma unroll
-      for (int q = 0; q < 2; ++q) co[q] = *reinterpret_cast<const u32x4*>(stg + (16 * q + (lane >> 2)) * RR_SRS + (lane & 3) * 16);
+      for (int q = 0; q < 2; ++q) co[q] = *reinterpret_cast<const u32x4*>(stg + (16 * q + (lane >> 2)) * SRS + (lane & 3) * 16);
     };
     const unsigned orow_off = (unsigned)((lane >> 2) * RR_G + (lane & 3) * 8) * 2u;
     auto co_store = [&](int zi, int cob, int q) {
@@ -932,7 +940,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
             const unsigned t1 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 16 * s + 2 * p + 1, 1);
             actA[ks][p] = u & ((t0 & 0xffffu) | (t1 & 0xffff0000u));
           }
-          if constexpr (!SKIP0) *reinterpret_cast<u32x4*>(stg + n * RR_SRS + 32 * s + 16 * h) = actA[ks];
+          if constexpr (!SKIP0) *reinterpret_cast<u32x4*>(stg + n * SRS + 32 * s + 16 * h) = actA[ks];
         }
         if constexpr (!SKIP0) {
           co_read(0);
@@ -1011,7 +1019,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
             pk[j][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f0, bf16x2));
             pk[j][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f1, bf16x2));
           } else {
-            *reinterpret_cast<u32x2*>(stg + n * RR_SRS + 16 * j + 8 * h) = pk[j];
+            *reinterpret_cast<u32x2*>(stg + n * SRS + 16 * j + 8 * h) = pk[j];
             if (dst) {
               dst[2 * pob + (j >> 1)][(j & 1) * 2 + 0] = pk[j][0];
               dst[2 * pob + (j >> 1)][(j & 1) * 2 + 1] = pk[j][1];
@@ -1075,7 +1083,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
         u32x2 pk;
         pk[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f0, bf16x2));
         pk[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f1, bf16x2));
-        *reinterpret_cast<u32x2*>(stg + n * RR_SRS + 16 * j + 8 * h) = pk;
+        *reinterpret_cast<u32x2*>(stg + n * SRS + 16 * j + 8 * h) = pk;
       }
       co_read(NS);
 #pragma unroll
