@@ -29,6 +29,7 @@ python tools/time_small.py > $OUT/small_kernels_alone.txt 2>/dev/null
 python tools/time_wgrad.py > $OUT/wgrad_alone.txt 2>/dev/null
 python tools/time_fwd_f16s.py > $OUT/fwd_chain_alone.txt 2>/dev/null
 python tools/time_k1.py > $OUT/k1_alone.txt 2>/dev/null
+python tools/time_bwd.py > $OUT/bwd_chain_alone.txt 2>/dev/null
 # 5. round 4: the fused extraction op alone + its written bytes, the convergence runs, the sustained run's clocks
 python tools/time_extract.py > $OUT/extract_alone.txt 2>/dev/null
 (cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_xw -o p -- python $R/tools/time_extract.py once > $OUT/pmc_extract.log 2>&1; python $R/tools/pmc_table.py $(find /tmp/p_xw -name "*counter_collection.csv" | head -1) | grep -i "extract" > $OUT/pmc_extract_write.txt)

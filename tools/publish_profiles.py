@@ -12,7 +12,7 @@ shutil.copy(os.path.join(src, "kernel_stats.csv"), dst("kernel_stats_rocprofv3.c
 shutil.copy(os.path.join(src, "bench_line.json"), dst("bench_line.json"))
 shutil.copy(os.path.join(src, "step_timeline.txt"), dst("step_timeline.txt"))
 for extra in ("bench_ir_fp.json", "bench_stress_b32_n196.json", "small_kernels_alone.txt", "k1_alone.txt", "wgrad_alone.txt", "fwd_chain_alone.txt",
-              "extract_alone.txt", "pmc_extract_write.txt", "convergence.txt", "clocks.txt"):
+              "bwd_chain_alone.txt", "extract_alone.txt", "pmc_extract_write.txt", "convergence.txt", "clocks.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), dst(extra))
 OURS = re.compile(r"(rr_kernel|rr_f16s|rr_bwd|wgrad|pair_|f_phi|cn_|lstm_|emb_bwd|conv3x3s2|conv_wgrad|clip_adam|sumsq|nll_|segsum|pack_frag|debug_stamp)")
