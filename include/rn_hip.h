@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RN_ABI_VERSION 4   /* bumped whenever a signature or a buffer layout of this header changes */
+#define RN_ABI_VERSION 5   /* bumped whenever a signature or a buffer layout of this header changes */
 
 enum { RN_BF16 = 0, RN_F32 = 1, RN_F16 = 2, RN_FP8 = 3 };   /* RN_F16: pair matrix / split weights of the f16s forward only;
                                                              * RN_FP8: OCP e4m3 copies of the stored activations (h_dtype / a_dtype) */
@@ -183,8 +183,9 @@ int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, int lda, floa
  *   job j:  dW[j] (256, 256) = dZ[j]^T A[j],  db[j] (256) = column sums of dZ[j]          (model.py:141-145 autograd)
  * dZ[j]: 16-bit image (dz_dtype[j] = RN_BF16); A[j]: image of the layer's input, a_dtype = RN_BF16 or RN_FP8 (all jobs alike).
  * dz_dtype[j] = RN_FP8 (needs a_dtype = RN_FP8): a GATE job -- the LAST layer, whose gradient is never stored:
- * dZ_3[(b, pair), f] = gate[(b, pair), f] * dxg[b][f].  dZ[j] is then the e4m3 {0, 1} image of the gate (the forward chain's gate_image),
- * multiplied with A[j] on the fp8 matrix pipe (exact products), and each question's sums are scaled by its row of dxg
+ * dZ_3[(b, pair), f] = gate[(b, pair), f] * dxg[b][f].  The gate is read from the SIGN BITS of A[j] (the forward chain called with
+ * gate_in_h2 != 0 writes H_2 that way: byte (m, f) = e4m3(H_2[m, f]) | gate_3[m, f] << 7); dZ[j] must be NULL or A[j].  Gate and
+ * activation bytes meet on the fp8 matrix pipe (exact products), and each question's sums are scaled by its row of dxg
  * (M / rows_per_question, 256) fp32 -- un-rounded, i.e. closer to the fp32 reference than a stored bf16 dZ_3 -- when the
  * question ends; rows_per_question % 64 == 0 then (otherwise it only steers the row splits; 0 = unknown).  M % 64 == 0.
  * Z = rn_wgrad_blocked_splits(M, rows_per_question, njobs, aligned) row splits per job (0: shape not covered): about 64 / njobs,
@@ -199,8 +200,6 @@ int rn_wgrad_blocked_splits(int M, int rows_per_question, int njobs, int aligned
 size_t rn_wgrad_blocked_db_partials_offset(int M, int rows_per_question, int njobs, int aligned, int job);
 int rn_g_wgrad_blocked(const void* const* dZ, const int* dz_dtype, const void* const* A, int a_dtype, const float* dxg,
                        int rows_per_question, int aligned, float* const* dW, float* const* db, int njobs, void* ws, int M, void* stream);
-/* The ReLU gate of the last g layer as an e4m3 {0, 1} row-blocked image (M x 256 bytes, byte 0x38 = 1.0) from the layer-3 lane
- * masks of rn_g_chain_fwd_rr* (rn_workspace_bytes(RN_WS_RR_MASK, M) bytes): the dZ operand of a gate job.  M % 32 == 0. */
 /* Health of an e4m3 activation copy H_l, l = 0..2 (h_dtype = RN_FP8; fixed scale 1: values below 2^-10 flush to zero, values
  * above 448 are clamped): mask = the layer's lane masks of the SAME forward call (which elements were positive before rounding),
  * img = its row-blocked e4m3 image.  out4 (4 x uint64, ZEROED by the caller, accumulated with integer atomics): positive elements,
@@ -430,14 +429,15 @@ int rn_bn_relu_bwd_conv_wgrad(const float* dy, const float* xc, const float* inp
  *     rn_pair_sum_tiles.  The backward side (rn_g_chain_bwd_rr with rows_per_question = n * njp, rn_g_wgrad_blocked,
  *     rn_pair_reduce_bwd with njp) then sees zero gradients for the invalid rows without knowing about the padding.  Question at
  *     layer 0 only.
- *   gate_image (may be NULL; with the e4m3 training output set): M x 256 bytes -- the last layer's ReLU gate as an e4m3 {0, 1}
- *     row-blocked image (1.0 = 0x38), exactly what rn_relu_gate_image (include/rn_hip_debug.h) builds from mask[3]: the `dZ` operand
- *     of the last layer's gate job in rn_g_wgrad_blocked, written from the forward kernel's epilogue. */
+ *   gate_in_h2 (with the e4m3 training output set only): != 0 -- the last layer's ReLU gate (= mask[3]) is also written into the
+ *     sign bits of the H[2] image: byte (m, f) = e4m3(H_2[m, f]) | gate_3[m, f] << 7 (exactly what rn_relu_gate_image of
+ *     include/rn_hip_debug.h merges into a plain image).  That one image is both operands of the last layer's gate job in
+ *     rn_g_wgrad_blocked; every other reader masks bit 7 off (rn_fp8_copy_health does). */
 int rn_pair_tables(const float* x, long sxb, long sxn, long sxk, const float* coord, int kf, const float* q, long ldq,
                    const float* W0T, const float* b0, void* Xp, int xp_dtype /* RN_BF16 | RN_F16 */, float* Vc, int B, int n, int k,
                    int Q, int N, void* stream);
 int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, int njp, const void* const* Whi, const void* const* Wlo, int dither,
-                                const float* const* bias, void* const* H, int h_dtype, void* const* mask, void* gate_image, float* xg_part,
+                                const float* const* bias, void* const* H, int h_dtype, void* const* mask, int gate_in_h2, float* xg_part,
                                 const float* Vq, int inject_layer, int M, int L, int G, void* stream);
 
 #ifdef __cplusplus

@@ -25,8 +25,9 @@ int rn_debug_stamp(unsigned long long* slot, void* stream);
  * The chains write the images themselves; tests and tools convert with this.  M % 16 == 0, dtype RN_BF16 or RN_FP8. */
 int rn_rows_to_blocked(const void* src, void* dst, int dtype, int M, int back, void* stream);
 
-/* e4m3 {0, 1} row-blocked image (1.0 = 0x38) of the last layer's lane masks -- what the f16s forward chain writes from its epilogue
- * (gate_image); the tests build the reference image with this.  M % 32 == 0. */
+/* Merges the last layer's lane masks into the sign bits of the e4m3 row-blocked image img (M x 256 bytes, in place): byte (m, f) =
+ * (byte & 0x7f) | gate[m, f] << 7 -- what the f16s forward chain writes for H_2 with gate_in_h2 != 0; the tests build the reference
+ * image with this.  M % 32 == 0. */
 int rn_relu_gate_image(const void* mask, void* img, int M, void* stream);
 
 #ifdef __cplusplus

@@ -302,7 +302,6 @@ struct RRArgsF {
   bf16* out[RR_L];
   u64* mask[RR_L];
   int prio;
-  unsigned char* gate;                                  // GATE: e4m3 {0, 1} row-blocked image of the last layer's ReLU gate
 };
 __device__ __forceinline__ unsigned relu_pack_f16(float a, float b) {     // saturate instead of overflowing fp16 to inf
   const f32x2 f = {fminf(a, 65504.f), fminf(b, 65504.f)};
@@ -325,12 +324,13 @@ struct F16Vm {
   static_assert((NK0 * 2) % RR_NW == 0, "layer-0 requests divide evenly over the waves");
   static constexpr int ops(int sidx) {
     int k = dpw(((sidx + F_LA) >> 3) & 3);                            // (stage sidx requests the weights of stage sidx + F_LA)
-    if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3)) k += (H8 && ((sidx - 2) >> 3) < RR_L - 1) ? (((sidx - 2) & 1) ? 2 : 0) : 2;
+    if (STORE && sidx >= 2 && (((sidx - 2) >> 3) < RR_L - 1 || ST3) && !(GATE && ((sidx - 2) >> 3) == RR_L - 2))    // (GATE: H_2 leaves with the gate, below)
+      k += (H8 && ((sidx - 2) >> 3) < RR_L - 1) ? (((sidx - 2) & 1) ? 2 : 0) : 2;
     if ((sidx >> 3) == RR_L - 1)
       for (int c = 0; c < PF_PER; ++c) k += ((sidx & 7) * PF_PER + c < NK0) ? 1 : 0;
     if (ALG0 && sidx == VC_STAGE) k += 1;
     if (INJ > 0 && sidx == VQ_STAGE) k += 1;
-    if (GATE && (sidx >> 3) == RR_L - 1 && (sidx & 7) >= 1) k += 1;   // the gate cells of the last layer's block (sidx & 7) - 1
+    if (GATE && (sidx >> 3) == RR_L - 1 && (sidx & 7) >= 1) k += 1;   // the H_2 | gate cells of block (sidx & 7) - 1
     return k;
   }
   static constexpr int tail() { return (STORE && ST3 ? 4 : 0) + (XG ? (ALG0 ? 1 : 8) : 0) + (GATE ? 1 : 0); }
@@ -375,12 +375,15 @@ struct F16Vm {
 // are INVALID: their ReLU lane-mask bits are cleared in every layer (the backward chain, the gate job and the pair reductions
 // then see zero gradients for them without knowing about the padding) and they are left out of the pair sum.  A 256-row tile
 // may straddle two questions at a wave boundary: it leaves TWO partial rows (rn_pair_sum_tiles adds them up per question).
-// GATE: the last layer's ReLU gate also leaves as an e4m3 {0, 1} byte image (1.0 = 0x38) in the row-blocked layout of the H copies
-// (byte (m, f) at ((m / 16) 256 + f) 16 + m % 16) -- the operand the gate job of rn_g_wgrad_blocked multiplies with the H_2 image;
-// built here it costs one 16-byte store per lane and block in the MFMA shadow instead of a kernel of its own (8 MB of masks ->
-// 67 MB) at the head of the HBM-bound window behind the backward chain.  In the un-swapped last layer a lane owns feature n of
-// rows 8 j + 4 h + r: per 16-row group two of the cell's four dwords, the other two sit in the partner lane (n, 1 - h) --
-// two v_permlane32_swap hand lane half 0 the whole cell of rows 0..15 and half 1 that of rows 16..31.
+// GATE: the last layer's ReLU gate leaves IN THE SIGN BITS of the e4m3 H_2 image (post-ReLU bytes are never negative): byte (m, f)
+// of out[2] = e4m3(H_2[m, f]) | gate_3[m, f] << 7 -- ONE 67-MB image is both operands of the gate job of rn_g_wgrad_blocked
+// (dZ_3 = gate_3 x dxg[question], never stored), instead of an H_2 image plus a {0, 1} byte image of the gate (round 3: 67 MB
+// written here and read there for 8 MB of information).  H_2 therefore leaves one layer late: block pob's bytes are converted from
+// the fp16 operand registers of the last layer (alive until its end) and staged during the stage that closes output block pob of
+// the LAST layer, read back transposed -- lane (n, h) receives rows 16 h .. 16 h + 15 of feature n -- and or-ed with the gate cell:
+// in the un-swapped last layer a lane owns feature n of rows 8 j + 4 h + r, i.e. per 16-row group two of the cell's four dwords,
+// the other two sit in the partner lane (n, 1 - h) -- two v_permlane32_swap hand lane half 0 the whole cell of rows 0..15 and half
+// 1 that of rows 16..31.  One 16-byte store per lane and block, all in the MFMA shadow.
 template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false, int ABL = 0, bool RAG = false,
           bool GATE = false>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __restrict__ P, int ldp, RRArgsF a,
@@ -522,6 +525,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
         dst[2 * pob + (j >> 1)][(j & 1) * 2 + 1] = f1;
         if constexpr (H8) { pk[j][0] = f0; pk[j][1] = f1; }
       }
+      if (GATE && pl == RR_L - 2) return;                             // (H_2 is staged by the last layer, with its gate)
       if (ph == 2 && STORE) {
         if constexpr (H8) {
           pk[j][0] = rn_fp8x4_from_f16(pk[j][0], pk[j][1]);
@@ -562,14 +566,30 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
     };
     float b3 = 0.f;
     unsigned gd[4];                                                    // GATE: the lane's four gate bytes of accumulator group j
+    u32x4 hcell;                                                       // GATE: rows 16 h .. 16 h + 15 of feature n of H_2 block pob, e4m3
     const unsigned gate_lane = (unsigned)((h * RR_G + n) * 16);
+    // H_2 block pob, accumulator group j: the lane's four features 8 j + 4 h + r of row n, from the fp16 operand pair of the last layer
+    auto h2_stage = [&](int pob, int j, unsigned f0, unsigned f1) {
+      if constexpr (GATE) *reinterpret_cast<unsigned*>(stg + n * RR_SRS8 + 32 * (pob & 1) + 8 * j + 4 * h) = rn_fp8x4_from_f16(f0, f1);
+    };
+    auto h2_read = [&](int pob) {
+      if constexpr (GATE) {
+        const int li = lane & 15, fg = (lane >> 4) & 1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const rr_i32x2 r = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_tr8)(stg + (16 * h + 8 * u + (li >> 1)) * RR_SRS8 + 32 * (pob & 1) + 16 * fg + 8 * (li & 1)));
+          hcell[2 * u] = (unsigned)r[0];
+          hcell[2 * u + 1] = (unsigned)r[1];
+        }
+      }
+    };
     auto gate_store = [&](int pob) {
       if constexpr (GATE) {
         // gd[0], gd[1]: dwords h, 2 + h of the cell (rows 0..15, feature n); gd[2], gd[3]: of the cell of rows 16..31
         const u32x2 s0 = __builtin_amdgcn_permlane32_swap(gd[0], gd[2], false, false);
         const u32x2 s1 = __builtin_amdgcn_permlane32_swap(gd[1], gd[3], false, false);
-        const u32x4 cell = {s0[0], s0[1], s1[0], s1[1]};
-        gbl_u8* base = (gbl_u8*)(a.gate + m0w * RR_G);
+        const u32x4 cell = {s0[0] | hcell[0], s0[1] | hcell[1], s1[0] | hcell[2], s1[1] | hcell[3]};
+        gbl_u8* base = (gbl_u8*)(reinterpret_cast<unsigned char*>(a.out[RR_L - 2]) + m0w * RR_G);
         asm volatile("" : "+s"(base));
         __builtin_nontemporal_store(cell, reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + gate_lane + 512 * pob));
       }
@@ -581,7 +601,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
       }
       if (ph == 3) {
         if constexpr (GATE) {
-          unsigned g = (v[j][0] > 0.f ? 0x38u : 0u) | (v[j][1] > 0.f ? 0x3800u : 0u) | (v[j][2] > 0.f ? 0x380000u : 0u) | (v[j][3] > 0.f ? 0x38000000u : 0u);
+          unsigned g = (v[j][0] > 0.f ? 0x80u : 0u) | (v[j][1] > 0.f ? 0x8000u : 0u) | (v[j][2] > 0.f ? 0x800000u : 0u) | (v[j][3] > 0.f ? 0x80000000u : 0u);
           if constexpr (RAG) g = keep3[j] != 0.f ? g : 0u;              // (padded rows: gate 0, like their mask bits)
           gd[j] = g;
         }
@@ -609,7 +629,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
       constexpr bool has_prev = sidx > 0;
       constexpr int pl = ob ? l : l - 1, pob = ob ? ob - 1 : 7;
       constexpr int cl = (sidx - 2) >> 3, cob = (sidx - 2) & 7;
-      constexpr bool has_co = !(ABL & 8) && STORE && sidx >= 2 && (cl < RR_L - 1 || ST3) && (!H8 || cl == RR_L - 1 || (cob & 1));
+      constexpr bool has_co = !(ABL & 8) && STORE && sidx >= 2 && (cl < RR_L - 1 || ST3) && (!H8 || cl == RR_L - 1 || (cob & 1)) && !(GATE && cl == RR_L - 2);
       constexpr int didx = sidx + F_LA;
       constexpr int dl = (didx >> 3) & 3, dob = didx & 7;
       constexpr int slot = ob & 3, nslot = (ob + 1) & 3, dslot = (ob + F_LA) & 3;
@@ -657,6 +677,11 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
             const int j = c / CPG, ph = c % CPG;
             if (pl == RR_L - 1) {
               if (ph < 4) epi3_group(pob, j, ph, v);
+              if (GATE && c < 4) {                                      // (H_2 block pob: complete since the last layer began)
+                const Frag& f = in[2 * pob + ((c & 3) >> 1)];
+                h2_stage(pob, c & 3, f[(c & 1) * 2], f[(c & 1) * 2 + 1]);
+              }
+              if (c == 6) h2_read(pob);
               if (j == 3 && ph == 3) gate_store(pob);
             } else if (CPG >= 4) {
               if (ph < 4) epi_group(pl, pob, j, ph, dst, pk);
@@ -691,6 +716,13 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
         for (int q = 0; q < 2; ++q) co_store(RR_L - 1, 6, q);
       }
       b3 = bias_s[(RR_L - 1) * RR_G + 32 * 7 + n];
+      if constexpr (GATE) {                                             // (constant indices: a loop here keeps the operand arrays out of registers)
+        h2_stage(7, 0, actB[14][0], actB[14][1]);
+        h2_stage(7, 1, actB[14][2], actB[14][3]);
+        h2_stage(7, 2, actB[15][0], actB[15][1]);
+        h2_stage(7, 3, actB[15][2], actB[15][3]);
+      }
+      h2_read(7);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         epi3_group(7, j, 0, v);
@@ -709,6 +741,11 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
         // area, idle since the last copy-out, and ONE row per tile leaves -- (M / 256, 256) instead of (M / 32, 256) for the
         // reduction launch behind this kernel.  Wave w adds feature block w in wave order (deterministic).
         float* const xs_s = reinterpret_cast<float*>(lds + RR_OFF_STG);
+        if constexpr (GATE) {                                           // (every wave has read its staged H_2 block back)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int ob = 0; ob < 8; ++ob) {
           const float tot = xs[ob] + __shfl_xor(xs[ob], 32);          // the two 16-row halves of this wave's 32 rows
@@ -1162,7 +1199,7 @@ static int rr_f16s_args(const char* who, RRArgsF& a, const void* const* Whi, con
 
 // The forward chain (f16s arithmetic, factored first layer): Xp16 = fp16 object rows (B*n [+ 1], 64).
 extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, int n, int njp, const void* const* Whi, const void* const* Wlo, int dither,
-                                           const float* const* bias, void* const* H, int h_dtype, void* const* mask, void* gate_image,
+                                           const float* const* bias, void* const* H, int h_dtype, void* const* mask, int gate_in_h2,
                                            float* xg_part, const float* Vq, int inject_layer, int M, int L, int G, void* stream) {
   RN_CHECK_ARG(Xp16 && Vc && Whi && Wlo && bias && M > 0 && xg_part, "rn_g_chain_fwd_rr_f16s_alg0: bad pointer/size");
   RN_CHECK_ARG(!H || h_dtype == RN_BF16 || h_dtype == RN_FP8, "rn_g_chain_fwd_rr_f16s_alg0: h_dtype must be RN_BF16 or RN_FP8 (got %d)", h_dtype);
@@ -1180,9 +1217,8 @@ extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, in
   if (int rc = rr_f16s_args("rn_g_chain_fwd_rr_f16s_alg0", a, Whi, Wlo, dither, bias, H, mask, &nh, &nm)) return rc;
   const bool h012 = nh == 3 && !a.out[RR_L - 1] && nm == RR_L;
   RN_CHECK_ARG((nh == 0 && nm == 0) || h012, "rn_g_chain_fwd_rr_f16s_alg0: H / masks: none (inference) or H_0..2 + all four masks (training)");
-  RN_CHECK_ARG(!gate_image || (h8 && h012 && (uintptr_t)gate_image % 16 == 0), "rn_g_chain_fwd_rr_f16s_alg0: the gate image goes with the e4m3 training output set");
-  a.gate = (unsigned char*)gate_image;
-  const bool gate = gate_image != nullptr;
+  RN_CHECK_ARG(!gate_in_h2 || (h8 && h012), "rn_g_chain_fwd_rr_f16s_alg0: the gate in the sign bits of H_2 goes with the e4m3 training output set");
+  const bool gate = gate_in_h2 != 0;
   const int ntiles = M / RR_TM;
   const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
   hipStream_t s = (hipStream_t)stream;

@@ -25,12 +25,14 @@
 //   db = dZ^T 1: one more MFMA against a tile of ones, spread evenly: of the 4 k-steps of a 64-row step each of the 4 waves
 //   that hold an n block (2 workgroups x 2 waves) takes one -- 4 partial rows per split, 18 instead of 16 MFMAs per wave.
 // GATE jobs -- the LAST layer's gradient is never stored: dZ_3[(b, pair), f] = gate_3 x dxg[b][f] (model.py:151-152: the pair sum
-//   broadcasts one row to all pairs of a question).  Its operand here is the gate itself as an e4m3 image of {0, 1}
-//   (rn_relu_gate_image expands the forward kernel's lane masks, 8 MB -> 67 MB, half of a stored bf16 dZ_3), multiplied with the
-//   e4m3 H_2 image on the fp8 matrix pipe (v_mfma_f32_32x32x16_fp8_fp8: products of {0, 1} and e4m3 values are exact, fp32
-//   accumulate, no conversions); the accumulators of a question are scaled by its dxg row -- in fp32, un-rounded -- when the
-//   question ends.  (Round 3, first version: the tile rebuilt inside this kernel from the masks -- 80 bit-test VALU
-//   instructions per wave and step beside 18 MFMAs: 75 us against 45 for a stored operand.)
+//   broadcasts one row to all pairs of a question).  The gate comes IN THE SIGN BITS of the e4m3 H_2 image (the forward chain
+//   writes byte (m, f) = e4m3(H_2[m, f]) | gate_3[m, f] << 7; post-ReLU bytes are never negative): ONE image is both operands.
+//   A fragment dword d becomes the gate operand (d >> 1) & 0x40404040 -- e4m3 {0, 2.0} -- or the activation operand
+//   d & 0x7f7f7f7f in the MFMA gaps of the half step before its use (3 VALU instructions per gap), both go to the fp8 matrix pipe
+//   (v_mfma_f32_32x32x16_fp8_fp8: products of {0, 2} and e4m3 values are exact, fp32 accumulate); the accumulators of a question
+//   are scaled by half its dxg row -- in fp32, un-rounded -- when the question ends.  (Round 3: a separate {0, 1} byte image of the
+//   gate, 67 MB written by the forward chain and read here for 8 MB of information; before that the tile rebuilt inside this
+//   kernel from the forward's lane masks -- 80 bit-test VALU instructions per wave and step beside 18 MFMAs: 75 us against 45.)
 // Same fp32 partial format and fixed-order reduction as the general kernel: bitwise deterministic.  Up to 4 jobs (the three
 // layers of a step) run as ONE launch + ONE reduction launch.
 #include "rn_common.h"
@@ -45,7 +47,7 @@ constexpr int KB_NT = 256, KB_NB = 4, KB_MAXJOBS = 4;
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 
 struct KbJob {
-  const unsigned char* dZ;      // blocked image: 16-bit dZ, or (gate != 0) the e4m3 {0, 1} gate
+  const unsigned char* dZ;      // blocked image: 16-bit dZ, or (gate != 0) the e4m3 image A itself (the gate = its sign bits)
   const unsigned char* A;       // blocked image of the layer's input
   const float* dxg;             // gate jobs: (M / rows_per_question, 256) fp32
   float* part;                  // [Z][256][256] fp32
@@ -172,7 +174,19 @@ __device__ __forceinline__ void kb_run(unsigned char* lds, const KbJob& jb_, int
     }
   };
 
-  f32x16 acc[2][2], acc_db[2];                            // Z8: the current question's sums (of gate x A, of the gate)
+  // gate jobs: dword 2 ab + hf of the 16-row cells of n block / k block ij -> the gate operand {0, 2.0} and the activation operand
+  auto gate_half = [&](KbFrag<Z8, A8>& f, int ab, int ij, int hf) {
+    if constexpr (Z8) {
+      unsigned z = f.dz[0][ij][2 * ab + hf], x = f.a[0][ij][2 * ab + hf];
+      z = (z >> 1) & 0x40404040u;
+      x &= 0x7f7f7f7fu;
+      asm volatile("" : "+v"(z), "+v"(x));                // (pinned like the conversions)
+      f.dz[0][ij][2 * ab + hf] = z;
+      f.a[0][ij][2 * ab + hf] = x;
+    }
+  };
+
+  f32x16 acc[2][2], acc_db[2];                            // Z8: the current question's sums (of 2 gate x A, of 2 gate)
   f32x16 tot[2][2], tot_db[2];                            // Z8: ... scaled by the question's dxg row and added up
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
@@ -208,10 +222,10 @@ __device__ __forceinline__ void kb_run(unsigned char* lds, const KbJob& jb_, int
           const int reg = 4 * g4 + r;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            tot[i][j][reg] += d[r] * acc[i][j][reg];
+            tot[i][j][reg] += (0.5f * d[r]) * acc[i][j][reg];
             acc[i][j][reg] = 0.f;
           }
-          tot_db[i][reg] += d[r] * acc_db[i][reg];
+          tot_db[i][reg] += (0.5f * d[r]) * acc_db[i][reg];
           acc_db[i][reg] = 0.f;
         }
       }
@@ -232,6 +246,8 @@ __device__ __forceinline__ void kb_run(unsigned char* lds, const KbJob& jb_, int
   for (int j = 0; j < 2; ++j) {
     conv_half(f0, 0, j, 0, bfc[j]);
     conv_half(f0, 0, j, 1, bfc[j]);
+    gate_half(f0, 0, j, 0);
+    gate_half(f0, 0, j, 1);
   }
 
   int slot = s0 % G::NSTG;
@@ -277,6 +293,7 @@ __device__ __forceinline__ void kb_run(unsigned char* lds, const KbJob& jb_, int
       {                                                   // the next half step's A operands: k block q / 2, half q % 2
         const int nh_ = (hh + 1) & 3, nR = nh_ >> 1, nab = nh_ & 1;
         if (!(ABL & 64)) conv_half(nR ? f1 : f0, nab, q >> 1, q & 1, bfn[q >> 1]);
+        if (!(ABL & 64)) gate_half(nR ? f1 : f0, nab, q >> 1, q & 1);
       }
       if (q == 3) {
         if (db_kk == hh) {
@@ -429,9 +446,10 @@ static int kb_launch(const void* const* dZ, const int* dz_dtype, const void* con
   float* part = (float*)ws;
   float* part_db = part + (size_t)njobs * Z * 256 * 256;
   for (int j = 0; j < njobs; ++j) {
-    RN_CHECK_ARG(dZ[j] && A[j] && dW[j], "rn_g_wgrad_blocked: job %d: dZ / A / dW is NULL", j);
+    RN_CHECK_ARG((dZ[j] || dz_dtype[j] == RN_FP8) && A[j] && dW[j], "rn_g_wgrad_blocked: job %d: dZ / A / dW is NULL", j);
     RN_CHECK_ARG(((uintptr_t)dZ[j] | (uintptr_t)A[j] | (uintptr_t)dW[j] | (uintptr_t)db[j]) % 16 == 0, "rn_g_wgrad_blocked: job %d: pointers must be 16-byte aligned", j);
-    RN_CHECK_ARG(dz_dtype[j] == RN_BF16 || dz_dtype[j] == RN_FP8, "rn_g_wgrad_blocked: job %d: dZ must be a bf16 image or an e4m3 gate image (dz_dtype=%d)", j, dz_dtype[j]);
+    RN_CHECK_ARG(dz_dtype[j] == RN_BF16 || dz_dtype[j] == RN_FP8, "rn_g_wgrad_blocked: job %d: dz_dtype must be RN_BF16 (a stored image) or RN_FP8 (gate job) (dz_dtype=%d)", j, dz_dtype[j]);
+    RN_CHECK_ARG(dz_dtype[j] != RN_FP8 || !dZ[j] || dZ[j] == A[j], "rn_g_wgrad_blocked: job %d is a gate job: its gate is the sign bits of A (dZ must be NULL or A)", j);
     a.job[j].dZ = (const unsigned char*)dZ[j];
     a.job[j].A = (const unsigned char*)A[j];
     a.job[j].part = part + (size_t)j * Z * 256 * 256;
@@ -439,7 +457,8 @@ static int kb_launch(const void* const* dZ, const int* dz_dtype, const void* con
     a.job[j].dW = dW[j];
     a.job[j].db = db[j];
     if (dz_dtype[j] == RN_FP8) {
-      RN_CHECK_ARG(a_dtype == RN_FP8, "rn_g_wgrad_blocked: job %d: a gate image goes with an e4m3 A image", j);
+      RN_CHECK_ARG(a_dtype == RN_FP8, "rn_g_wgrad_blocked: job %d: a gate job needs an e4m3 A image", j);
+      a.job[j].dZ = (const unsigned char*)A[j];
       RN_CHECK_ARG(dxg && (uintptr_t)dxg % 16 == 0, "rn_g_wgrad_blocked: job %d is a gate job: needs the 16-byte aligned dxg", j);
       RN_CHECK_ARG(rows_per_question > 0 && rows_per_question % 64 == 0 && M % rows_per_question == 0,
                    "rn_g_wgrad_blocked: gate job: rows_per_question=%d must be a multiple of 64 dividing M", rows_per_question);
@@ -481,10 +500,10 @@ extern "C" int rn_diag_wgrad_blocked(const void* const* dZ, const int* dz_dtype,
 }
 #endif
 
-// The ReLU gate of the last g layer as an e4m3 image of {0, 1} (byte 0x38 = 1.0): the forward kernel's layer-3 lane masks
-// (un-swapped epilogue: per 32-row block and 32-feature block 32 dwords, dword 2 (4 (r / 8) + r % 4) + (r / 4) % 2 = the 32
-// feature bits of row r) expanded to one byte per (row, feature) in the row-blocked layout.  A workgroup = one 32-row block,
-// a thread = one feature: 32 bit tests, two 16-byte stores (4 KB contiguous per workgroup and 16-row half).
+// The ReLU gate of the last g layer merged into the SIGN BITS of an e4m3 row-blocked image (tests / tools: the forward chain
+// writes H_2 that way itself): the forward kernel's layer-3 lane masks (un-swapped epilogue: per 32-row block and 32-feature block
+// 32 dwords, dword 2 (4 (r / 8) + r % 4) + (r / 4) % 2 = the 32 feature bits of row r) -> bit 7 of byte (row, feature).  A
+// workgroup = one 32-row block, a thread = one feature: 32 bit tests, two 16-byte read-modify-writes.
 __global__ __launch_bounds__(256) void relu_gate_image_kernel(const unsigned* __restrict__ mask, unsigned char* __restrict__ img) {
   const long wt = blockIdx.x;
   const int f = threadIdx.x, fb = f & 31;
@@ -502,11 +521,15 @@ __global__ __launch_bounds__(256) void relu_gate_image_kernel(const unsigned* __
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * p + e, d = 16 * hf + 8 * (r >> 3) + 2 * (r & 3) + ((r & 7) >> 2);
         const unsigned tbit = (unsigned)__builtin_amdgcn_sbfe((int)m[d >> 2][d & 3], fb, 1);
-        v |= tbit & (0x38u << (8 * e));
+        v |= tbit & (0x80u << (8 * e));
       }
       o[p] = v;
     }
-    __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(img + ((2 * wt + hf) * 256 + f) * 16));
+    u32x4* cell = reinterpret_cast<u32x4*>(img + ((2 * wt + hf) * 256 + f) * 16);
+    const u32x4 old = *cell;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) o[p] |= old[p] & 0x7f7f7f7fu;
+    *cell = o;
   }
 }
 
@@ -535,7 +558,7 @@ __global__ __launch_bounds__(256) void fp8_copy_health_kernel(const unsigned* __
     const u32x4 cell = *reinterpret_cast<const u32x4*>(img + ((2 * wt + hf) * 256 + f) * 16);     // rows 16 hf .. + 15 of feature f
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const unsigned byte = (cell[r >> 2] >> (8 * (r & 3))) & 0xffu, bit = (rowbits >> (16 * hf + r)) & 1u;
+      const unsigned byte = (cell[r >> 2] >> (8 * (r & 3))) & 0x7fu, bit = (rowbits >> (16 * hf + r)) & 1u;   // (bit 7 of H_2: the next layer's gate)
       pos += bit;
       flushed += bit & (byte == 0u ? 1u : 0u);
       sat += byte == 0x7eu ? 1u : 0u;

@@ -227,9 +227,9 @@ class RRMasks:
     """ReLU lane masks of the register-resident forward chain: what the backward pass keeps INSTEAD of the last
     activation (rn_g_chain_fwd_rr / rn_g_chain_bwd_rr)."""
 
-    def __init__(self, masks, gate=None):
+    def __init__(self, masks, gate=False):
         self.masks = masks
-        self.gate = gate          # the last layer's gate as an e4m3 {0, 1} row-blocked image, when the forward chain wrote it
+        self.gate = gate          # the forward chain wrote the last layer's gate into the sign bits of the e4m3 H_{L-2} image
 
 
 def padded_j(n):
@@ -304,13 +304,13 @@ def chain_forward(x, q, plan: LayerPlan, g_b, packed, keep, inj_w=None, coord=No
     Xp, Vc, Vq = _tables(x, q, plan, g_b, packed.w0T, inj_w, B, n, k, Q, G, coord)
     njp = n if inj_w is not None else padded_j(n)          # pair rows per (question, i) group: padded where n % 32 != 0
     Mp = B * n * njp
-    masks = Hs = gate = None
+    masks = Hs = None
+    gate = False
     if keep:
         Hs = [torch.empty(Mp, G, dtype=_h_copy_dtype(), device=dev) for l in range(L - 1)] + [None]
         masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(Mp), dtype=torch.uint8, device=dev))
-        if Hs[0].dtype in H.FP8_DTYPES and (n * njp) % 64 == 0:
-            # the operand of the last layer's weight-gradient gate job, written from the forward kernel's epilogue
-            gate = torch.empty(Mp, G, dtype=Hs[0].dtype, device=dev)
+        # the last layer's weight-gradient gate job reads the gate from the sign bits of the e4m3 H_{L-2} image
+        gate = Hs[0].dtype in H.FP8_DTYPES and (n * njp) % 64 == 0
     if njp != n:
         part = torch.empty(Mp // R * 2, G, dtype=torch.float32, device=dev)      # two partial rows per tile (it may straddle questions)
         H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, packed.frag_hi, packed.frag_lo[0], g_b, Hs, masks, part, Mp, G, njp=njp, gate=gate)
@@ -552,15 +552,14 @@ class RelationalFunction(torch.autograd.Function):
         B, n, k, Q, M, G = ctx.dims[:6]
         L, dev = plan.L, x.device
         f32 = dict(dtype=torch.float32, device=dev)
-        inputs, masks, gate_img, g_w = ctx.inputs, ctx.HL.masks, ctx.HL.gate, ctx.g_w
+        inputs, masks, gated, g_w = ctx.inputs, ctx.HL.masks, bool(ctx.HL.gate), ctx.g_w
         njp = ctx.njp                              # pair rows per (question, i) group: > n on the padded j axis
         Mc = B * n * njp                           # ... and the pair rows the chains / weight gradients work on
         inj = plan.inject > 0                      # the question entered at layer plan.inject as a per-question bias row
         dt = torch.bfloat16
         # the last layer's gradient dZ_{L-1} = gate x dxg[question] is never stored when the copies are e4m3: its only reader
-        # besides the chain itself, the layer's wgrad, multiplies the forward's gate image on the fp8 pipe (rn_g_wgrad_blocked);
+        # besides the chain itself, the layer's wgrad, takes the gate from the sign bits of its e4m3 input image (rn_g_wgrad_blocked);
         # layer 0's gradient is read by the pair-axis reductions only: formed inside the chain, dZ_0 never exists either
-        gated = gate_img is not None
         red_parts = None
         if gated:
             tpu = H.g_chain_bwd_rr_red_tpu(Mc, n) if (OPT.chain_reduce and njp == n) else 0
@@ -597,7 +596,7 @@ class RelationalFunction(torch.autograd.Function):
                 N_, kt_ = plan.widths[l], plan.ktrue[l]
                 gW[l] = grad_out(ctx.param_refs[l], (N_, kt_))
                 gB[l] = grad_out(ctx.param_refs[L + l], (N_,))
-                dz_l = dZ_of[l] if dZ_of[l] is not None else gate_img       # (the last layer without a stored gradient: its gate image)
+                dz_l = dZ_of[l]                                             # (None: the last layer without a stored gradient = a gate job)
                 if inj and l == plan.inject:
                     tmp = torch.empty(N_, plan.widths[l - 1], **f32)
                     jobs.append((dz_l, inputs[l], tmp, gB[l]))
@@ -621,7 +620,7 @@ class RelationalFunction(torch.autograd.Function):
         # re-joins at the end of the backward pass (engine callback).  Only when every parameter's .grad is None (assign, not
         # accumulate: autograd then launches no kernel on these tensors before the join).
         overlap = OPT.wgrad_overlap and all(_assign_only(p) for p in ctx.param_refs)
-        keep = [list(dZs), list(inputs), masks, gate_img, dxg]         # operands read on a side stream stay alive until the join
+        keep = [list(dZs), list(inputs), masks, dxg]         # operands read on a side stream stay alive until the join
         if overlap:
             main, side = torch.cuda.current_stream(), _side_stream(dev)
             side.wait_stream(main)

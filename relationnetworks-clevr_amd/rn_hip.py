@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librn_hip.so")
 RN_BF16, RN_F32, RN_F16, RN_FP8 = 0, 1, 2, 3
 RN_RELU, RN_ACCUMULATE = 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -31,7 +31,7 @@ SIGNATURES = {
     "rn_g_linear_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_rr_tile": (_I, []),
     "rn_pair_tables": (_I, [_P, _L, _L, _L, _P, _I, _P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
-    "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_g_chain_fwd_rr_f16s_alg0": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_sum_tiles": (_I, [_P, _P, _I, _I, _I, _P]),
     "rn_f_phi_fwd_from_partials": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -297,11 +297,11 @@ F16S_DITHER = 4      # tile-dithered hi images per g layer >= 1 (include/rn_hip.
 
 
 @_timed("g_fwd")
-def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlo0, biases, Hs, masks, xg_part, M, G, Vq=None, inject=0, njp=None, gate=None):
+def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlo0, biases, Hs, masks, xg_part, M, G, Vq=None, inject=0, njp=None, gate=False):
     """f16s forward chain with the factored first layer (fp16 object rows, no pair matrix).  Whis[0] / Wlo0: the hi / lo images of
     layer 0; Whis[1..3]: (dither, 65536) fp16 tile-dithered hi images each.  njp > n: padded j axis (M = B * n * njp, Xp16 with a
-    trailing zero row, two partial rows per tile in xg_part).  gate: (M * 256) e4m3 bytes receiving the last layer's gate image
-    (what relu_gate_image builds from masks[3]); with e4m3 Hs only."""
+    trailing zero row, two partial rows per tile in xg_part).  gate: the last layer's ReLU gate also goes into the sign bits of the
+    e4m3 Hs[2] image (what relu_gate_image merges from masks[3]) -- the operand of the gate job of g_wgrad_blocked."""
     L = len(Whis)
     dither = Whis[1].numel() // 65536
     hp = (C.c_void_p * L)(*[w.data_ptr() for w in Whis])
@@ -309,7 +309,7 @@ def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlo0, biases, Hs, masks, xg_part
     bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
     op = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None
-    _check(load().rn_g_chain_fwd_rr_f16s_alg0(Xp16.data_ptr(), Vc.data_ptr(), n, njp or n, hp, lp, dither, bp, op, _h_code(Hs), mp, _ptr(gate),
+    _check(load().rn_g_chain_fwd_rr_f16s_alg0(Xp16.data_ptr(), Vc.data_ptr(), n, njp or n, hp, lp, dither, bp, op, _h_code(Hs), mp, int(bool(gate)),
                                               xg_part.data_ptr(), _ptr(Vq), inject, M, L, G, _stream()), "rn_g_chain_fwd_rr_f16s_alg0")
 
 
@@ -402,9 +402,9 @@ def rows_to_blocked(src, back=False):
 
 
 @_timed("g_wgrad")
-def relu_gate_image(mask, M):
-    """Layer-3 lane masks of the forward chain -> the e4m3 {0, 1} row-blocked gate image (the dZ operand of a gate job)."""
-    img = torch.empty(M, 256, dtype=torch.float8_e4m3fn, device=mask.device)
+def relu_gate_image(mask, img, M):
+    """Layer-3 lane masks of the forward chain -> the sign bits of the e4m3 row-blocked image img (in place): the H_2 image of a
+    gate job, as the forward chain writes it with gate=True."""
     _check(load().rn_relu_gate_image(mask.data_ptr(), img.data_ptr(), M, _stream()), "rn_relu_gate_image")
     return img
 
@@ -412,7 +412,8 @@ def relu_gate_image(mask, M):
 @_timed("g_wgrad")
 def g_wgrad_blocked(jobs, M, dxg=None, rows_per_question=0, aligned=False, abl=0):
     """Weight gradients of the 256-wide g layers on the chains' row-blocked images, one launch for all `jobs`:
-    jobs = [(dZ, A, dW, db), ...]; a job whose dZ is an e4m3 image is a gate job (the last layer: gate image x dxg per question).
+    jobs = [(dZ, A, dW, db), ...]; a job whose dZ is None is a gate job (the last layer: the gate in the sign bits of its e4m3 A image
+    x dxg per question).
     aligned: question-aligned row splits (the db partials are then per-question sums of dZ).
     -> (ws, [db partials (Z, 4, 256) per job]): the workspace must stay alive while the partials are in use."""
     lib = load()
@@ -422,8 +423,8 @@ def g_wgrad_blocked(jobs, M, dxg=None, rows_per_question=0, aligned=False, abl=0
         raise RuntimeError("rn_g_wgrad_blocked: unsupported shape M=%d, %d jobs" % (M, nj))
     a8 = jobs[0][1].dtype in FP8_DTYPES
     ws = torch.empty(nb, dtype=torch.uint8, device=jobs[0][2].device)
-    zp = (C.c_void_p * nj)(*[j[0].data_ptr() for j in jobs])
-    zt = (C.c_int * nj)(*[(RN_FP8 if j[0].dtype in FP8_DTYPES else RN_BF16) for j in jobs])
+    zp = (C.c_void_p * nj)(*[(j[0].data_ptr() if j[0] is not None else None) for j in jobs])
+    zt = (C.c_int * nj)(*[(RN_FP8 if j[0] is None else RN_BF16) for j in jobs])
     ap = (C.c_void_p * nj)(*[j[1].data_ptr() for j in jobs])
     wp = (C.c_void_p * nj)(*[j[2].data_ptr() for j in jobs])
     bp = (C.c_void_p * nj)(*[j[3].data_ptr() for j in jobs])

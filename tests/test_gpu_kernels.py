@@ -441,20 +441,23 @@ def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
             assert same >= 0.97, (l, same)
             d = (Hs8[l].float() - HsA[l].float()).abs()
             assert bool((d <= HsA[l].float().abs() * 2.0 ** -4 + 2.0 ** -10).all()), l
-        # ... and with the last layer's gate image written from the epilogue: everything else bitwise as before, the image
-        # bitwise what rn_relu_gate_image builds from the layer's lane masks
+        # ... and with the last layer's gate in the sign bits of the H_2 image (written one layer late, from the last layer's
+        # epilogue): everything else bitwise as before, the image bitwise what rn_relu_gate_image merges into the plain H_2 image
         Hg = [torch.full((M, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [None]
         mg = list(torch.zeros(L, H.g_chain_rr_mask_bytes(M), dtype=torch.uint8, device="cuda"))
         pg = torch.full((M // 256, G), float("nan"), dtype=torch.float32, device="cuda")
-        gate = torch.full((M, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn)
-        H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, Hg, mg, pg, M, G, gate=gate)
+        H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, Hg, mg, pg, M, G, gate=True)
         torch.cuda.synchronize()
         assert torch.equal(pg, p8)
         for l in range(L):
             assert torch.equal(mg[l], m8[l]), l
-        for l in range(3):
+        for l in range(2):
             assert torch.equal(unblock(Hg[l]).view(torch.uint8), Hs8[l].view(torch.uint8)), l
-        assert torch.equal(gate.view(torch.uint8), H.relu_gate_image(m8[3], M).view(torch.uint8))
+        want = H.relu_gate_image(m8[3], H.rows_to_blocked(Hs8[2]), M)
+        torch.cuda.synchronize()
+        assert torch.equal(Hg[2].view(torch.uint8), want.view(torch.uint8))
+        assert torch.equal(unblock(Hg[2]).view(torch.uint8) & 0x7f, Hs8[2].view(torch.uint8))
+        assert torch.equal(unblock(Hg[2]).view(torch.uint8) >> 7, gate_image_ref(m8[3], M).to(torch.uint8))
 
 
 @pytest.mark.parametrize("B,n", [(16, 196), (4, 40)])
@@ -503,19 +506,26 @@ def test_g_chain_fwd_rr_f16s_alg0_padded(H, B, n):
         gA = torch.from_numpy(rr_mask_decode(mA[l], Mp, l))
         inval = gA.view(B * n, njp, G)[:, n:]
         assert not inval.any(), l                              # padded rows: gates cleared in every layer
-    # e4m3 copies + the last layer's gate image from the epilogue: the image is bitwise rn_relu_gate_image of the layer's masks
-    # (zero on the padded rows), the masks and pair sums those of the run above
+    # e4m3 copies with the last layer's gate in the sign bits of H_2: bitwise rn_relu_gate_image of the layer's masks merged into
+    # the plain e4m3 H_2 image (no gate on the padded rows), the masks and pair sums those of the run above
     H8 = [torch.full((Mp, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [None]
     m8 = list(torch.zeros(L, H.g_chain_rr_mask_bytes(Mp), dtype=torch.uint8, device="cuda"))
     p8 = torch.full_like(pA, float("nan"))
-    gate = torch.full((Mp, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn)
-    H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, H8, m8, p8, Mp, G, njp=njp, gate=gate)
+    H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, H8, m8, p8, Mp, G, njp=njp)
+    Hg = [torch.full((Mp, G), 0x7f, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn) for _ in range(3)] + [None]
+    mg = list(torch.zeros(L, H.g_chain_rr_mask_bytes(Mp), dtype=torch.uint8, device="cuda"))
+    pg = torch.full_like(pA, float("nan"))
+    H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, bd, Hg, mg, pg, Mp, G, njp=njp, gate=True)
     torch.cuda.synchronize()
-    assert torch.equal(p8, pA)
+    assert torch.equal(p8, pA) and torch.equal(pg, pA)
     for l in range(L):
-        assert torch.equal(m8[l], mA[l]), l
-    assert torch.equal(gate.view(torch.uint8), H.relu_gate_image(m8[3], Mp).view(torch.uint8))
-    assert not unblock(gate).view(torch.uint8).view(B * n, njp, G)[:, n:].any()
+        assert torch.equal(m8[l], mA[l]) and torch.equal(mg[l], mA[l]), l
+    for l in range(2):
+        assert torch.equal(Hg[l].view(torch.uint8), H8[l].view(torch.uint8)), l
+    want = H.relu_gate_image(m8[3], H8[2].clone(), Mp)
+    torch.cuda.synchronize()
+    assert torch.equal(Hg[2].view(torch.uint8), want.view(torch.uint8))
+    assert not (unblock(Hg[2]).view(torch.uint8) >> 7).view(B * n, njp, G)[:, n:].any()
 
 
 def gate_image_ref(mask, M):
@@ -527,17 +537,18 @@ def test_relu_gate_image(H):
     M = 32 * 77
     g = torch.Generator(device="cuda").manual_seed(3)
     mask = torch.randint(0, 256, (H.g_chain_rr_mask_bytes(M),), dtype=torch.uint8, device="cuda", generator=g)
-    img = H.relu_gate_image(mask, M)
+    base = torch.randint(0, 256, (M, 256), dtype=torch.uint8, device="cuda", generator=g)       # (stale sign bits are replaced)
+    img = H.relu_gate_image(mask, H.rows_to_blocked(base.view(torch.float8_e4m3fn)), M)
     torch.cuda.synchronize()
     got = unblock(img).view(torch.uint8)
-    assert torch.equal(got, gate_image_ref(mask, M).to(torch.uint8) * 0x38)
+    assert torch.equal(got, (base & 0x7f) | (gate_image_ref(mask, M).to(torch.uint8) << 7))
 
 
 @pytest.mark.parametrize("B,n", [(17, 64), (3, 64), (2, 32)])
 def test_wgrad_gated_and_bwd_skip0(H, B, n):
     """The last g layer without its gradient matrix: rn_g_chain_bwd_rr with dZ[0] = NULL must give the same dZ[1..3] as
     the full call; the stored dZ[0] image (row-blocked) = bf16(dxg) where the gate is set; and the GATE job of
-    rn_g_wgrad_blocked (gate image x e4m3 activations on the fp8 pipe, scaled by the un-rounded dxg per question) must give the
+    rn_g_wgrad_blocked (the gate in the sign bits of the e4m3 activation image, both on the fp8 pipe, scaled by the un-rounded dxg per question) must give the
     float64 product gate * dxg -- to fp32 accumulation accuracy, i.e. closer to the reference than the job on the stored,
     bf16-rounded dZ[0], which is checked against ITS float64 product.  B = 17: 272 tiles > 256 CUs, 34 question-aligned splits;
     B = 3: 48 splits; (2, 32): 32 steps in all -- fewer than the ring is deep, 16 steps per question."""
@@ -564,7 +575,7 @@ def test_wgrad_gated_and_bwd_skip0(H, B, n):
     dW0 = torch.full((G, G), float("nan"), device="cuda"); db0 = torch.full((G,), float("nan"), device="cuda")
     H.g_wgrad_blocked([(full[0], Ab, dW0, db0)], M, rows_per_question=n * n)
     dW1 = torch.full((G, G), float("nan"), device="cuda"); db1 = torch.full((G,), float("nan"), device="cuda")
-    H.g_wgrad_blocked([(H.relu_gate_image(masks[L - 1], M), Ab, dW1, db1)], M, dxg=dxg, rows_per_question=n * n)
+    H.g_wgrad_blocked([(None, H.relu_gate_image(masks[L - 1], Ab.clone(), M), dW1, db1)], M, dxg=dxg, rows_per_question=n * n)
     torch.cuda.synchronize()
     dz_stored = unblock(full[0]).double()
     dz_exact = dxg.double().repeat_interleave(n * n, 0) * gate
@@ -640,9 +651,10 @@ def test_wgrad_blocked_three_jobs(H, B, n, a8):
     mask = torch.randint(0, 256, (H.g_chain_rr_mask_bytes(M),), dtype=torch.uint8, device="cuda", generator=g)
     dxg = (torch.rand(B, G, device="cuda", generator=g) - 0.5)
     dZb = [H.rows_to_blocked(z) for z in dZ]
-    if a8:
-        dZb[2] = H.relu_gate_image(mask, M)
     Hb = [H.rows_to_blocked(h) for h in Hc]
+    if a8:
+        dZb[2] = None                                          # the gate job: gate = the sign bits of its activation image
+        H.relu_gate_image(mask, Hb[2], M)
     def run(sel, aligned=True):
         outs = [(torch.full((G, G), float("nan"), device="cuda"), torch.full((G,), float("nan"), device="cuda")) for _ in sel]
         ws, parts = H.g_wgrad_blocked([(dZb[j], Hb[j], o[0], o[1]) for j, o in zip(sel, outs)], M, dxg=dxg, rows_per_question=n * n, aligned=aligned)

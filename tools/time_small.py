@@ -25,9 +25,9 @@ Rj = torch.empty(B * n, G, device=dev); Ri = torch.empty(B * n, G, device=dev); 
 dx = torch.empty(B, n, k, device=dev); dq = torch.empty(B, Q, device=dev); dW0 = torch.empty(G, kt, device=dev); db0 = torch.empty(G, device=dev)
 gW = torch.empty(G, G, device=dev); gB = torch.empty(G, device=dev)
 masks = torch.randint(0, 255, (H.g_chain_rr_mask_bytes(M),), dtype=torch.uint8, device=dev)
-gate = H.relu_gate_image(masks, M); dZb = [H.rows_to_blocked(dZ) for _ in range(2)]; H8 = [H.rows_to_blocked(Hh) for _ in range(3)]
+dZb = [H.rows_to_blocked(dZ) for _ in range(2)]; H8 = [H.rows_to_blocked(Hh) for _ in range(3)]; H.relu_gate_image(masks, H8[2], M)
 gWs = [torch.empty(G, G, device=dev) for _ in range(3)]; gBs = [torch.empty(G, device=dev) for _ in range(3)]
-jobs = [(dZb[0], H8[0], gWs[0], gBs[0]), (dZb[1], H8[1], gWs[1], gBs[1]), (gate, H8[2], gWs[2], gBs[2])]
+jobs = [(dZb[0], H8[0], gWs[0], gBs[0]), (dZb[1], H8[1], gWs[1], gBs[1]), (None, H8[2], gWs[2], gBs[2])]
 part32 = torch.randn(M // 32 * (1 if n % 32 == 0 else 2), G, device=dev)
 rows = [
     ("pair_tables", lambda: H.pair_tables(x, q, w0T, b0, Xp, Vc, B, n, k, Q, G)),
@@ -37,7 +37,6 @@ rows = [
     ("pair_reduce_bwd (+finish)", lambda: H.pair_reduce_bwd(dZ, G, Rj, Ri, Rq, H.RN_BF16, B, n, G)),
     ("pair_dx_dq", lambda: H.pair_dx_dq(Rj, Ri, Rq, W0, dx, dq, B, n, k, Q, G)),
     ("wgrad0_from_reductions (part + finish)", lambda: H.wgrad0_from_reductions(Rj, Ri, Rq, x, q, dW0, db0)),
-    ("relu_gate_image (masks -> e4m3 {0,1} image)", lambda: H.relu_gate_image(masks, M)),
     ("g_wgrad_blocked, step's three jobs (2 stored + gate)", lambda: H.g_wgrad_blocked(jobs, M, dxg=dxg, rows_per_question=n * n)),
     ("pair_sum_tiles", lambda: H.pair_sum_tiles(part32, xg, M, n * n, G)),
 ]

@@ -25,31 +25,31 @@ def timeit(fn, n=15):
     return ts[len(ts) // 2]
 
 
+# (the kernel takes row-blocked images; random data: any bytes time the same)
 dZ = [((torch.rand(M, G, device="cuda") - 0.5) * 1e-2).bfloat16() for _ in range(3)]
 A16 = [(torch.rand(M, G, device="cuda") * 2).bfloat16() for _ in range(3)]
 A8 = [a.to(torch.float8_e4m3fn) for a in A16]
 mask = torch.randint(0, 256, (H.g_chain_rr_mask_bytes(M),), dtype=torch.uint8, device="cuda")
 dxg = torch.rand(B, G, device="cuda") - 0.5
 dW = [torch.empty(G, G, device="cuda") for _ in range(3)]; db = [torch.empty(G, device="cuda") for _ in range(3)]
-gate = H.relu_gate_image(mask, M)
+H.relu_gate_image(mask, A8[2], M)                          # the gate job's operand: the gate in the sign bits of its e4m3 image
 kw = dict(dxg=dxg, rows_per_question=n * n)
-us = timeit(lambda: H.relu_gate_image(mask, M))
-print("gate image (8 MB masks -> %d MB): %7.1f us" % (M * G / 1e6, us))
-for name, A, z3 in (("e4m3 A", A8, gate), ("bf16 A", A16, dZ[2])):
+for name, A, z3 in (("e4m3 A", A8, None), ("bf16 A", A16, dZ[2])):
     mb = (M * G * 2 + M * G * A[0].element_size()) / 1e6
     us = timeit(lambda: H.g_wgrad_blocked([(dZ[0], A[0], dW[0], db[0])], M, **kw))
     print("stored dZ, %s      : %7.1f us  (%.0f MB -> %.2f TB/s)" % (name, us, mb, mb / us))
-    mb = (M * G * z3.element_size() + M * G * A[0].element_size()) / 1e6
+    z3b = z3.element_size() if z3 is not None else 0
+    mb = (M * G * z3b + M * G * A[0].element_size()) / 1e6
     us = timeit(lambda: H.g_wgrad_blocked([(z3, A[2], dW[2], db[2])], M, **kw))
-    print("last layer (%s), %s: %7.1f us  (%.0f MB -> %.2f TB/s)" % ("gate job" if z3 is gate else "stored", name, us, mb, mb / us))
-    mb = (2 * M * G * 2 + M * G * z3.element_size() + 3 * M * G * A[0].element_size()) / 1e6
+    print("last layer (%s), %s: %7.1f us  (%.0f MB -> %.2f TB/s)" % ("gate job" if z3 is None else "stored", name, us, mb, mb / us))
+    mb = (2 * M * G * 2 + M * G * z3b + 3 * M * G * A[0].element_size()) / 1e6
     us = timeit(lambda: H.g_wgrad_blocked([(dZ[0], A[0], dW[0], db[0]), (dZ[1], A[1], dW[1], db[1]), (z3, A[2], dW[2], db[2])], M, **kw))
     print("three jobs, %s     : %7.1f us  (%.0f MB -> %.2f TB/s; 1.03e11 flop -> %.3f of 2.5 PF)" % (name, us, mb, mb / us, 3 * 2.0 * M * G * G / (us * 1e-6) / 2.5e15))
 us = timeit(lambda: H.g_linear_bwd_wgrad(dZ[0], G, A16[0], G, dW[0], db[0], 0, M, G, G, G))
 print("general row-major kernel: %7.1f us" % us)
 if os.environ.get("RN_DIAG", "0") == "1":
     for abl, what in ((1, "stream only"), (2, "compute only"), (3, "loop + barriers only"), (66, "compute only, no conversions"), (8, "no A frag reads"), (24, "no frag reads at all"), (10, "compute only, no A frag reads"), (26, "compute only, no frag reads")):
-        for name, jobs in (("stored, e4m3", [(dZ[0], A8[0], dW[0], db[0])]), ("gate job", [(gate, A8[2], dW[2], db[2])]),
-                           ("three jobs", [(dZ[0], A8[0], dW[0], db[0]), (dZ[1], A8[1], dW[1], db[1]), (gate, A8[2], dW[2], db[2])])):
+        for name, jobs in (("stored, e4m3", [(dZ[0], A8[0], dW[0], db[0])]), ("gate job", [(None, A8[2], dW[2], db[2])]),
+                           ("three jobs", [(dZ[0], A8[0], dW[0], db[0]), (dZ[1], A8[1], dW[1], db[1]), (None, A8[2], dW[2], db[2])])):
             us = timeit(lambda: H.g_wgrad_blocked(jobs, M, abl=abl, **kw))
             print("ABL %3d (%s) %s: %7.1f us" % (abl, what, name, us))
