@@ -672,7 +672,8 @@ class RelationalFunction(torch.autograd.Function):
             H.wgrad0_from_reductions(Rj, Ri, Rq, x, q if plan.inject == 0 else None, gW[0], gB[0], coord=ctx.coord)
         if overlap:
             # a stream of its own (measured on one box: on the weight-gradient stream 85.6, on the main stream behind dx / dq
-            # 87.0, here 87.9 k q/s); the weight-gradient stream waits for it, the end-of-backward join for that one
+            # 87.0, here 87.9 k q/s; forked behind the dx / dq launch instead of in front of it: -7 %); the weight-gradient
+            # stream waits for it, the end-of-backward join for that one
             s0 = _side_stream(dev, 2)
             s0.wait_stream(main)
             with torch.cuda.stream(s0):
