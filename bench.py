@@ -152,6 +152,14 @@ def parity_check(pkg, cfg, prec, hw=128):
                                      abs(float(np.linalg.norm(xt.grad.double().cpu().numpy())) - float(g["dx_norm"])) / float(g["dx_norm"])),
                        "dq_l2_rel": l2rel(qt.grad.cpu().numpy(), g["dq"]),
                        "bias_grads_l2_rel_max": max(l2rel(grads[k_[5:]], g[k_]) for k_ in g if k_.startswith("grad/"))}
+        if "dx" in g:
+            # per question: a ReLU network's gradient is discontinuous in the forward's rounding (a gate of f_phi that flips changes
+            # ONE question's dx / dq by percents: DESIGN section 4.4), so the whole-batch L2 figure above is dominated by the one or
+            # two such questions of the fixture; the median says what the arithmetic itself does
+            pq = lambda a, r: [l2rel(a[i], r[i]) for i in range(a.shape[0])]
+            ex, eq = pq(xt.grad.cpu().numpy(), g["dx"]), pq(qt.grad.cpu().numpy(), g["dq"])
+            out[tag_rl]["per_question"] = {"dx_l2_rel_median": float(np.median(ex)), "dx_l2_rel_max": float(np.max(ex)),
+                                           "dq_l2_rel_median": float(np.median(eq)), "dq_l2_rel_max": float(np.max(eq))}
         # the weight gradients (what the e4m3 activation copies touch): 64 sampled entries + the norm of every tensor the fixture
         # pins (gold.check_grads: max-norm relative error, worst of sample / norm)
         per = {}

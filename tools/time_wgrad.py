@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
 import relationnetworks_clevr_amd as pkg
 H = pkg.rn_hip
+if os.environ.get("RN_LIB"):                                # (a variant build: tools/dbg/variant_lib.sh)
+    H.LIB_PATH = os.path.abspath(os.environ["RN_LIB"])
 H.load()
 B, n, G = int(os.environ.get("B", 64)), int(os.environ.get("N_OBJ", 64)), 256
 M = B * n * n
@@ -48,7 +50,7 @@ for name, A, z3 in (("e4m3 A", A8, None), ("bf16 A", A16, dZ[2])):
 us = timeit(lambda: H.g_linear_bwd_wgrad(dZ[0], G, A16[0], G, dW[0], db[0], 0, M, G, G, G))
 print("general row-major kernel: %7.1f us" % us)
 if os.environ.get("RN_DIAG", "0") == "1":
-    for abl, what in ((1, "stream only"), (2, "compute only"), (3, "loop + barriers only"), (66, "compute only, no conversions"), (8, "no A frag reads"), (24, "no frag reads at all"), (10, "compute only, no A frag reads"), (26, "compute only, no frag reads")):
+    for abl, what in ((1, "stream only"), (257, "stream only, every step the same 4 steps' addresses (L2 hits)"), (513, "stream only, no second reader"), (2, "compute only"), (3, "loop + barriers only"), (66, "compute only, no conversions"), (8, "no A frag reads"), (24, "no frag reads at all"), (10, "compute only, no A frag reads"), (26, "compute only, no frag reads")):
         for name, jobs in (("stored, e4m3", [(dZ[0], A8[0], dW[0], db[0])]), ("gate job", [(None, A8[2], dW[2], db[2])]),
                            ("three jobs", [(dZ[0], A8[0], dW[0], db[0]), (dZ[1], A8[1], dW[1], db[1]), (None, A8[2], dW[2], db[2])])):
             us = timeit(lambda: H.g_wgrad_blocked(jobs, M, abl=abl, **kw))
