@@ -347,232 +347,6 @@ __device__ __forceinline__ void kb_run(unsigned char* lds, const KbJob& jb_, int
   }
 }
 
-// ================================================================================== register-streamed variant (round 4)
-// The same product with the operands pulled HBM -> REGISTERS: the row-blocked images hand a lane its MFMA operand in ONE 16-byte
-// global load (two 512-byte runs per instruction), so the LDS ring, its barriers and every ds_read can go.  What bounds the
-// stream is not the ring's depth but the number of CUs that pull (measured, tools/dbg/reg_stream_bench.hip: a CU sustains
-// ~19 GB/s of L2 MISSES whatever it keeps in flight -- 12 or 100 KB, LDS-DMA or register loads alike; 192 CUs = 3.6 TB/s,
-// 252 = 4.7), so the kernel's job is to hide ALL of its arithmetic under that stream.  With one ring per workgroup the four
-// waves met at a barrier every 64 rows and a wave that waited (for a request to issue, for a fragment) idled its matrix pipe
-// (three jobs alone: stream 138 us, arithmetic 126 us, together 178 us).  Here the four waves of a workgroup are independent:
-//   wave w takes the 32-row groups w, w + 4, .. of the workgroup's row range and accumulates the WHOLE 128 x 128 block over them
-//   (16 accumulators = 256 AGPRs); per group 8 + 4 loads (12 KB) feed 32 MFMAs; KR_D groups are in flight per wave;
-//   the four waves' blocks meet once, at the end, through LDS in a fixed order ((w0 + w2) + (w1 + w3)).
-// No operand byte crosses a CU twice, no LDS traffic in the loop, no barrier, no hand schedule.
-//   db: a lane adds up the 8 rows of its dZ fragments in fp32 (shift / mask + add: 16 VALU per fragment, only in the workgroups
-//   with kb == 0) -- no MFMA against a tile of ones, 4 accumulators instead of 64.
-//   GATE jobs: dZ_3 = gate_3 x dxg[b] is formed as a bf16 operand in registers -- the sign bit of an image byte is spread over a
-//   16-bit lane (v_perm_b32 + v_pk_ashrrev_i16) and ANDed with the packed bf16(dxg[b][n]) of the lane's feature: 3 VALU per
-//   dword, 96 per group beside 32 MFMAs.  dxg is rounded to bf16 here like every other dZ of this mode (the ring kernel scaled
-//   fp8-pipe accumulators by the fp32 dxg at question ends, which costs a second accumulator set: 512 registers at this tile).
-#ifndef KR_D
-#define KR_D 3            // 32-row groups in flight per wave (stored job: 48 VGPRs each)
-#endif
-#ifndef KR_ABL
-#define KR_ABL 0          // timing ablations (variant builds, wrong results): 1 = the stream alone, 2 = the arithmetic alone, 4 = no db sums
-#endif
-template <bool Z8>
-__device__ __forceinline__ void kr_run(unsigned char* lds, const KbJob& jb_, int S, int Z, int z, int nh, int kb, int rows_per_q) {
-  const int t = threadIdx.x, lane = t & 63, n = lane & 31, h = lane >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int s0 = __builtin_amdgcn_readfirstlane((int)((long)z * S / Z)), s1 = __builtin_amdgcn_readfirstlane((int)((long)(z + 1) * S / Z));
-  const int g_end = 2 * s1;
-  KbJob jb = jb_;
-  asm volatile("" : "+s"(jb.dZ), "+s"(jb.A), "+s"(jb.dxg));
-  constexpr int NZ = Z8 ? 4 : 8;
-  const int gpq = rows_per_q >= 32 ? rows_per_q / 32 : 1;   // groups per question
-  struct Grp { u32x4 z[NZ]; u32x4 a[4]; float x[Z8 ? 4 : 1]; };   // x: gate jobs, dxg[question of the group][the lane's 4 features]
-  // lane parts of the addresses (bytes): dZ bf16 image: 8-row block 4 g + q + 2 h; e4m3 images: 16-row block 2 g + h
-  const unsigned zlane = (unsigned)((((Z8 ? h : 2 * h) * 256) + nh * 128 + n) * 16);
-  const unsigned alane = (unsigned)(((h * 256) + kb * 128 + n) * 16);
-  // (address space 1 spelled out: through the by-value job struct the pointers are generic, and a FLAT load counts on lgkmcnt
-  // too -- every wait would be a full drain)
-  typedef __attribute__((address_space(1))) const unsigned char gcu8;
-  typedef __attribute__((address_space(1))) const u32x4 gfrag;
-  gcu8* const zimg = (gcu8*)jb.dZ;
-  gcu8* const aimg = (gcu8*)jb.A;
-  auto load_group = [&](int g, Grp& b) {
-    gcu8* zb = zimg + (long)g * (Z8 ? 2 : 4) * 256 * 16;
-    gcu8* ab = aimg + (long)g * 2 * 256 * 16;
-    if constexpr (Z8) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) b.z[i] = *reinterpret_cast<gfrag*>(zb + zlane + 32 * i * 16);
-    } else {
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) b.z[4 * q + i] = *reinterpret_cast<gfrag*>(zb + zlane + (q * 256 + 32 * i) * 16);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b.a[j] = *reinterpret_cast<gfrag*>(ab + alane + 32 * j * 16);
-    if constexpr (Z8) {
-      // every group fetches its question's dxg values (512 B per wave, L2 hits): a load issued only where the question changes
-      // would make the number of requests in flight path-dependent, and the compiler then waits for ALL of them at every use
-      const int q = g / gpq;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) b.x[i] = ((__attribute__((address_space(1))) const float*)jb.dxg)[(long)q * 256 + nh * 128 + 32 * i + n];
-    }
-  };
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  float dbs[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool do_db = kb == 0 && !(KR_ABL & 4);
-  // gate jobs: the packed bf16 (dxg, dxg) of the lane's feature in each n block, for the question of the current group
-  unsigned xx[4] = {0u, 0u, 0u, 0u};
-  auto compute_group = [&](Grp& b) {
-    if constexpr (Z8) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bf16x2 p = {(bf16)b.x[i], (bf16)b.x[i]};
-        xx[i] = __builtin_bit_cast(unsigned, p);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {                           // MFMA a (rows {0..7} u {16..23} of the group) / b (the rest)
-      u32x4 bfa[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        unsigned d0 = b.a[j][2 * q], d1 = b.a[j][2 * q + 1];
-        if constexpr (Z8) { d0 &= 0x7f7f7f7fu; d1 &= 0x7f7f7f7fu; }       // (the gate lives in the sign bits)
-        bfa[j][0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, RN_H8_SCALE, false));
-        bfa[j][1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, RN_H8_SCALE, true));
-        bfa[j][2] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, RN_H8_SCALE, false));
-        bfa[j][3] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, RN_H8_SCALE, true));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        u32x4 dz;
-        if constexpr (Z8) {
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const unsigned d = b.z[i][2 * q + c];
-            const rn_s16x2 m0 = __builtin_bit_cast(rn_s16x2, __builtin_amdgcn_perm(d, d, 0x01010000u)) >> 15;
-            const rn_s16x2 m1 = __builtin_bit_cast(rn_s16x2, __builtin_amdgcn_perm(d, d, 0x03030202u)) >> 15;
-            dz[2 * c] = __builtin_bit_cast(unsigned, m0) & xx[i];
-            dz[2 * c + 1] = __builtin_bit_cast(unsigned, m1) & xx[i];
-          }
-        } else {
-          dz = b.z[4 * q + i];
-        }
-        if (do_db) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) dbs[i] += __builtin_bit_cast(float, dz[c] << 16) + __builtin_bit_cast(float, dz[c] & 0xffff0000u);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dz), __builtin_bit_cast(bf16x8, bfa[j]), acc[i][j], 0, 0, 0);
-      }
-    }
-  };
-  // ---- the loop: KR_D groups in flight; buffer d holds group g + 4 d of the current round
-  // (every load is issued unconditionally -- past the end, the wave's last group again -- so that the request count is the same on
-  // every path and the compiler's vmcnt waits stay counted: the wait in front of a group leaves the younger KR_D - 1 groups in flight)
-  Grp buf[KR_D];
-  int g = 2 * s0 + w;
-  const int ngrp = g < g_end ? (g_end - 1 - g) / 4 + 1 : 0;  // groups of this wave (0: a one-step range leaves waves 2, 3 without)
-  const int g_last = ngrp ? g + 4 * (ngrp - 1) : 2 * s0;
-#pragma unroll
-  for (int d = 0; d < KR_D; ++d) {
-    load_group(min(g + 4 * d, g_last), buf[d]);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  const int nround = ngrp / KR_D, ntail = ngrp - nround * KR_D;
-  for (int r = 0; r < nround; ++r) {                        // whole rounds: no branch inside (the waits stay counted)
-#pragma unroll
-    for (int d = 0; d < KR_D; ++d) {
-      // (fenced: the machine scheduler otherwise reorders the requests of different groups, and a wait for "the oldest group"
-      // then has to wait for nearly everything)
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(KR_ABL & 1)) compute_group(buf[d]);
-      else asm volatile("" ::"v"(buf[d].z[0]), "v"(buf[d].z[NZ - 1]), "v"(buf[d].a[0]), "v"(buf[d].a[3]));
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(KR_ABL & 2)) load_group(min(g + 4 * (d + KR_D), g_last), buf[d]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    g += 4 * KR_D;
-  }
-#pragma unroll
-  for (int d = 0; d < KR_D - 1; ++d)                        // the last ntail < KR_D groups: already requested
-    if (d < ntail) compute_group(buf[d]);
-  // ---- the four waves' blocks: (w0 + w2) + (w1 + w3) through LDS (two 64-KB buffers; element e of lane l at (e * 64 + l))
-  float* red = reinterpret_cast<float*>(lds);
-  auto red_write = [&](int bufi) {
-    float* r = red + bufi * (256 * 64) + lane;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) r[((i * 4 + j) * 16 + e) * 64] = acc[i][j][e];
-        __builtin_amdgcn_sched_barrier(0);                 // (one block at a time: the accumulators come out of AGPRs in batches of 16)
-      }
-  };
-  auto red_add = [&](int bufi) {
-    const float* r = red + bufi * (256 * 64) + lane;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] += r[((i * 4 + j) * 16 + e) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-  };
-  float* dbr = red + 2 * 256 * 64;                          // db partial sums: [wave][half][n block][32]
-  if (do_db) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dbr[((w * 2 + h) * 4 + i) * 32 + n] = dbs[i];
-  }
-  if (w >= 2) red_write(w - 2);
-  __syncthreads();
-  if (w < 2) red_add(w);
-  __syncthreads();
-  if (w == 1) red_write(0);
-  __syncthreads();
-  if (w == 0) {
-    red_add(0);
-    float* pz = jb.part + (long)z * 256 * 256;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int kcol = kb * 128 + j * 32 + n;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int nrow = nh * 128 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-          pz[(long)nrow * 256 + kcol] = acc[i][j][reg];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-  }
-  if (do_db && t < 128) {                                   // thread t: feature nh 128 + t; the 8 (wave, half) partials in a fixed order
-    float v = 0.f;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) v += dbr[(p * 4 + (t >> 5)) * 32 + (t & 31)];
-    float* pd = jb.part_db + (long)z * 4 * 256;
-    pd[nh * 128 + t] = v;                                   // (row 0 of the split's four partial rows; the ring kernel fills all four)
-    pd[256 + nh * 128 + t] = 0.f;
-    pd[512 + nh * 128 + t] = 0.f;
-    pd[768 + nh * 128 + t] = 0.f;
-  }
-}
-
-__global__ __launch_bounds__(KB_NT) void wgrad_regstream_kernel(KbArgs a, int rows_per_q) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 256 * 64 * 4 + 8 * 4 * 32 * 4];
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int blk = slot % KB_NB, u = (slot / KB_NB) * 8 + xcd;
-  if (u >= a.njobs * a.Z) return;
-  const int job = u % a.njobs, z = u / a.njobs;
-  const KbJob& jb = a.job[job];
-  if (jb.gate) kr_run<true>(lds, jb, a.S, a.Z, z, blk & 1, blk >> 1, rows_per_q);
-  else kr_run<false>(lds, jb, a.S, a.Z, z, blk & 1, blk >> 1, rows_per_q);
-}
-
 template <bool A8, int ABL = 0>
 __global__ __launch_bounds__(KB_NT, KB_OCC) void wgrad_blocked_kernel(KbArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[kb_lds_bytes<A8>()];
@@ -712,11 +486,11 @@ static int kb_launch(const void* const* dZ, const int* dz_dtype, const void* con
   (void)abl;
   {
 #endif
-#ifndef RN_WGRAD_REG
-#define RN_WGRAD_REG 1
+#ifdef KB_FORCE_ABL                                         // (variant builds: what would the step cost with this launch ablated?)
+    if (a_dtype == RN_FP8) wgrad_blocked_kernel<true, KB_FORCE_ABL><<<grid, KB_NT, 0, s>>>(a);
+    else
 #endif
-    if (a_dtype == RN_FP8 && RN_WGRAD_REG) wgrad_regstream_kernel<<<grid, KB_NT, 0, s>>>(a, rows_per_question > 0 ? rows_per_question : 32);
-    else if (a_dtype == RN_FP8) wgrad_blocked_kernel<true><<<grid, KB_NT, 0, s>>>(a);
+    if (a_dtype == RN_FP8) wgrad_blocked_kernel<true><<<grid, KB_NT, 0, s>>>(a);
     else wgrad_blocked_kernel<false><<<grid, KB_NT, 0, s>>>(a);
   }
   RN_LAUNCH_CHECK("rn_g_wgrad_blocked");

@@ -136,6 +136,14 @@ def test_relational_layer_f16s_parity(pkg, tag):
     # whose pre-activation is rounding noise.  Measured dx / dq 1.4e-2 / 1.2e-2 on G-fp64 (two passes on every layer: 4.7e-3 /
     # 2.9e-3; the bf16 mode: up to 1.2e-1, BF16_GRAD_L2) -- noise, not bias: test_training_trajectory pins the consequence.
     assert e_dx <= 2e-2 and e_dq <= 2e-2 and e_b <= 1.2e-2, (e_dx, e_dq, e_b)
+    if g["dx"].shape[0] >= 32:
+        # per QUESTION (tools/dbg/grad_error_split.py): the whole-batch figures above are carried by the one or two
+        # questions in which an f_phi ReLU flips (8 - 13 % on G-fp64: one unit of a 256-wide layer); the median is what the arithmetic
+        # does -- flipped g_theta gates ~9e-3 on dx, the bf16 backward chain ~3e-3 on both
+        pq = lambda a, r: np.array([l2rel(a[i], r[i]) for i in range(a.shape[0])])
+        mx, mq = float(np.median(pq(dx, g["dx"]))), float(np.median(pq(dq, g["dq"])))
+        report(tag, precision="f16s", dx_l2_median_per_question=mx, dq_l2_median_per_question=mq)
+        assert mx <= 1.5e-2 and mq <= 6e-3, (mx, mq)
 
 
 @pytest.mark.parametrize("tag", ["G-fp64", "G-fp-small", "G-drop", "G-ir64", "G-ir-small", "G-sd4", "G-irsd4", "G-fp196"])
