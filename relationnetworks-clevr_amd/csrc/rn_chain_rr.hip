@@ -46,6 +46,18 @@ typedef __attribute__((ext_vector_type(2))) short s16x2;
 
 typedef unsigned long long u64;
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
+// the copies that leave for the weight gradient are written once and read once, half a step later: non-temporal stores keep them
+// from walking the other kernels' lines out of L2 / the Infinity Cache (variant builds: -DRR_FWD_STORE_T / -DRR_BWD_STORE_T = plain)
+#ifdef RR_FWD_STORE_T
+#define RR_FWD_STORE(v, p) (*(p) = (v))
+#else
+#define RR_FWD_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
+#ifdef RR_BWD_STORE_T
+#define RR_BWD_STORE(v, p) (*(p) = (v))
+#else
+#define RR_BWD_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
 typedef __attribute__((address_space(3))) const Frag lds_frag;
 
 struct RRBwdArgs {                                      // the per-layer buffers are equally spaced (checked on the host):
@@ -557,12 +569,12 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
         gbl_u8* baseb = (gbl_u8*)(reinterpret_cast<unsigned char*>(a.out[cl]) + m0w * RR_G * (H8 ? 1 : 2));
         asm volatile("" : "+s"(baseb));
         const unsigned off = H8 ? co_off_blk8(lane, cob, q) : co_off_blk16(lane, cob, q);
-        __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(baseb + off));
+        RR_FWD_STORE(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(baseb + off));
         return;
       }
       gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.out[cl] + m0w * RR_G);
       asm volatile("" : "+s"(base));
-      __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2));
+      RR_FWD_STORE(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2));
     };
     float b3 = 0.f;
     unsigned gd[4];                                                    // GATE: the lane's four gate bytes of accumulator group j
@@ -591,7 +603,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
         const u32x4 cell = {s0[0] | hcell[0], s0[1] | hcell[1], s1[0] | hcell[2], s1[1] | hcell[3]};
         gbl_u8* base = (gbl_u8*)(reinterpret_cast<unsigned char*>(a.out[RR_L - 2]) + m0w * RR_G);
         asm volatile("" : "+s"(base));
-        __builtin_nontemporal_store(cell, reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + gate_lane + 512 * pob));
+        RR_FWD_STORE(cell, reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + gate_lane + 512 * pob));
       }
     };
     auto epi3_group = [&](int pob, int j, int ph, f32x4 (&v)[4]) {
@@ -913,13 +925,13 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
       gbl_u8* base = (gbl_u8*)reinterpret_cast<unsigned char*>(a.dZ + zi * a.dz_stride + ((ABL & 32) ? (long)(blockIdx.x * RR_TM + RR_WR * w) : m0w) * RR_G);
       asm volatile("" : "+s"(base));
       if (zi < NS) {
-        __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + co_off_blk16(lane, cob, q)));
+        RR_BWD_STORE(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + co_off_blk16(lane, cob, q)));
         return;
       }
       // non-temporal: these rows are read back by ANOTHER kernel much later; allocated in L2 they only evict the
       // weight images that every workgroup re-reads for every tile (measured: 222 -> 150 us)
       if (ABL & 64) *reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2) = co[q];
-      else __builtin_nontemporal_store(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2));
+      else RR_BWD_STORE(co[q], reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + orow_off + (16 * q * RR_G + 32 * cob) * 2));
     };
     // ---- RED: epilogue of block pob of the LAST step (accumulator D[row 8 j + 4 h + r][feature 32 pob + n]), group j, phase ph
     unsigned rb = 0;

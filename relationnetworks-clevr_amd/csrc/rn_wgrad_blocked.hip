@@ -81,7 +81,14 @@ template <bool A8> constexpr int kb_lds_bytes() {
 
 __device__ __forceinline__ void kb_dma(const unsigned char* uniform_src, unsigned lane_off, unsigned lds_dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+  // NON-TEMPORAL requests: the launch streams 470 MB beside the latency-bound kernels that close the backward pass; with the default
+  // policy it walks their working set out of the XCD's L2 and the Infinity Cache (the step with this launch's requests ablated:
+  // 0.62 ms instead of 0.73 -- its arithmetic costs the step nothing, its stream 100 us).  nt: -2.5 % on the step, the launch
+  // alone unchanged (176 vs 178 us; the partner workgroup's second read of a line still hits).
+#ifndef KB_DMA_POLICY
+#define KB_DMA_POLICY " nt"    // (variant builds: "", " sc1", " sc1 nt", ..)
+#endif
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" KB_DMA_POLICY "\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(lane_off), "s"(uniform_src), "s"(lds_dst)
                : "memory");
