@@ -161,6 +161,7 @@ class PackedWeights:
 
 
 _SIDE_STREAMS = {}
+_EXP = {"wgrad_late": 1, "conv_wgrad_stream": 2}      # scheduling knobs (tools/dbg/exp_bench.py flips them for A/B runs)
 
 
 def _side_stream(dev, which=0):
@@ -621,13 +622,23 @@ class RelationalFunction(torch.autograd.Function):
         # accumulate: autograd then launches no kernel on these tensors before the join).
         overlap = OPT.wgrad_overlap and all(_assign_only(p) for p in ctx.param_refs)
         keep = [list(dZs), list(inputs), masks, dxg]         # operands read on a side stream stay alive until the join
+        # WHEN the launch starts (round 4): its 470-MB stream is what it costs the step (the step with its requests ablated: 0.62 ms
+        # instead of 0.70; with its arithmetic ablated: unchanged), and the first kernels behind the backward chain -- the partial
+        # sums, dx / dq, the layer-0 weight gradient -- are one or two memory round trips each: 7 + 18 | 21 us alone, 18 + 71 | 66 us
+        # beside the stream.  So the launch waits for the partial sums and the layer-0 weight gradient (its stream's join, below)
+        # and dx reaches the conv stack's backward ~60 us earlier: +1..1.6 % q/s together with the conv weight gradients moved to the
+        # layer-0 stream (they no longer queue behind this launch).  Behind dx / dq as well: -11 %; behind the partial sums ONLY
+        # (the layer-0 stream joined after the launch): -12..-16 % -- the captured graph's queue order, not arithmetic
+        # (tools/dbg/exp_bench.py wgrad_late=2 | 3).  The question-injected models need the launch's per-question sums for dq: early.
+        late = overlap and _EXP["wgrad_late"] and not rq_splits
         if overlap:
             main, side = torch.cuda.current_stream(), _side_stream(dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                _wgrads_blocked()
-                if rq_splits:
-                    inj_out["event"] = side.record_event()
+            if not late:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    _wgrads_blocked()
+                    if rq_splits:
+                        inj_out["event"] = side.record_event()
 
             def _join():
                 torch.cuda.current_stream().wait_stream(side)
@@ -663,6 +674,8 @@ class RelationalFunction(torch.autograd.Function):
             H.pair_reduce_parts(red_parts[0], red_parts[1], Rj, Ri, Rq, B, n, N, red_parts[2])
         else:
             H.pair_reduce_bwd(dZ_of[0], N, Rj, Ri, Rq, H.RN_BF16, B, n, N, njp=njp)
+        if late:
+            late_ev = torch.cuda.current_stream().record_event()
 
         def _wgrad0():
             # dW_0 = [Rj^T X | Ri^T X | Rq^T Q], db_0 = sum_b Rq: three tiny products on (B*n)-row matrices instead of a 235 MB pass
@@ -678,7 +691,8 @@ class RelationalFunction(torch.autograd.Function):
             s0.wait_stream(main)
             with torch.cuda.stream(s0):
                 _wgrad0()
-            side.wait_stream(s0)
+            if not (late and _EXP["wgrad_late"] == 3):
+                side.wait_stream(s0)
             # x and q too: they are alive only through this node's saved tensors, which autograd releases as soon as
             # backward() returns -- the caching allocator would hand their blocks to the conv / LSTM backward that the
             # main stream runs next while this side-stream kernel still reads them (seen as a wrong dW_0 on a busy GPU)
@@ -696,6 +710,15 @@ class RelationalFunction(torch.autograd.Function):
             H.pair_dx_dq(Rj, Ri, Rq, wl, dx, dq, B, n, k, Q, N)                    # dx and dq in one launch
         else:
             H.pair_dx_dq(Rj, Ri, None, wl, dx, None, B, n, k, 0, N)                # (dq came from the injected layer)
+        if late:
+            if _EXP["wgrad_late"] == 2:
+                side.wait_stream(main)                             # behind dx / dq
+            else:
+                side.wait_event(late_ev)                           # behind the partial sums only
+            with torch.cuda.stream(side):
+                _wgrads_blocked()
+            if _EXP["wgrad_late"] == 3:
+                side.wait_stream(s0)
         if rq_splits:
             dq = inj_out["dq"]
             if "event" in inj_out:                                 # produced on the wgrad stream
@@ -856,10 +879,12 @@ class ConvBNReLUFunction(torch.autograd.Function):
             # next layers' backward; the main stream re-joins at the end of the backward pass
             # Captured order and stream matter here (tools/step_timeline.py, same box): the input gradient is launched FIRST and the
             # weight gradient forks off the event recorded before it -- with the fork in front, every bwd_data launch of the
-            # captured step started 10-18 us late -- and the weight gradients share the g_theta weight-gradient stream instead of a
+            # captured step started 10-18 us late -- and the weight gradients share a side stream that exists already instead of a
             # stream of their own: the ROCm graph executor maps the capture's streams onto 4 hardware queues, and a fourth side
             # stream ended up behind another one's kernels (the LSTM backward then started 100 us late).  Together -2.5 % on the step.
-            main, side = torch.cuda.current_stream(), _side_stream(dx.device, 0)
+            # Which one (round 4): the layer-0 weight gradient's (idle by now), not the g_theta weight gradient's -- behind that
+            # 180-us launch the first of these started ~55 us after its operands were ready.
+            main, side = torch.cuda.current_stream(), _side_stream(dx.device, _EXP["conv_wgrad_stream"])
             ev = main.record_event()
             if ctx.direct and inp.shape[1] == 24:
                 din = torch.empty_like(inp)
