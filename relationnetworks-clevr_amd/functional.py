@@ -630,7 +630,7 @@ class RelationalFunction(torch.autograd.Function):
         # layer-0 stream (they no longer queue behind this launch).  Behind dx / dq as well: -11 %; behind the partial sums ONLY
         # (the layer-0 stream joined after the launch): -12..-16 % -- the captured graph's queue order, not arithmetic
         # (tools/dbg/exp_bench.py wgrad_late=2 | 3).  The question-injected models need the launch's per-question sums for dq: early.
-        late = overlap and _EXP["wgrad_late"] and not rq_splits
+        late = overlap and _EXP["wgrad_late"] and not inj
         if overlap:
             main, side = torch.cuda.current_stream(), _side_stream(dev)
             if not late:
