@@ -1251,7 +1251,7 @@ extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, in
     if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n);
 #ifdef RN_DIAG
 #define RN_ABL(v) else if (h8 && g_diag_abl == v) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, true, v><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n);
-    RN_ABL(1) RN_ABL(2) RN_ABL(4) RN_ABL(6) RN_ABL(8) RN_ABL(16) RN_ABL(24) RN_ABL(64)
+    RN_ABL(1) RN_ABL(2) RN_ABL(4) RN_ABL(6) RN_ABL(8) RN_ABL(16) RN_ABL(24) RN_ABL(64) RN_ABL(32) RN_ABL(96) RN_ABL(102) RN_ABL(88)
 #undef RN_ABL
 #endif
     else if (h8 && gate) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, true, 0, false, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n);

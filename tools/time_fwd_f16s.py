@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
 import relationnetworks_clevr_amd as pkg
 H = pkg.rn_hip
+if os.environ.get("RN_LIB"):
+    H.LIB_PATH = os.path.abspath(os.environ["RN_LIB"])
 lib = H.load()
 B, n, L, G, k, Q = 64, 64, 4, 256, 26, 128
 M, kt = B * n * n, 2 * 26 + 128
@@ -57,7 +59,8 @@ flops = 2.0 * M * G * (kt + 3 * G)
 variants = {"baseline": (lambda: None, run)}
 if os.environ.get("RN_DIAG", "0") == "1":
     names = {1: "no bias rows", 2: "no barriers", 4: "no weight-stream waits", 6: "no barriers, no waits", 8: "no copy-out", 16: "no mask stores", 24: "no copy-out, no mask stores",
-             64: "no weight requests"}
+             64: "no weight requests", 32: "no epilogue at all (MFMAs + weight stream + fragment reads)", 96: "no epilogue, no weight requests", 88: "no copy-out, no mask stores, no weight requests",
+             102: "MFMAs + fragment reads only (no epilogue, requests, barriers, waits)"}
     for abl, what in names.items():
         variants["ABL %3d (%s)" % (abl, what)] = ((lambda a=abl: lib.rn_diag_set_abl(a)), run)
     variants["baseline again"] = (lambda: lib.rn_diag_set_abl(0), run)
