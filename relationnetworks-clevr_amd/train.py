@@ -36,15 +36,25 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 # ------------------------------------------------------------------------------------------ data
-def load_tensor_data(batch, device, invert_questions=True):
+def load_tensor_data(batch, device, invert_questions=True, out=None):
     """utils.py:133-150: optionally reverse the token order of every question (padding zeros end up
-    FIRST, quirk C5), move to the device, turn the 1-based answer indices (B,1) into 0-based (B,)."""
+    FIRST, quirk C5), move to the device, turn the 1-based answer indices (B,1) into 0-based (B,).
+    out = (img, qst, label) device tensors (DataParallelTrainer.input_buffers): the host -> device copies land THERE when the
+    batch has their shapes and dtypes -- the step then needs no device-to-device hand-off copy -- and `out` is returned."""
     qst = batch["question"]
     if invert_questions:
         qst = torch.flip(qst, dims=[1])
-    img = batch["image"].to(device, non_blocking=True)
+    img, ans = batch["image"], batch["answer"]
+    if out is not None and all(torch.is_tensor(t) for t in out):
+        o_img, o_qst, o_lab = out
+        lab = ans.reshape(-1) - 1                               # (on the host: B integers)
+        if (img.shape == o_img.shape and img.dtype == o_img.dtype and qst.shape == o_qst.shape and qst.dtype == o_qst.dtype
+                and lab.shape == o_lab.shape and lab.dtype == o_lab.dtype):
+            o_img.copy_(img, non_blocking=True); o_qst.copy_(qst, non_blocking=True); o_lab.copy_(lab, non_blocking=True)
+            return o_img, o_qst, o_lab
+    img = img.to(device, non_blocking=True)
     qst = qst.to(device, non_blocking=True)
-    label = (batch["answer"].to(device, non_blocking=True) - 1).reshape(-1)
+    label = (ans.to(device, non_blocking=True) - 1).reshape(-1)
     return img, qst, label
 
 
@@ -209,8 +219,16 @@ def train_epoch(loader, trainer, epoch, device, log_interval=10, invert_question
     trainer.model.train()
     running, n_run = None, 0
     n_batches = len(loader) if hasattr(loader, "__len__") else 0
+    bufs = None
     for batch_idx, batch in enumerate(loader):
-        img, qst, label = load_tensor_data(batch, device, invert_questions)
+        img, qst, label = load_tensor_data(batch, device, invert_questions, out=bufs)
+        if bufs is None and getattr(trainer, "use_graph", False) and hasattr(trainer, "input_buffers"):
+            # from the second batch on the host -> device copies land in the step graph's own input tensors (no hand-off copy)
+            bufs = trainer.input_buffers(img, qst, label)
+            if bufs[0] is not img:
+                for d_, s_ in zip(bufs, (img, qst, label)):
+                    d_.copy_(s_)
+                img, qst, label = bufs
         loss = trainer.step(img, qst, label).detach()
         running = loss.clone() if running is None else running + loss
         n_run += 1

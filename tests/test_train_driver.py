@@ -46,6 +46,13 @@ def test_load_tensor_data_semantics(T):
     assert q.tolist() == [[0, 0, 7, 6, 5], [9, 4, 3, 2, 1]] and y.tolist() == [2, 27]
     _, q2, _ = T.load_tensor_data(batch, "cpu", invert_questions=False)
     assert q2.tolist() == batch["question"].tolist()
+    # out = the trainer's input buffers: the copies land there (same values); a batch of another shape gets tensors of its own
+    out = (torch.full((2, 3, 4, 4), 9.0), torch.zeros(2, 5, dtype=torch.int64), torch.zeros(2, dtype=torch.int64))
+    got = T.load_tensor_data(batch, "cpu", invert_questions=True, out=out)
+    assert all(a is b for a, b in zip(got, out)) and out[1].tolist() == q.tolist() and out[2].tolist() == [2, 27] and float(out[0].abs().sum()) == 0.0
+    small = {"image": torch.zeros(1, 3, 4, 4), "question": torch.tensor([[5, 6, 7, 0, 0]]), "answer": torch.tensor([[3]])}
+    got = T.load_tensor_data(small, "cpu", out=out)
+    assert got[0] is not out[0] and got[2].tolist() == [2]
 
 
 def test_synthetic_batches_have_reference_shapes(T):
@@ -182,6 +189,51 @@ def test_graph_trainer_overfits_one_batch(T):
     loss, res = T.test_epoch([batch], m, 1, torch.device("cuda"), 28, log=lines.append)
     assert res["n_samples"] == 16 and res["confusion"].sum() == 16 and 0 <= res["global_accuracy"] <= 1
     assert re.search(r".* Accuracy = (\d+\.\d+)%", lines[0]) and re.search(r".* Invalids = (\d+\.\d+)%", lines[0])
+
+
+@pytest.mark.gpu
+def test_batches_written_into_the_step_graphs_input_buffers_need_no_hand_off_copy(T, monkeypatch):
+    """DataParallelTrainer.input_buffers: a loader that lands its batches in the captured step's own input tensors hands them over
+    with no device-to-device copy (rn_copy_many is never launched), and the step computes what it computes on tensors of the
+    caller's own -- same losses, bitwise, from identically seeded models; train_epoch takes that route from its second batch on."""
+    import relationnetworks_clevr_amd as pkg
+    from relationnetworks_clevr_amd import dp
+
+    class A:
+        qdict_size, adict_size = 82, 28
+
+    batches = list(T.SyntheticClevr(48, 16, seed=5))
+    losses, copies = [], []
+    real = dp.RF.H.copy_many
+    for own in (True, False):
+        torch.manual_seed(0)
+        m = pkg.RN(A, dict(formula.HYP["original-fp"], dropout=0.0)).cuda()
+        opt = torch.optim.Adam(m.parameters(), lr=3e-4, weight_decay=1e-4, fused=True)
+        tr = dp.DataParallelTrainer(m, opt, clip_norm=50.0, use_graph=True, copy_guard_every=0)
+        n_copy = [0]
+        monkeypatch.setattr(dp.RF.H, "copy_many", lambda todo, n_copy=n_copy: (n_copy.__setitem__(0, n_copy[0] + 1), real(todo))[1])
+        ls = []
+        bufs = None
+        for b in batches + batches:
+            dev_batch = T.load_tensor_data(b, "cuda", out=bufs)
+            if not own and bufs is None:
+                bufs = tr.input_buffers(*dev_batch)
+                for d_, s_ in zip(bufs, dev_batch):
+                    d_.copy_(s_)
+                dev_batch = bufs
+            ls.append(float(tr.step(*dev_batch).detach()))
+        losses.append(ls); copies.append(n_copy[0])
+    assert losses[0] == losses[1], (losses[0][:3], losses[1][:3])
+    assert copies[0] == len(losses[0]) and copies[1] == 0, copies
+    # the epoch loop of train.py takes the buffers by itself
+    torch.manual_seed(0)
+    m = pkg.RN(A, dict(formula.HYP["original-fp"], dropout=0.0)).cuda()
+    tr = dp.DataParallelTrainer(m, torch.optim.Adam(m.parameters(), lr=3e-4, weight_decay=1e-4, fused=True), clip_norm=50.0, use_graph=True,
+                                copy_guard_every=0)
+    n_copy = [0]
+    monkeypatch.setattr(dp.RF.H, "copy_many", lambda todo: (n_copy.__setitem__(0, n_copy[0] + 1), real(todo))[1])
+    T.train_epoch(batches, tr, 1, torch.device("cuda"), log=lambda *_: None)
+    assert n_copy[0] == 0
 
 
 # ------------------------------------------------------------------------------------------ N4: evaluation bookkeeping
