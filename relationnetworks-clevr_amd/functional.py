@@ -178,6 +178,7 @@ def _side_stream(dev, which=0):
 # no concatenation kernel between the end of the backward pass and the optimiser.  Only when autograd will ASSIGN
 # (_assign_only: .grad is None, no hooks): accumulating `grad += view-of-the-same-memory` would double the new gradient.
 _GRAD_SLOTS = {}
+_SLOTS_OUT = set()       # parameters whose slot has been handed out in the backward pass that is running (cleared by an engine callback)
 
 
 def register_grad_slots(params, flat, offsets):
@@ -194,7 +195,17 @@ def grad_out(param, shape=None):
     if slot is not None:
         pref, fref, off = slot
         flat = fref()
-        if pref() is param and flat is not None and flat.device == param.device and shape == tuple(param.shape) and _assign_only(param):
+        if (pref() is param and flat is not None and flat.device == param.device and shape == tuple(param.shape) and _assign_only(param)
+                and id(param) not in _SLOTS_OUT):
+            # ONE hand-out per parameter and backward pass: a parameter that receives two gradients in a pass (the model run twice,
+            # the losses summed) would get the same memory twice, the second function overwriting what autograd still holds as the
+            # first addend (-> 2 x the second gradient, silently).  The second request gets a tensor of its own; autograd adds.
+            if not _SLOTS_OUT:
+                try:
+                    torch.autograd.Variable._execution_engine.queue_callback(_SLOTS_OUT.clear)
+                except RuntimeError:                          # (not inside a backward pass: nothing to protect)
+                    return flat[off:off + param.numel()].view(shape)
+            _SLOTS_OUT.add(id(param))
             return flat[off:off + param.numel()].view(shape)
     return torch.empty(shape, dtype=torch.float32, device=param.device)
 

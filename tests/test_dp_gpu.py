@@ -70,6 +70,21 @@ def test_backward_writes_gradients_into_the_bucket_only_when_autograd_assigns():
     torch.cuda.synchronize()
     err = (bucket.flat - 2 * in_place).abs().max() / in_place.abs().max()
     assert float(err) <= 1e-5, float(err)
+    # TWO gradients for every parameter in ONE backward pass (the model run twice, the losses summed), gather mode: the slot may be
+    # handed out once per pass -- the second backward function must get memory of its own, or autograd adds a buffer to itself
+    img2, qst2, lab2 = make_batch(8, torch.device("cuda"), 128)
+    img2 = img2.flip(0).contiguous()
+    def grads_of(batches):
+        bucket.detach_()
+        sum(torch.nn.functional.nll_loss(model(i_, q_), l_) for i_, q_, l_ in batches).backward()
+        bucket.gather_()
+        torch.cuda.synchronize()
+        return bucket.flat.clone()
+    model.eval()                                          # (batch statistics of two passes would interact through the running buffers only)
+    g1, g2 = grads_of([(img, qst, lab)]), grads_of([(img2, qst2, lab2)])
+    both = grads_of([(img, qst, lab), (img2, qst2, lab2)])
+    err = (both - (g1 + g2)).abs().max() / (g1 + g2).abs().max()
+    assert float(err) <= 1e-5, float(err)
 
 
 def test_fused_clip_adam_grad_scale_equals_single_rank_and_torch():
