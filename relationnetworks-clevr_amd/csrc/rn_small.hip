@@ -560,199 +560,6 @@ extern "C" int rn_f_phi_fwd_from_partials(const float* xg_part, int parts_per_ro
   return 0;
 }
 
-// ------------------------------------------------------------------------------------------------ f_phi, one launch per layer
-// The training step's f_phi (forward + loss + backward dz chain) as EIGHT small launches instead of one (round 4).  In the one-launch
-// form every workgroup owns 4 rows and pulls all six weight matrices (1.5 MB) through its CU -- and what a CU sustains is ~93 GB/s of
-// L2 hits and ~19 GB/s of misses: 40 us inside the step, cold behind the forward chain's 240-MB stream, whatever
-// the arithmetic.  Here a workgroup owns 8 OUTPUT FEATURES of one layer for all rows: it pulls 8 KB of weights and the 64-KB activation
-// matrix, 32 workgroups per layer; the hand-off between layers is the kernel boundary, which inside a replayed graph costs 0.2-0.3 us
-// on one queue (tools/dbg/graph_gaps.py).  Same products in the same order as the one-launch kernel (16 k-slices of an output added
-// up in slice order, then the bias): bitwise the same f1 / f2 / log-probs / loss / dz rows / dxg.
-//   lane = row (64 per workgroup and row block), wave = 2 output features: the weights of a wave are wave-uniform (scalar loads),
-//   the activations come from LDS (row stride K + 1: a bank per lane).
-namespace {
-constexpr int FPX_F = 8;            // output features per workgroup (4 waves x 2)
-constexpr int FPX_MAXK = 512;       // widest input the LDS tile holds (64 rows x (K + 1) floats <= 131 KB)
-constexpr int FPX_MAXA = 64;        // most classes the head kernel's LDS tile holds (256 rows x (A + 1) floats)
-struct FpxArgs {
-  const float* in;                  // (R, K) row-major
-  const float* W;                   // (N, K) row-major: the (out, in) matrix of this product
-  const float* bias;                // (N) or NULL
-  int R, K, N;
-  float* out;                       // (R, N): what the epilogue stores
-  const float* mask;                // (R, N) dropout mask or NULL        (EPI 1, 3)
-  const float* gate;                // (R, N) the forward activation whose sign gates the gradient (EPI 3, 4)
-};
-// EPI: 0 relu(z) | 1 relu(z * mask) | 2 z | 3 (gate > 0 ? z * mask : 0) | 4 (gate > 0 ? z : 0)
-template <int EPI>
-__global__ __launch_bounds__(256) void fpx_layer_kernel(FpxArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float fpx_s[];
-  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int K = a.K, ld = K + 1, r0 = blockIdx.y * 64;
-  // the activation tile -> LDS: 8 sixteen-byte loads per thread in flight per trip (K = 256: two trips; one load per trip would be
-  // a chain of 16 round trips -- 14 us per layer, measured)
-  const int K4 = K >> 2, total = 64 * K4;
-  for (int c0 = t; c0 < total; c0 += 256 * 8) {
-    f32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int c = c0 + 256 * u, r = c / K4, k = (c - r * K4) << 2;
-      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (c < total && r0 + r < a.R) v[u] = *reinterpret_cast<const f32x4*>(a.in + (long)(r0 + r) * K + k);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int c = c0 + 256 * u, r = c / K4, k = (c - r * K4) << 2;
-      if (c < total) {
-        float* d = fpx_s + r * ld + k;
-        d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
-      }
-    }
-  }
-  __syncthreads();
-  const int j0 = blockIdx.x * FPX_F + 2 * w;
-  if (j0 >= a.N) return;
-  const bool two = j0 + 1 < a.N;
-  const float* __restrict__ w0 = a.W + (long)j0 * K;
-  const float* __restrict__ w1 = a.W + (long)(two ? j0 + 1 : j0) * K;
-  const float* xr = fpx_s + lane * ld;
-  // the one-launch kernel's association: KQ (16; 4 when N % 4 != 0) k-slices, a slice's products added in k order, the slices in order
-  const int nsl = (a.N & 3) == 0 ? FP_KQ : FP_KS;
-  const int chunk = ((K + nsl - 1) / nsl + 3) & ~3;
-  float v0 = 0.f, v1 = 0.f;
-  if (chunk == 16 && nsl * 16 == K) {
-    // the 256-wide layers: two slices per trip -- 32 activations (LDS) and 2 x 32 weights (four 64-byte scalar loads) requested
-    // together, ONE wait per trip (scalar loads return out of order: every wait on them is a full one), 8 trips per layer
-    for (int q = 0; q < nsl; q += 2) {
-      float x[32], a0[32], a1[32];
-#pragma unroll
-      for (int u = 0; u < 32; ++u) { x[u] = xr[16 * q + u]; a0[u] = w0[16 * q + u]; a1[u] = w1[16 * q + u]; }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float p0 = 0.f, p1 = 0.f;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          p0 = fmaf(x[16 * h + u], a0[16 * h + u], p0);
-          p1 = fmaf(x[16 * h + u], a1[16 * h + u], p1);
-        }
-        v0 = (q + h) ? v0 + p0 : p0;
-        v1 = (q + h) ? v1 + p1 : p1;
-      }
-    }
-  } else {
-    for (int q = 0; q < nsl; ++q) {
-      const int i0 = min(K, q * chunk), i1 = min(K, i0 + chunk);
-      float p0 = 0.f, p1 = 0.f;
-      for (int k = i0; k < i1; k += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float x = xr[k + u];
-          p0 = fmaf(x, w0[k + u], p0);
-          p1 = fmaf(x, w1[k + u], p1);
-        }
-      }
-      v0 = q ? v0 + p0 : p0;
-      v1 = q ? v1 + p1 : p1;
-    }
-  }
-  const int r = r0 + lane;
-  if (r >= a.R) return;
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    if (e && !two) break;
-    const int j = j0 + e;
-    const float z = (e ? v1 : v0) + (a.bias ? a.bias[j] : 0.f);
-    const long o = (long)r * a.N + j;
-    float v;
-    if constexpr (EPI == 0) v = fmaxf(z, 0.f);
-    else if constexpr (EPI == 1) v = fmaxf(z * (a.mask ? a.mask[o] : 1.f), 0.f);
-    else if constexpr (EPI == 2) v = z;
-    else if constexpr (EPI == 3) v = (a.gate[o] > 0.f) ? z * (a.mask ? a.mask[o] : 1.f) : 0.f;
-    else v = (a.gate[o] > 0.f) ? z : 0.f;
-    a.out[o] = v;
-  }
-}
-
-// xg[b][k] = sum_p xg_part[(b * parts + p)][k], p = 0, 1, ... (the order of the one-launch kernel's prologue)
-__global__ __launch_bounds__(256) void fpx_xg_kernel(const float* __restrict__ part, int parts, float* __restrict__ xg, long n4, int G4) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  const long b = i / G4;
-  const int k4 = (int)(i - b * G4);
-  const f32x4* src = reinterpret_cast<const f32x4*>(part) + b * parts * G4 + k4;
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  int p = 0;
-  for (; p + 16 <= parts; p += 16) {
-    f32x4 u[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) u[q] = src[(long)(p + q) * G4];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v += u[q];
-  }
-  for (; p < parts; ++p) v += src[(long)p * G4];
-  reinterpret_cast<f32x4*>(xg)[i] = v;
-}
-
-// log_softmax of the logits in `out` (in place), the mean NLL, and dz3 = d loss / d logits for d loss = 1 -- one workgroup, a thread
-// per row; the loss is added up the way the one-launch kernel does (blocks of FP_RB rows, then the blocks in order)
-__global__ __launch_bounds__(256) void fpx_head_kernel(float* __restrict__ out, const long long* __restrict__ label, float* __restrict__ loss,
-                                                       float* __restrict__ dz3, float* __restrict__ lrow, int B, int A) {
-  __shared__ float zs[256 * (FPX_MAXA + 1)];
-  const float gl = -1.f / (float)B;
-  for (int b0 = 0; b0 < B; b0 += 256) {
-    // 256 rows of logits -> LDS in one coalesced sweep (a thread walking its own row in global memory is a chain of round trips)
-    const int nb = min(256, B - b0);
-    for (int c = threadIdx.x; c < nb * A; c += 256) zs[(c / A) * (FPX_MAXA + 1) + c % A] = out[(long)b0 * A + c];
-    __syncthreads();
-    const int b = b0 + threadIdx.x;
-    if (b < B) {
-      float* z = zs + threadIdx.x * (FPX_MAXA + 1);
-      float mx = z[0];
-      for (int a = 1; a < A; ++a) mx = fmaxf(mx, z[a]);
-      float s = 0.f;
-      for (int a = 0; a < A; ++a) s += expf(z[a] - mx);
-      const float ls = mx + logf(s);
-      const int lb = fp_label(label[b], A);
-      lrow[b] = -(z[lb] - ls);
-      for (int a = 0; a < A; ++a) z[a] -= ls;
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < nb * A; c += 256) {
-      const int r = c / A, a = c % A;
-      const float lp = zs[r * (FPX_MAXA + 1) + a];
-      out[(long)b0 * A + c] = lp;
-      dz3[(long)b0 * A + c] = (a == fp_label(label[b0 + r], A) ? gl : 0.f) - expf(lp) * gl;
-    }
-    __syncthreads();
-  }
-  __threadfence_block();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float tot = 0.f;
-    for (int b0 = 0; b0 < B; b0 += FP_RB) {
-      float l[FP_RB];
-#pragma unroll
-      for (int i = 0; i < FP_RB; ++i) l[i] = b0 + i < B ? lrow[b0 + i] : 0.f;
-      tot += ((l[0] + l[1]) + l[2]) + l[3];
-    }
-    *loss = tot / (float)B;
-  }
-}
-static_assert(FP_RB == 4, "fpx_head_kernel spells the block sum out");
-
-template <int EPI>
-void fpx_launch(const float* in, const float* W, const float* bias, int R, int K, int N, float* out, const float* mask, const float* gate, hipStream_t s) {
-  FpxArgs a{in, W, bias, R, K, N, out, mask, gate};
-  const size_t lds = (size_t)64 * (K + 1) * sizeof(float);
-  static bool once = false;
-  if (!once) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(fpx_layer_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (FPX_MAXK + 1) * 4);
-    once = true;
-  }
-  fpx_layer_kernel<EPI><<<dim3(cdiv(N, FPX_F), cdiv(R, 64)), 256, lds, s>>>(a);
-}
-}  // namespace
-
 // rn_f_phi_fwd_from_partials (transposed weights, loss folded in) + the backward dz chain for d loss = 1 in the SAME launch:
 // W1..3 = the natural (out, in) weights, bwd_ws = rn_f_phi_bwd_ws_bytes(...) bytes (receives the dz rows), dxg (B, G) out.
 // rn_f_phi_bwd_grads then produces the six parameter gradients from bwd_ws; a loss gradient other than 1 takes rn_f_phi_bwd_nll.
@@ -775,24 +582,6 @@ extern "C" int rn_f_phi_fwd_bwd_from_partials(const float* xg_part, int parts_pe
   bt.dz2 = bt.dz1 + (size_t)B * F1;
   bt.dz3 = bt.dz2 + (size_t)B * F2;
   bt.dxg = dxg;
-#ifndef RN_FPHI_LAYERS
-#define RN_FPHI_LAYERS 1
-#endif
-  if (RN_FPHI_LAYERS && G <= FPX_MAXK && F1 <= FPX_MAXK && F2 <= FPX_MAXK && A <= FPX_MAXA && A % 4 == 0 && B <= 4096) {
-    // one launch per layer (above): forward on the natural (out, in) weights, backward on their transposed copies
-    hipStream_t s = (hipStream_t)stream;
-    const long n4 = (long)B * G / 4;
-    fpx_xg_kernel<<<(unsigned)cdiv(n4, 256), 256, 0, s>>>(xg_part, parts_per_row, xg, n4, G / 4);
-    fpx_launch<0>(xg, W1, b1, B, G, F1, f1, nullptr, nullptr, s);
-    fpx_launch<1>(f1, W2, b2, B, F1, F2, f2, mask, nullptr, s);
-    fpx_launch<2>(f2, W3, b3, B, F2, A, out, nullptr, nullptr, s);
-    fpx_head_kernel<<<1, 256, 0, s>>>(out, label, loss, bt.dz3, bt.dz1, B, A);       // (dz1's buffer holds the per-row losses until the last-but-one launch overwrites it)
-    fpx_launch<3>(bt.dz3, W3T, nullptr, B, A, F2, bt.dz2, mask, f2, s);
-    fpx_launch<4>(bt.dz2, W2T, nullptr, B, F2, F1, bt.dz1, nullptr, f1, s);
-    fpx_launch<2>(bt.dz1, W1T, nullptr, B, F1, G, dxg, nullptr, nullptr, s);
-    RN_LAUNCH_CHECK("rn_f_phi_fwd_bwd_from_partials");
-    return 0;
-  }
   f_phi_fwd_kernel<true><<<cdiv(B, FP_RB), FP_KS * 256, 0, (hipStream_t)stream>>>(nullptr, W1T, b1, W2T, b2, W3T, b3, mask, f1, f2, out, B, G, F1, F2, A,
                                                                                   label, loss, part, cnt, xg_part, parts_per_row, xg, bt);
   RN_LAUNCH_CHECK("rn_f_phi_fwd_bwd_from_partials");
