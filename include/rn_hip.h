@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RN_ABI_VERSION 5   /* bumped whenever a signature or a buffer layout of this header changes */
+#define RN_ABI_VERSION 6   /* bumped whenever a signature or a buffer layout of this header changes */
 
 enum { RN_BF16 = 0, RN_F32 = 1, RN_F16 = 2, RN_FP8 = 3 };   /* RN_F16: pair matrix / split weights of the f16s forward only;
                                                              * RN_FP8: OCP e4m3 copies of the stored activations (h_dtype / a_dtype) */
@@ -333,6 +333,11 @@ int rn_clip_adam_step_dev(const void* chunks, int nchunks, float* g, float* m, f
  * copies as ONE launch (three library copies are three launches, ~12 us in front of every replay at the headline shape).
  * dst[i], src[i]: 16-byte aligned, bytes[i] any size (a multiple of 16 bytes goes through 16-byte accesses, the rest bytewise). */
 int rn_copy_many(void* const* dst, const void* const* src, const size_t* bytes, int n, void* stream);
+/* The f_phi dropout mask (model.py:76, :158: F.dropout(p) on the (B, f_fc2) activations): mask[i] = keep ? 1 / (1 - p) : 0, keep with
+ * probability 1 - p, from a counter-based hash of (seed, draw number, i).  state: two 64-bit device words {draws so far, 0}, advanced
+ * by the launch itself (capturable: every replay draws the next mask; no host-side generator state, so a replayed step graph needs
+ * no fill launches in front of it).  Not the reference's random stream -- no GPU port reproduces torch's CPU Philox draws. */
+int rn_dropout_mask(float* mask, long n, float p, unsigned long long seed, unsigned long long* state, void* stream);
 
 /* Question encoder (reference model.py:39-58): embedding lookup + 1-layer LSTM (E = 32 -> H = 128, gate order
  * i, f, g, o, zero initial state) as ONE launch per direction (rn_lstm.hip), fp32.

@@ -839,6 +839,44 @@ __global__ __launch_bounds__(256) void copy_many_kernel(CopyMany c) {
   if (off + CM_PER_BLOCK >= n && n16 + threadIdx.x < n && off <= n16) d[n16 + threadIdx.x] = s[n16 + threadIdx.x];   // (< 16 bytes)
 }
 
+// ------------------------------------------------------------------------------------------------ dropout mask
+// The f_phi dropout mask (model.py:158: F.dropout on the (B, f_fc2) activations) from a counter-based generator of the library's
+// own: mask[i] = hash(seed, draw, i) >= p ? 1 / (1 - p) : 0 with `draw` a DEVICE counter that the launch itself advances (the last
+// block to finish: every block has read it by then).  Why not torch's generator: a captured graph that draws from it makes every
+// replay launch two fill kernels for the Philox seed / offset IN FRONT of the graph -- 10 us of the 16 between two steps
+// (tools/dbg/graph_gaps.py).  state[0] = draws so far, state[1] = completion count (zero between launches).
+__device__ __forceinline__ unsigned long long dm_mix(unsigned long long z) {      // splitmix64's finaliser
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ mask, long n, float p, float keep_scale,
+                                                           unsigned long long seed, unsigned long long* __restrict__ state) {
+  const unsigned long long draw = state[0];
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const unsigned long long z = dm_mix(dm_mix(seed + 0x9E3779B97F4A7C15ull * (draw + 1)) + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1));
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);                      // 24 bits -> [0, 1)
+    mask[i] = u >= p ? keep_scale : 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&state[1], 1ull) == (unsigned long long)gridDim.x - 1) {
+      state[0] = draw + 1;
+      state[1] = 0ull;
+    }
+  }
+}
+
+extern "C" int rn_dropout_mask(float* mask, long n, float p, unsigned long long seed, unsigned long long* state, void* stream) {
+  RN_CHECK_ARG(mask && state && n > 0 && p >= 0.f && p < 1.f, "rn_dropout_mask: bad argument (n=%ld, p=%g: 0 <= p < 1)", n, (double)p);
+  RN_CHECK_ARG((uintptr_t)state % 8 == 0, "rn_dropout_mask: state must be two aligned 64-bit words");
+  dropout_mask_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(mask, n, p, 1.0f / (1.0f - p), seed, state);
+  RN_LAUNCH_CHECK("rn_dropout_mask");
+  return 0;
+}
+
 extern "C" int rn_copy_many(void* const* dst, const void* const* src, const size_t* bytes, int n, void* stream) {
   RN_CHECK_ARG(dst && src && bytes && n > 0 && n <= 4, "rn_copy_many: bad argument (n=%d, 1..4)", n);
   CopyMany c;

@@ -102,6 +102,10 @@ class RelationalLayerBase(nn.Module):
         self.f_fc2 = nn.Linear(hyp["f_fc1"], hyp["f_fc2"])
         self.f_fc3 = nn.Linear(hyp["f_fc2"], out_size)
         self.dropout = nn.Dropout(p=hyp["dropout"])
+        # draw counter of the library's dropout-mask generator (rn_dropout_mask): {draws so far, 0}.  A NON-persistent buffer: it moves
+        # with .cuda(), the trainer's copy guard puts it back like BatchNorm's buffers, and state_dict() keeps the reference's keys
+        self.register_buffer("_dropout_draws", torch.zeros(2, dtype=torch.int64), persistent=False)
+        self._dropout_seed = None                               # drawn from torch's CPU generator at the first mask (torch.manual_seed governs it)
         self.on_gpu = False
         self.hyp = hyp
         self.qst_size = qst_size
@@ -164,6 +168,16 @@ class RelationalLayer(RelationalLayerBase):
         if self.forced_dropout_mask is not None:
             return self.forced_dropout_mask.to(device=device, dtype=torch.float32)
         if self.training and self.dropout.p > 0:
+            dev = torch.device(device)
+            if OPT.native_dropout and dev.type == "cuda" and self.dropout.p < 1 and self._dropout_draws.device == dev:
+                # the library's own counter-based generator, advanced on the device by the launch itself: a captured step that draws
+                # from torch's generator makes every replay launch two fill kernels (Philox seed / offset) in front of the graph
+                if self._dropout_seed is None:
+                    import torch.distributed as dist
+                    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+                    # (every rank draws its own masks: identically seeded replicas would otherwise drop the same units of their shards)
+                    self._dropout_seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) + rank * 0x9E3779B97F4A7C15) & (2 ** 63 - 1)
+                return H.dropout_mask(torch.empty(b, self.f_fc2.out_features, device=dev), self.dropout.p, self._dropout_seed, self._dropout_draws)
             # same RNG consumption as the reference's self.dropout(x_f) on a (B, f_fc2) tensor
             return self.dropout(torch.ones(b, self.f_fc2.out_features, device=device))
         return None

@@ -23,6 +23,7 @@ _SPEC = {
     "grads_in_bucket":   ("RN_NO_GRADS_IN_BUCKET", True, "backward kernels write parameter gradients straight into a registered FlatGradBucket (trainer)"),
     "fused_adam":        ("RN_NO_FUSED_ADAM", True, "fused clip + Adam on the flat bucket (trainer)"),
     "graph_allreduce":   ("RN_NO_GRAPH_ALLREDUCE", True, "N > 1 over RCCL: the gradient all-reduce inside the captured step too (else eager, with the optimiser behind it)"),
+    "native_dropout":    ("RN_NO_NATIVE_DROPOUT", True, "f_phi dropout mask from the library's counter-based generator (device-side draw counter: a replayed step graph needs no generator fills in front of it); False: torch's F.dropout"),
     "graph_adam":        ("RN_NO_GRAPH_ADAM", True, "clip + Adam (and, N > 1, the all-reduce) inside the captured step"),
 }
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librn_hip.so")
 RN_BF16, RN_F32, RN_F16, RN_FP8 = 0, 1, 2, 3
 RN_RELU, RN_ACCUMULATE = 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -69,6 +69,7 @@ SIGNATURES = {
     "rn_lstm_bwd_tail": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_clip_adam_step_dev": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P]),
     "rn_copy_many": (_I, [_P, _P, _P, _I, _P]),
+    "rn_dropout_mask": (_I, [_P, C.c_long, C.c_float, C.c_ulonglong, _P, _P]),
     "rn_clip_adam_step": (_I, [_P, _I, _P, _P, _P, _L, _P] + [C.c_float] * 7 + [_I, _P, _P]),
     "rn_conv3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_conv3x3s2_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -735,6 +736,16 @@ def nll_mean_fwd(logp, label, loss):
 
 def nll_mean_bwd(label, gloss, gout):
     _check(load().rn_nll_mean_bwd(label.data_ptr(), gloss.data_ptr(), gout.data_ptr(), gout.shape[0], gout.shape[1], _stream()), "rn_nll_mean_bwd")
+
+
+def dropout_mask(mask, p, seed, state):
+    """mask (fp32, contiguous) <- keep ? 1 / (1 - p) : 0 from the library's counter-based generator; state: int64 (2,) device tensor
+    {draws so far, 0}, advanced by the launch (rn_dropout_mask)."""
+    _dev(mask, "mask"); _dev(state, "state")
+    if not (mask.is_contiguous() and mask.dtype == torch.float32 and state.dtype == torch.int64 and state.numel() >= 2 and state.is_contiguous()):
+        raise ValueError("dropout_mask: mask must be contiguous fp32, state a contiguous int64 (2,) tensor")
+    _check(load().rn_dropout_mask(mask.data_ptr(), mask.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, state.data_ptr(), _stream()), "rn_dropout_mask")
+    return mask
 
 
 def copy_many(pairs):

@@ -1187,3 +1187,30 @@ def test_lstm_bwd_tail(H, B, T, V):
     ref = torch.zeros(V, 32, dtype=torch.float64, device="cuda").index_add_(0, idx.t().reshape(-1), dx.double())
     assert rel(d1.cpu().numpy(), ref.cpu().numpy()) <= F32_TOL
     assert rel(b1.cpu().numpy(), dg.double().sum((0, 1)).cpu().numpy()) <= F32_TOL
+
+
+def test_dropout_mask_generator(H):
+    """rn_dropout_mask: values in {0, 1 / (1 - p)}; keep rate = 1 - p to 4 sigma; the launch advances the device draw counter by one
+    and leaves the completion word at zero; same (seed, draw) -> the same mask, the next draw / another seed -> another one; masks of
+    successive draws are uncorrelated."""
+    n, p = 64 * 256, 0.5
+    st = torch.zeros(2, dtype=torch.int64, device="cuda")
+    m0 = H.dropout_mask(torch.empty(64, 256, device="cuda"), p, 1234, st)
+    torch.cuda.synchronize()
+    assert st.tolist() == [1, 0]
+    vals = set(m0.unique().tolist())
+    assert vals == {0.0, 2.0}
+    keep = float((m0 > 0).float().mean())
+    assert abs(keep - (1 - p)) <= 4 * (p * (1 - p) / n) ** 0.5, keep
+    m1 = H.dropout_mask(torch.empty(64, 256, device="cuda"), p, 1234, st)
+    st2 = torch.zeros(2, dtype=torch.int64, device="cuda")
+    m0b = H.dropout_mask(torch.empty(64, 256, device="cuda"), p, 1234, st2)
+    m0c = H.dropout_mask(torch.empty(64, 256, device="cuda"), p, 99, torch.zeros(2, dtype=torch.int64, device="cuda"))
+    torch.cuda.synchronize()
+    assert st.tolist() == [2, 0] and torch.equal(m0, m0b) and not torch.equal(m0, m1) and not torch.equal(m0, m0c)
+    agree = float(((m0 > 0) == (m1 > 0)).float().mean())
+    assert abs(agree - 0.5) <= 4 * (0.25 / n) ** 0.5, agree
+    for pp in (0.1, 0.75):
+        m = H.dropout_mask(torch.empty(100003, device="cuda"), pp, 7, torch.zeros(2, dtype=torch.int64, device="cuda"))
+        k_ = float((m > 0).float().mean())
+        assert abs(k_ - (1 - pp)) <= 4 * (pp * (1 - pp) / 100003) ** 0.5 and abs(float(m.max()) - 1 / (1 - pp)) <= 1e-6

@@ -236,6 +236,40 @@ def test_batches_written_into_the_step_graphs_input_buffers_need_no_hand_off_cop
     assert n_copy[0] == 0
 
 
+@pytest.mark.gpu
+def test_replayed_steps_draw_fresh_dropout_masks_and_the_copy_guard_puts_the_counter_back(T):
+    """The f_phi dropout mask comes from the library's generator with a DEVICE draw counter: every replay of the captured step draws the
+    next mask (counter = number of forward passes), two identically seeded runs are bitwise equal, the trainer's copy guard (an extra
+    probe forward) does not consume a draw, and switching to torch's dropout (options.native_dropout = False) still trains."""
+    import relationnetworks_clevr_amd as pkg
+    from relationnetworks_clevr_amd import dp
+
+    class A:
+        qdict_size, adict_size = 82, 28
+
+    batch = next(iter(T.SyntheticClevr(16, 16, seed=3)))
+    img, q, y = T.load_tensor_data(batch, "cuda")
+
+    def run(guard_every, native=True, steps=6):
+        with pkg.options.override(native_dropout=native):
+            torch.manual_seed(0)
+            m = pkg.RN(A, dict(formula.HYP["original-fp"])).cuda()           # dropout 0.5 (config.json)
+            assert m.rl.dropout.p == 0.5
+            tr = dp.DataParallelTrainer(m, torch.optim.Adam(m.parameters(), lr=3e-4, weight_decay=1e-4, fused=True), clip_norm=50.0,
+                                        use_graph=True, copy_guard_every=guard_every)
+            ls = [float(tr.step(img, q, y).detach()) for _ in range(steps)]
+            return ls, m.rl._dropout_draws.tolist(), tr
+    a, draws_a, tr = run(0)
+    b, draws_b, _ = run(0)
+    assert a == b and draws_a == draws_b
+    assert draws_a[1] == 0 and draws_a[0] == 6 + 2                          # 6 steps + the 2 warm-up passes in front of the capture
+    c, draws_c, _ = run(2)                                                  # the guard probes at steps 1, 2, 4, 6: no draw consumed
+    assert c == a and draws_c == draws_a
+    assert "_dropout_draws" not in tr.model.state_dict() and "rl._dropout_draws" not in tr.model.state_dict()
+    d, draws_d, _ = run(0, native=False)
+    assert draws_d[0] == 0 and all(np.isfinite(d)) and d != a
+
+
 # ------------------------------------------------------------------------------------------ N4: evaluation bookkeeping
 def eval_loop_restatement(preds, labels, dictionaries):
     """The per-sample loops of the reference's test() (train.py:69-127) restated: the checker for EvalBookkeeper.
