@@ -161,7 +161,7 @@ class PackedWeights:
 
 
 _SIDE_STREAMS = {}
-_EXP = {"wgrad_late": 1, "conv_wgrad_stream": 2}      # scheduling knobs (tools/dbg/exp_bench.py flips them for A/B runs)
+_EXP = {"wgrad_late": 1, "conv_wgrad_stream": 2, "fphi_grads_late": 1}      # scheduling knobs (tools/dbg/exp_bench.py flips them for A/B runs)
 
 
 def _side_stream(dev, which=0):
@@ -534,10 +534,19 @@ class RelationalFunction(torch.autograd.Function):
         dW3 = grad_out(fp[2], (A, F2)); db3 = grad_out(fp[5], (A,))
         dW2 = grad_out(fp[1], (F2, F1)); db2 = grad_out(fp[4], (F2,))
         dW1 = grad_out(fp[0], (F1, G)); db1 = grad_out(fp[3], (F1,))
+        ctx.fphi_job = None
         if gout is None and ctx.fphi_pre is not None and is_unit_loss_grad(gloss):
             # the forward launch already ran the dz chain for d loss = 1: the parameter gradients are all that is left
             ws_, dxg = ctx.fphi_pre
-            H.f_phi_bwd_grads(ws_, xg, f1, f2, (dW1, dW2, dW3), (db1, db2, db3))
+            job = lambda: H.f_phi_bwd_grads(ws_, xg, f1, f2, (dW1, dW2, dW3), (db1, db2, db3))
+            if ctx.chain and _EXP["fphi_grads_late"]:
+                # Nothing in the backward pass reads these six gradients, and no launch of the replayed step lasts less than 6-7 us:
+                # in front of the backward chain this one sat on the critical path.  The chain path runs it on the layer-0 stream
+                # in front of that weight gradient -- a fork that exists anyway (a fork / join pair of its own cost more than the
+                # kernel): +0.6 % q/s (93.9 vs 93.3 k, six alternating runs)
+                ctx.fphi_job = (job, [ws_, xg, f1, f2])
+            else:
+                job()
         elif gout is None:
             dxg = torch.empty(B, G, **f32)
             H.f_phi_bwd_nll(gloss, label, out, f2, f1, xg, fw, ctx.mask, (dW1, dW2, dW3), (db1, db2, db3), dxg)
@@ -701,6 +710,10 @@ class RelationalFunction(torch.autograd.Function):
             s0 = _side_stream(dev, 2)
             s0.wait_stream(main)
             with torch.cuda.stream(s0):
+                if ctx.fphi_job is not None:
+                    ctx.fphi_job[0]()
+                    keep.append(ctx.fphi_job[1])
+                    ctx.fphi_job = None
                 _wgrad0()
             if not (late and _EXP["wgrad_late"] == 3):
                 side.wait_stream(s0)
@@ -709,6 +722,9 @@ class RelationalFunction(torch.autograd.Function):
             # main stream runs next while this side-stream kernel still reads them (seen as a wrong dW_0 on a busy GPU)
             keep.append([Rj, Ri, Rq, x, q, ctx.coord, red_parts])
         else:
+            if ctx.fphi_job is not None:
+                ctx.fphi_job[0]()
+                ctx.fphi_job = None
             _wgrad0()
         if ctx.coord is not None:
             # the gradient goes straight into the conv grid's layout (B, k - 2, n): the two coordinate columns carry
