@@ -438,10 +438,15 @@ def main():
     dt, loss = timed_steps(lambda: trainer.step(img, qst, lab), args.steps, args.warmup, sync)
     with_copy = None
     if use_graph and img0 is not img:
+        # (both forms once more, back to back: the K timed steps above start 5 replays after an idle chip and run a few percent under
+        # the rate the chip reaches some milliseconds later -- the pair below is measured in ONE clock state)
+        dt_a, _ = timed_steps(lambda: trainer.step(img, qst, lab), args.steps, 2, sync)
         dt_c, _ = timed_steps(lambda: trainer.step(img0, qst0, lab0), args.steps, 2, sync)
-        dt_c = max_over_ranks(dt_c, world, dev)
+        dt_a, dt_c = max_over_ranks(dt_a, world, dev), max_over_ranks(dt_c, world, dev)
         with_copy = {"value": world * B * args.steps / dt_c, "ms_per_step": 1e3 * dt_c / args.steps,
-                     "what": "the same K steps with the batch in tensors of the caller's own: one rn_copy_many launch in front of every replay"}
+                     "same_moment_without_copy": world * B * args.steps / dt_a,
+                     "what": "K more steps with the batch in tensors of the caller's own (one rn_copy_many launch in front of every replay), "
+                             "right behind K more steps without that copy: compare these two, not with `value`"}
     sustained = None
     if args.sustain > 0:
         # The contract's K = 20 steps last ~15 ms -- too short for the chip to reach its sustained clocks under matrix load.
