@@ -8,8 +8,10 @@ different is everything under `RelationalLayer.forward`: the repeat / cat /
 Linear / relu / sum op sequence of model.py:104-162 is replaced by hand-written
 HIP kernels reached through the C-ABI library librn_hip.so (functional.py).
 
-The conv stack and the LSTM are ordinary torch.nn modules (MIOpen on ROCm); they
-are ~1 % of the step's flops and outside the hot path.
+The conv stack and the question encoder keep the reference's torch.nn modules as parameter holders (checkpoint keys); on the GPU their
+forward / backward run through this library's kernels too (rn_conv.hip, rn_convnorm.hip, rn_lstm.hip: the 3x3 / stride-2 / 24-channel
+convolutions with their batch norms, the one-layer LSTM) -- outside the SURVEY section-8 hot path (section 2 #4, #5), built because they
+are half of the step's time; other shapes fall back to MIOpen / torch, and the LSTM's two weight-gradient products are torch.mm.
 
 Deliberate deviations from reference quirks:
   C1  the coordinate tensor is cached per (batch, grid, device), every entry kept for the life of
