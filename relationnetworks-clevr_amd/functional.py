@@ -161,7 +161,12 @@ class PackedWeights:
 
 
 _SIDE_STREAMS = {}
-_EXP = {"wgrad_late": 1, "conv_wgrad_stream": 2, "fphi_grads_late": 1}      # scheduling knobs (tools/dbg/exp_bench.py flips them for A/B runs)
+# Launch-order choices of the backward pass that only measurements decide (the captured graph's queue order): kept as named knobs so that
+# tools/dbg/exp_bench.py can A/B them on one box.  wgrad_late: 0 the g_theta weight-gradient launch right behind the backward chain,
+# 1 behind the partial sums AND the layer-0 stream (default), 2 behind dx / dq too, 3 behind the partial sums only;
+# conv_wgrad_stream: the side stream the conv weight gradients share (0 the g_theta weight gradient's, 2 the layer-0 stream's);
+# fphi_grads_late: f_phi's parameter gradients on the layer-0 stream instead of in front of the backward chain.
+SCHED = {"wgrad_late": 1, "conv_wgrad_stream": 2, "fphi_grads_late": 1}
 
 
 def _side_stream(dev, which=0):
@@ -539,7 +544,7 @@ class RelationalFunction(torch.autograd.Function):
             # the forward launch already ran the dz chain for d loss = 1: the parameter gradients are all that is left
             ws_, dxg = ctx.fphi_pre
             job = lambda: H.f_phi_bwd_grads(ws_, xg, f1, f2, (dW1, dW2, dW3), (db1, db2, db3))
-            if ctx.chain and _EXP["fphi_grads_late"]:
+            if ctx.chain and SCHED["fphi_grads_late"]:
                 # Nothing in the backward pass reads these six gradients, and no launch of the replayed step lasts less than 6-7 us:
                 # in front of the backward chain this one sat on the critical path.  The chain path runs it on the layer-0 stream
                 # in front of that weight gradient -- a fork that exists anyway (a fork / join pair of its own cost more than the
@@ -650,7 +655,7 @@ class RelationalFunction(torch.autograd.Function):
         # layer-0 stream (they no longer queue behind this launch).  Behind dx / dq as well: -11 %; behind the partial sums ONLY
         # (the layer-0 stream joined after the launch): -12..-16 % -- the captured graph's queue order, not arithmetic
         # (tools/dbg/exp_bench.py wgrad_late=2 | 3).  The question-injected models need the launch's per-question sums for dq: early.
-        late = overlap and _EXP["wgrad_late"] and not inj
+        late = overlap and SCHED["wgrad_late"] and not inj
         if overlap:
             main, side = torch.cuda.current_stream(), _side_stream(dev)
             if not late:
@@ -715,7 +720,7 @@ class RelationalFunction(torch.autograd.Function):
                     keep.append(ctx.fphi_job[1])
                     ctx.fphi_job = None
                 _wgrad0()
-            if not (late and _EXP["wgrad_late"] == 3):
+            if not (late and SCHED["wgrad_late"] == 3):
                 side.wait_stream(s0)
             # x and q too: they are alive only through this node's saved tensors, which autograd releases as soon as
             # backward() returns -- the caching allocator would hand their blocks to the conv / LSTM backward that the
@@ -738,13 +743,13 @@ class RelationalFunction(torch.autograd.Function):
         else:
             H.pair_dx_dq(Rj, Ri, None, wl, dx, None, B, n, k, 0, N)                # (dq came from the injected layer)
         if late:
-            if _EXP["wgrad_late"] == 2:
+            if SCHED["wgrad_late"] == 2:
                 side.wait_stream(main)                             # behind dx / dq
             else:
                 side.wait_event(late_ev)                           # behind the partial sums only
             with torch.cuda.stream(side):
                 _wgrads_blocked()
-            if _EXP["wgrad_late"] == 3:
+            if SCHED["wgrad_late"] == 3:
                 side.wait_stream(s0)
         if rq_splits:
             dq = inj_out["dq"]
@@ -911,7 +916,7 @@ class ConvBNReLUFunction(torch.autograd.Function):
             # stream ended up behind another one's kernels (the LSTM backward then started 100 us late).  Together -2.5 % on the step.
             # Which one (round 4): the layer-0 weight gradient's (idle by now), not the g_theta weight gradient's -- behind that
             # 180-us launch the first of these started ~55 us after its operands were ready.
-            main, side = torch.cuda.current_stream(), _side_stream(dx.device, _EXP["conv_wgrad_stream"])
+            main, side = torch.cuda.current_stream(), _side_stream(dx.device, SCHED["conv_wgrad_stream"])
             ev = main.record_event()
             if ctx.direct and inp.shape[1] == 24:
                 din = torch.empty_like(inp)

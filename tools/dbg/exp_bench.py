@@ -7,7 +7,7 @@ args = sys.argv[1:]
 cut = args.index("--") if "--" in args else len(args)
 for kv in args[:cut]:
     k, v = kv.split("=")
-    pkg.functional._EXP[k] = int(v)
+    pkg.functional.SCHED[k] = int(v)
 sys.argv = ["bench.py"] + args[cut + 1:]
 import bench
 bench.main()
