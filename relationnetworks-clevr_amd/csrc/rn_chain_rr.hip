@@ -143,6 +143,13 @@ struct RRCore {
 // data cache: the kernel ends with s_dcache_wb.  hipcc neither counts nor pads them (s_nop: VALU-written SGPR
 // read by SMEM).
 __device__ __forceinline__ void mask_store4(u64* p, u64 m0, u64 m1, u64 m2, u64 m3) {
+#ifndef RR_MASK_X2
+  // two 16-byte scalar stores instead of four 8-byte ones (the compiler puts the four masks into two aligned SGPR quads; -DRR_MASK_X2: the old form)
+  const u32x4 qa = {(unsigned)m0, (unsigned)(m0 >> 32), (unsigned)m1, (unsigned)(m1 >> 32)};
+  const u32x4 qb = {(unsigned)m2, (unsigned)(m2 >> 32), (unsigned)m3, (unsigned)(m3 >> 32)};
+  asm volatile("s_nop 4\n\ts_store_dwordx4 %0, %2, 0x0\n\ts_store_dwordx4 %1, %2, 0x10" : : "s"(qa), "s"(qb), "s"(p) : "memory");
+  return;
+#endif
   asm volatile("s_nop 4\n\ts_store_dwordx2 %0, %4, 0x0\n\ts_store_dwordx2 %1, %4, 0x8\n\ts_store_dwordx2 %2, %4, 0x10\n\t"
                "s_store_dwordx2 %3, %4, 0x18"
                :
