@@ -17,10 +17,14 @@ for extra in ("bench_ir_fp.json", "bench_stress_b32_n196.json", "small_kernels_a
         shutil.copy(os.path.join(src, extra), dst(extra))
 OURS = re.compile(r"(rr_kernel|rr_f16s|rr_bwd|wgrad|pair_|f_phi|cn_|lstm_|emb_bwd|conv3x3s2|conv_wgrad|clip_adam|sumsq|nll_|segsum|pack_frag|debug_stamp)")
 rows = list(csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))))
+# eager steps in the trace = launches of the forward chain (one per step; 13 with --sustain 0, ~1400 when the sustained run is traced too)
 steps = 13.0
+for r_ in rows:
+    if "rr_f16s_kernel" in r_["kernel"] and float(r_["calls"]) > 0:
+        steps = float(r_["calls"])
 with open(dst("hot_path_kernels.txt"), "w") as f:
     f.write("# this repo's HIP kernels in one training step (same rocprofv3 --kernel-trace run as %s_kernel_stats_rocprofv3.csv,\n"
-            "# `bench.py --no-graph --steps 10 --warmup 3`: 13 eager steps): launches/step, average duration.  Profiled clocks are ~5-10 %%\n"
+            "# `bench.py --no-graph --steps 10 --warmup 3`, eager steps incl. the sustained run): launches/step, average duration.  Profiled clocks are ~5-10 %%\n"
             "# slower than the timed bench and the queues are serialised by the tracer (no stream overlap).\n" % tag)
     f.write("%-58s %9s %9s %9s\n" % ("kernel", "per step", "avg us", "us/step"))
     tot = 0.0
