@@ -654,7 +654,8 @@ class RelationalFunction(torch.autograd.Function):
         # and dx reaches the conv stack's backward ~60 us earlier: +1..1.6 % q/s together with the conv weight gradients moved to the
         # layer-0 stream (they no longer queue behind this launch).  Behind dx / dq as well: -11 %; behind the partial sums ONLY
         # (the layer-0 stream joined after the launch): -12..-16 % -- the captured graph's queue order, not arithmetic
-        # (tools/dbg/exp_bench.py wgrad_late=2 | 3).  The question-injected models need the launch's per-question sums for dq: early.
+        # (tools/dbg/exp_bench.py wgrad_late=2 | 3).  The question-injected models need the launch's per-question sums for dq: early (taking the
+        # sums from a pass of their own over dZ_2 instead, so that the launch can be late there too: -0.5 % on ir-fp).
         late = overlap and SCHED["wgrad_late"] and not inj
         if overlap:
             main, side = torch.cuda.current_stream(), _side_stream(dev)
