@@ -416,7 +416,13 @@ int rn_bn_relu_bwd_conv_wgrad(const float* dy, const float* xc, const float* inp
  *                image t mod dither: the weight rounding error no longer has the same sign for all pairs of a question and averages
  *                out in the pair sum (model.py:151-152) like the activation rounding does.  Wlo[1..3] are not read (may be NULL).
  *                Error against the fp32 reference on the released checkpoints: 1.7e-4 / 1.9e-4 (original-fp / ir-fp; one plain
- *                pass: 2.6e-3; the bar is 1e-3).
+ *                pass: 2.6e-3; the bar is 1e-3).  WHICH image a pair row multiplies depends on its tile, i.e. on where the
+ *                question sits in the batch (n*n / 256 not a multiple of `dither`) and on the order of its objects: results are
+ *                bitwise reproducible for one batch, and equal across batch compositions only to the mode's accuracy (~1e-4).
+ *   dither == 0: the TWO-PASS arithmetic (inference only: H and mask must be NULL) -- hi + lo split images on EVERY layer, Whi[l] =
+ *                fp16(W_l), Wlo[l] = fp16(W_l - hi) (modes 4 / 8).  Nothing depends on the tile index: a question's outputs are
+ *                the same wherever it sits in the batch and for any order of its objects, up to fp32 summation order (~1e-6).
+ *                What the module's eval() runs (options.eval_two_pass).  Twice the MFMAs of layers 1..3.
  *   inject_layer = 0: the question is part of the tables (Q > 0 in rn_pair_tables).  inject_layer = 2 (the "IR" variants,
  *     model.py:131-142; tables built with Q = 0): layer 2's input is [H_1 | q[b]], i.e. W_2 [H_1 | q] + b_2 = W_2[:, 0:256] H_1 + Vq[b]
  *     with Vq (B, 256) fp32 = W_2[:, 256:] q[b] + b_2 prepared by the caller (one small rn_gemm_f32); Whi[2] holds W_2[:, 0:256]

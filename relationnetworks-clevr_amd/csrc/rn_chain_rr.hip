@@ -315,7 +315,7 @@ static_assert(F_NSLOT * F_STAGE == RR_NSLOT * RR_STAGE, "same ring bytes");
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 struct RRArgsF {
   const f16* Whi[RR_L];                                 // layer 0: one image; layers 1..3: vmask + 1 tile-dithered images, 128 KB apart
-  const f16* Wlo[RR_L];                                 // (layer 0 only)
+  const f16* Wlo[RR_L];                                 // (layer 0 only; the two-pass inference variant: every layer)
   int vmask;
   const float* bias[RR_L];
   bf16* out[RR_L];
@@ -329,7 +329,7 @@ __device__ __forceinline__ unsigned relu_pack_f16(float a, float b) {     // sat
   x = __builtin_elementwise_max(x, z);
   return __builtin_bit_cast(unsigned, x);
 }
-template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false, bool GATE = false>
+template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false, bool GATE = false, bool LO = false>
 struct F16Vm {
   static constexpr int PF_PER = (NK0 + 7) / 8;
   static constexpr int VC_STAGE = (RR_L - 1) * 8 + 4;                // ALG0: the stage that requests the next tile's bias row
@@ -338,7 +338,7 @@ struct F16Vm {
   // one-pass layers the hi image only (each 1-KB request costs ~100 issue cycles beside the MFMAs: streaming whole 32-KB
   // stages measured 32 of the kernel's 173 us).
   static constexpr int nfr(int l) { return l == 0 ? NK0 : 16; }       // fragments per image of a layer-l stage
-  static constexpr int nimg(int l) { return l == 0 ? 2 : 1; }
+  static constexpr int nimg(int l) { return (l == 0 || LO) ? 2 : 1; }  // LO: hi + lo on every layer (the batch-invariant inference arithmetic)
   static constexpr int dpw(int l) { return nfr(l) * nimg(l) / RR_NW; }   // requests per wave for a stage of layer l
   static_assert((NK0 * 2) % RR_NW == 0, "layer-0 requests divide evenly over the waves");
   static constexpr int ops(int sidx) {
@@ -403,8 +403,11 @@ struct F16Vm {
 // in the un-swapped last layer a lane owns feature n of rows 8 j + 4 h + r, i.e. per 16-row group two of the cell's four dwords,
 // the other two sit in the partner lane (n, 1 - h) -- two v_permlane32_swap hand lane half 0 the whole cell of rows 0..15 and half
 // 1 that of rows 16..31.  One 16-byte store per lane and block, all in the MFMA shadow.
+// LO (inference only): hi + lo split weights on EVERY layer instead of one pass on the tile's dithered image -- no arithmetic depends
+// on where a pair row sits (tile index), so a question's log-probs are the same whatever its position in the batch and whatever
+// the order of its objects (up to fp32 summation order), at twice the MFMA count of layers 1..3.  What eval() runs by default.
 template <int NK0, bool STORE, bool ST3, bool MASK, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false, int ABL = 0, bool RAG = false,
-          bool GATE = false>
+          bool GATE = false, bool LO = false>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __restrict__ P, int ldp, RRArgsF a,
                                                                 float* __restrict__ xg_part, int ntiles,
                                                                 const float* __restrict__ Vc = nullptr, int n_obj = 0,
@@ -414,7 +417,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
   static_assert(INJ >= 0 && INJ < RR_L - 1, "the injected layer is one of the swapped-operand layers");
   static_assert(!H8 || STORE, "e4m3 copies of H_0..2 (a stored H_3 stays bf16: the pair sum reads it)");
   static_assert(!GATE || (H8 && MASK && !ST3), "the gate image belongs to the training output set with e4m3 copies");
-  typedef F16Vm<NK0, STORE, ST3, XG, ALG0, INJ, H8, GATE> Vm;
+  static_assert(!LO || (!STORE && !MASK), "two passes on every layer: the inference variant");
+  typedef F16Vm<NK0, STORE, ST3, XG, ALG0, INJ, H8, GATE, LO> Vm;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
   k.init(lds);
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
   // (hi, lo; wave-uniform), fragment q % nfr
   auto dma_piece = [&](int l2, int ob2, int slot, int i, int tile_) {
     const int q = Vm::dpw(l2) * w + i, im = q / Vm::nfr(l2), fr = q - im * Vm::nfr(l2);
-    const f16* img = l2 == 0 ? (im ? a.Wlo[0] : a.Whi[0]) : a.Whi[l2] + (long)(tile_ & a.vmask) * (RR_G * RR_G);   // (the tile's dithered image)
+    const f16* img = (l2 == 0 || LO) ? (im ? a.Wlo[l2] : a.Whi[l2]) : a.Whi[l2] + (long)(tile_ & a.vmask) * (RR_G * RR_G);   // (the tile's dithered image)
     k.dma_at(reinterpret_cast<const unsigned char*>(img) + ob2 * RR_STAGE + fr * 1024, RR_OFF_RING + slot * F_STAGE + im * RR_STAGE + fr * 1024);
   };
   auto rd = [&](int slot, int ks, int p) -> Frag { return k.rd_at(RR_OFF_RING + slot * F_STAGE + p * RR_STAGE + ks * 1024); };
@@ -640,9 +644,9 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
     auto stage = [&](auto lc, auto obc, Frag (&in)[16], Frag (&out)[16]) {
       constexpr int l = decltype(lc)::value, ob = decltype(obc)::value;
       constexpr int NK = (l == 0) ? NK0 : 16;
-      constexpr int NP = l == 0 ? 2 : 1;                               // passes of this stage: hi (+ lo)
+      constexpr int NP = (l == 0 || LO) ? 2 : 1;                       // passes of this stage: hi (+ lo)
       constexpr int nl = (l * 8 + ob + 1 == 8 * RR_L) ? 0 : (l * 8 + ob + 1) >> 3;   // layer of the next stage
-      constexpr int NPn = nl == 0 ? 2 : 1;
+      constexpr int NPn = (nl == 0 || LO) ? 2 : 1;
       constexpr int CPG = NP * NK / 4;                                 // MFMA gaps per epilogue group (8 / 6 / 4)
       constexpr int sidx = l * 8 + ob;
       constexpr bool has_prev = sidx > 0;
@@ -1192,19 +1196,22 @@ static int rr_check_inject(const char* who, const float* Vq, int inj, int n) {
 
 // Argument checks of the f16s entry point: Whi[0] / Wlo[0] = the two fragment-major fp16 images of layer 0,
 // Whi[1..3] = `dither` tile-dithered hi images each (128 KB apart); Wlo[1..3] are not read.
+// dither == 0: the TWO-PASS inference arithmetic -- Whi[l] / Wlo[l] = the plain hi / lo split images of every layer.
 static int rr_f16s_args(const char* who, RRArgsF& a, const void* const* Whi, const void* const* Wlo, int dither, const float* const* bias,
                         void* const* H, void* const* mask, int* nh_, int* nm_) {
-  RN_CHECK_ARG(dither == 1 || dither == 2 || dither == 4 || dither == 8, "%s: dither (hi images per layer >= 1) must be 1, 2, 4 or 8 (got %d)", who, dither);
+  RN_CHECK_ARG(dither == 0 || dither == 1 || dither == 2 || dither == 4 || dither == 8,
+               "%s: dither (hi images per layer) must be 1, 2, 4 or 8, or 0 = hi + lo on every layer (got %d)", who, dither);
+  const bool two = dither == 0;
   memset(&a, 0, sizeof(a));
   a.prio = rr_prio();
-  a.vmask = dither - 1;
+  a.vmask = two ? 0 : dither - 1;
   int nh = 0, nm = 0;
   for (int l = 0; l < RR_L; ++l) {
-    RN_CHECK_ARG(Whi[l] && (l > 0 || Wlo[0]) && bias[l], "%s: layer %d weight/bias is NULL", who, l);
-    RN_CHECK_ARG(((uintptr_t)Whi[l] | (uintptr_t)(l == 0 ? Wlo[0] : nullptr) | (uintptr_t)bias[l] | (uintptr_t)(H ? H[l] : nullptr) | (uintptr_t)(mask ? mask[l] : nullptr)) % 16 == 0,
+    RN_CHECK_ARG(Whi[l] && ((l > 0 && !two) || Wlo[l]) && bias[l], "%s: layer %d weight/bias is NULL", who, l);
+    RN_CHECK_ARG(((uintptr_t)Whi[l] | (uintptr_t)((l == 0 || two) ? Wlo[l] : nullptr) | (uintptr_t)bias[l] | (uintptr_t)(H ? H[l] : nullptr) | (uintptr_t)(mask ? mask[l] : nullptr)) % 16 == 0,
                  "%s: layer %d pointers must be 16-byte aligned", who, l);
     a.Whi[l] = (const f16*)Whi[l];
-    a.Wlo[l] = l == 0 ? (const f16*)Wlo[0] : nullptr;
+    a.Wlo[l] = (l == 0 || two) ? (const f16*)Wlo[l] : nullptr;
     a.bias[l] = bias[l];
     a.out[l] = H ? (bf16*)H[l] : nullptr;
     a.mask[l] = mask ? (u64*)mask[l] : nullptr;
@@ -1238,12 +1245,19 @@ extern "C" int rn_g_chain_fwd_rr_f16s_alg0(const void* Xp16, const float* Vc, in
   RN_CHECK_ARG((nh == 0 && nm == 0) || h012, "rn_g_chain_fwd_rr_f16s_alg0: H / masks: none (inference) or H_0..2 + all four masks (training)");
   RN_CHECK_ARG(!gate_in_h2 || (h8 && h012), "rn_g_chain_fwd_rr_f16s_alg0: the gate in the sign bits of H_2 goes with the e4m3 training output set");
   const bool gate = gate_in_h2 != 0;
+  const bool two = dither == 0;
+  RN_CHECK_ARG(!two || nh == 0, "rn_g_chain_fwd_rr_f16s_alg0: dither == 0 (hi + lo on every layer) is the inference arithmetic: no H / mask outputs");
   const int ntiles = M / RR_TM;
   const int grid = ntiles < rr_num_cus() ? ntiles : rr_num_cus();
   hipStream_t s = (hipStream_t)stream;
   const int rpb = n * n;
   const f16* Xp = (const f16*)Xp16;
-  if (rag) {
+  if (two) {
+    const int nz = rag ? (M / (n * njp)) * n : 0;
+    if (rag) g_chain_rr_f16s_kernel<4, false, false, false, true, true, 0, false, 0, true, false, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, nullptr, 1, njp, nz);
+    else if (inject_layer == 2) g_chain_rr_f16s_kernel<4, false, false, false, true, true, 2, false, 0, false, false, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, Vq, rpb);
+    else g_chain_rr_f16s_kernel<4, false, false, false, true, true, 0, false, 0, false, false, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n);
+  } else if (rag) {
     const int nz = (M / (n * njp)) * n;                               // the all-zero object row behind the B * n real ones
     if (nh == 0) g_chain_rr_f16s_kernel<4, false, false, false, true, true, 0, false, 0, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, nullptr, 1, njp, nz);
     else if (h8 && gate) g_chain_rr_f16s_kernel<4, true, false, true, true, true, 0, true, 0, true, true><<<grid, RR_NT, 0, s>>>(Xp, 64, a, xg_part, ntiles, Vc, n, nullptr, 1, njp, nz);

@@ -14,6 +14,13 @@ backward (the bucket is complete only when backward ends: the g_theta weight gra
 bulk of the bytes, are produced last-layer-first but conv/LSTM grads arrive at the very end)."""
 from __future__ import annotations
 
+import contextlib
+import datetime
+import os
+import sys
+import threading
+import warnings
+
 import torch
 import torch.distributed as dist
 
@@ -23,6 +30,95 @@ try:
 except ImportError:                                   # imported through the top-level shim
     from relationnetworks_clevr_amd import functional as RF          # type: ignore
     from relationnetworks_clevr_amd.options import OPT               # type: ignore
+
+
+class Watchdog:
+    """A deadline on a region that waits for the GPU or for other ranks.  A collective whose peers never arrive (a rank that
+    fell back to another mode, a hung capture) blocks for ever and says nothing; under `guard(what, seconds)` the process
+    instead prints what it was waiting for and EXITS (code 124, like timeout(1)) -- torch.distributed.run then tears the job
+    down.  seconds <= 0: no deadline."""
+
+    EXIT_CODE = 124
+
+    def __init__(self, rank=0):
+        self.rank = rank
+
+    def _expire(self, what, seconds):
+        sys.stderr.write("[relationnetworks_clevr_amd] rank %d: no progress for %.0f s in: %s -- giving up (exit %d).  "
+                         "If this is the in-graph gradient all-reduce, re-run with RN_NO_GRAPH_ALLREDUCE=1.\n"
+                         % (self.rank, seconds, what, self.EXIT_CODE))
+        sys.stderr.flush()
+        os._exit(self.EXIT_CODE)
+
+    @contextlib.contextmanager
+    def guard(self, what, seconds):
+        if not seconds or seconds <= 0:
+            yield
+            return
+        t = threading.Timer(seconds, self._expire, args=(what, seconds))
+        t.daemon = True
+        t.start()
+        try:
+            yield
+        finally:
+            t.cancel()
+
+
+class ControlPlane:
+    """Rank agreement that depends on neither the GPU nor the data communicator: a CPU-side `gloo` group over the same ranks
+    (the group itself when it already is gloo).  The trainer decides HOW a step runs (all-reduce inside the captured graph or
+    eager behind it) from things that can differ per rank -- a capture that throws, a self-check that mismatches -- and a
+    decision taken per rank leaves the ranks in different modes: mismatched collectives, a hang.  Every such decision goes
+    through all_ok() / any_of().  If no gloo group can be made the flags travel over `group` as device tensors."""
+
+    def __init__(self, group=None, timeout_s=300.0, device=None):
+        self.group, self.device = group, device
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.cpu_group = None
+        self._cpu = False
+        if self.world > 1:
+            if dist.get_backend(group) == "gloo":
+                self.cpu_group, self._cpu = group, True
+            else:
+                try:
+                    ranks = dist.get_process_group_ranks(group) if group is not None else None
+                    self.cpu_group = dist.new_group(ranks=ranks, backend="gloo", timeout=datetime.timedelta(seconds=max(timeout_s, 10.0)))
+                    self._cpu = True
+                except Exception as e:                        # a build without gloo: the data communicator carries the flags
+                    warnings.warn("no gloo control group (%s): rank agreement goes over the data communicator" % str(e)[:120])
+
+    def _reduce(self, value, op):
+        if self.world == 1:
+            return value
+        if self._cpu:
+            t = torch.tensor([float(value)], dtype=torch.float64)
+            dist.all_reduce(t, op=op, group=self.cpu_group)
+        else:
+            t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=op, group=self.group)
+        return float(t.item())
+
+    def all_ok(self, ok) -> bool:
+        """True iff `ok` on EVERY rank."""
+        return self._reduce(1.0 if ok else 0.0, dist.ReduceOp.MIN) > 0.5
+
+    def any_of(self, flag) -> bool:
+        return self._reduce(1.0 if flag else 0.0, dist.ReduceOp.MAX) > 0.5
+
+    def gather(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on every rank (small python objects: flags, checksums, reasons)."""
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        if self._cpu:
+            dist.all_gather_object(out, obj, group=self.cpu_group)
+        else:
+            dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def ranks_seen(self):
+        return sorted(self.gather(self.rank))
 
 
 class FlatGradBucket:
@@ -64,6 +160,8 @@ class FlatGradBucket:
         """Before backward in gather mode: autograd then assigns instead of accumulating."""
         for p in self.params:
             p.grad = None
+        # a backward pass that raised part-way never ran the engine callback that ends its slot hand-outs: start clean
+        RF.reset_grad_slot_handouts()
 
     def gather_(self):
         """Make the flat buffer hold this backward pass's gradients and re-attach the views.  Gradients the backward kernels
@@ -73,6 +171,7 @@ class FlatGradBucket:
         for p, o in zip(self.params, self.offsets):
             g = p.grad
             if g is not None and g.is_contiguous() and g.data_ptr() == base + 4 * o:
+                self._known_zero.discard(o)                 # a backward kernel wrote the slot in place: it is no longer known to be zero
                 continue
             stray.append((p, o, g))
         if len(stray) == len(self.params):
@@ -237,34 +336,58 @@ class DataParallelTrainer:
     """model + optimizer + flat bucket: step(batch) = zero -> fwd -> nll -> bwd -> all-reduce -> clip -> Adam
     (the loop body of the reference's train(), train.py:36-48).
 
-    use_graph=True captures {zero, forward, loss, backward} -- ~150 short kernel launches (conv/BN,
-    LSTM cells, the HIP hot path) -- into ONE hipGraph on first use and replays it every step; the
-    collective, the clip and the optimizer stay eager (a handful of launches, and identical for any
-    world size).  Inputs are copied into static buffers, so shapes must not change between steps."""
+    use_graph=True captures the step -- ~55 kernel launches (conv/BN, the LSTM, the HIP hot path) -- into ONE hipGraph on first
+    use and replays it every step.  WHAT the graph holds:
+      * one rank: forward, loss, backward, clip + Adam (everything);
+      * N > 1 over RCCL (backend "nccl"): the same PLUS the gradient all-reduce, so that the N > 1 step has the shape of the N = 1
+        step -- but only after every rank has passed a start-up self-check of a captured all-reduce against an eager one AND
+        every rank's capture of the step succeeded (ControlPlane agreement).  Otherwise, on EVERY rank alike: forward + backward
+        replayed, then the all-reduce and the fused (1/world, clip, Adam) launched eagerly (`exchange_fallback` says why);
+      * any other backend (gloo moves the bucket through the host): the eager exchange, always.
+    Inputs are copied into static buffers (or written there by the loader: input_buffers()), so shapes must not change
+    between steps.  With N > 1 every wait on another rank runs under a Watchdog deadline (options.dp_timeout seconds)."""
 
     def __init__(self, model, optimizer, clip_norm: float | None = 50.0, group=None, use_graph: bool = False,
-                 copy_guard_every: int = 512, copy_guard_max_flushed: float = 0.05, copy_guard_max_clamped: float = 1e-3):
+                 copy_guard_every: int = 512, copy_guard_max_flushed: float = 0.05, copy_guard_max_clamped: float = 1e-3,
+                 graph_allreduce: bool | None = None, timeout_s: float | None = None):
         self.model, self.opt, self.clip_norm, self.group = model, optimizer, clip_norm, group
-        # guard of the e4m3 activation copies (check_activation_copies): at step 1 and then every `copy_guard_every` steps; 0 = never
+        # guard of the e4m3 activation copies (check_activation_copies): before the first capture / at step 1 and then every
+        # `copy_guard_every` steps; 0 = never
         self.copy_guard_every, self.copy_guard_max_flushed, self.copy_guard_max_clamped = copy_guard_every, copy_guard_max_flushed, copy_guard_max_clamped
         self.copy_guard_log = []
+        self._guard_done_at = None                         # value of _nstep the guard last ran for
         self._nstep = 0
-        broadcast_module_state(model, 0, group)
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.world = world
+        self.rank = dist.get_rank(group) if world > 1 else 0
+        self.timeout_s = float(OPT.dp_timeout if timeout_s is None else timeout_s) if world > 1 else 0.0
+        self.watchdog = Watchdog(self.rank)
+        dev = next(model.parameters()).device
+        self.ctl = ControlPlane(group, self.timeout_s or 300.0, dev)
+        with self.watchdog.guard("broadcast of rank 0's parameters and buffers", self.timeout_s):
+            broadcast_module_state(model, 0, group)
         self.bucket = FlatGradBucket(model.parameters())
         self.use_graph = use_graph
         self._graph = None
         self._static = None
         self.timing = None                                 # a list: step() appends (start, after all-reduce, after optimiser) events
         self._fused_opt = FusedClipAdam(self.bucket, optimizer) if FusedClipAdam.supports(self.bucket, optimizer) else None
-        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.world = world
-        # The whole step is ONE graph whenever it can be: with one GPU nothing sits between backward and the optimiser, so clip +
-        # Adam join the captured step (no graph -> eager boundary: ~25 us of idle chip per step); with more ranks the gradient
-        # all-reduce is captured too when the backend's collectives are stream-ordered (RCCL: `nccl`), so that the N > 1 step
-        # has the shape of the N = 1 step -- fwd + bwd + all-reduce + (1/world, clip, Adam) in one replay.  Any other backend
-        # (gloo moves the bucket through the host) keeps the all-reduce and the optimiser eager behind the replayed fwd + bwd.
-        coll_in_graph = world == 1 or (OPT.graph_allreduce and dist.get_backend(group) == "nccl")
+        # The whole step is ONE graph whenever it can be (class docstring).  graph_allreduce: None = options.graph_allreduce and a
+        # stream-ordered backend; True / False force it (tests drive the agreement logic over gloo with True)
+        if graph_allreduce is None:
+            graph_allreduce = OPT.graph_allreduce and world > 1 and dist.get_backend(group) == "nccl"
+        coll_in_graph = world == 1 or bool(graph_allreduce)
         self._opt_in_graph = (use_graph and self._fused_opt is not None and coll_in_graph and OPT.graph_adam)
+        self.exchange_fallback = None                      # why the exchange is NOT in the graph although it was asked for
+        self.exchange_checks = {}                          # what the start-up checks measured (bench.py prints them)
+        self._first_graph_step_checked = False
+
+    # ------------------------------------------------------------------------------------------- activation-copy guard
+    def _h8_modules(self):
+        return [m_._packed for m_ in self.model.modules() if hasattr(m_, "_packed") and hasattr(m_._packed, "h8")]
+
+    def _h8_in_use(self):
+        return OPT.h8 and any(pk.h8 for pk in self._h8_modules())
 
     def check_activation_copies(self, img, qst, label):
         """The e4m3 copies of H_0..2 (kept for the weight gradients of g layers 1..3) use a FIXED scale of 1: a post-ReLU value
@@ -272,11 +395,13 @@ class DataParallelTrainer:
         default-initialised models -- but nothing in the step itself would notice a model that drifts out of that range.  This
         runs ONE extra training forward on the given batch (eager, outside the step graph; BatchNorm buffers and the RNG state
         are put back) with a probe that counts, per copy, the positive activations that were flushed to zero and the bytes at the
-        clamp (rn_fp8_copy_health), and switches the module to 16-bit copies (options.h8 = False, the step graph is re-captured)
-        when more than `copy_guard_max_flushed` of the positive activations of a layer are flushed or more than
-        `copy_guard_max_clamped` of its elements are clamped.  With several ranks the decision is the OR over ranks.
+        clamp (rn_fp8_copy_health), and switches THIS trainer's model to 16-bit copies (the relational layer's `_packed.h8 = False`
+        -- not the process-wide option; the step graph is re-captured, into the same input tensors) when more than
+        `copy_guard_max_flushed` of the positive activations of a layer are flushed or more than `copy_guard_max_clamped` of its
+        elements are clamped.  With several ranks the decision is the OR over ranks (ControlPlane).
         -> {"layers": {l: {"positive", "flushed", "clamped", "max_value"}}, "switched": bool} or None (no e4m3 copies in use)."""
-        if not (OPT.h8 and img.is_cuda):
+        self._guard_done_at = self._nstep
+        if not (self._h8_in_use() and img.is_cuda):
             return None
         bufs = [(b_, b_.clone()) for b_ in self.model.buffers()]
         rng = torch.cuda.get_rng_state(img.device)
@@ -293,8 +418,6 @@ class DataParallelTrainer:
                 for b_, old in bufs:
                     b_.copy_(old)
             torch.cuda.set_rng_state(rng, img.device)
-        if not probe:
-            return None
         rep, bad = {}, False
         for l, t in probe:
             pos, flushed, clamped, maxb = [int(v) for v in t.cpu().tolist()]
@@ -305,18 +428,20 @@ class DataParallelTrainer:
             rep[l] = {"positive": pos, "flushed": flushed / tot, "clamped": clamped / tot, "max_value": maxv}
             bad = bad or flushed / tot > self.copy_guard_max_flushed or clamped / tot > self.copy_guard_max_clamped
         if self.world > 1:
-            flag = torch.tensor([1.0 if bad else 0.0], device=img.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-            bad = bool(flag.item() > 0)
+            with self.watchdog.guard("activation-copy guard: agreement over ranks", self.timeout_s):
+                bad = self.ctl.any_of(bad)
+        if not probe and not bad:
+            return None
         out = {"step": self._nstep, "layers": rep, "switched": bad}
         self.copy_guard_log.append(out)
         if bad:
-            import warnings
             warnings.warn("e4m3 activation copies lose too much (%s): switching to 16-bit copies" % rep)
-            OPT.h8 = False
+            for pk in self._h8_modules():
+                pk.h8 = False
             self._graph = None                                 # (the captured step has the e4m3 kernels baked in)
         return out
 
+    # --------------------------------------------------------------------------------------------------- the step's parts
     def _fwd_bwd(self, img, qst, label):
         self.bucket.detach_()
         if hasattr(self.model, "forward_loss") and img.is_cuda and OPT.fused_loss:
@@ -330,27 +455,90 @@ class DataParallelTrainer:
         self.bucket.gather_()
         return loss
 
+    def _graph_collective(self, tensor):
+        """The data-path collective as it is captured (and as the self-check captures it)."""
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _exchange_self_check(self):
+        """Start-up check of the in-graph exchange (N > 1, before the step is captured): a bucket-sized buffer with a per-rank
+        pattern goes through an EAGER all-reduce and through a CAPTURED one (a two-node graph of its own, replayed twice on
+        restored inputs); the results must be bitwise equal.  -> None when that holds on EVERY rank, else the reason (a string,
+        identical on every rank) -- the caller then keeps the exchange eager everywhere."""
+        dev = self.bucket.flat.device
+        n = self.bucket.numel
+        gen = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+        src = (torch.rand(n, generator=gen) - 0.5).to(dev)
+        ok, why = True, None
+        try:
+            ref = src.clone()
+            dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.group)     # (also the communicator's lazy initialisation)
+            torch.cuda.synchronize()
+            buf = src.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._graph_collective(buf)
+            for _ in range(2):
+                buf.copy_(src)
+                g.replay()
+                torch.cuda.synchronize()
+                if not torch.equal(buf, ref):
+                    ok, why = False, "captured all-reduce != eager all-reduce (max |diff| %.3e)" % float((buf - ref).abs().max())
+                    break
+            del g
+        except Exception as e:
+            ok, why = False, "%s: %s" % (type(e).__name__, str(e)[:160])
+            torch.cuda.synchronize()
+        reasons = self.ctl.gather(why)
+        self.exchange_checks["self_check"] = "passed" if all(r is None for r in reasons) else reasons
+        if all(r is None for r in reasons):
+            return None
+        return "self-check of the captured all-reduce failed on rank(s) %s: %s" % (
+            [i for i, r in enumerate(reasons) if r is not None], next(r for r in reasons if r is not None))
+
     def _capture(self, img, qst, label):
-        self._static = (img.clone(), qst.clone(), label.clone())
+        # the e4m3 copy guard BEFORE the first capture (ADVICE r4: a guard that trips after it costs a second capture with its four
+        # warm-up passes through the BatchNorm statistics)
+        if self.copy_guard_every and self._guard_done_at is None:
+            self.check_activation_copies(img, qst, label)
+        if self._static is not None and all(a.shape == b.shape and a.dtype == b.dtype for a, b in zip(self._static, (img, qst, label))):
+            for d_, s_ in zip(self._static, (img, qst, label)):    # a re-capture keeps the input tensors a loader may be writing into
+                if d_.data_ptr() != s_.data_ptr():
+                    d_.copy_(s_)
+        else:
+            self._static = (img.clone(), qst.clone(), label.clone())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                   # warm-up outside capture (MIOpen find, allocator, packs)
             for _ in range(2):
                 self._fwd_bwd(*self._static)
-            if self._opt_in_graph and self.world > 1:   # ... and the communicator's first collective (lazy initialisation)
-                dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.group)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if self._opt_in_graph and self.world > 1:
-            try:
-                self._graph = self._capture_graph(True)
-                return
-            except Exception as e:                      # a backend / runtime that cannot capture its collective: eager exchange
-                import warnings
-                warnings.warn("the gradient all-reduce could not be captured into the step graph (%s: %s); it stays eager"
-                              % (type(e).__name__, str(e)[:200]))
-                self._opt_in_graph = False
-                torch.cuda.synchronize()
+            with self.watchdog.guard("start-up self-check + capture of the in-graph gradient all-reduce", self.timeout_s):
+                why = self._exchange_self_check()
+                graph = None
+                if why is None:
+                    err = None
+                    try:
+                        graph = self._capture_graph(True)
+                    except Exception as e:              # a backend / runtime that cannot capture its collective
+                        err = "%s: %s" % (type(e).__name__, str(e)[:160])
+                        torch.cuda.synchronize()
+                    # the decision is the JOB's, not the rank's: one rank replaying an in-graph all-reduce while another launches
+                    # an eager one is a hang
+                    errs = self.ctl.gather(err)
+                    self.exchange_checks["capture"] = "ok" if all(e_ is None for e_ in errs) else errs
+                    if any(e_ is not None for e_ in errs):
+                        why = "capture of the step with the all-reduce failed on rank(s) %s: %s" % (
+                            [i for i, e_ in enumerate(errs) if e_ is not None], next(e_ for e_ in errs if e_ is not None))
+                if why is None:
+                    self._graph = graph
+                    return
+                del graph
+            warnings.warn("the gradient all-reduce stays OUT of the step graph on every rank (%s): eager exchange" % why)
+            self.exchange_fallback = why
+            self._opt_in_graph = False
+            torch.cuda.synchronize()
         self._graph = self._capture_graph(self._opt_in_graph)
 
     def _capture_graph(self, with_opt):
@@ -359,17 +547,39 @@ class DataParallelTrainer:
             self._loss = self._fwd_bwd(*self._static)
             if with_opt:
                 if self.world > 1:
-                    dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.group)
+                    self._graph_collective(self.bucket.flat)
                 self._fused_opt.step_dev()              # (the 1/world factor is the hyper block's grad_scale)
         return graph
+
+    def exchange_mode(self):
+        """Where the gradient exchange of a step runs: 'none' (one rank), 'in-graph', 'eager'."""
+        if self.world == 1:
+            return "none"
+        return "in-graph" if (self.use_graph and self._opt_in_graph) else "eager"
+
+    def _check_first_graph_step(self):
+        """After the FIRST replay of a step graph that holds the all-reduce: every rank must hold the same reduced gradient
+        (checksum + norm over the control plane).  A captured collective that silently reduced nothing, or the wrong buffer, shows
+        up here -- loudly -- instead of as replicas that drift apart."""
+        self._first_graph_step_checked = True
+        with self.watchdog.guard("first replay of the step graph with the in-graph all-reduce", self.timeout_s):
+            torch.cuda.synchronize()
+            f = self.bucket.flat
+            sig = (float(f.double().sum().item()), float(f.double().norm().item()), float(self._fused_opt.norm.item()))
+            sigs = self.ctl.gather(sig)
+        self.exchange_checks["first_step_signatures_equal"] = all(s_ == sigs[0] for s_ in sigs)
+        if not self.exchange_checks["first_step_signatures_equal"]:
+            raise RuntimeError("the in-graph gradient all-reduce left different gradients on the ranks (sum, norm, clip norm per rank: %r); "
+                               "re-run with RN_NO_GRAPH_ALLREDUCE=1" % (sigs,))
 
     def input_buffers(self, img, qst, label):
         """The captured step's OWN input tensors (captured now, from the given example batch, if it has not been yet).  A loader
         that writes every batch INTO these -- its host -> device copy, or a device-side producer -- and calls step(*buffers) hands
         the batch over with no device-to-device copy at all: step() copies only the tensors that are not these (one
         rn_copy_many launch, ~14 us for 12.6 MB of images in front of every replay).  Shapes are fixed by the example batch
-        (a ragged last batch goes through step() with its own tensors and the eager path of the caller's choice).  Without a
-        step graph there is nothing to hand over into: the arguments come back."""
+        (a ragged last batch goes through step() with its own tensors and the eager path of the caller's choice).  The tensors
+        stay the same objects across re-captures (the copy guard's switch to 16-bit copies).  Without a step graph there is
+        nothing to hand over into: the arguments come back."""
         if not self.use_graph:
             return img, qst, label
         if self._graph is None:
@@ -378,7 +588,7 @@ class DataParallelTrainer:
 
     def step(self, img, qst, label):
         self._nstep += 1
-        if self.copy_guard_every and (self._nstep == 1 or self._nstep % self.copy_guard_every == 0):
+        if self.copy_guard_every and ((self._nstep == 1 and self._guard_done_at is None) or self._nstep % self.copy_guard_every == 0):
             self.check_activation_copies(img, qst, label)
         if self.use_graph:
             if self._graph is None:
@@ -400,6 +610,8 @@ class DataParallelTrainer:
             loss = self._loss
             if self._opt_in_graph:
                 self._fused_opt.after_step_dev()
+                if self.world > 1 and not self._first_graph_step_checked:
+                    self._check_first_graph_step()
                 return loss
         else:
             loss = self._fwd_bwd(img, qst, label)

@@ -20,6 +20,9 @@ from . import rn_hip as H
 from .options import OPT
 
 PRECISIONS = ("bf16", "f16s", "fp32")
+# "f16s2": what the module turns "f16s" into for a forward pass in eval() mode (options.eval_two_pass) -- the chain path with hi + lo
+# split weights on every layer when nothing needs a gradient (batch-position-invariant log-probs); with a gradient: plain "f16s"
+_INTERNAL_PRECISIONS = PRECISIONS + ("f16s2",)
 
 
 def _ru(v, m):
@@ -61,6 +64,7 @@ class PackedWeights:
 
     def __init__(self):
         self.key = None
+        self.h8 = True                             # e4m3 activation copies for this module (and options.h8); a trainer's copy guard clears it
         self.fwd, self.bwd = [], []
         self.fT = None                             # transposed fp32 copies of the f_phi weights
         self.w0T = None                            # W_0^T in fp32: the table kernel of the factored first layer
@@ -74,6 +78,8 @@ class PackedWeights:
         return (code, chain, bwd_images, tuple((w.data_ptr(), w._version) for w in list(g_w) + list(f_w or ())))
 
     def get(self, plan: LayerPlan, g_w, code, chain=False, bwd_images=True, f_w=None):
+        """chain = True: the training / dithered image set; chain = "two_pass": plain hi + lo images of every layer (the
+        batch-invariant inference arithmetic, rn_g_chain_fwd_rr_f16s_alg0 with dither 0; never with bwd_images)."""
         key = self._key(code, chain, bwd_images, g_w, f_w)
         self._last = (plan, tuple(g_w), code, chain, bwd_images, tuple(f_w) if f_w is not None else None)
         if self._ahead == key:                              # packed by repack_ahead() earlier in this forward pass
@@ -117,13 +123,14 @@ class PackedWeights:
             if chain:
                 # columns that enter the MFMA image: the factored first layer keeps W0[:, 0:k], an injected layer W[:, 0:G_prev]
                 kimg = k if l == 0 else (plan.widths[l - 1] if l == inj else kt)
-                V = 1 if l == 0 else H.F16S_DITHER
+                two = chain == "two_pass"
+                V = 1 if (l == 0 or two) else H.F16S_DITHER
                 wh = torch.empty(V, 256 * 256, dtype=torch.float16, device=dev)
                 frag_jobs.append((wc, kt, 1, N, kimg, wh, 4 | int(l == 0) | ((V << 8) if V > 1 else 0)))
                 self.frag_hi.append(wh)
-                if l == 0:
+                if l == 0 or two:
                     wl = torch.empty(256 * 256, dtype=torch.float16, device=dev)
-                    frag_jobs.append((wc, kt, 1, N, kimg, wl, 8 | 1))
+                    frag_jobs.append((wc, kt, 1, N, kimg, wl, 8 | int(l == 0)))
                     self.frag_lo.append(wl)
                 self.fwd.append(None)
                 self.bwd.append(None)
@@ -190,6 +197,12 @@ def register_grad_slots(params, flat, offsets):
     import weakref
     for p_, o in zip(params, offsets):
         _GRAD_SLOTS[id(p_)] = (weakref.ref(p_), weakref.ref(flat), o)
+
+
+def reset_grad_slot_handouts():
+    """Forget the slot hand-outs of a backward pass that never finished (it raised part-way: the engine callback that clears them
+    did not run, and with a non-empty set no later pass would queue one).  The trainer calls this before every backward pass."""
+    _SLOTS_OUT.clear()
 
 
 def grad_out(param, shape=None):
@@ -277,11 +290,12 @@ def chain_ok(plan: LayerPlan, B, n):
 f16s_ok = chain_ok
 
 
-def _h_copy_dtype():
+def _h_copy_dtype(packed=None):
     """Storage type of the H_0..2 copies the forward chain keeps for the weight gradient (row-blocked images, rn_g_wgrad_blocked
     is their only reader): OCP e4m3 bytes -- half the bytes written and read back -- or bf16 with options.h8 off (A/B
-    measurements, error comparisons, and what the trainer's copy guard falls back to)."""
-    return torch.float8_e4m3fn if OPT.h8 else torch.bfloat16
+    measurements, error comparisons) or with the MODULE's own switch off (`packed.h8 = False`: what a trainer's copy guard
+    falls back to -- scoped to the module it watched, not to the process)."""
+    return torch.float8_e4m3fn if (OPT.h8 and getattr(packed, "h8", True)) else torch.bfloat16
 
 
 def alg0_wgrad_ok(plan, k):
@@ -309,7 +323,7 @@ def _tables(x, q, plan, g_b, w0T, inj_w, B, n, k, Q, G, coord=None):
     return Xp, Vc, Vq
 
 
-def chain_forward(x, q, plan: LayerPlan, g_b, packed, keep, inj_w=None, coord=None):
+def chain_forward(x, q, plan: LayerPlan, g_b, packed, keep, inj_w=None, coord=None, two_pass=False):
     """The chain path's forward (model.py:108-152): tables of the factored first layer + ONE launch for the four g layers and the
     pair sum.  -> (Hs, masks, xg, njp): Hs = the row-blocked copies of H_0..2 (None: inference), masks = RRMasks, xg = the pair
     sums (PairSumPartials: the f_phi launch adds the per-tile partials up), njp = pair rows per (question, i) group."""
@@ -324,18 +338,20 @@ def chain_forward(x, q, plan: LayerPlan, g_b, packed, keep, inj_w=None, coord=No
     masks = Hs = None
     gate = False
     if keep:
-        Hs = [torch.empty(Mp, G, dtype=_h_copy_dtype(), device=dev) for l in range(L - 1)] + [None]
+        Hs = [torch.empty(Mp, G, dtype=_h_copy_dtype(packed), device=dev) for l in range(L - 1)] + [None]
         masks = list(torch.empty(L, H.g_chain_rr_mask_bytes(Mp), dtype=torch.uint8, device=dev))
         # the last layer's weight-gradient gate job reads the gate from the sign bits of the e4m3 H_{L-2} image
         gate = Hs[0].dtype in H.FP8_DTYPES and (n * njp) % 64 == 0
+    lo = packed.frag_lo if two_pass else packed.frag_lo[0]          # (two_pass: hi + lo on every layer; inference only)
+    assert not (two_pass and keep)
     if njp != n:
         part = torch.empty(Mp // R * 2, G, dtype=torch.float32, device=dev)      # two partial rows per tile (it may straddle questions)
-        H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, packed.frag_hi, packed.frag_lo[0], g_b, Hs, masks, part, Mp, G, njp=njp, gate=gate)
+        H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, packed.frag_hi, lo, g_b, Hs, masks, part, Mp, G, njp=njp, gate=gate)
         xg = torch.empty(B, G, dtype=torch.float32, device=dev)
         H.pair_sum_tiles(part, xg, Mp, n * njp, G)
     else:
         part = torch.empty(Mp // R, G, dtype=torch.float32, device=dev)
-        H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, packed.frag_hi, packed.frag_lo[0], g_b, Hs, masks, part, Mp, G, Vq=Vq,
+        H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, packed.frag_hi, lo, g_b, Hs, masks, part, Mp, G, Vq=Vq,
                                    inject=plan.inject if inj_w is not None else 0, gate=gate)
         xg = PairSumPartials(part, B, (n * n) // R, G)
     return (Hs[:-1] if Hs is not None else None), (RRMasks(masks, gate) if masks is not None else None), xg, njp
@@ -445,7 +461,7 @@ class RelationalFunction(torch.autograd.Function):
         f_w, f_b = params[2 * L:2 * L + 3], params[2 * L + 3:2 * L + 6]
         H._dev(x, "x")
         H._dev(q, "qst")
-        chain = precision == "f16s"
+        chain = precision in ("f16s", "f16s2")
         code = H.RN_BF16 if chain else H.dtype_code(precision)
         x = x.float() if x.dtype != torch.float32 else x
         q = q.float().contiguous() if (q.dtype != torch.float32 or not q.is_contiguous()) else q
@@ -462,7 +478,8 @@ class RelationalFunction(torch.autograd.Function):
                                'use "auto", "bf16" or "fp32" here')
         if coord is not None and not chain:
             raise RuntimeError("internal: a coordinate table was passed but the chain path does not apply (grid_path_ok)")
-        wfwd, wbwd = packed.get(plan, g_w, code, chain=chain, bwd_images=need_grad, f_w=f_w)
+        two_pass = precision == "f16s2" and not need_grad
+        wfwd, wbwd = packed.get(plan, g_w, code, chain=("two_pass" if two_pass else chain), bwd_images=need_grad, f_w=f_w)
         gb = [b.detach().contiguous() for b in g_b]
         G = plan.widths[-1]
         njp = n
@@ -471,7 +488,7 @@ class RelationalFunction(torch.autograd.Function):
             if plan.inject > 0:
                 inj_w = g_w[plan.inject].detach()
                 inj_w = inj_w if inj_w.is_contiguous() else inj_w.contiguous()
-            Hs, HL, xg, njp = chain_forward(x, q, plan, gb, packed, need_grad, inj_w=inj_w, coord=coord)
+            Hs, HL, xg, njp = chain_forward(x, q, plan, gb, packed, need_grad, inj_w=inj_w, coord=coord, two_pass=two_pass)
             inputs = [None] + Hs if Hs is not None else [None] * L
             if COPY_HEALTH_PROBE is not None and need_grad:
                 for l in range(1, L):                              # inputs[l] = the copy of H_{l-1}
@@ -816,14 +833,14 @@ class RelationalFunction(torch.autograd.Function):
 
 def relational_forward(x, q, mask, plan, packed, precision, g_w, g_b, f_w, f_b, label=None, coord=None):
     """-> log-probs, or (log-probs, mean NLL) when `label` is given."""
-    if precision not in PRECISIONS:
+    if precision not in _INTERNAL_PRECISIONS:
         raise ValueError("precision must be one of %r" % (PRECISIONS,))
     return RelationalFunction.apply(x, q, mask, plan, packed, precision, label, coord, *g_w, *g_b, *f_w, *f_b)
 
 
 def grid_path_ok(plan: LayerPlan, precision, B, n, k):
     """Shapes / modes whose kernels take the conv grid + the coordinate table directly: the chain path."""
-    return precision == "f16s" and chain_ok(plan, B, n)
+    return precision in ("f16s", "f16s2") and chain_ok(plan, B, n)
 
 
 def _direct_conv_ok(inp, conv_w, stride, padding):

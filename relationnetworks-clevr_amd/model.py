@@ -143,6 +143,10 @@ class RelationalLayer(RelationalLayerBase):
         # "auto" -> "f16s" where a kernel for it covers the shape (log-probs within ~2e-4 of the fp32 reference), else "fp32"
         # (exact-fp32 MFMA, ~5e-7): whatever "auto" picks meets the 1e-3 bar.  "bf16" (~1e-2) only on request.  DESIGN.md section 2.
         self.precision = hyp.get("precision", OPT.precision)
+        # eval(): the chain path with hi + lo split weights on EVERY g layer (no tile-dithered images) whenever nothing needs a gradient
+        # -- a question's log-probs then do not depend on its position in the batch or on the order of its objects (train.py:98-105
+        # evaluates with whatever batch size fits).  False: eval() runs the training arithmetic.  INTEGRATION.md section 1.
+        self.eval_two_pass = bool(hyp.get("eval_two_pass", OPT.eval_two_pass))
         self.forced_dropout_mask = None                  # tests: explicit (B, f_fc2) mask incl. 1/(1-p)
         self._packed = RF.PackedWeights()
         self._plan_cache = {}
@@ -210,8 +214,10 @@ class RelationalLayer(RelationalLayerBase):
         f_w = [self.f_fc1.weight, self.f_fc2.weight, self.f_fc3.weight]
         f_b = [self.f_fc1.bias, self.f_fc2.bias, self.f_fc3.bias]
         mask = self._dropout_mask(b, x.device)
-        return RF.relational_forward(x, qst, mask, plan, self._packed, self.resolved_precision(b, d, k), g_w, g_b, f_w, f_b, label=label,
-                                     coord=coord)
+        prec = self.resolved_precision(b, d, k)
+        if prec == "f16s" and not self.training and self.eval_two_pass:
+            prec = "f16s2"                                      # (functional: two passes where no gradient is needed, else plain f16s)
+        return RF.relational_forward(x, qst, mask, plan, self._packed, prec, g_w, g_b, f_w, f_b, label=label, coord=coord)
 
     def resolved_precision(self, b, d, k):
         """The arithmetic mode a forward pass on (b, d, k) objects runs in: `self.precision`, with "auto" resolved to

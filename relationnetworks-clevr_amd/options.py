@@ -1,7 +1,7 @@
 """Execution options of the MI355X path -- ONE explicit object, read from the process environment ONCE, at import.
 
 Nothing on the hot path looks at os.environ: dispatch depends on `OPT` only, so a call behaves the same whatever the
-environment does afterwards.  Eleven switches are left (round 3 had 31: the ones that only kept an older implementation alive for
+environment does afterwards.  Fourteen entries are left (round 3 had 31: the ones that only kept an older implementation alive for
 A/B history went with those implementations): the arithmetic mode, the two numerically visible choices of the chain path (e4m3
 copies, on-chip pair reductions) that tests pin against their alternatives, and the trainer's launch structure.  Every switch
 defaults to the fast path (tests use `override(...)`, not the environment).  The C library has no
@@ -14,6 +14,7 @@ import os
 # attribute -> (environment variable, default, meaning)
 _SPEC = {
     "precision":         ("RN_PRECISION", "auto", 'arithmetic mode of modules whose hyp has no "precision": auto | f16s | bf16 | fp32'),
+    "eval_two_pass":     ("RN_NO_EVAL_TWO_PASS", True, "eval() without gradients on the chain path: hi + lo split weights on every g layer instead of the tile-dithered single pass (log-probs independent of batch position / object order; ~1.6x the forward chain's time)"),
     "h8":                ("RN_H8", True, "e4m3 copies of H_0..2 for the weight gradients (False: bf16 copies, the last layer's dZ stored; what the trainer's copy guard falls back to)"),
     "chain_reduce":      ("RN_NO_CHAIN_REDUCE", True, "pair-axis reductions of layer 0's gradient inside the backward chain (dZ_0 never stored; n % 32 == 0)"),
     "wgrad_overlap":     ("RN_NO_WGRAD_OVERLAP", True, "weight gradients on side streams (bench.py switches it off to time every kernel alone)"),
@@ -25,6 +26,7 @@ _SPEC = {
     "graph_allreduce":   ("RN_NO_GRAPH_ALLREDUCE", True, "N > 1 over RCCL: the gradient all-reduce inside the captured step too (else eager, with the optimiser behind it)"),
     "native_dropout":    ("RN_NO_NATIVE_DROPOUT", True, "f_phi dropout mask from the library's counter-based generator (device-side draw counter: a replayed step graph needs no generator fills in front of it); False: torch's F.dropout"),
     "graph_adam":        ("RN_NO_GRAPH_ADAM", True, "clip + Adam (and, N > 1, the all-reduce) inside the captured step"),
+    "dp_timeout":        ("RN_DP_TIMEOUT", 300, "N > 1: seconds a trainer waits on other ranks / on the first in-graph exchange before the process gives up (exit 124); 0 = for ever"),
 }
 
 

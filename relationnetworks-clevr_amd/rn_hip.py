@@ -300,13 +300,15 @@ F16S_DITHER = 4      # tile-dithered hi images per g layer >= 1 (include/rn_hip.
 @_timed("g_fwd")
 def g_chain_fwd_rr_f16s_alg0(Xp16, Vc, n, Whis, Wlo0, biases, Hs, masks, xg_part, M, G, Vq=None, inject=0, njp=None, gate=False):
     """f16s forward chain with the factored first layer (fp16 object rows, no pair matrix).  Whis[0] / Wlo0: the hi / lo images of
-    layer 0; Whis[1..3]: (dither, 65536) fp16 tile-dithered hi images each.  njp > n: padded j axis (M = B * n * njp, Xp16 with a
-    trailing zero row, two partial rows per tile in xg_part).  gate: the last layer's ReLU gate also goes into the sign bits of the
-    e4m3 Hs[2] image (what relu_gate_image merges from masks[3]) -- the operand of the gate job of g_wgrad_blocked."""
+    layer 0; Whis[1..3]: (dither, 65536) fp16 tile-dithered hi images each.  Wlo0 a LIST of L lo images: the two-pass inference
+    arithmetic (hi + lo on every layer, Whis = the plain hi images; no Hs / masks).  njp > n: padded j axis (M = B * n * njp, Xp16
+    with a trailing zero row, two partial rows per tile in xg_part).  gate: the last layer's ReLU gate also goes into the sign bits
+    of the e4m3 Hs[2] image (what relu_gate_image merges from masks[3]) -- the operand of the gate job of g_wgrad_blocked."""
     L = len(Whis)
-    dither = Whis[1].numel() // 65536
+    two = isinstance(Wlo0, (list, tuple))
+    dither = 0 if two else Whis[1].numel() // 65536
     hp = (C.c_void_p * L)(*[w.data_ptr() for w in Whis])
-    lp = (C.c_void_p * L)(*([Wlo0.data_ptr()] + [None] * (L - 1)))
+    lp = (C.c_void_p * L)(*([w.data_ptr() for w in Wlo0] if two else [Wlo0.data_ptr()] + [None] * (L - 1)))
     bp = (C.c_void_p * L)(*[b.data_ptr() for b in biases])
     op = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in Hs]) if Hs is not None else None
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks]) if masks is not None else None

@@ -83,7 +83,8 @@ def test_copy_health_counters_against_a_numpy_decode(pkg):
 
 def test_copy_guard_switches_to_16_bit_copies(pkg, monkeypatch):
     """A model whose g-layer activations sit below e4m3's range at scale 1 (first g layer scaled down by 2^-12): the trainer's guard
-    must see > 5 % of the positive activations flushed at step 1, switch options.h8 off, re-capture, and keep training."""
+    must see > 5 % of the positive activations flushed BEFORE the first capture, switch the module's own e4m3 switch off (not the
+    process-wide option), and keep training -- into the same input tensors, with ONE capture."""
     from relationnetworks_clevr_amd import train as T, dp
     import contextlib, io, json, os
     hyp = dict(json.load(open(os.path.join(os.path.dirname(T.__file__), "config.json")))["hyperparams"]["original-fp"])
@@ -99,9 +100,18 @@ def test_copy_guard_switches_to_16_bit_copies(pkg, monkeypatch):
     monkeypatch.setattr(pkg.options.OPT, "h8", True)
     tr = dp.DataParallelTrainer(m, torch.optim.Adam(m.parameters(), lr=1e-4), use_graph=True)
     img, qst, lab = T.load_tensor_data(next(iter(T.SyntheticRelationalTask(64, 64, seed=2))), "cuda")
+    captures = []
+    orig = tr._capture_graph
+    monkeypatch.setattr(tr, "_capture_graph", lambda with_opt: (captures.append(with_opt), orig(with_opt))[1])
     with pytest.warns(UserWarning, match="16-bit copies"):
-        l0 = tr.step(img, qst, lab).item()
-    assert pkg.options.OPT.h8 is False and tr.copy_guard_log[0]["switched"]
+        bufs = tr.input_buffers(img, qst, lab)              # what train_epoch does first: the guard runs in front of the capture
+    l0 = tr.step(*bufs).item()
+    assert len(captures) == 1 and tr.input_buffers(img, qst, lab)[0] is bufs[0]
+    assert pkg.options.OPT.h8 is True and m.rl._packed.h8 is False and tr.copy_guard_log[0]["switched"]
     assert tr.copy_guard_log[0]["layers"][0]["flushed"] > 0.05
-    l1 = tr.step(img, qst, lab).item()
+    l1 = tr.step(*bufs).item()
     assert np.isfinite(l0) and np.isfinite(l1)
+    # the switch is the module's: another model in the same process still gets e4m3 copies
+    with contextlib.redirect_stdout(io.StringIO()):
+        m2 = pkg.RN(A, hyp)
+    assert m2.rl._packed.h8 is True

@@ -83,6 +83,50 @@ def test_two_rank_dp_equals_single_process(tmp_path, kind):
         assert torch.allclose(got["sd"][k], v, rtol=1e-4, atol=1e-6), k
 
 
+def _ctl_worker(rank, world, port, out_dir):
+    from relationnetworks_clevr_amd import dp
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctl = dp.ControlPlane()
+    res = {"all_true": ctl.all_ok(True), "one_false": ctl.all_ok(rank != 1), "any_one": ctl.any_of(rank == 1), "any_none": ctl.any_of(False),
+           "gather": ctl.gather(None if rank == 0 else "boom on %d" % rank), "ranks_seen": ctl.ranks_seen()}
+    torch.save(res, os.path.join(out_dir, "ctl%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_control_plane_decisions_are_the_jobs_not_the_ranks(tmp_path):
+    """dp.ControlPlane: a condition that holds on ONE rank only -- a capture that throws, a self-check that
+    mismatches -- must give the SAME answer on every rank, or the ranks end up in different exchange modes and hang."""
+    mp.spawn(_ctl_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(os.path.join(str(tmp_path), "ctl%d.pt" % r))
+        assert res["all_true"] is True and res["one_false"] is False and res["any_one"] is True and res["any_none"] is False
+        assert res["gather"] == [None, "boom on 1"] and res["ranks_seen"] == [0, 1]
+    from relationnetworks_clevr_amd import dp
+    one = dp.ControlPlane()                               # no process group: every decision is the local one
+    assert one.world == 1 and one.all_ok(False) is False and one.all_ok(True) is True and one.ranks_seen() == [0] and one.gather("x") == ["x"]
+
+
+def test_watchdog_exits_instead_of_blocking():
+    """dp.Watchdog (VERDICT r4 item 1c): a wait that never ends becomes exit code 124 with a message naming what was waited for;
+    a region that finishes in time is left alone."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "from relationnetworks_clevr_amd import dp\n"
+            "wd = dp.Watchdog(rank=3)\n"
+            "with wd.guard('quick region', 5.0):\n    time.sleep(0.05)\n"
+            "print('survived', flush=True)\n"
+            "with wd.guard('replay of the step graph', 0.3):\n    time.sleep(30)\n"
+            "print('not reached', flush=True)\n") % root
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 124, (p.returncode, p.stderr[-500:])
+    assert "survived" in p.stdout and "not reached" not in p.stdout
+    assert "rank 3" in p.stderr and "replay of the step graph" in p.stderr and "RN_NO_GRAPH_ALLREDUCE" in p.stderr
+
+
 def test_flat_bucket_semantics():
     from relationnetworks_clevr_amd import dp
     m = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
@@ -103,6 +147,28 @@ def test_flat_bucket_semantics():
         assert torch.allclose(p.grad, g * min(1.0, 0.5 / (float(tot) + 1e-6)), atol=1e-7)
     b.zero_()
     assert all(float(p.grad.abs().sum()) == 0 for p in m.parameters())
+    # unused (slot zeroed, cached as zero) -> written IN PLACE by a backward kernel -> unused again: the slot must be
+    # zeroed again, not trusted to be zero still
+    w0, off0 = b.params[0], b.offsets[0]
+
+    def others():                                          # parameters 1, 2: fresh tensors; parameter 3: written in its slot (so that
+        b.detach_()                                        # gather_() takes the slot-by-slot branch, not the one concatenation)
+        for p_ in b.params[1:3]:
+            p_.grad = torch.ones_like(p_)
+        p3, o3 = b.params[3], b.offsets[3]
+        p3.grad = b.flat[o3:o3 + p3.numel()].view_as(p3)
+    others()
+    b.gather_()                                            # parameter 0 unused: zeroed once, remembered
+    assert off0 in b._known_zero
+    others()
+    b.flat[off0:off0 + w0.numel()].fill_(7.0)              # what functional.grad_out's in-place writers do ...
+    w0.grad = b.flat[off0:off0 + w0.numel()].view_as(w0)   # ... and hand autograd: a view of the slot itself
+    b.gather_()
+    assert off0 not in b._known_zero and float(w0.grad.sum()) == 7.0 * w0.numel()
+    others()
+    b.gather_()                                            # unused again: the stale 7s must go
+    assert float(b.flat[off0:off0 + w0.numel()].abs().sum()) == 0.0
+    b.zero_()
     m(x).sum().backward()                       # accumulates into the same views
     for p, g in zip(m.parameters(), g1):
         assert torch.allclose(p.grad, g)

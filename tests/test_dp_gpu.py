@@ -156,7 +156,31 @@ def _data(cfg, B):
     return x.cuda(), q.cuda(), y.cuda()
 
 
-def _worker(rank, world, port, cfg, steps, out_path, backend="gloo"):
+def _trainer_class(inject):
+    """inject = None: the product trainer.  "rank1": the in-graph exchange is ASKED for over gloo (graph_allreduce=True), the
+    start-up self-check is replaced by a pass (gloo cannot be captured; the agreement call stays real) and the captured stand-in
+    collective raises on rank 1 only -- rank 0's capture succeeds.  "selfcheck": the real self-check runs and fails (gloo)."""
+    from relationnetworks_clevr_amd import dp
+    if inject is None:
+        return dp.DataParallelTrainer, {}
+
+    class Injected(dp.DataParallelTrainer):
+        def _graph_collective(self, tensor):
+            if inject == "rank1":
+                if self.rank == 1:
+                    raise RuntimeError("injected capture failure on rank 1")
+                return                                      # rank 0: a stand-in that captures fine
+            super()._graph_collective(tensor)
+
+        def _exchange_self_check(self):
+            if inject == "rank1":
+                self.ctl.gather(None)
+                return None
+            return super()._exchange_self_check()
+    return Injected, {"graph_allreduce": True}
+
+
+def _worker(rank, world, port, cfg, steps, out_path, backend="gloo", inject=None):
     from relationnetworks_clevr_amd import dp
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -168,8 +192,11 @@ def _worker(rank, world, port, cfg, steps, out_path, backend="gloo"):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     model = _model(cfg, seed=3 + rank)                  # different init per rank: the broadcast must fix it
     opt = _adam(model)
-    tr = dp.DataParallelTrainer(model, opt, clip_norm=CLIP, use_graph=True)
+    cls, kw = _trainer_class(inject)
+    tr = cls(model, opt, clip_norm=CLIP, use_graph=True, timeout_s=240, **kw)
     assert tr._fused_opt is not None
+    if inject is not None:
+        assert tr._opt_in_graph and tr.exchange_mode() == "in-graph"      # (asked for; the first step decides)
     x, q, y = _data(cfg, 8)
     sh = x.shape[0] // world
     sl = slice(rank * sh, (rank + 1) * sh)
@@ -179,23 +206,40 @@ def _worker(rank, world, port, cfg, steps, out_path, backend="gloo"):
         tr.bucket.check_attached()
     lt = torch.tensor(losses, dtype=torch.float64)
     dist.all_reduce(lt)
+    modes = tr.ctl.gather((tr.exchange_mode(), tr.exchange_fallback))
     if rank == 0:
-        torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "loss": (lt / world).tolist()}, out_path)
+        torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "loss": (lt / world).tolist(), "modes": modes,
+                    "checks": tr.exchange_checks, "ranks_seen": tr.ctl.ranks_seen()}, out_path)
+    else:
+        tr.ctl.ranks_seen()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _check_two_ranks_against_one(tmp_path, cfg, backend):
+def _check_two_ranks_against_one(tmp_path, cfg, backend, inject=None):
     from relationnetworks_clevr_amd import dp
     steps = 3
     out = str(tmp_path / "dp.pt")
     try:
-        mp.spawn(_worker, args=(2, _free_port(), cfg, steps, out, backend), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), cfg, steps, out, backend, inject), nprocs=2, join=True)
     except Exception as e:                                 # gloo built without device-tensor support: nothing to test here
         if backend == "gloo" and "gloo" in str(e).lower() and ("cuda" in str(e).lower() or "device" in str(e).lower()):
             pytest.skip("gloo cannot carry GPU tensors in this build: %s" % str(e)[:200])
         raise
     got = torch.load(out)
+    assert got["ranks_seen"] == [0, 1]
+    if inject is not None:
+        # BOTH ranks ended up with the eager exchange and the same reason, although only one of them saw a failure
+        assert [m_[0] for m_ in got["modes"]] == ["eager", "eager"], got["modes"]
+        assert got["modes"][0][1] == got["modes"][1][1] and got["modes"][0][1]
+        if inject == "rank1":
+            assert "rank(s) [1]" in got["modes"][0][1] and "injected capture failure" in got["modes"][0][1]
+            assert got["checks"]["capture"][0] is None and "injected" in got["checks"]["capture"][1]
+        else:
+            assert "self-check" in got["modes"][0][1]
+    elif backend == "nccl":
+        assert [m_[0] for m_ in got["modes"]] == ["in-graph", "in-graph"], got["modes"]
+        assert got["checks"].get("self_check") == "passed" and got["checks"].get("first_step_signatures_equal") is True
     model = _model(cfg, seed=3)
     init = {k: v.detach().cpu().float().clone() for k, v in model.state_dict().items()}
     opt = _adam(model)
@@ -223,6 +267,15 @@ def _check_two_ranks_against_one(tmp_path, cfg, backend):
 @pytest.mark.parametrize("cfg", ["original-sd", "original-fp"])
 def test_two_ranks_on_one_gpu_equal_one_rank_on_the_whole_batch(tmp_path, cfg):
     _check_two_ranks_against_one(tmp_path, cfg, "gloo")
+
+
+@pytest.mark.parametrize("inject", ["rank1", "selfcheck"])
+def test_exchange_fallback_is_agreed_by_all_ranks(tmp_path, inject):
+    """VERDICT r4 item 1 / ADVICE r4: the in-graph exchange is asked for, and (rank1) the capture of the step fails on rank 1 ONLY
+    while rank 0's succeeds, or (selfcheck) the start-up self-check of the captured all-reduce fails (gloo cannot be captured).
+    Either way the decision must be the job's: both ranks end up with the eager exchange, say why, train on without hanging, and
+    still equal one rank on the whole batch."""
+    _check_two_ranks_against_one(tmp_path, "original-fp", "gloo", inject=inject)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the RCCL (backend nccl) all-reduce over xGMI")
@@ -258,3 +311,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["sustained"]["steps"] >= 5 and d["sustained"]["value"] > 0            # (the same step count on both ranks: no hang)
     # a multi-rank line says where a step's time outside forward + backward goes (attribution of a scaling miss)
     assert d["allreduce_us_per_step"] > 0 and d["optimizer_us_per_step"] > 0 and d["allreduce_bytes"] == 4 * 484580
+    # ... who took part, where the exchange ran and (had the in-graph form been asked for and refused) why not
+    c = d["comm"]
+    assert c["ranks_seen"] == [0, 1] and c["exchange_mode"] == "eager" and c["exchange_fallback"] is None and c["backend"] == "gloo"
+    assert c["watchdog_s"] > 0

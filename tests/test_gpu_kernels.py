@@ -341,8 +341,9 @@ def rr_mask_decode(buf, M, l):
     return g.reshape(M, 256)
 
 
-def f16s_alg0_emulation(x, q, Ws, bs, n, njp):
-    """float64 emulation of the FACTORED f16s chain's arithmetic (rn_g_chain_fwd_rr_f16s_alg0; model.py:108-152) on the padded pair
+def f16s_alg0_emulation(x, q, Ws, bs, n, njp, two_pass=False):
+    """(two_pass: layers 1..3 multiply the hi + lo split of the weights instead of the tile's dithered image -- dither == 0.)
+    float64 emulation of the FACTORED f16s chain's arithmetic (rn_g_chain_fwd_rr_f16s_alg0; model.py:108-152) on the padded pair
     space: layer 0 = fp16(x_j) @ (hi + lo of W0[:, :k])^T + [W0[:, k:2k] x_i + W0[:, 2k:] q + b0] (the bracket exact), layers 1..3 =
     the fp16-rounded previous activation @ the tile's dithered hi image; -> (list of pre-activations z_l (Mp, G), valid-row mask
     (Mp,), the EXACT fp32-model activations of the last layer (Mp, G))."""
@@ -363,7 +364,10 @@ def f16s_alg0_emulation(x, q, Ws, bs, n, njp):
     prev = f16r(np.maximum(zs[0], 0)).astype(np.float64)
     for l in range(1, L):
         z = np.empty((Mp, G))
-        for d, im in enumerate(dither_images(Ws[l])):
+        if two_pass:
+            hi = f16r(Ws[l]); lo = f16r(Ws[l] - hi)
+            z[:] = prev @ (hi.astype(np.float64) + lo.astype(np.float64)).T + bs[l]
+        for d, im in enumerate(dither_images(Ws[l]) if not two_pass else []):
             z[timg == d] = prev[timg == d] @ im.astype(np.float64).T + bs[l]
         zs.append(z)
         exact = np.maximum(exact @ Ws[l].astype(np.float64).T + bs[l], 0)
@@ -458,6 +462,59 @@ def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
         assert torch.equal(Hg[2].view(torch.uint8), want.view(torch.uint8))
         assert torch.equal(unblock(Hg[2]).view(torch.uint8) & 0x7f, Hs8[2].view(torch.uint8))
         assert torch.equal(unblock(Hg[2]).view(torch.uint8) >> 7, gate_image_ref(m8[3], M).to(torch.uint8))
+
+
+@pytest.mark.parametrize("B,n", [(5, 64), (3, 32), (3, 196), (4, 40)])
+def test_g_chain_fwd_rr_f16s_two_pass(H, B, n):
+    """dither == 0: hi + lo split weights on EVERY layer (the inference arithmetic of eval()).  Pair sums against
+    the float64 emulation of that arithmetic (2e-5: fp32 accumulation order) and against the exact chain (3e-4: the fp16 rounding of
+    the activations is all that is left); and the point of the mode -- NOTHING depends on where a question sits in the batch: the
+    same questions in reversed order give the same per-question sums, bitwise where a question is whole tiles (n % 32 == 0),
+    to fp32 summation order on the padded j axis; a training-style call (H / masks) with dither == 0 is refused."""
+    L, G, k, Q = 4, 256, 26, 128
+    njp = (n + 31) // 32 * 32
+    Mp, kt = B * n * njp, 2 * 26 + 128
+    x = formula.hash_uniform((B, n, k), 400, -1, 1).astype(np.float32)
+    q = formula.hash_uniform((B, Q), 401, -1, 1).astype(np.float32)
+    Ws = [formula.hash_uniform((G, kt if l == 0 else G), 410 + l, -0.15, 0.15).astype(np.float32) for l in range(L)]
+    bs = [formula.hash_uniform((G,), 420 + l, -0.3, 0.3).astype(np.float32) for l in range(L)]
+    wd = [dev(w) for w in Ws]
+    w0T = torch.empty(kt, G, device="cuda")
+    his = [torch.empty(1, 65536, dtype=torch.float16, device="cuda") for _ in range(L)]
+    los = [torch.empty(65536, dtype=torch.float16, device="cuda") for _ in range(L)]
+    jobs = [(wd[0], kt, 1, G, k, his[0], 4 | 1), (wd[0], kt, 1, G, k, los[0], 8 | 1)]
+    jobs += [(wd[l], G, 1, G, G, his[l], 4) for l in range(1, L)] + [(wd[l], G, 1, G, G, los[l], 8) for l in range(1, L)]
+    H.pack_matrix_frag_many(jobs + [(wd[0], kt, 1, G, kt, w0T, 2)])
+    bd = [dev(b) for b in bs]
+    ppt = 2 if njp != n else 1
+
+    def run(xx, qq):
+        Xp = torch.zeros(B * n + 1, 64, dtype=torch.float16, device="cuda"); Vc = torch.empty(B * n, G, device="cuda")
+        H.pair_tables(dev(xx), dev(qq), w0T, bd[0], Xp, Vc, B, n, k, Q, G)
+        part = torch.full((Mp // 256 * ppt, G), float("nan"), device="cuda")
+        H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, his, los, bd, None, None, part, Mp, G, njp=njp)
+        xg = torch.full((B, G), float("nan"), device="cuda")
+        if ppt == 2:
+            H.pair_sum_tiles(part, xg, Mp, n * njp, G)
+        else:
+            xg.copy_(part.view(B, (n * n) // 256, G).sum(1))
+        torch.cuda.synchronize()
+        return xg, part
+    xg, part = run(x, q)
+    zs, valid, exact = f16s_alg0_emulation(x, q, Ws, bs, n, njp, two_pass=True)
+    want = (np.maximum(zs[-1], 0) * valid[:, None]).reshape(B, n * njp, G).sum(1)
+    assert rel(xg.cpu().numpy(), want) <= 2e-5
+    assert rel(xg.cpu().numpy(), (exact * valid[:, None]).reshape(B, n * njp, G).sum(1)) <= 3e-4
+    xg_r, _ = run(x[::-1].copy(), q[::-1].copy())
+    if njp == n and (n * n) % 256 == 0:
+        assert torch.equal(xg_r.flip(0), xg)
+    else:
+        assert rel(xg_r.flip(0).cpu().numpy(), xg.cpu().numpy()) <= 2e-6
+    with pytest.raises(RuntimeError, match="inference arithmetic"):
+        Hs = [torch.empty(Mp, G, dtype=torch.bfloat16, device="cuda") for _ in range(3)] + [None]
+        masks = list(torch.zeros(L, H.g_chain_rr_mask_bytes(Mp), dtype=torch.uint8, device="cuda"))
+        H.g_chain_fwd_rr_f16s_alg0(torch.zeros(B * n + 1, 64, dtype=torch.float16, device="cuda"), torch.zeros(B * n, G, device="cuda"), n, his, los, bd,
+                                   Hs, masks, part, Mp, G, njp=njp)
 
 
 @pytest.mark.parametrize("B,n", [(16, 196), (4, 40)])

@@ -9,7 +9,8 @@ gpurun_out/parity_report.jsonl by every run):
       under a different (equally valid) fp32 summation order; one flipped unit moves one object's dx by ~1e-3 of
       max|dx| (measured: sparse (b, j) rows at 6e-4..1.3e-3, everything else at 1e-6);
   precision="f16s" / "auto" (the HEADLINE mode: fp16 activations x split fp16 weights, bf16 backward): log-probs
-      <= 2e-4 (measured 2e-6..7.4e-5; the bar is 1e-3), argmax agreement with the reference = 1.0, gradients
+      <= 1e-3 = the contract (CONTRACT) and, separately, <= 3e-4 = a regression guard at 1.5x the worst measured value
+      (F16S_GUARD; measured 2e-6..2.0e-4), argmax agreement with the reference = 1.0, gradients
       <= 1.2e-2 in relative L2 (measured 2e-3..5e-3: bf16 storage of dZ / H in the backward pass);
   precision="bf16" (single-pass bf16, the throughput mode -- NOT the headline): log-probs <= 3e-3 with formula
       weights (measured 0.4e-3..1.5e-3) and <= 2e-2 on the released checkpoints (measured 0.9e-2..1e-2: the
@@ -30,6 +31,13 @@ from oracle import formula
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+# Two bounds on the headline mode's log-probs, on purpose (a bound set AT the measurement is a coin flip):
+CONTRACT = 1e-3       # north_star: "logits matching the reference PyTorch path within 1e-3 relative fp32 tolerance" -- the parity bar
+# ... and a REGRESSION GUARD that says the arithmetic has not got worse: 1.5x the worst value measured on MI355X over rounds 3-5
+# (1.99e-4: the released ir-fp checkpoint in the training arithmetic; G-fp64 1.6e-4; profiles/r05_parity_report.jsonl has every value).
+# A failure of the guard alone means "look at what changed", not "parity lost".
+F16S_GUARD = 3e-4
+TWO_PASS_GUARD = 1.5e-4     # the eval() arithmetic (hi + lo on every layer): measured <= 7e-5
 RL_TAGS = ["G-sd4", "G-irsd4", "G-fp-small", "G-ir-small", "G-fp64", "G-ir64", "G-fp196", "G-drop"]
 # relative-L2 gradient bounds of the bf16 mode, ~2x the measured value per fixture (dx, dq, bias grads)
 BF16_GRAD_L2 = {"G-drop": 3e-2, "G-fp-small": 3e-2, "G-fp196": 3e-2, "G-fp64": 8e-2, "G-sd4": 8e-2, "G-irsd4": 0.12,
@@ -129,7 +137,8 @@ def test_relational_layer_f16s_parity(pkg, tag):
     e_w = gold.check_grads(g, grads, 3e-2, per)
     report(tag, precision="f16s", log_probs=e_lp, dx_l2=e_dx, dq_l2=e_dq, params_l2=e_b, argmax_agree=agree, param_grads_max=e_w,
            g_weight_grads={k: v for k, v in per.items() if k.startswith("g_layers") and k.endswith("weight")})
-    assert e_lp <= 2e-4
+    assert e_lp <= CONTRACT
+    assert e_lp <= F16S_GUARD, "regression guard (the contract, 1e-3, still holds)"
     assert agree == 1.0
     # gradients: the backward pass of a ReLU network depends on the forward pass through the GATES only; one-pass fp16 weights
     # (2^-12 relative per row -- the dithering averages over tiles, not inside a row) flip the gate of ~1e-3 of the units, those
@@ -151,7 +160,7 @@ def test_headline_mode_is_the_module_default_and_meets_the_bar(pkg, tag):
     """precision="auto" -- what a user who touches nothing gets, and what bench.py reports as `value` -- is parity-clean on EVERY
     fixture: "f16s" on the headline shape family (four 256-wide g layers -- the 14 x 14 grid, n = 196, on the padded j axis),
     "fp32" where no f16s kernel covers the shape (the 512-wide *-sd models of config.json) -- never single-pass bf16.
-    Log-probs within 2e-4 of the reference (bar: 1e-3), same answers."""
+    Log-probs within the contract (1e-3) and the regression guard (3e-4) of the reference, same answers."""
     g = gold.load(tag)
     hyp = formula.HYP[g["meta"]["cfg"]]
     rl = pkg.RelationalLayer(hyp["rl_in_size"], formula.ADICT, hyp["lstm_hidden"], dict(hyp))
@@ -160,7 +169,8 @@ def test_headline_mode_is_the_module_default_and_meets_the_bar(pkg, tag):
     lp, loss, dx, dq, grads = run_rl(pkg, g, "auto")
     e_lp = gold.rel_err(lp, g["log_probs"])
     report(tag, precision="auto", resolved=resolved, log_probs=e_lp)
-    assert e_lp <= 2e-4 and (lp.argmax(1) == g["log_probs"].argmax(1)).all()
+    assert e_lp <= CONTRACT and (lp.argmax(1) == g["log_probs"].argmax(1)).all()
+    assert e_lp <= F16S_GUARD, "regression guard (the contract, 1e-3, still holds)"
 
 
 @pytest.mark.parametrize("tag,precision", [("G-fp64", "f16s"), ("G-ir64", "f16s")])
@@ -258,9 +268,9 @@ def test_f16s_refuses_unsupported_shapes(pkg):
         run_rl(pkg, g, "f16s")
 
 
-def build_full(pkg, g, precision):
+def build_full(pkg, g, precision, **extra):
     meta = g["meta"]
-    hyp = dict(formula.HYP[meta["cfg"]], precision=precision)
+    hyp = dict(formula.HYP[meta["cfg"]], precision=precision, **extra)
 
     class Args:
         qdict_size = formula.QDICT
@@ -271,10 +281,11 @@ def build_full(pkg, g, precision):
 
 
 @pytest.mark.parametrize("tag", ["G-e2e", "G-e2e-ir"])
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("bf16", 3e-3), ("f16s", 2e-4)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("bf16", 3e-3), ("f16s", F16S_GUARD), ("f16s-eval", TWO_PASS_GUARD)])
 def test_full_model_e2e(pkg, tag, precision, tol):
+    """"f16s": the TRAINING arithmetic (eval_two_pass off -- what bench.py times); "f16s-eval": what eval() runs by default."""
     g = gold.load(tag)
-    m, meta = build_full(pkg, g, precision)
+    m, meta = build_full(pkg, g, precision.split("-")[0], eval_two_pass=precision.endswith("-eval"))
     shapes = {k: tuple(v) for k, v in json.loads(str(g["state_names"])).items()}
     sd = formula.formula_fill_state(shapes, meta["seed"])
     res = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
@@ -288,17 +299,21 @@ def test_full_model_e2e(pkg, tag, precision, tol):
         qe = m.text(qst).cpu().numpy()
     e = gold.rel_err(lp, g["log_probs"])
     report(tag, precision=precision, log_probs=e, conv=gold.rel_err(conv, g["conv_out"]), qst=gold.rel_err(qe, g["qst_emb"]))
-    assert e <= tol
+    assert e <= (CONTRACT if precision.startswith("f16s") else tol)
+    assert e <= tol, "regression guard"
 
 
 @pytest.mark.parametrize("tag,precision,tol", [("pretrained_original_fp", "fp32", 2e-6), ("pretrained_ir_fp", "fp32", 2e-6),
                                                ("pretrained_original_fp", "bf16", 2e-2), ("pretrained_ir_fp", "bf16", 2e-2),
-                                               ("pretrained_original_fp", "f16s", 2e-4), ("pretrained_original_fp", "auto", 2e-4),
-                                               ("pretrained_ir_fp", "f16s", 2e-4), ("pretrained_ir_fp", "auto", 2e-4)])
+                                               ("pretrained_original_fp", "f16s", F16S_GUARD), ("pretrained_original_fp", "auto", F16S_GUARD),
+                                               ("pretrained_ir_fp", "f16s", F16S_GUARD), ("pretrained_ir_fp", "auto", F16S_GUARD),
+                                               ("pretrained_original_fp", "auto-eval", TWO_PASS_GUARD), ("pretrained_ir_fp", "auto-eval", TWO_PASS_GUARD)])
 def test_released_checkpoints_load_and_match(pkg, tag, precision, tol):
-    """README.md:86-95 checkpoints (as arrays): strict key match + log-probs."""
+    """README.md:86-95 checkpoints (as arrays): strict key match + log-probs.  "f16s" / "auto": the TRAINING
+    arithmetic (eval_two_pass off: the tile-dithered single pass bench.py times); "auto-eval": what eval() runs by default (hi + lo
+    split weights on every g layer).  The headline modes are held to the CONTRACT (1e-3) and, separately, to a regression guard."""
     g = gold.load(tag)
-    m, meta = build_full(pkg, g, precision)
+    m, meta = build_full(pkg, g, precision.split("-")[0], eval_two_pass=precision.endswith("-eval"))
     sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd/")}
     res = m.load_state_dict(sd, strict=False)
     assert not res.unexpected_keys and all(k.endswith("num_batches_tracked") for k in res.missing_keys), res
@@ -310,7 +325,9 @@ def test_released_checkpoints_load_and_match(pkg, tag, precision, tol):
     e = gold.rel_err(lp, g["log_probs"])
     agree = float((lp.argmax(1) == g["log_probs"].argmax(1)).mean())
     report(tag, precision=precision, log_probs=e, argmax_agree=agree)
-    assert e <= tol
+    if precision != "bf16" and precision != "fp32":
+        assert e <= CONTRACT
+    assert e <= tol, "regression guard" if precision not in ("bf16", "fp32") else "bound"
     if precision != "bf16":
         assert agree == 1.0
 
@@ -521,7 +538,7 @@ def test_full_size_properties(pkg, precision):
     lp_p, dx_p, dq_p = run(x[:, perm].contiguous(), q, lab)
     # (f16s: a pair row's position decides which of the tile-dithered weight images it multiplies -- a permutation changes more
     # than summation order, by what the mode's accuracy class allows: 2e-4)
-    tol = {"fp32": 2e-6, "bf16": 2e-5}.get(precision, 2e-4)
+    tol = {"fp32": 2e-6, "bf16": 2e-5}.get(precision, F16S_GUARD)
     assert gold.rel_err(lp_p.cpu().numpy(), lp.cpu().numpy()) <= tol
     assert l2rel(dx_p.cpu().numpy(), dx[:, perm].cpu().numpy()) <= (1e-5 if precision == "fp32" else 2e-2)
     assert l2rel(dq_p.cpu().numpy(), dq.cpu().numpy()) <= (1e-5 if precision == "fp32" else 2e-2)
@@ -536,15 +553,60 @@ def test_full_size_properties(pkg, precision):
         ref, _ = _full_rl(pkg, "fp32")
         ref.load_state_dict(rl.state_dict())
         lp_r = ref(x, q).detach()
-        assert gold.rel_err(lp.cpu().numpy(), lp_r.cpu().numpy()) <= (2e-4 if precision == "f16s" else 1e-2)
+        assert gold.rel_err(lp.cpu().numpy(), lp_r.cpu().numpy()) <= (F16S_GUARD if precision == "f16s" else 1e-2)
+
+
+@pytest.mark.parametrize("cfg", ["original-fp", "ir-fp"])
+def test_eval_log_probs_do_not_depend_on_batch_position_or_object_order(pkg, cfg):
+    """VERDICT r4 weak #3 / train.py:98-105 (the reference evaluates with whatever batch size fits): in eval() without gradients the
+    chain path multiplies hi + lo split weights on every g layer (options.eval_two_pass) instead of the tile-dithered single pass --
+    a question's log-probs are then the same in a batch of 64, alone in a slice of 4 at another batch position, and for any order
+    of its objects (<= 5e-5; measured ~1e-6: fp32 summation order), and within TWO_PASS_GUARD of the exact fp32 mode.  With the
+    option off eval() runs the training arithmetic, whose weight image depends on the pair row's tile (<= F16S_GUARD)."""
+    B, n, k, Q = 64, 64, 26, 128
+    hyp = dict(formula.HYP[cfg], precision="auto")
+    torch.manual_seed(11)
+    rl = pkg.RelationalLayer(hyp["rl_in_size"], formula.ADICT, hyp["lstm_hidden"], hyp).cuda().eval()
+    assert rl.eval_two_pass is True
+    x = torch.from_numpy(formula.hash_uniform((B, n, k), 900, -1, 1).astype(np.float32)).cuda()
+    q = torch.from_numpy(formula.hash_uniform((B, Q), 901, -1, 1).astype(np.float32)).cuda()
+    perm = torch.from_numpy(np.random.RandomState(3).permutation(n)).cuda()
+    errs = {}
+    for two in (True, False):
+        rl.eval_two_pass = two
+        with torch.no_grad():
+            lp = rl(x, q)
+            lp_s = rl(x[20:24].contiguous(), q[20:24].contiguous())
+            lp_o = rl(x[1:5].contiguous(), q[1:5].contiguous())              # (an odd tile offset: question 1 starts at tile 16)
+            lp_p = rl(x[:, perm].contiguous(), q)
+        errs[two] = (gold.rel_err(lp_s.cpu().numpy(), lp[20:24].cpu().numpy()), gold.rel_err(lp_o.cpu().numpy(), lp[1:5].cpu().numpy()),
+                     gold.rel_err(lp_p.cpu().numpy(), lp.cpu().numpy()))
+        if two:
+            lp2 = lp
+    ref = pkg.RelationalLayer(hyp["rl_in_size"], formula.ADICT, hyp["lstm_hidden"], dict(hyp, precision="fp32")).cuda().eval()
+    ref.load_state_dict(rl.state_dict())
+    with torch.no_grad():
+        e_ref = gold.rel_err(lp2.cpu().numpy(), ref(x, q).cpu().numpy())
+    report("eval-invariance-" + cfg, precision="auto", two_pass=errs[True], training_arithmetic=errs[False], two_pass_vs_fp32=e_ref)
+    assert max(errs[True]) <= 5e-5, errs
+    assert max(errs[False]) <= F16S_GUARD, errs
+    assert e_ref <= TWO_PASS_GUARD
+    # a forward pass that needs a gradient runs the training arithmetic whatever the mode (the backward needs its masks / copies)
+    rl.eval_two_pass = True
+    xg = x[:4].clone().requires_grad_(True)
+    lp_g = rl(xg, q[:4].contiguous())
+    rl.train(); rl.forced_dropout_mask = torch.ones(4, rl.f_fc2.out_features, device="cuda")
+    lp_t = rl(xg, q[:4].contiguous())
+    assert torch.equal(lp_g, lp_t)
 
 
 # ----------------------------------------------------------------------------- BASELINE configs[4] at its real size
 @pytest.mark.parametrize("precision", ["auto", "bf16", "f16s", "fp32"])
 def test_stress_config_real_dispatch(pkg, precision):
-    """original-fp stress: 14x14 grid (n = 196), B = 32 -- M = 1,229,312 pair rows, n*n % 32 != 0: the register-resident chain
-    runs on a pair matrix with waves that straddle two questions, H_3 is stored for the stand-alone pair sum, the last
-    wgrad reads a stored dZ_3 ("auto"/"f16s": the LDS-resident split-weight chain).  Checked against G-fp196-b32, recorded
+    """original-fp stress: 14x14 grid (n = 196), B = 32 -- M = 1,229,312 pair rows, n % 32 != 0: "auto" / "f16s" run the factored
+    register-resident chain on the PADDED j axis (196 -> 224 pair rows per (question, i) group, 256-row tiles that may straddle
+    two questions, two partial pair-sum rows per tile; no pair matrix, no stored H_3 / dZ_3); "bf16" / "fp32" the per-layer
+    kernels on the materialised pair matrix.  Checked against G-fp196-b32, recorded
     from the reference at this very size (make_golden.py stress): log-probs, loss, dq, dx (norm + 4096 sampled entries),
     bias gradients, weight-gradient norms + samples; plus the size-independent properties (object permutation, batch slice)."""
     g = gold.load("G-fp196-b32")
@@ -579,7 +641,7 @@ def test_stress_config_real_dispatch(pkg, precision):
     agree = float((lp.argmax(1) == g["log_probs"].argmax(1)).mean())
     report("G-fp196-b32", precision=precision, resolved=rl.resolved_precision(32, 196, 26), log_probs=e_lp, loss=abs(loss - float(g["loss"])) / float(g["loss"]),
            dq_l2=e_dq, dx_sample_l2=e_dxs, dx_norm=e_dxn, bias_l2=e_b, wnorm=e_wn, argmax_agree=agree)
-    lp_tol, g_tol = {"fp32": (1e-5, 1e-3), "f16s": (2e-4, 1.2e-2), "auto": (2e-4, 1.2e-2), "bf16": (3e-3, 6e-2)}[precision]
+    lp_tol, g_tol = {"fp32": (1e-5, 1e-3), "f16s": (F16S_GUARD, 1.2e-2), "auto": (F16S_GUARD, 1.2e-2), "bf16": (3e-3, 6e-2)}[precision]
     assert np.isfinite(lp).all() and e_lp <= lp_tol
     assert abs(loss - float(g["loss"])) <= max(lp_tol, 1e-6) * 10 * abs(float(g["loss"]))
     assert e_dq <= g_tol and e_dxs <= g_tol and e_dxn <= g_tol and e_b <= g_tol and e_wn <= g_tol
@@ -589,7 +651,7 @@ def test_stress_config_real_dispatch(pkg, precision):
     # M = 8 * 196^2 stays a multiple of 128, so that "auto" / "f16s" run the same kernels on the slice)
     sl = slice(8, 16)
     lp_s, _, dx_s, dq_s = run(np.ascontiguousarray(x[sl]), np.ascontiguousarray(q[sl]), labt[sl])
-    ptol = {"fp32": 2e-6, "bf16": 5e-5}.get(precision, 2e-4)     # (f16s / auto: the tile-dithered weight image depends on the row's position)
+    ptol = {"fp32": 2e-6, "bf16": 5e-5}.get(precision, F16S_GUARD)     # (f16s / auto: the tile-dithered weight image depends on the row's position)
     assert gold.rel_err(lp_s, lp[sl]) <= ptol
     gt = 1e-5 if precision == "fp32" else 3e-2
     assert l2rel(dx_s * (8 / 32), dx[sl]) <= gt and l2rel(dq_s * (8 / 32), dq[sl]) <= gt       # (mean-loss scaling)
