@@ -399,6 +399,7 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     if dry:
+        args.batch = args.batch or 64
         return dry_run(args, world, rank, backend)
     if os.environ.get("RN_BENCH_SAME_GPU", "0") == "1":     # tests: every rank on device 0 (with RN_BENCH_BACKEND=gloo: RCCL refuses that)
         local = 0

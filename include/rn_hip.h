@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RN_ABI_VERSION 6   /* bumped whenever a signature or a buffer layout of this header changes */
+#define RN_ABI_VERSION 7   /* bumped whenever a signature or a buffer layout of this header changes */
 
 enum { RN_BF16 = 0, RN_F32 = 1, RN_F16 = 2, RN_FP8 = 3 };   /* RN_F16: pair matrix / split weights of the f16s forward only;
                                                              * RN_FP8: OCP e4m3 copies of the stored activations (h_dtype / a_dtype) */
@@ -43,6 +43,13 @@ enum { RN_RELU = 1, RN_ACCUMULATE = 2 };
 
 int rn_abi_version(void);
 const char* rn_last_error(void);
+
+/* Host-side helper of the data-parallel trainer's fallback ladder (no reference counterpart; train.py:256-258 has no graphs): if
+ * `stream` is in capture mode -- in particular if its capture was INVALIDATED by something the capture did not allow and the
+ * framework's own end-of-capture threw before it reached hipStreamEndCapture -- end that capture and destroy whatever graph comes
+ * back, so that the thread leaves (global) capture mode and eager launches work again.  Returns 0 when the stream is not
+ * capturing afterwards (also when it never was), else the hipError_t. */
+int rn_stream_abandon_capture(void* stream);
 
 /* Bytes of caller-provided scratch (`ws`, `sync_ws`, mask buffers) an entry point needs for a shape -- ONE getter for all of them:
  * op names the entry point, a..d are its shape arguments in the order given here (unused ones 0). */

@@ -21,6 +21,23 @@ void rn_set_error(const char* fmt, ...) {
 extern "C" const char* rn_last_error(void) { return g_err; }
 extern "C" int rn_abi_version(void) { return RN_ABI_VERSION; }
 
+extern "C" int rn_stream_abandon_capture(void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  hipError_t e = hipStreamIsCapturing(s, &st);
+  if (e == hipSuccess && st == hipStreamCaptureStatusNone) return 0;
+  hipGraph_t g = nullptr;
+  (void)hipStreamEndCapture(s, &g);                      // (an invalidated capture returns an error here AND leaves capture mode)
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  st = hipStreamCaptureStatusNone;
+  e = hipStreamIsCapturing(s, &st);
+  (void)hipGetLastError();
+  if (e == hipSuccess && st == hipStreamCaptureStatusNone) return 0;
+  rn_set_error("rn_stream_abandon_capture: the stream is still capturing (status %d, %s)", (int)st, hipGetErrorString(e));
+  return e != hipSuccess ? (int)e : 1;
+}
+
 // ------------------------------------------------------------------ workspace sizes
 extern "C" size_t rn_workspace_bytes(int op, int a, int b, int c, int d) {
   switch (op) {

@@ -32,6 +32,15 @@ except ImportError:                                   # imported through the top
     from relationnetworks_clevr_amd.options import OPT               # type: ignore
 
 
+def _immortal(obj):
+    """Keep `obj` alive for the life of the process, interpreter shutdown included.  For a torch.cuda.CUDAGraph whose capture
+    FAILED: its destructor calls into the runtime with the invalidated capture and throws -- from a destructor, i.e.
+    std::terminate (seen with a gloo collective inside a capture).  A leaked handle costs nothing; an abort costs the job."""
+    import ctypes
+    if obj is not None:
+        ctypes.pythonapi.Py_IncRef(ctypes.py_object(obj))
+
+
 class Watchdog:
     """A deadline on a region that waits for the GPU or for other ranks.  A collective whose peers never arrive (a rank that
     fell back to another mode, a hung capture) blocks for ever and says nothing; under `guard(what, seconds)` the process
@@ -342,7 +351,9 @@ class DataParallelTrainer:
       * N > 1 over RCCL (backend "nccl"): the same PLUS the gradient all-reduce, so that the N > 1 step has the shape of the N = 1
         step -- but only after every rank has passed a start-up self-check of a captured all-reduce against an eager one AND
         every rank's capture of the step succeeded (ControlPlane agreement).  Otherwise, on EVERY rank alike: forward + backward
-        replayed, then the all-reduce and the fused (1/world, clip, Adam) launched eagerly (`exchange_fallback` says why);
+        replayed, then the all-reduce and the fused (1/world, clip, Adam) launched eagerly (`exchange_fallback` says why) -- and if
+        even that graph cannot be captured on some rank (an invalidated capture poisons torch's capture state), eager steps
+        everywhere (`use_graph` goes False);
       * any other backend (gloo moves the bucket through the host): the eager exchange, always.
     Inputs are copied into static buffers (or written there by the loader: input_buffers()), so shapes must not change
     between steps.  With N > 1 every wait on another rank runs under a Watchdog deadline (options.dp_timeout seconds)."""
@@ -381,6 +392,7 @@ class DataParallelTrainer:
         self.exchange_fallback = None                      # why the exchange is NOT in the graph although it was asked for
         self.exchange_checks = {}                          # what the start-up checks measured (bench.py prints them)
         self._first_graph_step_checked = False
+        self._capturing = None                             # the graph object of the capture in progress / last attempted
 
     # ------------------------------------------------------------------------------------------- activation-copy guard
     def _h8_modules(self):
@@ -468,14 +480,15 @@ class DataParallelTrainer:
         n = self.bucket.numel
         gen = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
         src = (torch.rand(n, generator=gen) - 0.5).to(dev)
-        ok, why = True, None
+        ok, why, g = True, None, None
         try:
             ref = src.clone()
             dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.group)     # (also the communicator's lazy initialisation)
             torch.cuda.synchronize()
             buf = src.clone()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            self._capture_stream = cs = torch.cuda.Stream()       # (a stream of this capture's own: a failure must not poison torch's shared one)
+            with torch.cuda.graph(g, stream=cs):
                 self._graph_collective(buf)
             for _ in range(2):
                 buf.copy_(src)
@@ -484,10 +497,9 @@ class DataParallelTrainer:
                 if not torch.equal(buf, ref):
                     ok, why = False, "captured all-reduce != eager all-reduce (max |diff| %.3e)" % float((buf - ref).abs().max())
                     break
-            del g
         except Exception as e:
             ok, why = False, "%s: %s" % (type(e).__name__, str(e)[:160])
-            torch.cuda.synchronize()
+            self._abandon_capture(g)
         reasons = self.ctl.gather(why)
         self.exchange_checks["self_check"] = "passed" if all(r is None for r in reasons) else reasons
         if all(r is None for r in reasons):
@@ -523,7 +535,7 @@ class DataParallelTrainer:
                         graph = self._capture_graph(True)
                     except Exception as e:              # a backend / runtime that cannot capture its collective
                         err = "%s: %s" % (type(e).__name__, str(e)[:160])
-                        torch.cuda.synchronize()
+                        self._abandon_capture(self._capturing)
                     # the decision is the JOB's, not the rank's: one rank replaying an in-graph all-reduce while another launches
                     # an eager one is a hang
                     errs = self.ctl.gather(err)
@@ -534,16 +546,58 @@ class DataParallelTrainer:
                 if why is None:
                     self._graph = graph
                     return
-                del graph
+                graph = None
             warnings.warn("the gradient all-reduce stays OUT of the step graph on every rank (%s): eager exchange" % why)
             self.exchange_fallback = why
             self._opt_in_graph = False
             torch.cuda.synchronize()
-        self._graph = self._capture_graph(self._opt_in_graph)
+        if self.world == 1:
+            self._graph = self._capture_graph(self._opt_in_graph)
+            return
+        # N > 1: the last rung of the ladder.  A capture that was INVALIDATED (not merely refused) leaves torch's capture machinery
+        # in a state in which no later capture on this process succeeds; if the plain forward + backward graph cannot be captured
+        # on some rank, EVERY rank runs its steps eagerly (same kernels, same exchange, no graph) -- slower, never hung
+        err, graph = None, None
+        try:
+            graph = self._capture_graph(False)
+        except Exception as e:
+            err = "%s: %s" % (type(e).__name__, str(e)[:160])
+            self._abandon_capture(self._capturing)
+        with self.watchdog.guard("agreement on the capture of the step graph", self.timeout_s):
+            errs = self.ctl.gather(err)
+        if any(e_ is not None for e_ in errs):
+            why2 = "capture of forward + backward failed on rank(s) %s: %s" % ([i for i, e_ in enumerate(errs) if e_ is not None],
+                                                                              next(e_ for e_ in errs if e_ is not None))
+            warnings.warn("no step graph on any rank (%s): eager steps" % why2)
+            self.exchange_fallback = (self.exchange_fallback + "; " if self.exchange_fallback else "") + why2
+            self.exchange_checks["step_graph"] = errs
+            self.use_graph = False
+            self._graph = None
+            return
+        self._graph = graph
+
+    def _abandon_capture(self, graph):
+        """After a capture that raised: the graph object is never destroyed (_immortal), the capture's stream is taken out of
+        capture mode if the failure left it there (an INVALIDATED capture: torch's capture_end throws before it ends the capture,
+        and the thread stays in global capture mode -- every later eager launch fails), the device is drained."""
+        _immortal(graph)
+        cs = getattr(self, "_capture_stream", None)
+        if cs is not None and self.bucket.flat.is_cuda:
+            try:
+                RF.H.stream_abandon_capture(cs)
+            except Exception:
+                pass
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
 
     def _capture_graph(self, with_opt):
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        graph = self._capturing = torch.cuda.CUDAGraph()
+        # N > 1: every capture on a stream of its own (torch.cuda.graph otherwise re-uses ONE class-level capture stream: a capture
+        # that failed on it would fail every later one)
+        self._capture_stream = cs = torch.cuda.Stream() if self.world > 1 else None
+        with torch.cuda.graph(graph, stream=cs):
             self._loss = self._fwd_bwd(*self._static)
             if with_opt:
                 if self.world > 1:
@@ -584,7 +638,7 @@ class DataParallelTrainer:
             return img, qst, label
         if self._graph is None:
             self._capture(img, qst, label)
-        return self._static
+        return self._static if self.use_graph else (img, qst, label)
 
     def step(self, img, qst, label):
         self._nstep += 1
@@ -593,6 +647,7 @@ class DataParallelTrainer:
         if self.use_graph:
             if self._graph is None:
                 self._capture(img, qst, label)
+        if self.use_graph:                                  # (still: with N > 1 a capture that fails on any rank ends in eager steps everywhere)
             todo = [(dst, src) for dst, src in zip(self._static, (img, qst, label)) if dst.data_ptr() != src.data_ptr()]
             if todo and all(s_.is_cuda and s_.is_contiguous() and s_.dtype == d.dtype and s_.shape == d.shape
                                                      and s_.data_ptr() % 16 == 0 for d, s_ in todo):

@@ -455,6 +455,8 @@ class RelationalFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, q, mask, plan, packed, precision, label, coord, *params):
+        # (precision, grad mode of the CALLER): inside forward() autograd is always off and ctx.needs_input_grad ignores torch.no_grad()
+        precision, grad_on = precision if isinstance(precision, tuple) else (precision, True)
         ctx.set_materialize_grads(False)
         L = plan.L
         g_w, g_b = params[0:L], params[L:2 * L]
@@ -471,7 +473,7 @@ class RelationalFunction(torch.autograd.Function):
         Q = q.shape[1]
         M = B * n * n
         dev = x.device
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = grad_on and any(ctx.needs_input_grad)      # under no_grad nothing is kept for a backward pass (inference kernels)
         if chain and not chain_ok(plan, B, n):
             raise RuntimeError('precision "f16s" needs the register-resident chains: four 256-wide g layers, <= 32 features per object, '
                                'the question at layer 0 (n % 4 == 0) or 2 (n % 32 == 0), whole 256-row tiles (functional.chain_ok); '
@@ -835,7 +837,7 @@ def relational_forward(x, q, mask, plan, packed, precision, g_w, g_b, f_w, f_b, 
     """-> log-probs, or (log-probs, mean NLL) when `label` is given."""
     if precision not in _INTERNAL_PRECISIONS:
         raise ValueError("precision must be one of %r" % (PRECISIONS,))
-    return RelationalFunction.apply(x, q, mask, plan, packed, precision, label, coord, *g_w, *g_b, *f_w, *f_b)
+    return RelationalFunction.apply(x, q, mask, plan, packed, (precision, torch.is_grad_enabled()), label, coord, *g_w, *g_b, *f_w, *f_b)
 
 
 def grid_path_ok(plan: LayerPlan, precision, B, n, k):

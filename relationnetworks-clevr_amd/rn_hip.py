@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librn_hip.so")
 RN_BF16, RN_F32, RN_F16, RN_FP8 = 0, 1, 2, 3
 RN_RELU, RN_ACCUMULATE = 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 
@@ -25,6 +25,7 @@ SIGNATURES = {
     "rn_abi_version": (_I, []),
     "rn_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "rn_last_error": (C.c_char_p, []),
+    "rn_stream_abandon_capture": (_I, [_P]),
     "rn_pair_build_fwd": (_I, [_P, _L, _L, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_qst_broadcast": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_pack_matrix": (_I, [_P, _L, _L, _I, _I, _P, _I, _I, _I, _P]),
@@ -137,6 +138,12 @@ def _check(rc: int, name: str):
     if rc != 0:
         msg = load().rn_last_error()
         raise RuntimeError("%s failed (rc=%d): %s" % (name, rc, msg.decode() if msg else "?"))
+
+
+def stream_abandon_capture(stream) -> bool:
+    """End (and throw away) whatever capture `stream` (a torch.cuda.Stream) is in -- see include/rn_hip.h.  -> True when the
+    stream is not capturing afterwards."""
+    return load().rn_stream_abandon_capture(C.c_void_p(stream.cuda_stream)) == 0
 
 
 def _stream() -> int:

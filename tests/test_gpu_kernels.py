@@ -464,7 +464,7 @@ def test_g_chain_fwd_rr_f16s_alg0(H, mode, B, n):
         assert torch.equal(unblock(Hg[2]).view(torch.uint8) >> 7, gate_image_ref(m8[3], M).to(torch.uint8))
 
 
-@pytest.mark.parametrize("B,n", [(5, 64), (3, 32), (3, 196), (4, 40)])
+@pytest.mark.parametrize("B,n", [(5, 64), (3, 32), (2, 196), (4, 40)])
 def test_g_chain_fwd_rr_f16s_two_pass(H, B, n):
     """dither == 0: hi + lo split weights on EVERY layer (the inference arithmetic of eval()).  Pair sums against
     the float64 emulation of that arithmetic (2e-5: fp32 accumulation order) and against the exact chain (3e-4: the fp16 rounding of
