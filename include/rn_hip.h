@@ -66,7 +66,8 @@ enum {
   RN_WS_F_PHI_NLL = 9,        /* (B)                                  sync_ws of the f_phi launches that carry the loss           */
   RN_WS_CLIP_ADAM = 10,       /* ()                                   rn_clip_adam_step*                                          */
   RN_WS_CONV_BWD_WEIGHT = 11, /* (N, Cin, H, W)                       rn_conv3x3s2_bwd_weight, rn_bn_relu_bwd_conv_wgrad          */
-  RN_WS_BN_RELU = 12          /* (N, C, HW)                           rn_bn_relu_fwd / _bwd                                       */
+  RN_WS_BN_RELU = 12,         /* (N, C, HW)                           rn_bn_relu_fwd / _bwd                                       */
+  RN_WS_F_PHI_SPLIT = 13      /* ()                                   sync_ws of rn_f_phi_split (zeroed ONCE by the caller)       */
 };
 size_t rn_workspace_bytes(int op, int a, int b, int c, int d);
 
@@ -298,6 +299,26 @@ int rn_f_phi_fwd_bwd_from_partials(const float* xg_part, int parts_per_row, floa
                                    const float* b2, const float* W3T, const float* b3, const float* W1, const float* W2, const float* W3,
                                    const float* mask, const long long* label, float* f1, float* f2, float* out, float* loss, void* sync_ws,
                                    void* bwd_ws, float* dxg, int B, int G, int F1, int F2, int A, void* stream);
+/* f_phi as a FEATURE-SPLIT fp32 MFMA chain in ONE launch (model.py:155-162; rn_fphi.hip): 16 workgroups, workgroup w owns output
+ * features 16 w .. 16 w + 15 of every 256-wide layer (a 16-KB slab of each weight matrix, fetched once into MFMA operand
+ * registers; v_mfma_f32_16x16x4_f32 = exact fp32, k-ordered), and the (B x 256) activations are handed from layer to layer INSIDE
+ * the launch (sc1 stores + drained flag -> relaxed poll + sc1 loads; no kernel boundary).  Same contract as
+ * rn_f_phi_fwd_from_partials / rn_f_phi_fwd_bwd_from_partials:
+ *   xg_part != NULL: xg (B, 256) is an OUTPUT = the sums of the parts_per_row partial rows of every question, in order;
+ *   xg_part == NULL: xg is the input;   label / loss: both (mean NLL folded in) or both NULL;
+ *   bwd_ws != NULL (needs label, dxg and the (in, out) copies W1T, W2T): the backward dz chain for d loss = 1 in the same launch --
+ *   bwd_ws (rn_workspace_bytes(RN_WS_F_PHI_BWD, ..)) receives the dz rows for rn_f_phi_bwd_grads, dxg (B, 256) the input gradient.
+ * W1..W3: the nn.Linear (out, in) weights.  Results equal the row-split kernels' to fp32 summation order (~1e-7).
+ * sync_ws: rn_workspace_bytes(RN_WS_F_PHI_SPLIT) bytes, ZEROED ONCE by the caller and then owned by these launches (an epoch word
+ * advanced by every launch, so a replayed hipGraph needs no memset node).  Shapes: rn_f_phi_split_ok (B <= 64, G = F1 = F2 = 256,
+ * A <= 32).  A poll that is not answered within ~1 s gives up instead of hanging; rn_f_phi_split_status(sync_ws) (synchronises the
+ * stream) returns 0 when that has never happened, else 1 + the stage. */
+int rn_f_phi_split_ok(int B, int G, int F1, int F2, int A);
+int rn_f_phi_split(const float* xg_part, int parts_per_row, float* xg, const float* W1, const float* b1, const float* W2, const float* b2,
+                   const float* W3, const float* b3, const float* W1T, const float* W2T, const float* mask, const long long* label,
+                   float* f1, float* f2, float* out, float* loss, void* bwd_ws, float* dxg, void* sync_ws, int B, int G, int F1, int F2,
+                   int A, void* stream);
+int rn_f_phi_split_status(const void* sync_ws, void* stream);
 int rn_f_phi_bwd_grads(const void* bwd_ws, const float* xg, const float* f1, const float* f2, float* dW1, float* db1, float* dW2,
                        float* db2, float* dW3, float* db3, int B, int G, int F1, int F2, int A, void* stream);
 int rn_f_phi_bwd(const float* gout, const float* out, const float* f2, const float* f1, const float* xg, const float* W1,

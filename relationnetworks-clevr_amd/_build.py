@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "librn_hip.so")
-SOURCES = ["rn_pair.hip", "rn_gemm.hip", "rn_chain_rr.hip", "rn_wgrad.hip", "rn_wgrad_blocked.hip", "rn_small.hip", "rn_extract.hip", "rn_convnorm.hip", "rn_lstm.hip", "rn_conv.hip"]
+SOURCES = ["rn_pair.hip", "rn_gemm.hip", "rn_chain_rr.hip", "rn_wgrad.hip", "rn_wgrad_blocked.hip", "rn_small.hip", "rn_fphi.hip", "rn_extract.hip", "rn_convnorm.hip", "rn_lstm.hip", "rn_conv.hip"]
 HEADERS = [os.path.join(CSRC, "rn_common.h"), os.path.join(HERE, "..", "include", "rn_hip.h"), os.path.join(HERE, "..", "include", "rn_hip_debug.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # RN_DIAG=1: a diagnostics build (timing ablations with wrong results, rn_diag_* entry points) for tools/ -- never the product build

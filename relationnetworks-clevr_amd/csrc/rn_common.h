@@ -73,6 +73,7 @@ size_t rnws_pair_features(int B, int npairs, int F);
 size_t rnws_f_phi_nll(int B);
 size_t rnws_f_phi_bwd(int B, int F1, int F2, int A);
 size_t rnws_clip_adam(void);
+size_t rnws_f_phi_split(void);
 size_t rnws_wgrad(int M, int N, int K);
 size_t rnws_wgrad_blocked(int M, int rows_per_question, int njobs, int aligned);
 

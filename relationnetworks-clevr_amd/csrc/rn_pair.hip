@@ -54,6 +54,7 @@ extern "C" size_t rn_workspace_bytes(int op, int a, int b, int c, int d) {
     case RN_WS_CLIP_ADAM: return rnws_clip_adam();
     case RN_WS_CONV_BWD_WEIGHT: return rnws_conv_bwd_weight(a, b, c, d);
     case RN_WS_BN_RELU: return rnws_bn_relu(a, b, c);
+    case RN_WS_F_PHI_SPLIT: return rnws_f_phi_split();
     default: rn_set_error("rn_workspace_bytes: unknown op %d", op); return 0;
   }
 }

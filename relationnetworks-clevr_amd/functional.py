@@ -70,6 +70,7 @@ class PackedWeights:
         self.w0T = None                            # W_0^T in fp32: the table kernel of the factored first layer
         self._last = None                          # arguments of the previous get(): what repack_ahead() repeats
         self._ahead = None                         # key of an ahead-of-time pack not consumed yet
+        self._fphi_sync = None                     # sync workspace of the feature-split f_phi launch (rn_f_phi_split), one per module
         self.frag_hi, self.frag_lo = [], []        # fragment-major fp16 hi / lo images of the forward chain
         self.fragT = []                            # backward step s -> W_{L-1-s}^T (bf16 fragment-major)
 
@@ -91,6 +92,11 @@ class PackedWeights:
         if key == self.key and not torch.cuda.is_current_stream_capturing():
             return self.fwd, self.bwd
         return self._pack(key, plan, g_w, code, chain, bwd_images, f_w)
+
+    def fphi_sync(self, device):
+        if self._fphi_sync is None or self._fphi_sync.device != torch.device(device):
+            self._fphi_sync = H.f_phi_split_sync_ws(device)
+        return self._fphi_sync
 
     def repack_ahead(self):
         """Repeat the previous get()'s pack NOW, on the caller's current stream -- RN.forward calls this on the question
@@ -407,7 +413,7 @@ class PairSumPartials:
         self.xg = torch.empty(B, G, dtype=torch.float32, device=part.device)
 
 
-def f_phi_forward(xg, fw, fb, mask, wT=None, label=None, pre_bwd=False):
+def f_phi_forward(xg, fw, fb, mask, wT=None, label=None, pre_bwd=False, packed=None):
     """f_phi + log_softmax (model.py:155-162): fc1 -> relu -> fc2 -> dropout mask -> relu -> fc3 -> log_softmax,
     fp32.  Returns (f1, f2, log_probs), with `label` (int64 (B,)) also the mean NLL as a fourth element (same launch).
     xg: the (B, G) pair sums, or PairSumPartials (their summation then rides in the same launch; .xg holds them afterwards)."""
@@ -420,6 +426,18 @@ def f_phi_forward(xg, fw, fb, mask, wT=None, label=None, pre_bwd=False):
     f1 = torch.empty(B, F1, dtype=torch.float32, device=dev)
     f2 = torch.empty(B, F2, dtype=torch.float32, device=dev)
     out = torch.empty(B, A, dtype=torch.float32, device=dev)
+    if OPT.fphi_split and packed is not None and H.f_phi_split_ok(B, G, F1, F2, A) and (wT is not None or not pre_bwd):
+        # the feature-split MFMA chain (rn_fphi.hip): one launch, 16 workgroups, in-launch hand-offs -- every shape of config.json's
+        # 256-wide f_phi at B <= 64 (the row-split kernels below: everything else)
+        sync = packed.fphi_sync(dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev) if label is not None else None
+        part, parts = (lazy.part, lazy.parts) if lazy is not None else (None, 0)
+        if pre_bwd and label is not None:
+            dxg = torch.empty(B, G, dtype=torch.float32, device=dev)
+            ws = H.f_phi_split(part, parts, xg, fw, fb, wT, mask, label, f1, f2, out, loss, sync, dxg=dxg)
+            return f1, f2, out, loss, (ws, dxg)
+        H.f_phi_split(part, parts, xg, fw, fb, None, mask, label, f1, f2, out, loss, sync)
+        return (f1, f2, out, loss) if label is not None else (f1, f2, out)
     if lazy is not None and pre_bwd and label is not None and wT is not None:
         # the training step: the backward dz chain (for d loss = 1) rides in the same launch -> (.., loss, (dz workspace, dxg))
         loss = torch.empty((), dtype=torch.float32, device=dev)
@@ -509,13 +527,13 @@ class RelationalFunction(torch.autograd.Function):
         ctx.fphi_pre = None
         if label is not None:
             label = label.long().contiguous()
-            r = f_phi_forward(xg, fw, fb, mask, wT=packed.fT, label=label,
-                              pre_bwd=need_grad and OPT.fphi_fused_bwd and isinstance(xg, PairSumPartials))
+            r = f_phi_forward(xg, fw, fb, mask, wT=packed.fT, label=label, packed=packed,
+                              pre_bwd=need_grad and OPT.fphi_fused_bwd and (isinstance(xg, PairSumPartials) or OPT.fphi_split))
             f1, f2, out, loss = r[:4]
             if len(r) == 5:
                 ctx.fphi_pre = r[4]
         else:
-            f1, f2, out = f_phi_forward(xg, fw, fb, mask, wT=packed.fT)
+            f1, f2, out = f_phi_forward(xg, fw, fb, mask, wT=packed.fT, packed=packed)
         if isinstance(xg, PairSumPartials):
             xg = xg.xg
         ctx.label = label

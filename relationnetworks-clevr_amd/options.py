@@ -1,7 +1,7 @@
 """Execution options of the MI355X path -- ONE explicit object, read from the process environment ONCE, at import.
 
 Nothing on the hot path looks at os.environ: dispatch depends on `OPT` only, so a call behaves the same whatever the
-environment does afterwards.  Fourteen entries are left (round 3 had 31: the ones that only kept an older implementation alive for
+environment does afterwards.  Fifteen entries are left (round 3 had 31: the ones that only kept an older implementation alive for
 A/B history went with those implementations): the arithmetic mode, the two numerically visible choices of the chain path (e4m3
 copies, on-chip pair reductions) that tests pin against their alternatives, and the trainer's launch structure.  Every switch
 defaults to the fast path (tests use `override(...)`, not the environment).  The C library has no
@@ -19,6 +19,7 @@ _SPEC = {
     "chain_reduce":      ("RN_NO_CHAIN_REDUCE", True, "pair-axis reductions of layer 0's gradient inside the backward chain (dZ_0 never stored; n % 32 == 0)"),
     "wgrad_overlap":     ("RN_NO_WGRAD_OVERLAP", True, "weight gradients on side streams (bench.py switches it off to time every kernel alone)"),
     "overlap_streams":   ("RN_OVERLAP_STREAMS", True, "question encoder beside the conv stack (second stream)"),
+    "fphi_split":        ("RN_NO_FPHI_SPLIT", True, "f_phi as the feature-split fp32 MFMA chain in one launch (rn_f_phi_split: B <= 64, 256-wide layers); False: the row-split FMA kernels"),
     "fphi_fused_bwd":    ("RN_NO_FPHI_FUSED_BWD", True, "trainer: f_phi's backward dz chain in the forward launch (the loss gradient is the cached 1)"),
     "fused_loss":        ("RN_NO_FUSED_LOSS", True, "loss inside the f_phi launch (trainer)"),
     "grads_in_bucket":   ("RN_NO_GRADS_IN_BUCKET", True, "backward kernels write parameter gradients straight into a registered FlatGradBucket (trainer)"),

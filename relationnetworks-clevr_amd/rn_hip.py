@@ -59,6 +59,9 @@ SIGNATURES = {
     "rn_f_phi_fwd_nll": (_I, [_P] * 14 + [_I] * 6 + [_P]),
     "rn_f_phi_fwd_bwd_from_partials": (_I, [_P, _I] + [_P] * 19 + [_I] * 5 + [_P]),
     "rn_f_phi_bwd_grads": (_I, [_P] * 10 + [_I] * 5 + [_P]),
+    "rn_f_phi_split_ok": (_I, [_I] * 5),
+    "rn_f_phi_split": (_I, [_P, _I] + [_P] * 18 + [_I] * 5 + [_P]),
+    "rn_f_phi_split_status": (_I, [_P, _P]),
     "rn_f_phi_bwd_nll": (_I, [_P] * 18 + [_I] * 5 + [_P]),
     "rn_f_phi_bwd": (_I, [_P] * 17 + [_I] * 5 + [_P]),
     "rn_lstm_fwd": (_I, [_P] * 10 + [_I] * 5 + [_P]),
@@ -105,6 +108,7 @@ WS_F_PHI_NLL = 9
 WS_CLIP_ADAM = 10
 WS_CONV_BWD_WEIGHT = 11
 WS_BN_RELU = 12
+WS_F_PHI_SPLIT = 13
 
 
 def workspace_bytes(op, a=0, b=0, c=0, d=0) -> int:
@@ -597,6 +601,53 @@ def f_phi_fwd_bwd_from_partials(xg_part, parts_per_row, xg, fwT, fb, fw, mask, l
                                               fw[1].data_ptr(), fw[2].data_ptr(), _ptr(mask), label.data_ptr(), f1.data_ptr(), f2.data_ptr(),
                                               out.data_ptr(), loss.data_ptr(), _nll_sync_ws(B, xg.device).data_ptr(), ws.data_ptr(),
                                               dxg.data_ptr(), B, G, F1, F2, A, _stream()), "rn_f_phi_fwd_bwd_from_partials")
+    return ws
+
+
+_SPLIT_WS = []          # weak references to every sync workspace handed out (f_phi_split_status walks them)
+
+
+def f_phi_split_sync_ws(device):
+    """A zeroed sync workspace for rn_f_phi_split (epoch, completion counter, error word, stage flags).  ONE per caller that may
+    launch concurrently with others (functional.PackedWeights keeps one per module): launches that share a workspace must be
+    stream-ordered.  Allocate it OUTSIDE a hipGraph capture (a captured torch.zeros would re-zero it on every replay: harmless,
+    but a memset node per step)."""
+    import weakref
+    ws = torch.zeros(max(workspace_bytes(WS_F_PHI_SPLIT, 0, 0, 0, 0), 16), dtype=torch.uint8, device=device)
+    _SPLIT_WS.append(weakref.ref(ws))
+    return ws
+
+
+def f_phi_split_ok(B, G, F1, F2, A) -> bool:
+    return bool(load().rn_f_phi_split_ok(B, G, F1, F2, A))
+
+
+def f_phi_split_status(device=None) -> int:
+    """0 when no launch of rn_f_phi_split (on `device`) ever gave up on a poll, else 1 + the stage (synchronises)."""
+    worst = 0
+    for ref in list(_SPLIT_WS):
+        ws = ref()
+        if ws is None:
+            _SPLIT_WS.remove(ref)
+        elif device is None or ws.device == torch.device(device):
+            worst = max(worst, load().rn_f_phi_split_status(ws.data_ptr(), torch.cuda.current_stream(ws.device).cuda_stream))
+    return worst
+
+
+@_timed("f_phi")
+def f_phi_split(xg_part, parts_per_row, xg, fw, fb, fwT, mask, label, f1, f2, out, loss, sync_ws, dxg=None):
+    """f_phi as a feature-split fp32 MFMA chain in one launch (rn_f_phi_split): fw = the natural (out, in) weights, fwT the
+    (in, out) copies (needed with dxg).  dxg given: the backward dz chain for d loss = 1 rides along -> the dz workspace."""
+    B, G = xg.shape
+    F1, F2, A = fw[0].shape[0], fw[1].shape[0], fw[2].shape[0]
+    ws = None
+    if dxg is not None:
+        ws = torch.empty(max(workspace_bytes(WS_F_PHI_BWD, B, F1, F2, A), 16), dtype=torch.uint8, device=xg.device)
+    _check(load().rn_f_phi_split(_ptr(xg_part), parts_per_row, xg.data_ptr(), fw[0].data_ptr(), fb[0].data_ptr(), fw[1].data_ptr(),
+                                 fb[1].data_ptr(), fw[2].data_ptr(), fb[2].data_ptr(), _ptr(fwT[0]) if fwT else None,
+                                 _ptr(fwT[1]) if fwT else None, _ptr(mask), _ptr(label), f1.data_ptr(), f2.data_ptr(), out.data_ptr(),
+                                 _ptr(loss), _ptr(ws), _ptr(dxg), sync_ws.data_ptr(), B, G, F1, F2, A, _stream()),
+           "rn_f_phi_split")
     return ws
 
 

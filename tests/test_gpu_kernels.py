@@ -1211,6 +1211,87 @@ def test_f_phi_from_partials(H, B, parts, nll, tr):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B,parts,use_mask,bwd", [(64, 16, True, True), (64, 16, False, False), (5, 7, True, True), (33, 0, True, True), (64, 0, False, False)])
+def test_f_phi_split(H, B, parts, use_mask, bwd):
+    """rn_f_phi_split -- f_phi as a feature-split fp32 MFMA chain in one launch with in-launch hand-offs (model.py:155-162, VERDICT r4
+    item 5) -- against a float64 restatement of the same formulas (<= 2e-6: fp32 products in another summation order) and against
+    the row-split kernels (rn_f_phi_fwd_bwd_from_partials: same bound); the pair sums = the partial rows added in order (bitwise the
+    row-split kernel's); B < 64 leaves the rows beyond B untouched; a second launch on the same workspace (epoch 2) and 50 more
+    under a competing stream give bitwise the first launch's results; no poll ever gave up (rn_f_phi_split_status == 0)."""
+    G, F1, F2, A = 256, 256, 256, 28
+    g = torch.Generator(device="cuda").manual_seed(5)
+    part = torch.randn(B * max(parts, 1), G, device="cuda", generator=g)
+    fw = [torch.randn(F1, G, device="cuda", generator=g) * 0.05, torch.randn(F2, F1, device="cuda", generator=g) * 0.05, torch.randn(A, F2, device="cuda", generator=g) * 0.05]
+    fwT = [x.t().contiguous() for x in fw]
+    fb = [torch.randn(F1, device="cuda", generator=g) * 0.1, torch.randn(F2, device="cuda", generator=g) * 0.1, torch.randn(A, device="cuda", generator=g) * 0.1]
+    mask = (torch.rand(B, F2, device="cuda", generator=g) > 0.5).float() * 2 if use_mask else None
+    label = torch.randint(0, A, (B,), device="cuda", generator=g)
+    NAN = float("nan")
+    mk = lambda *s: torch.full(s, NAN, device="cuda")
+    sync = H.f_phi_split_sync_ws("cuda")
+
+    def run():
+        xg = mk(B, G) if parts else part.clone()
+        f1, f2, out, loss = mk(B, F1), mk(B, F2), mk(B, A), mk()
+        dxg = mk(B, G) if bwd else None
+        ws = H.f_phi_split(part if parts else None, parts, xg, fw, fb, fwT, mask, label, f1, f2, out, loss, sync, dxg=dxg)
+        torch.cuda.synchronize()
+        dz = ws.view(torch.float32).clone() if bwd else None
+        return xg, f1, f2, out, loss, dxg, dz
+    xg, f1, f2, out, loss, dxg, dz = run()
+    assert H.f_phi_split_ok(B, G, F1, F2, A) and not H.f_phi_split_ok(65, G, F1, F2, A) and not H.f_phi_split_ok(B, G, 512, F2, A)
+    # float64 restatement
+    d = lambda t: t.double()
+    xr = d(part).view(B, parts, G).sum(1) if parts else d(part)
+    m = d(mask) if use_mask else 1.0
+    f1r = torch.relu(xr @ d(fw[0]).t() + d(fb[0]))
+    f2r = torch.relu((f1r @ d(fw[1]).t() + d(fb[1])) * m)
+    lpr = torch.log_softmax(f2r @ d(fw[2]).t() + d(fb[2]), 1)
+    lossr = -lpr[torch.arange(B), label].mean()
+    tol = 2e-6
+    assert rel(xg.cpu().numpy(), xr.cpu().numpy()) <= 1e-6
+    assert rel(f1.cpu().numpy(), f1r.cpu().numpy()) <= tol and rel(f2.cpu().numpy(), f2r.cpu().numpy()) <= tol
+    assert rel(out.cpu().numpy(), lpr.cpu().numpy()) <= tol and abs(float(loss) - float(lossr)) <= tol * abs(float(lossr))
+    if bwd:
+        gl = torch.zeros(B, A, dtype=torch.float64, device="cuda"); gl[torch.arange(B), label] = -1.0 / B
+        dz3r = gl - lpr.exp() * gl.sum(1, keepdim=True)
+        dz2r = (dz3r @ d(fw[2])) * m * (f2r > 0)
+        dz1r = (dz2r @ d(fw[1])) * (f1r > 0)
+        dxgr = dz1r @ d(fw[0])
+        dz1, dz2, dz3 = dz[:B * F1].view(B, F1), dz[B * F1:B * (F1 + F2)].view(B, F2), dz[B * (F1 + F2):B * (F1 + F2 + A)].view(B, A)
+        for got, want in ((dz3, dz3r), (dz2, dz2r), (dz1, dz1r), (dxg, dxgr)):
+            assert rel(got.cpu().numpy(), want.cpu().numpy()) <= 5e-6
+    # the row-split kernels on the same inputs
+    if parts and bwd and use_mask:
+        xg3, f1c, f2c, outc, lossc, dxgc = mk(B, G), mk(B, F1), mk(B, F2), mk(B, A), mk(), mk(B, G)
+        wsc = H.f_phi_fwd_bwd_from_partials(part, parts, xg3, fwT, fb, fw, mask, label, f1c, f2c, outc, lossc, dxgc)
+        torch.cuda.synchronize()
+        assert torch.equal(xg3, xg)                                   # (the same partial order)
+        assert rel(f2.cpu().numpy(), f2c.cpu().numpy()) <= tol and rel(out.cpu().numpy(), outc.cpu().numpy()) <= tol
+        assert rel(dxg.cpu().numpy(), dxgc.cpu().numpy()) <= 5e-6 and rel(dz.cpu().numpy(), wsc.view(torch.float32).cpu().numpy()) <= 5e-6
+        # ... and the parameter gradients from the split launch's workspace
+        ws2 = H.f_phi_split(part, parts, xg3, fw, fb, fwT, mask, label, f1c, f2c, outc, lossc, sync, dxg=dxgc)
+        dWa = [mk(*x.shape) for x in fw]; dba = [mk(x.shape[0]) for x in fw]
+        H.f_phi_bwd_grads(ws2, xg3, f1c, f2c, dWa, dba)
+        torch.cuda.synchronize()
+        for got, want in zip(dWa + dba, [dz1r.t() @ xr, dz2r.t() @ f1r, dz3r.t() @ f2r, dz1r.sum(0), dz2r.sum(0), dz3r.sum(0)]):
+            assert rel(got.cpu().numpy(), want.cpu().numpy()) <= 5e-6
+    # epoch 2, 3, ...: bitwise the same, also while another stream keeps the chip busy (uneven load: the hand-offs' worst case)
+    first = [t_.clone() for t_ in (xg, f1, f2, out, loss) + ((dxg, dz) if bwd else ())]
+    side = torch.cuda.Stream()
+    big = torch.randn(8192, 8192, device="cuda")
+    for it in range(50):
+        if it % 5 == 0:
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    big.mul_(1.0001)
+        got = run()
+        for a_, b_ in zip(first, [t_ for t_ in got if t_ is not None]):
+            assert torch.equal(a_, b_), it
+    torch.cuda.synchronize()
+    assert H.f_phi_split_status() == 0
+
+
 def test_copy_many(H):
     """The batch hand-off: up to four copies in one launch, sizes with and without a 16-byte tail; bytes outside stay untouched."""
     srcs = [torch.randn(64, 3, 128, 128, device="cuda"), torch.randint(0, 80, (64, 43), device="cuda"), torch.randint(0, 28, (64,), device="cuda"),

@@ -28,11 +28,17 @@ masks = torch.randint(0, 255, (H.g_chain_rr_mask_bytes(M),), dtype=torch.uint8, 
 dZb = [H.rows_to_blocked(dZ) for _ in range(2)]; H8 = [H.rows_to_blocked(Hh) for _ in range(3)]; H.relu_gate_image(masks, H8[2], M)
 gWs = [torch.empty(G, G, device=dev) for _ in range(3)]; gBs = [torch.empty(G, device=dev) for _ in range(3)]
 jobs = [(dZb[0], H8[0], gWs[0], gBs[0]), (dZb[1], H8[1], gWs[1], gBs[1]), (None, H8[2], gWs[2], gBs[2])]
+mask_fp = (torch.rand(B, 256, device=dev) > 0.5).float() * 2; sync_fp = H.f_phi_split_sync_ws(dev)
+ws_fp = H.f_phi_split(part[:B * 16], 16, xg, fw, fb, fT, mask_fp, label, f1, f2, out, loss, sync_fp, dxg=dxg)
 part32 = torch.randn(M // 32 * (1 if n % 32 == 0 else 2), G, device=dev)
 rows = [
     ("pair_tables", lambda: H.pair_tables(x, q, w0T, b0, Xp, Vc, B, n, k, Q, G)),
     ("pair_sum_fwd (segsum of the chain partials)", lambda: H.pair_sum_fwd(part, G, xg, H.RN_F32, B, (n * n) // 256, G)),
     ("f_phi_fwd_nll", lambda: H.f_phi_fwd_nll(xg, fT, fb, None, label, f1, f2, out, loss, transposed=True)),
+    ("f_phi_fwd_bwd_from_partials (row-split, fwd + loss + dz chain)", lambda: H.f_phi_fwd_bwd_from_partials(part[:B * 16], 16, xg, fT, fb, fw, mask_fp, label, f1, f2, out, loss, dxg)),
+    ("f_phi_split (feature-split MFMA, fwd + loss + dz chain)", lambda: H.f_phi_split(part[:B * 16], 16, xg, fw, fb, fT, mask_fp, label, f1, f2, out, loss, sync_fp, dxg=dxg)),
+    ("f_phi_split, forward + loss only", lambda: H.f_phi_split(part[:B * 16], 16, xg, fw, fb, fT, mask_fp, label, f1, f2, out, loss, sync_fp)),
+    ("f_phi_bwd_grads (six parameter gradients)", lambda: H.f_phi_bwd_grads(ws_fp, xg, f1, f2, dW, db)),
     ("f_phi_bwd_nll (dz + grads)", lambda: H.f_phi_bwd_nll(gloss, label, out, f2, f1, xg, fw, None, dW, db, dxg)),
     ("pair_reduce_bwd (+finish)", lambda: H.pair_reduce_bwd(dZ, G, Rj, Ri, Rq, H.RN_BF16, B, n, G)),
     ("pair_dx_dq", lambda: H.pair_dx_dq(Rj, Ri, Rq, W0, dx, dq, B, n, k, Q, G)),
