@@ -681,7 +681,7 @@ def main():
             ach = kern["g_fwd"]["achieved_tflops"]
             out["frac_algorithmic"], out["frac_executed"] = ach / peak, ach_ex / peak
             pb = ksum_step.get("pair_build")
-            if pb:
+            if pb and pb[0] > 0 and pb[1] > 0:
                 esz = 4 if prec == "fp32" else 2
                 Q = hyp["lstm_hidden"] if hyp["question_injection_position"] == 0 else 0
                 nbytes = M * (2 * k + Q) * esz + B * n * k * 4 + B * Q * 4

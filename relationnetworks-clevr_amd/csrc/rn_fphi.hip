@@ -83,6 +83,18 @@ __device__ __forceinline__ void fs_sweep_rows(unsigned char* sync, int stage, in
   const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, row = row0 + i;
   const __amdgpu_buffer_rsrc_t r = fs_rsrc(sync + FS_OFF_GRAN + (size_t)stage * FS_GRAN_BYTES, FS_GRAN_BYTES);
   const bool live = row < B;
+  // light poll first: ONE granule per producer (lane l < 16: the granule of the wave's last live row in slab l's last column) until
+  // all 16 carry this launch's tag -- a full sweep is 32 KB per wave (~1.3 us), a light pass 16 loads; the full sweep below still
+  // verifies EVERY tag (stores are not ordered), it just starts when it is likely to succeed
+  {
+    const int lastrow = (row0 + 15 < B ? row0 + 15 : B - 1);
+    const unsigned char* sp = sync + FS_OFF_GRAN + (size_t)stage * FS_GRAN_BYTES + ((size_t)lastrow * FS_W + 16 * (lane & 15) + 15) * 8 + 4;
+    for (unsigned spins = 0; spins < FS_SPIN_MAX; ++spins) {
+      const unsigned tg = lane < FS_NW ? fs_ld(sp) : epoch;
+      if (__ballot(tg != epoch) == 0ull) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
   for (unsigned spins = 0;; ++spins) {
     u32x4 lo[16], hi[16];
 #pragma unroll
@@ -182,36 +194,36 @@ __global__ __launch_bounds__(FS_NT) void f_phi_split_kernel(FsArgs a) {
   const unsigned epoch = fs_ld(a.sync) + 1u;
   const int j = lane & 15, g = lane >> 4, f = FS_NW * wg + j, row0 = 16 * wv, myrow = row0 + wg;
 
-  // ---- prologue: W3 -> LDS (the only workgroup-wide step; nothing in front of it waits for another workgroup)
+  f32x4 w[16];
+  fs_load_slab(a.W1, wg, w);                               // (in flight during the pair sums and the first sweep)
+  // ---- GX first (nothing else is waited for by other workgroups): row 16 v + w of the pair sums, partials added in order
+  if (myrow < B) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (a.xg_part) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(a.xg_part + (long)myrow * a.parts * FS_W) + lane;
+      int p = 0;
+      for (; p + 16 <= a.parts; p += 16) {                // 16 loads in flight: one round trip per batch
+        f32x4 u[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) u[i] = src[(long)(p + i) * (FS_W / 4)];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += u[i];
+      }
+      for (; p < a.parts; ++p) v += src[(long)p * (FS_W / 4)];
+      reinterpret_cast<f32x4*>(a.xg + (long)myrow * FS_W)[lane] = v;
+    } else {
+      v = reinterpret_cast<const f32x4*>(a.xg + (long)myrow * FS_W)[lane];
+    }
+    fs_publish_row(a.sync, FS_GX, myrow, epoch, v);
+  }
+  // ---- W3 -> LDS (this workgroup's own; one wave: no barrier beyond its own LDS wait)
   for (int c = t; c < FS_AMAX * (FS_W / 4); c += FS_NT) {
     const int r = c / (FS_W / 4), k4 = c - r * (FS_W / 4);
     const f32x4 v = r < A ? reinterpret_cast<const f32x4*>(a.W3 + (long)r * FS_W)[k4] : f32x4{0.f, 0.f, 0.f, 0.f};
     *reinterpret_cast<f32x4*>(w3s + r * W3S + 4 * k4) = v;
   }
-  f32x4 w[16];
-  fs_load_slab(a.W1, wg, w);                               // (in flight during the pair sums and the first sweep)
   __syncthreads();
   if (row0 < B) {                                          // (a pipeline without rows has nothing to do; its waves still check out below)
-    // ---- GX: row 16 v + w of the pair sums, partials added in order (deterministic)
-    if (myrow < B) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (a.xg_part) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.xg_part + (long)myrow * a.parts * FS_W) + lane;
-        int p = 0;
-        for (; p + 16 <= a.parts; p += 16) {              // 16 loads in flight: one round trip per batch
-          f32x4 u[16];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) u[i] = src[(long)(p + i) * (FS_W / 4)];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) v += u[i];
-        }
-        for (; p < a.parts; ++p) v += src[(long)p * (FS_W / 4)];
-        reinterpret_cast<f32x4*>(a.xg + (long)myrow * FS_W)[lane] = v;
-      } else {
-        v = reinterpret_cast<const f32x4*>(a.xg + (long)myrow * FS_W)[lane];
-      }
-      fs_publish_row(a.sync, FS_GX, myrow, epoch, v);
-    }
     f32x4 act[16];
     // ---- GF1
     f32x4 f1r;

@@ -413,6 +413,13 @@ class DataParallelTrainer:
         elements are clamped.  With several ranks the decision is the OR over ranks (ControlPlane).
         -> {"layers": {l: {"positive", "flushed", "clamped", "max_value"}}, "switched": bool} or None (no e4m3 copies in use)."""
         self._guard_done_at = self._nstep
+        if img.is_cuda:
+            # (same cadence, same host sync: the in-launch hand-offs of the feature-split f_phi kernel have bounded spins -- a sweep
+            # that gave up leaves an error word instead of a hang; training on with garbage must not be silent)
+            st = RF.H.f_phi_split_status(img.device)
+            if st:
+                raise RuntimeError("rn_f_phi_split: a hand-off inside the launch was not answered (stage %d); results since then are "
+                                   "invalid -- re-run with RN_NO_FPHI_SPLIT=1" % (st - 1))
         if not (self._h8_in_use() and img.is_cuda):
             return None
         bufs = [(b_, b_.clone()) for b_ in self.model.buffers()]
