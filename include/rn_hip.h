@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RN_ABI_VERSION 7   /* bumped whenever a signature or a buffer layout of this header changes */
+#define RN_ABI_VERSION 8   /* bumped whenever a signature or a buffer layout of this header changes */
 
 enum { RN_BF16 = 0, RN_F32 = 1, RN_F16 = 2, RN_FP8 = 3 };   /* RN_F16: pair matrix / split weights of the f16s forward only;
                                                              * RN_FP8: OCP e4m3 copies of the stored activations (h_dtype / a_dtype) */
@@ -129,13 +129,18 @@ int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* con
  *            over the i of its tiles_per_unit tiles (8 consecutive i each) for the 32 objects j of block jg;
  *   ri_part (M / 16, 256): rows ((b*n + i) * n/32 + jg) * 2 + {0, 1} = the sums over the two 16-object halves of block jg.
  * rn_pair_reduce_parts adds them up to Rj, Ri (B*n, 256) and Rq (B, 256) -- what rn_pair_reduce_bwd produces from a stored dZ_0.
- * Needs n % 32 == 0 (no padded j axis), the masks of a forward call with the same M, dZ[0] == NULL (the gate job of
- * rn_g_wgrad_blocked stands in for it) and dZ[1], dZ[2] as above; dZ[3] is ignored.  tiles_per_unit: any divisor of n / 8 --
- * rn_g_chain_bwd_rr_red_tpu(M, n) returns the largest power of two that still gives every CU a unit (0: shape not supported). */
-int rn_g_chain_bwd_rr_red_tpu(int M, int n);
-int rn_g_chain_bwd_rr_red(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M, int n, int L, int G,
-                          float* rj_part, float* ri_part, int tiles_per_unit, void* stream);
-int rn_pair_reduce_parts(const float* rj_part, const float* ri_part, float* Rj, float* Ri, float* Rq, int B, int n, int G, int nu,
+ * Needs the masks of a forward call with the same M and njp, dZ[0] == NULL (the gate job of rn_g_wgrad_blocked stands in for it)
+ * and dZ[1], dZ[2] as above; dZ[3] is ignored.  tiles_per_unit: any divisor of ceil(n / 8) -- rn_g_chain_bwd_rr_red_tpu(M, n, njp)
+ * returns the largest one that still gives every CU a unit (0: shape not supported).
+ * PADDED j axis (njp = 32 ceil(n / 32) > n, e.g. the 14 x 14 grid: n = 196, njp = 224; M = B * n * njp): the same kernel -- a
+ * (question, i) group is njp / 32 wave-tiles, the rows j >= n have cleared mask bits and come out as exact zeros, and n need not
+ * be a multiple of 8: the last tile of a (question, j block) holds fewer than 8 values of i (its spare waves repeat the last one
+ * and contribute zeros).  Index formulas with n/32 -> njp/32, n/8 -> ceil(n/8): rj_part (B * njp/32 * nu, 32, 256),
+ * ri_part (M / 16, 256); rn_pair_reduce_parts reads only the rows j < n. */
+int rn_g_chain_bwd_rr_red_tpu(int M, int n, int njp);
+int rn_g_chain_bwd_rr_red(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M, int n, int njp, int L,
+                          int G, float* rj_part, float* ri_part, int tiles_per_unit, void* stream);
+int rn_pair_reduce_parts(const float* rj_part, const float* ri_part, float* Rj, float* Ri, float* Rq, int B, int n, int njp, int G, int nu,
                          void* stream);
 /* MFMA-fragment-major weight images for the register-resident chains, `count` (<= 16) of them in ONE launch; all arguments are
  * HOST arrays of `count` entries.  Image i: dst (65536 elements) gets, for output block ob, K16 step ks, lane, element e:

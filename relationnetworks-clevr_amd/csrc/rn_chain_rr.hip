@@ -850,12 +850,13 @@ constexpr int RR_OFF_XB1 = 0, RR_OFF_XB0 = RR_OFF_RING, RR_OFF_RING_RED = RR_OFF
 static_assert(RR_OFF_XB1 + RR_XBUF_BYTES <= RR_OFF_RING && RR_OFF_RING_RED + 6 * RR_STAGE <= RR_LDS, "exchange buffers + 6-slot ring");
 struct RRRedArgs {
   float* rj_part;                                                     // (units, 32, 256) fp32
-  float* ri_part;                                                     // (M / 16, 256) fp32: row ((b*n + i) * (n/32) + jg) * 2 + lane half
+  float* ri_part;                                                     // (M / 16, 256) fp32: row ((b*n + i) * (njp/32) + jg) * 2 + lane half
   int n_obj, tiles_per_unit;
+  int njp;                                                            // pair rows per (question, i) group: n_obj, or 32 ceil(n_obj / 32) (padded j axis)
 };
 }  // namespace
 template <int ABL, bool SKIP0 = false, bool RED = false>
-__global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int ntiles, RRRedArgs ra = RRRedArgs{nullptr, nullptr, 0, 1}) {
+__global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int ntiles, RRRedArgs ra = RRRedArgs{nullptr, nullptr, 0, 1, 0}) {
   static_assert(!RED || (SKIP0 && ABL == 0), "in-kernel pair reductions: the product variant without a stored dZ[0]");
   typedef BwdVm<SKIP0, RED> Vm;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
@@ -901,7 +902,11 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
   // dword of a block's (un-swapped, last-layer) mask image that holds row n: mask i = 4 (n / 8) + n % 4, half (n / 4) % 2
   const int rowsel = 2 * (4 * (n >> 3) + (n & 3)) + ((n >> 2) & 1);
   // RED: the same dword index, read the other way -- in a SWAPPED layer's mask image it holds the 32 row bits of feature n
-  const int jgs = RED ? ra.n_obj / RR_WR : 1, tpbj = RED ? ra.n_obj / RR_NW : 1;
+  // (padded j axis: njp / 32 wave-tiles per (question, i) -- the rows j >= n_obj have cleared mask bits in every layer and come out
+  //  as exact zeros --; n_obj need not be a multiple of 8 either: the last tile of a (question, j block) then has fewer than 8 i,
+  //  and its spare waves re-do the LAST valid i -- same loads, same stores of the same values (the counted waits stay valid) -- but
+  //  hand ZEROS to the Rj exchange)
+  const int jgs = RED ? ra.njp / RR_WR : 1, tpbj = RED ? (ra.n_obj + RR_NW - 1) / RR_NW : 1;
   unsigned char* const xwb = lds + (w * 8) * 512 + lane * 8;          // this wave's slice of an exchange buffer
   const unsigned char* const xrb = lds + w * 512 + lane * 8;          // ... and the piece it owns of every wave's slice
 
@@ -914,9 +919,13 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
     const int tile = RED ? unit * ra.tiles_per_unit + tu : unit;
     // wave-tile of this wave = index of the forward wave whose 32 pair rows it takes over
     long wt = (long)tile * RR_NW + w;
+    bool wvalid = true;
     if constexpr (RED) {
       const int bj = tile / tpbj, ig = tile - bj * tpbj, bq = bj / jgs, jg = bj - bq * jgs;
-      wt = ((long)bq * ra.n_obj + ig * RR_NW + w) * jgs + jg;
+      int iw = ig * RR_NW + w;
+      wvalid = iw < ra.n_obj;
+      iw = wvalid ? iw : ra.n_obj - 1;
+      wt = ((long)bq * ra.n_obj + iw) * jgs + jg;
     }
     const long m0w = wt * RR_WR;
     const long b = (m0w + n) / a.rows_per_b;                          // question of THIS lane's pair row (a wave may straddle two)
@@ -965,8 +974,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
         rs = j == 0 ? s4 : rs + s4;
       } else {
         unsigned char* xw = xwb + ((pob & 1) ? RR_OFF_XB1 : RR_OFF_XB0);
-        *reinterpret_cast<f32x2*>(xw + (2 * j) * 512) = f32x2{gx[0], gx[1]};
-        *reinterpret_cast<f32x2*>(xw + (2 * j + 1) * 512) = f32x2{gx[2], gx[3]};
+        *reinterpret_cast<f32x2*>(xw + (2 * j) * 512) = wvalid ? f32x2{gx[0], gx[1]} : f32x2{0.f, 0.f};
+        *reinterpret_cast<f32x2*>(xw + (2 * j + 1) * 512) = wvalid ? f32x2{gx[2], gx[3]} : f32x2{0.f, 0.f};
         if (j == 3) {
           // Ri partials of this wave-tile: the two lane halves hold rows 8 j + 4 h + {0..3} of the same feature and leave one
           // partial row EACH (a full-wave 256-byte store; v_permlane32_swap on two copies of one value is mis-compiled by hipcc 7.2)
@@ -1335,21 +1344,27 @@ extern "C" int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, cons
 }
 
 // The backward chain with the pair-axis reductions of layer 0's gradient formed on chip (g_chain_rr_bwd_kernel, RED).
-extern "C" int rn_g_chain_bwd_rr_red_tpu(int M, int n) {
-  if (M <= 0 || n <= 0 || n % RR_WR != 0 || n % RR_NW != 0 || M % ((long)n * n) != 0 || M % RR_TM != 0) return 0;
-  const int ntiles = M / RR_TM, tpbj = n / RR_NW;                     // tiles per (question, block of 32 j)
-  int tpu = 1;
-  while (tpu * 2 <= tpbj && tpbj % (tpu * 2) == 0 && ntiles / (tpu * 2) >= rr_num_cus()) tpu *= 2;
+// tiles of the reducing backward chain: B questions x njp / 32 j blocks x ceil(n / 8) groups of 8 i
+static long rr_red_tiles(int M, int n, int njp) { return (long)(M / ((long)n * njp)) * (njp / RR_WR) * ((n + RR_NW - 1) / RR_NW); }
+
+extern "C" int rn_g_chain_bwd_rr_red_tpu(int M, int n, int njp) {
+  if (M <= 0 || n <= 0 || njp < n || njp - n >= RR_WR || njp % RR_WR != 0 || M % ((long)n * njp) != 0) return 0;
+  const long ntiles = rr_red_tiles(M, n, njp);
+  const int tpbj = (n + RR_NW - 1) / RR_NW;                           // tiles per (question, block of 32 j)
+  int tpu = 1;                                                        // the largest divisor of tpbj that still gives every CU a unit
+  for (int d = 2; d <= tpbj; ++d)
+    if (tpbj % d == 0 && ntiles / d >= rr_num_cus()) tpu = d;
   return tpu;
 }
 
 extern "C" int rn_g_chain_bwd_rr_red(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M, int n,
-                                     int L, int G, float* rj_part, float* ri_part, int tiles_per_unit, void* stream) {
+                                     int njp, int L, int G, float* rj_part, float* ri_part, int tiles_per_unit, void* stream) {
   RN_CHECK_ARG(dxg && mask && Wtf && dZ && rj_part && ri_part && M > 0, "rn_g_chain_bwd_rr_red: bad pointer/size");
   RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_bwd_rr_red: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
-  RN_CHECK_ARG(rn_g_chain_bwd_rr_red_tpu(M, n) > 0, "rn_g_chain_bwd_rr_red: needs n %% 32 == 0 and M a multiple of n*n (M=%d n=%d)", M, n);
-  const int ntiles = M / RR_TM, tpbj = n / RR_NW;
-  RN_CHECK_ARG(tiles_per_unit > 0 && tpbj % tiles_per_unit == 0, "rn_g_chain_bwd_rr_red: tiles_per_unit=%d must divide n / 8 = %d", tiles_per_unit, tpbj);
+  RN_CHECK_ARG(rn_g_chain_bwd_rr_red_tpu(M, n, njp) > 0,
+               "rn_g_chain_bwd_rr_red: needs njp = 32 ceil(n / 32) pair rows per (question, i) and M a multiple of n*njp (M=%d n=%d njp=%d)", M, n, njp);
+  const int ntiles = (int)rr_red_tiles(M, n, njp), tpbj = (n + RR_NW - 1) / RR_NW;
+  RN_CHECK_ARG(tiles_per_unit > 0 && tpbj % tiles_per_unit == 0, "rn_g_chain_bwd_rr_red: tiles_per_unit=%d must divide ceil(n / 8) = %d", tiles_per_unit, tpbj);
   RRBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.prio = rr_prio();
@@ -1371,8 +1386,8 @@ extern "C" int rn_g_chain_bwd_rr_red(const float* dxg, const void* const* mask, 
   }
   RN_CHECK_ARG(((uintptr_t)dxg | (uintptr_t)rj_part | (uintptr_t)ri_part) % 16 == 0, "rn_g_chain_bwd_rr_red: dxg / partials must be 16-byte aligned");
   a.dxg = dxg;
-  a.rows_per_b = n * n;
-  RRRedArgs ra{rj_part, ri_part, n, tiles_per_unit};
+  a.rows_per_b = n * njp;
+  RRRedArgs ra{rj_part, ri_part, n, tiles_per_unit, njp};
   const int nunits = ntiles / tiles_per_unit;
   const int grid = nunits < rr_num_cus() ? nunits : rr_num_cus();
   g_chain_rr_bwd_kernel<0, true, true><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles, ra);

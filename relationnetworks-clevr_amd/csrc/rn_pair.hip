@@ -637,15 +637,15 @@ extern "C" int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri
 // j for Rj; the Rq partials of the row lanes meet in LDS and are added in lane order -- every sum has a fixed order.
 __global__ __launch_bounds__(1024) void pair_reduce_parts_kernel(const f32x4* __restrict__ rj_part, const f32x4* __restrict__ ri_part,
                                                                  f32x4* __restrict__ Rj, f32x4* __restrict__ Ri, f32x4* __restrict__ Rq,
-                                                                 int n, int G4, int nu) {
+                                                                 int n, int G4, int nu, int njp) {
   __shared__ f32x4 red[32][32];
   const int b = blockIdx.x, c = blockIdx.y * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
-  const int jgs = n / 16;                                             // partial rows per (question, i)
+  const int jgs = njp / 16;                                           // partial rows per (question, i) (padded j axis: njp > n)
   f32x4 q = {0.f, 0.f, 0.f, 0.f};
   if (c < G4) {
     for (int r = rl; r < n; r += 32) {
       const f32x4* pi = ri_part + ((long)b * n + r) * jgs * G4 + c;
-      const f32x4* pj = rj_part + (((long)b * (n / 32) + (r >> 5)) * nu * 32 + (r & 31)) * G4 + c;
+      const f32x4* pj = rj_part + (((long)b * (njp / 32) + (r >> 5)) * nu * 32 + (r & 31)) * G4 + c;
       f32x4 si = pi[0], sj = pj[0];
       for (int g = 1; g < jgs; ++g) si += pi[(long)g * G4];
       for (int u = 1; u < nu; ++u) sj += pj[(long)u * 32 * G4];
@@ -664,14 +664,14 @@ __global__ __launch_bounds__(1024) void pair_reduce_parts_kernel(const f32x4* __
   }
 }
 
-extern "C" int rn_pair_reduce_parts(const float* rj_part, const float* ri_part, float* Rj, float* Ri, float* Rq, int B, int n, int G,
-                                    int nu, void* stream) {
-  RN_CHECK_ARG(rj_part && ri_part && Rj && Ri && B > 0 && n > 0 && n % 32 == 0 && nu > 0 && G % 4 == 0,
-               "rn_pair_reduce_parts: bad pointer/size (B=%d n=%d G=%d nu=%d; n %% 32 == 0)", B, n, G, nu);
+extern "C" int rn_pair_reduce_parts(const float* rj_part, const float* ri_part, float* Rj, float* Ri, float* Rq, int B, int n, int njp,
+                                    int G, int nu, void* stream) {
+  RN_CHECK_ARG(rj_part && ri_part && Rj && Ri && B > 0 && n > 0 && njp >= n && njp % 32 == 0 && nu > 0 && G % 4 == 0,
+               "rn_pair_reduce_parts: bad pointer/size (B=%d n=%d njp=%d G=%d nu=%d; njp %% 32 == 0)", B, n, njp, G, nu);
   RN_CHECK_ARG(((uintptr_t)rj_part | (uintptr_t)ri_part | (uintptr_t)Rj | (uintptr_t)Ri | (uintptr_t)Rq) % 16 == 0, "rn_pair_reduce_parts: pointers must be 16-byte aligned");
   const int G4 = G / 4;
   pair_reduce_parts_kernel<<<dim3(B, cdiv(G4, 32)), 1024, 0, (hipStream_t)stream>>>((const f32x4*)rj_part, (const f32x4*)ri_part, (f32x4*)Rj,
-                                                                                     (f32x4*)Ri, (f32x4*)Rq, n, G4, nu);
+                                                                                     (f32x4*)Ri, (f32x4*)Rq, n, G4, nu, njp);
   RN_LAUNCH_CHECK("rn_pair_reduce_parts");
   return 0;
 }

@@ -625,11 +625,12 @@ class RelationalFunction(torch.autograd.Function):
         # layer 0's gradient is read by the pair-axis reductions only: formed inside the chain, dZ_0 never exists either
         red_parts = None
         if gated:
-            tpu = H.g_chain_bwd_rr_red_tpu(Mc, n) if (OPT.chain_reduce and njp == n) else 0
+            tpu = H.g_chain_bwd_rr_red_tpu(Mc, n, njp) if OPT.chain_reduce else 0
             if tpu > 0:
                 dZs = [None] + list(torch.empty(L - 2, Mc, G, dtype=dt, device=dev)) + [None]
-                red_parts = (torch.empty(Mc // 256 // tpu, 32, G, **f32), torch.empty(Mc // 16, G, **f32), (n // 8) // tpu)
-                H.g_chain_bwd_rr_red(dxg, masks, ctx.fragT, dZs, Mc, n, G, red_parts[0], red_parts[1], tpu)
+                red_parts = (torch.empty(H.g_chain_bwd_rr_red_units(Mc, n, njp, tpu), 32, G, **f32), torch.empty(Mc // 16, G, **f32),
+                             ((n + 7) // 8) // tpu)
+                H.g_chain_bwd_rr_red(dxg, masks, ctx.fragT, dZs, Mc, n, G, red_parts[0], red_parts[1], tpu, njp=njp)
             else:
                 dZs = [None] + list(torch.empty(L - 1, Mc, G, dtype=dt, device=dev))
         else:
@@ -734,7 +735,7 @@ class RelationalFunction(torch.autograd.Function):
         wl = g_w[0] if g_w[0].is_contiguous() else g_w[0].contiguous()
         Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32); Rq = torch.empty(B, N, **f32)
         if red_parts is not None:                                  # the chain has already reduced: add its partials up
-            H.pair_reduce_parts(red_parts[0], red_parts[1], Rj, Ri, Rq, B, n, N, red_parts[2])
+            H.pair_reduce_parts(red_parts[0], red_parts[1], Rj, Ri, Rq, B, n, N, red_parts[2], njp=njp)
         else:
             H.pair_reduce_bwd(dZ_of[0], N, Rj, Ri, Rq, H.RN_BF16, B, n, N, njp=njp)
         if late:

@@ -16,7 +16,7 @@ _SPEC = {
     "precision":         ("RN_PRECISION", "auto", 'arithmetic mode of modules whose hyp has no "precision": auto | f16s | bf16 | fp32'),
     "eval_two_pass":     ("RN_NO_EVAL_TWO_PASS", True, "eval() without gradients on the chain path: hi + lo split weights on every g layer instead of the tile-dithered single pass (log-probs independent of batch position / object order; ~1.6x the forward chain's time)"),
     "h8":                ("RN_H8", True, "e4m3 copies of H_0..2 for the weight gradients (False: bf16 copies, the last layer's dZ stored; what the trainer's copy guard falls back to)"),
-    "chain_reduce":      ("RN_NO_CHAIN_REDUCE", True, "pair-axis reductions of layer 0's gradient inside the backward chain (dZ_0 never stored; n % 32 == 0)"),
+    "chain_reduce":      ("RN_NO_CHAIN_REDUCE", True, "pair-axis reductions of layer 0's gradient inside the backward chain (dZ_0 never stored; any chain shape, the padded j axis included)"),
     "wgrad_overlap":     ("RN_NO_WGRAD_OVERLAP", True, "weight gradients on side streams (bench.py switches it off to time every kernel alone)"),
     "overlap_streams":   ("RN_OVERLAP_STREAMS", True, "question encoder beside the conv stack (second stream)"),
     "fphi_split":        ("RN_NO_FPHI_SPLIT", True, "f_phi as the feature-split fp32 MFMA chain in one launch (rn_f_phi_split: B <= 64, 256-wide layers); False: the row-split FMA kernels"),

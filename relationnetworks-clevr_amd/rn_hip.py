@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librn_hip.so")
 RN_BF16, RN_F32, RN_F16, RN_FP8 = 0, 1, 2, 3
 RN_RELU, RN_ACCUMULATE = 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 
@@ -36,9 +36,9 @@ SIGNATURES = {
     "rn_pair_sum_tiles": (_I, [_P, _P, _I, _I, _I, _P]),
     "rn_f_phi_fwd_from_partials": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "rn_g_chain_bwd_rr_red_tpu": (_I, [_I, _I]),
-    "rn_g_chain_bwd_rr_red": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
-    "rn_pair_reduce_parts": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rn_g_chain_bwd_rr_red_tpu": (_I, [_I, _I, _I]),
+    "rn_g_chain_bwd_rr_red": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "rn_pair_reduce_parts": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rn_pack_matrix_frag_many": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "rn_pair_sum_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_sum_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
@@ -341,26 +341,32 @@ def g_chain_bwd_rr(dxg, masks, Wtfs, dZs, M, rows_per_question, G):
     _check(load().rn_g_chain_bwd_rr(dxg.data_ptr(), mp, wp, zp, M, rows_per_question, L, G, _stream()), "rn_g_chain_bwd_rr")
 
 
-def g_chain_bwd_rr_red_tpu(M, n):
-    """Tiles per unit of the reducing backward chain for this shape (0: not supported -- store dZ_0 and use pair_reduce_bwd)."""
-    return int(load().rn_g_chain_bwd_rr_red_tpu(M, n))
+def g_chain_bwd_rr_red_tpu(M, n, njp=None):
+    """Tiles per unit of the reducing backward chain for this shape (0: not supported -- store dZ_0 and use pair_reduce_bwd).
+    njp > n: padded j axis (M = B * n * njp)."""
+    return int(load().rn_g_chain_bwd_rr_red_tpu(M, n, njp or n))
+
+
+def g_chain_bwd_rr_red_units(M, n, njp, tpu):
+    """Units (rows / 32 of rj_part) of the reducing backward chain: B * njp/32 * ceil(n/8) / tpu."""
+    return (M // (n * njp)) * (njp // 32) * ((n + 7) // 8) // tpu
 
 
 @_timed("g_dgrad")
-def g_chain_bwd_rr_red(dxg, masks, Wtfs, dZs, M, n, G, rj_part, ri_part, tpu):
+def g_chain_bwd_rr_red(dxg, masks, Wtfs, dZs, M, n, G, rj_part, ri_part, tpu, njp=None):
     """Register-resident backward chain with the pair-axis reductions of layer 0's gradient formed on chip: dZs[0] None (gate job),
     dZs[1..2] row-blocked images, dZs[3] not written; partial sums to rj_part / ri_part (pair_reduce_parts adds them up)."""
     L = len(dZs)
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks])
     wp = (C.c_void_p * (L - 1))(*[w.data_ptr() for w in Wtfs])
     zp = (C.c_void_p * L)(*[(z.data_ptr() if z is not None else None) for z in dZs])
-    _check(load().rn_g_chain_bwd_rr_red(dxg.data_ptr(), mp, wp, zp, M, n, L, G, rj_part.data_ptr(), ri_part.data_ptr(), tpu, _stream()),
+    _check(load().rn_g_chain_bwd_rr_red(dxg.data_ptr(), mp, wp, zp, M, n, njp or n, L, G, rj_part.data_ptr(), ri_part.data_ptr(), tpu, _stream()),
            "rn_g_chain_bwd_rr_red")
 
 
 @_timed("pair_reduce")
-def pair_reduce_parts(rj_part, ri_part, Rj, Ri, Rq, B, n, G, nu):
-    _check(load().rn_pair_reduce_parts(rj_part.data_ptr(), ri_part.data_ptr(), Rj.data_ptr(), Ri.data_ptr(), _ptr(Rq), B, n, G, nu, _stream()),
+def pair_reduce_parts(rj_part, ri_part, Rj, Ri, Rq, B, n, G, nu, njp=None):
+    _check(load().rn_pair_reduce_parts(rj_part.data_ptr(), ri_part.data_ptr(), Rj.data_ptr(), Ri.data_ptr(), _ptr(Rq), B, n, njp or n, G, nu, _stream()),
            "rn_pair_reduce_parts")
 
 

@@ -641,17 +641,46 @@ def test_wgrad_gated_and_bwd_skip0(H, B, n):
         assert rel(db.cpu().numpy(), dz.sum(0).cpu().numpy()) <= 2e-5
 
 
-@pytest.mark.parametrize("B,n,tpu", [(17, 64, 0), (64, 64, 0), (3, 64, 1), (3, 64, 8), (2, 32, 2), (2, 96, 0)])
+def _padded_forward_masks(H, B, n, njp):
+    """Lane masks of a real forward call on the PADDED j axis (their bits are cleared for the rows j >= n in every layer)."""
+    L, G, k, Q = 4, 256, 26, 128
+    Mp, kt = B * n * njp, 2 * 26 + 128
+    x = formula.hash_uniform((B, n, k), 400, -1, 1).astype(np.float32)
+    q = formula.hash_uniform((B, Q), 401, -1, 1).astype(np.float32)
+    Ws = [formula.hash_uniform((G, kt if l == 0 else G), 410 + l, -0.15, 0.15).astype(np.float32) for l in range(L)]
+    bs = [formula.hash_uniform((G,), 420 + l, -0.3, 0.3).astype(np.float32) for l in range(L)]
+    wd = [dev(w) for w in Ws]
+    w0T = torch.empty(kt, G, device="cuda")
+    hiA, loA, jobsA = f16s_images(H, wd, kt, k)
+    H.pack_matrix_frag_many(jobsA + [(wd[0], kt, 1, G, kt, w0T, 2)])
+    Xp = torch.zeros(B * n + 1, 64, dtype=torch.float16, device="cuda"); Vc = torch.empty(B * n, G, device="cuda")
+    H.pair_tables(dev(x), dev(q), w0T, dev(bs[0]), Xp, Vc, B, n, k, Q, G)
+    Hs = [torch.empty(Mp, G, dtype=torch.bfloat16, device="cuda") for _ in range(3)] + [None]
+    masks = list(torch.zeros(L, H.g_chain_rr_mask_bytes(Mp), dtype=torch.uint8, device="cuda"))
+    part = torch.empty(Mp // 256 * 2, G, device="cuda")
+    H.g_chain_fwd_rr_f16s_alg0(Xp, Vc, n, hiA, loA, [dev(b) for b in bs], Hs, masks, part, Mp, G, njp=njp)
+    torch.cuda.synchronize()
+    return masks
+
+
+@pytest.mark.parametrize("B,n,tpu", [(17, 64, 0), (64, 64, 0), (3, 64, 1), (3, 64, 8), (2, 32, 2), (2, 96, 0), (2, 196, 0), (32, 196, 0), (4, 40, 0), (4, 40, 1)])
 def test_g_chain_bwd_rr_red(H, B, n, tpu):
     """rn_g_chain_bwd_rr_red: the pair-axis reductions of layer 0's gradient formed inside the backward chain.  The stored images
     dZ[1], dZ[2] must be bitwise those of rn_g_chain_bwd_rr; Rj / Ri / Rq (rn_pair_reduce_parts) must equal, to fp32 accumulation
     accuracy, the float64 reductions of (dZ[2] @ W_1) * gate_0 computed from the kernel's OWN stored dZ[2] and the forward's
     layer-0 lane masks (model.py:117-127 backward; oracle.rl_backward_np's Rj / Ri).  tpu = 0: the library's choice of tiles per
-    unit; (17, 64): more units than CUs; (64, 64): the headline shape; (2, 96): three j blocks per (question, i)."""
+    unit; (17, 64): more units than CUs; (64, 64): the headline shape; (2, 96): three j blocks per (question, i); (., 196), (4, 40):
+    the PADDED j axis (njp = 224 / 64 pair rows per (question, i), masks of a real padded forward call) with n % 8 != 0 -- the last
+    tile of a (question, j block) has four valid i, its spare waves repeat the last one and must add nothing; (32, 196) is
+    BASELINE.json configs[4] at its real size."""
     L, G = 4, 256
-    M = B * n * n
+    njp = (n + 31) // 32 * 32
+    M = B * n * njp
     g = torch.Generator(device="cuda").manual_seed(7)
-    masks = list(torch.randint(0, 256, (L, H.g_chain_rr_mask_bytes(M)), dtype=torch.uint8, device="cuda", generator=g))
+    if njp == n:
+        masks = list(torch.randint(0, 256, (L, H.g_chain_rr_mask_bytes(M)), dtype=torch.uint8, device="cuda", generator=g))
+    else:
+        masks = _padded_forward_masks(H, B, n, njp)
     dxg = (torch.rand(B, G, device="cuda", generator=g) - 0.5)
     Wt = list(torch.empty(L - 1, 65536, dtype=torch.bfloat16, device="cuda"))
     Ws = []
@@ -659,34 +688,37 @@ def test_g_chain_bwd_rr_red(H, B, n, tpu):
         Ws.append(bf16_round(formula.hash_uniform((G, G), 340 + st, -0.15, 0.15)))
         pack_frag(H, dev(Ws[-1]), 1, G, G, G, Wt[st], st == 0)
     old = [None] + list(torch.zeros(L - 1, M, G, dtype=torch.bfloat16, device="cuda"))
-    H.g_chain_bwd_rr(dxg, masks, Wt, old, M, n * n, G)
-    tpu = tpu or H.g_chain_bwd_rr_red_tpu(M, n)
-    assert tpu > 0 and (n // 8) % tpu == 0
-    nu = (n // 8) // tpu
+    H.g_chain_bwd_rr(dxg, masks, Wt, old, M, n * njp, G)
+    tpu = tpu or H.g_chain_bwd_rr_red_tpu(M, n, njp)
+    tpbj = (n + 7) // 8
+    assert tpu > 0 and tpbj % tpu == 0
+    nu = tpbj // tpu
     new = [None] + list(torch.zeros(L - 2, M, G, dtype=torch.bfloat16, device="cuda")) + [None]
-    rj_part = torch.full((M // 256 // tpu, 32, G), float("nan"), device="cuda")
+    rj_part = torch.full((H.g_chain_bwd_rr_red_units(M, n, njp, tpu), 32, G), float("nan"), device="cuda")
     ri_part = torch.full((M // 16, G), float("nan"), device="cuda")
-    H.g_chain_bwd_rr_red(dxg, masks, Wt, new, M, n, G, rj_part, ri_part, tpu)
+    H.g_chain_bwd_rr_red(dxg, masks, Wt, new, M, n, G, rj_part, ri_part, tpu, njp=njp)
     Rj = torch.full((B * n, G), float("nan"), device="cuda"); Ri = torch.full((B * n, G), float("nan"), device="cuda")
     Rq = torch.full((B, G), float("nan"), device="cuda")
-    H.pair_reduce_parts(rj_part, ri_part, Rj, Ri, Rq, B, n, G, nu)
+    H.pair_reduce_parts(rj_part, ri_part, Rj, Ri, Rq, B, n, G, nu, njp=njp)
     # a second run must give the same bits (fixed summation orders)
     rj2, ri2 = torch.empty_like(rj_part), torch.empty_like(ri_part)
-    H.g_chain_bwd_rr_red(dxg, masks, Wt, new, M, n, G, rj2, ri2, tpu)
+    H.g_chain_bwd_rr_red(dxg, masks, Wt, new, M, n, G, rj2, ri2, tpu, njp=njp)
     torch.cuda.synchronize()
     assert torch.equal(rj2, rj_part) and torch.equal(ri2, ri_part)
+    assert not torch.isnan(rj_part).any() and not torch.isnan(ri_part).any()
     for s_ in (1, 2):
         assert torch.equal(old[s_], new[s_]), s_
     gate0 = torch.from_numpy(rr_mask_decode(masks[0], M, 0)).cuda()
     dz2 = unblock(new[2]).double()
-    dz0 = ((dz2 @ dev(Ws[2]).double()) * gate0).view(B, n, n, G)                   # [b, i, j, :]
+    dz0 = ((dz2 @ dev(Ws[2]).double()) * gate0).view(B, n, njp, G)                 # [b, i, j, :]
+    assert not dz0[:, :, n:].any()                                                 # (padded rows: exact zeros)
     scale = dz0.abs().max().item()
-    assert (Rj.double().view(B, n, G) - dz0.sum(1)).abs().max().item() <= 2e-4 * scale       # (n terms of ~1e-6 relative error each)
-    assert (Ri.double().view(B, n, G) - dz0.sum(2)).abs().max().item() <= 2e-4 * scale
-    assert (Rq.double() - dz0.sum((1, 2))).abs().max().item() <= 2e-3 * scale
+    assert (Rj.double().view(B, n, G) - dz0.sum(1)[:, :n]).abs().max().item() <= 2e-4 * scale * max(1.0, n / 64)   # (n terms of ~1e-6 relative error each)
+    assert (Ri.double().view(B, n, G) - dz0.sum(2)).abs().max().item() <= 2e-4 * scale * max(1.0, n / 64)
+    assert (Rq.double() - dz0.sum((1, 2))).abs().max().item() <= 2e-3 * scale * max(1.0, n / 64)
     # ... and the stored-dZ_0 path (bf16 rows + rn_pair_reduce_bwd) agrees within ITS rounding (2^-9 per term)
     Rj_o = torch.empty_like(Rj); Ri_o = torch.empty_like(Ri); Rq_o = torch.empty_like(Rq)
-    H.pair_reduce_bwd(old[3], G, Rj_o, Ri_o, Rq_o, 0, B, n, G)
+    H.pair_reduce_bwd(old[3], G, Rj_o, Ri_o, Rq_o, 0, B, n, G, njp=njp)
     torch.cuda.synchronize()
     assert (Rj_o - Rj).abs().max().item() <= n * 2.0 ** -9 * scale and (Ri_o - Ri).abs().max().item() <= n * 2.0 ** -9 * scale
 

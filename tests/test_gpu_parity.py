@@ -213,9 +213,10 @@ def test_e4m3_activation_copies_touch_only_the_g_weight_gradients(pkg, tag, prec
            ref_err_e4m3={k: v[2] for k, v in rep.items()})
 
 
-@pytest.mark.parametrize("tag", ["G-fp64", "G-ir64", "G-fp-small"])
+@pytest.mark.parametrize("tag", ["G-fp64", "G-ir64", "G-fp-small", "G-fp196"])
 def test_pair_reductions_inside_the_backward_chain(pkg, tag, monkeypatch):
-    """rn_g_chain_bwd_rr_red (the module default where n % 32 == 0): layer 0's gradient never leaves the chip, its pair-axis sums are
+    """rn_g_chain_bwd_rr_red (the module default on the chain path, the padded j axis of the 14 x 14 grid included -- G-fp196):
+    layer 0's gradient never leaves the chip, its pair-axis sums are
     formed in fp32 from the un-rounded accumulators.  Against the stored-dZ_0 path (bf16 rows + rn_pair_reduce_bwd,
     RN_NO_CHAIN_REDUCE=1): the forward and everything that does not read those sums -- log-probs, dW / db of layers 1..3, f_phi --
     is bitwise the same; dx, dq (question at layer 0), dW_0, db_0 move by the bf16 rounding that is gone (<= 5e-3 relative L2) and

@@ -13,7 +13,7 @@ x = torch.randn(B, n, k, device=dev); q = torch.randn(B, Q, device=dev)
 W0 = torch.randn(G, kt, device=dev) * 0.05
 Rj = torch.randn(B * n, G, device=dev); Ri = torch.randn(B * n, G, device=dev); Rq = torch.randn(B, G, device=dev)
 dx = torch.empty(B, n, k, device=dev); dq = torch.empty(B, Q, device=dev); dW0 = torch.empty(G, kt, device=dev); db0 = torch.empty(G, device=dev)
-tpu = H.g_chain_bwd_rr_red_tpu(M, n)
+tpu = H.g_chain_bwd_rr_red_tpu(M, n, n)
 rjp = torch.randn(M // 256 // tpu, 32, G, device=dev); rip = torch.randn(M // 16, G, device=dev)
 dZ = torch.randn(M, G, device=dev).bfloat16(); Hh = torch.randn(M, G, device=dev).abs().to(torch.float8_e4m3fn)
 dZb = [H.rows_to_blocked(dZ) for _ in range(2)]; H8 = [H.rows_to_blocked(Hh) for _ in range(3)]

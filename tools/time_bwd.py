@@ -17,7 +17,7 @@ masks = list(torch.randint(0, 256, (L, H.g_chain_rr_mask_bytes(M)), dtype=torch.
 dxg = torch.rand(B, G, device="cuda", generator=g) - 0.5
 Wt = list((torch.rand(L - 1, 65536, device="cuda", generator=g) * 0.2 - 0.1).bfloat16())
 dZ = list(torch.empty(L - 1, M, G, dtype=torch.bfloat16, device="cuda"))
-tpu = H.g_chain_bwd_rr_red_tpu(M, n)
+tpu = H.g_chain_bwd_rr_red_tpu(M, n, n)
 rj = torch.empty(M // 256 // tpu, 32, G, device="cuda"); ri = torch.empty(M // 16, G, device="cuda")
 Rj = torch.empty(B * n, G, device="cuda"); Ri = torch.empty(B * n, G, device="cuda"); Rq = torch.empty(B, G, device="cuda")
 red = [None, dZ[0], dZ[1], None]
