@@ -157,6 +157,20 @@ __device__ __forceinline__ void mask_store4(u64* p, u64 m0, u64 m1, u64 m2, u64 
                : "memory");
 }
 
+// ... the same with the byte offset as an IMMEDIATE (one base pointer per tile and layer instead of a 64-bit add per store) and
+// WITHOUT the hazard padding: the caller issues it at least one MFMA gap (>= 5 instructions of this wave) behind the v_cmp that
+// wrote the masks.
+template <int OFF, bool PAD = false>
+__device__ __forceinline__ void mask_store4_at(const u64* base, unsigned soff, u64 m0, u64 m1, u64 m2, u64 m3) {
+  // address = layer base (a kernel argument: already in SGPRs) + ONE 32-bit wave-tile offset shared by the four layers + immediate
+  const u32x4 qa = {(unsigned)m0, (unsigned)(m0 >> 32), (unsigned)m1, (unsigned)(m1 >> 32)};
+  const u32x4 qb = {(unsigned)m2, (unsigned)(m2 >> 32), (unsigned)m3, (unsigned)(m3 >> 32)};
+  if constexpr (PAD)
+    asm volatile("s_nop 4\n\ts_store_dwordx4 %0, %2, %3 offset:%4\n\ts_store_dwordx4 %1, %2, %3 offset:%5" : : "s"(qa), "s"(qb), "s"(base), "s"(soff), "n"(OFF), "n"(OFF + 16) : "memory");
+  else
+    asm volatile("s_store_dwordx4 %0, %2, %3 offset:%4\n\ts_store_dwordx4 %1, %2, %3 offset:%5" : : "s"(qa), "s"(qb), "s"(base), "s"(soff), "n"(OFF), "n"(OFF + 16) : "memory");
+}
+
 template <int N> struct IC { static constexpr int value = N; };
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -323,11 +337,21 @@ struct RRArgsF {
   int prio;
 };
 __device__ __forceinline__ unsigned relu_pack_f16(float a, float b) {     // saturate instead of overflowing fp16 to inf
+  // convert (RNE, +inf beyond 65520), ReLU on the packed pair (a negative fp16 is a negative int16), then ONE packed unsigned
+  // minimum against 0x7BFF = 65504 -- the same bits as clamping both floats first, with one VALU instruction less per pair
+#ifdef RR_RELU_PACK_OLD                                    // (variant builds: the two v_min_f32 in front of the conversion)
   const f32x2 f = {fminf(a, 65504.f), fminf(b, 65504.f)};
+#else
+  const f32x2 f = {a, b};
+#endif
   s16x2 x = __builtin_bit_cast(s16x2, __builtin_convertvector(f, f16x2));
   const s16x2 z = {0, 0};
   x = __builtin_elementwise_max(x, z);
+#ifdef RR_RELU_PACK_OLD
   return __builtin_bit_cast(unsigned, x);
+#else
+  return rn_pk_min_u16(__builtin_bit_cast(unsigned, x), 0x7BFF);
+#endif
 }
 template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false, bool GATE = false, bool LO = false>
 struct F16Vm {
@@ -531,17 +555,38 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
         for (int r = 0; r < 4; ++r) cinit[4 * j + r] = b[r];
       }
     };
-    auto mask_out = [&](int pl, int pob, int j, float x0, float x1, float x2, float x3) {
+    // lane masks of a group: compared in one MFMA gap (mask_cmp), stored in the next (mask_put) -- the VALU -> SMEM hazard of the
+    // compare results is then covered by the instructions in between (no s_nop), and a store is base + IMMEDIATE (the wave-tile's
+    // 1-KB record of layer pl starts at mbase[pl])
+    unsigned moff = (unsigned)(wt * 1024);                            // byte offset of the wave-tile's 1-KB record in every layer's mask buffer
+    asm volatile("" : "+s"(moff));
+    u64 mk[4];
+    auto mask_cmp = [&](int pl, int j, float x0, float x1, float x2, float x3) {
       if constexpr (MASK && !(ABL & 16)) {
         const u64 vm = !RAG ? ~0ull : (pl == RR_L - 1 ? vm3[j] : vm012);
-        mask_store4(a.mask[pl] + (wt * 8 + pob) * 16 + 4 * j, __ballot(x0 > 0.f) & vm, __ballot(x1 > 0.f) & vm, __ballot(x2 > 0.f) & vm,
-                    __ballot(x3 > 0.f) & vm);
+        mk[0] = __ballot(x0 > 0.f) & vm; mk[1] = __ballot(x1 > 0.f) & vm; mk[2] = __ballot(x2 > 0.f) & vm; mk[3] = __ballot(x3 > 0.f) & vm;
+      }
+    };
+    auto mask_put = [&](auto plc, auto pobc, int j, auto padc) {     // (j: an unrolled loop's constant -- the switch folds)
+      if constexpr (MASK && !(ABL & 16)) {
+        constexpr int pl = decltype(plc)::value < 0 ? 0 : decltype(plc)::value, pob = decltype(pobc)::value;   // (-1: the never-executed instance of stage 0)
+        constexpr bool pad = decltype(padc)::value != 0;
+        switch (j) {
+          case 0: mask_store4_at<(pob * 16 + 0) * 8, pad>(a.mask[pl], moff, mk[0], mk[1], mk[2], mk[3]); break;
+          case 1: mask_store4_at<(pob * 16 + 4) * 8, pad>(a.mask[pl], moff, mk[0], mk[1], mk[2], mk[3]); break;
+          case 2: mask_store4_at<(pob * 16 + 8) * 8, pad>(a.mask[pl], moff, mk[0], mk[1], mk[2], mk[3]); break;
+          default: mask_store4_at<(pob * 16 + 12) * 8, pad>(a.mask[pl], moff, mk[0], mk[1], mk[2], mk[3]); break;
+        }
       }
     };
     // phases of group j: 0 masks, 1 fp16 operand of the next layer, 2 bf16 copy for HBM, 3 staging write
-    auto epi_group = [&](int pl, int pob, int j, int ph, Frag* dst, u32x2 (&pk)[4]) {
+    auto epi_group = [&](auto plc, auto pobc, int j, int ph, Frag* dst, u32x2 (&pk)[4]) {
+      constexpr int pl = decltype(plc)::value, pob = decltype(pobc)::value;
       const f32x16& c = acc[pob & 1];
-      if (ph == 0) mask_out(pl, pob, j, c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]);
+      if (ph == 0) {
+        mask_cmp(pl, j, c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]);
+        mask_put(plc, pobc, j, IC<1>{});                               // (right behind the compare: padded -- keeping the masks in SGPRs
+      }                                                                //  over an MFMA gap spills: the kernel sits at the 102-SGPR limit)
       if (ph == 1 && dst) {
         const unsigned f0 = relu_pack_f16(c[4 * j + 0], c[4 * j + 1]), f1 = relu_pack_f16(c[4 * j + 2], c[4 * j + 3]);
         dst[2 * pob + (j >> 1)][(j & 1) * 2 + 0] = f0;
@@ -617,7 +662,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
         RR_FWD_STORE(cell, reinterpret_cast<__attribute__((address_space(1))) u32x4*>(base + gate_lane + 512 * pob));
       }
     };
-    auto epi3_group = [&](int pob, int j, int ph, f32x4 (&v)[4]) {
+    auto epi3_group = [&](auto pobc, int j, int ph, f32x4 (&v)[4], auto padc) {
+      constexpr int pob = decltype(pobc)::value;
       if (ph == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[j][r] = fmaxf(acc[pob & 1][4 * j + r] + b3, 0.f);
@@ -632,7 +678,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
       if (ph == 1) {
         if constexpr (XG && RAG) xs[pob] += keep3[j] * ((v[j][0] + v[j][1]) + (v[j][2] + v[j][3]));
         else if constexpr (XG) xs[pob] += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-        mask_out(RR_L - 1, pob, j, v[j][0], v[j][1], v[j][2], v[j][3]);
+        mask_cmp(RR_L - 1, j, v[j][0], v[j][1], v[j][2], v[j][3]);
+        mask_put(IC<RR_L - 1>{}, pobc, j, IC<1>{});
       }
       if (ph == 2) {
         if constexpr (STORE && ST3) {
@@ -699,7 +746,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
           if (has_prev && !(ABL & 32)) {
             const int j = c / CPG, ph = c % CPG;
             if (pl == RR_L - 1) {
-              if (ph < 4) epi3_group(pob, j, ph, v);
+              if (ph < 4) epi3_group(IC<pob>{}, j, ph, v, IC<0>{});
               if (GATE && c < 4) {                                      // (H_2 block pob: complete since the last layer began)
                 const Frag& f = in[2 * pob + ((c & 3) >> 1)];
                 h2_stage(pob, c & 3, f[(c & 1) * 2], f[(c & 1) * 2 + 1]);
@@ -707,10 +754,10 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
               if (c == 6) h2_read(pob);
               if (j == 3 && ph == 3) gate_store(pob);
             } else if (CPG >= 4) {
-              if (ph < 4) epi_group(pl, pob, j, ph, dst, pk);
+              if (ph < 4) epi_group(IC<pl>{}, IC<pob>{}, j, ph, dst, pk);
             } else {                                                  // NK = 4: two gaps per group, two phases per gap
-              epi_group(pl, pob, j, 2 * ph, dst, pk);
-              epi_group(pl, pob, j, 2 * ph + 1, dst, pk);
+              epi_group(IC<pl>{}, IC<pob>{}, j, 2 * ph, dst, pk);
+              epi_group(IC<pl>{}, IC<pob>{}, j, 2 * ph + 1, dst, pk);
             }
           }
           constexpr int CO2 = NP * NK > 8 ? 8 : NP * NK - 1;
@@ -748,10 +795,10 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
       h2_read(7);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        epi3_group(7, j, 0, v);
-        epi3_group(7, j, 1, v);
-        epi3_group(7, j, 2, v);
-        epi3_group(7, j, 3, v);
+        epi3_group(IC<7>{}, j, 0, v, IC<1>{});                           // (straight-line tail: the store right behind the compare -> padded)
+        epi3_group(IC<7>{}, j, 1, v, IC<1>{});
+        epi3_group(IC<7>{}, j, 2, v, IC<1>{});
+        epi3_group(IC<7>{}, j, 3, v, IC<1>{});
       }
       gate_store(7);
       if constexpr (STORE && ST3) {
