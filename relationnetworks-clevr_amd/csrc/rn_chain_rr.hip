@@ -336,21 +336,37 @@ struct RRArgsF {
   u64* mask[RR_L];
   int prio;
 };
-__device__ __forceinline__ unsigned relu_pack_f16(float a, float b) {     // saturate instead of overflowing fp16 to inf
-  // convert (RNE, +inf beyond 65520), ReLU on the packed pair (a negative fp16 is a negative int16), then ONE packed unsigned
-  // minimum against 0x7BFF = 65504 -- the same bits as clamping both floats first, with one VALU instruction less per pair
-#ifdef RR_RELU_PACK_OLD                                    // (variant builds: the two v_min_f32 in front of the conversion)
+// The forward kernel runs with MODE.FP16_OVFL = 1 (rr_fp16_ovfl_on, first instruction): fp16 results that overflow are CLAMPED to
+// +-65504 by the conversion itself, and -- same mode bit -- v_cvt_scalef32_pk_fp8_f16 saturates at 448 (byte 0x7e) instead of
+// producing the NaN byte 0x7f (tools/dbg/ovfl_probe.hip pins both on gfx950).  The saturation that round 4 bought with three packed
+// minimums per four values (65504 on the operand pair, 448 on both pairs in front of the e4m3 conversion) is therefore free:
+// same bits, 16 VALU instructions less per stage -- the kernel is bound by VALU issue beside the MFMAs (forward chain alone,
+// same box, alternating: 126.3 us with the float clamps of round 4 -> 119.3 with packed minimums -> this).
+__device__ __forceinline__ void rr_fp16_ovfl_on() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }   // hwreg(HW_REG_MODE, 23, 1)
+__device__ __forceinline__ unsigned relu_pack_f16(float a, float b) {     // (FP16_OVFL: saturates instead of overflowing to inf)
+#if defined(RR_RELU_PACK_OLD)                               // (variant builds: the two v_min_f32 in front of the conversion)
   const f32x2 f = {fminf(a, 65504.f), fminf(b, 65504.f)};
 #else
   const f32x2 f = {a, b};
 #endif
   s16x2 x = __builtin_bit_cast(s16x2, __builtin_convertvector(f, f16x2));
   const s16x2 z = {0, 0};
-  x = __builtin_elementwise_max(x, z);
-#ifdef RR_RELU_PACK_OLD
-  return __builtin_bit_cast(unsigned, x);
-#else
+  x = __builtin_elementwise_max(x, z);                      // ReLU on the packed pair: a negative fp16 is a negative int16
+#if defined(RR_NO_FP16_OVFL) && !defined(RR_RELU_PACK_OLD)
   return rn_pk_min_u16(__builtin_bit_cast(unsigned, x), 0x7BFF);
+#else
+  return __builtin_bit_cast(unsigned, x);
+#endif
+}
+// two packed NON-NEGATIVE fp16 pairs -> four e4m3 bytes; the clamp at 448 is the conversion's own under FP16_OVFL
+__device__ __forceinline__ unsigned rr_fp8x4_from_f16(unsigned lo, unsigned hi) {
+#if defined(RR_NO_FP16_OVFL) || defined(RR_RELU_PACK_OLD)
+  return rn_fp8x4_from_f16(lo, hi);
+#else
+  rn_s16x2 r = {0, 0};
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(rn_f16x2, lo), RN_H8_SCALE, false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(rn_f16x2, hi), RN_H8_SCALE, true);
+  return __builtin_bit_cast(unsigned, r);
 #endif
 }
 template <int NK0, bool STORE, bool ST3, bool XG, bool ALG0 = false, int INJ = 0, bool H8 = false, bool GATE = false, bool LO = false>
@@ -443,6 +459,9 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
   static_assert(!GATE || (H8 && MASK && !ST3), "the gate image belongs to the training output set with e4m3 copies");
   static_assert(!LO || (!STORE && !MASK), "two passes on every layer: the inference variant");
   typedef F16Vm<NK0, STORE, ST3, XG, ALG0, INJ, H8, GATE, LO> Vm;
+#if !defined(RR_NO_FP16_OVFL) && !defined(RR_RELU_PACK_OLD)
+  rr_fp16_ovfl_on();
+#endif
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
   k.init(lds);
@@ -596,7 +615,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
       if (GATE && pl == RR_L - 2) return;                             // (H_2 is staged by the last layer, with its gate)
       if (ph == 2 && STORE) {
         if constexpr (H8) {
-          pk[j][0] = rn_fp8x4_from_f16(pk[j][0], pk[j][1]);
+          pk[j][0] = rr_fp8x4_from_f16(pk[j][0], pk[j][1]);
         } else {
           pk[j][0] = relu_pack_bf16(c[4 * j + 0], c[4 * j + 1]);
           pk[j][1] = relu_pack_bf16(c[4 * j + 2], c[4 * j + 3]);
@@ -638,7 +657,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
     const unsigned gate_lane = (unsigned)((h * RR_G + n) * 16);
     // H_2 block pob, accumulator group j: the lane's four features 8 j + 4 h + r of row n, from the fp16 operand pair of the last layer
     auto h2_stage = [&](int pob, int j, unsigned f0, unsigned f1) {
-      if constexpr (GATE) *reinterpret_cast<unsigned*>(stg + n * RR_SRS8 + 32 * (pob & 1) + 8 * j + 4 * h) = rn_fp8x4_from_f16(f0, f1);
+      if constexpr (GATE) *reinterpret_cast<unsigned*>(stg + n * RR_SRS8 + 32 * (pob & 1) + 8 * j + 4 * h) = rr_fp8x4_from_f16(f0, f1);
     };
     auto h2_read = [&](int pob) {
       if constexpr (GATE) {
