@@ -114,8 +114,56 @@ class SyntheticRelationalTask(SyntheticClevr):
             yield {"image": img, "question": qst, "answer": ans}
 
 
+class SyntheticPairRelationTask(SyntheticClevr):
+    """A RELATIONAL learnable task (the one-square task above needs no pair reasoning): three 20 x 20 squares,
+    one per colour channel, in three distinct cells of a 4 x 4 grid over noise in [0, 0.3).  Question = (kind, colour c) in the
+    first two tokens (the rest is filler 7; load_tensor_data's reversal moves them to the end like the reference's, utils.py:138-141):
+      kind 1: in which COLUMN is the c square?                               -> answers 1..4   (one object)
+      kind 2: which colour has the square CLOSEST to the c square?           -> answers 5..7   (a comparison over pairs; ties are
+              excluded by construction: squared grid distances to the two others differ)
+      kind 3: how many OTHER squares share the c square's ROW?               -> answers 8..10  (a count over pairs)
+    1-based answers like the reference's (utils.py:149)."""
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed)
+        hw = self.hw
+        cell, side = hw // 4, (5 * hw) // 32
+        for _ in range(len(self)):
+            B = self.bs
+            img = torch.rand(B, 3, hw, hw, generator=g) * 0.3
+            kind = torch.randint(1, 4, (B,), generator=g)
+            col = torch.randint(0, 3, (B,), generator=g)
+            ans = torch.zeros(B, 1, dtype=torch.int64)
+            for s_ in range(B):
+                while True:                                             # three distinct cells, no tie for "closest"
+                    cells = torch.randperm(16, generator=g)[:3].tolist()
+                    pos = [(c_ // 4, c_ % 4) for c_ in cells]
+                    c0 = int(col[s_])
+                    o = [i for i in range(3) if i != c0]
+                    d = [(pos[c0][0] - pos[i][0]) ** 2 + (pos[c0][1] - pos[i][1]) ** 2 for i in o]
+                    if d[0] != d[1]:
+                        break
+                for ch, (r_, c_) in enumerate(pos):
+                    y0, x0 = r_ * cell + (cell - side) // 2, c_ * cell + (cell - side) // 2
+                    img[s_, ch, y0:y0 + side, x0:x0 + side] = 0.9
+                k_ = int(kind[s_])
+                if k_ == 1:
+                    ans[s_, 0] = 1 + pos[c0][1]
+                elif k_ == 2:
+                    ans[s_, 0] = 5 + (o[0] if d[0] < d[1] else o[1])
+                else:
+                    ans[s_, 0] = 8 + sum(1 for i in o if pos[i][0] == pos[c0][0])
+            qst = torch.full((B, self.max_len), 7, dtype=torch.int64)
+            qst[:, 0] = kind
+            qst[:, 1] = 4 + col
+            yield {"image": img, "question": qst, "answer": ans}
+
+
+TASKS = {"square": SyntheticRelationalTask, "pairs": SyntheticPairRelationTask}
+
+
 def convergence_run(precision, steps=400, batch=64, lr=1e-3, seed=0, device="cuda", h8=None, eval_batches=4, log_every=25,
-                    model_name="original-fp", use_graph=True):
+                    model_name="original-fp", use_graph=True, task="square"):
     """Train `model_name` for `steps` Adam steps (clip 50, weight decay 1e-4: train.py:45-46,330) on SyntheticRelationalTask in the
     arithmetic mode `precision`, same seeds whatever the mode -> {"loss": [mean loss per `log_every` steps], "final_loss",
     "accuracy" (held-out batches, eval mode), "copy_guard": the trainer's e4m3 guard log}.  The run the convergence test and
@@ -136,7 +184,7 @@ def convergence_run(precision, steps=400, batch=64, lr=1e-3, seed=0, device="cud
     ctx = _opt.override(h8=h8) if h8 is not None else contextlib.nullcontext()
     with ctx:
         tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0, use_graph=use_graph)
-        data = SyntheticRelationalTask((steps + eval_batches) * batch, batch, seed=seed + 1)
+        data = TASKS[task]((steps + eval_batches) * batch, batch, seed=seed + 1)
         it = iter(data)
         curve, acc_l = [], []
         for st in range(steps):
@@ -152,7 +200,7 @@ def convergence_run(precision, steps=400, batch=64, lr=1e-3, seed=0, device="cud
                 img, qst, lab = load_tensor_data(next(it), device)
                 hit += int((model(img, qst).argmax(1) == lab).sum())
                 tot += lab.numel()
-    return {"precision": precision, "h8": _opt.OPT.h8 if h8 is None else h8, "steps": steps, "batch": batch, "lr": lr, "loss": curve,
+    return {"precision": precision, "task": task, "h8": _opt.OPT.h8 if h8 is None else h8, "steps": steps, "batch": batch, "lr": lr, "loss": curve,
             "final_loss": curve[-1], "accuracy": hit / tot, "copy_guard": tr.copy_guard_log}
 
 

@@ -65,6 +65,32 @@ def test_synthetic_batches_have_reference_shapes(T):
     assert sd["image"].shape == (4, 12, 7) and bool((sd["image"][:, -1] == 0).all())
 
 
+def test_pair_relation_task_labels_follow_from_the_images(T):
+    """train.SyntheticPairRelationTask (the relational convergence task): the answers are re-derived here from the IMAGES alone --
+    squares found by thresholding each colour channel -- so that the labels the convergence runs train on are what the docstring
+    says: column of a square, colour of the closest other square (never a tie), number of other squares in its row."""
+    data = T.SyntheticPairRelationTask(3 * 32, 32, seed=5)
+    seen = set()
+    for batch in data:
+        img, qst, ans = batch["image"], batch["question"], batch["answer"].reshape(-1)
+        assert img.shape == (32, 3, 128, 128) and qst.shape == (32, 20) and int(qst[:, 2:].min()) == 7 == int(qst[:, 2:].max())
+        for s_ in range(32):
+            pos = []
+            for ch in range(3):
+                ys, xs = torch.nonzero(img[s_, ch] > 0.5, as_tuple=True)
+                assert ys.numel() == 400                                   # one 20 x 20 square per channel
+                pos.append((int(ys.min()) // 32, int(xs.min()) // 32))
+            assert len(set(pos)) == 3
+            kind, c0 = int(qst[s_, 0]), int(qst[s_, 1]) - 4
+            o = [i for i in range(3) if i != c0]
+            d = [(pos[c0][0] - pos[i][0]) ** 2 + (pos[c0][1] - pos[i][1]) ** 2 for i in o]
+            assert d[0] != d[1]
+            want = {1: 1 + pos[c0][1], 2: 5 + (o[0] if d[0] < d[1] else o[1]), 3: 8 + sum(pos[i][0] == pos[c0][0] for i in o)}[kind]
+            assert int(ans[s_]) == want
+            seen.add(want)
+    assert seen >= set(range(1, 10))                                       # every answer family occurs (a count of 2 is rare)
+
+
 def test_checkpoint_roundtrip_and_module_prefix(T, tmp_path):
     import relationnetworks_clevr_amd as pkg
 

@@ -6,13 +6,14 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from kname import pretty
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_final")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 dst = lambda n: os.path.join(ROOT, "profiles", "%s_%s" % (tag, n))
 shutil.copy(os.path.join(src, "kernel_stats.csv"), dst("kernel_stats_rocprofv3.csv"))
 shutil.copy(os.path.join(src, "bench_line.json"), dst("bench_line.json"))
 shutil.copy(os.path.join(src, "step_timeline.txt"), dst("step_timeline.txt"))
-for extra in ("bench_ir_fp.json", "bench_stress_b32_n196.json", "small_kernels_alone.txt", "k1_alone.txt", "wgrad_alone.txt", "fwd_chain_alone.txt",
-              "bwd_chain_alone.txt", "extract_alone.txt", "pmc_extract_write.txt", "convergence.txt", "clocks.txt"):
+for extra in ("bench_ir_fp.json", "bench_stress_b32_n196.json", "bench_original_sd_b4.json", "small_kernels_alone.txt", "k1_alone.txt", "wgrad_alone.txt",
+              "fwd_chain_alone.txt", "bwd_chain_alone.txt", "extract_alone.txt", "pmc_extract_write.txt", "convergence.txt", "convergence_pairs.txt",
+              "clocks.txt", "graph_gaps.txt", "parity_report.jsonl", "kernel_resources.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), dst(extra))
 OURS = re.compile(r"(rr_kernel|rr_f16s|rr_bwd|wgrad|pair_|f_phi|cn_|lstm_|emb_bwd|conv3x3s2|conv_wgrad|clip_adam|sumsq|nll_|segsum|pack_frag|debug_stamp)")
@@ -49,4 +50,16 @@ with open(dst("pmc_sq_counters.txt"), "w") as f:
             "# SQ_VALU_MFMA_BUSY_CYCLES (cycles = 32 x MFMA count for v_mfma_f32_32x32x16_bf16), MI355X_MICROARCH.md units\n")
     for c in ("sq1", "sq2"):
         f.write(open(os.path.join(src, "pmc_%s.txt" % c)).read())
-print("published to profiles/%s_*" % tag)
+# the A/B and ablation logs DESIGN.md quotes: the DIAG-build ablations of the collection run + whatever A/B logs of the round sit in
+# gpurun_out/ (one gpurun call each: same box within a file)
+abl_dst = os.path.join(ROOT, "profiles", "%s_ablations" % tag)
+os.makedirs(abl_dst, exist_ok=True)
+abl_src = os.path.join(src, "ablations")
+if os.path.isdir(abl_src):
+    for f in sorted(os.listdir(abl_src)):
+        if f.endswith(".txt"):
+            shutil.copy(os.path.join(abl_src, f), os.path.join(abl_dst, f))
+for f in sorted(os.listdir(os.path.join(ROOT, "gpurun_out"))):
+    if f.startswith("ab_") and f.endswith(".txt"):
+        shutil.copy(os.path.join(ROOT, "gpurun_out", f), os.path.join(abl_dst, f))
+print("published to profiles/%s_* and profiles/%s_ablations/" % (tag, tag))
