@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RN_ABI_VERSION 8   /* bumped whenever a signature or a buffer layout of this header changes */
+#define RN_ABI_VERSION 9   /* bumped whenever a signature or a buffer layout of this header changes */
 
 enum { RN_BF16 = 0, RN_F32 = 1, RN_F16 = 2, RN_FP8 = 3 };   /* RN_F16: pair matrix / split weights of the f16s forward only;
                                                              * RN_FP8: OCP e4m3 copies of the stored activations (h_dtype / a_dtype) */
@@ -125,8 +125,14 @@ int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* con
  * 0's pre-activation (dZ[3] above: 134 MB at B = 64, n = 64) is neither written nor read back -- its only readers are
  *   Rj[b,j,:] = sum_i dZ_0[(b,i,j),:]   and   Ri[b,i,:] = sum_j dZ_0[(b,i,j),:]
  * and the kernel leaves fp32 PARTIALS of both, summed from the un-rounded accumulators in a fixed order (bitwise reproducible):
- *   rj_part (M / 256 / tiles_per_unit, 32, 256): unit u = ((b * n/32 + jg) * nu + v), nu = (n / 8) / tiles_per_unit, holds the sum
+ *   rj_part (records, 32, 256): unit u = ((b * n/32 + jg) * nu + v), nu = (n / 8) / tiles_per_unit, holds the sum
  *            over the i of its tiles_per_unit tiles (8 consecutive i each) for the 32 objects j of block jg;
+ *            BALANCED TAIL (ABI 9): units u < units_whole run as a whole and leave record u; the tiles of the units behind them are
+ *            handed to the workgroups one by one (U units on C CUs: the last U mod C units would otherwise occupy U mod C CUs for a
+ *            whole unit while the rest idle) and leave a record EACH: tile 0 in record u, tile t > 0 in record
+ *            nunits + (u - units_whole) (tiles_per_unit - 1) + t - 1.  records = nunits + (nunits - units_whole) (tiles_per_unit - 1);
+ *            rn_g_chain_bwd_rr_red_whole(M, n, njp, tiles_per_unit) returns the library's choice (C floor(U / C); -1: shape not
+ *            supported); any value in [0, nunits] is valid (nunits = no tail) as long as rn_pair_reduce_parts gets the same one;
  *   ri_part (M / 16, 256): rows ((b*n + i) * n/32 + jg) * 2 + {0, 1} = the sums over the two 16-object halves of block jg.
  * rn_pair_reduce_parts adds them up to Rj, Ri (B*n, 256) and Rq (B, 256) -- what rn_pair_reduce_bwd produces from a stored dZ_0.
  * Needs the masks of a forward call with the same M and njp, dZ[0] == NULL (the gate job of rn_g_wgrad_blocked stands in for it)
@@ -138,10 +144,11 @@ int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* con
  * and contribute zeros).  Index formulas with n/32 -> njp/32, n/8 -> ceil(n/8): rj_part (B * njp/32 * nu, 32, 256),
  * ri_part (M / 16, 256); rn_pair_reduce_parts reads only the rows j < n. */
 int rn_g_chain_bwd_rr_red_tpu(int M, int n, int njp);
+int rn_g_chain_bwd_rr_red_whole(int M, int n, int njp, int tiles_per_unit);
 int rn_g_chain_bwd_rr_red(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M, int n, int njp, int L,
-                          int G, float* rj_part, float* ri_part, int tiles_per_unit, void* stream);
+                          int G, float* rj_part, float* ri_part, int tiles_per_unit, int units_whole, void* stream);
 int rn_pair_reduce_parts(const float* rj_part, const float* ri_part, float* Rj, float* Ri, float* Rq, int B, int n, int njp, int G, int nu,
-                         void* stream);
+                         int tiles_per_unit, int units_whole, void* stream);
 /* MFMA-fragment-major weight images for the register-resident chains, `count` (<= 16) of them in ONE launch; all arguments are
  * HOST arrays of `count` entries.  Image i: dst (65536 elements) gets, for output block ob, K16 step ks, lane, element e:
  * src[32 ob + lane % 32][kidx] (0 beyond R rows / C columns) with

@@ -919,10 +919,13 @@ struct RRRedArgs {
   float* ri_part;                                                     // (M / 16, 256) fp32: row ((b*n + i) * (njp/32) + jg) * 2 + lane half
   int n_obj, tiles_per_unit;
   int njp;                                                            // pair rows per (question, i) group: n_obj, or 32 ceil(n_obj / 32) (padded j axis)
+  int units_whole;                                                    // units [0, units_whole) run as tiles_per_unit tiles and leave ONE Rj record; the others
+                                                                      // run one tile at a time (a balanced tail) and leave one record PER TILE: tile 0 in the
+                                                                      // unit's own record, tile t > 0 in record nunits + (unit - units_whole) (tpu - 1) + t - 1
 };
 }  // namespace
 template <int ABL, bool SKIP0 = false, bool RED = false>
-__global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int ntiles, RRRedArgs ra = RRRedArgs{nullptr, nullptr, 0, 1, 0}) {
+__global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int ntiles, RRRedArgs ra = RRRedArgs{nullptr, nullptr, 0, 1, 0, 0}) {
   static_assert(!RED || (SKIP0 && ABL == 0), "in-kernel pair reductions: the product variant without a stored dZ[0]");
   typedef BwdVm<SKIP0, RED> Vm;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
@@ -951,8 +954,12 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
   float rs = 0.f;
 
   const int nunits = RED ? ntiles / ra.tiles_per_unit : ntiles;       // (non-RED: a unit is a tile)
-  int unit = blockIdx.x;
-  if (unit >= nunits) return;
+  // RED: work items = the whole units, then the tiles of the remaining units one by one -- with U units on C CUs the last
+  // U mod C units would keep U mod C workgroups busy for a whole unit while the others idle (14 x 14 grid: 1120 units of 5 tiles
+  // on 256 CUs = 25 tile times; 1024 whole units + 480 single tiles = 22)
+  const int nitems = RED ? ra.units_whole + (nunits - ra.units_whole) * ra.tiles_per_unit : ntiles;
+  int item = blockIdx.x;
+  if (item >= nitems) return;
   // Two waves share each SIMD; the hardware arbitrates their issue slots by priority, then age, and the second-dispatched
   // half loses every stage head.  One static s_setprio for that half evens the pair out (MI355X_MICROARCH.md, "Two waves
   // per SIMD", item 4).  RN_RR_PRIO=0 turns it off.
@@ -976,13 +983,23 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
   unsigned char* const xwb = lds + (w * 8) * 512 + lane * 8;          // this wave's slice of an exchange buffer
   const unsigned char* const xrb = lds + w * 512 + lane * 8;          // ... and the piece it owns of every wave's slice
 
-  for (; unit < nunits; unit += gridDim.x) {
+  for (; item < nitems; item += gridDim.x) {
+   int tile0 = item, tcount = 1;
+   long rec = item;                                                   // Rj record of this item
    if constexpr (RED) {
 #pragma unroll
      for (int ob = 0; ob < 8; ++ob) racc[ob][0] = racc[ob][1] = 0.f;
+     if (item < ra.units_whole) {
+       tile0 = item * ra.tiles_per_unit;
+       tcount = ra.tiles_per_unit;
+     } else {
+       const int f = item - ra.units_whole, uo = f / ra.tiles_per_unit, t = f - uo * ra.tiles_per_unit;
+       tile0 = (ra.units_whole + uo) * ra.tiles_per_unit + t;
+       rec = t == 0 ? ra.units_whole + uo : (long)nunits + (long)uo * (ra.tiles_per_unit - 1) + t - 1;
+     }
    }
-   for (int tu = 0; tu < (RED ? ra.tiles_per_unit : 1); ++tu) {
-    const int tile = RED ? unit * ra.tiles_per_unit + tu : unit;
+   for (int tu = 0; tu < tcount; ++tu) {
+    const int tile = tile0 + tu;
     // wave-tile of this wave = index of the forward wave whose 32 pair rows it takes over
     long wt = (long)tile * RR_NW + w;
     bool wvalid = true;
@@ -1227,7 +1244,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
    }
    if constexpr (RED) {
      // the unit's Rj partial: this wave owns accumulator group w / 2, register pair w % 2 -> rows 8 (w / 2) + 4 h + 2 (w % 2) + e
-     float* dst = ra.rj_part + ((long)unit * RR_WR + 8 * (w >> 1) + 4 * h + 2 * (w & 1)) * RR_G + n;
+     float* dst = ra.rj_part + (rec * RR_WR + 8 * (w >> 1) + 4 * h + 2 * (w & 1)) * RR_G + n;
 #pragma unroll
      for (int ob = 0; ob < 8; ++ob) {
        dst[32 * ob] = racc[ob][0];
@@ -1423,8 +1440,16 @@ extern "C" int rn_g_chain_bwd_rr_red_tpu(int M, int n, int njp) {
   return tpu;
 }
 
+// Whole units of the balanced schedule: with U units on C CUs, the first C floor(U / C); the tiles of the other U mod C units are
+// handed out one by one.  (tiles_per_unit == 1: a unit IS a tile -- all whole.)
+extern "C" int rn_g_chain_bwd_rr_red_whole(int M, int n, int njp, int tiles_per_unit) {
+  if (rn_g_chain_bwd_rr_red_tpu(M, n, njp) <= 0 || tiles_per_unit <= 0 || ((n + RR_NW - 1) / RR_NW) % tiles_per_unit != 0) return -1;
+  const int nunits = (int)(rr_red_tiles(M, n, njp) / tiles_per_unit);
+  return tiles_per_unit == 1 ? nunits : (nunits / rr_num_cus()) * rr_num_cus();
+}
+
 extern "C" int rn_g_chain_bwd_rr_red(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M, int n,
-                                     int njp, int L, int G, float* rj_part, float* ri_part, int tiles_per_unit, void* stream) {
+                                     int njp, int L, int G, float* rj_part, float* ri_part, int tiles_per_unit, int units_whole, void* stream) {
   RN_CHECK_ARG(dxg && mask && Wtf && dZ && rj_part && ri_part && M > 0, "rn_g_chain_bwd_rr_red: bad pointer/size");
   RN_CHECK_ARG(G == RR_G && L == RR_L, "rn_g_chain_bwd_rr_red: needs G == 256 and L == 4 (G=%d L=%d)", G, L);
   RN_CHECK_ARG(rn_g_chain_bwd_rr_red_tpu(M, n, njp) > 0,
@@ -1453,9 +1478,11 @@ extern "C" int rn_g_chain_bwd_rr_red(const float* dxg, const void* const* mask, 
   RN_CHECK_ARG(((uintptr_t)dxg | (uintptr_t)rj_part | (uintptr_t)ri_part) % 16 == 0, "rn_g_chain_bwd_rr_red: dxg / partials must be 16-byte aligned");
   a.dxg = dxg;
   a.rows_per_b = n * njp;
-  RRRedArgs ra{rj_part, ri_part, n, tiles_per_unit, njp};
   const int nunits = ntiles / tiles_per_unit;
-  const int grid = nunits < rr_num_cus() ? nunits : rr_num_cus();
+  RN_CHECK_ARG(units_whole >= 0 && units_whole <= nunits, "rn_g_chain_bwd_rr_red: units_whole=%d must lie in [0, %d]", units_whole, nunits);
+  RRRedArgs ra{rj_part, ri_part, n, tiles_per_unit, njp, units_whole};
+  const long nitems = units_whole + (long)(nunits - units_whole) * tiles_per_unit;
+  const int grid = nitems < rr_num_cus() ? (int)nitems : rr_num_cus();
   g_chain_rr_bwd_kernel<0, true, true><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles, ra);
   RN_LAUNCH_CHECK("rn_g_chain_bwd_rr_red");
   return 0;

@@ -178,8 +178,9 @@ _SIDE_STREAMS = {}
 # tools/dbg/exp_bench.py can A/B them on one box.  wgrad_late: 0 the g_theta weight-gradient launch right behind the backward chain,
 # 1 behind the partial sums AND the layer-0 stream (default), 2 behind dx / dq too, 3 behind the partial sums only;
 # conv_wgrad_stream: the side stream the conv weight gradients share (0 the g_theta weight gradient's, 2 the layer-0 stream's);
-# fphi_grads_late: f_phi's parameter gradients on the layer-0 stream instead of in front of the backward chain.
-SCHED = {"wgrad_late": 1, "conv_wgrad_stream": 2, "fphi_grads_late": 1}
+# fphi_grads_late: f_phi's parameter gradients on the layer-0 stream instead of in front of the backward chain;
+# chain_balance: the reducing backward chain's units beyond a whole number of rounds over the CUs run tile by tile (0: whole units only).
+SCHED = {"wgrad_late": 1, "conv_wgrad_stream": 2, "fphi_grads_late": 1, "chain_balance": 1}
 
 
 def _side_stream(dev, which=0):
@@ -628,9 +629,11 @@ class RelationalFunction(torch.autograd.Function):
             tpu = H.g_chain_bwd_rr_red_tpu(Mc, n, njp) if OPT.chain_reduce else 0
             if tpu > 0:
                 dZs = [None] + list(torch.empty(L - 2, Mc, G, dtype=dt, device=dev)) + [None]
-                red_parts = (torch.empty(H.g_chain_bwd_rr_red_units(Mc, n, njp, tpu), 32, G, **f32), torch.empty(Mc // 16, G, **f32),
-                             ((n + 7) // 8) // tpu)
-                H.g_chain_bwd_rr_red(dxg, masks, ctx.fragT, dZs, Mc, n, G, red_parts[0], red_parts[1], tpu, njp=njp)
+                # balanced tail (round 5): the units beyond a whole number of rounds over the CUs run tile by tile
+                whole = H.g_chain_bwd_rr_red_whole(Mc, n, njp, tpu) if SCHED["chain_balance"] else H.g_chain_bwd_rr_red_units(Mc, n, njp, tpu)
+                red_parts = (torch.empty(H.g_chain_bwd_rr_red_records(Mc, n, njp, tpu, whole), 32, G, **f32), torch.empty(Mc // 16, G, **f32),
+                             ((n + 7) // 8) // tpu, tpu, whole)
+                H.g_chain_bwd_rr_red(dxg, masks, ctx.fragT, dZs, Mc, n, G, red_parts[0], red_parts[1], tpu, njp=njp, whole=whole)
             else:
                 dZs = [None] + list(torch.empty(L - 1, Mc, G, dtype=dt, device=dev))
         else:
@@ -735,7 +738,7 @@ class RelationalFunction(torch.autograd.Function):
         wl = g_w[0] if g_w[0].is_contiguous() else g_w[0].contiguous()
         Rj = torch.empty(B * n, N, **f32); Ri = torch.empty(B * n, N, **f32); Rq = torch.empty(B, N, **f32)
         if red_parts is not None:                                  # the chain has already reduced: add its partials up
-            H.pair_reduce_parts(red_parts[0], red_parts[1], Rj, Ri, Rq, B, n, N, red_parts[2], njp=njp)
+            H.pair_reduce_parts(red_parts[0], red_parts[1], Rj, Ri, Rq, B, n, N, red_parts[2], njp=njp, tpu=red_parts[3], whole=red_parts[4])
         else:
             H.pair_reduce_bwd(dZ_of[0], N, Rj, Ri, Rq, H.RN_BF16, B, n, N, njp=njp)
         if late:

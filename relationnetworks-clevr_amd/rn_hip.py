@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librn_hip.so")
 RN_BF16, RN_F32, RN_F16, RN_FP8 = 0, 1, 2, 3
 RN_RELU, RN_ACCUMULATE = 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 
@@ -37,8 +37,9 @@ SIGNATURES = {
     "rn_f_phi_fwd_from_partials": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rn_g_chain_bwd_rr_red_tpu": (_I, [_I, _I, _I]),
-    "rn_g_chain_bwd_rr_red": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
-    "rn_pair_reduce_parts": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rn_g_chain_bwd_rr_red_whole": (_I, [_I, _I, _I, _I]),
+    "rn_g_chain_bwd_rr_red": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P]),
+    "rn_pair_reduce_parts": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "rn_pack_matrix_frag_many": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "rn_pair_sum_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "rn_pair_sum_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
@@ -348,26 +349,44 @@ def g_chain_bwd_rr_red_tpu(M, n, njp=None):
 
 
 def g_chain_bwd_rr_red_units(M, n, njp, tpu):
-    """Units (rows / 32 of rj_part) of the reducing backward chain: B * njp/32 * ceil(n/8) / tpu."""
+    """Units of the reducing backward chain: B * njp/32 * ceil(n/8) / tpu."""
     return (M // (n * njp)) * (njp // 32) * ((n + 7) // 8) // tpu
 
 
+def g_chain_bwd_rr_red_whole(M, n, njp, tpu):
+    """The library's split point of the balanced schedule: units below it run as a whole, the tiles of the others one by one."""
+    w = int(load().rn_g_chain_bwd_rr_red_whole(M, n, njp or n, tpu))
+    if w < 0:
+        raise ValueError(f"rn_g_chain_bwd_rr_red_whole: shape not supported (M={M} n={n} njp={njp} tpu={tpu})")
+    return w
+
+
+def g_chain_bwd_rr_red_records(M, n, njp, tpu, whole=None):
+    """Records (rows / 32 of rj_part) the chain leaves: one per whole unit, one per TILE of the units behind them."""
+    u = g_chain_bwd_rr_red_units(M, n, njp, tpu)
+    whole = u if whole is None else whole
+    return u + (u - whole) * (tpu - 1)
+
+
 @_timed("g_dgrad")
-def g_chain_bwd_rr_red(dxg, masks, Wtfs, dZs, M, n, G, rj_part, ri_part, tpu, njp=None):
+def g_chain_bwd_rr_red(dxg, masks, Wtfs, dZs, M, n, G, rj_part, ri_part, tpu, njp=None, whole=None):
     """Register-resident backward chain with the pair-axis reductions of layer 0's gradient formed on chip: dZs[0] None (gate job),
     dZs[1..2] row-blocked images, dZs[3] not written; partial sums to rj_part / ri_part (pair_reduce_parts adds them up)."""
     L = len(dZs)
     mp = (C.c_void_p * L)(*[m.data_ptr() for m in masks])
     wp = (C.c_void_p * (L - 1))(*[w.data_ptr() for w in Wtfs])
     zp = (C.c_void_p * L)(*[(z.data_ptr() if z is not None else None) for z in dZs])
-    _check(load().rn_g_chain_bwd_rr_red(dxg.data_ptr(), mp, wp, zp, M, n, njp or n, L, G, rj_part.data_ptr(), ri_part.data_ptr(), tpu, _stream()),
+    whole = g_chain_bwd_rr_red_units(M, n, njp or n, tpu) if whole is None else whole      # (None: no balanced tail)
+    assert rj_part.numel() >= g_chain_bwd_rr_red_records(M, n, njp or n, tpu, whole) * 32 * G, "rj_part: one record per whole unit + one per tile behind them"
+    _check(load().rn_g_chain_bwd_rr_red(dxg.data_ptr(), mp, wp, zp, M, n, njp or n, L, G, rj_part.data_ptr(), ri_part.data_ptr(), tpu, whole, _stream()),
            "rn_g_chain_bwd_rr_red")
 
 
 @_timed("pair_reduce")
-def pair_reduce_parts(rj_part, ri_part, Rj, Ri, Rq, B, n, G, nu, njp=None):
-    _check(load().rn_pair_reduce_parts(rj_part.data_ptr(), ri_part.data_ptr(), Rj.data_ptr(), Ri.data_ptr(), _ptr(Rq), B, n, njp or n, G, nu, _stream()),
-           "rn_pair_reduce_parts")
+def pair_reduce_parts(rj_part, ri_part, Rj, Ri, Rq, B, n, G, nu, njp=None, tpu=1, whole=None):
+    whole = B * ((njp or n) // 32) * nu if whole is None else whole
+    _check(load().rn_pair_reduce_parts(rj_part.data_ptr(), ri_part.data_ptr(), Rj.data_ptr(), Ri.data_ptr(), _ptr(Rq), B, n, njp or n, G, nu, tpu, whole,
+                                       _stream()), "rn_pair_reduce_parts")
 
 
 @_timed("pair_sum")

@@ -663,8 +663,9 @@ def _padded_forward_masks(H, B, n, njp):
     return masks
 
 
-@pytest.mark.parametrize("B,n,tpu", [(17, 64, 0), (64, 64, 0), (3, 64, 1), (3, 64, 8), (2, 32, 2), (2, 96, 0), (2, 196, 0), (32, 196, 0), (4, 40, 0), (4, 40, 1)])
-def test_g_chain_bwd_rr_red(H, B, n, tpu):
+@pytest.mark.parametrize("B,n,tpu,whole", [(17, 64, 0, "lib"), (64, 64, 0, "lib"), (3, 64, 1, "lib"), (3, 64, 8, "all"), (3, 64, 8, 0), (3, 64, 4, 5), (2, 32, 2, "lib"),
+                                          (2, 96, 0, "lib"), (2, 196, 0, "lib"), (32, 196, 0, "lib"), (32, 196, 0, "all"), (2, 196, 5, 33), (4, 40, 0, "lib"), (4, 40, 1, "lib")])
+def test_g_chain_bwd_rr_red(H, B, n, tpu, whole):
     """rn_g_chain_bwd_rr_red: the pair-axis reductions of layer 0's gradient formed inside the backward chain.  The stored images
     dZ[1], dZ[2] must be bitwise those of rn_g_chain_bwd_rr; Rj / Ri / Rq (rn_pair_reduce_parts) must equal, to fp32 accumulation
     accuracy, the float64 reductions of (dZ[2] @ W_1) * gate_0 computed from the kernel's OWN stored dZ[2] and the forward's
@@ -672,7 +673,9 @@ def test_g_chain_bwd_rr_red(H, B, n, tpu):
     unit; (17, 64): more units than CUs; (64, 64): the headline shape; (2, 96): three j blocks per (question, i); (., 196), (4, 40):
     the PADDED j axis (njp = 224 / 64 pair rows per (question, i), masks of a real padded forward call) with n % 8 != 0 -- the last
     tile of a (question, j block) has four valid i, its spare waves repeat the last one and must add nothing; (32, 196) is
-    BASELINE.json configs[4] at its real size."""
+    BASELINE.json configs[4] at its real size.  whole: the split point of the BALANCED schedule -- units below it run as a whole,
+    the tiles of the others one by one with a record each ("lib": rn_g_chain_bwd_rr_red_whole's choice -- 1024 of the 1120 units of
+    (32, 196) on 256 CUs --, "all": no tail, 0: every tile on its own, 5 / 33: a split inside a (question, j block))."""
     L, G = 4, 256
     njp = (n + 31) // 32 * 32
     M = B * n * njp
@@ -693,16 +696,21 @@ def test_g_chain_bwd_rr_red(H, B, n, tpu):
     tpbj = (n + 7) // 8
     assert tpu > 0 and tpbj % tpu == 0
     nu = tpbj // tpu
+    nunits = H.g_chain_bwd_rr_red_units(M, n, njp, tpu)
+    whole = {"lib": H.g_chain_bwd_rr_red_whole(M, n, njp, tpu), "all": nunits}.get(whole, whole)
+    assert 0 <= whole <= nunits
+    if (B, n) == (32, 196) and whole != nunits:
+        assert tpu == 5 and whole == (nunits // 256) * 256 < nunits            # (the stress shape HAS a tail on a 256-CU chip)
     new = [None] + list(torch.zeros(L - 2, M, G, dtype=torch.bfloat16, device="cuda")) + [None]
-    rj_part = torch.full((H.g_chain_bwd_rr_red_units(M, n, njp, tpu), 32, G), float("nan"), device="cuda")
+    rj_part = torch.full((H.g_chain_bwd_rr_red_records(M, n, njp, tpu, whole), 32, G), float("nan"), device="cuda")
     ri_part = torch.full((M // 16, G), float("nan"), device="cuda")
-    H.g_chain_bwd_rr_red(dxg, masks, Wt, new, M, n, G, rj_part, ri_part, tpu, njp=njp)
+    H.g_chain_bwd_rr_red(dxg, masks, Wt, new, M, n, G, rj_part, ri_part, tpu, njp=njp, whole=whole)
     Rj = torch.full((B * n, G), float("nan"), device="cuda"); Ri = torch.full((B * n, G), float("nan"), device="cuda")
     Rq = torch.full((B, G), float("nan"), device="cuda")
-    H.pair_reduce_parts(rj_part, ri_part, Rj, Ri, Rq, B, n, G, nu, njp=njp)
+    H.pair_reduce_parts(rj_part, ri_part, Rj, Ri, Rq, B, n, G, nu, njp=njp, tpu=tpu, whole=whole)
     # a second run must give the same bits (fixed summation orders)
     rj2, ri2 = torch.empty_like(rj_part), torch.empty_like(ri_part)
-    H.g_chain_bwd_rr_red(dxg, masks, Wt, new, M, n, G, rj2, ri2, tpu, njp=njp)
+    H.g_chain_bwd_rr_red(dxg, masks, Wt, new, M, n, G, rj2, ri2, tpu, njp=njp, whole=whole)
     torch.cuda.synchronize()
     assert torch.equal(rj2, rj_part) and torch.equal(ri2, ri_part)
     assert not torch.isnan(rj_part).any() and not torch.isnan(ri_part).any()

@@ -55,7 +55,7 @@ def test_library_exports_every_declared_symbol(pkg):
     hdr = open(os.path.join(ROOT, "include", "rn_hip.h")).read()
     for name, val in re.findall(r"(RN_WS_[A-Z0-9_]+) = (\d+)", hdr):
         assert getattr(Hm, name[3:]) == int(val), name
-    assert len(declared) <= 60
+    assert len(declared) <= 61
     # row splits of the blocked weight gradient: njobs x Z x 4 workgroups ~ three quarters of the CUs; question-aligned on request
     sp = loaded.rn_wgrad_blocked_splits
     assert sp(64 * 4096, 4096, 1, 0) == 48 and sp(64 * 4096, 4096, 3, 0) == 16 and sp(2 * 1024, 1024, 1, 0) == 32 and sp(100, 0, 1, 0) == 0
