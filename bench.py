@@ -248,6 +248,24 @@ def time_launch(fn, n=20):
     return bracket(2) - bracket(1)
 
 
+def sustained_mfma(H, dev):
+    """The matrix pipe's sustained rate on THIS device, now: a bare stream of v_mfma_f32_32x32x16 on every SIMD of every CU
+    (rn_probe_mfma_stream: two waves per SIMD like the chains, nothing but MFMAs, launched alone for ~0.4 ms per bracket).  The chip
+    clocks to its power budget, so the nominal 2.5 PFLOP/s (2.4 GHz x 1024 flop / cycle / SIMD) is not what an MFMA-bound kernel can
+    reach: the chains' `frac_of_sustained` divides by THIS figure (f16 for the forward chain, bf16 for the backward chain and the
+    weight gradient); `frac` stays the fraction of the nominal peak."""
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    out = torch.empty(cus * 512, device=dev)
+    res = {}
+    for name, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        iters = 600
+        flops = H.probe_mfma_stream(out, cus, 2, iters, dt)
+        ms = time_launch(lambda: H.probe_mfma_stream(out, cus, 2, iters, dt), n=7)
+        res[name] = {"tflops": flops / (ms * 1e-3) / 1e12, "ns_per_mfma_slot": ms * 1e6 / (2 * iters * 16), "us_per_launch": 1e3 * ms}
+    res["what"] = "bare v_mfma_f32_32x32x16 stream, 2 waves per SIMD on every CU, launched alone (a 32-cycle slot at 2.4 GHz = 13.3 ns)"
+    return res
+
+
 def pair_build_k1(H, B, n, k, Q, dev):
     """K1 on its own at the benched shape: the (M, 2k+Q) bf16 pair matrix of model.py:112-127."""
     M = B * n * n
@@ -646,6 +664,11 @@ def main():
                 kern[kk]["hbm_frac"] = (tr_ / (per[kk] * 1e-3) / 1e9 / PEAK_HBM_GBS) if tr_ else None
                 if kk in alg_bytes:
                     kern[kk]["algorithmic_hbm_bytes"] = alg_bytes[kk]
+            # what the matrix pipe sustains on this box (the chip clocks to its power budget): the second denominator
+            sus = sustained_mfma(H, dev) if prec == "f16s" else None
+            if sus:
+                for kk in kern:
+                    kern[kk]["frac_of_sustained"] = kern[kk]["achieved_tflops"] / sus["f16" if kk == "g_fwd" else "bf16"]["tflops"]
             ach_ex = executed / (per["g_fwd"] * 1e-3) / 1e12
             g_ms, g_ms_step = sum(per.values()), sum(per_step.values())
             knames = {"g_fwd": ("%s<ALG0> (rn_chain_rr.hip): 4-layer g_theta forward chain + pair sum, 1 launch/step" % kname) if kname else
@@ -660,12 +683,15 @@ def main():
             kd = kern[dom]
             chain = dict(kern["g_fwd"], kernel=knames["g_fwd"], frac_executed=ach_ex / peak, achieved_executed=ach_ex,
                          executed_flops_per_launch=executed)
+            if sus:
+                chain["frac_executed_of_sustained"] = ach_ex / sus["f16"]["tflops"]
             out["roofline"] = {"bound": "mfma", "achieved": kd["achieved_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": kd["frac"],
                                "kernel": knames[dom], "kernel_key": dom,
                                "why_this_kernel": "longest g_theta kernel of the step (%.1f us of %.1f us of g_theta kernels)" % (1e3 * per[dom], 1e3 * g_ms),
                                "algorithmic_flops_per_launch": fl[dom], "ms_per_launch": per[dom],
                                "traffic": kd["traffic"], "traffic_source": kd["traffic_source"], "hbm_frac": kd["hbm_frac"],
                                "algorithmic_hbm_bytes": kd.get("algorithmic_hbm_bytes"),
+                               "frac_of_sustained": kd.get("frac_of_sustained"), "sustained_mfma": sus,
                                "gemm_chain": chain,
                                "kernels": kern,
                                "all_g_theta": {"algorithmic_flops_per_step": 3 * fwd, "ms_per_step": g_ms, "launches_per_step": g_launch,

@@ -30,6 +30,12 @@ int rn_rows_to_blocked(const void* src, void* dst, int dtype, int M, int back, v
  * image with this.  M % 32 == 0. */
 int rn_relu_gate_image(const void* mask, void* img, int M, void* stream);
 
+/* The matrix pipe's SUSTAINED rate on this device: `workgroups` workgroups of 256 * waves_per_simd threads, every wave issuing
+ * iters x 16 v_mfma_f32_32x32x16 (dtype RN_F16 | RN_BF16) on two alternating accumulators and nothing else.  The caller times the
+ * launch: flops = workgroups * 4 * waves_per_simd * iters * 16 * 32768.  bench.py quotes the chains against this measured rate
+ * beside the nominal 2.5 PFLOP/s (the chip clocks to its power budget).  out: workgroups * 256 * waves_per_simd floats (a sink). */
+int rn_probe_mfma_stream(float* out, int workgroups, int waves_per_simd, int iters, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,33 +104,31 @@ struct RRCore {
       asm volatile("" : "+v"(rbase[r]));
     }
   }
-  // one 1-KB piece of a 16-KB weight block: SGPR base + one lane-constant 32-bit offset, LDS address in M0.
-  // Inline asm on purpose: hipcc marks the LDS-DMA builtin as a FLAT operation that may touch both memories and
-  // from then on turns EVERY vmcnt / lgkmcnt wait into a full drain (0) while one is pending.  An asm statement
-  // is invisible to its bookkeeping; its own counted waits only get a little stricter.  M0 is the compiler's:
-  // saved and restored.
-  __device__ __forceinline__ void dma_piece(const bf16* Wl, int ob2, int slot, int i, int ring_off = RR_OFF_RING) const {
-    unsigned z = 0;
-    asm volatile("" : "+s"(z));                        // opaque 0: the base is computed AT the use (SALU), not hoisted and spilled
-    const unsigned char* ub = reinterpret_cast<const unsigned char*>(Wl) + (z + ob2 * RR_STAGE + (RR_DPW * w + i) * 1024);
-    const unsigned dst = (unsigned)(size_t)(lds_u8*)lds + (z + ring_off + slot * RR_STAGE + (RR_DPW * w + i) * 1024);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(lane16), "s"(ub), "s"(dst)
-                 : "memory");
+  // The requests of ONE ring stage that this wave issues: NPC consecutive 1-KB pieces from `src` (wave-uniform: SGPRs) to the LDS
+  // byte address wl + DST (wl: the wave's slice of the ring, an SGPR; DST: compile-time) -- SGPR base + one lane-constant 32-bit
+  // offset, LDS address in M0.  The instruction offset moves BOTH addresses (tools/dbg/ldsdma_offset_probe.hip), so ONE M0 write
+  // serves all pieces of a stage, and M0 needs no save / restore: gfx9 DS instructions do not read it and the compiler has no other
+  // use for it in these kernels (tools/kernel_resources.py checks that nothing else in them touches M0).  Round 5: 6 instructions
+  // per stage where the per-piece form (opaque zero + 64-bit adds + M0 save / restore) had 26 -- the chains are ISSUE-bound.
+  // Inline asm on purpose: hipcc marks the LDS-DMA builtin as a FLAT operation that may touch both memories and from then on turns
+  // EVERY vmcnt / lgkmcnt wait into a full drain (0) while one is pending.  An asm statement is invisible to its bookkeeping; its
+  // own counted waits only get a little stricter.
+  template <int NPC, int DST>
+  __device__ __forceinline__ void dma_run(const unsigned char* src, unsigned wl) const {
+    static_assert(NPC == 1 || NPC == 2 || NPC == 4, "pieces per wave and stage");
+    if constexpr (NPC == 1)
+      asm volatile("s_add_i32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3" : : "v"(lane16), "s"(wl), "n"(DST), "s"(src) : "memory");
+    else if constexpr (NPC == 2)
+      asm volatile("s_add_i32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\tglobal_load_lds_dwordx4 %0, %3 offset:1024"
+                   : : "v"(lane16), "s"(wl), "n"(DST), "s"(src) : "memory");
+    else
+      asm volatile("s_add_i32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\tglobal_load_lds_dwordx4 %0, %3 offset:1024\n\t"
+                   "global_load_lds_dwordx4 %0, %3 offset:2048\n\tglobal_load_lds_dwordx4 %0, %3 offset:3072"
+                   : : "v"(lane16), "s"(wl), "n"(DST), "s"(src) : "memory");
   }
-  // the same two operations with explicit geometry (the f16s kernel: 32-KB stages = hi | lo images)
-  __device__ __forceinline__ void dma_at(const void* uniform_src, int lds_off) const {
-    unsigned z = 0;
-    asm volatile("" : "+s"(z));
-    const unsigned char* ub = reinterpret_cast<const unsigned char*>(uniform_src) + z;
-    const unsigned dst = (unsigned)(size_t)(lds_u8*)lds + (z + lds_off);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(lane16), "s"(ub), "s"(dst)
-                 : "memory");
+  // this wave's slice of a ring stage as an LDS byte address (SGPR): `off` = its offset inside the stage
+  __device__ __forceinline__ unsigned lds_addr(int off) const {
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)(lds_u8*)lds + (unsigned)off));
   }
   __device__ __forceinline__ Frag rd_at(int abs) const { return *reinterpret_cast<lds_frag*>(rbase[abs >> 16] + (abs & 0xffff)); }
   __device__ __forceinline__ Frag rd_frag(int slot, int ks, int ring_off = RR_OFF_RING) const {
@@ -474,13 +472,21 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
     asm volatile("" : "+s"(base));
     return *reinterpret_cast<__attribute__((address_space(1))) const Frag*>(base + prow_off + 32 * ks);
   };
-  // request i of this wave for a stage of layer l2: piece q = dpw w + i of the stage's nimg x nfr fragments -- image q / nfr
-  // (hi, lo; wave-uniform), fragment q % nfr
-  auto dma_piece = [&](int l2, int ob2, int slot, int i, int tile_) {
-    const int q = Vm::dpw(l2) * w + i, im = q / Vm::nfr(l2), fr = q - im * Vm::nfr(l2);
+  // The requests of this wave for a stage of layer l2: pieces q = dpw w .. dpw w + dpw - 1 of the stage's nimg x nfr fragments -- image
+  // q / nfr (hi, lo; wave-uniform: dpw divides nfr), fragments q % nfr ..: consecutive KBs in the image and in the ring stage.
+  // wsrc(l2, tile_): the wave's first source byte of block 0; wdst[l2 != 0]: its slice of a ring stage (LDS byte address).
+  static_assert(Vm::nfr(0) % Vm::dpw(0) == 0 && Vm::nfr(1) % Vm::dpw(1) == 0, "a wave's pieces lie inside one image");
+  auto wsrc = [&](int l2, int tile_) -> const unsigned char* {
+    const int q = Vm::dpw(l2) * w, im = q / Vm::nfr(l2), fr = q - im * Vm::nfr(l2);
     const f16* img = (l2 == 0 || LO) ? (im ? a.Wlo[l2] : a.Whi[l2]) : a.Whi[l2] + (long)(tile_ & a.vmask) * (RR_G * RR_G);   // (the tile's dithered image)
-    k.dma_at(reinterpret_cast<const unsigned char*>(img) + ob2 * RR_STAGE + fr * 1024, RR_OFF_RING + slot * F_STAGE + im * RR_STAGE + fr * 1024);
+    return reinterpret_cast<const unsigned char*>(img) + fr * 1024;
   };
+  auto wdst_of = [&](int l2) -> unsigned {
+    const int q = Vm::dpw(l2) * w, im = q / Vm::nfr(l2), fr = q - im * Vm::nfr(l2);
+    return k.lds_addr(im * RR_STAGE + fr * 1024);
+  };
+  const unsigned wdst[2] = {wdst_of(0), wdst_of(1)};
+  const unsigned char* wsp[RR_L];                                     // per layer, for the tile at hand (layer 0: any tile)
   auto rd = [&](int slot, int ks, int p) -> Frag { return k.rd_at(RR_OFF_RING + slot * F_STAGE + p * RR_STAGE + ks * 1024); };
 
   auto op_row = [&](long m0w_) -> long {
@@ -522,10 +528,11 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
   // half loses every stage head.  One static s_setprio for that half evens the pair out (MI355X_MICROARCH.md, "Two waves
   // per SIMD", item 4).  RN_RR_PRIO=0 turns it off.
   if (a.prio && k.w >= RR_NW / 2) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-  for (int s = 0; s < F_LA; ++s)
-#pragma unroll
-    for (int i = 0; i < Vm::dpw(0); ++i) dma_piece(0, s, s, i, tile);
+  wsp[0] = wsrc(0, tile);
+  static_assert(F_LA == 3, "prologue: three stages of layer 0");
+  k.template dma_run<Vm::dpw(0), RR_OFF_RING + 0 * F_STAGE>(wsp[0] + 0 * RR_STAGE, wdst[0]);
+  k.template dma_run<Vm::dpw(0), RR_OFF_RING + 1 * F_STAGE>(wsp[0] + 1 * RR_STAGE, wdst[0]);
+  k.template dma_run<Vm::dpw(0), RR_OFF_RING + 2 * F_STAGE>(wsp[0] + 2 * RR_STAGE, wdst[0]);
 #pragma unroll
   for (int ks = 0; ks < NK0; ++ks) actA[ks] = in_frag((long)tile * RR_TM + RR_WR * w, ks);
   if constexpr (ALG0) *reinterpret_cast<f32x4*>(vc_s + lane * 4) = vc_load((long)tile * RR_TM + RR_WR * w);
@@ -547,6 +554,14 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
     const long wt = (long)tile * RR_NW + w;
     const int tnext = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
     const long m0n = (long)tnext * RR_TM + RR_WR * w;
+    // the wave's weight sources of this tile (layers 1..3: the tile's dithered image; layer 0 -- also what the last F_LA stages
+    // request for the NEXT tile -- has one image pair).  Opaque per tile: `pointer + constant` is then formed at the use (two SALU
+    // operations) instead of being hoisted out of the tile loop into 56 live address pairs.
+#pragma unroll
+    for (int l2 = 0; l2 < RR_L; ++l2) {
+      wsp[l2] = wsrc(l2, tile);
+      asm volatile("" : "+s"(wsp[l2]));
+    }
     float xs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) xs[i] = 0.f;
@@ -761,7 +776,9 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_f16s_kernel(const f16* __res
             // a one-pass stage in front of a two-pass one (the next tile's first layer): its lo read-ahead rides here
             if (NP == 1 && NPn == 2 && f >= NK) ring[ks % F_RDK][1] = rd(nslot, f - NK, 1);
           }
-          if ((c & 1) && (c >> 1) < Vm::dpw(dl) && !(ABL & 64)) dma_piece(dl, dob, dslot, c >> 1, didx >= 8 * RR_L ? tnext : tile);
+          // (stage didx >= 8 L belongs to the next tile: layer 0, whose images do not depend on the tile)
+          static_assert(F_LA < 8, "the look-ahead reaches no further than the next tile's first layer");
+          if (c == 1 && !(ABL & 64)) k.template dma_run<Vm::dpw(dl), RR_OFF_RING + dslot * F_STAGE>(wsp[dl] + dob * RR_STAGE, wdst[dl != 0]);
           if (has_prev && !(ABL & 32)) {
             const int j = c / CPG, ph = c % CPG;
             if (pl == RR_L - 1) {
@@ -926,7 +943,11 @@ struct RRRedArgs {
 }  // namespace
 template <int ABL, bool SKIP0 = false, bool RED = false>
 __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int ntiles, RRRedArgs ra = RRRedArgs{nullptr, nullptr, 0, 1, 0, 0}) {
+#ifdef RN_DIAG
+  static_assert(!RED || SKIP0, "in-kernel pair reductions: the variant without a stored dZ[0]");
+#else
   static_assert(!RED || (SKIP0 && ABL == 0), "in-kernel pair reductions: the product variant without a stored dZ[0]");
+#endif
   typedef BwdVm<SKIP0, RED> Vm;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RR_LDS];
   RRCore k;
@@ -964,10 +985,21 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
   // half loses every stage head.  One static s_setprio for that half evens the pair out (MI355X_MICROARCH.md, "Two waves
   // per SIMD", item 4).  RN_RR_PRIO=0 turns it off.
   if (a.prio && k.w >= RR_NW / 2) __builtin_amdgcn_s_setprio(1);
+  // this wave's slice of every weight block: RR_DPW consecutive KBs, in the image and in the ring stage
+  const unsigned wdst = k.lds_addr(RR_DPW * w * 1024);
+  const unsigned char* wsp[NS];
 #pragma unroll
-  for (int s = 0; s < LA; ++s)
-#pragma unroll
-    for (int i = 0; i < RR_DPW; ++i) k.dma_piece(a.W, s, s, i, RING);
+  for (int s = 0; s < NS; ++s) wsp[s] = reinterpret_cast<const unsigned char*>(a.W + s * a.w_stride) + RR_DPW * w * 1024;
+  static_assert(LA == 5 || LA == 7, "prologue: LA stages of the first step");
+  k.template dma_run<RR_DPW, RING + 0 * RR_STAGE>(wsp[0] + 0 * RR_STAGE, wdst);
+  k.template dma_run<RR_DPW, RING + 1 * RR_STAGE>(wsp[0] + 1 * RR_STAGE, wdst);
+  k.template dma_run<RR_DPW, RING + 2 * RR_STAGE>(wsp[0] + 2 * RR_STAGE, wdst);
+  k.template dma_run<RR_DPW, RING + 3 * RR_STAGE>(wsp[0] + 3 * RR_STAGE, wdst);
+  k.template dma_run<RR_DPW, RING + 4 * RR_STAGE>(wsp[0] + 4 * RR_STAGE, wdst);
+  if constexpr (LA == 7) {
+    k.template dma_run<RR_DPW, RING + 5 * RR_STAGE>(wsp[0] + 5 * RR_STAGE, wdst);
+    k.template dma_run<RR_DPW, RING + 6 * RR_STAGE>(wsp[0] + 6 * RR_STAGE, wdst);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma unroll
@@ -1000,6 +1032,10 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
    }
    for (int tu = 0; tu < tcount; ++tu) {
     const int tile = tile0 + tu;
+    // (opaque per tile: a block's address = pointer + constant is then formed at its use -- two SALU operations -- instead of being
+    //  hoisted out of the tile loop into 24 live address pairs)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) asm volatile("" : "+s"(wsp[s]));
     // wave-tile of this wave = index of the forward wave whose 32 pair rows it takes over
     long wt = (long)tile * RR_NW + w;
     bool wvalid = true;
@@ -1158,7 +1194,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
           if (f < 16) ring[ks % RR_RD] = k.rd_frag(slot, f, RING);
           else ring[ks % RR_RD] = k.rd_frag(nslot, f - 16, RING);
         }
-        if ((c & 1) && (c >> 1) < RR_DPW) k.dma_piece(a.W + dl * a.w_stride, dob, dslot, c >> 1, RING);
+        if (c == 1) k.template dma_run<RR_DPW, RING + dslot * RR_STAGE>(wsp[dl] + dob * RR_STAGE, wdst);
         if (has_prev && c >= 2 && c < 14) {                           // epilogue of the previous block, 3 gaps per group
           const int j = (c - 2) / 3, ph = (c - 2) % 3;
           if constexpr (RED && ps == NS - 1) {
@@ -1483,7 +1519,16 @@ extern "C" int rn_g_chain_bwd_rr_red(const float* dxg, const void* const* mask, 
   RRRedArgs ra{rj_part, ri_part, n, tiles_per_unit, njp, units_whole};
   const long nitems = units_whole + (long)(nunits - units_whole) * tiles_per_unit;
   const int grid = nitems < rr_num_cus() ? (int)nitems : rr_num_cus();
+#ifdef RN_DIAG
+  switch (g_diag_abl) {                                    // timing-only ablations (results are wrong): 2 no mask loads, 4 no dZ stores, 8 no waits / barriers, 32 stores to L2-resident addresses
+#define RN_ABL(v) case v: g_chain_rr_bwd_kernel<v, true, true><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles, ra); break;
+    RN_ABL(2) RN_ABL(4) RN_ABL(6) RN_ABL(8) RN_ABL(14) RN_ABL(32) RN_ABL(64)
+#undef RN_ABL
+    default: g_chain_rr_bwd_kernel<0, true, true><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles, ra); break;
+  }
+#else
   g_chain_rr_bwd_kernel<0, true, true><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles, ra);
+#endif
   RN_LAUNCH_CHECK("rn_g_chain_bwd_rr_red");
   return 0;
 }

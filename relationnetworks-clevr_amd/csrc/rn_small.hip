@@ -808,6 +808,48 @@ extern "C" int rn_debug_stamp(unsigned long long* slot, void* stream) {
   return 0;
 }
 
+// ---- the matrix pipe's SUSTAINED rate on the device at hand: every wave issues `iters` x 16 v_mfma_f32_32x32x16_{f16|bf16} on two
+// alternating accumulators from constant registers -- nothing else, one workgroup per CU, 1 or 2 waves per SIMD.  The chip clocks
+// to its power budget: this bare stream is what "MFMA-bound" can mean on a given box at a given moment (measured on the pool:
+// 19.5-20 ns per 32-cycle MFMA slot = 1.7 PFLOP/s where the nominal figure is 2.5), and bench.py quotes the chains against both.
+template <bool BF>
+__global__ __launch_bounds__(512) void mfma_stream_kernel(float* out, int iters) {
+  typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+  typedef __attribute__((ext_vector_type(8))) __bf16 b8;
+  typedef __attribute__((ext_vector_type(16))) float f16v;
+  const int lane = threadIdx.x & 63;
+  f16v acc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+  h8 ah, bh;
+  b8 ab, bb;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = 0.37f * (float)((lane * 7 + i * 3) % 17 - 8), y = 0.21f * (float)((lane * 5 + i * 11) % 13 - 6);
+    ah[i] = (_Float16)x; bh[i] = (_Float16)y; ab[i] = (__bf16)x; bb[i] = (__bf16)y;
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if constexpr (BF) acc[c & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, acc[c & 1], 0, 0, 0);
+      else acc[c & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[c & 1], 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[0][i] + acc[1][i];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+extern "C" int rn_probe_mfma_stream(float* out, int workgroups, int waves_per_simd, int iters, int dtype, void* stream) {
+  RN_CHECK_ARG(out && workgroups > 0 && (waves_per_simd == 1 || waves_per_simd == 2) && iters > 0 && (dtype == RN_BF16 || dtype == RN_F16),
+               "rn_probe_mfma_stream: out (workgroups * 256 * waves_per_simd floats), waves_per_simd 1 | 2, dtype RN_F16 | RN_BF16");
+  if (dtype == RN_BF16) mfma_stream_kernel<true><<<workgroups, 256 * waves_per_simd, 0, (hipStream_t)stream>>>(out, iters);
+  else mfma_stream_kernel<false><<<workgroups, 256 * waves_per_simd, 0, (hipStream_t)stream>>>(out, iters);
+  RN_LAUNCH_CHECK("rn_probe_mfma_stream");
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ batch hand-off
 namespace {
 struct CopyMany {

@@ -92,6 +92,7 @@ DEBUG_SIGNATURES = {
     "rn_probe_tr16": (_I, [_P, _P, _P]),
     "rn_probe_tr8": (_I, [_P, _P, _P]),
     "rn_probe_fp8_cvt": (_I, [_P, C.c_float, _P, _P, _P, _I, _P]),
+    "rn_probe_mfma_stream": (_I, [_P, _I, _I, _I, _I, _P]),
 }
 
 
@@ -255,6 +256,13 @@ def _timed(name):
 def debug_stamp(buf, slot):
     """Store the device wall clock into buf[slot] (int64 tensor), in stream order (diagnostics only)."""
     _check(load().rn_debug_stamp(buf.data_ptr() + 8 * slot, _stream()), "rn_debug_stamp")
+
+
+def probe_mfma_stream(out, workgroups, waves_per_simd, iters, dtype):
+    """Launch the bare MFMA stream (diagnostics: the matrix pipe's sustained rate on this device); returns its flop count."""
+    assert out.numel() >= workgroups * 256 * waves_per_simd and out.dtype == torch.float32
+    _check(load().rn_probe_mfma_stream(out.data_ptr(), workgroups, waves_per_simd, iters, {torch.float16: RN_F16, torch.bfloat16: RN_BF16}[dtype], _stream()), "rn_probe_mfma_stream")
+    return workgroups * 4 * waves_per_simd * iters * 16 * 32768.0
 
 
 @_timed("pair_build")
