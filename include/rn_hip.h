@@ -127,10 +127,12 @@ int rn_g_chain_bwd_rr(const float* dxg, const void* const* mask, const void* con
  * and the kernel leaves fp32 PARTIALS of both, summed from the un-rounded accumulators in a fixed order (bitwise reproducible):
  *   rj_part (records, 32, 256): unit u = ((b * n/32 + jg) * nu + v), nu = (n / 8) / tiles_per_unit, holds the sum
  *            over the i of its tiles_per_unit tiles (8 consecutive i each) for the 32 objects j of block jg;
- *            BALANCED TAIL (ABI 9): units u < units_whole run as a whole and leave record u; the tiles of the units behind them are
- *            handed to the workgroups one by one (U units on C CUs: the last U mod C units would otherwise occupy U mod C CUs for a
- *            whole unit while the rest idle) and leave a record EACH: tile 0 in record u, tile t > 0 in record
- *            nunits + (u - units_whole) (tiles_per_unit - 1) + t - 1.  records = nunits + (nunits - units_whole) (tiles_per_unit - 1);
+ *            BALANCED TAIL (ABI 9): the kernel walks the units in the order p = (v * n/32 + jg) * B + b (question fastest).  Units at
+ *            walk positions p < units_whole run as a whole and leave record u; the tiles of the units behind them are handed to the
+ *            workgroups one by one (U units on C CUs: the last U mod C units would otherwise occupy U mod C CUs for a whole unit
+ *            while the rest idle) and leave a record EACH: tile 0 in record u, tile t > 0 in record
+ *            nunits + (p - units_whole) (tiles_per_unit - 1) + t - 1 -- spread evenly over the questions, which is what
+ *            rn_pair_reduce_parts (one workgroup per question) needs.  records = nunits + (nunits - units_whole) (tiles_per_unit - 1);
  *            rn_g_chain_bwd_rr_red_whole(M, n, njp, tiles_per_unit) returns the library's choice (C floor(U / C); -1: shape not
  *            supported); any value in [0, nunits] is valid (nunits = no tail) as long as rn_pair_reduce_parts gets the same one;
  *   ri_part (M / 16, 256): rows ((b*n + i) * n/32 + jg) * 2 + {0, 1} = the sums over the two 16-object halves of block jg.

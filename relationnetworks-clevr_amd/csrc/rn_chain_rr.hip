@@ -936,9 +936,12 @@ struct RRRedArgs {
   float* ri_part;                                                     // (M / 16, 256) fp32: row ((b*n + i) * (njp/32) + jg) * 2 + lane half
   int n_obj, tiles_per_unit;
   int njp;                                                            // pair rows per (question, i) group: n_obj, or 32 ceil(n_obj / 32) (padded j axis)
-  int units_whole;                                                    // units [0, units_whole) run as tiles_per_unit tiles and leave ONE Rj record; the others
-                                                                      // run one tile at a time (a balanced tail) and leave one record PER TILE: tile 0 in the
-                                                                      // unit's own record, tile t > 0 in record nunits + (unit - units_whole) (tpu - 1) + t - 1
+  // The units are WALKED in the order p = (v * njp/32 + jg) * B + b (question fastest) for unit ((b * njp/32 + jg) * nu + v).  Walk
+  // positions [0, units_whole) run as tiles_per_unit tiles and leave ONE Rj record (the unit's own); the units behind them run one
+  // tile at a time (a balanced tail) and leave one record PER TILE: tile 0 in the unit's own record, tile t > 0 in record
+  // nunits + (p - units_whole) (tpu - 1) + t - 1.  With the question fastest the tail's extra records spread evenly over the
+  // questions (rn_pair_reduce_parts is one workgroup per question: the natural order made three questions carry the whole tail).
+  int units_whole;
 };
 }  // namespace
 template <int ABL, bool SKIP0 = false, bool RED = false>
@@ -1021,13 +1024,20 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
    if constexpr (RED) {
 #pragma unroll
      for (int ob = 0; ob < 8; ++ob) racc[ob][0] = racc[ob][1] = 0.f;
+     const int nu = tpbj / ra.tiles_per_unit, nb = nunits / (jgs * nu);
+     auto unit_at = [&](int p) {                                      // walk position -> unit
+       const int r = p / nb, b_ = p - r * nb, v_ = r / jgs, jg_ = r - v_ * jgs;
+       return (b_ * jgs + jg_) * nu + v_;
+     };
      if (item < ra.units_whole) {
-       tile0 = item * ra.tiles_per_unit;
+       rec = unit_at(item);
+       tile0 = (int)rec * ra.tiles_per_unit;
        tcount = ra.tiles_per_unit;
      } else {
        const int f = item - ra.units_whole, uo = f / ra.tiles_per_unit, t = f - uo * ra.tiles_per_unit;
-       tile0 = (ra.units_whole + uo) * ra.tiles_per_unit + t;
-       rec = t == 0 ? ra.units_whole + uo : (long)nunits + (long)uo * (ra.tiles_per_unit - 1) + t - 1;
+       const int unit = unit_at(ra.units_whole + uo);
+       tile0 = unit * ra.tiles_per_unit + t;
+       rec = t == 0 ? unit : (long)nunits + (long)uo * (ra.tiles_per_unit - 1) + t - 1;
      }
    }
    for (int tu = 0; tu < tcount; ++tu) {

@@ -632,14 +632,15 @@ extern "C" int rn_pair_reduce_bwd(const void* dZ, int lddz, float* Rj, float* Ri
 
 // ---- the same three reductions from the partials of the backward chain that reduces on chip (rn_g_chain_bwd_rr_red):
 //   rj_part (records, 32, G): unit ((b * n/32 + jg) * nu + u) = sum over the unit's i of dZ_0[(b, i, 32 jg + j), :] -- one record for
-//            a unit < units_whole; a later unit left one record per tile: tile 0 in its own record, tile t > 0 in record
-//            nunits + (unit - units_whole) (tpu - 1) + t - 1  (the balanced tail of rn_g_chain_bwd_rr_red)
+//            a unit whose walk position p = (u * njp/32 + jg) * B + b is < units_whole; a later unit left one record per tile: tile
+//            0 in its own record, tile t > 0 in record nunits + (p - units_whole) (tpu - 1) + t - 1  (the balanced tail of
+//            rn_g_chain_bwd_rr_red; question fastest in p: every question carries the same share of the tail)
 //   ri_part (B * n * n/16, G):      rows ((b * n + i) * n/32 + jg) * 2 + {0, 1} = sums over the 16 + 16 j of a wave's lane halves
 // Block = (question, 128 columns); thread = (row lane of 32, float4 column): rows r = lane, lane + 32, ... serve as i for Ri and as
 // j for Rj; the Rq partials of the row lanes meet in LDS and are added in lane order -- every sum has a fixed order.
 __global__ __launch_bounds__(1024) void pair_reduce_parts_kernel(const f32x4* __restrict__ rj_part, const f32x4* __restrict__ ri_part,
                                                                  f32x4* __restrict__ Rj, f32x4* __restrict__ Ri, f32x4* __restrict__ Rq,
-                                                                 int n, int G4, int nu, int njp, int tpu, int units_whole, int nunits) {
+                                                                 int n, int G4, int nu, int njp, int tpu, int units_whole, int nunits, int nb) {
   __shared__ f32x4 red[32][32];
   const int b = blockIdx.x, c = blockIdx.y * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
   const int jgs = njp / 16;                                           // partial rows per (question, i) (padded j axis: njp > n)
@@ -651,10 +652,11 @@ __global__ __launch_bounds__(1024) void pair_reduce_parts_kernel(const f32x4* __
       const f32x4* pj = rj_part + (long)(r & 31) * G4 + c;
       f32x4 si = pi[0], sj = {0.f, 0.f, 0.f, 0.f};
       for (int g = 1; g < jgs; ++g) si += pi[(long)g * G4];
-      for (int u = u0; u < u0 + nu; ++u) {
-        sj += pj[(long)u * 32 * G4];
-        if (u >= units_whole)
-          for (int t = 0; t < tpu - 1; ++t) sj += pj[((long)nunits + (long)(u - units_whole) * (tpu - 1) + t) * 32 * G4];
+      for (int u = 0; u < nu; ++u) {
+        sj += pj[(long)(u0 + u) * 32 * G4];
+        const int p = (u * (njp / 32) + (r >> 5)) * nb + b;           // walk position of the unit
+        if (p >= units_whole)
+          for (int t = 0; t < tpu - 1; ++t) sj += pj[((long)nunits + (long)(p - units_whole) * (tpu - 1) + t) * 32 * G4];
       }
       Ri[((long)b * n + r) * G4 + c] = si;
       Rj[((long)b * n + r) * G4 + c] = sj;
@@ -680,7 +682,7 @@ extern "C" int rn_pair_reduce_parts(const float* rj_part, const float* ri_part, 
   RN_CHECK_ARG(tiles_per_unit > 0 && units_whole >= 0 && units_whole <= nunits,
                "rn_pair_reduce_parts: tiles_per_unit=%d, units_whole=%d (of %d units)", tiles_per_unit, units_whole, nunits);
   pair_reduce_parts_kernel<<<dim3(B, cdiv(G4, 32)), 1024, 0, (hipStream_t)stream>>>((const f32x4*)rj_part, (const f32x4*)ri_part, (f32x4*)Rj,
-                                                                                     (f32x4*)Ri, (f32x4*)Rq, n, G4, nu, njp, tiles_per_unit, units_whole, nunits);
+                                                                                     (f32x4*)Ri, (f32x4*)Rq, n, G4, nu, njp, tiles_per_unit, units_whole, nunits, B);
   RN_LAUNCH_CHECK("rn_pair_reduce_parts");
   return 0;
 }
