@@ -1,5 +1,5 @@
 /* Diagnostic entry points of librn_hip.so -- NOT part of the product ABI (include/rn_hip.h).
- * Used by tests/ and tools/ only; nothing under relationnetworks-clevr_amd/ on the training / inference path calls them. */
+ * Used by tests/, tools/ and bench.py only; nothing under relationnetworks-clevr_amd/ on the training / inference path calls them. */
 #ifndef RN_HIP_DEBUG_H
 #define RN_HIP_DEBUG_H
 #ifdef __cplusplus
@@ -29,6 +29,11 @@ int rn_rows_to_blocked(const void* src, void* dst, int dtype, int M, int back, v
  * (byte & 0x7f) | gate[m, f] << 7 -- what the f16s forward chain writes for H_2 with gate_in_h2 != 0; the tests build the reference
  * image with this.  M % 32 == 0. */
 int rn_relu_gate_image(const void* mask, void* img, int M, void* stream);
+
+/* The work items of rn_g_chain_bwd_rr_red for a shape, as the kernel decodes them (host code, no launch): out (items, 3) ints =
+ * {first tile, tiles, Rj record}; returns the number of items (< 0: argument error).  tests/test_host_cpu.py checks on the CPU that
+ * every tile is run exactly once and that every record rn_pair_reduce_parts reads is written exactly once. */
+int rn_probe_red_schedule(int M, int n, int njp, int tiles_per_unit, int units_whole, int* out, int max_items);
 
 /* The matrix pipe's SUSTAINED rate on this device: `workgroups` workgroups of 256 * waves_per_simd threads, every wave issuing
  * iters x 16 v_mfma_f32_32x32x16 (dtype RN_F16 | RN_BF16) on two alternating accumulators and nothing else.  The caller times the

@@ -1025,20 +1025,8 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
 #pragma unroll
      for (int ob = 0; ob < 8; ++ob) racc[ob][0] = racc[ob][1] = 0.f;
      const int nu = tpbj / ra.tiles_per_unit, nb = nunits / (jgs * nu);
-     auto unit_at = [&](int p) {                                      // walk position -> unit
-       const int r = p / nb, b_ = p - r * nb, v_ = r / jgs, jg_ = r - v_ * jgs;
-       return (b_ * jgs + jg_) * nu + v_;
-     };
-     if (item < ra.units_whole) {
-       rec = unit_at(item);
-       tile0 = (int)rec * ra.tiles_per_unit;
-       tcount = ra.tiles_per_unit;
-     } else {
-       const int f = item - ra.units_whole, uo = f / ra.tiles_per_unit, t = f - uo * ra.tiles_per_unit;
-       const int unit = unit_at(ra.units_whole + uo);
-       tile0 = unit * ra.tiles_per_unit + t;
-       rec = t == 0 ? unit : (long)nunits + (long)uo * (ra.tiles_per_unit - 1) + t - 1;
-     }
+     const RnRedItem it = rn_red_item(item, nunits, ra.tiles_per_unit, ra.units_whole, nb, jgs, nu);   // (rn_common.h: shared with the reader)
+     tile0 = it.tile0; tcount = it.tcount; rec = it.rec;
    }
    for (int tu = 0; tu < tcount; ++tu) {
     const int tile = tile0 + tu;
@@ -1119,6 +1107,7 @@ __global__ __launch_bounds__(RR_NT) void g_chain_rr_bwd_kernel(RRBwdArgs a, int 
     if (ABL & 1) {
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) actA[ks] = Frag{(unsigned)tile, 0u, 1u, 0u};
+    } else if ((ABL & 128) && item != (int)blockIdx.x) {              // (timing only: the prologue runs for the workgroup's first tile only)
     } else {
       const float* dxb = a.dxg + b * RR_G + 8 * h;
       const unsigned* m3 = reinterpret_cast<const unsigned*>(a.mask + (RR_L - 1) * a.mask_stride) + wt * 8 * 32 + rowsel;
@@ -1494,6 +1483,22 @@ extern "C" int rn_g_chain_bwd_rr_red_whole(int M, int n, int njp, int tiles_per_
   return tiles_per_unit == 1 ? nunits : (nunits / rr_num_cus()) * rr_num_cus();
 }
 
+// The work items of a launch as the kernel decodes them (diagnostics: the CPU tests check that every tile is run exactly once and that
+// rn_pair_reduce_parts reads exactly the records that are written).  out: (items, 3) ints = first tile, tiles, record.
+extern "C" int rn_probe_red_schedule(int M, int n, int njp, int tiles_per_unit, int units_whole, int* out, int max_items) {
+  RN_CHECK_ARG(rn_g_chain_bwd_rr_red_tpu(M, n, njp) > 0 && tiles_per_unit > 0 && ((n + RR_NW - 1) / RR_NW) % tiles_per_unit == 0, "rn_probe_red_schedule: bad shape");
+  const int tpbj = (n + RR_NW - 1) / RR_NW, jgs = njp / RR_WR, nu = tpbj / tiles_per_unit;
+  const int nunits = (int)(rr_red_tiles(M, n, njp) / tiles_per_unit), nb = nunits / (jgs * nu);
+  RN_CHECK_ARG(units_whole >= 0 && units_whole <= nunits, "rn_probe_red_schedule: units_whole=%d must lie in [0, %d]", units_whole, nunits);
+  const long nitems = units_whole + (long)(nunits - units_whole) * tiles_per_unit;
+  RN_CHECK_ARG(out && nitems <= max_items, "rn_probe_red_schedule: %ld items do not fit (max_items=%d)", nitems, max_items);
+  for (int i = 0; i < (int)nitems; ++i) {
+    const RnRedItem it = rn_red_item(i, nunits, tiles_per_unit, units_whole, nb, jgs, nu);
+    out[3 * i] = it.tile0; out[3 * i + 1] = it.tcount; out[3 * i + 2] = (int)it.rec;
+  }
+  return (int)nitems;
+}
+
 extern "C" int rn_g_chain_bwd_rr_red(const float* dxg, const void* const* mask, const void* const* Wtf, void* const* dZ, int M, int n,
                                      int njp, int L, int G, float* rj_part, float* ri_part, int tiles_per_unit, int units_whole, void* stream) {
   RN_CHECK_ARG(dxg && mask && Wtf && dZ && rj_part && ri_part && M > 0, "rn_g_chain_bwd_rr_red: bad pointer/size");
@@ -1530,9 +1535,9 @@ extern "C" int rn_g_chain_bwd_rr_red(const float* dxg, const void* const* mask, 
   const long nitems = units_whole + (long)(nunits - units_whole) * tiles_per_unit;
   const int grid = nitems < rr_num_cus() ? (int)nitems : rr_num_cus();
 #ifdef RN_DIAG
-  switch (g_diag_abl) {                                    // timing-only ablations (results are wrong): 2 no mask loads, 4 no dZ stores, 8 no waits / barriers, 32 stores to L2-resident addresses
+  switch (g_diag_abl) {                                    // timing-only ablations (results are wrong): 128 the tile prologue (gated dxg operand) only once per workgroup, 2 no mask loads, 4 no dZ stores, 8 no waits / barriers, 32 stores to L2-resident addresses
 #define RN_ABL(v) case v: g_chain_rr_bwd_kernel<v, true, true><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles, ra); break;
-    RN_ABL(2) RN_ABL(4) RN_ABL(6) RN_ABL(8) RN_ABL(14) RN_ABL(32) RN_ABL(64)
+    RN_ABL(2) RN_ABL(4) RN_ABL(6) RN_ABL(8) RN_ABL(14) RN_ABL(32) RN_ABL(64) RN_ABL(128) RN_ABL(142)
 #undef RN_ABL
     default: g_chain_rr_bwd_kernel<0, true, true><<<grid, RR_NT, 0, (hipStream_t)stream>>>(a, ntiles, ra); break;
   }

@@ -61,6 +61,36 @@ static inline const char* rn_diag_env(const char* name) { return getenv(name); }
 static inline const char* rn_diag_env(const char*) { return nullptr; }
 #endif
 
+// ---- work items of the reducing backward chain (rn_chain_rr.hip) and the records its partial-sum kernel reads (rn_pair.hip): ONE
+// definition for the kernel that writes and the kernel that reads (and rn_probe_red_schedule, which the CPU tests walk).
+// Unit ((b * jgs + jg) * nu + v) -- question b, block jg of 32 objects j, v-th group of tiles_per_unit tiles -- sits at WALK position
+// p = (v * jgs + jg) * nb + b (question fastest).  Work items: the nwhole units at walk positions [0, nwhole) as a whole (one Rj
+// record: the unit's own), then the tiles of the units behind them one by one (tile 0 -> the unit's own record, tile t > 0 ->
+// record nunits + (p - nwhole) (tpu - 1) + t - 1).
+struct RnRedItem { int tile0, tcount; long rec; };
+__host__ __device__ inline int rn_red_walk_pos(int b, int jg, int v, int nb, int jgs) { return (v * jgs + jg) * nb + b; }
+__host__ __device__ inline int rn_red_unit_at(int p, int nb, int jgs, int nu) {
+  const int r = p / nb, b = p - r * nb, v = r / jgs, jg = r - v * jgs;
+  return (b * jgs + jg) * nu + v;
+}
+__host__ __device__ inline long rn_red_extra_rec(int p, int t, int nunits, int tpu, int nwhole) {   // record of tile t > 0 of the tail unit at walk position p
+  return (long)nunits + (long)(p - nwhole) * (tpu - 1) + t - 1;
+}
+__host__ __device__ inline RnRedItem rn_red_item(int item, int nunits, int tpu, int nwhole, int nb, int jgs, int nu) {
+  RnRedItem it;
+  if (item < nwhole) {
+    it.rec = rn_red_unit_at(item, nb, jgs, nu);
+    it.tile0 = (int)it.rec * tpu;
+    it.tcount = tpu;
+  } else {
+    const int f = item - nwhole, uo = f / tpu, t = f - uo * tpu, unit = rn_red_unit_at(nwhole + uo, nb, jgs, nu);
+    it.tile0 = unit * tpu + t;
+    it.tcount = 1;
+    it.rec = t == 0 ? unit : rn_red_extra_rec(nwhole + uo, t, nunits, tpu, nwhole);
+  }
+  return it;
+}
+
 // workspace sizes of the entry points, one function per file that owns the layout; exported through rn_workspace_bytes (rn_pair.hip)
 size_t rnws_rr_mask(int M);
 size_t rnws_conv_bwd_weight(int N, int Cin, int H, int W);

@@ -654,9 +654,9 @@ __global__ __launch_bounds__(1024) void pair_reduce_parts_kernel(const f32x4* __
       for (int g = 1; g < jgs; ++g) si += pi[(long)g * G4];
       for (int u = 0; u < nu; ++u) {
         sj += pj[(long)(u0 + u) * 32 * G4];
-        const int p = (u * (njp / 32) + (r >> 5)) * nb + b;           // walk position of the unit
+        const int p = rn_red_walk_pos(b, r >> 5, u, nb, njp / 32);    // walk position of the unit (rn_common.h: shared with the writer)
         if (p >= units_whole)
-          for (int t = 0; t < tpu - 1; ++t) sj += pj[((long)nunits + (long)(p - units_whole) * (tpu - 1) + t) * 32 * G4];
+          for (int t = 1; t < tpu; ++t) sj += pj[rn_red_extra_rec(p, t, nunits, tpu, units_whole) * 32 * G4];
       }
       Ri[((long)b * n + r) * G4 + c] = si;
       Rj[((long)b * n + r) * G4 + c] = sj;

@@ -93,6 +93,7 @@ DEBUG_SIGNATURES = {
     "rn_probe_tr8": (_I, [_P, _P, _P]),
     "rn_probe_fp8_cvt": (_I, [_P, C.c_float, _P, _P, _P, _I, _P]),
     "rn_probe_mfma_stream": (_I, [_P, _I, _I, _I, _I, _P]),
+    "rn_probe_red_schedule": (_I, [_I, _I, _I, _I, _I, _P, _I]),
 }
 
 

@@ -212,3 +212,63 @@ def test_flat_import_like_the_reference_has_no_relative_imports_behind_it():
             % (ROOT, pkgdir))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=pkgdir)
     assert r.returncode == 0 and "flat ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("B,n,tpu,whole", [(32, 196, 5, "lib"), (32, 196, 5, 0), (32, 196, 5, "all"), (32, 196, 1, "lib"), (64, 64, 4, "lib"), (17, 64, 1, 100),
+                                          (3, 64, 8, 5), (3, 64, 4, 0), (2, 96, 3, 7), (4, 40, 5, 3), (2, 196, 25, 9), (40, 64, 2, "lib")])
+def test_reducing_chain_schedule_covers_every_tile_and_record_once(pkg, B, n, tpu, whole):
+    """Host logic of the reducing backward chain's BALANCED schedule (rn_common.h rn_red_item / rn_red_walk_pos, walked through
+    rn_probe_red_schedule -- no GPU): every tile of the launch is run by exactly one work item; a whole unit is tiles_per_unit
+    consecutive tiles of ONE (question, j block) and leaves the unit's own record; the tail's single tiles leave one record each,
+    all distinct and inside the buffer; and the records rn_pair_reduce_parts adds up for a unit -- its own + the extra ones at the
+    unit's walk position (question fastest) -- are exactly those written for that unit's tiles.  (32, 196, 5): BASELINE.json
+    configs[4] on a 256-CU chip: 1024 whole units + 480 single tiles, three tail units per question."""
+    lib = pkg.rn_hip.load()
+    njp = (n + 31) // 32 * 32
+    M = B * n * njp
+    tpbj, jgs = (n + 7) // 8, njp // 32
+    assert tpbj % tpu == 0 and lib.rn_g_chain_bwd_rr_red_tpu(M, n, njp) > 0
+    nu = tpbj // tpu
+    nunits = B * jgs * nu
+    ntiles = nunits * tpu
+    lib_whole = lib.rn_g_chain_bwd_rr_red_whole(M, n, njp, tpu)
+    assert 0 <= lib_whole <= nunits and (tpu == 1 and lib_whole == nunits or tpu > 1 and lib_whole % 256 == 0 and nunits - lib_whole < 256)
+    whole = {"lib": lib_whole, "all": nunits}.get(whole, whole)
+    nitems = whole + (nunits - whole) * tpu
+    out = (ctypes.c_int * (3 * nitems))()
+    assert lib.rn_probe_red_schedule(M, n, njp, tpu, whole, out, nitems) == nitems
+    assert lib.rn_probe_red_schedule(M, n, njp, tpu, whole, out, nitems - 1) < 0          # (too small a buffer is refused)
+    assert lib.rn_probe_red_schedule(M, n, njp, tpu, nunits + 1, out, nitems) < 0
+    items = np.frombuffer(out, dtype=np.int32).reshape(nitems, 3)
+    records = nunits + (nunits - whole) * (tpu - 1)
+    assert records == pkg.rn_hip.g_chain_bwd_rr_red_records(M, n, njp, tpu, whole)
+    seen_tiles = np.zeros(ntiles, dtype=np.int32)
+    written = {}                                            # record -> unit whose tiles it sums
+    for i, (tile0, tcount, rec) in enumerate(items):
+        assert tcount == (tpu if i < whole else 1)
+        seen_tiles[tile0:tile0 + tcount] += 1
+        unit = tile0 // tpu
+        assert (tile0 + tcount - 1) // tpu == unit          # an item never straddles two units
+        assert 0 <= rec < records and rec not in written
+        written[int(rec)] = unit
+        if i < whole or tile0 % tpu == 0:
+            assert rec == unit                              # whole units and a tail unit's first tile: the unit's own record
+        else:
+            assert rec >= nunits
+    assert (seen_tiles == 1).all() and len(written) == records
+    # what rn_pair_reduce_parts reads for unit (b, jg, v): its own record, and -- walk position p = (v * jgs + jg) * B + b >= whole --
+    # the records nunits + (p - whole) (tpu - 1) + t - 1, t = 1 .. tpu - 1
+    per_question_extra = np.zeros(B, dtype=np.int64)
+    for b in range(B):
+        for jg in range(jgs):
+            for v in range(nu):
+                unit = (b * jgs + jg) * nu + v
+                p = (v * jgs + jg) * B + b
+                reads = [unit] + ([nunits + (p - whole) * (tpu - 1) + t - 1 for t in range(1, tpu)] if p >= whole else [])
+                assert all(written[r] == unit for r in reads), (b, jg, v)
+                per_question_extra[b] += len(reads) - 1
+    assert sum(per_question_extra) == records - nunits
+    if (nunits - whole) % B == 0:                           # the tail spreads evenly over the questions (question-fastest walk)
+        assert per_question_extra.max() == per_question_extra.min()
+    else:
+        assert per_question_extra.max() - per_question_extra.min() <= tpu - 1

@@ -23,6 +23,7 @@ python tools/time_wgrad.py > $OUT/wgrad_alone.txt 2>/dev/null
 python tools/time_fwd_f16s.py > $OUT/fwd_chain_alone.txt 2>/dev/null
 python tools/time_k1.py > $OUT/k1_alone.txt 2>/dev/null
 python tools/time_bwd.py > $OUT/bwd_chain_alone.txt 2>/dev/null
+B=32 N_OBJ=196 python tools/time_bwd.py > $OUT/bwd_chain_alone_b32_n196.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 # 3. kernel trace of the bench command (eager launches: per-kernel durations; the timed bench line itself uses the hipGraph)
 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-modes --no-parity --no-kernel-timing --no-graph > $OUT/kt.log 2>&1
@@ -61,8 +62,11 @@ python tools/convergence.py 3000 5e-4 pairs 250 > $OUT/convergence_pairs.txt 2>/
 RN_DIAG=1 python relationnetworks-clevr_amd/_build.py --force > $ABL/diag_build.log 2>&1
 RN_DIAG=1 python tools/time_fwd_f16s.py > $ABL/fwd_chain_ablations.txt 2>/dev/null
 RN_DIAG=1 python tools/time_wgrad.py > $ABL/wgrad_ablations.txt 2>/dev/null
+RN_DIAG=1 python tools/time_bwd_abl.py > $ABL/bwd_chain_ablations.txt 2>/dev/null
 python relationnetworks-clevr_amd/_build.py --force > /dev/null 2>&1
 mkdir -p tools/dbg/libs
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/dbg/libs/reg_stream_bench tools/dbg/reg_stream_bench.hip > /dev/null 2>&1 && tools/dbg/libs/reg_stream_bench > $ABL/reg_stream_bench.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o tools/dbg/libs/mfma_filler_bench tools/dbg/mfma_filler_bench.hip > /dev/null 2>&1 && tools/dbg/libs/mfma_filler_bench > $ABL/mfma_filler_bench.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o tools/dbg/libs/ldsdma_offset_probe tools/dbg/ldsdma_offset_probe.hip > /dev/null 2>&1 && tools/dbg/libs/ldsdma_offset_probe > $ABL/ldsdma_offset_probe.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/dbg/libs/ovfl_probe tools/dbg/ovfl_probe.hip > /dev/null 2>&1 && tools/dbg/libs/ovfl_probe > $ABL/fp16_ovfl_probe.txt 2>&1
 ls -la $OUT $ABL

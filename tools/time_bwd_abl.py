@@ -27,7 +27,7 @@ run = lambda: H.g_chain_bwd_rr_red(dxg, masks, Wt, red, M, n, G, rj, ri, tpu, nj
 flops = 2.0 * B * n * n * G * 3 * G
 variants = {"baseline": (lambda: None, run)}
 if os.environ.get("RN_DIAG", "0") == "1":
-    names = {2: "no mask loads", 4: "no dZ stores", 6: "no mask loads, no dZ stores", 8: "no counted waits / barriers", 14: "no masks, stores, waits, barriers",
+    names = {128: "tile prologue once per workgroup only", 142: "no prologue, masks, stores, waits, barriers", 2: "no mask loads", 4: "no dZ stores", 6: "no mask loads, no dZ stores", 8: "no counted waits / barriers", 14: "no masks, stores, waits, barriers",
              32: "dZ stores to L2-resident addresses", 64: "plain instead of non-temporal dZ stores"}
     for abl, what in names.items():
         variants["ABL %3d (%s)" % (abl, what)] = ((lambda a=abl: lib.rn_diag_set_abl(a)), run)
