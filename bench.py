@@ -24,6 +24,8 @@ that is "f16s", the mode that meets the 1e-3 log-prob bar).  What the line carri
                    off; `step`: g_theta's flops over the whole step's time.
   sustained        the same graph replayed for --sustain seconds (default 3) right after the K timed steps: rate, ms/step and the
                    rocm-smi clocks / power sampled meanwhile -- K = 20 steps are 15 ms, too short for the chip's sustained clocks.
+  roofline.sustained_mfma / frac_of_sustained: the bare-MFMA stream's rate on this box (rn_probe_mfma_stream) and the g_theta
+                   kernels against it (`frac`: against the nominal 2.5 PFLOP/s).
   convergence      (--convergence STEPS) fp32 and the benched mode trained on a learnable synthetic task with the same seeds:
                    loss curves, held-out accuracy, and the e4m3 copy guard's log.
   pair_build_k1    rn_pair_build_fwd launched on its own at the benched shape: 94.83 MB / duration vs 8 TB/s

@@ -13,6 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librn_hip.so")
+_PRODUCT_LIB_PATH = LIB_PATH                         # (tools may point LIB_PATH at a variant build)
 RN_BF16, RN_F32, RN_F16, RN_FP8 = 0, 1, 2, 3
 RN_RELU, RN_ACCUMULATE = 1, 2
 ABI_VERSION = 9
@@ -130,7 +131,10 @@ def load(path: str | None = None):
             "HIP extension %s not found: build it with `python __graft_entry__.py build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % p)
     lib = C.CDLL(p)
+    variant = os.path.abspath(p) != os.path.abspath(_PRODUCT_LIB_PATH)       # (tools/: a variant build for an A/B may predate a diagnostic entry point)
     for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
+        if variant and name in DEBUG_SIGNATURES and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.restype, fn.argtypes = res, args
     v = lib.rn_abi_version()
