@@ -71,6 +71,7 @@ class PackedWeights:
         self._last = None                          # arguments of the previous get(): what repack_ahead() repeats
         self._ahead = None                         # key of an ahead-of-time pack not consumed yet
         self._fphi_sync = None                     # sync workspace of the feature-split f_phi launch (rn_f_phi_split), one per module
+        self.q_grad_async = False                  # the question is QuestionLSTMFunction's output on a side stream: its gradient may be handed over by event (_GRAD_EVENTS)
         self.frag_hi, self.frag_lo = [], []        # fragment-major fp16 hi / lo images of the forward chain
         self.fragT = []                            # backward step s -> W_{L-1-s}^T (bf16 fragment-major)
 
@@ -173,14 +174,21 @@ class PackedWeights:
         return self.fwd, self.bwd
 
 
+# Gradients handed to ANOTHER autograd node on ANOTHER stream without making the producing node's stream wait for them: data_ptr ->
+# event.  The one user: the question gradient of a question-injected relational layer (ir-*), which comes out of the weight-gradient
+# launch on its side stream ~100 us after dx is ready -- QuestionLSTMFunction.backward (the question encoder's stream) waits for the
+# event itself, and the conv stack's backward starts with dx instead of behind dq (RN.forward sets PackedWeights.q_grad_async when
+# the question IS that node's output; any other producer gets the synchronous hand-off).
+_GRAD_EVENTS = {}
 _SIDE_STREAMS = {}
 # Launch-order choices of the backward pass that only measurements decide (the captured graph's queue order): kept as named knobs so that
 # tools/dbg/exp_bench.py can A/B them on one box.  wgrad_late: 0 the g_theta weight-gradient launch right behind the backward chain,
 # 1 behind the partial sums AND the layer-0 stream (default), 2 behind dx / dq too, 3 behind the partial sums only;
 # conv_wgrad_stream: the side stream the conv weight gradients share (0 the g_theta weight gradient's, 2 the layer-0 stream's);
 # fphi_grads_late: f_phi's parameter gradients on the layer-0 stream instead of in front of the backward chain;
-# chain_balance: the reducing backward chain's units beyond a whole number of rounds over the CUs run tile by tile (0: whole units only).
-SCHED = {"wgrad_late": 1, "conv_wgrad_stream": 2, "fphi_grads_late": 1, "chain_balance": 1}
+# chain_balance: the reducing backward chain's units beyond a whole number of rounds over the CUs run tile by tile (0: whole units only);
+# dq_async: the question gradient of a question-injected layer is handed to the question encoder's backward by event (0: the main stream waits for it).
+SCHED = {"wgrad_late": 1, "conv_wgrad_stream": 2, "fphi_grads_late": 1, "chain_balance": 1, "dq_async": 1}
 
 
 def _side_stream(dev, which=0):
@@ -541,6 +549,7 @@ class RelationalFunction(torch.autograd.Function):
         if need_grad:
             ctx.plan, ctx.code, ctx.dims = plan, code, (B, n, k, Q, M, G, F1, F2, A)
             ctx.chain, ctx.njp = chain, njp
+            ctx.q_grad_async = bool(getattr(packed, "q_grad_async", False))
             ctx.coord = coord
             ctx.inputs, ctx.HL, ctx.wbwd = inputs, HL, wbwd
             ctx.fragT = list(packed.fragT)
@@ -645,7 +654,16 @@ class RelationalFunction(torch.autograd.Function):
         # question injected at layer > 0: its per-question sums Rq come from the wgrad kernel's per-split column sums when no split
         # straddles two questions, else from a pass over the layer's stored gradient (rn_blocked_question_sums)
         rq_splits, inj_out = 0, {}
-        if inj:
+        # The weight gradients are not needed by anything upstream: they go to a side stream and overlap the rest of this backward
+        # AND the conv / LSTM backward that autograd runs next (small kernels that leave the chip mostly empty).  The main stream
+        # re-joins at the end of the backward pass (engine callback).  Only when every parameter's .grad is None (assign, not
+        # accumulate: autograd then launches no kernel on these tensors before the join).
+        overlap = OPT.wgrad_overlap and all(_assign_only(p) for p in ctx.param_refs)
+        # ir-*: the question gradient produced BY ITS CONSUMER's stream (round 5): the question encoder's backward -- a stream that has
+        # been idle since the forward pass -- sums the injected layer's stored gradient per question and forms dq itself, right behind
+        # the backward chain, instead of waiting for the per-question sums that fall out of the 190-us weight-gradient launch
+        dq_by_consumer = bool(inj and overlap and ctx.q_grad_async and SCHED["dq_async"])
+        if inj and not dq_by_consumer:
             z_ = H.wgrad_blocked_splits(M, n * n, L - 1, aligned=True)
             if z_ > 0 and z_ % B == 0 and (M // 64) % z_ == 0 and (n * n) % (M // z_) == 0:
                 rq_splits = z_
@@ -682,11 +700,6 @@ class RelationalFunction(torch.autograd.Function):
                     H.gemm_f32(rq_, 1, N_, q, Q, 1, gW[l], kt_, N_, Q, B, c_off=kt_ - Q)          # gW[l][:, G_prev:] = Rq^T q
                     inj_out["dq"], inj_out["keep"] = dq_, [ws_, rq_, wl_, tmp]
 
-        # The weight gradients are not needed by anything upstream: they go to a side stream and overlap the rest of this backward
-        # AND the conv / LSTM backward that autograd runs next (small kernels that leave the chip mostly empty).  The main stream
-        # re-joins at the end of the backward pass (engine callback).  Only when every parameter's .grad is None (assign, not
-        # accumulate: autograd then launches no kernel on these tensors before the join).
-        overlap = OPT.wgrad_overlap and all(_assign_only(p) for p in ctx.param_refs)
         keep = [list(dZs), list(inputs), masks, dxg]         # operands read on a side stream stay alive until the join
         # WHEN the launch starts (round 4): its 470-MB stream is what it costs the step (the step with its requests ablated: 0.62 ms
         # instead of 0.70; with its arithmetic ablated: unchanged), and the first kernels behind the backward chain -- the partial
@@ -695,9 +708,10 @@ class RelationalFunction(torch.autograd.Function):
         # and dx reaches the conv stack's backward ~60 us earlier: +1..1.6 % q/s together with the conv weight gradients moved to the
         # layer-0 stream (they no longer queue behind this launch).  Behind dx / dq as well: -11 %; behind the partial sums ONLY
         # (the layer-0 stream joined after the launch): -12..-16 % -- the captured graph's queue order, not arithmetic
-        # (tools/dbg/exp_bench.py wgrad_late=2 | 3).  The question-injected models need the launch's per-question sums for dq: early (taking the
-        # sums from a pass of their own over dZ_2 instead, so that the launch can be late there too: -0.5 % on ir-fp).
-        late = overlap and SCHED["wgrad_late"] and not inj
+        # (tools/dbg/exp_bench.py wgrad_late=2 | 3).  The question-injected models took dq from the launch's per-question sums through round 4 (early
+        # launch); since round 5 the sums are a pass of their own in FRONT of the late launch and dq is handed to its consumer by event
+        # (dq_by_consumer above: +5 % on ir-fp -- with the main stream waiting for dq the same change measured -0.5 %).
+        late = overlap and SCHED["wgrad_late"] and (not inj or dq_by_consumer)
         if overlap:
             main, side = torch.cuda.current_stream(), _side_stream(dev)
             if not late:
@@ -720,13 +734,33 @@ class RelationalFunction(torch.autograd.Function):
             N, kt = plan.widths[l], plan.ktrue[l]
             wl = g_w[l] if g_w[l].is_contiguous() else g_w[l].contiguous()
             Rq2 = torch.empty(B, N, **f32)
-            H.blocked_question_sums(dZ_of[l], Rq2, M, n * n)       # (this layer's dZ is a row-blocked image)
             dq = torch.empty(B, Q, **f32)
-            H.gemm_f32(Rq2, N, 1, wl, kt, 1, dq, Q, B, Q, N, b_off=kt - Q)   # Rq @ W[:, -Q:]
 
-            def _wgrad_question():                                  # gW[l][:, G_prev:] = Rq^T q
+            def _wgrad_question(l=l, N=N, kt=kt):                   # gW[l][:, G_prev:] = Rq^T q  (bound NOW: N, kt are layer 0's further down)
                 H.gemm_f32(Rq2, 1, N, q, Q, 1, gW[l], kt, N, Q, B, c_off=kt - Q)
-            if overlap:
+            if dq_by_consumer:
+                # on the weight-gradient stream, IN FRONT of that (late) launch: the sums + the small product run beside the partial
+                # sums / dx on the main stream; the question encoder's backward waits for the event, this stream does not.  (Run by
+                # the consumer on ITS stream instead -- a fifth concurrent branch of the replayed graph -- the executor serialised
+                # the conv weight gradients behind the weight-gradient launch: no gain.)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    H.blocked_question_sums(dZ_of[l], Rq2, M, n * n)
+                    H.gemm_f32(Rq2, N, 1, wl, kt, 1, dq, Q, B, Q, N, b_off=kt - Q)
+                    _GRAD_EVENTS.clear()
+                    _GRAD_EVENTS[dq.data_ptr()] = (side.record_event(), None)
+                if late:
+                    inj_out["question_cols"] = _wgrad_question     # (behind the weight-gradient launch, which creates gW[l])
+                else:
+                    with torch.cuda.stream(side):
+                        _wgrad_question()
+                keep.append([Rq2, q, wl, dq])
+            else:
+                H.blocked_question_sums(dZ_of[l], Rq2, M, n * n)       # (this layer's dZ is a row-blocked image)
+                H.gemm_f32(Rq2, N, 1, wl, kt, 1, dq, Q, B, Q, N, b_off=kt - Q)   # Rq @ W[:, -Q:]
+            if dq_by_consumer:
+                pass
+            elif overlap:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     _wgrad_question()
@@ -791,13 +825,21 @@ class RelationalFunction(torch.autograd.Function):
                 side.wait_event(late_ev)                           # behind the partial sums only
             with torch.cuda.stream(side):
                 _wgrads_blocked()
+                if "question_cols" in inj_out:
+                    inj_out["question_cols"]()
             if SCHED["wgrad_late"] == 3:
                 side.wait_stream(s0)
         if rq_splits:
             dq = inj_out["dq"]
             if "event" in inj_out:                                 # produced on the wgrad stream
-                torch.cuda.current_stream().wait_event(inj_out["event"])
-                dq.record_stream(torch.cuda.current_stream())
+                if ctx.q_grad_async and SCHED["dq_async"]:
+                    # its consumer waits for it (QuestionLSTMFunction.backward); this stream goes on with dx: the conv stack's
+                    # backward starts ~100 us earlier (ir-fp: +x % on the step)
+                    _GRAD_EVENTS.clear()
+                    _GRAD_EVENTS[dq.data_ptr()] = (inj_out["event"], None)
+                else:
+                    torch.cuda.current_stream().wait_event(inj_out["event"])
+                    dq.record_stream(torch.cuda.current_stream())
                 keep.append(inj_out["keep"])
         return dx, dq, gW, gB
 
@@ -1015,6 +1057,12 @@ class QuestionLSTMFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dhn):
         idx, xs, gates, cs, hs, W_ih, W_hh = ctx.saved_tensors
+        handed = _GRAD_EVENTS.pop(dhn.data_ptr(), None)           # a gradient that is not complete on the producing node's stream:
+        if handed is not None:                                     # wait for its event; then, if given, run what fills it in -- HERE
+            torch.cuda.current_stream().wait_event(handed[0])
+            if handed[1] is not None:
+                handed[1]()
+            dhn.record_stream(torch.cuda.current_stream())
         T, B, G4 = gates.shape
         dgates = torch.empty_like(gates)
         H.lstm_bwd(dhn.float().contiguous(), gates, cs, W_hh, dgates)

@@ -408,10 +408,14 @@ class RN(nn.Module):
                 x = torch.cat([x.view(b, k, d * d), self._coords(b, d, x.device)], 1).permute(0, 2, 1)   # (B, d*d, 26) strided view
         if side is None:
             qst = self.text(qst_idxs)
+            self.rl._packed.q_grad_async = False
         else:
             cur = torch.cuda.current_stream()
             cur.wait_stream(side)
             qst.record_stream(cur)
+            # the question's gradient goes to the question encoder's backward on ITS stream and to nothing else: a relational layer
+            # that produces it on a side stream of its own (question injected behind layer 0) may hand it over by event
+            self.rl._packed.q_grad_async = type(qst.grad_fn).__name__ == "QuestionLSTMFunctionBackward"
             ahead = getattr(self.rl, "_mask_ahead", None)
             if ahead is not None:
                 ahead[1].record_stream(cur)

@@ -695,3 +695,51 @@ def test_fused_coordinate_tagging_equals_the_concatenated_path(pkg, cfg, precisi
     assert torch.equal(lp_a, lp_b) and loss_a == loss_b
     for n_ in g_b:
         assert torch.equal(g_a[n_], g_b[n_]), n_
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [8, 64])
+def test_question_gradient_hand_off_by_event_matches_the_synchronous_path(pkg, B):
+    """ir-fp (question injected at layer 2, model.py:131-142): the question gradient is formed on the weight-gradient stream from the
+    per-question sums of the stored dZ_2 and handed to the question encoder's backward BY EVENT (functional._GRAD_EVENTS) -- the main
+    stream goes on with dx.  Against the synchronous hand-off (SCHED dq_async = 0: dq from the weight-gradient launch's per-question
+    partials where its splits are question-aligned, B = 64; from the same sums on the main stream otherwise, B = 8): same log-probs
+    and loss bitwise, every gradient to fp32 summation order -- the encoder's own gradients included, which is what would be garbage
+    if its backward ran ahead of the event.  Three passes each: the hand-off registry must not leak between passes."""
+    class Args:
+        qdict_size = formula.QDICT
+        adict_size = formula.ADICT
+
+    RF = pkg.functional
+    img = torch.from_numpy(formula.hash_uniform((B, 3, 128, 128), 331, 0.0, 1.0)).cuda()
+    qst = torch.from_numpy(formula.hash_ints((B, 20), 332, 1, formula.QDICT + 1)).cuda()
+    lab = torch.from_numpy(formula.hash_ints((B,), 333, 0, formula.ADICT)).cuda()
+
+    def run(async_):
+        old = RF.SCHED["dq_async"]
+        RF.SCHED["dq_async"] = async_
+        try:
+            torch.manual_seed(11)
+            m = pkg.RN(Args, dict(formula.HYP["ir-fp"], precision="auto", dropout=0.0)).cuda()
+            m.train()
+            outs = []
+            for _ in range(3):
+                m.zero_grad(set_to_none=True)
+                lp, loss = m.forward_loss(img, qst, lab)
+                assert m.rl._packed.q_grad_async                      # (the question IS the LSTM function's output)
+                loss.backward()
+                torch.cuda.synchronize()
+                assert not RF._GRAD_EVENTS                            # consumed by the encoder's backward
+                outs.append((lp.detach().clone(), float(loss.detach()), {n_: p_.grad.clone() for n_, p_ in m.named_parameters()}))
+            return outs
+        finally:
+            RF.SCHED["dq_async"] = old
+
+    a, s = run(1), run(0)
+    for (lp_a, loss_a, g_a), (lp_s, loss_s, g_s) in zip(a, s):
+        assert torch.equal(lp_a, lp_s) and loss_a == loss_s
+        for n_ in g_s:
+            assert l2rel(g_a[n_].cpu().numpy(), g_s[n_].cpu().numpy()) <= 2e-5, n_
+    for n_ in a[0][2]:                                                # ... and a pass repeats itself bitwise
+        assert torch.equal(a[0][2][n_], a[2][2][n_]), n_
+    assert float(a[0][2]["text.wembedding.weight"].abs().sum()) > 0

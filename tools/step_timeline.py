@@ -6,7 +6,7 @@ so after a replay the buffer holds begin / end device times of every op with the
 The stamps cost a few microseconds per op: read the table for structure (what overlaps what, which stream ends
 last), not for absolute step time.
 
-    python tools/step_timeline.py [--precision bf16] [--batch 64]"""
+    python tools/step_timeline.py [--precision bf16] [--batch 64] [--config ir-fp]"""
 import argparse
 import contextlib
 import io
@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--precision", default="auto")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--hw", type=int, default=128)
+    ap.add_argument("--config", default="original-fp")
     args = ap.parse_args()
     import relationnetworks_clevr_amd as pkg
     from relationnetworks_clevr_amd import dp
@@ -35,7 +36,7 @@ def main():
     H.load()
     dev = torch.device("cuda", 0)
     hyps = json.load(open(os.path.join(ROOT, "relationnetworks-clevr_amd", "config.json")))["hyperparams"]
-    hyp = dict(hyps["original-fp"], precision=args.precision)
+    hyp = dict(hyps[args.config], precision=args.precision)
 
     class A:
         qdict_size, adict_size = 82, 28
