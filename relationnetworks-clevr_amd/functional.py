@@ -659,11 +659,12 @@ class RelationalFunction(torch.autograd.Function):
         # re-joins at the end of the backward pass (engine callback).  Only when every parameter's .grad is None (assign, not
         # accumulate: autograd then launches no kernel on these tensors before the join).
         overlap = OPT.wgrad_overlap and all(_assign_only(p) for p in ctx.param_refs)
-        # ir-*: the question gradient produced BY ITS CONSUMER's stream (round 5): the question encoder's backward -- a stream that has
-        # been idle since the forward pass -- sums the injected layer's stored gradient per question and forms dq itself, right behind
-        # the backward chain, instead of waiting for the per-question sums that fall out of the 190-us weight-gradient launch
-        dq_by_consumer = bool(inj and overlap and ctx.q_grad_async and SCHED["dq_async"])
-        if inj and not dq_by_consumer:
+        # ir-*: the question gradient handed to its consumer BY EVENT (round 5): the injected layer's stored gradient is summed per
+        # question by a pass of its own on the weight-gradient stream, in front of that launch, and the question encoder's backward
+        # waits for the event -- not this node's stream, which returns dx ~100 us earlier than the per-question sums that fall out
+        # of the 190-us weight-gradient launch would let it
+        dq_by_event = bool(inj and overlap and ctx.q_grad_async and SCHED["dq_async"])
+        if inj and not dq_by_event:
             z_ = H.wgrad_blocked_splits(M, n * n, L - 1, aligned=True)
             if z_ > 0 and z_ % B == 0 and (M // 64) % z_ == 0 and (n * n) % (M // z_) == 0:
                 rq_splits = z_
@@ -710,8 +711,8 @@ class RelationalFunction(torch.autograd.Function):
         # (the layer-0 stream joined after the launch): -12..-16 % -- the captured graph's queue order, not arithmetic
         # (tools/dbg/exp_bench.py wgrad_late=2 | 3).  The question-injected models took dq from the launch's per-question sums through round 4 (early
         # launch); since round 5 the sums are a pass of their own in FRONT of the late launch and dq is handed to its consumer by event
-        # (dq_by_consumer above: +5 % on ir-fp -- with the main stream waiting for dq the same change measured -0.5 %).
-        late = overlap and SCHED["wgrad_late"] and (not inj or dq_by_consumer)
+        # (dq_by_event above: +5 % on ir-fp -- with the main stream waiting for dq the same change measured -0.5 %).
+        late = overlap and SCHED["wgrad_late"] and (not inj or dq_by_event)
         if overlap:
             main, side = torch.cuda.current_stream(), _side_stream(dev)
             if not late:
@@ -738,7 +739,7 @@ class RelationalFunction(torch.autograd.Function):
 
             def _wgrad_question(l=l, N=N, kt=kt):                   # gW[l][:, G_prev:] = Rq^T q  (bound NOW: N, kt are layer 0's further down)
                 H.gemm_f32(Rq2, 1, N, q, Q, 1, gW[l], kt, N, Q, B, c_off=kt - Q)
-            if dq_by_consumer:
+            if dq_by_event:
                 # on the weight-gradient stream, IN FRONT of that (late) launch: the sums + the small product run beside the partial
                 # sums / dx on the main stream; the question encoder's backward waits for the event, this stream does not.  (Run by
                 # the consumer on ITS stream instead -- a fifth concurrent branch of the replayed graph -- the executor serialised
@@ -758,7 +759,7 @@ class RelationalFunction(torch.autograd.Function):
             else:
                 H.blocked_question_sums(dZ_of[l], Rq2, M, n * n)       # (this layer's dZ is a row-blocked image)
                 H.gemm_f32(Rq2, N, 1, wl, kt, 1, dq, Q, B, Q, N, b_off=kt - Q)   # Rq @ W[:, -Q:]
-            if dq_by_consumer:
+            if dq_by_event:
                 pass
             elif overlap:
                 side.wait_stream(main)
