@@ -413,23 +413,39 @@ extern "C" int rn_pair_sum_bwd(const float* dxg, const void* HL, int ldh, void* 
 }
 
 // ---- x_g from the two-rows-per-tile partials of the padded-j forward chain (rn_g_chain_fwd_rr_f16s_alg0, njp > n)
-__global__ __launch_bounds__(256) void pair_sum_tiles_kernel(const float* __restrict__ part, float* __restrict__ xg, long rpq, int G) {
-  const int b = blockIdx.x;
-  const long t0 = (long)b * rpq / 256, t1 = ((long)(b + 1) * rpq - 1) / 256;          // tiles that hold rows of question b
-  for (int f = threadIdx.x; f < G; f += 256) {
+// Block = question; thread = (tile lane of 4, feature): a lane adds every fourth tile of the question, four loads in flight, and the
+// four lanes meet in LDS in lane order -- a fixed summation order.  (Round 5: one thread per feature walking all ~172 tiles of a
+// 14 x 14 question with a 64-bit division per step was 172 dependent round trips -- 82 us between the forward chain and f_phi.)
+__global__ __launch_bounds__(1024) void pair_sum_tiles_kernel(const float* __restrict__ part, float* __restrict__ xg, long rpq, int G) {
+  __shared__ float red[4][256];
+  const int b = blockIdx.x, tl = threadIdx.x >> 8;
+  const long r0 = (long)b * rpq;                                                        // first pair row of question b
+  const long t0 = r0 / 256, t1 = (r0 + rpq - 1) / 256;                                  // tiles that hold rows of question b
+  for (int f0 = 0; f0 < G; f0 += 256) {
+    const int f = f0 + (threadIdx.x & 255);
     float acc = 0.f;
-    for (long t = t0; t <= t1; ++t) {
-      const long q0 = t * 256 / rpq;                                                    // first question of the tile: its row 0
-      acc += part[(2 * t + (q0 == b ? 0 : 1)) * G + f];
+    if (f < G) {
+      // a tile's row 0 belongs to the question of its FIRST pair row, row 1 to the next one: question b owns row 0 of the tiles
+      // that start inside it and row 1 of the one that starts before it
+      auto row = [&](long t) { return (2 * t + (t * 256 >= r0 ? 0 : 1)) * G + f; };
+      long t = t0 + tl;
+      for (; t + 12 <= t1; t += 16) {
+        const float a0 = part[row(t)], a1 = part[row(t + 4)], a2 = part[row(t + 8)], a3 = part[row(t + 12)];
+        acc += (a0 + a1) + (a2 + a3);
+      }
+      for (; t <= t1; t += 4) acc += part[row(t)];
     }
-    xg[(long)b * G + f] = acc;
+    __syncthreads();
+    red[tl][threadIdx.x & 255] = acc;
+    __syncthreads();
+    if (tl == 0 && f < G) xg[(long)b * G + f] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
   }
 }
 
 extern "C" int rn_pair_sum_tiles(const float* part, float* xg, int M, int rows_per_question, int G, void* stream) {
   RN_CHECK_ARG(part && xg && M > 0 && rows_per_question >= 256 && M % rows_per_question == 0 && M % 256 == 0 && G > 0,
                "rn_pair_sum_tiles: needs M %% 256 == 0 and rows_per_question >= 256 dividing M (M=%d, rows_per_question=%d)", M, rows_per_question);
-  pair_sum_tiles_kernel<<<M / rows_per_question, 256, 0, (hipStream_t)stream>>>(part, xg, rows_per_question, G);
+  pair_sum_tiles_kernel<<<M / rows_per_question, 1024, 0, (hipStream_t)stream>>>(part, xg, rows_per_question, G);
   RN_LAUNCH_CHECK("rn_pair_sum_tiles");
   return 0;
 }
@@ -650,10 +666,23 @@ __global__ __launch_bounds__(1024) void pair_reduce_parts_kernel(const f32x4* __
       const f32x4* pi = ri_part + ((long)b * n + r) * jgs * G4 + c;
       const int u0 = (b * (njp / 32) + (r >> 5)) * nu;                // first unit of (question, j block)
       const f32x4* pj = rj_part + (long)(r & 31) * G4 + c;
-      f32x4 si = pi[0], sj = {0.f, 0.f, 0.f, 0.f};
-      for (int g = 1; g < jgs; ++g) si += pi[(long)g * G4];
-      for (int u = 0; u < nu; ++u) {
-        sj += pj[(long)(u0 + u) * 32 * G4];
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      // eight loads in flight per step (a padded 14 x 14 question is 14 + 5 partial rows per output row: one load per round trip
+      // made this kernel 48 us alone at that shape); the order of the adds is fixed
+      f32x4 si = z4, sj = z4;
+      for (int g0 = 0; g0 < jgs; g0 += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = g0 + e < jgs ? pi[(long)(g0 + e) * G4] : z4;
+        si += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
+      for (int v0 = 0; v0 < nu; v0 += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v0 + e < nu ? pj[(long)(u0 + v0 + e) * 32 * G4] : z4;
+        sj += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
+      for (int u = 0; u < nu; ++u) {                                  // the balanced tail's extra records (a few units per question)
         const int p = rn_red_walk_pos(b, r >> 5, u, nb, njp / 32);    // walk position of the unit (rn_common.h: shared with the writer)
         if (p >= units_whole)
           for (int t = 1; t < tpu; ++t) sj += pj[rn_red_extra_rec(p, t, nunits, tpu, units_whole) * 32 * G4];
