@@ -17,7 +17,7 @@ ls -la $OUT
 # 2. the other BASELINE configs: original-sd B=4 (configs[0]), ir-fp (configs[3]) and the 14x14 / B=32 stress shape (configs[4])
 python bench.py --config original-sd --no-other-modes > $OUT/bench_original_sd_b4.json 2>> $OUT/bench.err
 python bench.py --config ir-fp --no-cpu-baseline > $OUT/bench_ir_fp.json 2>> $OUT/bench.err
-python bench.py --hw 224 --batch 32 --steps 10 --no-cpu-baseline > $OUT/bench_stress_b32_n196.json 2>> $OUT/bench.err
+python bench.py --hw 224 --batch 32 --steps 40 --no-cpu-baseline > $OUT/bench_stress_b32_n196.json 2>> $OUT/bench.err
 python tools/time_small.py > $OUT/small_kernels_alone.txt 2>/dev/null
 python tools/time_wgrad.py > $OUT/wgrad_alone.txt 2>/dev/null
 python tools/time_fwd_f16s.py > $OUT/fwd_chain_alone.txt 2>/dev/null

@@ -46,7 +46,7 @@ def main():
     model.cuda(dev).train()
     opt = torch.optim.Adam(model.parameters(), lr=5e-6, weight_decay=1e-4, fused=True)
     tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0, use_graph=True)
-    batch = make_batch(args.batch, dev, args.hw)
+    batch = make_batch(args.batch, dev, args.hw, state_desc=bool(hyp.get("state_description")))
 
     buf = torch.zeros(8192, dtype=torch.int64, device=dev)
     state = {"idx": 0, "ops": []}
