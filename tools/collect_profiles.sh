@@ -57,6 +57,7 @@ python tools/kernel_resources.py > $OUT/kernel_resources.txt 2>/dev/null
 if [ "$QUICK" = "quick" ]; then ls -la $OUT; exit 0; fi
 # 7. the relational convergence task (three squares; closest / same-row questions): 3000 steps per mode, ~2.5 min each
 python tools/convergence.py 3000 5e-4 pairs 250 > $OUT/convergence_pairs.txt 2>/dev/null
+python tools/convergence.py 3000 5e-4 pairs 250 ir-fp short > $OUT/convergence_pairs_ir_fp.txt 2>/dev/null
 # 8. ablations quoted in DESIGN.md, from a DIAGNOSTICS build of the library (timing-only variants with wrong results; the product
 # library is rebuilt afterwards)
 RN_DIAG=1 python relationnetworks-clevr_amd/_build.py --force > $ABL/diag_build.log 2>&1
