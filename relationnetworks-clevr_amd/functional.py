@@ -180,6 +180,7 @@ class PackedWeights:
 # event itself, and the conv stack's backward starts with dx instead of behind dq (RN.forward sets PackedWeights.q_grad_async when
 # the question IS that node's output; any other producer gets the synchronous hand-off).
 _GRAD_EVENTS = {}
+HANDED_BY_EVENT = [0]                              # how many gradients went that way (tests)
 _SIDE_STREAMS = {}
 # Launch-order choices of the backward pass that only measurements decide (the captured graph's queue order): kept as named knobs so that
 # tools/dbg/exp_bench.py can A/B them on one box.  wgrad_late: 0 the g_theta weight-gradient launch right behind the backward chain,
@@ -485,6 +486,7 @@ class RelationalFunction(torch.autograd.Function):
         # (precision, grad mode of the CALLER): inside forward() autograd is always off and ctx.needs_input_grad ignores torch.no_grad()
         precision, grad_on = precision if isinstance(precision, tuple) else (precision, True)
         ctx.set_materialize_grads(False)
+        q_grad_async, packed.q_grad_async = bool(getattr(packed, "q_grad_async", False)), False   # ONE call's permission (RN.forward sets it right in front of this call)
         L = plan.L
         g_w, g_b = params[0:L], params[L:2 * L]
         f_w, f_b = params[2 * L:2 * L + 3], params[2 * L + 3:2 * L + 6]
@@ -549,7 +551,7 @@ class RelationalFunction(torch.autograd.Function):
         if need_grad:
             ctx.plan, ctx.code, ctx.dims = plan, code, (B, n, k, Q, M, G, F1, F2, A)
             ctx.chain, ctx.njp = chain, njp
-            ctx.q_grad_async = bool(getattr(packed, "q_grad_async", False))
+            ctx.q_grad_async = q_grad_async
             ctx.coord = coord
             ctx.inputs, ctx.HL, ctx.wbwd = inputs, HL, wbwd
             ctx.fragT = list(packed.fragT)
@@ -750,6 +752,7 @@ class RelationalFunction(torch.autograd.Function):
                     H.gemm_f32(Rq2, N, 1, wl, kt, 1, dq, Q, B, Q, N, b_off=kt - Q)
                     _GRAD_EVENTS.clear()
                     _GRAD_EVENTS[dq.data_ptr()] = (side.record_event(), None)
+                    HANDED_BY_EVENT[0] += 1
                 if late:
                     inj_out["question_cols"] = _wgrad_question     # (behind the weight-gradient launch, which creates gW[l])
                 else:

@@ -726,10 +726,12 @@ def test_question_gradient_hand_off_by_event_matches_the_synchronous_path(pkg, B
             for _ in range(3):
                 m.zero_grad(set_to_none=True)
                 lp, loss = m.forward_loss(img, qst, lab)
-                assert m.rl._packed.q_grad_async                      # (the question IS the LSTM function's output)
+                assert not m.rl._packed.q_grad_async                  # (the permission is one call's: consumed by the layer's forward)
+                n0 = RF.HANDED_BY_EVENT[0]
                 loss.backward()
                 torch.cuda.synchronize()
-                assert not RF._GRAD_EVENTS                            # consumed by the encoder's backward
+                assert RF.HANDED_BY_EVENT[0] - n0 == (1 if async_ else 0)   # the event path ran / did not run
+                assert not RF._GRAD_EVENTS                            # ... and the encoder's backward consumed the entry
                 outs.append((lp.detach().clone(), float(loss.detach()), {n_: p_.grad.clone() for n_, p_ in m.named_parameters()}))
             return outs
         finally:
@@ -740,6 +742,14 @@ def test_question_gradient_hand_off_by_event_matches_the_synchronous_path(pkg, B
         assert torch.equal(lp_a, lp_s) and loss_a == loss_s
         for n_ in g_s:
             assert l2rel(g_a[n_].cpu().numpy(), g_s[n_].cpu().numpy()) <= 2e-5, n_
+    # a relational layer called with a question of the caller's own gets the synchronous hand-off (no permission was given)
+    m = pkg.RN(Args, dict(formula.HYP["ir-fp"], precision="auto", dropout=0.0)).cuda().train()
+    x = torch.from_numpy(formula.hash_uniform((B, 64, 26), 334, -1.0, 1.0)).cuda().requires_grad_()
+    q = torch.from_numpy(formula.hash_uniform((B, 128), 335, -1.0, 1.0)).cuda().requires_grad_()
+    n0 = RF.HANDED_BY_EVENT[0]
+    m.rl(x, q).sum().backward()
+    torch.cuda.synchronize()
+    assert RF.HANDED_BY_EVENT[0] == n0 and q.grad is not None and torch.isfinite(q.grad).all()
     for n_ in a[0][2]:                                                # ... and a pass repeats itself bitwise
         assert torch.equal(a[0][2][n_], a[2][2][n_]), n_
     assert float(a[0][2]["text.wembedding.weight"].abs().sum()) > 0
