@@ -95,7 +95,8 @@ int rn_pack_matrix(const float* src, long sr, long sc, int R, int C, void* dst, 
 /* K2 -- one g_theta layer:  H = relu(A @ W^T + bias)      (model.py:141-145)
  * A: (M, lda) dtype, reduction length K (K % 64 == 0, columns >= true K are zero),
  * Wp: (N, ldw) packed dtype (rn_pack_matrix), bias: fp32 (N), H: (M, ldh) dtype.
- * N % 256 == 0. */
+ * N % 64 == 0.  Workgroup tiles: 128 x 256 when those give at least half the chip work (N % 256 == 0), 64 x 64 otherwise (the
+ * state-description models' short pair matrices) -- the same k-ordered sums either way, bit for bit. */
 int rn_g_linear_fwd(const void* A, int lda, const void* Wp, int ldw, const float* bias, void* H, int ldh,
                     int dtype, int M, int N, int K, void* stream);
 
@@ -183,7 +184,7 @@ int rn_pair_sum_bwd(const float* dxg, const void* HL, int ldh, void* dZ, int ldd
 /* dgrad of one g layer fused with the previous layer's ReLU gate:
  *   dZprev = (dZ @ W[:, :Kin]) * (Hprev > 0)
  * dZ: (M, lddz), reduction length N (layer width, N % 64 == 0); Wt: (Kin, ldwt) packed
- * transposed weight (Wt[k][n] = W[n][k]); Hprev, dZprev: (M, Kin), Kin % 256 == 0. */
+ * transposed weight (Wt[k][n] = W[n][k]); Hprev, dZprev: (M, Kin), Kin % 64 == 0 (tiles as above). */
 int rn_g_linear_bwd_dgrad(const void* dZ, int lddz, const void* Wt, int ldwt, const void* Hprev, int ldhp,
                           void* dZprev, int lddzp, int dtype, int M, int N, int Kin, void* stream);
 

@@ -34,16 +34,22 @@ template <> struct Mma<float> {
   }
 };
 
-constexpr int TM = 128, TN = 256;
+// Two tile shapes (workgroup tile = 2 x 2 waves of MT x NT 32 x 32 MFMA tiles): 128 x 256 for the pair matrices of the image
+// models (thousands of workgroups), 64 x 64 for the state-description models (BASELINE configs[0]: M = B * 144 = 576 pair rows at
+// B = 4, 512 features -- 10 of the big tiles, i.e. 10 of 256 CUs at 55 us a layer; 72 small ones).  The k order of every output
+// element is the same in both: results are bitwise identical whichever tile computes them.
+constexpr int TN_BIG = 256;            // the entry points accept output widths that are multiples of the small tile's 64
+constexpr int GEMM_SMALL_BELOW = 128;  // big tiles on fewer than this many workgroups -> small tiles
 constexpr int SLAB_B = 128;            // bytes of K per row per slab
 constexpr int ROW_B = SLAB_B + 16;     // padded LDS row stride: conflict-free ds_read_b128
 
-template <typename T, int EPI>
+template <typename T, int EPI, int MT, int NT>
 __global__ __launch_bounds__(256, 2) void gemm_rowtile_kernel(const T* __restrict__ A, int lda,
                                                               const T* __restrict__ W, int ldw,
                                                               const float* __restrict__ bias,
                                                               const T* __restrict__ gate, int ldg,
                                                               T* __restrict__ C, int ldc, int M, int K) {
+  constexpr int TM = 64 * MT, TN = 64 * NT;
   constexpr int CH = Elem<T>::kPer16B;
   constexpr int BKE = SLAB_B / (int)sizeof(T);
   typedef typename Mma<T>::Frag Frag;
@@ -57,36 +63,36 @@ __global__ __launch_bounds__(256, 2) void gemm_rowtile_kernel(const T* __restric
   const int n0 = blockIdx.y * TN;
   const int srow = t >> 3, scc = t & 7;        // staging: 8 consecutive lanes cover one 128-byte row slab
 
-  u32x4 ra[4], rw[8];
-  const T* a_ptr[4];
-  const T* w_ptr[8];
+  u32x4 ra[2 * MT], rw[2 * NT];
+  const T* a_ptr[2 * MT];
+  const T* w_ptr[2 * NT];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
+  for (int s = 0; s < 2 * MT; ++s) {
     long r = m0 + srow + 32 * s;
     if (r > M - 1) r = M - 1;                   // clamp: rows >= M are computed but never stored
     a_ptr[s] = A + r * lda + scc * CH;
   }
 #pragma unroll
-  for (int s = 0; s < 8; ++s) w_ptr[s] = W + (long)(n0 + srow + 32 * s) * ldw + scc * CH;
+  for (int s = 0; s < 2 * NT; ++s) w_ptr[s] = W + (long)(n0 + srow + 32 * s) * ldw + scc * CH;
 
   auto gload = [&](int kt) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) ra[s] = *reinterpret_cast<const u32x4*>(a_ptr[s] + kt * BKE);
+    for (int s = 0; s < 2 * MT; ++s) ra[s] = *reinterpret_cast<const u32x4*>(a_ptr[s] + kt * BKE);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) rw[s] = *reinterpret_cast<const u32x4*>(w_ptr[s] + kt * BKE);
+    for (int s = 0; s < 2 * NT; ++s) rw[s] = *reinterpret_cast<const u32x4*>(w_ptr[s] + kt * BKE);
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4*>(ldsA + (srow + 32 * s) * ROW_B + scc * 16) = ra[s];
+    for (int s = 0; s < 2 * MT; ++s) *reinterpret_cast<u32x4*>(ldsA + (srow + 32 * s) * ROW_B + scc * 16) = ra[s];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) *reinterpret_cast<u32x4*>(ldsW + (srow + 32 * s) * ROW_B + scc * 16) = rw[s];
+    for (int s = 0; s < 2 * NT; ++s) *reinterpret_cast<u32x4*>(ldsW + (srow + 32 * s) * ROW_B + scc * 16) = rw[s];
   };
 
-  f32x16 acc[2][4];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -94,21 +100,21 @@ __global__ __launch_bounds__(256, 2) void gemm_rowtile_kernel(const T* __restric
   gload(0);
   lstore();
   __syncthreads();
-  const unsigned char* fa_base = ldsA + (wm * 64 + (lane & 31)) * ROW_B + (lane >> 5) * 16;
-  const unsigned char* fw_base = ldsW + (wn * 128 + (lane & 31)) * ROW_B + (lane >> 5) * 16;
+  const unsigned char* fa_base = ldsA + (wm * 32 * MT + (lane & 31)) * ROW_B + (lane >> 5) * 16;
+  const unsigned char* fw_base = ldsW + (wn * 32 * NT + (lane & 31)) * ROW_B + (lane >> 5) * 16;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      Frag fa[2], fw[4];
+      Frag fa[MT], fw[NT];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const Frag*>(fa_base + mt * 32 * ROW_B + ks * 32);
+      for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const Frag*>(fa_base + mt * 32 * ROW_B + ks * 32);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) fw[nt] = *reinterpret_cast<const Frag*>(fw_base + nt * 32 * ROW_B + ks * 32);
+      for (int nt = 0; nt < NT; ++nt) fw[nt] = *reinterpret_cast<const Frag*>(fw_base + nt * 32 * ROW_B + ks * 32);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) Mma<T>::mma(fw[nt], fa[mt], acc[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) Mma<T>::mma(fw[nt], fa[mt], acc[mt][nt]);
     }
     __syncthreads();
     if (kt + 1 < nk) {
@@ -119,14 +125,14 @@ __global__ __launch_bounds__(256, 2) void gemm_rowtile_kernel(const T* __restric
 
   // ---- epilogue: lane holds, per (mt, nt, g), features nb..nb+3 of pair row `row`
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const long row = m0 + wm * 64 + mt * 32 + (lane & 31);
+  for (int mt = 0; mt < MT; ++mt) {
+    const long row = m0 + wm * 32 * MT + mt * 32 + (lane & 31);
     if (row >= M) continue;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int nb = n0 + wn * 128 + nt * 32 + 8 * g + 4 * (lane >> 5);
+        const int nb = n0 + wn * 32 * NT + nt * 32 + 8 * g + 4 * (lane >> 5);
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][4 * g + r];
@@ -157,19 +163,25 @@ static int gemm_launch(const void* A, int lda, const void* W, int ldw, const flo
   RN_CHECK_ARG(A && W && C && M > 0, "%s: bad pointer/size", who);
   RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "%s: bad dtype %d", who, dtype);
   const int CH = dtype == RN_BF16 ? 8 : 4;
-  RN_CHECK_ARG(N % TN == 0, "%s: output width %d must be a multiple of %d", who, N, TN);
+  RN_CHECK_ARG(N % 64 == 0, "%s: output width %d must be a multiple of 64", who, N);
   RN_CHECK_ARG(K % 64 == 0 && K > 0, "%s: reduction length %d must be a multiple of 64", who, K);
   RN_CHECK_ARG(lda % CH == 0 && ldw % CH == 0 && ldc % CH == 0 && lda >= K && ldw >= K && ldc >= N,
                "%s: leading dimensions (lda=%d ldw=%d ldc=%d) must be 16-byte multiples and cover K=%d / N=%d", who, lda,
                ldw, ldc, K, N);
   RN_CHECK_ARG(((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)gate) % 16 == 0, "%s: pointers must be 16-byte aligned", who);
-  dim3 grid(cdiv(M, TM), N / TN);
-  if (dtype == RN_BF16)
-    gemm_rowtile_kernel<bf16, EPI><<<grid, 256, 0, s>>>((const bf16*)A, lda, (const bf16*)W, ldw, bias, (const bf16*)gate,
-                                                        ldg, (bf16*)C, ldc, M, K);
-  else
-    gemm_rowtile_kernel<float, EPI><<<grid, 256, 0, s>>>((const float*)A, lda, (const float*)W, ldw, bias,
-                                                         (const float*)gate, ldg, (float*)C, ldc, M, K);
+  // 128 x 256 tiles when they give every CU work; 64 x 64 ones for the short matrices (same sums, bit for bit)
+  const bool small = N % TN_BIG != 0 || (long)cdiv(M, 128) * (N / TN_BIG) < GEMM_SMALL_BELOW;
+#define RN_GEMM_LAUNCH(T, MT, NT)                                                                                              \
+  gemm_rowtile_kernel<T, EPI, MT, NT><<<dim3(cdiv(M, 64 * MT), N / (64 * NT)), 256, 0, s>>>(                                    \
+      (const T*)A, lda, (const T*)W, ldw, bias, (const T*)gate, ldg, (T*)C, ldc, M, K)
+  if (dtype == RN_BF16) {
+    if (small) RN_GEMM_LAUNCH(bf16, 1, 1);
+    else RN_GEMM_LAUNCH(bf16, 2, 4);
+  } else {
+    if (small) RN_GEMM_LAUNCH(float, 1, 1);
+    else RN_GEMM_LAUNCH(float, 2, 4);
+  }
+#undef RN_GEMM_LAUNCH
   RN_LAUNCH_CHECK(who);
   return 0;
 }

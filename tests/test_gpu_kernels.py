@@ -248,7 +248,8 @@ def _gemm_case(M, N, K, Ktrue, seed):
 
 
 @pytest.mark.parametrize("code", [0, 1])
-@pytest.mark.parametrize("M,N,K,Ktrue", [(128, 256, 192, 180), (576, 512, 320, 270), (1000, 256, 256, 256), (4096, 256, 64, 52)])
+@pytest.mark.parametrize("M,N,K,Ktrue", [(128, 256, 192, 180), (576, 512, 320, 270), (1000, 256, 256, 256), (4096, 256, 64, 52),
+                                          (16512, 256, 128, 100), (200, 320, 128, 128)])
 def test_g_linear_fwd(H, code, M, N, K, Ktrue):
     A, W, b = _gemm_case(M, N, K, Ktrue, 20)
     if code == 0:
@@ -261,6 +262,25 @@ def test_g_linear_fwd(H, code, M, N, K, Ktrue):
     tol = BF16_ULP if code == 0 else F32_TOL
     err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max() * 1e-2)
     assert err.max() <= tol, (err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
+@pytest.mark.parametrize("code", [0, 1])
+def test_g_linear_tiles_agree_bitwise(H, code):
+    """rn_gemm.hip picks 64 x 64 workgroup tiles for short matrices (the state-description models: M = B * 144) and 128 x 256 ones
+    when those fill the chip; every output element's k order is the same in both, so the first rows of a long matrix (big tiles)
+    equal the same rows computed as a short matrix (small tiles) bit for bit -- forward and gated dgrad."""
+    Ms, Mb, N, K = 576, 128 * 64 + 40, 512, 512                    # 65 x 2 big tiles = 130 workgroups >= GEMM_SMALL_BELOW
+    A, W, b = _gemm_case(Mb, N, K, K, 50)
+    Ad, Wd, bd = dev(A).to(tdt(code)), dev(W).to(tdt(code)), dev(b)
+    big = torch.empty(Mb, N, dtype=tdt(code), device="cuda")
+    small = torch.empty(Ms, N, dtype=tdt(code), device="cuda")
+    H.g_linear_fwd(Ad, K, Wd, K, bd, big, N, code, Mb, N, K)
+    H.g_linear_fwd(Ad, K, Wd, K, bd, small, N, code, Ms, N, K)
+    assert torch.equal(big[:Ms], small) and small.float().abs().sum() > 0
+    gate = dev(np.maximum(formula.hash_uniform((Mb, N), 51, -1, 1), 0)).to(tdt(code))
+    H.g_linear_bwd_dgrad(Ad, K, Wd, K, gate, N, big, N, code, Mb, K, N)
+    H.g_linear_bwd_dgrad(Ad, K, Wd, K, gate, N, small, N, code, Ms, K, N)
+    assert torch.equal(big[:Ms], small) and small.float().abs().sum() > 0
 
 
 @pytest.mark.parametrize("code", [0, 1])

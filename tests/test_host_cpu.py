@@ -101,7 +101,7 @@ def test_argument_validation_without_gpu(pkg):
     rc = lib.rn_pair_build_fwd(None, 0, 0, 0, None, 0, None, 0, 1, 1, 1, 0, 64, None)
     assert rc < 0 and b"bad pointer" in lib.rn_last_error()
     rc = lib.rn_g_linear_fwd(1 << 20, 256, 1 << 20, 256, 1 << 20, 1 << 20, 256, 0, 128, 100, 256, None)
-    assert rc < 0 and b"multiple of 256" in lib.rn_last_error()
+    assert rc < 0 and b"multiple of 64" in lib.rn_last_error()
 
 
 def test_missing_library_is_loud(pkg, tmp_path):
