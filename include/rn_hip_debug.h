@@ -41,6 +41,11 @@ int rn_probe_red_schedule(int M, int n, int njp, int tiles_per_unit, int units_w
  * beside the nominal 2.5 PFLOP/s (the chip clocks to its power budget).  out: workgroups * 256 * waves_per_simd floats (a sink). */
 int rn_probe_mfma_stream(float* out, int workgroups, int waves_per_simd, int iters, int dtype, void* stream);
 
+/* Which f_phi kernels rn_f_phi_fwd / _fwd_nll / _bwd / _bwd_nll launch: 0 = by size (the per-layer, feature-split launches for
+ * anything wider than the 256-wide image models: config.json's *-sd), 1 = always the per-layer launches, -1 = never.  Returns the
+ * previous mode.  tests/ compare the two paths bit for bit with it; the product never calls it. */
+int rn_debug_f_phi_wide(int mode);
+
 #ifdef __cplusplus
 }
 #endif

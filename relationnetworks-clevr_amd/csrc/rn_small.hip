@@ -245,6 +245,58 @@ __device__ __forceinline__ void fp_layer_pass(const float* __restrict__ W, const
 }
 }  // namespace
 
+// Layer 3 + log_softmax (+ the mean NLL of the batch) on the block's FP_RB rows: sa = the rows of f2 in LDS, sb <- the logits.
+// Shared by the one-launch kernel below and by the head launch of the wide path.
+template <bool TR>
+__device__ __forceinline__ void fp_head(const float* __restrict__ W3, const float* __restrict__ b3, const float* sa, float* sb, float* red,
+                                        float* lrow, float* __restrict__ out, int B, int F2, int A, int r0,
+                                        const long long* __restrict__ label, float* __restrict__ loss, float* loss_part,
+                                        unsigned* done_count) {
+  const int t = threadIdx.x;
+  fp_layer_pass<TR>(W3, b3, sa, F2, A, red, [&](int r, int f, float z) { sb[r * FP_MAXW + f] = z; });
+  __syncthreads();
+  if (t < FP_RB && r0 + t < B) {                       // log_softmax of one row (A <= 1024 logits in LDS)
+    const float* z = sb + t * FP_MAXW;
+    float mx = z[0];
+    for (int a = 1; a < A; ++a) mx = fmaxf(mx, z[a]);
+    float s = 0.f;
+    for (int a = 0; a < A; ++a) s += expf(z[a] - mx);
+    const float ls = mx + logf(s);
+    for (int a = 0; a < A; ++a) out[(long)(r0 + t) * A + a] = z[a] - ls;
+    if (label) lrow[t] = -(z[fp_label(label[r0 + t], A)] - ls);
+  } else if (t < FP_RB) {
+    lrow[t] = 0.f;
+  }
+  // mean NLL of the batch (train.py:41) in the same launch: block partials in a fixed order, combined by whichever
+  // block finishes last (also in a fixed order: deterministic); the counter re-arms itself for the next launch
+  if (label) {
+    __shared__ int last_s;
+    __syncthreads();
+    if (t == 0) {
+      loss_part[blockIdx.x] = ((lrow[0] + lrow[1]) + lrow[2]) + lrow[3];
+      __threadfence();
+      last_s = atomicAdd(done_count, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last_s && t < 64) {
+      // the last block adds the block partials in block order; up to 64 of them are fetched by one wave at once (one round trip
+      // instead of a chain of them on the tail of the launch) and read back lane by lane: the same sum as the plain loop
+      __threadfence();
+      float tot = 0.f;
+      for (unsigned i0 = 0; i0 < gridDim.x; i0 += 64) {
+        const unsigned i = i0 + t;
+        const float v = i < gridDim.x ? reinterpret_cast<volatile float*>(loss_part)[i] : 0.f;
+        const unsigned cnt = gridDim.x - i0 < 64u ? gridDim.x - i0 : 64u;
+        for (unsigned j = 0; j < cnt; ++j) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)j));
+      }
+      if (t == 0) {
+        *loss = tot / (float)B;
+        *done_count = 0u;
+      }
+    }
+  }
+}
+
 // The backward dz chain of the SAME rows in the same launch (training step with the loss folded in: the log-prob gradient is
 // -1/B at the label whatever the rest of the step does, so nothing has to be waited for): W1..3 natural (out, in) weights (NULL:
 // no tail), dz3 / dz2 / dz1 (B x A / F2 / F1) and dxg (B x G) outputs -- for d loss = 1; rn_f_phi_bwd_grads finishes the job.
@@ -316,48 +368,7 @@ __global__ __launch_bounds__(TR ? FP_KS * 256 : 256) void f_phi_fwd_kernel(
     if (ok) f2[(long)(r0 + r) * F2 + f] = v;
   });
   __syncthreads();
-  fp_layer_pass<TR>(W3, b3, sa, F2, A, red, [&](int r, int f, float z) { sb[r * FP_MAXW + f] = z; });
-  __syncthreads();
-  if (t < FP_RB && r0 + t < B) {                       // log_softmax of one row (A <= 1024 logits in LDS)
-    const float* z = sb + t * FP_MAXW;
-    float mx = z[0];
-    for (int a = 1; a < A; ++a) mx = fmaxf(mx, z[a]);
-    float s = 0.f;
-    for (int a = 0; a < A; ++a) s += expf(z[a] - mx);
-    const float ls = mx + logf(s);
-    for (int a = 0; a < A; ++a) out[(long)(r0 + t) * A + a] = z[a] - ls;
-    if (label) lrow[t] = -(z[fp_label(label[r0 + t], A)] - ls);
-  } else if (t < FP_RB) {
-    lrow[t] = 0.f;
-  }
-  // mean NLL of the batch (train.py:41) in the same launch: block partials in a fixed order, combined by whichever
-  // block finishes last (also in a fixed order: deterministic); the counter re-arms itself for the next launch
-  if (label) {
-    __shared__ int last_s;
-    __syncthreads();
-    if (t == 0) {
-      loss_part[blockIdx.x] = ((lrow[0] + lrow[1]) + lrow[2]) + lrow[3];
-      __threadfence();
-      last_s = atomicAdd(done_count, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (last_s && t < 64) {
-      // the last block adds the block partials in block order; up to 64 of them are fetched by one wave at once (one round trip
-      // instead of a chain of them on the tail of the launch) and read back lane by lane: the same sum as the plain loop
-      __threadfence();
-      float tot = 0.f;
-      for (unsigned i0 = 0; i0 < gridDim.x; i0 += 64) {
-        const unsigned i = i0 + t;
-        const float v = i < gridDim.x ? reinterpret_cast<volatile float*>(loss_part)[i] : 0.f;
-        const unsigned cnt = gridDim.x - i0 < 64u ? gridDim.x - i0 : 64u;
-        for (unsigned j = 0; j < cnt; ++j) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)j));
-      }
-      if (t == 0) {
-        *loss = tot / (float)B;
-        *done_count = 0u;
-      }
-    }
-  }
+  fp_head<TR>(W3, b3, sa, sb, red, lrow, out, B, F2, A, r0, label, loss, loss_part, done_count);
   if constexpr (TR) {
     if (bt.W1 && label) {
       // ---- backward dz chain of this block's rows (what f_phi_bwd_dz_kernel does from global memory in a launch of its own)
@@ -459,6 +470,124 @@ __global__ __launch_bounds__(FP_KS * 256) void f_phi_bwd_dz_kernel(const float* 
   });
 }
 
+// ---- the WIDE f_phi of the state-description models (config.json *-sd: 512 -> 512 -> 1024 -> 28, 3 MB of fp32 weights).  The
+// one-launch kernels split ROWS over workgroups, so every workgroup pulls every weight through one CU: at B = 4 that is ONE
+// workgroup and 177 us forward + 58 us backward (a CU takes 20 - 40 GB/s from L2 / HBM).  Here a layer is a launch of its own,
+// split over OUTPUT FEATURES (64 per workgroup: 8 - 16 CUs share a layer's weights, 128 - 256 KB each) and rows (FP_RB per
+// workgroup, as before).  The thread map differs, the arithmetic does not: the same 16 k-slices, the same fmaf chain inside a
+// slice (fp_cols4), the same slice-order sum, the same bias add -- bit for bit what f_phi_fwd_kernel<true> / f_phi_bwd_dz_kernel
+// compute (GPU test: the wide shapes through both).
+namespace {
+constexpr int FPW_COLS = 64;
+enum { FPW_RELU = 0, FPW_MASK_RELU = 1, FPW_GATE_MASK = 2, FPW_GATE = 3, FPW_PLAIN = 4 };
+// the dispatch: anything wider than the 256-wide image models (whose f_phi is rn_fphi.hip's / the one-launch kernels' business)
+int g_fp_wide_mode = 0;             // rn_debug_f_phi_wide (tests): -1 never, 0 by size, 1 always
+inline bool fp_is_wide(int G, int F1, int F2) {
+  return g_fp_wide_mode ? g_fp_wide_mode > 0 : (long)G * F1 + (long)F1 * F2 > 2L * 256 * 256;
+}
+}  // namespace
+extern "C" int rn_debug_f_phi_wide(int mode) {
+  const int was = g_fp_wide_mode;
+  g_fp_wide_mode = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
+  return was;
+}
+
+// out[r][f] = epi(bias[f] + sum_k in[r][k] * WT[k][f]); WT: (K, N) row-major, N % 4 == 0; grid (rows / FP_RB, N / 64)
+//   FPW_RELU: relu(z) | FPW_MASK_RELU: relu(z * mask) | FPW_GATE_MASK: act > 0 ? z * mask : 0 | FPW_GATE: act > 0 ? z : 0 | FPW_PLAIN: z
+template <int EPI>
+__global__ __launch_bounds__(256) void fp_wide_layer_kernel(const float* __restrict__ in, const float* __restrict__ WT,
+                                                            const float* __restrict__ bias, const float* __restrict__ act,
+                                                            const float* __restrict__ mask, float* __restrict__ out, int B, int K, int N) {
+  __shared__ __attribute__((aligned(16))) float in_s[FP_RB * FP_MAXW], red[FP_KQ * FP_RB * FPW_COLS];
+  const int t = threadIdx.x, r0 = blockIdx.x * FP_RB, c0 = blockIdx.y * FPW_COLS;
+  for (int c = t; c < FP_RB * K; c += 256) {
+    const int r = c / K, k = c - r * K;
+    in_s[r * FP_MAXW + k] = (r0 + r < B) ? in[(long)(r0 + r) * K + k] : 0.f;
+  }
+  __syncthreads();
+  {
+    // thread = (k-slice, four columns): 16 slices x 16 column quads; a wave holds four slices
+    const int lane = t & 63, j4 = lane & 15, kq = (t >> 6) * 4 + (lane >> 4), f0 = c0 + 4 * j4;
+    const int chunk = ((K + FP_KQ - 1) / FP_KQ + 3) & ~3, i0 = min(K, kq * chunk), i1 = min(K, i0 + chunk);
+    f32x4 a4[FP_RB];
+#pragma unroll
+    for (int r = 0; r < FP_RB; ++r) a4[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (f0 < N) fp_cols4(WT, in_s, i0, i1, N, f0, a4);
+#pragma unroll
+    for (int r = 0; r < FP_RB; ++r) *reinterpret_cast<f32x4*>(red + (kq * FP_RB + r) * FPW_COLS + 4 * j4) = a4[r];
+  }
+  __syncthreads();
+  const int r = t >> 6, f = c0 + (t & 63);
+  if (f < N && r0 + r < B) {
+    float v = red[r * FPW_COLS + (t & 63)];
+#pragma unroll
+    for (int q = 1; q < FP_KQ; ++q) v += red[(q * FP_RB + r) * FPW_COLS + (t & 63)];
+    const float z = v + (bias ? bias[f] : 0.f);
+    const long o = (long)(r0 + r) * N + f;
+    float y;
+    if constexpr (EPI == FPW_RELU) y = fmaxf(z, 0.f);
+    else if constexpr (EPI == FPW_MASK_RELU) y = fmaxf(z * (mask ? mask[o] : 1.f), 0.f);
+    else if constexpr (EPI == FPW_GATE_MASK) y = (act[o] > 0.f) ? z * (mask ? mask[o] : 1.f) : 0.f;
+    else if constexpr (EPI == FPW_GATE) y = (act[o] > 0.f) ? z : 0.f;
+    else y = z;
+    out[o] = y;
+  }
+}
+
+// the head of the wide forward: f2 rows -> LDS, then layer 3 + log_softmax (+ mean NLL) exactly as the one-launch kernel
+__global__ __launch_bounds__(FP_KS * 256) void fp_wide_head_kernel(const float* __restrict__ f2, const float* __restrict__ W3T,
+                                                                   const float* __restrict__ b3, float* __restrict__ out, int B, int F2,
+                                                                   int A, const long long* __restrict__ label, float* __restrict__ loss,
+                                                                   float* loss_part, unsigned* done_count) {
+  __shared__ __attribute__((aligned(16))) float sa[FP_RB * FP_MAXW], sb[FP_RB * FP_MAXW], red[FP_KQ * FP_RB * 256];
+  __shared__ float lrow[FP_RB];
+  const int t = threadIdx.x, r0 = blockIdx.x * FP_RB;
+  for (int c = t; c < FP_RB * F2; c += blockDim.x) {
+    const int r = c / F2, k = c - r * F2;
+    sa[r * FP_MAXW + k] = (r0 + r < B) ? f2[(long)(r0 + r) * F2 + k] : 0.f;
+  }
+  __syncthreads();
+  fp_head<true>(W3T, b3, sa, sb, red, lrow, out, B, F2, A, r0, label, loss, loss_part, done_count);
+}
+
+// dz3 = d loss / d logits from the stored log-probs (f_phi_bwd_dz_kernel's first step): thread = one row
+__global__ __launch_bounds__(64) void fp_wide_dz3_kernel(const float* __restrict__ gout, const float* __restrict__ out,
+                                                         float* __restrict__ dz3, int B, int A, const long long* __restrict__ label,
+                                                         const float* __restrict__ gloss) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const float gl = label ? -gloss[0] / (float)B : 0.f;
+  const int lb = label ? fp_label(label[b], A) : -1;
+  float s = label ? gl : 0.f;
+  if (!label)
+    for (int a = 0; a < A; ++a) s += gout[(long)b * A + a];
+  for (int a = 0; a < A; ++a) {
+    const float go = label ? (a == lb ? gl : 0.f) : gout[(long)b * A + a];
+    dz3[(long)b * A + a] = go - expf(out[(long)b * A + a]) * s;
+  }
+}
+
+// forward of the wide path: three launches (W*T transposed weights); label / loss / part / cnt NULL: no loss
+static void fp_wide_fwd(const float* xg, const float* W1T, const float* b1, const float* W2T, const float* b2, const float* W3T,
+                        const float* b3, const float* mask, float* f1, float* f2, float* out, int B, int G, int F1, int F2, int A,
+                        const long long* label, float* loss, float* part, unsigned* cnt, hipStream_t s) {
+  const int rb = cdiv(B, FP_RB);
+  fp_wide_layer_kernel<FPW_RELU><<<dim3(rb, cdiv(F1, FPW_COLS)), 256, 0, s>>>(xg, W1T, b1, nullptr, nullptr, f1, B, G, F1);
+  fp_wide_layer_kernel<FPW_MASK_RELU><<<dim3(rb, cdiv(F2, FPW_COLS)), 256, 0, s>>>(f1, W2T, b2, nullptr, mask, f2, B, F1, F2);
+  fp_wide_head_kernel<<<rb, FP_KS * 256, 0, s>>>(f2, W3T, b3, out, B, F2, A, label, loss, part, cnt);
+}
+
+// ... and of the backward dz chain (W* natural (out, in) weights = the (in, out) operands of these products): four launches
+static void fp_wide_bwd_dz(const float* gout, const float* out, const float* f2, const float* f1, const float* W1, const float* W2,
+                           const float* W3, const float* mask, float* dz3, float* dz2, float* dz1, float* dxg, int B, int G, int F1,
+                           int F2, int A, const long long* label, const float* gloss, hipStream_t s) {
+  const int rb = cdiv(B, FP_RB);
+  fp_wide_dz3_kernel<<<cdiv(B, 64), 64, 0, s>>>(gout, out, dz3, B, A, label, gloss);
+  fp_wide_layer_kernel<FPW_GATE_MASK><<<dim3(rb, cdiv(F2, FPW_COLS)), 256, 0, s>>>(dz3, W3, nullptr, f2, mask, dz2, B, A, F2);
+  fp_wide_layer_kernel<FPW_GATE><<<dim3(rb, cdiv(F1, FPW_COLS)), 256, 0, s>>>(dz2, W2, nullptr, f1, nullptr, dz1, B, F2, F1);
+  fp_wide_layer_kernel<FPW_PLAIN><<<dim3(rb, cdiv(G, FPW_COLS)), 256, 0, s>>>(dz1, W1, nullptr, nullptr, nullptr, dxg, B, F1, G);
+}
+
 // block = one output row i of dW1 (F1 rows) | dW2 (F2) | dW3 (A): dW[i][j] = sum_b dz[b][i] * act[b][j]; db[i] = sum_b dz[b][i]
 __global__ __launch_bounds__(256) void f_phi_bwd_grads_kernel(const float* __restrict__ dz1, const float* __restrict__ dz2,
                                                               const float* __restrict__ dz3, const float* __restrict__ xg,
@@ -518,7 +647,8 @@ extern "C" int rn_f_phi_fwd(const float* xg, const float* W1, const float* b1, c
   RN_CHECK_ARG(xg && W1 && b1 && W2 && b2 && W3 && b3 && f1 && f2 && out, "rn_f_phi_fwd: NULL pointer");
   if (int rc = fp_check("rn_f_phi_fwd", B, G, F1, F2, A)) return rc;
   RN_CHECK_ARG(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)W3) % 16 == 0, "rn_f_phi_fwd: weights must be 16-byte aligned");
-  if (transposed) f_phi_fwd_kernel<true><<<cdiv(B, FP_RB), FP_KS * 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A);
+  if (transposed && fp_is_wide(G, F1, F2)) fp_wide_fwd(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+  else if (transposed) f_phi_fwd_kernel<true><<<cdiv(B, FP_RB), FP_KS * 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A);
   else f_phi_fwd_kernel<false><<<cdiv(B, FP_RB), 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A);
   RN_LAUNCH_CHECK("rn_f_phi_fwd");
   return 0;
@@ -536,7 +666,8 @@ extern "C" int rn_f_phi_fwd_nll(const float* xg, const float* W1, const float* b
   RN_CHECK_ARG(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)W3) % 16 == 0, "rn_f_phi_fwd_nll: weights must be 16-byte aligned");
   unsigned* cnt = (unsigned*)sync_ws;
   float* part = (float*)sync_ws + 4;
-  if (transposed) f_phi_fwd_kernel<true><<<cdiv(B, FP_RB), FP_KS * 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A, label, loss, part, cnt);
+  if (transposed && fp_is_wide(G, F1, F2)) fp_wide_fwd(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A, label, loss, part, cnt, (hipStream_t)stream);
+  else if (transposed) f_phi_fwd_kernel<true><<<cdiv(B, FP_RB), FP_KS * 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A, label, loss, part, cnt);
   else f_phi_fwd_kernel<false><<<cdiv(B, FP_RB), 256, 0, (hipStream_t)stream>>>(xg, W1, b1, W2, b2, W3, b3, mask, f1, f2, out, B, G, F1, F2, A, label, loss, part, cnt);
   RN_LAUNCH_CHECK("rn_f_phi_fwd_nll");
   return 0;
@@ -611,7 +742,8 @@ extern "C" int rn_f_phi_bwd(const float* gout, const float* out, const float* f2
   float* dz2 = dz1 + (size_t)B * F1;
   float* dz3 = dz2 + (size_t)B * F2;
   hipStream_t s = (hipStream_t)stream;
-  f_phi_bwd_dz_kernel<<<cdiv(B, FP_RB), FP_KS * 256, 0, s>>>(gout, out, f2, f1, W1, W2, W3, mask, dz3, dz2, dz1, dxg, B, G, F1, F2, A);
+  if (fp_is_wide(G, F1, F2)) fp_wide_bwd_dz(gout, out, f2, f1, W1, W2, W3, mask, dz3, dz2, dz1, dxg, B, G, F1, F2, A, nullptr, nullptr, s);
+  else f_phi_bwd_dz_kernel<<<cdiv(B, FP_RB), FP_KS * 256, 0, s>>>(gout, out, f2, f1, W1, W2, W3, mask, dz3, dz2, dz1, dxg, B, G, F1, F2, A);
   f_phi_bwd_grads_kernel<<<F1 + F2 + A, 256, 0, s>>>(dz1, dz2, dz3, xg, f1, f2, dW1, db1, dW2, db2, dW3, db3, B, G, F1, F2, A);
   RN_LAUNCH_CHECK("rn_f_phi_bwd");
   return 0;
@@ -629,7 +761,8 @@ extern "C" int rn_f_phi_bwd_nll(const float* gloss, const long long* label, cons
   float* dz2 = dz1 + (size_t)B * F1;
   float* dz3 = dz2 + (size_t)B * F2;
   hipStream_t s = (hipStream_t)stream;
-  f_phi_bwd_dz_kernel<<<cdiv(B, FP_RB), FP_KS * 256, 0, s>>>(nullptr, out, f2, f1, W1, W2, W3, mask, dz3, dz2, dz1, dxg, B, G, F1, F2, A, label, gloss);
+  if (fp_is_wide(G, F1, F2)) fp_wide_bwd_dz(nullptr, out, f2, f1, W1, W2, W3, mask, dz3, dz2, dz1, dxg, B, G, F1, F2, A, label, gloss, s);
+  else f_phi_bwd_dz_kernel<<<cdiv(B, FP_RB), FP_KS * 256, 0, s>>>(nullptr, out, f2, f1, W1, W2, W3, mask, dz3, dz2, dz1, dxg, B, G, F1, F2, A, label, gloss);
   f_phi_bwd_grads_kernel<<<F1 + F2 + A, 256, 0, s>>>(dz1, dz2, dz3, xg, f1, f2, dW1, db1, dW2, db2, dW3, db3, B, G, F1, F2, A);
   RN_LAUNCH_CHECK("rn_f_phi_bwd_nll");
   return 0;

@@ -163,11 +163,17 @@ class PackedWeights:
             frag_jobs.append((w0, w0.shape[1], 1, w0.shape[0], w0.shape[1], self.w0T, 2))
         # f_phi weights as (in, out) fp32 copies: the forward kernel's thread-per-output-feature walk is then coalesced
         self.fT = None
-        if f_w is not None and all(max(w.shape) <= 256 for w in f_w):
+        if f_w is not None:
             self.fT = [torch.empty(w.shape[1], w.shape[0], dtype=torch.float32, device=dev) for w in f_w]
+            small = all(max(w.shape) <= 256 for w in f_w)           # (the one-launch packer takes matrices up to 256 x 256)
             for w, wt in zip(f_w, self.fT):
                 wc = w.detach().contiguous()
-                frag_jobs.append((wc, wc.shape[1], 1, wc.shape[0], wc.shape[1], wt, 2))
+                if small:
+                    frag_jobs.append((wc, wc.shape[1], 1, wc.shape[0], wc.shape[1], wt, 2))
+                else:
+                    # the wide f_phi of the state-description models (512 / 1024): its forward runs one feature-split launch per
+                    # layer on these copies (rn_small.hip, fp_wide_*) instead of pulling 3 MB of weights through one CU per 4 rows
+                    H.pack_matrix(wc, 1, wc.shape[1], wc.shape[1], wc.shape[0], wt, H.RN_F32, wc.shape[0], wc.shape[1])
         if frag_jobs:
             H.pack_matrix_frag_many(frag_jobs)                                     # one launch for all images
         self.key = key

@@ -1141,6 +1141,55 @@ def test_f_phi_nll_fused(H):
         assert rel(a.cpu().numpy(), b.cpu().numpy()) <= 1e-6
 
 
+@pytest.mark.parametrize("B,G,F1,F2,A,use_mask", [(4, 512, 512, 1024, 28, True), (64, 512, 512, 1024, 28, True), (7, 256, 256, 256, 28, False),
+                                                  (37, 512, 512, 1024, 30, True)])
+def test_f_phi_wide_path_bitwise(H, B, G, F1, F2, A, use_mask):
+    """The state-description models' f_phi (512 -> 512 -> 1024 -> 28: 3 MB of weights) runs as one launch PER LAYER, split over output
+    features (rn_small.hip, fp_wide_*): forward with the loss and both backward entries equal the one-launch row-split kernels bit for
+    bit (same k-slices, same fmaf chains, same slice-order sums), whichever path the size rule picks (rn_debug_f_phi_wide forces each);
+    and the log-probs agree with an fp64 evaluation."""
+    lib = H.load()
+    xg = dev(formula.hash_uniform((B, G), 520, -1, 1))
+    fw = [dev(formula.hash_uniform(sh, 521 + i, -0.06, 0.06)) for i, sh in enumerate([(F1, G), (F2, F1), (A, F2)])]
+    fb = [dev(formula.hash_uniform((n_,), 525 + i, -0.1, 0.1)) for i, n_ in enumerate([F1, F2, A])]
+    mask = dev((formula.hash_uniform((B, F2), 529, 0, 1) > 0.05).astype(np.float32) / 0.95) if use_mask else None
+    label = torch.tensor(formula.hash_uniform((B,), 530, 0, A).astype(np.int64).clip(0, A - 1), device="cuda")
+    wT = [w.t().contiguous() for w in fw]
+    f32 = dict(dtype=torch.float32, device="cuda")
+    gl = torch.tensor(0.7, **f32)
+    gout = dev(formula.hash_uniform((B, A), 531, -1, 1))
+    res = {}
+    was = lib.rn_debug_f_phi_wide(0)
+    try:
+        for mode in (-1, 1):
+            lib.rn_debug_f_phi_wide(mode)
+            nan = lambda *sh: torch.full(sh, float("nan"), **f32)
+            for rep in range(2):                                             # the loss counter re-arms
+                f1, f2, out, loss = nan(B, F1), nan(B, F2), nan(B, A), nan()
+                H.f_phi_fwd_nll(xg, wT, fb, mask, label, f1, f2, out, loss, transposed=True)
+            e1, e2, eo = nan(B, F1), nan(B, F2), nan(B, A)
+            H.f_phi_fwd(xg, wT, fb, mask, e1, e2, eo, transposed=True)
+            mk = lambda: ([nan(*w.shape) for w in fw], [nan(*b.shape) for b in fb], nan(B, G))
+            dWa, dba, dxa = mk(); dWb, dbb, dxb = mk()
+            H.f_phi_bwd_nll(gl, label, out, f2, f1, xg, fw, mask, dWa, dba, dxa)
+            H.f_phi_bwd(gout, out, f2, f1, xg, fw, mask, dWb, dbb, dxb)
+            torch.cuda.synchronize()
+            res[mode] = [f1, f2, out, loss, e1, e2, eo] + dWa + dba + [dxa] + dWb + dbb + [dxb]
+    finally:
+        lib.rn_debug_f_phi_wide(was)
+    for a, b in zip(res[-1], res[1]):
+        assert not torch.isnan(a).any() and torch.equal(a, b)
+    f1, f2, out, loss = res[1][:4]
+    x64 = xg.double().cpu().numpy()
+    h1 = np.maximum(x64 @ fw[0].double().cpu().numpy().T + fb[0].double().cpu().numpy(), 0)
+    z2 = h1 @ fw[1].double().cpu().numpy().T + fb[1].double().cpu().numpy()
+    h2 = np.maximum(z2 * (mask.double().cpu().numpy() if use_mask else 1.0), 0)
+    z3 = h2 @ fw[2].double().cpu().numpy().T + fb[2].double().cpu().numpy()
+    ref = z3 - np.log(np.exp(z3 - z3.max(1, keepdims=True)).sum(1, keepdims=True)) - z3.max(1, keepdims=True)
+    assert rel(out.cpu().numpy(), ref) <= 2e-6
+    assert abs(float(loss) + ref[np.arange(B), label.cpu().numpy()].mean()) <= 2e-6 * abs(float(loss))
+
+
 # ----------------------------------------------------------------------------- mean NLL loss
 def test_nll_mean():
     """NllMeanFunction against F.nll_loss (mean): value and gradient (exact up to the final rounding)."""
