@@ -933,17 +933,20 @@ extern "C" int rn_pair_features(const void* A, int lda, int F, float* maxf, floa
 // ------------------------------------------ input gradients of the pair expansion from the reductions
 // dx[b,j,:] = Rj[b,j,:] W0[:, 0:k] + Ri[b,j,:] W0[:, k:2k]     dq[b,:] = Rq[b,:] W0[:, 2k:2k+Q]      (W0: (N, kt) row-major)
 // One launch instead of three small GEMMs on the critical path of the backward pass (dx feeds the conv stack, dq the
-// question encoder).  Block = a 16-row x 32-column output tile (x blocks: both products; q blocks: one); the feature
-// axis is walked in chunks of 64 staged in LDS, the next chunk's global loads issued before the current chunk's FMAs.
-constexpr int DXQ_FC = 64;
-__global__ __launch_bounds__(512) void pair_dx_dq_kernel(const float* __restrict__ Rj, const float* __restrict__ Ri,
+// question encoder), on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate).  Workgroup = 4 waves
+// = a 16-row x 32-column output tile (x blocks: both products; q blocks: one); wave w takes every fourth group of 16 features, its
+// operands straight from global memory in the MFMA's own lane layout (A: lane = (row, k), B: lane = (column, k) -- no LDS in the
+// loop), all of a wave's loads in flight at once; the four waves' partial tiles meet in LDS and are added in wave order
+// (deterministic).  Round 5's version -- a thread per output, both operands through LDS, two ds_read_b32 per FMA on 8 waves -- was
+// LDS-issue bound: 18 us alone for 0.2 GFLOP on the critical path; a register-tiled VALU version (4 rows per thread, ds_read_b128)
+// measured 24.6 us.
+__global__ __launch_bounds__(256) void pair_dx_dq_kernel(const float* __restrict__ Rj, const float* __restrict__ Ri,
                                                          const float* __restrict__ Rq, const float* __restrict__ W0, int kt,
                                                          float* __restrict__ dx, float* __restrict__ dq, int rows, int B, int k,
                                                          int Q, int N, int xblocks, int qcol_tiles, int n, long sdb, long sdn,
                                                          long sdk, int kout) {
-  __shared__ float rs[2][16][DXQ_FC];
-  __shared__ float ws[2][DXQ_FC][32];
-  const int t = threadIdx.x;
+  __shared__ float red[4][2][4][64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const float *R1, *R2;
   float* out;
   int off1, off2, ncols, nrows, r0, ld;
@@ -954,65 +957,68 @@ __global__ __launch_bounds__(512) void pair_dx_dq_kernel(const float* __restrict
     R1 = Rq; R2 = nullptr; off1 = 2 * k + 32 * ct; off2 = 0; ncols = min(32, Q - 32 * ct); nrows = B; r0 = (qb / qcol_tiles) * 16;
     out = dq + 32 * ct; ld = Q;
   }
-  // staging roles: rows -> 2 floats per thread per operand, weights -> 4 floats per thread per operand
-  const int sr = t >> 5, sf = (t & 31) * 2;          // rs[.][sr][sf..sf+1]
-  const int wc = t & 31, wf = t >> 5;                // ws[.][wf + 16 u][wc], u = 0..3
-  const bool srow_ok = r0 + sr < nrows, wcol_ok = wc < ncols;
-  float pr1[2], pr2[2], pw1[4], pw2[4];
-  auto fetch = [&](int f0) {
+  const bool two = R2 != nullptr;
+  const int li = lane & 15, kq = lane >> 4;                              // operand lane: (row | column li, k = kq)
+  const bool row_ok = r0 + li < nrows, c0_ok = li < ncols, c1_ok = 16 + li < ncols;
+  const float* a1p = R1 + (long)(row_ok ? r0 + li : 0) * N;
+  const float* a2p = (two ? R2 : R1) + (long)(row_ok ? r0 + li : 0) * N;
+  f32x4 acc[2][2];                                                       // [operand][column tile]
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int f = f0 + sf + u;
-      const bool ok = srow_ok && f < N;
-      pr1[u] = ok ? R1[(long)(r0 + sr) * N + f] : 0.f;
-      pr2[u] = (ok && R2) ? R2[(long)(r0 + sr) * N + f] : 0.f;
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[o][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // groups of 16 features: MFMA i of a group multiplies features g + 4 kq + i (both operands agree; any order is a valid sum).
+  // FOUR groups per trip: 4 x (2 x 4 + 4 x 4) = 96 loads of a lane in flight before the first MFMA.
+  constexpr int GPT = 4;
+  for (int g0 = 16 * w * GPT; g0 < N; g0 += 64 * GPT) {
+    float xa[GPT][2][4], wb[GPT][2][2][4];
+#pragma unroll
+    for (int gi = 0; gi < GPT; ++gi) {
+      const int g = g0 + 16 * gi;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = g + 4 * kq + i;
+        const bool fok = f < N;
+        xa[gi][0][i] = (fok && row_ok) ? a1p[f] : 0.f;
+        xa[gi][1][i] = (fok && row_ok && two) ? a2p[f] : 0.f;
+        const float* wr = W0 + (long)(fok ? f : 0) * kt;
+        wb[gi][0][0][i] = (fok && c0_ok) ? wr[off1 + li] : 0.f;
+        wb[gi][0][1][i] = (fok && c1_ok) ? wr[off1 + 16 + li] : 0.f;
+        wb[gi][1][0][i] = (fok && c0_ok && two) ? wr[off2 + li] : 0.f;
+        wb[gi][1][1][i] = (fok && c1_ok && two) ? wr[off2 + 16 + li] : 0.f;
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int f = f0 + wf + 16 * u;
-      const bool ok = wcol_ok && f < N;
-      pw1[u] = ok ? W0[(long)f * kt + off1 + wc] : 0.f;
-      pw2[u] = (ok && R2) ? W0[(long)f * kt + off2 + wc] : 0.f;
-    }
-  };
-  const int r = t >> 5, c = t & 31;
-  float a0 = 0.f, a1 = 0.f;
-  // The kernel sits on the critical path between the pair reduction and the conv backward, beside the wgrad stream: what
-  // counts is the number of dependent memory round trips.  The operands of FOUR feature chunks are requested at once (one
-  // trip per 256 features instead of one per 64); the chunks then pass through LDS one after the other (same FMA order).
-  constexpr int NCH = 4;
-  float qr1[NCH][2], qr2[NCH][2], qw1[NCH][4], qw2[NCH][4];
-  for (int g0 = 0; g0 < N; g0 += NCH * DXQ_FC) {
+    for (int gi = 0; gi < GPT; ++gi) {
+      if (g0 + 16 * gi >= N) break;                                      // (wave-uniform)
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      fetch(g0 + ch * DXQ_FC);                                         // (columns beyond N read as zeros)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) { qr1[ch][u] = pr1[u]; qr2[ch][u] = pr2[u]; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { qw1[ch][u] = pw1[u]; qw2[ch][u] = pw2[u]; }
-    }
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      if (g0 + ch * DXQ_FC >= N) break;                                // uniform
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < 2; ++u) { rs[0][sr][sf + u] = qr1[ch][u]; rs[1][sr][sf + u] = qr2[ch][u]; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { ws[0][wf + 16 * u][wc] = qw1[ch][u]; ws[1][wf + 16 * u][wc] = qw2[ch][u]; }
-      __syncthreads();
-#pragma unroll 16
-      for (int f = 0; f < DXQ_FC; ++f) {
-        a0 = fmaf(rs[0][r][f], ws[0][f][c], a0);
-        a1 = fmaf(rs[1][r][f], ws[1][f][c], a1);
+      for (int i = 0; i < 4; ++i) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[gi][0][i], wb[gi][0][0][i], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[gi][0][i], wb[gi][0][1][i], acc[0][1], 0, 0, 0);
+        if (two) {
+          acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[gi][1][i], wb[gi][1][0][i], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[gi][1][i], wb[gi][1][1][i], acc[1][1], 0, 0, 0);
+        }
       }
     }
   }
-  if (c < ncols && r0 + r < nrows) {
-    if ((int)blockIdx.x < xblocks) {                                   // dx[b, j, c] at element strides (sdb, sdn, sdk); columns >= kout
-      const int row = r0 + r, b = row / n, j = row - b * n;           // (the coordinate tags: no gradient, model.py:216) are dropped
-      if (c < kout) dx[b * sdb + j * sdn + c * sdk] = a0 + a1;
-    } else {
-      out[(long)(r0 + r) * ld + c] = a0 + a1;
+  // D layout: register r of lane l = output (row 4 (l >> 4) + r, column l & 15) of the tile
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w][c][r][lane] = acc[0][c][r] + acc[1][c][r];
+  __syncthreads();
+  for (int o = t; o < 512; o += 256) {                                   // output o: row o / 32, column o % 32
+    const int ro = o >> 5, c = o & 31, ct = c >> 4, l = (c & 15) + 16 * (ro >> 2), r = ro & 3;
+    const float v = ((red[0][ct][r][l] + red[1][ct][r][l]) + red[2][ct][r][l]) + red[3][ct][r][l];
+    const int row = r0 + ro;
+    if (c < ncols && row < nrows) {
+      if ((int)blockIdx.x < xblocks) {                                   // dx[b, j, c] at element strides (sdb, sdn, sdk); columns >= kout
+        const int b = row / n, j = row - b * n;                          // (the coordinate tags: no gradient, model.py:216) are dropped
+        if (c < kout) dx[b * sdb + j * sdn + c * sdk] = v;
+      } else {
+        out[(long)row * ld + c] = v;
+      }
     }
   }
 }
@@ -1023,7 +1029,7 @@ extern "C" int rn_pair_dx_dq(const float* Rj, const float* Ri, const float* Rq, 
   RN_CHECK_ARG(Rj && Ri && W0 && dx && B > 0 && n > 0 && N > 0, "rn_pair_dx_dq: bad pointer/size");
   RN_CHECK_ARG(k > 0 && k <= 32 && (Q == 0 || (Rq && dq)), "rn_pair_dx_dq: k=%d (<= 32), Q=%d unsupported", k, Q);
   const int rows = B * n, xblocks = cdiv(rows, 16), qct = cdiv(Q, 32), qblocks = Q ? cdiv(B, 16) * qct : 0;
-  pair_dx_dq_kernel<<<xblocks + qblocks, 512, 0, (hipStream_t)stream>>>(Rj, Ri, Rq, W0, 2 * k + Q, dx, dq, rows, B, k, Q, N, xblocks,
+  pair_dx_dq_kernel<<<xblocks + qblocks, 256, 0, (hipStream_t)stream>>>(Rj, Ri, Rq, W0, 2 * k + Q, dx, dq, rows, B, k, Q, N, xblocks,
                                                                          qct ? qct : 1, n, sdb, sdn, sdk, kout);
   RN_LAUNCH_CHECK("rn_pair_dx_dq");
   return 0;
