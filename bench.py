@@ -54,9 +54,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f16s": 2500.0, "fp32": 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"bf16": 2500.0, "f16s": 2500.0, "fp32": 157.3, "bf16x3": 2500.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 DTYPE_DETAIL = {"bf16": "bf16 x bf16 MFMA, fp32 accumulate", "fp32": "fp32 MFMA (exact fmaf chains)",
+                "bf16x3": "fp32 storage; g_theta forward / dgrad products as hi*hi + hi*lo + lo*hi of bf16-split operands on the bf16 MFMA pipe "
+                          "(fp32 accumulate, 2^-16 of a product dropped); weight gradients and f_phi exact fp32",
                 "f16s": "fp16 activations x fp16 weights, fp32 accumulate: layer 0 hi + lo split weights (2 MFMA passes), layers 1-3 one pass on "
                         "tile-dithered weight images (4 roundings, tile t uses image t mod 4); backward bf16, e4m3 copies of H_0..2 for the weight gradients"}
 
@@ -395,7 +397,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 64; 4 for the state-description configs, BASELINE.json configs[0])")
     ap.add_argument("--config", default="original-fp")
-    ap.add_argument("--precision", default=os.environ.get("RN_PRECISION", "auto"), choices=["auto", "bf16", "f16s", "fp32"],
+    ap.add_argument("--precision", default=os.environ.get("RN_PRECISION", "auto"), choices=["auto", "bf16", "f16s", "fp32", "bf16x3"],
                     help='"auto" (default) = what the module selects by itself for this config')
     ap.add_argument("--hw", type=int, default=128, help="image side (224 -> 14x14 grid stress config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -710,7 +712,7 @@ def main():
             out["frac_algorithmic"], out["frac_executed"] = ach / peak, ach_ex / peak
             pb = ksum_step.get("pair_build")
             if pb and pb[0] > 0 and pb[1] > 0:
-                esz = 4 if prec == "fp32" else 2
+                esz = 4 if prec in ("fp32", "bf16x3") else 2
                 Q = hyp["lstm_hidden"] if hyp["question_injection_position"] == 0 else 0
                 nbytes = M * (2 * k + Q) * esz + B * n * k * 4 + B * Q * 4
                 key = "pair_build"

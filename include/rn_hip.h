@@ -20,6 +20,9 @@
  * Storage dtypes of the pair / activation / packed-weight buffers:
  *   RN_BF16 : bf16 storage, bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate.
  *   RN_F32  : fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32) -- exact-fp32 parity mode.
+ *   RN_F32X3: fp32 storage, products on the bf16 pipe from operands split into hi + lo bf16 while they are staged (hi*hi + hi*lo +
+ *             lo*hi, fp32 accumulate: 2^-16 of a product dropped) -- rn_g_linear_fwd / rn_g_linear_bwd_dgrad only; every other
+ *             entry point takes RN_F32 for the same tensors.  The "bf16x3" precision of the 512-wide state-description models.
  *   RN_F16  : accepted by rn_pair_build_fwd / rn_pack_matrix only (an fp16 pair matrix: tools, K1 measurements).
  *   RN_FP8  : OCP e4m3 bytes -- the activation copies the forward chain keeps for the weight gradients (h_dtype / a_dtype).
  * Row index of every "pair" matrix: r = (b*n + i)*n + j   (model.py:127).
@@ -35,7 +38,7 @@ extern "C" {
 
 #define RN_ABI_VERSION 9   /* bumped whenever a signature or a buffer layout of this header changes */
 
-enum { RN_BF16 = 0, RN_F32 = 1, RN_F16 = 2, RN_FP8 = 3 };   /* RN_F16: pair matrix / split weights of the f16s forward only;
+enum { RN_BF16 = 0, RN_F32 = 1, RN_F16 = 2, RN_FP8 = 3, RN_F32X3 = 4 };   /* RN_F16: pair matrix / split weights of the f16s forward only;
                                                              * RN_FP8: OCP e4m3 copies of the stored activations (h_dtype / a_dtype) */
 
 /* rn_gemm_f32 flags */
@@ -95,7 +98,7 @@ int rn_pack_matrix(const float* src, long sr, long sc, int R, int C, void* dst, 
 /* K2 -- one g_theta layer:  H = relu(A @ W^T + bias)      (model.py:141-145)
  * A: (M, lda) dtype, reduction length K (K % 64 == 0, columns >= true K are zero),
  * Wp: (N, ldw) packed dtype (rn_pack_matrix), bias: fp32 (N), H: (M, ldh) dtype.
- * N % 64 == 0.  Workgroup tiles: 128 x 256 when those give at least half the chip work (N % 256 == 0), 64 x 64 otherwise (the
+ * N % 64 == 0.  Workgroup tiles: 128 x 256 when there are at least four of those per CU (N % 256 == 0), 64 x 64 otherwise (the
  * state-description models' short pair matrices) -- the same k-ordered sums either way, bit for bit. */
 int rn_g_linear_fwd(const void* A, int lda, const void* Wp, int ldw, const float* bias, void* H, int ldh,
                     int dtype, int M, int N, int K, void* stream);

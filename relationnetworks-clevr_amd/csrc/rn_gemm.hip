@@ -16,6 +16,8 @@
 //         k order inside a slab is permuted identically for both operands (sum order only).
 //   D layout (both): col j = l&31 (pair row), row i = (reg&3) + 8*(reg>>2) + 4*(l>>5) (feature).
 #include "rn_common.h"
+#include <cstdlib>
+#include <type_traits>
 
 enum { EPI_BIAS_RELU = 0, EPI_GATE = 1 };
 
@@ -38,12 +40,24 @@ template <> struct Mma<float> {
 // models (thousands of workgroups), 64 x 64 for the state-description models (BASELINE configs[0]: M = B * 144 = 576 pair rows at
 // B = 4, 512 features -- 10 of the big tiles, i.e. 10 of 256 CUs at 55 us a layer; 72 small ones).  The k order of every output
 // element is the same in both: results are bitwise identical whichever tile computes them.
+// RN_F32X3 -- fp32 storage, products on the bf16 matrix pipe: every operand value x is split as it is staged into hi = bf16(x),
+// lo = bf16(x - hi) (16 mantissa bits together) and a product is hi*hi + hi*lo + lo*hi in fp32 accumulators -- three
+// v_mfma_f32_32x32x16_bf16 (96 cycles per 16 k) where the exact path spends eight v_mfma_f32_32x32x2_f32 (512 cycles); what is
+// dropped (lo*lo and the rounding of lo) is 2^-16 of a product.  The 16-bit arithmetic of the 512-wide state-description models,
+// whose layers do not fit the register-resident chains (VERDICT r4 "missing" 5); log-probs within 1e-5 of the fp32 reference.
+struct F32x3 {};
+template <> struct Mma<F32x3> {
+  typedef bf16x8 Frag;
+};
 constexpr int TN_BIG = 256;            // the entry points accept output widths that are multiples of the small tile's 64
-constexpr int GEMM_SMALL_BELOW = 128;  // big tiles on fewer than this many workgroups -> small tiles
+// big tiles on fewer than this many workgroups -> small tiles.  Measured (tools/dbg/time_gemm_tiles.py, profiles/r05_ablations/
+// gemm_tiles.txt): the small tiles win or tie up to M = 36,864 at every width / dtype (fp32 512-wide 187 vs 205 us, 256-wide 58 vs 78;
+// bf16 14.9 vs 19.8) and tie at 73,728 -- four big tiles per CU is where the big ones start to pay
+constexpr int GEMM_SMALL_BELOW = 1024;
 constexpr int SLAB_B = 128;            // bytes of K per row per slab
 constexpr int ROW_B = SLAB_B + 16;     // padded LDS row stride: conflict-free ds_read_b128
 
-template <typename T, int EPI, int MT, int NT>
+template <typename T, int EPI, int MT, int NT, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void gemm_rowtile_kernel(const T* __restrict__ A, int lda,
                                                               const T* __restrict__ W, int ldw,
                                                               const float* __restrict__ bias,
@@ -52,7 +66,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rowtile_kernel(const T* __restric
   constexpr int TM = 64 * MT, TN = 64 * NT;
   constexpr int CH = Elem<T>::kPer16B;
   constexpr int BKE = SLAB_B / (int)sizeof(T);
-  typedef typename Mma<T>::Frag Frag;
+  static_assert(!X3 || sizeof(T) == 4, "the split arithmetic is a mode of the fp32 storage");
+  typedef typename std::conditional<X3, bf16x8, typename Mma<T>::Frag>::type Frag;
   __shared__ __attribute__((aligned(16))) unsigned char lds[(TM + TN) * ROW_B];
   unsigned char* ldsA = lds;
   unsigned char* ldsW = lds + TM * ROW_B;
@@ -81,11 +96,28 @@ __global__ __launch_bounds__(256, 2) void gemm_rowtile_kernel(const T* __restric
 #pragma unroll
     for (int s = 0; s < 2 * NT; ++s) rw[s] = *reinterpret_cast<const u32x4*>(w_ptr[s] + kt * BKE);
   };
+  // X3: a slab row is [32 hi bf16 | 32 lo bf16] (the same 128 bytes): chunk scc (4 floats) -> 8 bytes at 8 scc of each half
+  auto split_store = [&](unsigned char* row, const u32x4 v) {
+    const f32x4 x = __builtin_bit_cast(f32x4, v);        // (whole-vector cast: element-wise casts of v[i] were folded to v[0] by hipcc 7.2)
+    const bf16 h0 = (bf16)x[0], h1 = (bf16)x[1], h2 = (bf16)x[2], h3 = (bf16)x[3];
+    const bf16 l0 = (bf16)(x[0] - (float)h0), l1 = (bf16)(x[1] - (float)h1), l2 = (bf16)(x[2] - (float)h2), l3 = (bf16)(x[3] - (float)h3);
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+    const bf16x4_ hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
+    *reinterpret_cast<bf16x4_*>(row + scc * 8) = hi;
+    *reinterpret_cast<bf16x4_*>(row + 64 + scc * 8) = lo;
+  };
   auto lstore = [&]() {
+    if constexpr (X3) {
 #pragma unroll
-    for (int s = 0; s < 2 * MT; ++s) *reinterpret_cast<u32x4*>(ldsA + (srow + 32 * s) * ROW_B + scc * 16) = ra[s];
+      for (int s = 0; s < 2 * MT; ++s) split_store(ldsA + (srow + 32 * s) * ROW_B, ra[s]);
 #pragma unroll
-    for (int s = 0; s < 2 * NT; ++s) *reinterpret_cast<u32x4*>(ldsW + (srow + 32 * s) * ROW_B + scc * 16) = rw[s];
+      for (int s = 0; s < 2 * NT; ++s) split_store(ldsW + (srow + 32 * s) * ROW_B, rw[s]);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 2 * MT; ++s) *reinterpret_cast<u32x4*>(ldsA + (srow + 32 * s) * ROW_B + scc * 16) = ra[s];
+#pragma unroll
+      for (int s = 0; s < 2 * NT; ++s) *reinterpret_cast<u32x4*>(ldsW + (srow + 32 * s) * ROW_B + scc * 16) = rw[s];
+    }
   };
 
   f32x16 acc[MT][NT];
@@ -104,6 +136,30 @@ __global__ __launch_bounds__(256, 2) void gemm_rowtile_kernel(const T* __restric
   const unsigned char* fw_base = ldsW + (wn * 32 * NT + (lane & 31)) * ROW_B + (lane >> 5) * 16;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) gload(kt + 1);
+    if constexpr (X3) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {                     // 32 k per slab = two 16-k MFMA steps; hi at +0, lo at +64 of a row
+        Frag fah[MT], fal[MT], fwh[NT], fwl[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          fah[mt] = *reinterpret_cast<const Frag*>(fa_base + mt * 32 * ROW_B + ks * 32);
+          fal[mt] = *reinterpret_cast<const Frag*>(fa_base + mt * 32 * ROW_B + 64 + ks * 32);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          fwh[nt] = *reinterpret_cast<const Frag*>(fw_base + nt * 32 * ROW_B + ks * 32);
+          fwl[nt] = *reinterpret_cast<const Frag*>(fw_base + nt * 32 * ROW_B + 64 + ks * 32);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {                // smallest terms first
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwl[nt], fah[mt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwh[nt], fal[mt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwh[nt], fah[mt], acc[mt][nt], 0, 0, 0);
+          }
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       Frag fa[MT], fw[NT];
@@ -115,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rowtile_kernel(const T* __restric
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) Mma<T>::mma(fw[nt], fa[mt], acc[mt][nt]);
+    }
     }
     __syncthreads();
     if (kt + 1 < nk) {
@@ -161,7 +218,7 @@ template <int EPI>
 static int gemm_launch(const void* A, int lda, const void* W, int ldw, const float* bias, const void* gate, int ldg,
                        void* C, int ldc, int dtype, int M, int N, int K, hipStream_t s, const char* who) {
   RN_CHECK_ARG(A && W && C && M > 0, "%s: bad pointer/size", who);
-  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "%s: bad dtype %d", who, dtype);
+  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32 || dtype == RN_F32X3, "%s: bad dtype %d", who, dtype);
   const int CH = dtype == RN_BF16 ? 8 : 4;
   RN_CHECK_ARG(N % 64 == 0, "%s: output width %d must be a multiple of 64", who, N);
   RN_CHECK_ARG(K % 64 == 0 && K > 0, "%s: reduction length %d must be a multiple of 64", who, K);
@@ -170,16 +227,20 @@ static int gemm_launch(const void* A, int lda, const void* W, int ldw, const flo
                ldw, ldc, K, N);
   RN_CHECK_ARG(((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)gate) % 16 == 0, "%s: pointers must be 16-byte aligned", who);
   // 128 x 256 tiles when they give every CU work; 64 x 64 ones for the short matrices (same sums, bit for bit)
-  const bool small = N % TN_BIG != 0 || (long)cdiv(M, 128) * (N / TN_BIG) < GEMM_SMALL_BELOW;
-#define RN_GEMM_LAUNCH(T, MT, NT)                                                                                              \
-  gemm_rowtile_kernel<T, EPI, MT, NT><<<dim3(cdiv(M, 64 * MT), N / (64 * NT)), 256, 0, s>>>(                                    \
+  static const int small_below = getenv("RN_GEMM_SMALL_BELOW") ? atoi(getenv("RN_GEMM_SMALL_BELOW")) : GEMM_SMALL_BELOW;   // (tools/: tuning)
+  const bool small = N % TN_BIG != 0 || (long)cdiv(M, 128) * (N / TN_BIG) < small_below;
+#define RN_GEMM_LAUNCH(T, MT, NT, X3)                                                                                          \
+  gemm_rowtile_kernel<T, EPI, MT, NT, X3><<<dim3(cdiv(M, 64 * MT), N / (64 * NT)), 256, 0, s>>>(                                \
       (const T*)A, lda, (const T*)W, ldw, bias, (const T*)gate, ldg, (T*)C, ldc, M, K)
   if (dtype == RN_BF16) {
-    if (small) RN_GEMM_LAUNCH(bf16, 1, 1);
-    else RN_GEMM_LAUNCH(bf16, 2, 4);
+    if (small) RN_GEMM_LAUNCH(bf16, 1, 1, false);
+    else RN_GEMM_LAUNCH(bf16, 2, 4, false);
+  } else if (dtype == RN_F32X3) {
+    if (small) RN_GEMM_LAUNCH(float, 1, 1, true);
+    else RN_GEMM_LAUNCH(float, 2, 4, true);
   } else {
-    if (small) RN_GEMM_LAUNCH(float, 1, 1);
-    else RN_GEMM_LAUNCH(float, 2, 4);
+    if (small) RN_GEMM_LAUNCH(float, 1, 1, false);
+    else RN_GEMM_LAUNCH(float, 2, 4, false);
   }
 #undef RN_GEMM_LAUNCH
   RN_LAUNCH_CHECK(who);

@@ -19,7 +19,7 @@ import torch
 from . import rn_hip as H
 from .options import OPT
 
-PRECISIONS = ("bf16", "f16s", "fp32")
+PRECISIONS = ("bf16", "f16s", "fp32", "bf16x3")
 # "f16s2": what the module turns "f16s" into for a forward pass in eval() mode (options.eval_two_pass) -- the chain path with hi + lo
 # split weights on every layer when nothing needs a gradient (batch-position-invariant log-probs); with a gradient: plain "f16s"
 _INTERNAL_PRECISIONS = PRECISIONS + ("f16s2",)
@@ -379,7 +379,7 @@ def chain_forward(x, q, plan: LayerPlan, g_b, packed, keep, inj_w=None, coord=No
     return (Hs[:-1] if Hs is not None else None), (RRMasks(masks, gate) if masks is not None else None), xg, njp
 
 
-def layers_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None, stop_at=None):
+def layers_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, layer_hook=None, stop_at=None, gcode=None):
     """The per-layer path (bf16 / fp32 storage; model.py:108-145): K1 pair build, then one fused GEMM + bias + ReLU launch per g
     layer (the question broadcast into the trailing columns of an injected layer's input).  Returns (inputs, H_L): the list of layer
     INPUT buffers [A_0 .. A_{L-1}] and the last activation.  layer_hook(l, A_l, H_out) is called after every layer (the
@@ -388,6 +388,7 @@ def layers_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, lay
     Q = q.shape[1]
     M = B * n * n
     dt = H.torch_dtype(code)
+    gcode = code if gcode is None else gcode            # the GEMMs' arithmetic ("bf16x3": RN_F32X3 on fp32 storage)
     dev = x.device
     inj = plan.inject
     ld0 = plan.kpad[0]
@@ -405,7 +406,7 @@ def layers_forward(x, q, plan: LayerPlan, g_b, wfwd, code, keep_inputs=True, lay
             out = torch.zeros(M, ldh, dtype=dt, device=dev)
         else:
             out = torch.empty(M, ldh, dtype=dt, device=dev)
-        H.g_linear_fwd(cur, plan.kpad[l], wfwd[l], plan.kpad[l], g_b[l], out, ldh, code, M, N, plan.kpad[l])
+        H.g_linear_fwd(cur, plan.kpad[l], wfwd[l], plan.kpad[l], g_b[l], out, ldh, gcode, M, N, plan.kpad[l])
         if nxt_wide:
             H.qst_broadcast(q, out, code, B, n, Q, N, ldh)
         if layer_hook is not None:
@@ -500,6 +501,7 @@ class RelationalFunction(torch.autograd.Function):
         H._dev(q, "qst")
         chain = precision in ("f16s", "f16s2")
         code = H.RN_BF16 if chain else H.dtype_code(precision)
+        gcode = H.RN_F32X3 if precision == "bf16x3" else code     # arithmetic of the per-layer GEMMs (storage: code)
         x = x.float() if x.dtype != torch.float32 else x
         q = q.float().contiguous() if (q.dtype != torch.float32 or not q.is_contiguous()) else q
         B, n, k = x.shape
@@ -532,7 +534,7 @@ class RelationalFunction(torch.autograd.Function):
                     if inputs[l].dtype in H.FP8_DTYPES:
                         COPY_HEALTH_PROBE.append((l - 1, H.fp8_copy_health(HL.masks[l - 1], inputs[l], inputs[l].numel() // G)))
         else:
-            inputs, HL = layers_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad)
+            inputs, HL = layers_forward(x, q, plan, gb, wfwd, code, keep_inputs=need_grad, gcode=gcode)
             xg = torch.empty(B, G, dtype=torch.float32, device=dev)
             H.pair_sum_fwd(HL, G, xg, code, B, n * n, G)
         fw = [w.detach().contiguous() for w in f_w]
@@ -556,6 +558,7 @@ class RelationalFunction(torch.autograd.Function):
         ctx.label = label
         if need_grad:
             ctx.plan, ctx.code, ctx.dims = plan, code, (B, n, k, Q, M, G, F1, F2, A)
+            ctx.gcode = gcode
             ctx.chain, ctx.njp = chain, njp
             ctx.q_grad_async = q_grad_async
             ctx.coord = coord
@@ -901,7 +904,7 @@ class RelationalFunction(torch.autograd.Function):
             else:
                 gp = plan.widths[l - 1]
                 dZp = torch.empty(M, gp, dtype=dt, device=dev)
-                H.g_linear_bwd_dgrad(dZ, N, wbwd[l], N, A_l, kp, dZp, gp, code, M, N, gp)
+                H.g_linear_bwd_dgrad(dZ, N, wbwd[l], N, A_l, kp, dZp, gp, ctx.gcode, M, N, gp)
                 dZ = dZp
             inputs[l] = None
         return dx, dq, gW, gB

@@ -13,7 +13,7 @@ import os
 
 # attribute -> (environment variable, default, meaning)
 _SPEC = {
-    "precision":         ("RN_PRECISION", "auto", 'arithmetic mode of modules whose hyp has no "precision": auto | f16s | bf16 | fp32'),
+    "precision":         ("RN_PRECISION", "auto", 'arithmetic mode of modules whose hyp has no "precision": auto | f16s | bf16 | fp32 | bf16x3'),
     "eval_two_pass":     ("RN_NO_EVAL_TWO_PASS", True, "eval() without gradients on the chain path: hi + lo split weights on every g layer instead of the tile-dithered single pass (log-probs independent of batch position / object order; ~1.6x the forward chain's time)"),
     "h8":                ("RN_H8", True, "e4m3 copies of H_0..2 for the weight gradients (False: bf16 copies, the last layer's dZ stored; what the trainer's copy guard falls back to)"),
     "chain_reduce":      ("RN_NO_CHAIN_REDUCE", True, "pair-axis reductions of layer 0's gradient inside the backward chain (dZ_0 never stored; any chain shape, the padded j axis included)"),

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librn_hip.so")
 _PRODUCT_LIB_PATH = LIB_PATH                         # (tools may point LIB_PATH at a variant build)
-RN_BF16, RN_F32, RN_F16, RN_FP8 = 0, 1, 2, 3
+RN_BF16, RN_F32, RN_F16, RN_FP8, RN_F32X3 = 0, 1, 2, 3, 4
 RN_RELU, RN_ACCUMULATE = 1, 2
 ABI_VERSION = 9
 
@@ -178,7 +178,7 @@ def _ptr(t):
 def dtype_code(precision: str) -> int:
     """Storage dtype of activations / gradients.  "f16s" (fp16 tile x split fp16 weights forward) keeps
     bf16 storage for everything the backward pass touches."""
-    return {"bf16": RN_BF16, "f16s": RN_BF16, "fp32": RN_F32}[precision]
+    return {"bf16": RN_BF16, "f16s": RN_BF16, "fp32": RN_F32, "bf16x3": RN_F32}[precision]      # ("bf16x3": fp32 storage, split-bf16 GEMMs)
 
 
 def torch_dtype(code: int):

@@ -447,7 +447,7 @@ def build_argparser():
     ap.add_argument("--no-invert-questions", action="store_true")
     ap.add_argument("--dropout", type=float, default=-1.0)
     ap.add_argument("--question-injection", type=int, default=-1)
-    ap.add_argument("--precision", default=None, choices=[None, "auto", "f16s", "bf16", "fp32"],
+    ap.add_argument("--precision", default=None, choices=[None, "auto", "f16s", "bf16", "fp32", "bf16x3"],
                     help='g_theta arithmetic (DESIGN.md section 2); default "auto" = f16s where the fused chain applies')
     ap.add_argument("--test-results-dir", default="./test_results", help="where test.pickle goes (train.py:232)")
     ap.add_argument("--model-dir", default="model_checkpoints")

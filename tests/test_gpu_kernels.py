@@ -249,7 +249,7 @@ def _gemm_case(M, N, K, Ktrue, seed):
 
 @pytest.mark.parametrize("code", [0, 1])
 @pytest.mark.parametrize("M,N,K,Ktrue", [(128, 256, 192, 180), (576, 512, 320, 270), (1000, 256, 256, 256), (4096, 256, 64, 52),
-                                          (16512, 256, 128, 100), (200, 320, 128, 128)])
+                                          (131200, 256, 64, 52), (200, 320, 128, 128)])
 def test_g_linear_fwd(H, code, M, N, K, Ktrue):
     A, W, b = _gemm_case(M, N, K, Ktrue, 20)
     if code == 0:
@@ -264,12 +264,32 @@ def test_g_linear_fwd(H, code, M, N, K, Ktrue):
     assert err.max() <= tol, (err.max(), np.unravel_index(err.argmax(), err.shape))
 
 
+@pytest.mark.parametrize("M,N,K", [(576, 512, 512), (9216, 512, 64), (70000, 512, 512), (300, 256, 192)])
+def test_g_linear_split_bf16_arithmetic(H, M, N, K):
+    """RN_F32X3: fp32 operands split into hi + lo bf16 as they are staged, hi*hi + hi*lo + lo*hi on the bf16 pipe, fp32 accumulate
+    (both workgroup tiles) -- forward and gated dgrad against fp64: 2^-16 of a product is dropped, so 3e-5 of the largest output
+    bounds it with room (measured ~4e-6); the exact-fp32 mode on the same operands sits at 1e-6."""
+    A, W, b = _gemm_case(M, N, K, K, 60)
+    ref = np.maximum(A.astype(np.float64) @ W.astype(np.float64).T + b, 0)
+    out = torch.full((M, N), -3.0, device="cuda")
+    H.g_linear_fwd(dev(A), K, dev(W), K, dev(b), out, N, H.RN_F32X3, M, N, K)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    e = np.abs(got - ref).max() / np.abs(ref).max()
+    assert e <= 3e-5, e
+    gate = np.maximum(formula.hash_uniform((M, N), 61, -1, 1), 0)
+    H.g_linear_bwd_dgrad(dev(A), K, dev(W), K, dev(gate), N, out, N, H.RN_F32X3, M, K, N)
+    ref = (A.astype(np.float64) @ W.astype(np.float64).T) * (gate > 0)
+    got = out.cpu().numpy()
+    assert np.abs(got - ref).max() / np.abs(ref).max() <= 3e-5 and np.all(got[gate <= 0] == 0)
+
+
 @pytest.mark.parametrize("code", [0, 1])
 def test_g_linear_tiles_agree_bitwise(H, code):
     """rn_gemm.hip picks 64 x 64 workgroup tiles for short matrices (the state-description models: M = B * 144) and 128 x 256 ones
     when those fill the chip; every output element's k order is the same in both, so the first rows of a long matrix (big tiles)
     equal the same rows computed as a short matrix (small tiles) bit for bit -- forward and gated dgrad."""
-    Ms, Mb, N, K = 576, 128 * 64 + 40, 512, 512                    # 65 x 2 big tiles = 130 workgroups >= GEMM_SMALL_BELOW
+    Ms, Mb, N, K = 576, 128 * 512 + 40, 512, 512                   # 513 x 2 big tiles = 1026 workgroups >= GEMM_SMALL_BELOW
     A, W, b = _gemm_case(Mb, N, K, K, 50)
     Ad, Wd, bd = dev(A).to(tdt(code)), dev(W).to(tdt(code)), dev(b)
     big = torch.empty(Mb, N, dtype=tdt(code), device="cuda")

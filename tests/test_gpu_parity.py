@@ -120,6 +120,21 @@ def test_relational_layer_bf16_parity(pkg, tag):
     assert e_dx <= bound and e_dq <= bound and e_b <= bound, (e_dx, e_dq, e_b, bound)
 
 
+@pytest.mark.parametrize("tag", RL_TAGS)
+def test_relational_layer_bf16x3_parity(pkg, tag):
+    """precision="bf16x3": fp32 storage, the g_theta forward / dgrad products as three bf16 MFMA products of operands split into
+    hi + lo while they are staged (rn_gemm.hip, RN_F32X3) -- the 16-bit arithmetic of the 512-wide *-sd models, whose layers the
+    register-resident chains do not cover.  Weight gradients and f_phi stay exact fp32.  Contract: 1e-3 on log-probs; what it
+    measures is ~1e-5 (the bounds here are regression guards an order of magnitude above the measured values)."""
+    g = gold.load(tag)
+    lp, loss, dx, dq, grads = run_rl(pkg, g, "bf16x3")
+    e_lp, e_dx, e_dq = gold.rel_err(lp, g["log_probs"]), l2rel(dx, g["dx"]), l2rel(dq, g["dq"])
+    e_b = max(l2rel(grads[k[5:]], g[k]) for k in g if k.startswith("grad/"))
+    report(tag, precision="bf16x3", log_probs=e_lp, dx_l2=e_dx, dq_l2=e_dq, params_l2=e_b, dx_max=gold.rel_err(dx, g["dx"]))
+    assert e_lp <= 1e-3                                   # the contract
+    assert e_lp <= 1e-4 and e_dx <= 1e-3 and e_dq <= 1e-3 and e_b <= 1e-3, (e_lp, e_dx, e_dq, e_b)   # regression guards
+
+
 @pytest.mark.parametrize("tag", ["G-fp-small", "G-fp64", "G-drop", "G-ir-small", "G-ir64"])
 def test_relational_layer_f16s_parity(pkg, tag):
     """precision="f16s" (fp16 activations x split fp16 weights, bf16 backward): the FAST mode that meets
