@@ -46,6 +46,11 @@ int rn_probe_mfma_stream(float* out, int workgroups, int waves_per_simd, int ite
  * previous mode.  tests/ compare the two paths bit for bit with it; the product never calls it. */
 int rn_debug_f_phi_wide(int mode);
 
+/* Moves the tile switch of the per-layer GEMMs (rn_g_linear_fwd / _bwd_dgrad): 64 x 64 workgroup tiles where the 128 x 256 ones
+ * would be fewer than n workgroups (n < 0: the built-in value).  Returns the previous value.  tools/dbg/time_gemm_tiles.py sweeps
+ * with it; the results do not depend on the tile (bit for bit). */
+int rn_debug_gemm_small_below(int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,6 @@
 //         k order inside a slab is permuted identically for both operands (sum order only).
 //   D layout (both): col j = l&31 (pair row), row i = (reg&3) + 8*(reg>>2) + 4*(l>>5) (feature).
 #include "rn_common.h"
-#include <cstdlib>
 #include <type_traits>
 
 enum { EPI_BIAS_RELU = 0, EPI_GATE = 1 };
@@ -54,6 +53,7 @@ constexpr int TN_BIG = 256;            // the entry points accept output widths 
 // gemm_tiles.txt): the small tiles win or tie up to M = 36,864 at every width / dtype (fp32 512-wide 187 vs 205 us, 256-wide 58 vs 78;
 // bf16 14.9 vs 19.8) and tie at 73,728 -- four big tiles per CU is where the big ones start to pay
 constexpr int GEMM_SMALL_BELOW = 1024;
+static int g_gemm_small_below = GEMM_SMALL_BELOW;     // (rn_debug_gemm_small_below: the sweep tool moves the switch)
 constexpr int SLAB_B = 128;            // bytes of K per row per slab
 constexpr int ROW_B = SLAB_B + 16;     // padded LDS row stride: conflict-free ds_read_b128
 
@@ -227,8 +227,7 @@ static int gemm_launch(const void* A, int lda, const void* W, int ldw, const flo
                ldw, ldc, K, N);
   RN_CHECK_ARG(((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)gate) % 16 == 0, "%s: pointers must be 16-byte aligned", who);
   // 128 x 256 tiles when they give every CU work; 64 x 64 ones for the short matrices (same sums, bit for bit)
-  static const int small_below = getenv("RN_GEMM_SMALL_BELOW") ? atoi(getenv("RN_GEMM_SMALL_BELOW")) : GEMM_SMALL_BELOW;   // (tools/: tuning)
-  const bool small = N % TN_BIG != 0 || (long)cdiv(M, 128) * (N / TN_BIG) < small_below;
+  const bool small = N % TN_BIG != 0 || (long)cdiv(M, 128) * (N / TN_BIG) < g_gemm_small_below;
 #define RN_GEMM_LAUNCH(T, MT, NT, X3)                                                                                          \
   gemm_rowtile_kernel<T, EPI, MT, NT, X3><<<dim3(cdiv(M, 64 * MT), N / (64 * NT)), 256, 0, s>>>(                                \
       (const T*)A, lda, (const T*)W, ldw, bias, (const T*)gate, ldg, (T*)C, ldc, M, K)
@@ -245,6 +244,12 @@ static int gemm_launch(const void* A, int lda, const void* W, int ldw, const flo
 #undef RN_GEMM_LAUNCH
   RN_LAUNCH_CHECK(who);
   return 0;
+}
+
+extern "C" int rn_debug_gemm_small_below(int n) {
+  const int was = g_gemm_small_below;
+  g_gemm_small_below = n < 0 ? GEMM_SMALL_BELOW : n;
+  return was;
 }
 
 extern "C" int rn_g_linear_fwd(const void* A, int lda, const void* Wp, int ldw, const float* bias, void* H, int ldh,

@@ -96,6 +96,7 @@ DEBUG_SIGNATURES = {
     "rn_probe_mfma_stream": (_I, [_P, _I, _I, _I, _I, _P]),
     "rn_probe_red_schedule": (_I, [_I, _I, _I, _I, _I, _P, _I]),
     "rn_debug_f_phi_wide": (_I, [_I]),
+    "rn_debug_gemm_small_below": (_I, [_I]),
 }
 
 
