@@ -52,8 +52,9 @@ constexpr int TN_BIG = 256;            // the entry points accept output widths 
 // big tiles on fewer than this many workgroups -> small tiles.  Measured (tools/dbg/time_gemm_tiles.py, profiles/r05_ablations/
 // gemm_tiles.txt): the small tiles win or tie up to M = 36,864 at every width / dtype (fp32 512-wide 187 vs 205 us, 256-wide 58 vs 78;
 // bf16 14.9 vs 19.8) and tie at 73,728 -- four big tiles per CU is where the big ones start to pay
-constexpr int GEMM_SMALL_BELOW = 1024;
-static int g_gemm_small_below = GEMM_SMALL_BELOW;     // (rn_debug_gemm_small_below: the sweep tool moves the switch)
+constexpr int GEMM_SMALL_BELOW = 1024;     // exact fp32 (the matrix pipe is the limit: the small tiles' extra fragment reads are free)
+constexpr int GEMM_SMALL_BELOW_16 = 512;   // bf16 / bf16x3: the big tiles pay from two per CU (bf16x3 512-wide, M = 36,864: 91 vs 103 us)
+static int g_gemm_small_below = -1;        // (rn_debug_gemm_small_below: the sweep tool moves the switch; < 0: the values above)
 constexpr int SLAB_B = 128;            // bytes of K per row per slab
 constexpr int ROW_B = SLAB_B + 16;     // padded LDS row stride: conflict-free ds_read_b128
 
@@ -227,7 +228,7 @@ static int gemm_launch(const void* A, int lda, const void* W, int ldw, const flo
                ldw, ldc, K, N);
   RN_CHECK_ARG(((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)gate) % 16 == 0, "%s: pointers must be 16-byte aligned", who);
   // 128 x 256 tiles when they give every CU work; 64 x 64 ones for the short matrices (same sums, bit for bit)
-  const bool small = N % TN_BIG != 0 || (long)cdiv(M, 128) * (N / TN_BIG) < g_gemm_small_below;
+  const bool small = N % TN_BIG != 0 || (long)cdiv(M, 128) * (N / TN_BIG) < (g_gemm_small_below >= 0 ? g_gemm_small_below : (dtype == RN_F32 ? GEMM_SMALL_BELOW : GEMM_SMALL_BELOW_16));
 #define RN_GEMM_LAUNCH(T, MT, NT, X3)                                                                                          \
   gemm_rowtile_kernel<T, EPI, MT, NT, X3><<<dim3(cdiv(M, 64 * MT), N / (64 * NT)), 256, 0, s>>>(                                \
       (const T*)A, lda, (const T*)W, ldw, bias, (const T*)gate, ldg, (T*)C, ldc, M, K)
@@ -248,7 +249,7 @@ static int gemm_launch(const void* A, int lda, const void* W, int ldw, const flo
 
 extern "C" int rn_debug_gemm_small_below(int n) {
   const int was = g_gemm_small_below;
-  g_gemm_small_below = n < 0 ? GEMM_SMALL_BELOW : n;
+  g_gemm_small_below = n < 0 ? -1 : n;
   return was;
 }
 
