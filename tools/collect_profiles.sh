@@ -16,6 +16,11 @@ python tools/step_timeline.py > $OUT/step_timeline.txt 2>&1
 ls -la $OUT
 # 2. the other BASELINE configs: original-sd B=4 (configs[0]), ir-fp (configs[3]) and the 14x14 / B=32 stress shape (configs[4])
 python bench.py --config original-sd --no-other-modes > $OUT/bench_original_sd_b4.json 2>> $OUT/bench.err
+# ... and the same model at a training-sized batch in the exact-fp32 mode and in the split-bf16 one (precision "bf16x3")
+python bench.py --config original-sd --batch 64 --precision fp32 --no-cpu-baseline --no-other-modes > $OUT/bench_original_sd_b64_fp32.json 2>> $OUT/bench.err
+python bench.py --config original-sd --batch 64 --precision bf16x3 --no-cpu-baseline --no-other-modes > $OUT/bench_original_sd_b64_bf16x3.json 2>> $OUT/bench.err
+python tools/step_timeline.py --config original-sd --batch 4 > $OUT/step_timeline_original_sd_b4.txt 2>&1
+python tools/step_timeline.py --config ir-fp > $OUT/step_timeline_ir_fp.txt 2>&1
 python bench.py --config ir-fp --no-cpu-baseline > $OUT/bench_ir_fp.json 2>> $OUT/bench.err
 python bench.py --hw 224 --batch 32 --steps 40 --no-cpu-baseline > $OUT/bench_stress_b32_n196.json 2>> $OUT/bench.err
 python tools/time_small.py > $OUT/small_kernels_alone.txt 2>/dev/null
