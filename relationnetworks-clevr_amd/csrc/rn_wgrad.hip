@@ -15,7 +15,10 @@ template <typename T> struct WG;
 template <> struct WG<bf16> { static constexpr int ROWS = 64; };
 template <> struct WG<float> { static constexpr int ROWS = 32; };
 
-template <typename T, int NKT, bool USE_TR>
+// X3 (T = float only; dtype RN_F32X3, the "bf16x3" precision): fp32 operands split into hi + lo bf16 as they are staged -- two bf16
+// tiles per operand in LDS, read with the bf16 path's transposing reads -- and every 16-row step is three bf16 MFMAs
+// (lo x hi, hi x lo, hi x hi) instead of eight fp32 ones; 2^-16 of a product is dropped (rn_gemm.hip has the forward's twin).
+template <typename T, int NKT, bool USE_TR, bool X3 = false>
 __global__ __launch_bounds__(512) void wgrad_kernel(const T* __restrict__ dZ, int lddz, const T* __restrict__ A,
                                                     int lda, float* __restrict__ part, float* __restrict__ part_db,
                                                     int M, int N, int Kpad, int rows_per_split) {
@@ -23,14 +26,17 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const T* __restrict__ dZ, in
   constexpr int ROWS = WG<T>::ROWS;
   // LDS row stride (bytes), both tiles.  bf16: +64 B so that the 4 rows x 64 B a 32-lane group of
   // ds_read_b64_tr_b16 touches land on 4 distinct 16-bank quarters (stride = 16 dwords mod 64); fp32: +16 B.
-  constexpr int RSZ = 256 * (int)sizeof(T) + (sizeof(T) == 2 ? 64 : 16);
+  static_assert(!X3 || (sizeof(T) == 4 && USE_TR), "the split arithmetic is a mode of the fp32 storage");
+  constexpr int RSZ = X3 ? 256 * 2 + 64 : 256 * (int)sizeof(T) + (sizeof(T) == 2 ? 64 : 16);
   constexpr int CPZ = 256 / CH;                            // 16-byte chunks per dZ tile row
   constexpr int CPA = NKT * 32 / CH;                       // chunks per A tile row
   constexpr int NZ = ROWS * CPZ / 512;                     // dZ chunks per thread per step (4)
   constexpr int NA = (ROWS * CPA + 511) / 512;             // A chunks per thread per step (<= 4)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * ROWS * RSZ];   // 66-68 KB static
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(X3 ? 4 : 2) * ROWS * RSZ];   // 66-74 KB static
   unsigned char* ldsZ = lds;
   unsigned char* ldsA = lds + ROWS * RSZ;
+  unsigned char* ldsZl = lds + 2 * ROWS * RSZ;             // X3: the lo tiles (ldsZ / ldsA hold the hi ones)
+  unsigned char* ldsAl = lds + 3 * ROWS * RSZ;
 
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int n0 = blockIdx.x * 256;
@@ -70,12 +76,29 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const T* __restrict__ dZ, in
       ra[s] = (aok[s] && r < r_end) ? *reinterpret_cast<const u32x4*>(A + r * lda + k0 + acc_[s] * CH) : zero4;
     }
   };
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+  auto split_store = [&](unsigned char* hi_p, unsigned char* lo_p, const u32x4 v) {   // 4 floats -> 4 hi + 4 lo bf16 (8 bytes each)
+    const f32x4 x = __builtin_bit_cast(f32x4, v);
+    const bf16 h0 = (bf16)x[0], h1 = (bf16)x[1], h2 = (bf16)x[2], h3 = (bf16)x[3];
+    const bf16x4_ hi = {h0, h1, h2, h3};
+    const bf16x4_ lo = {(bf16)(x[0] - (float)h0), (bf16)(x[1] - (float)h1), (bf16)(x[2] - (float)h2), (bf16)(x[3] - (float)h3)};
+    *reinterpret_cast<bf16x4_*>(hi_p) = hi;
+    *reinterpret_cast<bf16x4_*>(lo_p) = lo;
+  };
   auto lstore = [&]() {
+    if constexpr (X3) {
 #pragma unroll
-    for (int s = 0; s < NZ; ++s) *reinterpret_cast<u32x4*>(ldsZ + zrow[s] * RSZ + zcc[s] * 16) = rz[s];
+      for (int s = 0; s < NZ; ++s) split_store(ldsZ + zrow[s] * RSZ + zcc[s] * 8, ldsZl + zrow[s] * RSZ + zcc[s] * 8, rz[s]);
 #pragma unroll
-    for (int s = 0; s < NA; ++s)
-      if (t + 512 * s < ROWS * CPA) *reinterpret_cast<u32x4*>(ldsA + arow[s] * RSZ + acc_[s] * 16) = ra[s];
+      for (int s = 0; s < NA; ++s)
+        if (t + 512 * s < ROWS * CPA) split_store(ldsA + arow[s] * RSZ + acc_[s] * 8, ldsAl + arow[s] * RSZ + acc_[s] * 8, ra[s]);
+    } else {
+#pragma unroll
+      for (int s = 0; s < NZ; ++s) *reinterpret_cast<u32x4*>(ldsZ + zrow[s] * RSZ + zcc[s] * 16) = rz[s];
+#pragma unroll
+      for (int s = 0; s < NA; ++s)
+        if (t + 512 * s < ROWS * CPA) *reinterpret_cast<u32x4*>(ldsA + arow[s] * RSZ + acc_[s] * 16) = ra[s];
+    }
   };
 
   f32x16 acc[NKT];
@@ -93,7 +116,28 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const T* __restrict__ dZ, in
   for (long r0 = r_begin; r0 < r_end; r0 += ROWS) {
     const bool more = (r0 + ROWS) < r_end;
     if (more) gload(r0 + ROWS);
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (X3) {
+#pragma unroll
+      for (int kk0 = 0; kk0 < ROWS; kk0 += 16) {
+        const int roff = (kk0 + rb * 8 + (i16 >> 2)) * RSZ;                    // (the bf16 path's transposing reads, on the hi and the lo tiles)
+        const int coff = (cb * 16 + 4 * (i16 & 3)) * 2;
+        typedef __attribute__((address_space(3))) s16x4* lptr;
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        auto frag = [&](const unsigned char* p) {
+          u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
+          u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 4 * RSZ));
+          return u.v;
+        };
+        const bf16x8 fzh = frag(ldsZ + roff + (w * 32) * 2 + coff), fzl = frag(ldsZl + roff + (w * 32) * 2 + coff);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          const bf16x8 fah = frag(ldsA + roff + (kt * 32) * 2 + coff), fal = frag(ldsAl + roff + (kt * 32) * 2 + coff);
+          acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fzl, fah, acc[kt], 0, 0, 0);
+          acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fzh, fal, acc[kt], 0, 0, 0);
+          acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fzh, fah, acc[kt], 0, 0, 0);
+        }
+      }
+    } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int kk0 = 0; kk0 < ROWS; kk0 += 16) {
         bf16x8 fz, fa[NKT];
@@ -142,8 +186,14 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const T* __restrict__ dZ, in
       }
     }
     if (do_db) {
+      if constexpr (X3) {
 #pragma unroll 8
-      for (int r = 0; r < ROWS; ++r) dbsum += Elem<T>::to_f32(*reinterpret_cast<const T*>(ldsZ + r * RSZ + t * sizeof(T)));
+        for (int r = 0; r < ROWS; ++r)
+          dbsum += (float)*reinterpret_cast<const bf16*>(ldsZ + r * RSZ + t * 2) + (float)*reinterpret_cast<const bf16*>(ldsZl + r * RSZ + t * 2);
+      } else {
+#pragma unroll 8
+        for (int r = 0; r < ROWS; ++r) dbsum += Elem<T>::to_f32(*reinterpret_cast<const T*>(ldsZ + r * RSZ + t * sizeof(T)));
+      }
     }
     __syncthreads();
     if (more) {
@@ -231,7 +281,13 @@ size_t rnws_wgrad(int M, int N, int K) {
 
 template <typename T, int NKT>
 static void wgrad_dispatch(dim3 grid, hipStream_t s, const T* dZ, int lddz, const T* A, int lda,
-                           float* part, float* part_db, int M, int N, int K, int rps) {
+                           float* part, float* part_db, int M, int N, int K, int rps, bool x3 = false) {
+  if constexpr (sizeof(T) == 4) {
+    if (x3) {
+      wgrad_kernel<T, NKT, true, true><<<grid, 512, 0, s>>>(dZ, lddz, A, lda, part, part_db, M, N, K, rps);
+      return;
+    }
+  }
   if constexpr (sizeof(T) == 2) {
     wgrad_kernel<T, NKT, true><<<grid, 512, 0, s>>>(dZ, lddz, A, lda, part, part_db, M, N, K, rps);
   } else {
@@ -241,10 +297,10 @@ static void wgrad_dispatch(dim3 grid, hipStream_t s, const T* dZ, int lddz, cons
 
 template <typename T>
 static int wgrad_launch_t(const T* dZ, int lddz, const T* A, int lda, float* part, float* part_db, int M, int N, int K,
-                          int nkt, int gy, int Z, int rps, hipStream_t s) {
+                          int nkt, int gy, int Z, int rps, hipStream_t s, bool x3 = false) {
   dim3 grid(N / 256, gy, Z);
   switch (nkt) {
-#define RN_CASE(n) case n: wgrad_dispatch<T, n>(grid, s, dZ, lddz, A, lda, part, part_db, M, N, K, rps); break;
+#define RN_CASE(n) case n: wgrad_dispatch<T, n>(grid, s, dZ, lddz, A, lda, part, part_db, M, N, K, rps, x3); break;
     RN_CASE(1) RN_CASE(2) RN_CASE(3) RN_CASE(4) RN_CASE(5) RN_CASE(6) RN_CASE(7) RN_CASE(8)
 #undef RN_CASE
     default: rn_set_error("rn_g_linear_bwd_wgrad: bad k-tile count %d", nkt); return -1;
@@ -255,7 +311,7 @@ static int wgrad_launch_t(const T* dZ, int lddz, const T* A, int lda, float* par
 extern "C" int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, int lda, float* dW, float* db, void* ws,
                                      int dtype, int M, int N, int K, int Ktrue, void* stream) {
   RN_CHECK_ARG(dZ && A && dW && ws && M > 0, "rn_g_linear_bwd_wgrad: bad pointer/size");
-  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32, "rn_g_linear_bwd_wgrad: bad dtype %d", dtype);
+  RN_CHECK_ARG(dtype == RN_BF16 || dtype == RN_F32 || dtype == RN_F32X3, "rn_g_linear_bwd_wgrad: bad dtype %d", dtype);
   const int CH = dtype == RN_BF16 ? 8 : 4;
   RN_CHECK_ARG(N % 256 == 0 && K % 32 == 0 && Ktrue > 0 && Ktrue <= K, "rn_g_linear_bwd_wgrad: N=%d K=%d Ktrue=%d unsupported",
                N, K, Ktrue);
@@ -270,7 +326,7 @@ extern "C" int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, in
   if (dtype == RN_BF16)
     rc = wgrad_launch_t<bf16>((const bf16*)dZ, lddz, (const bf16*)A, lda, part, part_db, M, N, K, nkt, gy, Z, rps, s);
   else
-    rc = wgrad_launch_t<float>((const float*)dZ, lddz, (const float*)A, lda, part, part_db, M, N, K, nkt, gy, Z, rps, s);
+    rc = wgrad_launch_t<float>((const float*)dZ, lddz, (const float*)A, lda, part, part_db, M, N, K, nkt, gy, Z, rps, s, dtype == RN_F32X3);
   if (rc) return rc;
   RN_LAUNCH_CHECK("rn_g_linear_bwd_wgrad");
   const int nbw = cdiv((long)N * K / 4, 16), nbb = cdiv(N / 4, 16);

@@ -878,7 +878,7 @@ class RelationalFunction(torch.autograd.Function):
             if not (l == 0 and alg0):
                 gW[l] = grad_out(ctx.param_refs[l], (N, kt))
                 gB[l] = grad_out(ctx.param_refs[L + l], (N,))
-                H.g_linear_bwd_wgrad(dZ, N, A_l, kp, gW[l], gB[l], code, M, N, kp, kt)
+                H.g_linear_bwd_wgrad(dZ, N, A_l, kp, gW[l], gB[l], ctx.gcode, M, N, kp, kt)
             wl = g_w[l] if g_w[l].is_contiguous() else g_w[l].contiguous()
             if l == plan.inject:
                 Rq = torch.empty(B, N, **f32)

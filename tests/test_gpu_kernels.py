@@ -919,6 +919,25 @@ def test_g_linear_bwd_wgrad(H, code, M, N, K, Ktrue):
     assert torch.equal(dW, dW2) and torch.equal(db, db2)
 
 
+@pytest.mark.parametrize("M,N,K,Ktrue", [(576, 512, 512, 512), (9216, 512, 32, 14), (5000, 256, 192, 180)])
+def test_g_linear_bwd_wgrad_split_bf16_arithmetic(H, M, N, K, Ktrue):
+    """RN_F32X3 weight gradient: the fp32 operands split into hi + lo bf16 tiles in LDS, three bf16 MFMAs per 16 rows -- dW and db
+    against fp64 (2^-16 of a product dropped: 3e-5 of the largest entry with room), and bitwise reproducible."""
+    dZ = formula.hash_uniform((M, N), 70, -1, 1)
+    A = np.zeros((M, K), np.float32); A[:, :Ktrue] = np.maximum(formula.hash_uniform((M, Ktrue), 71, -1, 1), 0)
+    dW = torch.full((N, Ktrue), float("nan"), device="cuda"); db = torch.full((N,), float("nan"), device="cuda")
+    H.g_linear_bwd_wgrad(dev(dZ), N, dev(A), K, dW, db, H.RN_F32X3, M, N, K, Ktrue)
+    torch.cuda.synchronize()
+    refW = dZ.astype(np.float64).T @ A[:, :Ktrue].astype(np.float64)
+    refb = dZ.sum(0, dtype=np.float64)
+    eW = np.abs(dW.cpu().numpy() - refW).max() / np.abs(refW).max()
+    eb = np.abs(db.cpu().numpy() - refb).max() / np.abs(refb).max()
+    assert eW <= 3e-5 and eb <= 3e-5, (eW, eb)
+    dW2 = torch.empty_like(dW); db2 = torch.empty_like(db)
+    H.g_linear_bwd_wgrad(dev(dZ), N, dev(A), K, dW2, db2, H.RN_F32X3, M, N, K, Ktrue)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+
+
 @pytest.mark.parametrize("B,n,k,Q,N", [(64, 64, 26, 128, 256), (3, 12, 7, 256, 512), (5, 9, 32, 40, 100)])
 def test_pair_dx_dq(H, B, n, k, Q, N):
     """dx = Rj W0[:, :k] + Ri W0[:, k:2k], dq = Rq W0[:, 2k:] in one launch, against float64."""
