@@ -57,8 +57,8 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"bf16": 2500.0, "f16s": 2500.0, "fp32": 157.3, "bf16x3": 2500.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 DTYPE_DETAIL = {"bf16": "bf16 x bf16 MFMA, fp32 accumulate", "fp32": "fp32 MFMA (exact fmaf chains)",
-                "bf16x3": "fp32 storage; g_theta forward / dgrad products as hi*hi + hi*lo + lo*hi of bf16-split operands on the bf16 MFMA pipe "
-                          "(fp32 accumulate, 2^-16 of a product dropped); weight gradients and f_phi exact fp32",
+                "bf16x3": "fp32 storage; g_theta forward / dgrad / weight-gradient products as hi*hi + hi*lo + lo*hi of bf16-split operands on the bf16 "
+                          "MFMA pipe (fp32 accumulate, 2^-16 of a product dropped); f_phi exact fp32",
                 "f16s": "fp16 activations x fp16 weights, fp32 accumulate: layer 0 hi + lo split weights (2 MFMA passes), layers 1-3 one pass on "
                         "tile-dithered weight images (4 roundings, tile t uses image t mod 4); backward bf16, e4m3 copies of H_0..2 for the weight gradients"}
 

@@ -21,7 +21,7 @@
  *   RN_BF16 : bf16 storage, bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate.
  *   RN_F32  : fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32) -- exact-fp32 parity mode.
  *   RN_F32X3: fp32 storage, products on the bf16 pipe from operands split into hi + lo bf16 while they are staged (hi*hi + hi*lo +
- *             lo*hi, fp32 accumulate: 2^-16 of a product dropped) -- rn_g_linear_fwd / rn_g_linear_bwd_dgrad only; every other
+ *             lo*hi, fp32 accumulate: 2^-16 of a product dropped) -- rn_g_linear_fwd / rn_g_linear_bwd_dgrad / rn_g_linear_bwd_wgrad; every other
  *             entry point takes RN_F32 for the same tensors.  The "bf16x3" precision of the 512-wide state-description models.
  *   RN_F16  : accepted by rn_pair_build_fwd / rn_pack_matrix only (an fp16 pair matrix: tools, K1 measurements).
  *   RN_FP8  : OCP e4m3 bytes -- the activation copies the forward chain keeps for the weight gradients (h_dtype / a_dtype).

@@ -124,7 +124,7 @@ def test_relational_layer_bf16_parity(pkg, tag):
 def test_relational_layer_bf16x3_parity(pkg, tag):
     """precision="bf16x3": fp32 storage, the g_theta forward / dgrad products as three bf16 MFMA products of operands split into
     hi + lo while they are staged (rn_gemm.hip, RN_F32X3) -- the 16-bit arithmetic of the 512-wide *-sd models, whose layers the
-    register-resident chains do not cover.  Weight gradients and f_phi stay exact fp32.  Contract: 1e-3 on log-probs; what it
+    register-resident chains do not cover (the weight gradients run the same arithmetic, rn_wgrad.hip; f_phi stays exact fp32).  Contract: 1e-3 on log-probs; what it
     measures is ~1e-5 (the bounds here are regression guards an order of magnitude above the measured values)."""
     g = gold.load(tag)
     lp, loss, dx, dq, grads = run_rl(pkg, g, "bf16x3")
