@@ -221,12 +221,13 @@ class FlatGradBucket:
             if g is None or g.untyped_storage().data_ptr() != self.flat.untyped_storage().data_ptr():
                 raise RuntimeError("a .grad left the flat bucket (zero_grad(set_to_none=True) was called?)")
 
-    def all_reduce_mean(self, group=None, scale=True):
+    def all_reduce_mean(self, group=None, scale=True, even_alone=False):
         """sum over ranks, then scale by 1/world -> gradient of the global-batch mean loss.  scale=False leaves the
-        1/world factor to the caller (the fused clip + Adam kernel applies it); returns that factor."""
+        1/world factor to the caller (the fused clip + Adam kernel applies it); returns that factor.  even_alone: launch the
+        collective on a one-rank communicator too (DataParallelTrainer(single_rank_exchange=True))."""
         if dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(group)
-            if world > 1:
+            if world > 1 or even_alone:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
                 if scale:
                     self.flat.mul_(1.0 / world)
@@ -360,7 +361,7 @@ class DataParallelTrainer:
 
     def __init__(self, model, optimizer, clip_norm: float | None = 50.0, group=None, use_graph: bool = False,
                  copy_guard_every: int = 512, copy_guard_max_flushed: float = 0.05, copy_guard_max_clamped: float = 1e-3,
-                 graph_allreduce: bool | None = None, timeout_s: float | None = None):
+                 graph_allreduce: bool | None = None, timeout_s: float | None = None, single_rank_exchange: bool = False):
         self.model, self.opt, self.clip_norm, self.group = model, optimizer, clip_norm, group
         # guard of the e4m3 activation copies (check_activation_copies): before the first capture / at step 1 and then every
         # `copy_guard_every` steps; 0 = never
@@ -371,7 +372,12 @@ class DataParallelTrainer:
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.world = world
         self.rank = dist.get_rank(group) if world > 1 else 0
-        self.timeout_s = float(OPT.dp_timeout if timeout_s is None else timeout_s) if world > 1 else 0.0
+        # single_rank_exchange (diagnostic): run the N > 1 machinery -- self-check, capture of the all-reduce into the step graph,
+        # first-replay signature check, or the eager exchange -- on a ONE-rank communicator.  The sum over one rank is the
+        # identity, so the step must equal the plain one-rank step bit for bit; what it exercises is the collective's launch,
+        # capture and replay (on RCCL: the only part of the N > 1 step a one-GPU box can execute)
+        self.exchange = world > 1 or (bool(single_rank_exchange) and dist.is_available() and dist.is_initialized())
+        self.timeout_s = float(OPT.dp_timeout if timeout_s is None else timeout_s) if self.exchange else 0.0
         self.watchdog = Watchdog(self.rank)
         dev = next(model.parameters()).device
         self.ctl = ControlPlane(group, self.timeout_s or 300.0, dev)
@@ -386,8 +392,8 @@ class DataParallelTrainer:
         # The whole step is ONE graph whenever it can be (class docstring).  graph_allreduce: None = options.graph_allreduce and a
         # stream-ordered backend; True / False force it (tests drive the agreement logic over gloo with True)
         if graph_allreduce is None:
-            graph_allreduce = OPT.graph_allreduce and world > 1 and dist.get_backend(group) == "nccl"
-        coll_in_graph = world == 1 or bool(graph_allreduce)
+            graph_allreduce = OPT.graph_allreduce and self.exchange and dist.get_backend(group) == "nccl"
+        coll_in_graph = not self.exchange or bool(graph_allreduce)
         self._opt_in_graph = (use_graph and self._fused_opt is not None and coll_in_graph and OPT.graph_adam)
         self.exchange_fallback = None                      # why the exchange is NOT in the graph although it was asked for
         self.exchange_checks = {}                          # what the start-up checks measured (bench.py prints them)
@@ -532,7 +538,7 @@ class DataParallelTrainer:
                 self._fwd_bwd(*self._static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if self._opt_in_graph and self.world > 1:
+        if self._opt_in_graph and self.exchange:
             with self.watchdog.guard("start-up self-check + capture of the in-graph gradient all-reduce", self.timeout_s):
                 why = self._exchange_self_check()
                 graph = None
@@ -558,7 +564,7 @@ class DataParallelTrainer:
             self.exchange_fallback = why
             self._opt_in_graph = False
             torch.cuda.synchronize()
-        if self.world == 1:
+        if not self.exchange:
             self._graph = self._capture_graph(self._opt_in_graph)
             return
         # N > 1: the last rung of the ladder.  A capture that was INVALIDATED (not merely refused) leaves torch's capture machinery
@@ -603,18 +609,18 @@ class DataParallelTrainer:
         graph = self._capturing = torch.cuda.CUDAGraph()
         # N > 1: every capture on a stream of its own (torch.cuda.graph otherwise re-uses ONE class-level capture stream: a capture
         # that failed on it would fail every later one)
-        self._capture_stream = cs = torch.cuda.Stream() if self.world > 1 else None
+        self._capture_stream = cs = torch.cuda.Stream() if self.exchange else None
         with torch.cuda.graph(graph, stream=cs):
             self._loss = self._fwd_bwd(*self._static)
             if with_opt:
-                if self.world > 1:
+                if self.exchange:
                     self._graph_collective(self.bucket.flat)
                 self._fused_opt.step_dev()              # (the 1/world factor is the hyper block's grad_scale)
         return graph
 
     def exchange_mode(self):
         """Where the gradient exchange of a step runs: 'none' (one rank), 'in-graph', 'eager'."""
-        if self.world == 1:
+        if not self.exchange:
             return "none"
         return "in-graph" if (self.use_graph and self._opt_in_graph) else "eager"
 
@@ -672,7 +678,7 @@ class DataParallelTrainer:
             loss = self._loss
             if self._opt_in_graph:
                 self._fused_opt.after_step_dev()
-                if self.world > 1 and not self._first_graph_step_checked:
+                if self.exchange and not self._first_graph_step_checked:
                     self._check_first_graph_step()
                 return loss
         else:
@@ -682,7 +688,7 @@ class DataParallelTrainer:
             if tm is not None:
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                 ev[0].record()
-            gs = self.bucket.all_reduce_mean(self.group, scale=False)
+            gs = self.bucket.all_reduce_mean(self.group, scale=False, even_alone=self.exchange)
             if tm is not None:
                 ev[1].record()
             self._fused_opt.step(self.clip_norm, gs)      # (1/world) + clip + Adam: two launches on the flat gradient
@@ -690,7 +696,7 @@ class DataParallelTrainer:
                 ev[2].record()
                 tm.append(ev)
         else:
-            self.bucket.all_reduce_mean(self.group)
+            self.bucket.all_reduce_mean(self.group, even_alone=self.exchange)
             if self.clip_norm:
                 self.bucket.clip_grad_norm_(self.clip_norm)
             self.opt.step()

