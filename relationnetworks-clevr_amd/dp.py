@@ -501,7 +501,7 @@ class DataParallelTrainer:
             buf = src.clone()
             g = torch.cuda.CUDAGraph()
             self._capture_stream = cs = torch.cuda.Stream()       # (a stream of this capture's own: a failure must not poison torch's shared one)
-            with torch.cuda.graph(g, stream=cs):
+            with torch.cuda.graph(g, stream=cs, capture_error_mode=self._capture_mode()):
                 self._graph_collective(buf)
             for _ in range(2):
                 buf.copy_(src)
@@ -605,12 +605,21 @@ class DataParallelTrainer:
         except Exception:
             pass
 
+    def _capture_mode(self):
+        """hipStreamCaptureMode of the trainer's captures.  One rank: torch's default ("global": a forbidden call on ANY thread
+        invalidates the capture).  With a process group: "thread_local" -- ProcessGroupNCCL's watchdog thread polls the events of
+        earlier collectives (the parameter broadcast, the self-check's eager all-reduce) with hipEventQuery whenever it wakes up,
+        and under "global" such a query from another thread, landing inside the capture window, invalidates a capture that did
+        nothing wrong.  Kernels the autograd threads launch on the capturing stream are captured in either mode (capture is a
+        property of the stream, the mode only decides whose forbidden calls count)."""
+        return "thread_local" if self.exchange else "global"
+
     def _capture_graph(self, with_opt):
         graph = self._capturing = torch.cuda.CUDAGraph()
         # N > 1: every capture on a stream of its own (torch.cuda.graph otherwise re-uses ONE class-level capture stream: a capture
         # that failed on it would fail every later one)
         self._capture_stream = cs = torch.cuda.Stream() if self.exchange else None
-        with torch.cuda.graph(graph, stream=cs):
+        with torch.cuda.graph(graph, stream=cs, capture_error_mode=self._capture_mode()):
             self._loss = self._fwd_bwd(*self._static)
             if with_opt:
                 if self.exchange:
