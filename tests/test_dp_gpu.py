@@ -299,6 +299,10 @@ def _one_rank_rccl_worker(rank, port, cfg, steps, out_path, graph_allreduce):
     res = {}
     for name, kw in (("exchange", {"single_rank_exchange": True, "graph_allreduce": graph_allreduce, "timeout_s": 240}), ("plain", {})):
         model = _model(cfg, seed=3)
+        # BatchNorm in TRAINING mode here (the product step: the fused conv + BN kernels, bitwise reproducible from replay to
+        # replay -- tools/dbg/grad_repro.py).  _model()'s conv.eval() exists for the two-shard comparisons; it routes the conv
+        # weight gradients through a path whose fp32 sums vary in their last bit from run to run (1e-7 relative)
+        model.train()
         tr = dp.DataParallelTrainer(model, _adam(model), clip_norm=CLIP, use_graph=True, **kw)
         losses = [float(tr.step(x, q, y).detach()) for _ in range(steps)]
         tr.bucket.check_attached()
