@@ -289,6 +289,40 @@ def test_two_ranks_over_rccl_equal_one_rank_on_the_whole_batch(tmp_path, cfg):
     _check_two_ranks_against_one(tmp_path, cfg, "nccl")
 
 
+@pytest.mark.parametrize("cfg,B", [("original-fp", 64), ("ir-fp", 16), ("original-sd", 8)])
+def test_captured_step_gradient_is_bitwise_reproducible(cfg, B):
+    """The product step (BatchNorm in training mode, dropout on, the default arithmetic) replayed with lr = 0: the parameters stay
+    put, so every replay must leave the SAME flat gradient bucket and the same loss, bit for bit -- no atomics, no launch-order
+    dependence between the step's streams, no buffer shared across streams by accident (a race would show up as a replay that
+    differs).  (The dropout mask is drawn per replay: dropout = 0 here so that the replays are the same function.)"""
+    import contextlib, io, json
+    import relationnetworks_clevr_amd as pkg
+    from relationnetworks_clevr_amd import dp
+    from bench import make_batch
+    hyp = json.load(open(os.path.join(os.path.dirname(pkg.rn_hip.__file__), "config.json")))["hyperparams"][cfg]
+    torch.manual_seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = pkg.RN(A, dict(hyp, dropout=0.0))
+    model.cuda().train()
+    img, qst, lab = make_batch(B, torch.device("cuda"), 128, state_desc=bool(hyp["state_description"]))
+    opt = torch.optim.Adam(model.parameters(), lr=0.0, weight_decay=0.0)
+    tr = dp.DataParallelTrainer(model, opt, clip_norm=50.0, use_graph=True, copy_guard_every=0)
+    ref_flat = ref_loss = None
+    names = [n_ for n_, p_ in model.named_parameters() if p_.requires_grad]
+    for r in range(40):
+        loss = tr.step(img, qst, lab)
+        torch.cuda.synchronize()
+        if ref_flat is None:
+            ref_flat, ref_loss = tr.bucket.flat.clone(), float(loss.detach())
+            assert float(ref_flat.abs().sum()) > 0
+            continue
+        if not torch.equal(tr.bucket.flat, ref_flat):
+            bad = [n_ for n_, o, p_ in zip(names, tr.bucket.offsets, tr.bucket.params)
+                   if not torch.equal(tr.bucket.flat[o:o + p_.numel()], ref_flat[o:o + p_.numel()])]
+            raise AssertionError("replay %d: gradients differ from replay 0 in %r" % (r, bad))
+        assert float(loss.detach()) == ref_loss
+
+
 def _one_rank_rccl_worker(rank, port, cfg, steps, out_path, graph_allreduce):
     from relationnetworks_clevr_amd import dp
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
