@@ -23,6 +23,8 @@ python tools/step_timeline.py --config original-sd --batch 4 > $OUT/step_timelin
 python tools/step_timeline.py --config ir-fp > $OUT/step_timeline_ir_fp.txt 2>&1
 python bench.py --config ir-fp --no-cpu-baseline > $OUT/bench_ir_fp.json 2>> $OUT/bench.err
 python bench.py --hw 224 --batch 32 --steps 40 --no-cpu-baseline > $OUT/bench_stress_b32_n196.json 2>> $OUT/bench.err
+# the reference's DEFAULT batch size (train.py:370): one rank, B = 640
+python bench.py --batch 640 --steps 10 --warmup 3 --no-cpu-baseline --no-other-modes --no-parity > $OUT/bench_original_fp_b640.json 2>> $OUT/bench.err
 python tools/time_small.py > $OUT/small_kernels_alone.txt 2>/dev/null
 python tools/time_wgrad.py > $OUT/wgrad_alone.txt 2>/dev/null
 python tools/time_fwd_f16s.py > $OUT/fwd_chain_alone.txt 2>/dev/null

@@ -11,7 +11,7 @@ dst = lambda n: os.path.join(ROOT, "profiles", "%s_%s" % (tag, n))
 shutil.copy(os.path.join(src, "kernel_stats.csv"), dst("kernel_stats_rocprofv3.csv"))
 shutil.copy(os.path.join(src, "bench_line.json"), dst("bench_line.json"))
 shutil.copy(os.path.join(src, "step_timeline.txt"), dst("step_timeline.txt"))
-for extra in ("bench_original_sd_b64_fp32.json", "bench_original_sd_b64_bf16x3.json", "step_timeline_original_sd_b4.txt", "step_timeline_ir_fp.txt", "bench_ir_fp.json", "bench_stress_b32_n196.json", "bench_original_sd_b4.json", "small_kernels_alone.txt", "k1_alone.txt", "wgrad_alone.txt",
+for extra in ("bench_original_sd_b64_fp32.json", "bench_original_sd_b64_bf16x3.json", "step_timeline_original_sd_b4.txt", "step_timeline_ir_fp.txt", "bench_ir_fp.json", "bench_stress_b32_n196.json", "bench_original_fp_b640.json", "bench_original_sd_b4.json", "small_kernels_alone.txt", "k1_alone.txt", "wgrad_alone.txt",
               "fwd_chain_alone.txt", "bwd_chain_alone.txt", "bwd_chain_alone_b32_n196.txt", "extract_alone.txt", "pmc_extract_write.txt", "convergence.txt", "convergence_pairs.txt", "convergence_pairs_ir_fp.txt",
               "clocks.txt", "graph_gaps.txt", "parity_report.jsonl", "kernel_resources.txt"):
     if os.path.exists(os.path.join(src, extra)):
