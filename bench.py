@@ -382,8 +382,8 @@ def timed_steps(step, steps, warmup, sync):
 
 def max_over_ranks(dt, world, device):
     """The job's time is the slowest rank's."""
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -427,8 +427,18 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # RN_BENCH_ONE_RANK_EXCHANGE=1 (diagnostic, N = 1 only): a ONE-rank communicator and DataParallelTrainer(single_rank_exchange=True)
+    # -- every line of the N > 1 path below (roll call, barriers, the in-graph exchange with its self-check, `comm`) runs over RCCL on
+    # a one-GPU box; the sum over one rank is the identity, so `value` must equal the plain line's
+    one_rank = world == 1 and os.environ.get("RN_BENCH_ONE_RANK_EXCHANGE", "0") == "1"
+    multi = world > 1 or one_rank
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if one_rank:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend, device_id=dev)
         else:
@@ -458,13 +468,13 @@ def main():
     use_graph = not args.no_graph
     # copy_guard_every=0: the e4m3 copy guard (an eager forward + a host sync every 512 steps) runs ONCE, in front of the capture, and
     # then stays out of the timed / sustained windows; train.py keeps the periodic guard
-    trainer = dp.DataParallelTrainer(model, opt, clip_norm=50.0, use_graph=use_graph, copy_guard_every=0)
+    trainer = dp.DataParallelTrainer(model, opt, clip_norm=50.0, use_graph=use_graph, copy_guard_every=0, single_rank_exchange=one_rank)
     img, qst, lab = make_batch(B, dev, args.hw, state_desc=state_desc)
     if use_graph:
         trainer.check_activation_copies(img, qst, lab)
-    wd, wd_s = trainer.watchdog, (float(pkg.options.OPT.dp_timeout) if world > 1 else 0.0)
+    wd, wd_s = trainer.watchdog, (float(pkg.options.OPT.dp_timeout) if multi else 0.0)
     ranks_seen = None
-    if world > 1:
+    if multi:
         with wd.guard("bench: roll call of the ranks", wd_s):
             ranks_seen = trainer.ctl.ranks_seen()
         if ranks_seen != list(range(world)):
@@ -472,7 +482,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -519,7 +529,7 @@ def main():
         sustained = {"value": world * B * n_sus / dt_s, "unit": "questions/s", "ms_per_step": 1e3 * dt_s / n_sus, "steps": n_sus,
                      "seconds": dt_s, "clocks": clocks.summary() if clocks else None}
     comm = None
-    if world > 1:
+    if multi:
         # attribution (outside the timed region): K more steps with event brackets around the gradient all-reduce and the fused
         # 1/world + clip + Adam -- the only parts of a step that exist because of the other ranks
         if getattr(trainer, "_opt_in_graph", False):
@@ -607,7 +617,7 @@ def main():
                                                    if prec in ("bf16", "f16s") and pkg.options.OPT.h8 else "as the mode's storage type"),
                        "options_non_default": pkg.options.OPT.non_default(),
                        "launch": ("eager" if not use_graph else
-                                  "one hipGraph replay per step: fwd + bwd + all-reduce + clip + Adam" if (getattr(trainer, "_opt_in_graph", False) and world > 1) else
+                                  "one hipGraph replay per step: fwd + bwd + all-reduce + clip + Adam" if (getattr(trainer, "_opt_in_graph", False) and multi) else
                                   "one hipGraph replay per step: fwd + bwd + clip + Adam" if getattr(trainer, "_opt_in_graph", False) else
                                   "hipGraph replay of fwd+bwd, eager all-reduce/clip/Adam")},
             "loss": float(loss.detach()),
@@ -749,7 +759,7 @@ def main():
                 # BASELINE.md section 3's second CPU figure: configs[0], the reference's own CPU-runnable case (~10 ms per step)
                 out["cpu_baseline_sd4"] = cpu_baseline("original-sd", 4, 128, warm=5, steps=50)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

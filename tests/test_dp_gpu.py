@@ -409,3 +409,28 @@ def test_bench_two_ranks_on_one_gpu():
     c = d["comm"]
     assert c["ranks_seen"] == [0, 1] and c["exchange_mode"] == "eager" and c["exchange_fallback"] is None and c["backend"] == "gloo"
     assert c["watchdog_s"] > 0
+
+
+def test_bench_n_gt_1_path_over_one_rank_rccl():
+    """bench.py's N > 1 code path -- process group over `nccl`, roll call, barriers, the trainer's in-graph exchange with its
+    self-check, `comm` -- executed over RCCL on ONE device (RN_BENCH_ONE_RANK_EXCHANGE=1: a one-rank communicator; the sum over one
+    rank is the identity).  What the driver's multi-GPU run adds to this is more ranks, nothing else in the script."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, RN_BENCH_ONE_RANK_EXCHANGE="1", MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--sustain", "1", "--no-cpu-baseline",
+           "--no-other-modes", "--no-parity"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 64 and np.isfinite(d["loss"])
+    assert "all-reduce" in d["config"]["launch"]
+    c = d["comm"]
+    assert c["backend"] == "nccl" and c["ranks_seen"] == [0] and c["exchange_mode"] == "in-graph" and c["exchange_fallback"] is None
+    assert c["exchange_checks"] == {"self_check": "passed", "capture": "ok", "first_step_signatures_equal": True}
+    assert c["allreduce_bytes"] == 4 * 484580 and c["allreduce_us_per_step"] > 0 and c["watchdog_s"] > 0
+    assert d["sustained"]["steps"] >= 5 and d["sustained"]["value"] > 0
