@@ -13,6 +13,7 @@ H.load()
 B, n, G, L = int(os.environ.get("B", 640)), int(os.environ.get("N_OBJ", 64)), 256, 4
 njp = (n + 31) // 32 * 32
 chunks = [int(a) for a in sys.argv[1:]] or [B, 128, 64, 32]
+ONLY = os.environ.get("ONLY", "")               # "chain" / "wgrad": that launch alone
 g = torch.Generator(device="cuda").manual_seed(1)
 M = B * n * njp
 A8 = [(torch.rand(M, G, device="cuda", generator=g) * 2).to(torch.float8_e4m3fn) for _ in range(3)]      # H_0..2 images of the whole batch
@@ -34,9 +35,11 @@ def build(C):
     def run():
         for c in range(B // C):
             sl = slice(c * Mc, (c + 1) * Mc)
-            H.g_chain_bwd_rr_red(dxg[c * C:(c + 1) * C], masks, Wt, red, Mc, n, G, rj, ri, tpu, njp=njp, whole=whole)
-            H.g_wgrad_blocked([(dZ[1], A8[0][sl], dW[0], db[0]), (dZ[0], A8[1][sl], dW[1], db[1]), (None, A8[2][sl], dW[2], db[2])], Mc,
-                              dxg=dxg[c * C:(c + 1) * C], rows_per_question=n * njp)
+            if ONLY != "wgrad":
+                H.g_chain_bwd_rr_red(dxg[c * C:(c + 1) * C], masks, Wt, red, Mc, n, G, rj, ri, tpu, njp=njp, whole=whole)
+            if ONLY != "chain":
+                H.g_wgrad_blocked([(dZ[1], A8[0][sl], dW[0], db[0]), (dZ[0], A8[1][sl], dW[1], db[1]), (None, A8[2][sl], dW[2], db[2])], Mc,
+                                  dxg=dxg[c * C:(c + 1) * C], rows_per_question=n * njp)
     return run
 
 
@@ -60,5 +63,5 @@ for rep in range(2):
         if B % C:
             continue
         us = timeit(build(C))
-        print("B %d n %d, chunks of %4d questions (%4d MB of dZ per chunk): backward chain + weight gradient %8.1f us  = %6.1f us per 64 questions  (%.3f of 2.5 PF)"
+        print(ONLY or "both", "B %d n %d, chunks of %4d questions (%4d MB of dZ per chunk): backward chain + weight gradient %8.1f us  = %6.1f us per 64 questions  (%.3f of 2.5 PF)"
               % (B, n, C, 2 * C * n * njp * G * 2 // 1000000, us, us * 64 / B, flops / (us * 1e-6) / 2.5e15), flush=True)
