@@ -38,7 +38,9 @@ that is "f16s", the mode that meets the 1e-3 log-prob bar).  What the line carri
   comm             (N > 1) ranks_seen, where the gradient exchange runs (`exchange_mode`: in-graph | eager), why it fell back
                    (`exchange_fallback`), what the start-up checks measured, the all-reduce's stand-alone cost.
 
-  python bench.py --config original-sd      # BASELINE.json configs[0] on the GPU: B=4 state descriptions (per-layer fp32 kernels)"""
+  python bench.py --config original-sd      # BASELINE.json configs[0] on the GPU: B=4 state descriptions (per-layer fp32 kernels)
+  RN_BENCH_ONE_RANK_EXCHANGE=1 python bench.py    # diagnostic: the N > 1 code path (process group over RCCL, in-graph exchange, `comm`)
+                                                  # on a ONE-rank communicator -- what a one-GPU box can execute of it"""
 import argparse
 import contextlib
 import glob
