@@ -24,8 +24,11 @@ that is "f16s", the mode that meets the 1e-3 log-prob bar).  What the line carri
                    off; `step`: g_theta's flops over the whole step's time.
   sustained        the same graph replayed for --sustain seconds (default 3) right after the K timed steps: rate, ms/step and the
                    rocm-smi clocks / power sampled meanwhile -- K = 20 steps are 15 ms, too short for the chip's sustained clocks.
-  roofline.sustained_mfma / frac_of_sustained: the bare-MFMA stream's rate on this box (rn_probe_mfma_stream) and the g_theta
-                   kernels against it (`frac`: against the nominal 2.5 PFLOP/s).
+  roofline.frac_alone / ms_alone: the dominant weight-gradient launch timed on its own (nothing beside it: what a kernel trace of
+                   the eager step sees); `frac` / `ms_per_launch`: its bracket inside the step, beside the conv stack's backward.
+  roofline.diagnostics.mfma_stream_probe: a bare-MFMA stream's rate on this box on patterned and on all-zero operands
+                   (rn_probe_mfma_stream_ops) -- a probe of the power-limited clock, NOT a denominator: every `frac` divides by
+                   the nominal 2.5 PFLOP/s; `of_probe_not_peak` values are labelled as what they are.
   convergence      (--convergence STEPS) fp32 and the benched mode trained on a learnable synthetic task with the same seeds:
                    loss curves, held-out accuracy, and the e4m3 copy guard's log.
   pair_build_k1    rn_pair_build_fwd launched on its own at the benched shape: 94.83 MB / duration vs 8 TB/s
@@ -255,21 +258,41 @@ def time_launch(fn, n=20):
 
 
 def sustained_mfma(H, dev):
-    """The matrix pipe's sustained rate on THIS device, now: a bare stream of v_mfma_f32_32x32x16 on every SIMD of every CU
-    (rn_probe_mfma_stream: two waves per SIMD like the chains, nothing but MFMAs, launched alone for ~0.4 ms per bracket).  The chip
-    clocks to its power budget, so the nominal 2.5 PFLOP/s (2.4 GHz x 1024 flop / cycle / SIMD) is not what an MFMA-bound kernel can
-    reach: the chains' `frac_of_sustained` divides by THIS figure (f16 for the forward chain, bf16 for the backward chain and the
-    weight gradient); `frac` stays the fraction of the nominal peak."""
+    """DIAGNOSTIC, not a denominator: what a bare stream of v_mfma_f32_32x32x16 on every SIMD of every CU runs at on THIS device, now
+    (rn_probe_mfma_stream_ops: two waves per SIMD like the chains, nothing but MFMAs, launched alone for ~0.4 ms per bracket) -- on
+    patterned operands (what a real kernel multiplies) and on all-zero ones.  The chip clocks to its power budget
+    (MI355X_MICROARCH.md "DVFS give-back": zero-filled inputs run +19 % TF/s on the same binary; its 2495 TF for this instruction
+    is such a figure): the two rows bracket what "MFMA-bound" can mean here.  Every `frac` of this file divides by the NOMINAL dense
+    peak (2.5 PFLOP/s); `of_probe` values are labelled as what they are."""
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
     out = torch.empty(cus * 512, device=dev)
     res = {}
     for name, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
         iters = 600
-        flops = H.probe_mfma_stream(out, cus, 2, iters, dt)
-        ms = time_launch(lambda: H.probe_mfma_stream(out, cus, 2, iters, dt), n=7)
-        res[name] = {"tflops": flops / (ms * 1e-3) / 1e12, "ns_per_mfma_slot": ms * 1e6 / (2 * iters * 16), "us_per_launch": 1e3 * ms}
-    res["what"] = "bare v_mfma_f32_32x32x16 stream, 2 waves per SIMD on every CU, launched alone (a 32-cycle slot at 2.4 GHz = 13.3 ns)"
+        for zero in (False, True):
+            flops = H.probe_mfma_stream(out, cus, 2, iters, dt, zero_operands=zero)
+            ms = time_launch(lambda: H.probe_mfma_stream(out, cus, 2, iters, dt, zero_operands=zero), n=7)
+            res[name + ("_zero_operands" if zero else "")] = {"tflops": flops / (ms * 1e-3) / 1e12, "ns_per_mfma_slot": ms * 1e6 / (2 * iters * 16), "us_per_launch": 1e3 * ms}
+    res["what"] = ("bare v_mfma_f32_32x32x16 stream, 2 waves per SIMD on every CU, launched alone (a 32-cycle slot at 2.4 GHz = 13.3 ns); "
+                   "patterned operands vs all-zero operands: a probe of the power-limited clock, NOT the roofline's peak")
     return res
+
+
+def wgrad_alone(H, B, n, dev):
+    """The weight-gradient launch of the chain path on its own at the benched shape (two stored gradients on e4m3 activation images
+    + the gate job; random operands): HIP-event time of ONE launch (main kernel + its partial-sum reduction) with nothing beside
+    it -- what a kernel trace of the eager step sees, where the in-step bracket also holds the conv stack's backward on the other
+    streams."""
+    G, M = 256, B * n * n
+    dZ = [((torch.rand(M, G, device=dev) - 0.5) * 1e-2).bfloat16() for _ in range(2)]
+    A8 = [(torch.rand(M, G, device=dev) * 2).to(torch.float8_e4m3fn) for _ in range(3)]
+    mask = torch.randint(0, 256, (H.g_chain_rr_mask_bytes(M),), dtype=torch.uint8, device=dev)
+    H.relu_gate_image(mask, A8[2], M)
+    dxg = torch.rand(B, G, device=dev) - 0.5
+    dW = [torch.empty(G, G, device=dev) for _ in range(3)]
+    db = [torch.empty(G, device=dev) for _ in range(3)]
+    jobs = [(dZ[0], A8[0], dW[0], db[0]), (dZ[1], A8[1], dW[1], db[1]), (None, A8[2], dW[2], db[2])]
+    return time_launch(lambda: H.g_wgrad_blocked(jobs, M, dxg=dxg, rows_per_question=n * n), n=15)
 
 
 def pair_build_k1(H, B, n, k, Q, dev):
@@ -530,6 +553,14 @@ def main():
         dt_s = max_over_ranks(dt_s, world, dev)
         sustained = {"value": world * B * n_sus / dt_s, "unit": "questions/s", "ms_per_step": 1e3 * dt_s / n_sus, "steps": n_sus,
                      "seconds": dt_s, "clocks": clocks.summary() if clocks else None}
+    # the timed and sustained windows ran with the trainer's periodic guard off: validate them now -- a hand-off inside
+    # the feature-split f_phi launch that was not answered leaves an error word, and garbage results since then
+    fphi_status = H.f_phi_split_status(dev) if torch.cuda.is_available() else 0
+    if multi:
+        fphi_status = int(max_over_ranks(float(fphi_status), world, dev))
+    if fphi_status:
+        raise RuntimeError("rn_f_phi_split: a hand-off inside the launch was not answered during the timed / sustained window "
+                           "(stage %d): the measured steps are invalid" % (fphi_status - 1))
     comm = None
     if multi:
         # attribution (outside the timed region): K more steps with event brackets around the gradient all-reduce and the fused
@@ -651,14 +682,25 @@ def main():
             per_step = {kk: (ksum[kk][1] / args.steps) for kk in names if kk in ksum}
             g_launch = sum(ksum.get(kk, (0, 0.0))[0] for kk in names) // args.steps
             peak = PEAK_TFLOPS[prec]
-            fl = {"g_fwd": fwd, "g_dgrad": fwd * (1.0 - g_flops_fwd(M, dict(hyp, g_layers=hyp["g_layers"][:1]), k) / fwd), "g_wgrad": fwd}
-            kern = {kk: {"algorithmic_flops": fl[kk], "ms": per[kk], "achieved_tflops": fl[kk] / (per[kk] * 1e-3) / 1e12,
-                         "frac": fl[kk] / (per[kk] * 1e-3) / 1e12 / peak, "ms_serial": per_step.get(kk)} for kk in per}
             inj_l = hyp["question_injection_position"]
             # ONE shape predicate, the module's own (functional.chain_ok): the register-resident chains run iff the mode is "f16s"
             RFm = pkg.functional
             plan = model.rl._plan(k)
             alg0 = prec == "f16s" and RFm.chain_ok(plan, B, n)
+            # flops of each entry = the ALGORITHMIC flops of exactly what its launches compute (2 M K_l G per layer and
+            # direction).  Chain path: the `g_wgrad` launch is dW_1..L-1 only -- layer 0's weight gradient is another launch on
+            # another stream (`wgrad0_from_reductions`, its own entry below); the per-layer path's g_wgrad bracket holds every layer.
+            fl0 = g_flops_fwd(M, dict(hyp, g_layers=hyp["g_layers"][:1]), k)          # layer 0: 2 M K_0 G
+            fl = {"g_fwd": fwd, "g_dgrad": float(fwd - fl0), "g_wgrad": float(fwd - fl0) if alg0 else float(fwd)}
+            kern = {kk: {"algorithmic_flops": fl[kk], "ms": per[kk], "achieved_tflops": fl[kk] / (per[kk] * 1e-3) / 1e12,
+                         "frac": fl[kk] / (per[kk] * 1e-3) / 1e12 / peak, "ms_serial": per_step.get(kk)} for kk in per}
+            w0 = ksum_step.get("g_wgrad0")                         # (rn_hip.wgrad0_from_reductions has a timer key of its own)
+            if alg0 and w0 and w0[0] > 0 and w0[1] > 0:
+                ms0 = w0[1] / args.steps
+                kern["g_wgrad0"] = {"algorithmic_flops": float(fl0), "ms": ms0, "achieved_tflops": fl0 / (ms0 * 1e-3) / 1e12,
+                                    "frac": fl0 / (ms0 * 1e-3) / 1e12 / peak, "traffic": None, "traffic_source": None, "ms_serial": (ksum.get("g_wgrad0", (0, 0.0))[1] / args.steps) or None,
+                                    "what": "dW_0, db_0 = [Rj^T X | Ri^T X | Rq^T q] from the backward chain's pair reductions (wgrad0_part / finish kernels, "
+                                            "rn_pair.hip): the factored first layer EXECUTES ~0.1 GFLOP for these algorithmic flops -- latency-bound, no roofline claim"}
             njp = (n if inj_l else RFm.padded_j(n)) if alg0 else n
             # executed flops: the factored first layer runs K = 64 on chip (two passes: hi + lo weights) and the question, wherever
             # it is injected, enters as a bias row, so layers 1..3 are K = 256 products (one pass on tile-dithered images).
@@ -672,7 +714,7 @@ def main():
             Gw = 256
             alg_bytes = {"g_fwd": Mx * Gw * 3 + 4 * Mx * 32, "g_dgrad": Mx * Gw * 2 * 2 + 4 * Mx * 32,
                          "g_wgrad": Mx * Gw * (3 + 3 + 1)} if alg0 else {}
-            for kk in kern:
+            for kk in per:
                 tr_, src_ = (None, None)
                 if alg0 and B == 64 and n == 64 and inj_l == 0:
                     tr_, src_ = hbm_traffic_from_profiles(pats[kk])
@@ -680,18 +722,28 @@ def main():
                 kern[kk]["hbm_frac"] = (tr_ / (per[kk] * 1e-3) / 1e9 / PEAK_HBM_GBS) if tr_ else None
                 if kk in alg_bytes:
                     kern[kk]["algorithmic_hbm_bytes"] = alg_bytes[kk]
-            # what the matrix pipe sustains on this box (the chip clocks to its power budget): the second denominator
+            # DIAGNOSTIC: what a bare MFMA stream runs at on this box right now (the chip clocks to its power budget) -- a probe,
+            # not a peak: nothing below divides `frac` by it
             sus = sustained_mfma(H, dev) if prec == "f16s" else None
             if sus:
-                for kk in kern:
-                    kern[kk]["frac_of_sustained"] = kern[kk]["achieved_tflops"] / sus["f16" if kk == "g_fwd" else "bf16"]["tflops"]
+                for kk in per:
+                    kern[kk]["of_probe_not_peak"] = kern[kk]["achieved_tflops"] / sus["f16" if kk == "g_fwd" else "bf16"]["tflops"]
+            # the dominant weight-gradient launch ALONE (nothing beside it): what a kernel trace of the eager step reports for it
+            if alg0 and "g_wgrad" in kern and not inj_l and world == 1:
+                ms_a = wgrad_alone(H, B, n, dev)
+                kern["g_wgrad"]["ms_alone"] = ms_a
+                kern["g_wgrad"]["frac_alone"] = fl["g_wgrad"] / (ms_a * 1e-3) / 1e12 / peak
             ach_ex = executed / (per["g_fwd"] * 1e-3) / 1e12
-            g_ms, g_ms_step = sum(per.values()), sum(per_step.values())
+            # all of g_theta = the three big kernels + the launches that execute layer 0's share of the algorithmic flops on the
+            # chain path (tables of the factored first layer, partial-sum add-up + dx / dq, dW_0 from the reductions)
+            small = ("pair_build", "pair_reduce", "g_wgrad0") if alg0 else ()
+            g_ms = sum(per.values()) + sum(ksum_step[kk][1] / args.steps for kk in small if kk in ksum_step)
+            g_ms_step = sum(per_step.values()) + sum(ksum[kk][1] / args.steps for kk in small if kk in ksum)
             knames = {"g_fwd": ("%s<ALG0> (rn_chain_rr.hip): 4-layer g_theta forward chain + pair sum, 1 launch/step" % kname) if kname else
                                "g_theta forward kernels (%s per-layer path, rn_gemm.hip)" % prec,
                       "g_dgrad": "g_chain_rr_bwd_kernel<RED> (rn_chain_rr.hip): backward chain (3 dgrads, ReLU gates, pair-axis reductions), 1 launch/step"
                                  if alg0 else "g_theta dgrad kernels (%s per-layer path)" % prec,
-                      "g_wgrad": "wgrad_blocked_kernel (rn_wgrad_blocked.hip): dW_1..3 + db_1..3 in one launch (+ its partial-sum reduction)"
+                      "g_wgrad": "wgrad_blocked_kernel (rn_wgrad_blocked.hip): dW_1..3 + db_1..3 (NOT layer 0: kernels.g_wgrad0) in one launch (+ its partial-sum reduction)"
                                  if alg0 else "g_theta wgrad kernels (%s per-layer path, rn_wgrad.hip)" % prec}
             # THE roofline of this line = the g_theta kernel that takes the most time in the step (not the one that
             # scores best); the forward chain -- the GEMM chain north_star's >= 30 % target is written for -- is `gemm_chain` beside it
@@ -700,14 +752,15 @@ def main():
             chain = dict(kern["g_fwd"], kernel=knames["g_fwd"], frac_executed=ach_ex / peak, achieved_executed=ach_ex,
                          executed_flops_per_launch=executed)
             if sus:
-                chain["frac_executed_of_sustained"] = ach_ex / sus["f16"]["tflops"]
+                chain["executed_of_probe_not_peak"] = ach_ex / sus["f16"]["tflops"]
             out["roofline"] = {"bound": "mfma", "achieved": kd["achieved_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": kd["frac"],
                                "kernel": knames[dom], "kernel_key": dom,
                                "why_this_kernel": "longest g_theta kernel of the step (%.1f us of %.1f us of g_theta kernels)" % (1e3 * per[dom], 1e3 * g_ms),
                                "algorithmic_flops_per_launch": fl[dom], "ms_per_launch": per[dom],
                                "traffic": kd["traffic"], "traffic_source": kd["traffic_source"], "hbm_frac": kd["hbm_frac"],
                                "algorithmic_hbm_bytes": kd.get("algorithmic_hbm_bytes"),
-                               "frac_of_sustained": kd.get("frac_of_sustained"), "sustained_mfma": sus,
+                               "ms_alone": kd.get("ms_alone"), "frac_alone": kd.get("frac_alone"),
+                               "diagnostics": {"mfma_stream_probe": sus, "dominant_kernel_of_probe_not_peak": kd.get("of_probe_not_peak")},
                                "gemm_chain": chain,
                                "kernels": kern,
                                "all_g_theta": {"algorithmic_flops_per_step": 3 * fwd, "ms_per_step": g_ms, "launches_per_step": g_launch,

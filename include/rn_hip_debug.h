@@ -40,6 +40,8 @@ int rn_probe_red_schedule(int M, int n, int njp, int tiles_per_unit, int units_w
  * launch: flops = workgroups * 4 * waves_per_simd * iters * 16 * 32768.  bench.py quotes the chains against this measured rate
  * beside the nominal 2.5 PFLOP/s (the chip clocks to its power budget).  out: workgroups * 256 * waves_per_simd floats (a sink). */
 int rn_probe_mfma_stream(float* out, int workgroups, int waves_per_simd, int iters, int dtype, void* stream);
+/* ... the same stream on all-zero operands (zero_operands != 0): the data pattern "peak" figures are usually measured with */
+int rn_probe_mfma_stream_ops(float* out, int workgroups, int waves_per_simd, int iters, int dtype, int zero_operands, void* stream);
 
 /* Which f_phi kernels rn_f_phi_fwd / _fwd_nll / _bwd / _bwd_nll launch: 0 = by size (the per-layer, feature-split launches for
  * anything wider than the 256-wide image models: config.json's *-sd), 1 = always the per-layer launches, -1 = never.  Returns the

@@ -946,7 +946,7 @@ extern "C" int rn_debug_stamp(unsigned long long* slot, void* stream) {
 // to its power budget: this bare stream is what "MFMA-bound" can mean on a given box at a given moment (measured on the pool:
 // 19.5-20 ns per 32-cycle MFMA slot = 1.7 PFLOP/s where the nominal figure is 2.5), and bench.py quotes the chains against both.
 template <bool BF>
-__global__ __launch_bounds__(512) void mfma_stream_kernel(float* out, int iters) {
+__global__ __launch_bounds__(512) void mfma_stream_kernel(float* out, int iters, int zero_operands) {
   typedef __attribute__((ext_vector_type(8))) _Float16 h8;
   typedef __attribute__((ext_vector_type(8))) __bf16 b8;
   typedef __attribute__((ext_vector_type(16))) float f16v;
@@ -958,7 +958,9 @@ __global__ __launch_bounds__(512) void mfma_stream_kernel(float* out, int iters)
   b8 ab, bb;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const float x = 0.37f * (float)((lane * 7 + i * 3) % 17 - 8), y = 0.21f * (float)((lane * 5 + i * 11) % 13 - 6);
+    // zero_operands: the same instruction stream on all-zero inputs -- the data pattern most "peak" figures are measured with; the
+    // chip then draws less power per MFMA and clocks higher (MI355X_MICROARCH.md "DVFS give-back": +19 % TF/s on zero-filled inputs)
+    const float x = zero_operands ? 0.f : 0.37f * (float)((lane * 7 + i * 3) % 17 - 8), y = zero_operands ? 0.f : 0.21f * (float)((lane * 5 + i * 11) % 13 - 6);
     ah[i] = (_Float16)x; bh[i] = (_Float16)y; ab[i] = (__bf16)x; bb[i] = (__bf16)y;
   }
   for (int it = 0; it < iters; ++it) {
@@ -974,13 +976,16 @@ __global__ __launch_bounds__(512) void mfma_stream_kernel(float* out, int iters)
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-extern "C" int rn_probe_mfma_stream(float* out, int workgroups, int waves_per_simd, int iters, int dtype, void* stream) {
+extern "C" int rn_probe_mfma_stream_ops(float* out, int workgroups, int waves_per_simd, int iters, int dtype, int zero_operands, void* stream) {
   RN_CHECK_ARG(out && workgroups > 0 && (waves_per_simd == 1 || waves_per_simd == 2) && iters > 0 && (dtype == RN_BF16 || dtype == RN_F16),
                "rn_probe_mfma_stream: out (workgroups * 256 * waves_per_simd floats), waves_per_simd 1 | 2, dtype RN_F16 | RN_BF16");
-  if (dtype == RN_BF16) mfma_stream_kernel<true><<<workgroups, 256 * waves_per_simd, 0, (hipStream_t)stream>>>(out, iters);
-  else mfma_stream_kernel<false><<<workgroups, 256 * waves_per_simd, 0, (hipStream_t)stream>>>(out, iters);
+  if (dtype == RN_BF16) mfma_stream_kernel<true><<<workgroups, 256 * waves_per_simd, 0, (hipStream_t)stream>>>(out, iters, zero_operands);
+  else mfma_stream_kernel<false><<<workgroups, 256 * waves_per_simd, 0, (hipStream_t)stream>>>(out, iters, zero_operands);
   RN_LAUNCH_CHECK("rn_probe_mfma_stream");
   return 0;
+}
+extern "C" int rn_probe_mfma_stream(float* out, int workgroups, int waves_per_simd, int iters, int dtype, void* stream) {
+  return rn_probe_mfma_stream_ops(out, workgroups, waves_per_simd, iters, dtype, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ batch hand-off

@@ -58,10 +58,13 @@ struct KbJob {
   float* dW;
   float* db;
   int steps_per_q, gate;
+  int Z, wide;                  // row splits of THIS job; wide: one workgroup per split holds the whole 256 x 256 dW (kbw_run)
 };
 struct KbArgs {
   KbJob job[KB_MAXJOBS];
-  int njobs, S, Z;
+  int njobs, S;                 // S = M / 64
+  int nq, nw, grid_q;           // quad jobs (4 workgroups per split), wide jobs, workgroups of the quad part of the grid
+  int qjob[KB_MAXJOBS], wjob[KB_MAXJOBS];
 };
 
 template <bool Z8, bool A8> struct KbGeo {
@@ -354,23 +357,180 @@ __device__ __forceinline__ void kb_run(unsigned char* lds, const KbJob& jb_, int
   }
 }
 
+// ---- WIDE units (round 6): a stored-gradient job on e4m3 activations, ONE workgroup per row split ----------------------------
+// The quad mapping above reads every operand byte twice (two of the four workgroups of a row range need it) and, with a 64 x 64
+// tile per wave, pays one fragment read and two e4m3 -> bf16 conversions per MFMA and one barrier per 16 MFMAs -- on one wave per
+// SIMD that issue stream, not the matrix pipe, was its arithmetic floor (compute alone 127 us against 86 for the MFMAs).  Here a
+// workgroup owns the WHOLE 256 x 256 dW of its rows: wave (wn, wk) holds a 128 x 128 block as 16 accumulator tiles = 256 AGPRs
+// (the wave has the SIMD's 512 registers to itself), per 32-row group 8 dZ + 4 A fragment reads and 32 conversions feed 32
+// MFMAs (0.375 reads, 1 conversion per MFMA: half), a barrier every 32 MFMAs, and every operand byte enters the chip once --
+// a 32-row group is 16 KB of the dZ image + 8 KB of the A image, both CONTIGUOUS (all 256 features), 24 one-KB LDS-DMA pieces.
+// db: a lane's dZ fragment is 8 rows of ONE feature, so the column sums are in-lane -- v_dot2c_f32_bf16 against (1, 1), four per
+// fragment, in the MFMA gaps (the quad mapping spends 2 of 18 MFMAs on them); the two waves that hold the same features take
+// MFMA a's / MFMA b's row blocks.  Same partial format as the quad units ([z][256][256] + 4 db rows per split), same fixed-order
+// reduction.  Cost: a 256-KB partial tile per workgroup instead of 64 KB.
+struct KbwFrag {
+  u32x4 dz[2][4];                                         // [MFMA a / b][n block]: 8 rows (block 2 h + ab of the group) of one feature
+  u32x4 a[4];                                             // [k block]: 16 rows (block h) of one feature, e4m3
+};
+constexpr int KBW_ZB = 32 * 256 * 2, KBW_AB = 32 * 256, KBW_STG = KBW_ZB + KBW_AB, KBW_NSTG = 6, KBW_LA = KBW_NSTG - 1, KBW_NPIECE = 6;
+static_assert(KBW_NSTG * KBW_STG <= kb_lds_bytes<true>(), "the wide units' ring must fit the launch's LDS");
+
+template <int DBAB, int ABL = 0>
+__device__ __forceinline__ void kbw_run(unsigned char* lds, const KbJob& jb_, int S, int z) {
+  const int t = threadIdx.x, lane = t & 63, n = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6), wn = w >> 1, wk = w & 1;
+  KbJob jb = jb_;
+  asm volatile("" : "+s"(jb.dZ), "+s"(jb.A));
+  // 32-row groups of this workgroup (row splits are counted in 64-row steps like the quad units': an even number of groups)
+  const int s0 = 2 * __builtin_amdgcn_readfirstlane((int)((long)z * S / jb.Z)), s1 = 2 * __builtin_amdgcn_readfirstlane((int)((long)(z + 1) * S / jb.Z));
+  const unsigned ldsb = (unsigned)(size_t)(lds_u8*)lds;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  // the stream: group s -> ring slot s % NSTG; wave w requests dZ pieces 4 w .. 4 w + 3 and A pieces 2 w, 2 w + 1 (1 KB each)
+  auto issue_piece = [&](int s, int slot, int idx) {
+    const unsigned sb = ldsb + (unsigned)slot * KBW_STG;
+    if (ABL & 256) s &= 3;
+    if (idx < 4) {
+      const int q = 4 * w + idx;
+      kb_dma(jb.dZ + ((long)s * KBW_ZB + q * 1024), lane16, sb + q * 1024);
+    } else {
+      const int q = 2 * w + (idx - 4);
+      kb_dma(jb.A + ((long)s * KBW_AB + q * 1024), lane16, sb + KBW_ZB + q * 1024);
+    }
+  };
+  const unsigned zoff = (unsigned)(((2 * h) * 256 + wn * 128 + n) * 16);
+  const unsigned aoff = (unsigned)(KBW_ZB + (h * 256 + wk * 128 + n) * 16);
+  auto read_piece = [&](const unsigned char* st, KbwFrag& f, int p) {       // 12 pieces of a group
+    if (p < 8) {
+      if (ABL & 16) return;
+      f.dz[p >> 2][p & 3] = *reinterpret_cast<const u32x4*>(st + zoff + ((p >> 2) * 256 + 32 * (p & 3)) * 16);
+    } else {
+      if (ABL & 8) return;
+      f.a[p - 8] = *reinterpret_cast<const u32x4*>(st + aoff + (32 * (p - 8)) * 16);
+    }
+  };
+  // conversion c of 16 of MFMA ab's operands: k block c / 4, source dword 2 ab + (c / 2) % 2, its low / high byte pair
+  auto conv = [&](const KbwFrag& f, int ab, int c, u32x4 (&bf)[4]) {
+    if (ABL & 64) return;
+    const int j = c >> 2, hf = (c >> 1) & 1, hi = c & 1;
+    bf[j][2 * hf + hi] = __builtin_bit_cast(unsigned, hi ? __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(f.a[j][2 * ab + hf], RN_H8_SCALE, true)
+                                                        : __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(f.a[j][2 * ab + hf], RN_H8_SCALE, false));
+    asm volatile("" : "+v"(bf[j][2 * hf + hi]));          // pinned in its gap (the compiler otherwise sinks it to its use)
+  };
+
+  f32x16 acc[4][4];
+  float acc_db[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // ---- prologue: LA groups requested; groups s0, s0 + 1 visible; the first fragments + MFMA a's converted operands in registers
+  for (int s = s0; s < s0 + KBW_LA && s < s1; ++s)
+#pragma unroll
+    for (int i = 0; i < KBW_NPIECE; ++i) issue_piece(s, s % KBW_NSTG, i);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KBW_LA - 2) * KBW_NPIECE) : "memory");
+  if (s1 - s0 < KBW_LA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  KbwFrag f0, f1;
+  u32x4 bf[2][4];                                         // converted A operands of MFMA a / b, k blocks 0..3
+  {
+    const unsigned char* st = lds + (unsigned)(s0 % KBW_NSTG) * KBW_STG;
+#pragma unroll
+    for (int p = 0; p < 12; ++p) read_piece(st, f0, p);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) conv(f0, 0, c, bf[0]);
+  }
+
+  int slot = s0 % KBW_NSTG;
+  // one 32-row group: 32 MFMAs on F (in registers), the reads of the next group into Fn, one group's requests, the conversions
+  // of MFMA b's operands (first half) and of the NEXT group's MFMA a operands (second half), this wave's share of db
+  auto group = [&](KbwFrag& F, KbwFrag& Fn, int s) {
+    if (s + KBW_LA - 1 < s1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KBW_LA - 2) * KBW_NPIECE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(ABL & 4)) __builtin_amdgcn_s_barrier();         // group s + 1 visible; every wave is done with slot (s - 1) % NSTG
+    asm volatile("" ::: "memory");
+    const int pslot = slot == 0 ? KBW_NSTG - 1 : slot - 1;
+    const int nslot = slot + 1 == KBW_NSTG ? 0 : slot + 1;
+    const bool do_issue = s + KBW_LA < s1 && !(ABL & 2);
+    const unsigned char* stn = lds + (unsigned)nslot * KBW_STG;
+    slot = nslot;
+    if (ABL & 1) {
+      if (do_issue)
+#pragma unroll
+        for (int i = 0; i < KBW_NPIECE; ++i) issue_piece(s + KBW_LA, pslot, i);
+      return;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {
+      const int ab = g >> 4, i = (g >> 2) & 3, j = g & 3;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F.dz[ab][i]), __builtin_bit_cast(bf16x8, bf[ab][j]), acc[i][j], 0, 0, 0);
+      if (g < 12) read_piece(stn, Fn, g);                 // (behind the last group: a slot nobody uses)
+      if (g >= 12 && g < 12 + KBW_NPIECE && do_issue) issue_piece(s + KBW_LA, pslot, g - 12);
+      if (g < 16) conv(F, 1, g, bf[1]);
+      else conv(Fn, 0, g - 16, bf[0]);
+      if (g >= 16) {                                      // db: dword (g - 16) % 4 of the fragment of n block (g - 16) / 4
+        const int c = g - 16;
+        // (written as asm: hipcc 7.2 folds __builtin_amdgcn_fdot2_f32_bf16(bit_cast<bf16x2>(vector[c]), ..) to element 0 of the vector
+        // for every c -- one dword added four times -- and an asm statement stays in its gap)
+        asm volatile("v_dot2c_f32_bf16 %0, 0x3f803f80, %1" : "+v"(acc_db[c >> 2]) : "v"(F.dz[DBAB][c >> 2][c & 3]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  for (int s = s0; s < s1; s += 2) {
+    group(f0, f1, s);
+    group(f1, f0, s + 1);
+  }
+
+  // ---- fp32 partial tile part[z][n][k] (a lane holds one k column of 16 feature rows) and this wave's 2 of the split's 4 db rows
+  float* pz = jb.part + (long)z * 256 * 256;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kcol = wk * 128 + j * 32 + n;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int nrow = wn * 128 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        pz[(long)nrow * 256 + kcol] = acc[i][j][reg];
+      }
+    }
+  float* pd = jb.part_db + ((long)z * 4 + wk * 2 + h) * 256 + wn * 128 + n;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pd[i * 32] = acc_db[i];
+}
+
 template <bool A8, int ABL = 0>
 __global__ __launch_bounds__(KB_NT, KB_OCC) void wgrad_blocked_kernel(KbArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[kb_lds_bytes<A8>()];
   // XCD-aware decode: consecutive ids round-robin over the 8 XCDs; the NB blocks of one unit (a job's row range) share an XCD,
   // and the njobs x Z units are dealt out over the XCDs evenly (unit u -> XCD u % 8; jobs interleaved)
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int blk = slot % KB_NB, u = (slot / KB_NB) * 8 + xcd;
-  if (u >= a.njobs * a.Z) return;
-  const int job = u % a.njobs, z = u / a.njobs;
-  const KbJob& jb = a.job[job];
   if constexpr (A8) {
-    if (jb.gate) {
-      kb_run<true, true, ABL>(lds, jb, a.S, a.Z, z, blk & 1, blk >> 1);
+    if ((int)blockIdx.x >= a.grid_q) {                    // wide units: consecutive ids round-robin over the XCDs as they come
+      const int v = (int)blockIdx.x - a.grid_q;
+      const KbJob& jw = a.job[a.wjob[v % a.nw]];
+      if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) kbw_run<1, ABL>(lds, jw, a.S, v / a.nw);
+      else kbw_run<0, ABL>(lds, jw, a.S, v / a.nw);
       return;
     }
   }
-  kb_run<false, A8, ABL>(lds, jb, a.S, a.Z, z, blk & 1, blk >> 1);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int blk = slot % KB_NB, u = (slot / KB_NB) * 8 + xcd;
+  const int job = a.qjob[u % a.nq], z = u / a.nq;
+  const KbJob& jb = a.job[job];
+  if (z >= jb.Z) return;
+  if constexpr (A8) {
+    if (jb.gate) {
+      kb_run<true, true, ABL>(lds, jb, a.S, jb.Z, z, blk & 1, blk >> 1);
+      return;
+    }
+  }
+  kb_run<false, A8, ABL>(lds, jb, a.S, jb.Z, z, blk & 1, blk >> 1);
 }
 
 // Ordered reduction of the per-split partials of every job: blocks [0, nbw) of a job reduce dW, the rest db (4 partial rows
@@ -381,7 +541,7 @@ __global__ __launch_bounds__(256) void wgrad_blocked_reduce_kernel(KbArgs a, int
   const int o = threadIdx.x & 15, zs = threadIdx.x >> 4;
   const bool is_w = (int)blockIdx.x < nbw;
   const long E4 = is_w ? 256 * 256 / 4 : 256 / 4;
-  const int Zr = is_w ? a.Z : 4 * a.Z;
+  const int Zr = is_w ? jb.Z : 4 * jb.Z;
   const long g4 = (long)(is_w ? blockIdx.x : blockIdx.x - nbw) * 16 + o;
   const f32x4* src = reinterpret_cast<const f32x4*>(is_w ? jb.part : jb.part_db);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -405,9 +565,7 @@ __global__ __launch_bounds__(256) void wgrad_blocked_reduce_kernel(KbArgs a, int
 // three; 16 MB of partials per step instead of 50).  aligned != 0 (the question-injected layer's backward reads the db partials
 // as per-question sums of dZ): a count that never lets a split straddle two questions -- Z = B * d, d | steps per question, as
 // close to the target as such a count gets, or B itself -- when one exists within 256 splits.
-int kb_splits(int M, int rows_per_question, int njobs, int aligned) {
-  const int S = M / 64;
-  if (S < 1 || njobs < 1) return 0;
+int kb_total_units() {
   // 48 row splits over all jobs = 192 workgroups: three quarters of the chip.  The launch runs on a side stream beside the
   // latency-bound kernels that close the backward pass (pair reduction, dx / dq, the conv stack's backward); with a workgroup
   // on every CU (64 splits) those kernels wait for CU slots and stretch 3-5x -- measured on the whole step, same box: 64 ->
@@ -417,6 +575,12 @@ int kb_splits(int M, int rows_per_question, int njobs, int aligned) {
 #endif
   int total = RN_KB_TOTAL;
   if (const char* e = rn_diag_env("RN_KB_TOTAL")) total = atoi(e) > 0 ? atoi(e) : total;      // (diagnostics builds)
+  return total;
+}
+int kb_splits(int M, int rows_per_question, int njobs, int aligned) {
+  const int S = M / 64;
+  if (S < 1 || njobs < 1) return 0;
+  const int total = kb_total_units();
   const int target = total / njobs > 0 ? total / njobs : 1;
   const int Zd = S >= target ? target : S;
   if (!aligned || rows_per_question <= 0 || rows_per_question % 64 || M % rows_per_question) return Zd;
@@ -428,6 +592,38 @@ int kb_splits(int M, int rows_per_question, int njobs, int aligned) {
     if (spq % d == 0) best = B * d;
   return best;
 }
+// Row splits of a launch that mixes WIDE jobs (stored gradient x e4m3 image: one workgroup per split) and QUAD jobs (the gate
+// job: four workgroups per split) on the same budget of 4 x kb_total_units() workgroups, so that both kinds of workgroup take the
+// same time: a wide workgroup does 64 MFMAs per wave on 48 KB per 64 rows, a quad one 18 on 16 KB -- RN_KBW_RATIO_X8 / 8 quad
+// rows per wide row (swept on the step).
+#ifndef RN_KBW_RATIO_X8
+#define RN_KBW_RATIO_X8 24
+#endif
+void kb_mixed_splits(int M, int nw, int nq, int* Zw, int* Zq) {
+  const int S = M / 64, T = 4 * kb_total_units();
+  int r8 = RN_KBW_RATIO_X8;
+  if (const char* e = rn_diag_env("RN_KBW_RATIO_X8")) r8 = atoi(e) > 0 ? atoi(e) : r8;        // (diagnostics builds)
+  // nw Zw + 4 nq Zq = T, Zw = (r8 / 8) Zq
+  int zq = nq ? (8 * T + (nw * r8 + 32 * nq) / 2) / (nw * r8 + 32 * nq) : 0;
+  if (nq && zq < 1) zq = 1;
+  int zw = nw ? (T - 4 * nq * zq) / nw : 0;
+  if (nw && zw < 1) zw = 1;
+  *Zw = zw > S ? S : zw;
+  *Zq = zq > S ? S : zq;
+}
+// the most row splits any job of a launch can get (workspace sizing: the mix of job kinds is not known to the size query)
+int kb_max_units(int M, int rows_per_question, int njobs, int aligned) {
+  const int Zu = kb_splits(M, rows_per_question, njobs, aligned);
+  if (aligned) return njobs * Zu;
+  int most = njobs * Zu;
+  for (int nq = 0; nq <= njobs; ++nq) {
+    int zw, zq;
+    kb_mixed_splits(M, njobs - nq, nq, &zw, &zq);
+    const int u = (njobs - nq) * zw + nq * zq;
+    most = u > most ? u : most;
+  }
+  return most;
+}
 }  // namespace
 
 extern "C" int rn_wgrad_blocked_splits(int M, int rows_per_question, int njobs, int aligned) {
@@ -437,9 +633,10 @@ extern "C" int rn_wgrad_blocked_splits(int M, int rows_per_question, int njobs, 
 size_t rnws_wgrad_blocked(int M, int rows_per_question, int njobs, int aligned) {
   const int Z = rn_wgrad_blocked_splits(M, rows_per_question, njobs, aligned);
   if (Z <= 0) return 0;
-  return (size_t)njobs * ((size_t)Z * 256 * 256 + (size_t)Z * 4 * 256) * sizeof(float);
+  return (size_t)kb_max_units(M, rows_per_question, njobs, aligned) * ((size_t)256 * 256 + (size_t)4 * 256) * sizeof(float);
 }
 
+// (aligned launches only -- uniform splits: the db partials of job `job` as per-question column sums)
 extern "C" size_t rn_wgrad_blocked_db_partials_offset(int M, int rows_per_question, int njobs, int aligned, int job) {
   const int Z = rn_wgrad_blocked_splits(M, rows_per_question, njobs, aligned);
   if (Z <= 0 || job < 0 || job >= njobs) return 0;
@@ -450,24 +647,38 @@ static int kb_launch(const void* const* dZ, const int* dz_dtype, const void* con
                      int aligned, float* const* dW, float* const* db, int njobs, void* ws, int M, void* stream, int abl) {
   RN_CHECK_ARG(dZ && dz_dtype && A && dW && db && ws && njobs > 0 && njobs <= KB_MAXJOBS, "rn_g_wgrad_blocked: bad pointer / job count (%d, max %d)", njobs, KB_MAXJOBS);
   RN_CHECK_ARG(a_dtype == RN_BF16 || a_dtype == RN_FP8, "rn_g_wgrad_blocked: A must be bf16 or e4m3 (a_dtype=%d)", a_dtype);
-  const int Z = rn_wgrad_blocked_splits(M, rows_per_question, njobs, aligned);
-  RN_CHECK_ARG(Z > 0, "rn_g_wgrad_blocked: needs M %% 64 == 0 (M=%d)", M);
+  const int Zu = rn_wgrad_blocked_splits(M, rows_per_question, njobs, aligned);
+  RN_CHECK_ARG(Zu > 0, "rn_g_wgrad_blocked: needs M %% 64 == 0 (M=%d)", M);
   KbArgs a;
   memset(&a, 0, sizeof(a));
   a.njobs = njobs;
   a.S = M / 64;
-  a.Z = Z;
+  // kinds: a stored gradient on an e4m3 image runs as WIDE units unless the caller reads the db partials per question (aligned)
+  bool no_wide = aligned != 0 || a_dtype != RN_FP8;
+  if (const char* e = rn_diag_env("RN_KB_NO_WIDE")) no_wide = no_wide || atoi(e) != 0;          // (diagnostics builds)
+  for (int j = 0; j < njobs; ++j) {
+    RN_CHECK_ARG(dz_dtype[j] == RN_BF16 || dz_dtype[j] == RN_FP8, "rn_g_wgrad_blocked: job %d: dz_dtype must be RN_BF16 (a stored image) or RN_FP8 (gate job) (dz_dtype=%d)", j, dz_dtype[j]);
+    a.job[j].wide = (!no_wide && dz_dtype[j] == RN_BF16) ? 1 : 0;
+    if (a.job[j].wide) a.wjob[a.nw++] = j;
+    else a.qjob[a.nq++] = j;
+  }
+  int Zw = 0, Zq = Zu;
+  if (a.nw) kb_mixed_splits(M, a.nw, a.nq, &Zw, &Zq);
   float* part = (float*)ws;
-  float* part_db = part + (size_t)njobs * Z * 256 * 256;
+  size_t units = 0;
+  for (int j = 0; j < njobs; ++j) units += a.job[j].wide ? Zw : Zq;
+  float* part_db = part + units * 256 * 256;
+  size_t u0 = 0;
   for (int j = 0; j < njobs; ++j) {
     RN_CHECK_ARG((dZ[j] || dz_dtype[j] == RN_FP8) && A[j] && dW[j], "rn_g_wgrad_blocked: job %d: dZ / A / dW is NULL", j);
     RN_CHECK_ARG(((uintptr_t)dZ[j] | (uintptr_t)A[j] | (uintptr_t)dW[j] | (uintptr_t)db[j]) % 16 == 0, "rn_g_wgrad_blocked: job %d: pointers must be 16-byte aligned", j);
-    RN_CHECK_ARG(dz_dtype[j] == RN_BF16 || dz_dtype[j] == RN_FP8, "rn_g_wgrad_blocked: job %d: dz_dtype must be RN_BF16 (a stored image) or RN_FP8 (gate job) (dz_dtype=%d)", j, dz_dtype[j]);
     RN_CHECK_ARG(dz_dtype[j] != RN_FP8 || !dZ[j] || dZ[j] == A[j], "rn_g_wgrad_blocked: job %d is a gate job: its gate is the sign bits of A (dZ must be NULL or A)", j);
+    a.job[j].Z = a.job[j].wide ? Zw : Zq;
     a.job[j].dZ = (const unsigned char*)dZ[j];
     a.job[j].A = (const unsigned char*)A[j];
-    a.job[j].part = part + (size_t)j * Z * 256 * 256;
-    a.job[j].part_db = part_db + (size_t)j * Z * 4 * 256;
+    a.job[j].part = part + u0 * 256 * 256;
+    a.job[j].part_db = part_db + u0 * 4 * 256;
+    u0 += a.job[j].Z;
     a.job[j].dW = dW[j];
     a.job[j].db = db[j];
     if (dz_dtype[j] == RN_FP8) {
@@ -482,10 +693,15 @@ static int kb_launch(const void* const* dZ, const int* dz_dtype, const void* con
     }
   }
   hipStream_t s = (hipStream_t)stream;
-  const int grid = 8 * KB_NB * cdiv(njobs * Z, 8);
+  a.grid_q = a.nq ? 8 * KB_NB * cdiv(a.nq * Zq, 8) : 0;
+  if (!a.nq) a.nq = 1;                                        // (never indexed: every workgroup is a wide one; no division by zero)
+  if (!a.nw) a.nw = 1;
+  int nwide_wg = 0;
+  for (int j = 0; j < njobs; ++j) nwide_wg += a.job[j].wide ? a.job[j].Z : 0;
+  const int grid_all = a.grid_q + nwide_wg;
 #ifdef RN_DIAG
   switch (abl) {
-#define RN_ABL(v) case v: if (a_dtype == RN_FP8) wgrad_blocked_kernel<true, v><<<grid, KB_NT, 0, s>>>(a); else wgrad_blocked_kernel<false, v><<<grid, KB_NT, 0, s>>>(a); break;
+#define RN_ABL(v) case v: if (a_dtype == RN_FP8) wgrad_blocked_kernel<true, v><<<grid_all, KB_NT, 0, s>>>(a); else wgrad_blocked_kernel<false, v><<<grid_all, KB_NT, 0, s>>>(a); break;
     RN_ABL(257) RN_ABL(513) RN_ABL(1) RN_ABL(2) RN_ABL(3) RN_ABL(4) RN_ABL(6) RN_ABL(66) RN_ABL(8) RN_ABL(24) RN_ABL(10) RN_ABL(26)
 #undef RN_ABL
     default:
@@ -494,11 +710,11 @@ static int kb_launch(const void* const* dZ, const int* dz_dtype, const void* con
   {
 #endif
 #ifdef KB_FORCE_ABL                                         // (variant builds: what would the step cost with this launch ablated?)
-    if (a_dtype == RN_FP8) wgrad_blocked_kernel<true, KB_FORCE_ABL><<<grid, KB_NT, 0, s>>>(a);
+    if (a_dtype == RN_FP8) wgrad_blocked_kernel<true, KB_FORCE_ABL><<<grid_all, KB_NT, 0, s>>>(a);
     else
 #endif
-    if (a_dtype == RN_FP8) wgrad_blocked_kernel<true><<<grid, KB_NT, 0, s>>>(a);
-    else wgrad_blocked_kernel<false><<<grid, KB_NT, 0, s>>>(a);
+    if (a_dtype == RN_FP8) wgrad_blocked_kernel<true><<<grid_all, KB_NT, 0, s>>>(a);
+    else wgrad_blocked_kernel<false><<<grid_all, KB_NT, 0, s>>>(a);
   }
   RN_LAUNCH_CHECK("rn_g_wgrad_blocked");
   const int nbw = cdiv(256 * 256 / 4, 16), nbb = cdiv(256 / 4, 16);

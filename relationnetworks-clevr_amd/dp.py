@@ -423,9 +423,13 @@ class DataParallelTrainer:
             # (same cadence, same host sync: the in-launch hand-offs of the feature-split f_phi kernel have bounded spins -- a sweep
             # that gave up leaves an error word instead of a hang; training on with garbage must not be silent)
             st = RF.H.f_phi_split_status(img.device)
-            if st:
-                raise RuntimeError("rn_f_phi_split: a hand-off inside the launch was not answered (stage %d); results since then are "
-                                   "invalid -- re-run with RN_NO_FPHI_SPLIT=1" % (st - 1))
+            any_st = bool(st)
+            if self.world > 1:                                 # (raised on EVERY rank, or the peers hang in the next collective)
+                with self.watchdog.guard("f_phi hand-off status: agreement over ranks", self.timeout_s):
+                    any_st = self.ctl.any_of(any_st)
+            if any_st:
+                raise RuntimeError("rn_f_phi_split: a hand-off inside the launch was not answered (%s); results since then are "
+                                   "invalid -- re-run with RN_NO_FPHI_SPLIT=1" % ("stage %d on this rank" % (st - 1) if st else "on another rank"))
         if not (self._h8_in_use() and img.is_cuda):
             return None
         bufs = [(b_, b_.clone()) for b_ in self.model.buffers()]
@@ -493,26 +497,34 @@ class DataParallelTrainer:
         n = self.bucket.numel
         gen = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
         src = (torch.rand(n, generator=gen) - 0.5).to(dev)
-        ok, why, g = True, None, None
+        why, g, ref, buf = None, None, None, None
         try:
             ref = src.clone()
             dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.group)     # (also the communicator's lazy initialisation)
             torch.cuda.synchronize()
             buf = src.clone()
             g = torch.cuda.CUDAGraph()
-            self._capture_stream = cs = torch.cuda.Stream()       # (a stream of this capture's own: a failure must not poison torch's shared one)
+            self._capture_stream = cs = RF.fresh_stream(self.bucket.flat.device)       # (a stream of this capture's own: a failure must not poison torch's shared one)
             with torch.cuda.graph(g, stream=cs, capture_error_mode=self._capture_mode()):
                 self._graph_collective(buf)
-            for _ in range(2):
-                buf.copy_(src)
-                g.replay()
-                torch.cuda.synchronize()
-                if not torch.equal(buf, ref):
-                    ok, why = False, "captured all-reduce != eager all-reduce (max |diff| %.3e)" % float((buf - ref).abs().max())
-                    break
         except Exception as e:
-            ok, why = False, "%s: %s" % (type(e).__name__, str(e)[:160])
+            why = "%s: %s" % (type(e).__name__, str(e)[:160])
             self._abandon_capture(g)
+        # the replay IS a collective.  A rank whose capture raised must not leave the others blocked in g.replay() on an
+        # all-reduce it never joins (nobody would reach the gather below; the job would die at the watchdog instead of falling back):
+        # every rank learns whether EVERY capture succeeded before ANY rank replays.
+        captured = self.ctl.gather(why)
+        if all(r is None for r in captured):
+            try:
+                for _ in range(2):
+                    buf.copy_(src)
+                    g.replay()
+                    torch.cuda.synchronize()
+                    if not torch.equal(buf, ref):
+                        why = "captured all-reduce != eager all-reduce (max |diff| %.3e)" % float((buf - ref).abs().max())
+                        break
+            except Exception as e:
+                why = "%s: %s" % (type(e).__name__, str(e)[:160])
         reasons = self.ctl.gather(why)
         self.exchange_checks["self_check"] = "passed" if all(r is None for r in reasons) else reasons
         if all(r is None for r in reasons):
@@ -531,7 +543,7 @@ class DataParallelTrainer:
                     d_.copy_(s_)
         else:
             self._static = (img.clone(), qst.clone(), label.clone())
-        side = torch.cuda.Stream()
+        side = RF._side_stream(self.bucket.flat.device, "warmup")
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                   # warm-up outside capture (MIOpen find, allocator, packs)
             for _ in range(2):
@@ -618,7 +630,7 @@ class DataParallelTrainer:
         graph = self._capturing = torch.cuda.CUDAGraph()
         # N > 1: every capture on a stream of its own (torch.cuda.graph otherwise re-uses ONE class-level capture stream: a capture
         # that failed on it would fail every later one)
-        self._capture_stream = cs = torch.cuda.Stream() if self.exchange else None
+        self._capture_stream = cs = RF.fresh_stream(self.bucket.flat.device) if self.exchange else None
         with torch.cuda.graph(graph, stream=cs, capture_error_mode=self._capture_mode()):
             self._loss = self._fwd_bwd(*self._static)
             if with_opt:
@@ -642,11 +654,21 @@ class DataParallelTrainer:
             torch.cuda.synchronize()
             f = self.bucket.flat
             sig = (float(f.double().sum().item()), float(f.double().norm().item()), float(self._fused_opt.norm.item()))
-            sigs = self.ctl.gather(sig)
-        self.exchange_checks["first_step_signatures_equal"] = all(s_ == sigs[0] for s_ in sigs)
+            # the comparison itself is on the BYTES of the reduced bucket (a 64-bit sum of its words: NaN-safe, order-independent
+            # over the buffer, identical iff the ranks hold the same bits -- what a sum all-reduce of one buffer must leave)
+            words = f.view(torch.int32).to(torch.int64)
+            digest = int((words * (torch.arange(words.numel(), device=f.device, dtype=torch.int64) % 65521 + 1)).sum().item())
+            finite = bool(torch.isfinite(f).all().item())
+            sigs = self.ctl.gather((digest, finite, sig))
+        self.exchange_checks["first_step_all_finite"] = all(s_[1] for s_ in sigs)
+        self.exchange_checks["first_step_signatures_equal"] = all(s_[0] == sigs[0][0] for s_ in sigs)
+        if not self.exchange_checks["first_step_all_finite"]:
+            # (a NaN compares unequal to itself -- this used to be reported as "different gradients on the ranks")
+            raise RuntimeError("non-finite gradient after the first replayed step on rank(s) %s (sum, norm, clip norm per rank: %r): "
+                               "the model / batch diverged, not the exchange" % ([i for i, s_ in enumerate(sigs) if not s_[1]], [s_[2] for s_ in sigs]))
         if not self.exchange_checks["first_step_signatures_equal"]:
-            raise RuntimeError("the in-graph gradient all-reduce left different gradients on the ranks (sum, norm, clip norm per rank: %r); "
-                               "re-run with RN_NO_GRAPH_ALLREDUCE=1" % (sigs,))
+            raise RuntimeError("the in-graph gradient all-reduce left different BITS in the gradient bucket of the ranks (weighted word sum per rank: %r; "
+                               "sum, norm, clip norm per rank: %r); re-run with RN_NO_GRAPH_ALLREDUCE=1" % ([s_[0] for s_ in sigs], [s_[2] for s_ in sigs]))
 
     def input_buffers(self, img, qst, label):
         """The captured step's OWN input tensors (captured now, from the given example batch, if it has not been yet).  A loader

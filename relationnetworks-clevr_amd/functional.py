@@ -198,10 +198,36 @@ _SIDE_STREAMS = {}
 SCHED = {"wgrad_late": 1, "conv_wgrad_stream": 2, "fphi_grads_late": 1, "chain_balance": 1, "dq_async": 1}
 
 
+def _dev_key(dev):
+    dev = torch.device(dev)
+    return dev.index if dev.index is not None else torch.cuda.current_device()
+
+
+def fresh_stream(dev):
+    """A pool stream that is none of this package's role streams.  torch.cuda.Stream() hands out its 32 pool streams round-robin:
+    a process that builds many models / trainers gets the SAME hipStream again 32 allocations later, and two roles of one
+    captured step on one hipStream -- the question encoder's stream and the weight-gradient stream it waits on by event -- make
+    the capture's fork / join topology cyclic: hip::Stream::EndCapture then recurses until the stack ends (round 6: a segmentation
+    fault at the 16th ir-fp trainer of one process, found by the multi-seed convergence tool)."""
+    taken = {s.cuda_stream for (d, _w), s in _SIDE_STREAMS.items() if d == _dev_key(dev)}
+    taken.add(torch.cuda.current_stream(dev).cuda_stream)
+    cap = getattr(torch.cuda.graph, "default_capture_stream", None)        # (torch's class-level capture stream, once it exists)
+    if cap is not None:
+        taken.add(cap.cuda_stream)
+    for _ in range(64):
+        s = torch.cuda.Stream(device=dev)
+        if s.cuda_stream not in taken:
+            return s
+    raise RuntimeError("no HIP stream left that is not one of the package's role streams")
+
+
 def _side_stream(dev, which=0):
-    s = _SIDE_STREAMS.get((dev, which))
+    """THE stream of role `which` on `dev`, one per process (0, 1, 2: the backward pass' side streams; "text": the question encoder's;
+    "warmup": the trainer's eager passes in front of a capture): roles never share a hipStream (fresh_stream), instances do."""
+    key = (_dev_key(dev), which)
+    s = _SIDE_STREAMS.get(key)
     if s is None:
-        s = _SIDE_STREAMS[(dev, which)] = torch.cuda.Stream(device=dev)
+        s = _SIDE_STREAMS[key] = fresh_stream(dev)
     return s
 
 
@@ -734,8 +760,20 @@ class RelationalFunction(torch.autograd.Function):
                         inj_out["event"] = side.record_event()
 
             def _join():
-                torch.cuda.current_stream().wait_stream(side)
+                cur = torch.cuda.current_stream()
+                cur.wait_stream(side)
                 keep.clear()
+                #  a question gradient handed over by event that its consumer never took -- the gradient reached the
+                # question encoder's backward as ANOTHER tensor (a second user of the question: the engine accumulated; a tensor
+                # hook; retain_grad) and was read there without the wait: say so, and make this stream wait at least
+                if _GRAD_EVENTS:
+                    import warnings
+                    for ev, _fill in _GRAD_EVENTS.values():
+                        cur.wait_event(ev)
+                    _GRAD_EVENTS.clear()
+                    warnings.warn("the question gradient of the injected layer was handed over by event, but its consumer did not take it "
+                                  "(the question has another user, a hook or retain_grad): it may have been read before it was complete -- "
+                                  "set functional.SCHED['dq_async'] = 0 for such models")
             torch.autograd.Variable._execution_engine.queue_callback(_join)
         else:
             _wgrads_blocked()
@@ -1033,8 +1071,20 @@ class ConvBNReLUFunction(torch.autograd.Function):
             dw.record_stream(main)               # allocated on the side stream, handed to autograd on the main one
 
             def _join():
-                torch.cuda.current_stream().wait_stream(side)
+                cur = torch.cuda.current_stream()
+                cur.wait_stream(side)
                 keep.clear()
+                #  a question gradient handed over by event that its consumer never took -- the gradient reached the
+                # question encoder's backward as ANOTHER tensor (a second user of the question: the engine accumulated; a tensor
+                # hook; retain_grad) and was read there without the wait: say so, and make this stream wait at least
+                if _GRAD_EVENTS:
+                    import warnings
+                    for ev, _fill in _GRAD_EVENTS.values():
+                        cur.wait_event(ev)
+                    _GRAD_EVENTS.clear()
+                    warnings.warn("the question gradient of the injected layer was handed over by event, but its consumer did not take it "
+                                  "(the question has another user, a hook or retain_grad): it may have been read before it was complete -- "
+                                  "set functional.SCHED['dq_async'] = 0 for such models")
             torch.autograd.Variable._execution_engine.queue_callback(_join)
         else:
             din, dw, _ = conv_bwd([ctx.needs_input_grad[0], True, False])

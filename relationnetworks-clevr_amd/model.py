@@ -207,6 +207,7 @@ class RelationalLayer(RelationalLayerBase):
             k += coord.shape[0]
         plan = self._plan(k)
         if self._hooked():
+            self._packed.q_grad_async = False                   # (the permission is ONE relational_forward call's; this path makes none)
             out = self._forward_hook_compat(x, qst, plan)
             return out if label is None else (out, RF.nll_loss_mean(out, label))
         g_w = [l.weight for l in self.g_layers]
@@ -366,7 +367,7 @@ class RN(nn.Module):
         the conv stack.  Joined before the relational layer; capturable in a hipGraph."""
         cur = torch.cuda.current_stream()
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=qst_idxs.device)
+            self._side_stream = RF._side_stream(qst_idxs.device, "text")    # one per process and device: roles never alias (RF.fresh_stream)
         side = self._side_stream
         if after is not None:
             side.wait_event(after)

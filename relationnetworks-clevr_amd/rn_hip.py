@@ -94,6 +94,7 @@ DEBUG_SIGNATURES = {
     "rn_probe_tr8": (_I, [_P, _P, _P]),
     "rn_probe_fp8_cvt": (_I, [_P, C.c_float, _P, _P, _P, _I, _P]),
     "rn_probe_mfma_stream": (_I, [_P, _I, _I, _I, _I, _P]),
+    "rn_probe_mfma_stream_ops": (_I, [_P, _I, _I, _I, _I, _I, _P]),
     "rn_probe_red_schedule": (_I, [_I, _I, _I, _I, _I, _P, _I]),
     "rn_debug_f_phi_wide": (_I, [_I]),
     "rn_debug_gemm_small_below": (_I, [_I]),
@@ -265,10 +266,11 @@ def debug_stamp(buf, slot):
     _check(load().rn_debug_stamp(buf.data_ptr() + 8 * slot, _stream()), "rn_debug_stamp")
 
 
-def probe_mfma_stream(out, workgroups, waves_per_simd, iters, dtype):
+def probe_mfma_stream(out, workgroups, waves_per_simd, iters, dtype, zero_operands=False):
     """Launch the bare MFMA stream (diagnostics: the matrix pipe's sustained rate on this device); returns its flop count."""
     assert out.numel() >= workgroups * 256 * waves_per_simd and out.dtype == torch.float32
-    _check(load().rn_probe_mfma_stream(out.data_ptr(), workgroups, waves_per_simd, iters, {torch.float16: RN_F16, torch.bfloat16: RN_BF16}[dtype], _stream()), "rn_probe_mfma_stream")
+    _check(load().rn_probe_mfma_stream_ops(out.data_ptr(), workgroups, waves_per_simd, iters, {torch.float16: RN_F16, torch.bfloat16: RN_BF16}[dtype],
+                                           int(zero_operands), _stream()), "rn_probe_mfma_stream")
     return workgroups * 4 * waves_per_simd * iters * 16 * 32768.0
 
 
@@ -469,7 +471,7 @@ def g_wgrad_blocked(jobs, M, dxg=None, rows_per_question=0, aligned=False, abl=0
     jobs = [(dZ, A, dW, db), ...]; a job whose dZ is None is a gate job (the last layer: the gate in the sign bits of its e4m3 A image
     x dxg per question).
     aligned: question-aligned row splits (the db partials are then per-question sums of dZ).
-    -> (ws, [db partials (Z, 4, 256) per job]): the workspace must stay alive while the partials are in use."""
+    -> (ws, [db partials (Z, 4, 256) per job] when aligned, else []): the workspace must stay alive while the partials are in use."""
     lib = load()
     nj = len(jobs)
     nb = workspace_bytes(WS_WGRAD_BLOCKED, M, rows_per_question, nj, int(aligned))
@@ -489,8 +491,10 @@ def g_wgrad_blocked(jobs, M, dxg=None, rows_per_question=0, aligned=False, abl=0
         _check(fn(*args, abl), "rn_diag_wgrad_blocked")
     else:
         _check(lib.rn_g_wgrad_blocked(*args), "rn_g_wgrad_blocked")
-    Z = lib.rn_wgrad_blocked_splits(M, rows_per_question, nj, int(aligned))
     parts = []
+    if not aligned:                                           # (split counts per job kind are the library's own: wide / quad units)
+        return ws, parts
+    Z = lib.rn_wgrad_blocked_splits(M, rows_per_question, nj, int(aligned))
     for j in range(nj):
         off = lib.rn_wgrad_blocked_db_partials_offset(M, rows_per_question, nj, int(aligned), j) // 4
         parts.append(ws.view(torch.float32)[off: off + Z * 4 * 256].view(Z, 4, 256))
@@ -519,7 +523,7 @@ def pair_dx_dq(Rj, Ri, Rq, W0, dx, dq, B, n, k, Q, N):
                                 B, n, k, Q, N, _stream()), "rn_pair_dx_dq")
 
 
-@_timed("g_wgrad")
+@_timed("g_wgrad0")
 def wgrad0_from_reductions(Rj, Ri, Rq, x, q, dW0, db0, coord=None):
     B, n, kf = x.shape
     k = kf + (coord.shape[0] if coord is not None else 0)      # coord (k - kf, n): the coordinate tags are not part of x

@@ -34,6 +34,17 @@ def test_default_line_reports_the_dominant_kernels_roofline():
     assert "g_chain_rr_f16s_kernel" in g["kernel"] and 0.0 < g["frac"] < 1.0 and 0.0 < g["frac_executed"] < g["frac"]
     assert d["dtype"] == "f16s" and d["parity"]["meets_1e-3"] is True and d["vs_baseline"] is None
     assert "value_definition" in d and d["config"]["workload"].startswith("original-fp train step")
+    # an entry's flops are those of exactly what its launches compute.  The weight-gradient launch is dW_1..3
+    # (3 x 2 M 256^2); layer 0's weight gradient -- another launch on another stream -- is an entry of its own (2 M 180 256)
+    M = 64 * 64 * 64
+    assert r["kernel_key"] == "g_wgrad" and r["algorithmic_flops_per_launch"] == 3 * 2 * M * 256 ** 2
+    assert r["kernels"]["g_wgrad0"]["algorithmic_flops"] == 2 * M * 180 * 256 and r["kernels"]["g_dgrad"]["algorithmic_flops"] == 3 * 2 * M * 256 ** 2
+    assert r["kernels"]["g_fwd"]["algorithmic_flops"] == 2 * M * (180 + 3 * 256) * 256
+    # the dominant launch on its own beside its in-step bracket; the MFMA-stream probe is a diagnostic, never a denominator
+    assert 0.0 < r["frac_alone"] < 1.0 and abs(r["frac_alone"] - r["algorithmic_flops_per_launch"] / (r["ms_alone"] * 1e-3) / 1e12 / r["peak"]) < 1e-9
+    assert "frac_of_sustained" not in r and "sustained_mfma" not in r
+    pr = r["diagnostics"]["mfma_stream_probe"]
+    assert 0 < pr["bf16"]["tflops"] <= pr["bf16_zero_operands"]["tflops"] * 1.05 and pr["bf16_zero_operands"]["tflops"] < 2600
     for kk, v in r["kernels"].items():                                 # traffic is the tracked PMC summary's or null, never invented
         assert v["traffic"] is None or (v["traffic_source"].startswith("profiles/") and v["traffic"] > 0.5 * v["algorithmic_hbm_bytes"])
 

@@ -115,3 +115,19 @@ def test_copy_guard_switches_to_16_bit_copies(pkg, monkeypatch):
     with contextlib.redirect_stdout(io.StringIO()):
         m2 = pkg.RN(A, hyp)
     assert m2.rl._packed.h8 is True
+
+
+def test_many_trainers_in_one_process_keep_their_streams_apart(pkg):
+    """Round 6: the 16th ir-fp trainer of one process died inside hipStreamEndCapture (stack overflow in hip::Stream::EndCapture).
+    torch.cuda.Stream() hands out 32 pool streams round-robin, every model took one for its question encoder and every trainer one
+    for its warm-up, so after 16 of them the encoder's stream WAS the weight-gradient stream it waits on by event -- a cyclic fork /
+    join topology.  Role streams are now one per process and role (functional._side_stream) and never alias: 20 trainers, each
+    captured and replayed, and the role streams are pairwise distinct hipStreams."""
+    from relationnetworks_clevr_amd import train as T
+    for i in range(20):
+        r = T.convergence_run("auto", steps=3, batch=8, model_name="ir-fp", seed=i, eval_batches=1, log_every=1, task="pairs_dev")
+        assert np.isfinite(r["loss"]).all(), (i, r["loss"])
+    RF = pkg.functional
+    handles = [s.cuda_stream for s in RF._SIDE_STREAMS.values()]
+    assert len(handles) >= 4 and len(set(handles)) == len(handles), handles
+    assert torch.cuda.current_stream().cuda_stream not in handles

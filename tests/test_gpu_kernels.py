@@ -801,10 +801,17 @@ def test_wgrad_blocked_three_jobs(H, B, n, a8):
     again, _ = run([0, 1, 2])
     dz3 = dxg.double().repeat_interleave(n * n, 0) * gate_image_ref(mask, M)
     Z = H.wgrad_blocked_splits(M, n * n, 3, aligned=True)
-    free3, _ = run([0, 1, 2], aligned=False)                   # ~64 / 3 splits per job, not question-aligned: same sums, other order
+    # not question-aligned -- the product launch: on e4m3 activations the stored gradients run as WIDE units (one workgroup per row
+    # split holds the whole 256 x 256 dW, db from in-lane dot products) beside the gate job's quad units; same sums, other order
+    free3, _ = run([0, 1, 2], aligned=False)
+    free3b, _ = run([0, 1, 2], aligned=False)
     for j in range(3):
         assert torch.equal(all3[j][0], again[j][0]) and torch.equal(all3[j][1], again[j][1]), j
+        assert torch.equal(free3[j][0], free3b[j][0]) and torch.equal(free3[j][1], free3b[j][1]), j          # bitwise repeatable
         assert rel(free3[j][0].cpu().numpy(), all3[j][0].cpu().numpy()) <= 2e-5 and rel(free3[j][1].cpu().numpy(), all3[j][1].cpu().numpy()) <= 2e-5, j
+        dzj = (dxg.double().repeat_interleave(n * n, 0) * gate_image_ref(mask, M)) if (a8 and j == 2) else dZ[j].double()
+        assert rel(free3[j][0].cpu().numpy(), (dzj.t() @ Hc[j].double()).cpu().numpy()) <= 2e-5, j
+        assert rel(free3[j][1].cpu().numpy(), dzj.sum(0).cpu().numpy()) <= 2e-5, j
         if H.wgrad_blocked_splits(M, n * n, 1, aligned=True) == Z:       # (same splits alone and in the launch of three: bitwise)
             single, _ = run([j])
             assert torch.equal(all3[j][0], single[0][0]) and torch.equal(all3[j][1], single[0][1]), j
@@ -823,8 +830,10 @@ def test_wgrad_blocked_three_jobs(H, B, n, a8):
 
 
 def test_wgrad_fp8_operand(H):
-    """The activation operand as an e4m3 image (a_dtype = RN_FP8): every e4m3 value is a bf16 value and both images put a pair
-    row into the same MFMA k slot, so the kernel must give -- bitwise -- what it gives on the same values stored as bf16."""
+    """The activation operand as an e4m3 image (a_dtype = RN_FP8): every e4m3 value is a bf16 value, so both images must give the
+    float64 product to fp32-accumulation accuracy -- the e4m3 one as WIDE units (round 6: one workgroup per row split, other
+    split count and add order than the bf16 image's quad units) -- and, on the SAME mapping (quad units, an `aligned` launch),
+    bitwise the same sums: both images put a pair row into the same MFMA k slot."""
     B, n, G = 17, 64, 256
     M = B * n * n
     g = torch.Generator(device="cuda").manual_seed(11)
@@ -840,9 +849,18 @@ def test_wgrad_fp8_operand(H):
         H.g_wgrad_blocked([(dZb, H.rows_to_blocked(A), dW, db)], M, rows_per_question=n * n)
         out.append((dW, db))
     torch.cuda.synchronize()
-    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     ref = dZ.double().t() @ A8.double()
-    assert rel(out[1][0].cpu().numpy(), ref.cpu().numpy()) <= 1e-5
+    refb = dZ.double().sum(0)
+    for dW, db in out:
+        assert rel(dW.cpu().numpy(), ref.cpu().numpy()) <= 1e-5 and rel(db.cpu().numpy(), refb.cpu().numpy()) <= 1e-5
+    # the same mapping (quad units; what an `aligned` launch runs on either image) is bitwise the same on both images
+    outq = []
+    for A in (A16, A8):
+        dW = torch.full((G, G), float("nan"), device="cuda"); db = torch.full((G,), float("nan"), device="cuda")
+        H.g_wgrad_blocked([(dZb, H.rows_to_blocked(A), dW, db)], M, rows_per_question=n * n, aligned=True)
+        outq.append((dW, db))
+    torch.cuda.synchronize()
+    assert torch.equal(outq[0][0], outq[1][0]) and torch.equal(outq[0][1], outq[1][1])
 
 
 @pytest.mark.parametrize("B,npairs", [(2, 512), (24, 32 * 100), (16, 144)])

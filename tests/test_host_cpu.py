@@ -62,7 +62,11 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sp(64 * 4096, 4096, 1, 1) == 64 and sp(32 * 4096, 4096, 1, 1) == 32 and sp(3 * 4096, 4096, 1, 1) == 48 and sp(128 * 4096, 4096, 1, 1) == 128
     assert sp(17 * 4096, 4096, 1, 1) == 34 and sp(32 * 38416, 38416, 1, 1) == 48 and sp(64 * 4096, 4096, 3, 1) == 64 and sp(4 * 4096, 4096, 3, 1) == 16
     assert sp(64 * 4096, 4096, 5, 0) == 0
-    assert ws(Hm.WS_WGRAD_BLOCKED, 64 * 4096, 4096, 3, 0) == 3 * (16 * 65536 + 16 * 4 * 256) * 4
+    # workspace: one fp32 256 x 256 partial tile + 4 db rows per row split; not aligned: the most splits any mix of wide (one
+    # workgroup per split) and quad (four) jobs gets out of 4 x 48 workgroups -- three wide jobs: 3 x 64; aligned: uniform splits
+    assert ws(Hm.WS_WGRAD_BLOCKED, 64 * 4096, 4096, 3, 0) == 192 * (65536 + 4 * 256) * 4
+    assert ws(Hm.WS_WGRAD_BLOCKED, 64 * 4096, 4096, 3, 1) == 3 * 64 * (65536 + 4 * 256) * 4
+    assert ws(Hm.WS_WGRAD_BLOCKED, 2 * 1024, 1024, 1, 0) == 32 * (65536 + 4 * 256) * 4        # (never more splits than 64-row steps)
 
 
 def test_library_and_hot_path_never_read_the_environment(pkg):
