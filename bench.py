@@ -415,6 +415,36 @@ def max_over_ranks(dt, world, device):
     return dt
 
 
+# ---- a failed run still prints ONE JSON line on rank 0 (the first real N > 1 run is a one-shot -- whatever goes
+# wrong, the line says how far the job got: ranks seen, where the gradient exchange was running, why it fell back)
+FAIL = {"rank": 0, "world": 1, "args": None, "trainer": None, "ranks_seen": None, "phase": "start-up", "printed": False, "backend": None}
+
+
+def failure_line(reason):
+    a, tr = FAIL["args"], FAIL["trainer"]
+    comm = {"ranks_seen": FAIL["ranks_seen"], "exchange_mode": None, "exchange_fallback": None, "exchange_checks": None,
+            "allreduce_us_per_step": None, "backend": FAIL["backend"]}
+    if tr is not None:
+        try:
+            comm.update({"exchange_mode": tr.exchange_mode(), "exchange_fallback": tr.exchange_fallback, "exchange_checks": tr.exchange_checks})
+        except Exception:
+            pass
+    return {"metric": "CLEVR questions/sec (train fwd+bwd)", "value": None, "unit": "questions/s", "n_gpus": FAIL["world"],
+            "steps": getattr(a, "steps", None), "warmup": getattr(a, "warmup", None), "ms_per_step": None, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "data": "synthetic", "failed": True, "error": str(reason)[:600], "phase": FAIL["phase"],
+            "comm": comm}
+
+
+def print_failure(reason):
+    if FAIL["rank"] == 0 and not FAIL["printed"]:
+        FAIL["printed"] = True
+        try:
+            sys.stdout.write(json.dumps(failure_line(reason)) + "\n")
+            sys.stdout.flush()
+        except Exception:
+            pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -443,6 +473,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("RN_BENCH_BACKEND", "nccl")     # "gloo" + RN_BENCH_DRY=1: launch-plumbing dry run on CPU (tests)
     dry = os.environ.get("RN_BENCH_DRY", "0") == "1"
+    FAIL.update(rank=rank, world=world, args=args, backend=backend)
+    if world > 1:
+        import signal
+
+        def _terminated(signum, frame):                 # (torch.distributed.run tears the job down when ANOTHER rank died)
+            print_failure("terminated by signal %d in phase '%s' (another rank failed?)" % (signum, FAIL["phase"]))
+            os._exit(128 + signum)
+        signal.signal(signal.SIGTERM, _terminated)
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     if dry:
@@ -494,6 +532,9 @@ def main():
     # copy_guard_every=0: the e4m3 copy guard (an eager forward + a host sync every 512 steps) runs ONCE, in front of the capture, and
     # then stays out of the timed / sustained windows; train.py keeps the periodic guard
     trainer = dp.DataParallelTrainer(model, opt, clip_norm=50.0, use_graph=use_graph, copy_guard_every=0, single_rank_exchange=one_rank)
+    FAIL.update(trainer=trainer, phase="trainer built")
+    if multi:
+        dp.Watchdog.on_expire = lambda what, seconds: print_failure("watchdog: no progress for %.0f s in: %s" % (seconds, what))
     img, qst, lab = make_batch(B, dev, args.hw, state_desc=state_desc)
     if use_graph:
         trainer.check_activation_copies(img, qst, lab)
@@ -502,6 +543,7 @@ def main():
     if multi:
         with wd.guard("bench: roll call of the ranks", wd_s):
             ranks_seen = trainer.ctl.ranks_seen()
+        FAIL.update(ranks_seen=ranks_seen, phase="roll call done")
         if ranks_seen != list(range(world)):
             raise SystemExit("bench: expected ranks %r, saw %r" % (list(range(world)), ranks_seen))
 
@@ -523,6 +565,7 @@ def main():
                 d_.copy_(s_)
         img, qst, lab = bufs
     # ---- timed region: W warm-up steps, then exactly K steps, barrier + synchronize on both sides
+    FAIL["phase"] = "step graph captured (exchange: %s)" % trainer.exchange_mode()
     H.TIMER.enabled = False
     with wd.guard("bench: warm-up + timed region (%d + %d steps)" % (args.warmup, args.steps), wd_s):
         dt, loss = timed_steps(lambda: trainer.step(img, qst, lab), args.steps, args.warmup, sync)
@@ -814,6 +857,7 @@ def main():
                 # BASELINE.md section 3's second CPU figure: configs[0], the reference's own CPU-runnable case (~10 ms per step)
                 out["cpu_baseline_sd4"] = cpu_baseline("original-sd", 4, 128, warm=5, steps=50)
         print(json.dumps(out))
+        FAIL["printed"] = True
     if multi:
         dist.destroy_process_group()
 
@@ -830,6 +874,9 @@ def dry_run(args, world, rank, backend):
         if world > 1:
             dist.barrier()
 
+    FAIL["phase"] = "dry run: process group up"
+    if os.environ.get("RN_BENCH_DRY_FAIL_RANK", "") == str(rank):      # (tests: one rank dies -- rank 0 must still print its failure line)
+        raise RuntimeError("injected failure on rank %d" % rank)
     # ranks take different times per step: the MAX over ranks must be what is reported
     dt, _ = timed_steps(lambda: time.sleep(0.001 * (rank + 1)), args.steps, args.warmup, sync)
     dt = max_over_ranks(dt, world, "cpu")
@@ -843,4 +890,12 @@ def dry_run(args, world, rank, backend):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit as e:
+        if e.code not in (0, None):
+            print_failure("exit: %s" % (e.code,))
+        raise
+    except BaseException as e:
+        print_failure("%s: %s" % (type(e).__name__, e))
+        raise

@@ -140,6 +140,9 @@ __global__ __launch_bounds__(256) void pair_build_kernel(const float* __restrict
   // head chunks are read from LDS per row (the chunk that straddles column k is merged in registers: lanes of x_j under
   // the mask, x_i above it).  rpp rows per pass, consecutive lanes -> consecutive 16 B of consecutive rows (one contiguous
   // rpp * ld * sizeof(T) byte burst per pass).
+  // (round 6, measured and not adopted: the (b, i) span as one flat run of chunks, 256 per pass -- every lane stores in every pass
+  //  where rows-per-pass leaves 14 % of the store slots empty at ld = 192, but the j-independent chunk then comes from LDS per store
+  //  instead of from a register: 20.1 / 20.4 us against 19.5 / 20.0 alternating on one box; the kernel is not store-issue bound)
   const int rpp = 256 / cpr;                         // rows per pass (threads beyond rpp * cpr idle in the copy)
   if (rpp > 0) {
     const int jr = t / cpr, c = t - jr * cpr;

@@ -48,11 +48,17 @@ class Watchdog:
     down.  seconds <= 0: no deadline."""
 
     EXIT_CODE = 124
+    on_expire = None          # optional callable(what, seconds), run before the exit (bench.py: its one JSON line, marked as a failure)
 
     def __init__(self, rank=0):
         self.rank = rank
 
     def _expire(self, what, seconds):
+        if Watchdog.on_expire is not None:
+            try:
+                Watchdog.on_expire(what, seconds)
+            except Exception:
+                pass
         sys.stderr.write("[relationnetworks_clevr_amd] rank %d: no progress for %.0f s in: %s -- giving up (exit %d).  "
                          "If this is the in-graph gradient all-reduce, re-run with RN_NO_GRAPH_ALLREDUCE=1.\n"
                          % (self.rank, seconds, what, self.EXIT_CODE))

@@ -66,7 +66,7 @@ class ConvInputModel(nn.Module):
             conv, bn = self._modules["conv%d" % i], self._modules["batchNorm%d" % i]
             hw = ((x.shape[2] + 2 * conv.padding[0] - 3) // conv.stride[0] + 1) * ((x.shape[3] + 2 * conv.padding[1] - 3) // conv.stride[1] + 1)
             if fused and hw % 4 == 0 and bn.track_running_stats and bn.momentum is not None:
-                # MIOpen convolution + the fused batch-norm / ReLU kernels (rn_convnorm.hip)
+                # the package's own stride-2 3x3 convolution (rn_conv.hip) + the fused batch-norm / ReLU kernels (rn_convnorm.hip)
                 x = RF.ConvBNReLUFunction.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                                 bn.num_batches_tracked, self.training, bn.momentum, bn.eps, conv.stride, conv.padding)
             else:

@@ -152,6 +152,7 @@ def test_watchdog_exits_instead_of_blocking():
     code = ("import sys, time; sys.path.insert(0, %r)\n"
             "from relationnetworks_clevr_amd import dp\n"
             "wd = dp.Watchdog(rank=3)\n"
+            "dp.Watchdog.on_expire = lambda what, s: print('HOOK ' + what, flush=True)\n"
             "with wd.guard('quick region', 5.0):\n    time.sleep(0.05)\n"
             "print('survived', flush=True)\n"
             "with wd.guard('replay of the step graph', 0.3):\n    time.sleep(30)\n"
@@ -159,6 +160,7 @@ def test_watchdog_exits_instead_of_blocking():
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert p.returncode == 124, (p.returncode, p.stderr[-500:])
     assert "survived" in p.stdout and "not reached" not in p.stdout
+    assert "HOOK replay of the step graph" in p.stdout and "HOOK quick" not in p.stdout      # (bench.py hangs its failure line on this hook)
     assert "rank 3" in p.stderr and "replay of the step graph" in p.stderr and "RN_NO_GRAPH_ALLREDUCE" in p.stderr
 
 
@@ -239,3 +241,32 @@ def test_bench_launch_plumbing_dry_run_two_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["config"]["global_batch"] == 128
     assert d["ms_per_step"] >= 2.0          # rank 1 sleeps 2 ms per step, rank 0 only 1 ms: the MAX over ranks won
     assert abs(d["value"] - 2 * 64 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_prints_one_failure_line_whatever_goes_wrong():
+    """the first real N > 1 run is a one-shot, so a bench that fails must still leave ONE JSON line on rank 0 that
+    says how far it got (`failed`, `error`, `phase`, `n_gpus`, `comm.exchange_mode / exchange_fallback / ranks_seen /
+    allreduce_us_per_step`).  (a) a launch without torch.distributed.run; (b) two ranks over gloo (dry run) of which rank 1 raises:
+    torch.distributed.run tears rank 0 down with SIGTERM, and rank 0's handler prints the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert p.returncode != 0
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["failed"] is True and d["value"] is None and "torch.distributed.run" in d["error"]
+    assert set(d["comm"]) >= {"exchange_mode", "exchange_fallback", "ranks_seen", "allreduce_us_per_step"}
+    env = dict(os.environ, RN_BENCH_DRY="1", RN_BENCH_BACKEND="gloo", RN_BENCH_DRY_FAIL_RANK="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "400", "--warmup", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (p.stdout, p.stderr[-1500:])
+    d = json.loads(lines[0])
+    # (rank 0 either sees its collective break -- "Connection closed by peer" -- or is torn down by the launcher's SIGTERM first)
+    assert d["failed"] is True and d["n_gpus"] == 2 and d["steps"] == 400 and d["error"] and "dry run" in d["phase"]

@@ -29,6 +29,23 @@ def _free_port():
     return p
 
 
+# ---- FIRST when two devices are visible: the N > 1 path over RCCL, so that a failure there names its cause
+# before anything else of this file runs.  (Helpers are defined further down: resolved at call time.)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the RCCL (backend nccl) all-reduce over xGMI")
+@pytest.mark.parametrize("cfg", ["original-fp"])
+def test_two_ranks_over_rccl_equal_one_rank_on_the_whole_batch(tmp_path, cfg):
+    """The same assertion with one rank per DEVICE and backend "nccl" (= RCCL on ROCm) -- the configuration the reference's
+    DataParallel wrap stands for (train.py:256-258) and the driver's SCALE run uses.  Runs wherever two GPUs are visible."""
+    _check_two_ranks_against_one(tmp_path, cfg, "nccl")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: an asymmetric capture failure over RCCL")
+def test_two_ranks_over_rccl_agree_on_the_fallback_when_one_capture_fails(tmp_path):
+    """the same injected one-rank capture failure as test_exchange_fallback_is_agreed_by_all_ranks, but over RCCL on two
+    devices -- the configuration in which a rank-local decision would hang the job inside a real ring kernel."""
+    _check_two_ranks_against_one(tmp_path, "original-fp", "nccl", inject="rank1")
+
+
 def test_backward_writes_gradients_into_the_bucket_only_when_autograd_assigns():
     """functional.grad_out: with a FlatGradBucket registered and .grad = None (the trainer's gather mode) every parameter
     gradient of the whole model is produced in its slot of the flat buffer -- gather_() launches nothing -- and equals, bitwise,
@@ -281,14 +298,6 @@ def test_exchange_fallback_is_agreed_by_all_ranks(tmp_path, inject):
     _check_two_ranks_against_one(tmp_path, "original-fp", "gloo", inject=inject)
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the RCCL (backend nccl) all-reduce over xGMI")
-@pytest.mark.parametrize("cfg", ["original-fp"])
-def test_two_ranks_over_rccl_equal_one_rank_on_the_whole_batch(tmp_path, cfg):
-    """The same assertion with one rank per DEVICE and backend "nccl" (= RCCL on ROCm) -- the configuration the reference's
-    DataParallel wrap stands for (train.py:256-258) and the driver's SCALE run uses.  Runs wherever two GPUs are visible."""
-    _check_two_ranks_against_one(tmp_path, cfg, "nccl")
-
-
 @pytest.mark.parametrize("cfg,B", [("original-fp", 64), ("ir-fp", 16), ("original-sd", 8)])
 def test_captured_step_gradient_is_bitwise_reproducible(cfg, B):
     """The product step (BatchNorm in training mode, dropout on, the default arithmetic) replayed with lr = 0: the parameters stay
@@ -431,6 +440,6 @@ def test_bench_n_gt_1_path_over_one_rank_rccl():
     assert "all-reduce" in d["config"]["launch"]
     c = d["comm"]
     assert c["backend"] == "nccl" and c["ranks_seen"] == [0] and c["exchange_mode"] == "in-graph" and c["exchange_fallback"] is None
-    assert c["exchange_checks"] == {"self_check": "passed", "capture": "ok", "first_step_signatures_equal": True}
+    assert c["exchange_checks"] == {"self_check": "passed", "capture": "ok", "first_step_all_finite": True, "first_step_signatures_equal": True}
     assert c["allreduce_bytes"] == 4 * 484580 and c["allreduce_us_per_step"] > 0 and c["watchdog_s"] > 0
     assert d["sustained"]["steps"] >= 5 and d["sustained"]["value"] > 0

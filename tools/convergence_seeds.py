@@ -12,8 +12,6 @@ Per run: `exit_step` = first step at which the trailing 250-step mean loss is be
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
-import relationnetworks_clevr_amd as pkg
-from relationnetworks_clevr_amd import train as T
 
 MODES = {"fp32": ("fp32", None), "auto": ("auto", True), "auto16": ("auto", False), "bf16": ("bf16", True)}
 
@@ -37,7 +35,14 @@ def main():
     ap.add_argument("--modes", default="fp32,auto,auto16")
     ap.add_argument("--eval-batches", type=int, default=32)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "convergence_seeds.jsonl"))
+    ap.add_argument("--summary-of", default=None, metavar="JSONL", help="no runs: print the summary tables of an earlier --out file")
     a = ap.parse_args()
+    if a.summary_of:
+        rows = [json.loads(ln) for ln in open(a.summary_of) if ln.strip()]
+        print("# %d runs of %s: %s" % (len(rows), os.path.basename(a.summary_of), sorted({(r["model"], r["mode"]) for r in rows})))
+        return summarize(rows, sorted({r["model"] for r in rows}, reverse=True), [m for m in MODES if any(r["mode"] == m for r in rows)])
+    import relationnetworks_clevr_amd as pkg                # (imported here: --summary-of and the tests' use of exit_step need no GPU)
+    from relationnetworks_clevr_amd import train as T
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     rows = []
     with open(a.out, "a") as f:
@@ -59,10 +64,14 @@ def main():
                     gc.collect()
                     print("%-11s %-6s seed %d: exit %s final %.4f acc %.4f (%.1f s; %.1f GB allocated)" % (
                         model, mode, seed, row["exit_step"], row["final_loss"], row["accuracy"], row["seconds"], torch.cuda.memory_allocated() / 1e9), flush=True)
+    summarize(rows, a.models.split(","), a.modes.split(","))
+
+
+def summarize(rows, models, modes):
     print("\n# summary: mean +- s.d. over seeds (exit_step over the runs that left the plateau; `stuck` = runs that did not within --steps)")
     print("%-11s %-6s %2s  %-16s %-5s %-18s %-16s" % ("model", "mode", "n", "exit_step", "stuck", "final_loss", "accuracy"))
-    for model in a.models.split(","):
-        for mode in a.modes.split(","):
+    for model in models:
+        for mode in modes:
             c = [r for r in rows if r["model"] == model and r["mode"] == mode]
             if not c:
                 continue
@@ -71,6 +80,20 @@ def main():
             print("%-11s %-6s %2d  %7.0f +- %-5.0f %-5d %.4f +- %-8.4f %.4f +- %.4f" % (
                 model, mode, len(c), np.mean(ex) if ex else float("nan"), np.std(ex) if ex else float("nan"), len(c) - len(ex),
                 np.mean(fl), np.std(fl), np.mean(ac), np.std(ac)))
+    print("\n# paired differences to fp32, same seed (= same initial weights, same batches): mean, s.d., standard error, t = mean / s.e.")
+    for model in models:
+        by = {(r["mode"], r["seed"]): r for r in rows if r["model"] == model}
+        seeds = sorted({s_ for (_m, s_) in by})
+        for mode in modes:
+            if mode == "fp32":
+                continue
+            pairs = [(by[(mode, s_)], by[("fp32", s_)]) for s_ in seeds if (mode, s_) in by and ("fp32", s_) in by]
+            if len(pairs) < 2:
+                continue
+            for key in ("accuracy", "final_loss", "exit_step"):
+                d = np.array([a_[key] - b_[key] for a_, b_ in pairs if a_[key] is not None and b_[key] is not None], dtype=np.float64)
+                se = d.std(ddof=1) / np.sqrt(len(d))
+                print("%-11s %-6s - fp32  %-10s n %2d  mean %+9.4f  s.d. %8.4f  s.e. %8.4f  t %+5.2f" % (model, mode, key, len(d), d.mean(), d.std(ddof=1), se, d.mean() / se))
 
 
 if __name__ == "__main__":
