@@ -214,14 +214,19 @@ int rn_g_linear_bwd_wgrad(const void* dZ, int lddz, const void* A, int lda, floa
  * activation bytes meet on the fp8 matrix pipe (exact products), and each question's sums are scaled by its row of dxg
  * (M / rows_per_question, 256) fp32 -- un-rounded, i.e. closer to the fp32 reference than a stored bf16 dZ_3 -- when the
  * question ends; rows_per_question % 64 == 0 then (otherwise it only steers the row splits; 0 = unknown).  M % 64 == 0.
- * Z = rn_wgrad_blocked_splits(M, rows_per_question, njobs, aligned) row splits per job (0: shape not covered): about 64 / njobs,
- * so that the njobs x Z x 4 workgroups of a launch fill the chip once and all jobs stream at the same time; with aligned != 0
- * a count that never lets a split straddle two questions (Z = B * d for a divisor d of the 64-row steps per question, or B
- * itself) when one exists within 256.
- * ws: rn_workspace_bytes(RN_WS_WGRAD_BLOCKED, M, rows_per_question, njobs, aligned) bytes.  Afterwards ws holds, at
- * rn_wgrad_blocked_db_partials_offset(M, rows_per_question, njobs, aligned, j), (Z, 4, 256) fp32: four partial column sums of
- * dZ[j] over the 64-row steps [z*S/Z, (z+1)*S/Z) (S = M / 64) of split z -- per-question sums of dZ for free when the splits
- * are question-aligned.  Deterministic (fixed-order reduction).  dZ / dz_dtype / A / dW / db: HOST arrays. */
+ * Row splits.  aligned != 0 (or a_dtype = RN_BF16): Z = rn_wgrad_blocked_splits(M, rows_per_question, njobs, aligned) splits per job
+ * (0: shape not covered), four workgroups (a 128 x 128 block of dW each) per split, about 48 / njobs so that the njobs x Z x 4
+ * workgroups fill three quarters of the chip and all jobs stream at the same time; the count never lets a split straddle two questions
+ * (Z = B * d for a divisor d of the 64-row steps per question, or B itself) when one exists within 256.  aligned == 0 on e4m3 images
+ * (the product launch, round 6): a stored-gradient job runs as WIDE units -- ONE workgroup per split holds the whole 256 x 256 dW
+ * (128 x 128 per wave in accumulator registers, every operand byte read once, db from in-lane dot products) --, a gate job keeps
+ * the four-workgroup form, and the library picks the split counts of both kinds so that their workgroups finish together on the
+ * same budget of workgroups (not exported: nothing outside reads them).
+ * ws: rn_workspace_bytes(RN_WS_WGRAD_BLOCKED, M, rows_per_question, njobs, aligned) bytes (sized for the most splits any mix of job
+ * kinds can get).  With aligned != 0, afterwards ws holds, at rn_wgrad_blocked_db_partials_offset(M, rows_per_question, njobs,
+ * aligned, j), (Z, 4, 256) fp32: four partial column sums of dZ[j] over the 64-row steps [z*S/Z, (z+1)*S/Z) (S = M / 64) of split z
+ * -- per-question sums of dZ for free, the splits being question-aligned.  Deterministic either way (fp32 partial tiles, fixed-order
+ * reduction launch: bitwise repeatable).  dZ / dz_dtype / A / dW / db: HOST arrays. */
 int rn_wgrad_blocked_splits(int M, int rows_per_question, int njobs, int aligned);
 size_t rn_wgrad_blocked_db_partials_offset(int M, int rows_per_question, int njobs, int aligned, int job);
 int rn_g_wgrad_blocked(const void* const* dZ, const int* dz_dtype, const void* const* A, int a_dtype, const float* dxg,

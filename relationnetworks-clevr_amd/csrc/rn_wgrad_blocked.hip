@@ -566,12 +566,16 @@ __global__ __launch_bounds__(256) void wgrad_blocked_reduce_kernel(KbArgs a, int
 // as per-question sums of dZ): a count that never lets a split straddle two questions -- Z = B * d, d | steps per question, as
 // close to the target as such a count gets, or B itself -- when one exists within 256 splits.
 int kb_total_units() {
-  // 48 row splits over all jobs = 192 workgroups: three quarters of the chip.  The launch runs on a side stream beside the
-  // latency-bound kernels that close the backward pass (pair reduction, dx / dq, the conv stack's backward); with a workgroup
-  // on every CU (64 splits) those kernels wait for CU slots and stretch 3-5x -- measured on the whole step, same box: 64 ->
-  // 0.983 ms, 54 -> 0.955, 48 -> 0.931, 42 -> 0.944, 36 -> 0.976 (the kernel alone is fastest at 64).
+  // The row-split budget: 4 x RN_KB_TOTAL workgroups, one per CU.  The launch runs on a side stream beside the latency-bound kernels
+  // that close the backward pass (pair reduction, dx / dq, the conv stack's backward); with a workgroup on every CU those kernels
+  // wait for CU slots and stretch 3-5x.  Rounds 4-5 (quad units only, launch behind the partial sums): 48 = 192 workgroups, three
+  // quarters of the chip (64 -> 0.983 ms, 54 -> 0.955, 48 -> 0.931, 42 -> 0.944, 36 -> 0.976 on the whole step).  Round 6, with
+  // the wide units (the launch lost 34 us and left the step's critical path): re-swept on the whole step, alternating on one box --
+  // 32 / 36 / 40 / 44 / 48 / 52 / 56 / 64: 96.8 / 96.9 / 97.7 / 95.9 / 96.1 / 97.2 / 91.2 / 91.8 k q/s with the launch where it was,
+  // and launched right behind the backward chain (functional.SCHED "wgrad_late": 0 for models without question injection)
+  // 32 / 36 / 40 / 44: 99.9 / 99.4 / 100.5 / 92.1 -- 40 = 160 workgroups (profiles/r06_ablations/ab_kb_total_wide*.txt).
 #ifndef RN_KB_TOTAL
-#define RN_KB_TOTAL 48
+#define RN_KB_TOTAL 40
 #endif
   int total = RN_KB_TOTAL;
   if (const char* e = rn_diag_env("RN_KB_TOTAL")) total = atoi(e) > 0 ? atoi(e) : total;      // (diagnostics builds)

@@ -190,12 +190,16 @@ HANDED_BY_EVENT = [0]                              # how many gradients went tha
 _SIDE_STREAMS = {}
 # Launch-order choices of the backward pass that only measurements decide (the captured graph's queue order): kept as named knobs so that
 # tools/dbg/exp_bench.py can A/B them on one box.  wgrad_late: 0 the g_theta weight-gradient launch right behind the backward chain,
-# 1 behind the partial sums AND the layer-0 stream (default), 2 behind dx / dq too, 3 behind the partial sums only;
+# 1 behind the partial sums AND the layer-0 stream, 2 behind dx / dq too, 3 behind the partial sums only; -1 (default, round 6) =
+# 0 for models without question injection, 1 for the injected ones (ir-*: their question gradient comes off this stream) -- with the
+# wide-unit kernel on 160 workgroups the early launch is over before the conv stack's heavy last kernels start: original-fp
+# 97.8 -> 100.4 k q/s, the 14 x 14 stress shape 13.4 -> 14.05 k, B = 640 +-0; ir-fp 91.2 -> 82.7 k with it, hence not there
+# (profiles/r06_ablations/ab_kb_total_wide2.txt);
 # conv_wgrad_stream: the side stream the conv weight gradients share (0 the g_theta weight gradient's, 2 the layer-0 stream's);
 # fphi_grads_late: f_phi's parameter gradients on the layer-0 stream instead of in front of the backward chain;
 # chain_balance: the reducing backward chain's units beyond a whole number of rounds over the CUs run tile by tile (0: whole units only);
 # dq_async: the question gradient of a question-injected layer is handed to the question encoder's backward by event (0: the main stream waits for it).
-SCHED = {"wgrad_late": 1, "conv_wgrad_stream": 2, "fphi_grads_late": 1, "chain_balance": 1, "dq_async": 1}
+SCHED = {"wgrad_late": -1, "conv_wgrad_stream": 2, "fphi_grads_late": 1, "chain_balance": 1, "dq_async": 1}
 
 
 def _dev_key(dev):
@@ -749,7 +753,8 @@ class RelationalFunction(torch.autograd.Function):
         # (tools/dbg/exp_bench.py wgrad_late=2 | 3).  The question-injected models took dq from the launch's per-question sums through round 4 (early
         # launch); since round 5 the sums are a pass of their own in FRONT of the late launch and dq is handed to its consumer by event
         # (dq_by_event above: +5 % on ir-fp -- with the main stream waiting for dq the same change measured -0.5 %).
-        late = overlap and SCHED["wgrad_late"] and (not inj or dq_by_event)
+        late_mode = SCHED["wgrad_late"] if SCHED["wgrad_late"] >= 0 else (1 if inj else 0)
+        late = overlap and late_mode and (not inj or dq_by_event)
         if overlap:
             main, side = torch.cuda.current_stream(), _side_stream(dev)
             if not late:
@@ -847,7 +852,7 @@ class RelationalFunction(torch.autograd.Function):
                     keep.append(ctx.fphi_job[1])
                     ctx.fphi_job = None
                 _wgrad0()
-            if not (late and SCHED["wgrad_late"] == 3):
+            if not (late and late_mode == 3):
                 side.wait_stream(s0)
             # x and q too: they are alive only through this node's saved tensors, which autograd releases as soon as
             # backward() returns -- the caching allocator would hand their blocks to the conv / LSTM backward that the
@@ -870,7 +875,7 @@ class RelationalFunction(torch.autograd.Function):
         else:
             H.pair_dx_dq(Rj, Ri, None, wl, dx, None, B, n, k, 0, N)                # (dq came from the injected layer)
         if late:
-            if SCHED["wgrad_late"] == 2:
+            if late_mode == 2:
                 side.wait_stream(main)                             # behind dx / dq
             else:
                 side.wait_event(late_ev)                           # behind the partial sums only
@@ -878,7 +883,7 @@ class RelationalFunction(torch.autograd.Function):
                 _wgrads_blocked()
                 if "question_cols" in inj_out:
                     inj_out["question_cols"]()
-            if SCHED["wgrad_late"] == 3:
+            if late_mode == 3:
                 side.wait_stream(s0)
         if rq_splits:
             dq = inj_out["dq"]

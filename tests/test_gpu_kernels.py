@@ -647,8 +647,9 @@ def test_wgrad_gated_and_bwd_skip0(H, B, n):
     the full call; the stored dZ[0] image (row-blocked) = bf16(dxg) where the gate is set; and the GATE job of
     rn_g_wgrad_blocked (the gate in the sign bits of the e4m3 activation image, both on the fp8 pipe, scaled by the un-rounded dxg per question) must give the
     float64 product gate * dxg -- to fp32 accumulation accuracy, i.e. closer to the reference than the job on the stored,
-    bf16-rounded dZ[0], which is checked against ITS float64 product.  B = 17: 272 tiles > 256 CUs, 34 question-aligned splits;
-    B = 3: 48 splits; (2, 32): 32 steps in all -- fewer than the ring is deep, 16 steps per question."""
+    bf16-rounded dZ[0], which is checked against ITS float64 product.  B = 17: 272 tiles > 256 CUs; the stored job runs as 160 wide
+    units (6.8 64-row steps each), the gate job as 40 splits x 4 workgroups straddling questions; B = 3: 40 splits; (2, 32): 32
+    steps in all -- fewer than the ring is deep, 16 steps per question."""
     L, G = 4, 256
     M = B * n * n
     g = torch.Generator(device="cuda").manual_seed(5)

@@ -62,9 +62,14 @@ python -m pytest tests/test_gpu_parity.py tests/test_train_driver.py -m gpu -q >
 cp $R/gpurun_out/parity_report.jsonl $OUT/parity_report.jsonl 2>/dev/null
 python tools/kernel_resources.py > $OUT/kernel_resources.txt 2>/dev/null
 if [ "$QUICK" = "quick" ]; then ls -la $OUT; exit 0; fi
-# 7. the relational convergence task (three squares; closest / same-row questions): 3000 steps per mode, ~2.5 min each
-python tools/convergence.py 3000 5e-4 pairs 250 > $OUT/convergence_pairs.txt 2>/dev/null
-python tools/convergence.py 3000 5e-4 pairs 250 ir-fp short > $OUT/convergence_pairs_ir_fp.txt 2>/dev/null
+# 7. does the default arithmetic train like fp32?  24 seeds x {fp32, auto, auto with 16-bit copies} x {original-fp, ir-fp} on the
+# relational task with device-made batches (~3 s a run, 13 s in fp32: ~16 min), per-run lines + the summary / paired tables
+rm -f $OUT/convergence_seeds.jsonl
+python tools/convergence_seeds.py --seeds 24 --out $OUT/convergence_seeds.jsonl > $OUT/convergence_seeds_runs.txt 2>&1
+( echo "# python tools/convergence_seeds.py --seeds 24   (one MI355X box; per-run lines: convergence_seeds.jsonl)"
+  echo "# task: train.PairRelationTaskOnDevice (three squares; column / closest / same-row questions), 3000 Adam steps, lr 5e-4, B = 64, clip 50, wd 1e-4"
+  echo "# modes: fp32 = per-layer fp32-MFMA kernels; auto = f16s chains + e4m3 activation copies (the default); auto16 = the same with 16-bit copies"
+  python tools/convergence_seeds.py --summary-of $OUT/convergence_seeds.jsonl ) > $OUT/convergence_seeds.txt 2>&1
 # 8. ablations quoted in DESIGN.md, from a DIAGNOSTICS build of the library (timing-only variants with wrong results; the product
 # library is rebuilt afterwards)
 RN_DIAG=1 python relationnetworks-clevr_amd/_build.py --force > $ABL/diag_build.log 2>&1

@@ -6,13 +6,13 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from kname import pretty
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_final")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 dst = lambda n: os.path.join(ROOT, "profiles", "%s_%s" % (tag, n))
 shutil.copy(os.path.join(src, "kernel_stats.csv"), dst("kernel_stats_rocprofv3.csv"))
 shutil.copy(os.path.join(src, "bench_line.json"), dst("bench_line.json"))
 shutil.copy(os.path.join(src, "step_timeline.txt"), dst("step_timeline.txt"))
 for extra in ("bench_original_sd_b64_fp32.json", "bench_original_sd_b64_bf16x3.json", "step_timeline_original_sd_b4.txt", "step_timeline_ir_fp.txt", "bench_ir_fp.json", "bench_stress_b32_n196.json", "bench_original_fp_b640.json", "bench_original_sd_b4.json", "small_kernels_alone.txt", "k1_alone.txt", "wgrad_alone.txt",
-              "fwd_chain_alone.txt", "bwd_chain_alone.txt", "bwd_chain_alone_b32_n196.txt", "extract_alone.txt", "pmc_extract_write.txt", "convergence.txt", "convergence_pairs.txt", "convergence_pairs_ir_fp.txt",
+              "fwd_chain_alone.txt", "bwd_chain_alone.txt", "bwd_chain_alone_b32_n196.txt", "extract_alone.txt", "pmc_extract_write.txt", "convergence.txt", "convergence_pairs.txt", "convergence_pairs_ir_fp.txt", "convergence_seeds.txt", "convergence_seeds.jsonl",
               "clocks.txt", "graph_gaps.txt", "parity_report.jsonl", "kernel_resources.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), dst(extra))
@@ -60,6 +60,6 @@ if os.path.isdir(abl_src):
         if f.endswith(".txt"):
             shutil.copy(os.path.join(abl_src, f), os.path.join(abl_dst, f))
 for f in sorted(os.listdir(os.path.join(ROOT, "gpurun_out"))):
-    if f.startswith("ab_") and f.endswith(".txt"):
+    if (f.startswith("ab_") or f.startswith("wide_")) and f.endswith(".txt"):
         shutil.copy(os.path.join(ROOT, "gpurun_out", f), os.path.join(abl_dst, f))
 print("published to profiles/%s_* and profiles/%s_ablations/" % (tag, tag))
