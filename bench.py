@@ -278,12 +278,13 @@ def sustained_mfma(H, dev):
     return res
 
 
-def wgrad_alone(H, B, n, dev):
+def wgrad_alone(H, B, n, dev, njp=None):
     """The weight-gradient launch of the chain path on its own at the benched shape (two stored gradients on e4m3 activation images
     + the gate job; random operands): HIP-event time of ONE launch (main kernel + its partial-sum reduction) with nothing beside
     it -- what a kernel trace of the eager step sees, where the in-step bracket also holds the conv stack's backward on the other
     streams."""
-    G, M = 256, B * n * n
+    njp = njp or n                                           # (the padded j axis of the chain path: rows per question = n * njp)
+    G, M = 256, B * n * njp
     dZ = [((torch.rand(M, G, device=dev) - 0.5) * 1e-2).bfloat16() for _ in range(2)]
     A8 = [(torch.rand(M, G, device=dev) * 2).to(torch.float8_e4m3fn) for _ in range(3)]
     mask = torch.randint(0, 256, (H.g_chain_rr_mask_bytes(M),), dtype=torch.uint8, device=dev)
@@ -292,7 +293,7 @@ def wgrad_alone(H, B, n, dev):
     dW = [torch.empty(G, G, device=dev) for _ in range(3)]
     db = [torch.empty(G, device=dev) for _ in range(3)]
     jobs = [(dZ[0], A8[0], dW[0], db[0]), (dZ[1], A8[1], dW[1], db[1]), (None, A8[2], dW[2], db[2])]
-    return time_launch(lambda: H.g_wgrad_blocked(jobs, M, dxg=dxg, rows_per_question=n * n), n=15)
+    return time_launch(lambda: H.g_wgrad_blocked(jobs, M, dxg=dxg, rows_per_question=n * njp), n=15)
 
 
 def pair_build_k1(H, B, n, k, Q, dev):
@@ -740,10 +741,10 @@ def main():
             w0 = ksum_step.get("g_wgrad0")                         # (rn_hip.wgrad0_from_reductions has a timer key of its own)
             if alg0 and w0 and w0[0] > 0 and w0[1] > 0:
                 ms0 = w0[1] / args.steps
-                kern["g_wgrad0"] = {"algorithmic_flops": float(fl0), "ms": ms0, "achieved_tflops": fl0 / (ms0 * 1e-3) / 1e12,
-                                    "frac": fl0 / (ms0 * 1e-3) / 1e12 / peak, "traffic": None, "traffic_source": None, "ms_serial": (ksum.get("g_wgrad0", (0, 0.0))[1] / args.steps) or None,
+                kern["g_wgrad0"] = {"algorithmic_flops": float(fl0), "ms": ms0, "achieved_tflops": None,
+                                    "frac": None, "traffic": None, "traffic_source": None, "ms_serial": (ksum.get("g_wgrad0", (0, 0.0))[1] / args.steps) or None,
                                     "what": "dW_0, db_0 = [Rj^T X | Ri^T X | Rq^T q] from the backward chain's pair reductions (wgrad0_part / finish kernels, "
-                                            "rn_pair.hip): the factored first layer EXECUTES ~0.1 GFLOP for these algorithmic flops -- latency-bound, no roofline claim"}
+                                            "rn_pair.hip): the factored first layer EXECUTES ~0.1 GFLOP for these algorithmic flops -- latency-bound: no rate, no roofline fraction is quoted for it"}
             njp = (n if inj_l else RFm.padded_j(n)) if alg0 else n
             # executed flops: the factored first layer runs K = 64 on chip (two passes: hi + lo weights) and the question, wherever
             # it is injected, enters as a bias row, so layers 1..3 are K = 256 products (one pass on tile-dithered images).
@@ -773,7 +774,7 @@ def main():
                     kern[kk]["of_probe_not_peak"] = kern[kk]["achieved_tflops"] / sus["f16" if kk == "g_fwd" else "bf16"]["tflops"]
             # the dominant weight-gradient launch ALONE (nothing beside it): what a kernel trace of the eager step reports for it
             if alg0 and "g_wgrad" in kern and not inj_l and world == 1:
-                ms_a = wgrad_alone(H, B, n, dev)
+                ms_a = wgrad_alone(H, B, n, dev, njp)
                 kern["g_wgrad"]["ms_alone"] = ms_a
                 kern["g_wgrad"]["frac_alone"] = fl["g_wgrad"] / (ms_a * 1e-3) / 1e12 / peak
             ach_ex = executed / (per["g_fwd"] * 1e-3) / 1e12

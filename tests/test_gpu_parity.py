@@ -191,8 +191,9 @@ def test_headline_mode_is_the_module_default_and_meets_the_bar(pkg, tag):
 @pytest.mark.parametrize("tag,precision", [("G-fp64", "f16s"), ("G-ir64", "f16s")])
 def test_e4m3_activation_copies_touch_only_the_g_weight_gradients(pkg, tag, precision, monkeypatch):
     """The factored-first-layer chains keep H_0..2 for the weight gradient as e4m3 bytes (RN_H8=0: 16-bit copies).  Nothing but
-    dW of g layers 1..3 reads them: log-probs, dx, dq, the bias gradients of layers 0..2, the f_phi gradients and dW_0 (pair
-    reductions) must be bitwise those of the 16-bit copies, and the three weight gradients within 3e-3 (relative L2).  The LAST
+    dW of g layers 1..3 reads them: log-probs, dx, dq, the bias gradient of layer 0, the f_phi gradients and dW_0 (pair
+    reductions) must be bitwise those of the 16-bit copies, the bias gradients of layers 1, 2 the same sums in another fp32 order
+    (<= 2e-6: the wide units' in-lane column sums), and the three weight gradients within 3e-3 (relative L2).  The LAST
     layer's bias gradient moves too (<= 3e-3): with e4m3 copies its gradient matrix is never formed -- the gate job of
     rn_g_wgrad_blocked scales the gate sums by the un-rounded dxg -- while the 16-bit path stores bf16(dxg) x gate.  The error of
     every touched tensor against the fp32 reference (sampled entries + norm for the full-size fixtures) is measured and reported,
@@ -206,6 +207,10 @@ def test_e4m3_activation_copies_touch_only_the_g_weight_gradients(pkg, tag, prec
     lp1, loss1, dx1, dq1, gr1 = run_rl(pkg, g, precision)
     assert np.array_equal(lp0, lp1) and np.array_equal(dx0, dx1) and np.array_equal(dq0, dq1)
     touched = {"g_layers.%d.weight" % l for l in (1, 2, 3)} | {"g_layers.3.bias"}
+    # round 6: on e4m3 images the stored-gradient jobs run as WIDE units, whose db is an in-lane sum of the same bf16 dZ values
+    # (v_dot2c_f32_bf16) over other row splits than the quad units' MFMA against ones: the bias gradients of layers 1, 2 are the
+    # same sums in another fp32 order
+    reordered = {"g_layers.1.bias", "g_layers.2.bias"}
     rep = {}
 
     def ref_err(name, arr):
@@ -222,6 +227,8 @@ def test_e4m3_activation_copies_touch_only_the_g_weight_gradients(pkg, tag, prec
             rep[k] = (d, ref_err(k, gr0[k]), ref_err(k, gr1[k]))
             assert 0 < d <= 3e-3, (k, d)
             assert rep[k][2] <= max(2.0 * rep[k][1], 4e-3), (k, rep[k])     # e4m3 copies stay in the 16-bit copies' own error class
+        elif k in reordered:
+            assert l2rel(gr1[k], gr0[k]) <= 2e-6, (k, l2rel(gr1[k], gr0[k]))
         else:
             assert np.array_equal(gr0[k], gr1[k]), k
     report(tag, precision=precision, e4m3_vs_16bit={k: v[0] for k, v in rep.items()}, ref_err_16bit={k: v[1] for k, v in rep.items()},
