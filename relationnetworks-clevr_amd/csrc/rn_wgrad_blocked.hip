@@ -373,7 +373,10 @@ struct KbwFrag {
   u32x4 dz[2][4];                                         // [MFMA a / b][n block]: 8 rows (block 2 h + ab of the group) of one feature
   u32x4 a[4];                                             // [k block]: 16 rows (block h) of one feature, e4m3
 };
-constexpr int KBW_ZB = 32 * 256 * 2, KBW_AB = 32 * 256, KBW_STG = KBW_ZB + KBW_AB, KBW_NSTG = 6, KBW_LA = KBW_NSTG - 1, KBW_NPIECE = 6;
+#ifndef KBW_RING
+#define KBW_RING 6        // ring stages of the wide units (24 KB each): KBW_RING - 1 stages = 120 KB per CU in flight
+#endif
+constexpr int KBW_ZB = 32 * 256 * 2, KBW_AB = 32 * 256, KBW_STG = KBW_ZB + KBW_AB, KBW_NSTG = KBW_RING, KBW_LA = KBW_NSTG - 1, KBW_NPIECE = 6;
 static_assert(KBW_NSTG * KBW_STG <= kb_lds_bytes<true>(), "the wide units' ring must fit the launch's LDS");
 
 template <int DBAB, int ABL = 0>

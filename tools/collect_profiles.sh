@@ -61,6 +61,7 @@ rm -f $R/gpurun_out/parity_report.jsonl
 python -m pytest tests/test_gpu_parity.py tests/test_train_driver.py -m gpu -q > $OUT/parity_tests.log 2>&1
 cp $R/gpurun_out/parity_report.jsonl $OUT/parity_report.jsonl 2>/dev/null
 python tools/kernel_resources.py > $OUT/kernel_resources.txt 2>/dev/null
+python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1
 if [ "$QUICK" = "quick" ]; then ls -la $OUT; exit 0; fi
 # 7. does the default arithmetic train like fp32?  24 seeds x {fp32, auto, auto with 16-bit copies} x {original-fp, ir-fp} on the
 # relational task with device-made batches (~3 s a run, 13 s in fp32: ~16 min), per-run lines + the summary / paired tables
@@ -76,6 +77,9 @@ RN_DIAG=1 python relationnetworks-clevr_amd/_build.py --force > $ABL/diag_build.
 RN_DIAG=1 python tools/time_fwd_f16s.py > $ABL/fwd_chain_ablations.txt 2>/dev/null
 RN_DIAG=1 python tools/time_wgrad.py > $ABL/wgrad_ablations.txt 2>/dev/null
 RN_DIAG=1 python tools/time_bwd_abl.py > $ABL/bwd_chain_ablations.txt 2>/dev/null
+# the weight-gradient launch alone by workgroup budget (4 x RN_KB_TOTAL workgroups; product: 40) and with the quad mapping for every job
+( for t in 32 40 48 56 64; do echo "== RN_KB_TOTAL=$t (wide units for the stored jobs)"; RN_DIAG=1 RN_KB_TOTAL=$t python tools/time_wgrad.py 2>/dev/null | sed -n 1,3p; done
+  for t in 40 48 64; do echo "== RN_KB_TOTAL=$t RN_KB_NO_WIDE=1 (rounds 3-5: quad units for every job)"; RN_DIAG=1 RN_KB_TOTAL=$t RN_KB_NO_WIDE=1 python tools/time_wgrad.py 2>/dev/null | sed -n 1,3p; done ) > $ABL/wgrad_alone_by_budget.txt 2>&1
 python relationnetworks-clevr_amd/_build.py --force > /dev/null 2>&1
 mkdir -p tools/dbg/libs
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/dbg/libs/reg_stream_bench tools/dbg/reg_stream_bench.hip > /dev/null 2>&1 && tools/dbg/libs/reg_stream_bench > $ABL/reg_stream_bench.txt 2>&1

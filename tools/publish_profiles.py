@@ -13,7 +13,7 @@ shutil.copy(os.path.join(src, "bench_line.json"), dst("bench_line.json"))
 shutil.copy(os.path.join(src, "step_timeline.txt"), dst("step_timeline.txt"))
 for extra in ("bench_original_sd_b64_fp32.json", "bench_original_sd_b64_bf16x3.json", "step_timeline_original_sd_b4.txt", "step_timeline_ir_fp.txt", "bench_ir_fp.json", "bench_stress_b32_n196.json", "bench_original_fp_b640.json", "bench_original_sd_b4.json", "small_kernels_alone.txt", "k1_alone.txt", "wgrad_alone.txt",
               "fwd_chain_alone.txt", "bwd_chain_alone.txt", "bwd_chain_alone_b32_n196.txt", "extract_alone.txt", "pmc_extract_write.txt", "convergence.txt", "convergence_pairs.txt", "convergence_pairs_ir_fp.txt", "convergence_seeds.txt", "convergence_seeds.jsonl",
-              "clocks.txt", "graph_gaps.txt", "parity_report.jsonl", "kernel_resources.txt"):
+              "clocks.txt", "graph_gaps.txt", "parity_report.jsonl", "kernel_resources.txt", "smoke.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), dst(extra))
 OURS = re.compile(r"(rr_kernel|rr_f16s|rr_bwd|wgrad|pair_|f_phi|cn_|lstm_|emb_bwd|conv3x3s2|conv_wgrad|clip_adam|sumsq|nll_|segsum|pack_frag|debug_stamp)")
