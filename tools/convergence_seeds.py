@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--eval-batches", type=int, default=32)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "convergence_seeds.jsonl"))
     ap.add_argument("--summary-of", default=None, metavar="JSONL", help="no runs: print the summary tables of an earlier --out file")
+    ap.add_argument("--override", default="", help="bisection arms: options.OPT overrides for every run, e.g. chain_reduce=0,fphi_split=0")
+    ap.add_argument("--sched", default="", help="... and functional.SCHED knobs, e.g. dq_async=0")
+    ap.add_argument("--tag", default="", help="suffix of the mode name in the output rows (one arm = one tag)")
     a = ap.parse_args()
     if a.summary_of:
         rows = [json.loads(ln) for ln in open(a.summary_of) if ln.strip()]
@@ -44,6 +47,12 @@ def main():
     import relationnetworks_clevr_amd as pkg                # (imported here: --summary-of and the tests' use of exit_step need no GPU)
     from relationnetworks_clevr_amd import train as T
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    import contextlib
+    ov = {k: (v not in ("0", "False", "false")) for k, v in (kv.split("=") for kv in a.override.split(",") if kv)}
+    for kv in a.sched.split(","):
+        if kv:
+            k, v = kv.split("=")
+            pkg.functional.SCHED[k] = int(v)
     rows = []
     with open(a.out, "a") as f:
         for model in a.models.split(","):
@@ -51,10 +60,11 @@ def main():
                 for mode in a.modes.split(","):
                     prec, h8 = MODES[mode]
                     t0 = time.time()
-                    r = T.convergence_run(prec, steps=a.steps, lr=a.lr, h8=h8, task="pairs_dev", log_every=a.every,
-                                          eval_batches=a.eval_batches, model_name=model, seed=seed)
+                    with (pkg.options.override(**ov) if ov else contextlib.nullcontext()):
+                        r = T.convergence_run(prec, steps=a.steps, lr=a.lr, h8=h8, task="pairs_dev", log_every=a.every,
+                                              eval_batches=a.eval_batches, model_name=model, seed=seed)
                     k = max(250 // a.every, 1)
-                    row = {"model": model, "mode": mode, "seed": seed, "steps": a.steps, "lr": a.lr, "exit_step": exit_step(r["loss"], a.every),
+                    row = {"model": model, "mode": mode + a.tag, "seed": seed, "steps": a.steps, "lr": a.lr, "exit_step": exit_step(r["loss"], a.every),
                            "final_loss": float(np.mean(r["loss"][-k:])), "accuracy": r["accuracy"], "seconds": round(time.time() - t0, 1),
                            "switched": any(g.get("switched") for g in r["copy_guard"]), "every": a.every,
                            "loss": [round(v, 4) for v in r["loss"]]}
