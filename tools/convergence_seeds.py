@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--override", default="", help="bisection arms: options.OPT overrides for every run, e.g. chain_reduce=0,fphi_split=0")
     ap.add_argument("--sched", default="", help="... and functional.SCHED knobs, e.g. dq_async=0")
     ap.add_argument("--tag", default="", help="suffix of the mode name in the output rows (one arm = one tag)")
+    ap.add_argument("--dither", type=int, default=0, help="bisection arm: tile-dithered weight images per layer of the forward chain (1, 2, 4 = product, 8)")
     a = ap.parse_args()
     if a.summary_of:
         rows = [json.loads(ln) for ln in open(a.summary_of) if ln.strip()]
@@ -53,6 +54,8 @@ def main():
         if kv:
             k, v = kv.split("=")
             pkg.functional.SCHED[k] = int(v)
+    if a.dither:
+        pkg.rn_hip.F16S_DITHER = a.dither
     rows = []
     with open(a.out, "a") as f:
         for model in a.models.split(","):
