@@ -198,8 +198,11 @@ _SIDE_STREAMS = {}
 # conv_wgrad_stream: the side stream the conv weight gradients share (0 the g_theta weight gradient's, 2 the layer-0 stream's);
 # fphi_grads_late: f_phi's parameter gradients on the layer-0 stream instead of in front of the backward chain;
 # chain_balance: the reducing backward chain's units beyond a whole number of rounds over the CUs run tile by tile (0: whole units only);
-# dq_async: the question gradient of a question-injected layer is handed to the question encoder's backward by event (0: the main stream waits for it).
-SCHED = {"wgrad_late": -1, "conv_wgrad_stream": 2, "fphi_grads_late": 1, "chain_balance": 1, "dq_async": 1}
+# dq_async: the question gradient of a question-injected layer is handed to the question encoder's backward by event (0: the main stream waits for it);
+# lstm_hn_view / text_first (round 6, both measured and left off: profiles/r06_ablations/ab_lstm_hn_view.txt, ab_text_overlap.txt): the
+# question encoder's output as a view instead of a clone (one memcpy node less in front of the join with the conv stack: 103.9 vs
+# 104.0 k q/s), the question encoder captured in front of the conv stack instead of behind it (98.6 vs 100.2 k; ir-fp 87.5 vs 90.9 k).
+SCHED = {"lstm_hn_view": 0, "text_first": 0, "wgrad_late": -1, "conv_wgrad_stream": 2, "fphi_grads_late": 1, "chain_balance": 1, "dq_async": 1}
 
 
 def _dev_key(dev):
@@ -1117,7 +1120,9 @@ class QuestionLSTMFunction(torch.autograd.Function):
             ctx.save_for_backward(idx, xs, gates, cs, hs, ws[1], ws[2])
             ctx.vocab = emb.shape[0]
             ctx.leaf_refs = (emb, W_ih, W_hh, b_ih, b_hh)
-            return hs[T].clone()
+            # (a tensor of its own: a clone is a memcpy NODE of the captured step, on the question encoder's stream, in front of
+            #  the join with the conv stack; SCHED["lstm_hn_view"] = 1 returns the view instead -- A/B'd in round 6)
+            return hs[T] if SCHED.get("lstm_hn_view") else hs[T].clone()
         hn = torch.empty(B, Hh, **f32)
         H.lstm_fwd(idx, *ws, None, None, None, hn)
         return hn

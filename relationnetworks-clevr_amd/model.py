@@ -395,6 +395,9 @@ class RN(nn.Module):
         if self.state_desc:
             x = img                                             # (B, 12, 7) state descriptions
         else:
+            if fork_ev is not None and RF.SCHED.get("text_first"):      # (A/B knob: the question encoder captured IN FRONT of the conv stack)
+                qst, side = self._text_on_side_stream(qst_idxs, after=fork_ev)
+                fork_ev = None
             x = self.conv(img)                                  # (B, 24, d, d)
             if fork_ev is not None:
                 qst, side = self._text_on_side_stream(qst_idxs, after=fork_ev)
