@@ -436,12 +436,23 @@ def failure_line(reason):
             "comm": comm}
 
 
+def emit_line(obj):
+    """The ONE JSON line, as the LAST line of stdout: C-level stdio is flushed first (RCCL prints a version banner through printf
+    when a communicator is created; buffered, it would otherwise land behind this line when the process exits)."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(obj) + "\n")
+    sys.stdout.flush()
+
+
 def print_failure(reason):
     if FAIL["rank"] == 0 and not FAIL["printed"]:
         FAIL["printed"] = True
         try:
-            sys.stdout.write(json.dumps(failure_line(reason)) + "\n")
-            sys.stdout.flush()
+            emit_line(failure_line(reason))
         except Exception:
             pass
 
@@ -857,7 +868,7 @@ def main():
             if not (args.config == "original-sd" and B == 4):
                 # BASELINE.md section 3's second CPU figure: configs[0], the reference's own CPU-runnable case (~10 ms per step)
                 out["cpu_baseline_sd4"] = cpu_baseline("original-sd", 4, 128, warm=5, steps=50)
-        print(json.dumps(out))
+        emit_line(out)
         FAIL["printed"] = True
     if multi:
         dist.destroy_process_group()
