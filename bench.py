@@ -679,6 +679,14 @@ def main():
                 ksum = H.TIMER.summary(steps=args.steps)
                 pkg.options.OPT.wgrad_overlap = overlap_default
         trainer.use_graph = use_graph
+    # every rank empties its C-level and Python stdout buffers HERE, in front of a collective: whatever a library printed on any rank
+    # (RCCL's banner) is out before rank 0 emits the one JSON line behind that collective
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
     dt = max_over_ranks(dt, world, dev)
     if not torch.isfinite(loss).item():
         raise SystemExit("non-finite loss")
