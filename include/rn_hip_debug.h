@@ -40,6 +40,11 @@ int rn_probe_red_schedule(int M, int n, int njp, int tiles_per_unit, int units_w
  * launch: flops = workgroups * 4 * waves_per_simd * iters * 16 * 32768.  bench.py quotes the chains against this measured rate
  * beside the nominal 2.5 PFLOP/s (the chip clocks to its power budget).  out: workgroups * 256 * waves_per_simd floats (a sink). */
 int rn_probe_mfma_stream(float* out, int workgroups, int waves_per_simd, int iters, int dtype, void* stream);
+/* Row splits of an rn_g_wgrad_blocked launch (aligned == 0, e4m3 images) with `nw` stored-gradient jobs (WIDE units: one workgroup per
+ * split) and `nq` gate jobs (four workgroups per split): nw * Zw + 4 * nq * Zq <= 4 x the library's row-split budget (160 workgroups),
+ * Zw ~ 3 Zq so that both kinds of workgroup finish together; never more splits than 64-row steps.  Host arithmetic only. */
+int rn_debug_wgrad_blocked_mix(int M, int nw, int nq, int* Zw, int* Zq);
+
 /* ... the same stream on all-zero operands (zero_operands != 0): the data pattern "peak" figures are usually measured with */
 int rn_probe_mfma_stream_ops(float* out, int workgroups, int waves_per_simd, int iters, int dtype, int zero_operands, void* stream);
 

@@ -637,6 +637,13 @@ extern "C" int rn_wgrad_blocked_splits(int M, int rows_per_question, int njobs, 
   return (M > 0 && M % 64 == 0 && njobs > 0 && njobs <= KB_MAXJOBS) ? kb_splits(M, rows_per_question, njobs, aligned) : 0;
 }
 
+// (diagnostics / tests: the row splits a launch of `nw` wide and `nq` quad jobs gets -- host arithmetic only)
+extern "C" int rn_debug_wgrad_blocked_mix(int M, int nw, int nq, int* Zw, int* Zq) {
+  RN_CHECK_ARG(M > 0 && M % 64 == 0 && nw >= 0 && nq >= 0 && nw + nq > 0 && nw + nq <= KB_MAXJOBS && Zw && Zq, "rn_debug_wgrad_blocked_mix: bad argument");
+  kb_mixed_splits(M, nw, nq, Zw, Zq);
+  return 0;
+}
+
 size_t rnws_wgrad_blocked(int M, int rows_per_question, int njobs, int aligned) {
   const int Z = rn_wgrad_blocked_splits(M, rows_per_question, njobs, aligned);
   if (Z <= 0) return 0;

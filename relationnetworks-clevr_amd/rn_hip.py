@@ -95,6 +95,7 @@ DEBUG_SIGNATURES = {
     "rn_probe_fp8_cvt": (_I, [_P, C.c_float, _P, _P, _P, _I, _P]),
     "rn_probe_mfma_stream": (_I, [_P, _I, _I, _I, _I, _P]),
     "rn_probe_mfma_stream_ops": (_I, [_P, _I, _I, _I, _I, _I, _P]),
+    "rn_debug_wgrad_blocked_mix": (_I, [_I, _I, _I, _P, _P]),
     "rn_probe_red_schedule": (_I, [_I, _I, _I, _I, _I, _P, _I]),
     "rn_debug_f_phi_wide": (_I, [_I]),
     "rn_debug_gemm_small_below": (_I, [_I]),

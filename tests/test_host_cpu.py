@@ -63,6 +63,17 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sp(64 * 4096, 4096, 1, 1) == 64 and sp(32 * 4096, 4096, 1, 1) == 32 and sp(3 * 4096, 4096, 1, 1) == 24 and sp(128 * 4096, 4096, 1, 1) == 128
     assert sp(17 * 4096, 4096, 1, 1) == 34 and sp(32 * 38416, 38416, 1, 1) == 40 and sp(64 * 4096, 4096, 3, 1) == 64 and sp(4 * 4096, 4096, 3, 1) == 8
     assert sp(64 * 4096, 4096, 5, 0) == 0
+    # the product launch (not aligned, e4m3 images): wide units for the stored jobs, quad units for the gate job, 160 workgroups in all
+    def mix(M, nw, nq):
+        zw, zq = ctypes.c_int(-1), ctypes.c_int(-1)
+        assert loaded.rn_debug_wgrad_blocked_mix(M, nw, nq, ctypes.byref(zw), ctypes.byref(zq)) == 0
+        return zw.value, zq.value
+    assert mix(64 * 4096, 2, 1) == (48, 16) and 2 * 48 + 4 * 16 == 160        # the step's launch: two stored gradients + the gate job
+    assert mix(64 * 4096, 1, 0) == (160, 0) and mix(64 * 4096, 0, 1) == (0, 40) and mix(64 * 4096, 3, 0) == (53, 0)
+    assert mix(1024, 2, 1) == (16, 16)                                         # (never more splits than 64-row steps)
+    for M_, nw_, nq_ in ((640 * 4096, 2, 1), (32 * 196 * 224, 2, 1), (17 * 4096, 1, 1)):
+        zw, zq = mix(M_, nw_, nq_)
+        assert nw_ * zw + 4 * nq_ * zq <= 160 and zw >= 2 * zq > 0, (M_, zw, zq)
     # workspace: one fp32 256 x 256 partial tile + 4 db rows per row split; not aligned: the most splits any mix of wide (one
     # workgroup per split) and quad (four) jobs gets out of the 160 workgroups -- three wide jobs: 3 x 53; aligned: uniform splits
     assert ws(Hm.WS_WGRAD_BLOCKED, 64 * 4096, 4096, 3, 0) == 159 * (65536 + 4 * 256) * 4
